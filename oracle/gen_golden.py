@@ -1,0 +1,368 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors under tests/golden/ by running the
+UNMODIFIED reference (/root/reference) through the stand-in packages in
+oracle/refstubs.  Runs only in the build container (the reference tree and
+oracle/_ref must be present):
+
+    make -C oracle ref && python oracle/gen_golden.py
+
+The fixtures are data only: seeded inputs and the reference's outputs.
+TEST INFRASTRUCTURE — never imported by the product.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+from oracle import refimport  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+# ----------------------------------------------------------------------------
+# helpers
+# ----------------------------------------------------------------------------
+class FakeTelescope(object):
+    """Exposes exactly the attributes BeamTransfer/KLTransform read
+     on top of injected arrays."""
+
+    def __init__(self, nfreq, nbase, npol, lmax, mmax, npower, tsys_flat=1.0):
+        self.nfreq = nfreq
+        self.nbase = nbase
+        self.npairs = nbase
+        self.num_pol_sky = npol
+        self._npol_sky_ = npol
+        self.lmax = lmax
+        self.mmax = mmax
+        self.included_freq = np.arange(nfreq)
+        self.included_baseline = np.arange(nbase)
+        self.included_pol = np.arange(npol)
+        self.frequencies = np.linspace(400.0, 450.0, nfreq)
+        self.baselines = np.zeros((nbase, 2))
+        self.tsys_flat = tsys_flat
+        self._npower = npower  # (nfreq, nbase)
+
+    def noisepower(self, bl_indices, f_indices, ndays=None):
+        bl, fi = np.broadcast_arrays(bl_indices, f_indices)
+        return self._npower[fi, bl]
+
+
+def synth_beam_m(rng, F, B, P, L, m, polrank=None, polscale=0.05):
+    """Random m-block (F,2,B,P,L), zero for l < m; polarised part low rank."""
+    T = 2 * B
+    bm = np.zeros((F, T, P, L), dtype=np.complex128)
+    Lm = L - m
+    for f in range(F):
+        # smoothly decaying column weights so that the spectrum spans decades
+        colw = np.exp(-np.arange(Lm) / max(Lm / 6.0, 1.0))
+        a = (rng.standard_normal((T, Lm)) + 1j * rng.standard_normal((T, Lm))) * colw
+        bm[f, :, 0, m:] = a
+        if P > 1:
+            r = polrank if polrank is not None else max(T // 4, 1)
+            left = rng.standard_normal((T, r)) + 1j * rng.standard_normal((T, r))
+            for p in range(1, P):
+                right = rng.standard_normal((r, Lm)) + 1j * rng.standard_normal((r, Lm))
+                bm[f, :, p, m:] = polscale * (left @ right) / np.sqrt(r)
+    return bm.reshape(F, 2, B, P, L)
+
+
+def analytic_cl(frequencies, L, P, kind):
+    """The committed analytic C_l(nu,nu') model; shape (P,P,L,F,F)."""
+    nu = np.asarray(frequencies, dtype=np.float64)
+    F = nu.size
+    ell = np.arange(L, dtype=np.float64)
+    cv = np.zeros((P, P, L, F, F))
+    dnu = nu[:, None] - nu[None, :]
+    if kind == "signal":
+        corr = np.exp(-0.5 * (dnu / 2.0) ** 2)
+        cv[0, 0] = 1e-7 * (1.0 / (ell + 1.0))[:, None, None] * corr[None]
+    else:
+        lognu = np.log(nu[:, None] / nu[None, :])
+        corr = (nu[:, None] * nu[None, :] / 408.0**2) ** -2.8 * np.exp(-0.5 * lognu**2 / 4.0**2)
+        amp = 10.0 * ((ell + 1.0) / 100.0) ** -2.4
+        cv[0, 0] = amp[:, None, None] * corr[None]
+        if P >= 3:
+            corrp = (nu[:, None] * nu[None, :] / 408.0**2) ** -2.8 * np.exp(-0.5 * lognu**2 / 0.5**2)
+            cv[1, 1] = 0.05 * amp[:, None, None] * corrp[None]
+            cv[2, 2] = 0.05 * amp[:, None, None] * corrp[None]
+    return cv
+
+
+def write_beam_file(ref, bt, mi, beam_m):
+    import h5py  # the in-memory stand-in
+
+    f = h5py.File(bt._mfile(mi), "w")
+    f.create_dataset("beam_m", data=beam_m[..., mi:])
+    f.close()
+
+
+def read_svd_file(bt, mi):
+    import h5py
+
+    f = h5py.File(bt._svdfile(mi), "r")
+    out = {k: f[k][:] for k in ("beam_svd", "invbeam_svd", "beam_ut", "singularvalues")}
+    f.close()
+    return out
+
+
+# ----------------------------------------------------------------------------
+# fixtures
+# ----------------------------------------------------------------------------
+def gen_matrix_ops(ref):
+    rng = np.random.default_rng(1001)
+    bt = ref["beamtransfer"]
+    out = {}
+    cases = {
+        "rand_wide": rng.standard_normal((12, 30)) + 1j * rng.standard_normal((12, 30)),
+        "rand_tall": rng.standard_normal((20, 7)) + 1j * rng.standard_normal((20, 7)),
+        "lowrank": (rng.standard_normal((16, 4)) + 1j * rng.standard_normal((16, 4)))
+        @ (rng.standard_normal((4, 24)) + 1j * rng.standard_normal((4, 24))),
+        "empty": np.zeros((0, 9), dtype=np.complex128),
+    }
+    for name, A in cases.items():
+        for rtol in (1e-10, 1e-4, 0.0):
+            tag = "%s_r%g" % (name, rtol)
+            img, s = bt.matrix_image(A.copy(), rtol=rtol)
+            nul, s2 = bt.matrix_nullspace(A.copy(), rtol=rtol)
+            out["A_" + name] = A
+            out["img_" + tag] = img
+            out["imgs_" + tag] = s
+            out["nul_" + tag] = nul
+            out["nuls_" + tag] = s2
+    np.savez_compressed(os.path.join(OUT, "matrix_ops.npz"), **out)
+    print("matrix_ops.npz", len(out))
+
+
+def gen_svd_kl(ref, tag, F, B, P, lmax, mlist, polsvcut, seed, fg_threshold, threshold):
+    """SVD chain -> covariance projections -> KL / DoubleKL, all by the reference."""
+    btmod, klmod, dkmod = ref["beamtransfer"], ref["kltransform"], ref["doublekl"]
+    rng = np.random.default_rng(seed)
+    L = lmax + 1
+    mmax = lmax
+    # baseline-dependent white noise, the same for +m and -m
+    redundancy = rng.integers(1, 6, size=B).astype(np.float64)
+    npower = (2.5e-7 * (1.0 + 0.1 * np.arange(F))[:, None] / redundancy[None, :]).astype(np.float64)
+    tel = FakeTelescope(F, B, P, lmax, mmax, npower, tsys_flat=1.0)
+
+    bt = btmod.BeamTransfer("/mem/%s/bt" % tag, telescope=tel)
+    bt.polsvcut = polsvcut
+    bt.svcut = 1e-6
+
+    cv_sg = analytic_cl(tel.frequencies, L, P, "signal")
+    cv_fg = analytic_cl(tel.frequencies, L, P, "foreground")
+
+    out = dict(
+        F=F, B=B, P=P, lmax=lmax, mlist=np.array(mlist), polsvcut=polsvcut, svcut=bt.svcut,
+        npower=npower, frequencies=tel.frequencies, cv_sg=cv_sg, cv_fg=cv_fg,
+        fg_threshold=fg_threshold, threshold=threshold, tsys_flat=tel.tsys_flat,
+    )
+
+    kl = klmod.KLTransform(bt, subdir="kl")
+    kl._cvsg, kl._cvfg = cv_sg, cv_fg
+    kl.threshold = threshold
+    klnf = klmod.KLTransform(bt, subdir="klnf")
+    klnf._cvsg, klnf._cvfg = cv_sg, cv_fg
+    klnf.use_foregrounds = False
+    klnf.threshold = threshold
+    dk = dkmod.DoubleKL(bt, subdir="dk")
+    dk._cvsg, dk._cvfg = cv_sg, cv_fg
+    dk.foreground_threshold = fg_threshold
+    dk.threshold = threshold
+
+    for mi in mlist:
+        beam = synth_beam_m(rng, F, B, P, L, mi)
+        write_beam_file(ref, bt, mi, beam)
+        bt._generate_svdfile_m(mi)
+        svd = read_svd_file(bt, mi)
+        svnum, svbounds = bt._svd_num(mi)
+        pre = "m%d_" % mi
+        out[pre + "beam_m"] = beam
+        for k, v in svd.items():
+            out[pre + k] = v
+        out[pre + "svnum"] = svnum
+        out[pre + "svbounds"] = svbounds
+        out[pre + "proj_sg"] = bt.project_matrix_sky_to_svd(mi, cv_sg)
+        out[pre + "proj_fg"] = bt.project_matrix_sky_to_svd(mi, cv_fg)
+        out[pre + "proj_sg_temponly"] = bt.project_matrix_sky_to_svd(mi, cv_sg, temponly=True)
+        npw = np.concatenate([npower, npower], axis=1)
+        out[pre + "proj_noise"] = bt.project_matrix_diagonal_telescope_to_svd(mi, npw)
+
+        for name, obj in (("kl", kl), ("klnf", klnf)):
+            cs, cn = obj.sn_covariance(mi)
+            out[pre + name + "_cs"] = cs
+            out[pre + name + "_cn"] = cn
+            evals, evecs, inv, extra = obj._transform_m(mi)
+            out[pre + name + "_evals"] = evals
+            out[pre + name + "_evecs"] = evecs
+            out[pre + name + "_ac"] = extra["ac"]
+            i_ev = np.searchsorted(evals, obj.threshold)
+            out[pre + name + "_nkept"] = evals.size - i_ev
+
+        dk.use_thermal = True
+        evals, evecs, inv, extra = dk._transform_m(mi)
+        out[pre + "dk_evals"] = evals
+        out[pre + "dk_evecs"] = evecs
+        out[pre + "dk_f_evals"] = extra["f_evals"]
+        out[pre + "dk_ac"] = extra["ac"]
+        # the two covariance pairs DoubleKL used
+        dk.use_thermal = False
+        cs0, cn0 = dk.sn_covariance(mi)
+        dk.use_thermal = True
+        cs1, cn1 = dk.sn_covariance(mi)
+        out[pre + "dk_cs_nothermal"] = cs0
+        out[pre + "dk_cn_nothermal"] = cn0
+        out[pre + "dk_cs_thermal"] = cs1
+        out[pre + "dk_cn_thermal"] = cn1
+        print(tag, "m", mi, "ndof", svbounds[-1], "kl kept", out[pre + "kl_nkept"],
+              "dk modes", evals.size, "of", extra["f_evals"].size)
+
+    np.savez_compressed(os.path.join(OUT, "svdkl_%s.npz" % tag), **out)
+    print("svdkl_%s.npz" % tag)
+
+
+def gen_eigh_gen(ref):
+    kl = ref["kltransform"]
+    rng = np.random.default_rng(77)
+    out = {}
+    n = 24
+    X = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    A = X @ X.T.conj()
+    Y = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    B = Y @ Y.T.conj() + 0.1 * np.eye(n)
+    ev, evec, ac = kl.eigh_gen(A.copy(), B.copy())
+    out.update(pd_A=A, pd_B=B, pd_evals=ev, pd_evecs=evec, pd_ac=ac)
+    # B numerically not positive definite -> rescue branch (kltransform.py:101-111)
+    Yr = rng.standard_normal((n, n - 3)) + 1j * rng.standard_normal((n, n - 3))
+    Bn = Yr @ Yr.T.conj()
+    Bn -= 1e-9 * np.eye(n)
+    ev, evec, ac = kl.eigh_gen(A.copy(), Bn.copy())
+    out.update(npd_A=A, npd_B=Bn, npd_evals=ev, npd_evecs=evec, npd_ac=ac)
+    # all-zero A shortcut (kltransform.py:81-85)
+    Z = np.zeros((5, 5), dtype=np.complex128)
+    ev, evec, ac = kl.eigh_gen(Z.copy(), B[:5, :5].copy())
+    out.update(zero_A=Z, zero_B=B[:5, :5], zero_evals=ev, zero_evecs=evec, zero_ac=ac)
+    np.savez_compressed(os.path.join(OUT, "eigh_gen.npz"), **out)
+    print("eigh_gen.npz ac(npd) =", out["npd_ac"])
+
+
+def gen_geometry(ref):
+    cyl = ref["cylinder"]
+    tmod = ref["telescope"]
+    out = {}
+    cfgs = {
+        "testparams": ("pol", dict(num_freq=8, freq_start=400.0, freq_end=450.0, freq_mode="edge",
+                                    num_cylinders=2, cylinder_width=5.0, num_feeds=5, feed_spacing=0.5, tsys=1.0)),
+        "cfg2": ("unpol", dict(num_freq=16, freq_start=400.0, freq_end=450.0, freq_mode="edge",
+                               num_cylinders=2, cylinder_width=5.0, num_feeds=16, feed_spacing=0.4, tsys=1.0,
+                               force_lmax=128, force_mmax=128)),
+        "cfg3": ("pol", dict(num_freq=64, freq_start=400.0, freq_end=500.0, freq_mode="edge",
+                             num_cylinders=4, cylinder_width=12.0, num_feeds=16, feed_spacing=0.4, tsys=1.0,
+                             force_lmax=512, force_mmax=512)),
+        "skip": ("pol", dict(num_freq=8, freq_start=400.0, freq_end=450.0, freq_mode="edge",
+                             num_cylinders=2, cylinder_width=5.0, num_feeds=5, feed_spacing=0.5, tsys=1.0,
+                             skip_freq=[0, 3, 4], skip_baselines=[17, 18, 25])),
+        "noincyl": ("unpol", dict(num_freq=4, freq_start=600.0, freq_end=700.0, freq_mode="centre",
+                                  num_cylinders=3, cylinder_width=10.0, num_feeds=4, feed_spacing=0.6,
+                                  in_cylinder=False, tsys=50.0)),
+    }
+    for name, (kind, cfg) in cfgs.items():
+        klass = cyl.PolarisedCylinderTelescope if kind == "pol" else cyl.UnpolarisedCylinderTelescope
+        t = klass.from_config(cfg)
+        nat_l, nat_m = tmod.max_lm(t.baselines, t.wavelengths.min(), t.u_width, t.v_width)
+        bl = np.arange(t.nbase)
+        out[name + "_kind"] = kind
+        out[name + "_cfg_keys"] = np.array(sorted(cfg.keys()))
+        out[name + "_cfg_vals"] = np.array([repr(cfg[k]) for k in sorted(cfg.keys())])
+        out[name + "_feedpositions"] = t.feedpositions
+        out[name + "_beamclass"] = t.beamclass
+        out[name + "_uniquepairs"] = t.uniquepairs
+        out[name + "_baselines"] = t.baselines
+        out[name + "_redundancy"] = t.redundancy
+        out[name + "_feedmap"] = t.feedmap
+        out[name + "_feedmask"] = t.feedmask
+        out[name + "_feedconj"] = t.feedconj
+        out[name + "_frequencies"] = t.frequencies
+        out[name + "_wavelengths"] = t.wavelengths
+        out[name + "_lmax"] = t.lmax
+        out[name + "_mmax"] = t.mmax
+        out[name + "_natural_lmax"] = int(nat_l.max())
+        out[name + "_natural_mmax"] = int(nat_m.max())
+        out[name + "_noisepower"] = np.array(
+            [np.asarray(t.noisepower(bl, fi)).reshape(-1) for fi in range(t.nfreq)]
+        )
+        out[name + "_included_freq"] = t.included_freq
+        out[name + "_included_baseline"] = t.included_baseline
+        out[name + "_included_pol"] = t.included_pol
+        out[name + "_zenith"] = t.zenith
+        # per-(baseline, freq) band limits used by transfer_matrices (telescope.py:792-802)
+        bb, ff = [a.ravel() for a in np.meshgrid(bl, np.arange(t.nfreq), indexing="ij")]
+        lm, mm = np.ceil(t.l_boost * np.array(tmod.max_lm(
+            t.baselines[bb], t.wavelengths[ff], t.u_width, t.v_width
+        ))).astype(np.int64)
+        out[name + "_lmax_bf"] = lm.reshape(t.nbase, t.nfreq)
+        out[name + "_mmax_bf"] = mm.reshape(t.nbase, t.nfreq)
+        print(name, "nfeed", t.nfeed, "nbase", t.nbase, "lmax", t.lmax, "mmax", t.mmax,
+              "natural", int(nat_l.max()), int(nat_m.max()))
+    np.savez_compressed(os.path.join(OUT, "geometry.npz"), **out)
+    print("geometry.npz")
+
+
+def gen_pixel_kernels(ref):
+    """The reference's compiled Cython kernels and the cylinder beam model on a
+    seeded set of sky positions."""
+    ft = ref["fast_tools"]
+    cylbeam = ref["cylbeam"]
+    vis = ref["visibility"]
+    rng = np.random.default_rng(5)
+    n = 3000
+    theta = np.arccos(rng.uniform(-1, 1, n))
+    phi = rng.uniform(0, 2 * np.pi, n)
+    angpos = np.stack([theta, phi], axis=-1)
+    zenith = np.array([np.pi / 2.0 - np.radians(45.0), 0.0])
+    uv = np.array([7.3, -11.9])
+    out = dict(angpos=angpos, zenith=zenith, uv=uv)
+    fr = ft.fringe(angpos, zenith, uv)
+    out["fringe"] = fr
+    hz = vis.horizon(angpos, zenith)
+    out["horizon"] = hz
+    st = rng.uniform(-1, 1, 500)
+    out["exptan_in"] = st
+    out["exptan_fwhm"] = 1.3
+    out["exptan"] = ft.beam_exptan(st, 1.3)
+    width, fe, fh = 5.0 / 0.7, 2.0 * np.pi / 3.0 * 0.7, 2.0 * np.pi / 3.0 * 1.0
+    out["cyl_width"], out["cyl_fwhm_e"], out["cyl_fwhm_h"] = width, fe, fh
+    out["beam_amp"] = cylbeam.beam_amp(angpos, zenith, width, fh, fh)
+    bx = cylbeam.beam_x(angpos, zenith, width, fe, fh)
+    by = cylbeam.beam_y(angpos, zenith, width, fe, fh)
+    out["beam_x"], out["beam_y"] = bx, by
+    pat = cylbeam.fraunhofer_cylinder(lambda t: ft.beam_exptan(t, fh), width)
+    out["fraunhofer_x"], out["fraunhofer_y"], out["fraunhofer_y2"] = pat.x, pat.y, pat.y2
+    hzf = hz.astype(np.float64)
+    out["pol_real_xy"] = ft._construct_pol_real(bx, by, fr, hzf)
+    out["pol_real_xx"] = ft._construct_pol_real(bx, bx, fr, hzf)
+    bxc = bx * np.exp(0.3j)
+    byc = by * np.exp(-0.7j)
+    out["beam_xc"], out["beam_yc"] = bxc, byc
+    out["pol_complex_xy"] = ft._construct_pol_complex(bxc, byc, fr, hzf)
+    np.savez_compressed(os.path.join(OUT, "pixel_kernels.npz"), **out)
+    print("pixel_kernels.npz")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = refimport.load()
+    gen_matrix_ops(ref)
+    gen_eigh_gen(ref)
+    gen_geometry(ref)
+    gen_pixel_kernels(ref)
+    gen_svd_kl(ref, "unpol", F=4, B=10, P=1, lmax=24, mlist=[0, 5, 20], polsvcut=1e-4,
+               seed=2001, fg_threshold=1.0, threshold=0.1)
+    gen_svd_kl(ref, "pol", F=3, B=8, P=4, lmax=20, mlist=[0, 4, 17], polsvcut=1e-4,
+               seed=2002, fg_threshold=1e-4, threshold=1e-5)
+
+
+if __name__ == "__main__":
+    main()
