@@ -1,0 +1,267 @@
+"""ctypes binding of libdriftmi.so (the C ABI declared in include/driftmi.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C
+driftscan_amd/csrc`` into ``driftscan_amd/lib/libdriftmi.so``.  Loading fails
+loudly if it is missing; there is no alternative code path.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(_HERE, "lib", "libdriftmi.so")
+
+c_int = ctypes.c_int
+c_i64 = ctypes.c_int64
+c_dbl = ctypes.c_double
+c_vp = ctypes.c_void_p
+c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/driftmi.h one to one
+SIGNATURES = {
+    "dm_ctx_create": (c_int, [c_int, c_sz, c_vp, ctypes.POINTER(c_vp)]),
+    "dm_ctx_destroy": (c_int, [c_vp]),
+    "dm_ctx_sync": (c_int, [c_vp]),
+    "dm_ctx_workspace_bytes": (c_sz, [c_vp]),
+    "dm_last_error": (ctypes.c_char_p, [c_vp]),
+    "dm_version": (c_int, []),
+    "dm_zgemm_strided_batched": (
+        c_int,
+        [c_vp, c_int, c_int, c_int, c_dbl, c_vp, c_int, c_int, c_int, c_i64, c_vp, c_int, c_int, c_int, c_i64,
+         c_dbl, c_vp, c_int, c_i64, c_vp, c_i64, c_int],
+    ),
+    "dm_zpotrf_batched": (c_int, [c_vp, c_int, c_vp, c_int, c_i64, c_int, ctypes.POINTER(c_int)]),
+    "dm_ztrsm_left_lower_batched": (
+        c_int, [c_vp, c_int, c_int, c_vp, c_int, c_i64, c_vp, c_int, c_i64, c_int, c_int]),
+    "dm_jacobi_rows_batched": (
+        c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_i64, c_int, c_vp, ctypes.POINTER(c_int)]),
+    "dm_jacobi_herm_batched": (
+        c_int, [c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_int, c_i64, c_int, c_vp, ctypes.POINTER(c_int)]),
+    "dm_svd_chain": (
+        c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp,
+                ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "dm_project_cov": (
+        c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_vp,
+                c_int, ctypes.POINTER(c_int), c_vp, ctypes.POINTER(c_i64), c_int]),
+    "dm_project_diag": (
+        c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, ctypes.POINTER(c_int), c_vp, c_dbl, c_vp,
+                ctypes.POINTER(c_i64), c_int]),
+    "dm_regularise": (c_int, [c_vp, c_int, ctypes.POINTER(c_int), c_vp, ctypes.POINTER(c_i64), c_dbl]),
+    "dm_eigh_gen": (
+        c_int, [c_vp, c_int, ctypes.POINTER(c_int), c_vp, c_vp, ctypes.POINTER(c_i64), c_vp, ctypes.POINTER(c_i64),
+                c_vp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_int)]),
+}
+
+_lib = None
+
+
+class DriftMIError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libdriftmi.so and declare every prototype.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBPATH):
+        raise DriftMIError(
+            "libdriftmi.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)" % LIBPATH
+        )
+    lib = ctypes.CDLL(LIBPATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class Context(object):
+    """One per GPU / process.  Binds to torch's current stream on that device so
+    that torch.cuda events bracket the work."""
+
+    def __init__(self, device=0, workspace_bytes=1 << 30):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise DriftMIError("no GPU visible: libdriftmi has no CPU fallback")
+        self.torch = torch
+        self.lib = load()
+        self.device = int(device)
+        torch.cuda.set_device(self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        h = c_vp()
+        rc = self.lib.dm_ctx_create(self.device, int(workspace_bytes), c_vp(stream), ctypes.byref(h))
+        if rc != 0:
+            raise DriftMIError("dm_ctx_create failed with code %d" % rc)
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dm_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc, what=""):
+        if rc < 0:
+            msg = self.lib.dm_last_error(self.h)
+            raise DriftMIError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+        return rc
+
+    def sync(self):
+        self.check(self.lib.dm_ctx_sync(self.h), "dm_ctx_sync")
+
+    # ---- device array helpers (torch is used for memory only) -------------
+    def to_device(self, arr):
+        t = self.torch.from_numpy(np.ascontiguousarray(arr))
+        return t.to("cuda:%d" % self.device)
+
+    def empty(self, shape, dtype):
+        tdt = {np.dtype(np.complex128): self.torch.complex128, np.dtype(np.float64): self.torch.float64,
+               np.dtype(np.int32): self.torch.int32, np.dtype(np.int64): self.torch.int64}[np.dtype(dtype)]
+        return self.torch.empty(shape, dtype=tdt, device="cuda:%d" % self.device)
+
+    def zeros(self, shape, dtype):
+        t = self.empty(shape, dtype)
+        t.zero_()
+        return t
+
+    @staticmethod
+    def ptr(t):
+        return c_vp(t.data_ptr()) if t is not None else c_vp(0)
+
+    # ---- thin wrappers over the dense building blocks ---------------------
+    def zgemm(self, A, B, C, M, N, K, rsA, csA, rsB, csB, ldc, conjA=False, conjB=False, alpha=1.0, beta=0.0,
+              kscale=None, batch=1, strideA=0, strideB=0, strideC=0, stride_kscale=0):
+        rc = self.lib.dm_zgemm_strided_batched(
+            self.h, M, N, K, alpha, self.ptr(A), rsA, csA, int(conjA), strideA, self.ptr(B), rsB, csB, int(conjB),
+            strideB, beta, self.ptr(C), ldc, strideC, self.ptr(kscale), stride_kscale, batch)
+        self.check(rc, "dm_zgemm_strided_batched")
+
+    def zpotrf(self, A, n, ld, stride=0, batch=1):
+        info = (c_int * batch)()
+        self.check(self.lib.dm_zpotrf_batched(self.h, n, self.ptr(A), ld, stride, batch, info), "dm_zpotrf_batched")
+        return np.array(info[:], dtype=np.int64)
+
+    def ztrsm(self, L, B, n, nrhs, ldl, ldb, conjtrans=False, strideL=0, strideB=0, batch=1):
+        self.check(self.lib.dm_ztrsm_left_lower_batched(self.h, n, nrhs, self.ptr(L), ldl, strideL, self.ptr(B), ldb,
+                                                        strideB, int(conjtrans), batch), "dm_ztrsm")
+
+    def jacobi_rows(self, Z, rows, cols, gc0, gc1, ld, stride=0, batch=1):
+        sigma = self.empty((batch, max(rows, 1)), np.float64)
+        sw = c_int(0)
+        self.check(self.lib.dm_jacobi_rows_batched(self.h, rows, cols, gc0, gc1, self.ptr(Z), ld, stride, batch,
+                                                   self.ptr(sigma), ctypes.byref(sw)), "dm_jacobi_rows_batched")
+        return sigma, sw.value
+
+    def jacobi_herm(self, C, n, ldc, strideC=0, batch=1):
+        W = self.empty((batch, n, n), np.complex128)
+        ev = self.empty((batch, max(n, 1)), np.float64)
+        sw = c_int(0)
+        self.check(self.lib.dm_jacobi_herm_batched(self.h, n, self.ptr(C), ldc, strideC, self.ptr(W), n, n * n, batch,
+                                                   self.ptr(ev), ctypes.byref(sw)), "dm_jacobi_herm_batched")
+        return ev, W, sw.value
+
+
+def _iarr(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(ctypes.POINTER(c_int))
+
+
+def _larr(a):
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    return a, a.ctypes.data_as(ctypes.POINTER(c_i64))
+
+
+def _svd_chain(self, beam_m, noisew, polsvcut, skip_svd_inv=False):
+    """beam_m: device (nblk, F, T, P, L) c128; noisew: device (F, T) f64.
+    Returns dict of device tensors + host nmodes (nblk, F) + sweeps[4]."""
+    nblk, F, T, P, L = [int(x) for x in beam_m.shape]
+    K = min(L, T)
+    out = dict(
+        beam_svd=self.empty((nblk, F, K, P, L), np.complex128),
+        invbeam_svd=None if skip_svd_inv else self.empty((nblk, F, P, L, K), np.complex128),
+        beam_ut=self.empty((nblk, F, K, T), np.complex128),
+        singularvalues=self.empty((nblk, F, K), np.float64),
+    )
+    nmodes = (c_int * max(nblk * F, 1))()
+    sweeps = (c_int * 4)()
+    rc = self.lib.dm_svd_chain(self.h, nblk, F, T, P, L, self.ptr(beam_m), self.ptr(noisew), float(polsvcut),
+                               self.ptr(out["beam_svd"]), self.ptr(out["invbeam_svd"]), self.ptr(out["beam_ut"]),
+                               self.ptr(out["singularvalues"]), nmodes, sweeps)
+    self.check(rc, "dm_svd_chain")
+    out["nmodes"] = np.array(nmodes[: nblk * F], dtype=np.int64).reshape(nblk, F)
+    out["sweeps"] = list(sweeps)
+    return out
+
+
+def _block_offsets(ndofs):
+    ndofs = np.asarray(ndofs, dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(ndofs * ndofs)])
+    return off[:-1].copy(), int(off[-1])
+
+
+def _project_cov(self, beam_svd, svnum, cl_pfl, out, out_off, npol=None, polmask=None, l0=None, zero_first=True):
+    nblk, F, K, P, L = [int(x) for x in beam_svd.shape]
+    sv, svp = _iarr(svnum)
+    off, offp = _larr(out_off)
+    npol = P if npol is None else int(npol)
+    pm = pmp = None
+    if polmask is not None:
+        pm, pmp = _iarr(polmask)
+    l0a = l0p = None
+    if l0 is not None:
+        l0a, l0p = _iarr(l0)
+    rc = self.lib.dm_project_cov(self.h, nblk, F, K, P, L, self.ptr(beam_svd), svp, l0p, self.ptr(cl_pfl), npol, pmp,
+                                 self.ptr(out), offp, int(zero_first))
+    self.check(rc, "dm_project_cov")
+
+
+def _project_diag(self, beam_ut, svnum, dmat, out, out_off, alpha=1.0, accumulate=False):
+    nblk, F, K, T = [int(x) for x in beam_ut.shape]
+    sv, svp = _iarr(svnum)
+    off, offp = _larr(out_off)
+    rc = self.lib.dm_project_diag(self.h, nblk, F, K, T, self.ptr(beam_ut), svp, self.ptr(dmat), float(alpha),
+                                  self.ptr(out), offp, int(accumulate))
+    self.check(rc, "dm_project_diag")
+
+
+def _regularise(self, mats, ndofs, off, reg):
+    n, np_ = _iarr(ndofs)
+    o, op = _larr(off)
+    self.check(self.lib.dm_regularise(self.h, len(n), np_, self.ptr(mats), op, float(reg)), "dm_regularise")
+
+
+def _eigh_gen(self, A, B, ndofs, off):
+    """A, B: flat device c128 buffers holding the (n_b x n_b) blocks at `off`.  Destroys both.
+    Returns (evals flat device f64 [offsets evoff], evoff, evecs flat device c128 [same off], add_const, sweeps)."""
+    n, np_ = _iarr(ndofs)
+    o, op = _larr(off)
+    evoff = np.concatenate([[0], np.cumsum(n.astype(np.int64))])
+    eo, eop = _larr(evoff[:-1])
+    evals = self.empty((max(int(evoff[-1]), 1),), np.float64)
+    evecs = self.empty((max(int(A.numel()), 1),), np.complex128)
+    ac = (c_dbl * max(len(n), 1))()
+    sw = c_int(0)
+    rc = self.lib.dm_eigh_gen(self.h, len(n), np_, self.ptr(A), self.ptr(B), op, self.ptr(evals), eop,
+                              self.ptr(evecs), ac, ctypes.byref(sw))
+    self.check(rc, "dm_eigh_gen")
+    if rc > 0:
+        raise DriftMIError("dm_eigh_gen: B not positive definite even after the diagonal rescue (info=%d)" % rc)
+    return evals, evoff, evecs, np.array(ac[: len(n)], dtype=np.float64), sw.value
+
+
+Context.svd_chain = _svd_chain
+Context.project_cov = _project_cov
+Context.project_diag = _project_diag
+Context.regularise = _regularise
+Context.eigh_gen = _eigh_gen
+block_offsets = _block_offsets

@@ -1,0 +1,277 @@
+// dm_chol.hip — batched blocked Cholesky and triangular solves (gfx950).
+//
+// These are the zpotrf / zhegst pieces of scipy.linalg.eigh(A, B)
+// (drift/core/kltransform.py:89): N = L L^H, C = L^-1 S L^-H, and the
+// back-transformation of the eigenvectors with L^-H.
+//
+// Right-looking blocked Cholesky with NB = 32:
+//   potf2  : one workgroup factors the 32x32 diagonal block in LDS        (VALU)
+//   trsm   : rows below the block are solved against L_kk^H, 64 rows/WG  (VALU, LDS)
+//   update : A22 -= L21 L21^H on the matrix cores (grouped ZGEMM, lower tiles only)
+// Every step is one launch for the whole batch of matrices.
+//
+// The triangular solves are left-looking: for block row k one grouped ZGEMM
+// subtracts L[k, <k] X[<k] and a substitution kernel solves the 32x32 diagonal
+// system.  Plain substitution (not inverted diagonal blocks) keeps the solve
+// backward stable, which matters here: N is conditioned like 1e10.
+#include "dm_common.h"
+#include "dm_kernels.h"
+
+#include <algorithm>
+
+namespace {
+
+constexpr int NB = 32;
+
+struct chol_desc {
+  cplx* A; int ld; int n;
+};
+
+// ---- diagonal block factorisation ------------------------------------------------
+// grid = batch; 256 threads.  info[b] = first failing 1-based index (sticky).
+__global__ __launch_bounds__(256) void potf2_kernel(const chol_desc* __restrict__ ds, int k0, int* __restrict__ info) {
+  __shared__ cplx T[NB][NB + 1];
+  __shared__ int fail;
+  const chol_desc d = ds[blockIdx.x];
+  if (k0 >= d.n) return;
+  if (info[blockIdx.x] != 0) return;
+  const int nb = min(NB, d.n - k0);
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < NB * NB; idx += 256) {
+    int r = idx / NB, c = idx % NB;
+    T[r][c] = (r < nb && c < nb && c <= r) ? d.A[(size_t)(k0 + r) * d.ld + k0 + c] : make_double2(0.0, 0.0);
+  }
+  if (tid == 0) fail = 0;
+  __syncthreads();
+  for (int j = 0; j < nb; ++j) {
+    // diagonal
+    if (tid == 0) {
+      double djj = T[j][j].x;
+      if (!(djj > 0.0) || !isfinite(djj)) {
+        fail = j + 1;
+      } else {
+        T[j][j] = make_double2(sqrt(djj), 0.0);
+      }
+    }
+    __syncthreads();
+    if (fail) break;
+    const double inv = 1.0 / T[j][j].x;
+    // scale column j below the diagonal
+    if (tid > j && tid < nb) T[tid][j] = cscale(T[tid][j], inv);
+    __syncthreads();
+    // trailing update of the lower triangle: T[r][c] -= T[r][j] conj(T[c][j]),  j < c <= r
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+      int r = idx / NB, c = idx % NB;
+      if (c > j && c <= r && r < nb) T[r][c] = csub(T[r][c], cmulc(T[r][j], T[c][j]));
+    }
+    __syncthreads();
+  }
+  if (fail) {
+    if (tid == 0) info[blockIdx.x] = k0 + fail;
+    return;
+  }
+  for (int idx = tid; idx < NB * NB; idx += 256) {
+    int r = idx / NB, c = idx % NB;
+    if (r < nb && c < nb) {
+      cplx v = (c <= r) ? T[r][c] : make_double2(0.0, 0.0);
+      if (c == r) v.y = 0.0;
+      d.A[(size_t)(k0 + r) * d.ld + k0 + c] = v;
+    }
+  }
+}
+
+// ---- panel: rows below the diagonal block, X L_kk^H = A  -> X = A L_kk^-H ----------
+// grid = (row tiles of 64, batch).  Each thread-quad handles one row.
+__global__ __launch_bounds__(256) void panel_trsm_kernel(const chol_desc* __restrict__ ds, int k0,
+                                                         const int* __restrict__ info) {
+  __shared__ cplx Lk[NB][NB + 1];
+  __shared__ cplx R[64][NB + 1];
+  const chol_desc d = ds[blockIdx.y];
+  if (k0 + NB >= d.n) return;
+  if (info[blockIdx.y] != 0) return;
+  const int r0 = k0 + NB + blockIdx.x * 64;
+  if (r0 >= d.n) return;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < NB * NB; idx += 256) {
+    int r = idx / NB, c = idx % NB;
+    Lk[r][c] = d.A[(size_t)(k0 + r) * d.ld + k0 + c];
+  }
+  for (int idx = tid; idx < 64 * NB; idx += 256) {
+    int r = idx / NB, c = idx % NB;
+    R[r][c] = (r0 + r < d.n) ? d.A[(size_t)(r0 + r) * d.ld + k0 + c] : make_double2(0.0, 0.0);
+  }
+  __syncthreads();
+  // row x: x[c] = (a[c] - sum_{j<c} x[j] conj(L[c][j])) / L[c][c]; one thread per row
+  if (tid < 64) {
+    const int r = tid;
+    for (int c = 0; c < NB; ++c) {
+      cplx s = R[r][c];
+      for (int j = 0; j < c; ++j) s = csub(s, cmulc(R[r][j], Lk[c][j]));
+      R[r][c] = cscale(s, 1.0 / Lk[c][c].x);
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 64 * NB; idx += 256) {
+    int r = idx / NB, c = idx % NB;
+    if (r0 + r < d.n) d.A[(size_t)(r0 + r) * d.ld + k0 + c] = R[r][c];
+  }
+}
+
+__global__ void zero_upper_kernel(const chol_desc* __restrict__ ds) {
+  const chol_desc d = ds[blockIdx.z];
+  const int r = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < d.n && c < d.n && c > r) d.A[(size_t)r * d.ld + c] = make_double2(0.0, 0.0);
+}
+
+// ---- diagonal-block substitution for the triangular solves --------------------------
+struct trsm_desc {
+  const cplx* L; int ldl; int n; cplx* B; int ldb; int nrhs;
+};
+
+// Solve L_kk X_k = B_k (forward) or L_kk^H X_k = B_k (backward) for one block row.
+// grid = (column tiles of 64, batch); one thread per right-hand-side column.
+template <bool CONJTRANS>
+__global__ __launch_bounds__(64) void diag_solve_kernel(const trsm_desc* __restrict__ ds, int s, int nblk) {
+  __shared__ cplx Lk[NB][NB + 1];
+  const trsm_desc d = ds[blockIdx.y];
+  int k0;
+  if (!CONJTRANS) {
+    k0 = s * NB;
+  } else {
+    // smaller problems start later so that all finish with block row 0 on the last step
+    const int pn = (d.n + NB - 1) / NB;
+    if (s < nblk - pn) return;
+    k0 = (pn - 1 - (s - (nblk - pn))) * NB;
+  }
+  if (k0 >= d.n || k0 < 0) return;
+  const int nb = min(NB, d.n - k0);
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  for (int idx = threadIdx.x; idx < NB * NB; idx += 64) {
+    int r = idx / NB, c = idx % NB;
+    Lk[r][c] = (r < nb && c < nb) ? d.L[(size_t)(k0 + r) * d.ldl + k0 + c] : make_double2(0.0, 0.0);
+  }
+  __syncthreads();
+  if (col >= d.nrhs) return;
+  cplx x[NB];
+#pragma unroll
+  for (int r = 0; r < NB; ++r) x[r] = (r < nb) ? d.B[(size_t)(k0 + r) * d.ldb + col] : make_double2(0.0, 0.0);
+  if (!CONJTRANS) {
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      if (r < nb) {
+        cplx s = x[r];
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          if (j < r) s = csub(s, cmul(Lk[r][j], x[j]));
+        x[r] = cscale(s, 1.0 / Lk[r][r].x);
+      }
+    }
+  } else {
+    // (L^H)[r][j] = conj(L[j][r]), upper triangular: back substitution
+#pragma unroll
+    for (int rr = 0; rr < NB; ++rr) {
+      const int r = NB - 1 - rr;
+      if (r < nb) {
+        cplx s = x[r];
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          if (j > r && j < nb) s = csub(s, cmul(cconj(Lk[j][r]), x[j]));
+        x[r] = cscale(s, 1.0 / Lk[r][r].x);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NB; ++r)
+    if (r < nb) d.B[(size_t)(k0 + r) * d.ldb + col] = x[r];
+}
+
+}  // namespace
+
+int dm_potrf_batched(dm_ctx* ctx, const std::vector<dm_mat>& mats, int* info_dev) {
+  const int nbatch = (int)mats.size();
+  if (nbatch == 0) return DM_OK;
+  const size_t mark = dm_ws_mark(ctx);
+  std::vector<chol_desc> ds(nbatch);
+  int maxn = 0;
+  for (int i = 0; i < nbatch; ++i) {
+    ds[i] = chol_desc{mats[i].p, mats[i].ld, mats[i].n};
+    maxn = std::max(maxn, mats[i].n);
+  }
+  chol_desc* dd = dm_ws_upload(ctx, ds);
+  if (!dd) return DM_ENOMEM;
+  DM_HIP(ctx, hipMemsetAsync(info_dev, 0, sizeof(int) * nbatch, ctx->stream));
+  for (int k0 = 0; k0 < maxn; k0 += NB) {
+    hipLaunchKernelGGL(potf2_kernel, dim3(nbatch), dim3(256), 0, ctx->stream, dd, k0, info_dev);
+    if (k0 + NB >= maxn) break;
+    const int rt = (maxn - k0 - NB + 63) / 64;
+    hipLaunchKernelGGL(panel_trsm_kernel, dim3(rt, nbatch), dim3(256), 0, ctx->stream, dd, k0, info_dev);
+    // trailing update A22 -= L21 L21^H (lower tiles).  A failed matrix is updated
+    // too (harmless: its factor is discarded by the caller).
+    std::vector<dm_gemm_desc> g;
+    g.reserve(nbatch);
+    for (int i = 0; i < nbatch; ++i) {
+      const int rem = mats[i].n - k0 - NB;
+      if (rem <= 0) continue;
+      cplx* L21 = mats[i].p + (size_t)(k0 + NB) * mats[i].ld + k0;
+      cplx* A22 = mats[i].p + (size_t)(k0 + NB) * mats[i].ld + (k0 + NB);
+      g.push_back(dm_gemm_make(L21, mats[i].ld, 1, false, L21, 1, mats[i].ld, true, A22, mats[i].ld, rem, rem, NB,
+                               -1.0, 1.0, nullptr, DM_GEMM_LOWER));
+    }
+    DM_TRY(dm_gemm_grouped_launch(ctx, g));
+  }
+  hipLaunchKernelGGL(zero_upper_kernel, dim3((maxn + 255) / 256, maxn, nbatch), dim3(256), 0, ctx->stream, dd);
+  DM_HIP(ctx, hipGetLastError());
+  (void)mark;  // descriptors stay allocated until the caller releases its own mark
+  return DM_OK;
+}
+
+int dm_trsm_left_lower_batched(dm_ctx* ctx, const std::vector<dm_trsm_problem>& probs, bool conjtrans) {
+  const int nbatch = (int)probs.size();
+  if (nbatch == 0) return DM_OK;
+  std::vector<trsm_desc> ds(nbatch);
+  int maxn = 0, maxrhs = 0;
+  for (int i = 0; i < nbatch; ++i) {
+    ds[i] = trsm_desc{probs[i].L, probs[i].ldl, probs[i].n, probs[i].B, probs[i].ldb, probs[i].nrhs};
+    maxn = std::max(maxn, probs[i].n);
+    maxrhs = std::max(maxrhs, probs[i].nrhs);
+  }
+  if (maxn == 0 || maxrhs == 0) return DM_OK;
+  trsm_desc* dd = dm_ws_upload(ctx, ds);
+  if (!dd) return DM_ENOMEM;
+  const int nblk = (maxn + NB - 1) / NB;
+  const int ct = (maxrhs + 63) / 64;
+  for (int s = 0; s < nblk; ++s) {
+    std::vector<dm_gemm_desc> g;
+    g.reserve(nbatch);
+    for (int i = 0; i < nbatch; ++i) {
+      const dm_trsm_problem& P = probs[i];
+      const int pn = (P.n + NB - 1) / NB;
+      if (!conjtrans) {
+        // forward: block row k = s ; B_k -= L[k, 0:k0] X[0:k0]
+        const int k0 = s * NB;
+        if (k0 >= P.n || k0 == 0) continue;
+        const int nb = std::min(NB, P.n - k0);
+        g.push_back(dm_gemm_make(P.L + (size_t)k0 * P.ldl, P.ldl, 1, false, P.B, P.ldb, 1, false,
+                                 P.B + (size_t)k0 * P.ldb, P.ldb, nb, P.nrhs, k0, -1.0, 1.0));
+      } else {
+        // backward: block row k = pn-1-s (per problem) ; B_k -= (L[k1:, k])^H X[k1:]
+        const int kb = pn - 1 - (s - (nblk - pn));
+        if (s < nblk - pn) continue;  // smaller problems start later so that all finish together
+        const int k0 = kb * NB;
+        const int nb = std::min(NB, P.n - k0);
+        const int k1 = k0 + nb;
+        if (k1 >= P.n) continue;
+        // A = (L[k1:n, k0:k0+nb])^H viewed as (nb x (n-k1)): element (i, j) = conj(L[k1+j][k0+i])
+        g.push_back(dm_gemm_make(P.L + (size_t)k1 * P.ldl + k0, 1, P.ldl, true, P.B + (size_t)k1 * P.ldb, P.ldb, 1,
+                                 false, P.B + (size_t)k0 * P.ldb, P.ldb, nb, P.nrhs, P.n - k1, -1.0, 1.0));
+      }
+    }
+    DM_TRY(dm_gemm_grouped_launch(ctx, g));
+    if (!conjtrans)
+      hipLaunchKernelGGL(diag_solve_kernel<false>, dim3(ct, nbatch), dim3(64), 0, ctx->stream, dd, s, nblk);
+    else
+      hipLaunchKernelGGL(diag_solve_kernel<true>, dim3(ct, nbatch), dim3(64), 0, ctx->stream, dd, s, nblk);
+  }
+  DM_HIP(ctx, hipGetLastError());
+  return DM_OK;
+}

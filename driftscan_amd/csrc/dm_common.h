@@ -1,0 +1,137 @@
+// dm_common.h — shared host/device definitions for libdriftmi (gfx950 only).
+//
+// Everything in csrc/ is written for CDNA4 (MI355X): 64-wide wavefronts, the
+// fp64 MFMA v_mfma_f64_16x16x4_f64, 160 KiB LDS per CU, 8 XCDs.  There is no
+// other back-end and no CPU fallback.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+typedef double2 cplx;  // interleaved (re, im) complex128, matches numpy/HDF5 {r,i}
+
+// ---------------------------------------------------------------------------
+// context: one per GPU, one host thread per context (include/driftmi.h)
+// ---------------------------------------------------------------------------
+struct dm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // bump-allocated device workspace; grows on demand (growth synchronises)
+  char* ws = nullptr;
+  size_t ws_cap = 0;
+  size_t ws_used = 0;
+  std::vector<void*> retired;  // old arenas kept alive until the next reset
+  // pinned host staging for small descriptor uploads / flag read-backs
+  char* hpin = nullptr;
+  size_t hpin_cap = 0;
+  std::string err;
+};
+
+#define DM_OK 0
+#define DM_EARG (-1)
+#define DM_EHIP (-2)
+#define DM_ENOMEM (-3)
+
+#define DM_HIP(ctx, call)                                                        \
+  do {                                                                           \
+    hipError_t e__ = (call);                                                     \
+    if (e__ != hipSuccess) {                                                     \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);           \
+      return DM_EHIP;                                                            \
+    }                                                                            \
+  } while (0)
+
+#define DM_ARG(ctx, cond)                                         \
+  do {                                                            \
+    if (!(cond)) {                                                \
+      (ctx)->err = std::string("bad argument: ") + #cond;         \
+      return DM_EARG;                                             \
+    }                                                             \
+  } while (0)
+
+#define DM_TRY(expr)            \
+  do {                          \
+    int rc__ = (expr);          \
+    if (rc__ != DM_OK) return rc__; \
+  } while (0)
+
+// workspace helpers (dm_ctx.cpp)
+int dm_ws_reserve(dm_ctx* ctx, size_t bytes);
+void* dm_ws_alloc(dm_ctx* ctx, size_t bytes);  // nullptr on failure (err set)
+size_t dm_ws_mark(dm_ctx* ctx);
+void dm_ws_release(dm_ctx* ctx, size_t mark);
+int dm_upload(dm_ctx* ctx, void* dst, const void* src, size_t bytes);    // async H2D via pinned staging
+int dm_download(dm_ctx* ctx, void* dst, const void* src, size_t bytes);  // D2H + stream sync
+
+template <typename T>
+static inline T* dm_ws_alloc_t(dm_ctx* ctx, size_t n) {
+  return reinterpret_cast<T*>(dm_ws_alloc(ctx, n * sizeof(T)));
+}
+
+// upload a std::vector into freshly bump-allocated workspace
+template <typename T>
+static inline T* dm_ws_upload(dm_ctx* ctx, const std::vector<T>& v) {
+  if (v.empty()) return dm_ws_alloc_t<T>(ctx, 1);
+  T* d = dm_ws_alloc_t<T>(ctx, v.size());
+  if (!d) return nullptr;
+  if (dm_upload(ctx, d, v.data(), v.size() * sizeof(T)) != DM_OK) return nullptr;
+  return d;
+}
+
+// ---------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------
+#if defined(__HIPCC__)
+
+typedef double dm_f64x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f64_16x16x4_f64: D(16x16) += A(16x4) * B(4x16), one f64 per lane for A and B.
+//   A: lane l holds A[i = l & 15][k = l >> 4]
+//   B: lane l holds B[k = l >> 4][j = l & 15]
+//   D: lane l, reg r holds D[row = (l >> 4) + 4 r][col = l & 15]
+// (cdna_hip_programming.md §3 "f64 MFMA does NOT use these maps")
+__device__ __forceinline__ dm_f64x4 dm_mfma(double a, double b, dm_f64x4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ cplx cmulc(cplx a, cplx b) {  // a * conj(b)
+  return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cplx cconj(cplx a) { return make_double2(a.x, -a.y); }
+__device__ __forceinline__ cplx cscale(cplx a, double s) { return make_double2(a.x * s, a.y * s); }
+__device__ __forceinline__ double cabs2(cplx a) { return a.x * a.x + a.y * a.y; }
+
+// XCD-aware remap of a 1-D block id: consecutive logical tiles land on the same
+// XCD (blocks b and b+8 share an XCD under the observed round-robin dispatch;
+// speed only, never correctness — MI355X_MICROARCH.md §Workgroup dispatch).
+__device__ __forceinline__ int dm_xcd_remap(int bid, int nblocks) {
+  const int nx = 8;
+  int per = nblocks / nx;
+  int full = per * nx;
+  if (bid >= full) return bid;  // ragged tail keeps its id
+  return (bid % nx) * per + bid / nx;
+}
+
+__device__ __forceinline__ double dm_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double dm_wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+#endif  // __HIPCC__

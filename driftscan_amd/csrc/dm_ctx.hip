@@ -1,0 +1,159 @@
+// dm_ctx.hip — context, workspace arena and host<->device staging for libdriftmi.
+#include "dm_common.h"
+#include "dm_kernels.h"
+#include "../../include/driftmi.h"
+
+namespace {
+constexpr size_t kAlign = 256;
+constexpr size_t kPinned = 64u << 20;  // staging ring for descriptor uploads
+size_t g_pin_used = 0;                 // per-process is fine: one ctx per process/GPU in practice
+inline size_t align_up(size_t x) { return (x + kAlign - 1) & ~(kAlign - 1); }
+}  // namespace
+
+int dm_ws_reserve(dm_ctx* ctx, size_t bytes) {
+  bytes = align_up(bytes);
+  if (bytes <= ctx->ws_cap) return DM_OK;
+  // growing: kernels in flight may still use the old arena -> drain first
+  DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->ws_used == 0 && ctx->ws) {
+    (void)hipFree(ctx->ws);
+    ctx->ws = nullptr;
+  } else if (ctx->ws) {
+    ctx->retired.push_back(ctx->ws);  // live allocations remain valid
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    ctx->err = std::string("hipMalloc workspace: ") + hipGetErrorString(e);
+    ctx->ws = nullptr;
+    ctx->ws_cap = 0;
+    return DM_ENOMEM;
+  }
+  ctx->ws = reinterpret_cast<char*>(p);
+  ctx->ws_cap = bytes;
+  ctx->ws_used = 0;
+  return DM_OK;
+}
+
+void* dm_ws_alloc(dm_ctx* ctx, size_t bytes) {
+  bytes = align_up(bytes ? bytes : 1);
+  if (ctx->ws_used + bytes > ctx->ws_cap) {
+    size_t want = ctx->ws_cap * 2 > ctx->ws_used + bytes ? ctx->ws_cap * 2 : (ctx->ws_used + bytes) * 2;
+    if (want < (256u << 20)) want = 256u << 20;
+    if (dm_ws_reserve(ctx, want) != DM_OK) return nullptr;
+  }
+  void* p = ctx->ws + ctx->ws_used;
+  ctx->ws_used += bytes;
+  return p;
+}
+
+size_t dm_ws_mark(dm_ctx* ctx) { return ctx->ws_used; }
+
+void dm_ws_release(dm_ctx* ctx, size_t mark) {
+  // Re-use is stream-ordered: every producer and consumer of workspace memory,
+  // including the H2D descriptor copies, runs on ctx->stream.
+  if (mark <= ctx->ws_used) ctx->ws_used = mark;
+  if (!ctx->retired.empty() && mark == 0) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void* p : ctx->retired) (void)hipFree(p);
+    ctx->retired.clear();
+  }
+}
+
+int dm_upload(dm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return DM_OK;
+  if (bytes > kPinned / 2) {  // big: synchronous path
+    DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DM_HIP(ctx, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return DM_OK;
+  }
+  size_t need = align_up(bytes);
+  if (g_pin_used + need > ctx->hpin_cap) {
+    // wrap the ring: make sure every earlier staged copy has been consumed
+    DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    g_pin_used = 0;
+  }
+  char* stage = ctx->hpin + g_pin_used;
+  g_pin_used += need;
+  std::memcpy(stage, src, bytes);
+  DM_HIP(ctx, hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return DM_OK;
+}
+
+int dm_download(dm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return DM_OK;
+  DM_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return DM_OK;
+}
+
+extern "C" {
+
+int dm_ctx_create(int device, size_t workspace_bytes, void* stream, dm_ctx** out) {
+  if (!out) return DM_EARG;
+  *out = nullptr;
+  dm_ctx* ctx = new dm_ctx();
+  ctx->device = device;
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) {
+    delete ctx;
+    return DM_EHIP;
+  }
+  if (stream) {
+    ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    ctx->own_stream = false;
+  } else {
+    e = hipStreamCreate(&ctx->stream);
+    if (e != hipSuccess) {
+      delete ctx;
+      return DM_EHIP;
+    }
+    ctx->own_stream = true;
+  }
+  void* hp = nullptr;
+  e = hipHostMalloc(&hp, kPinned, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return DM_ENOMEM;
+  }
+  ctx->hpin = reinterpret_cast<char*>(hp);
+  ctx->hpin_cap = kPinned;
+  if (workspace_bytes) {
+    int rc = dm_ws_reserve(ctx, workspace_bytes);
+    if (rc != DM_OK) {
+      (void)hipHostFree(hp);
+      if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+      delete ctx;
+      return rc;
+    }
+  }
+  *out = ctx;
+  return DM_OK;
+}
+
+int dm_ctx_destroy(dm_ctx* ctx) {
+  if (!ctx) return DM_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (void* p : ctx->retired) (void)hipFree(p);
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->hpin) (void)hipHostFree(ctx->hpin);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return DM_OK;
+}
+
+const char* dm_last_error(dm_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int dm_ctx_sync(dm_ctx* ctx) {
+  if (!ctx) return DM_EARG;
+  DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return DM_OK;
+}
+
+size_t dm_ctx_workspace_bytes(dm_ctx* ctx) { return ctx ? ctx->ws_cap : 0; }
+
+int dm_version(void) { return 100; }
+
+}  // extern "C"

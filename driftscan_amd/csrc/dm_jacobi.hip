@@ -1,0 +1,896 @@
+// dm_jacobi.hip — batched block-Jacobi engines on gfx950.
+//
+// Two drivers share three kernels:
+//
+//   one-sided ("rows")  : SVD of a wide/tall matrix — the rows of Z are unitarily
+//       mixed until mutually orthogonal over a chosen set of columns, every other
+//       column rides along as a passenger.  Replaces scipy.linalg.svd in
+//       matrix_image / matrix_nullspace (drift/core/beamtransfer.py:74, :113) and,
+//       through the passenger trick, also the projection GEMMs that follow them
+//       (beamtransfer.py:831, :850-851, :866, :877).
+//   two-sided ("herm")  : eigendecomposition of a Hermitian matrix; replaces the
+//       zheevd step of scipy.linalg.eigh(A, B) (drift/core/kltransform.py:89).
+//
+// Structure of one round (all matrices of the batch advance in lock-step):
+//   1. jac_gram      G = X X^H for every disjoint pair of 32-row blocks      (MFMA)
+//      (two-sided: G is read straight from the diagonal blocks of C)
+//   2. jac_inner     2-sided cyclic Jacobi on each 64x64 G inside LDS -> Q    (VALU+LDS)
+//   3. jac_apply     rows(pair) <- Q^H rows(pair) over all columns           (MFMA)
+// and a tournament of nb-1 rounds makes a sweep.  Because every m-block and every
+// frequency is an independent problem, one launch carries (#pairs x #problems)
+// workgroups — that is what fills 256 CUs with matrices this small.
+//
+// Accuracy: the inner solver is a Jacobi method too, so graded Gram blocks keep
+// their relative accuracy (an eigh-style inner solver does not: see DESIGN.md §5).
+#include "dm_common.h"
+#include "dm_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+namespace {
+
+constexpr int JB = 32;       // rows per block
+constexpr int JP = 64;       // rows per pair
+constexpr int GP = 65;       // LDS pitch (complex elements) of the 64x64 inner matrices
+constexpr int QP = 80;       // LDS pitch (doubles) of the Q^H planes in jac_apply
+constexpr int XP = 17;       // LDS pitch (doubles) of the gram staging planes
+
+struct jac_item {
+  cplx* Z;      // matrix base
+  int ld;       // leading dimension
+  int ra, na;   // first row / valid rows of block A
+  int rb, nb;   // first row / valid rows of block B (nb == 0: single block)
+  int c0, c1;   // columns transformed by jac_apply: [c0, c1)
+  int g0, g1;   // Gram columns [g0, g1)  (two-sided: g0 = column origin of the Hermitian block)
+  int prob;     // problem index (convergence bookkeeping)
+  int q;        // slot in the Q / G buffers
+};
+
+__device__ __forceinline__ int item_row(const jac_item& it, int k) {
+  // k in [0,64): local row -> global row or -1
+  if (k < JB) return (k < it.na) ? it.ra + k : -1;
+  k -= JB;
+  return (k < it.nb) ? it.rb + k : -1;
+}
+
+// ---------------------------------------------------------------------------
+// 1. Gram of a row-block pair (one-sided mode)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void jac_gram_kernel(const jac_item* __restrict__ items,
+                                                       const int* __restrict__ active, cplx* __restrict__ Gbuf) {
+  __shared__ double Xre[JP * XP], Xim[JP * XP];
+  const jac_item it = items[blockIdx.x];
+  if (!active[it.prob]) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fi = lane & 15, fk = lane >> 4;
+
+  dm_f64x4 gre[4], gim[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    gre[j] = dm_f64x4{0, 0, 0, 0};
+    gim[j] = dm_f64x4{0, 0, 0, 0};
+  }
+
+  // staging map: 64 rows x 16 cols, k fastest (each row segment = 256 contiguous bytes)
+  int srow[4], scol[4], grow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int idx = tid + 256 * i;
+    scol[i] = idx & 15;
+    srow[i] = idx >> 4;
+    grow[i] = item_row(it, srow[i]);
+  }
+  cplx r[4];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int c = it.g0 + k0 + scol[i];
+      r[i] = (grow[i] >= 0 && c < it.g1) ? it.Z[(size_t)grow[i] * it.ld + c] : make_double2(0.0, 0.0);
+    }
+  };
+  const int nk = (it.g1 - it.g0 + 15) / 16;
+  if (nk > 0) load(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      Xre[srow[i] * XP + scol[i]] = r[i].x;
+      Xim[srow[i] * XP + scol[i]] = r[i].y;
+    }
+    __syncthreads();
+    if (kt + 1 < nk) load((kt + 1) * 16);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      int ra = (wave * 16 + fi) * XP + kk * 4 + fk;
+      double a_re = Xre[ra], a_im = Xim[ra], a_ren = -a_re;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int rb = (j * 16 + fi) * XP + kk * 4 + fk;
+        double x_re = Xre[rb], x_im = Xim[rb];
+        // G[i][j] += a_i * conj(x_j)
+        gre[j] = dm_mfma(a_re, x_re, gre[j]);
+        gre[j] = dm_mfma(a_im, x_im, gre[j]);
+        gim[j] = dm_mfma(a_im, x_re, gim[j]);
+        gim[j] = dm_mfma(a_ren, x_im, gim[j]);
+      }
+    }
+  }
+  cplx* G = Gbuf + (size_t)it.q * JP * JP;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      int row = wave * 16 + (lane >> 4) + 4 * rr;
+      int col = j * 16 + (lane & 15);
+      G[row * JP + col] = make_double2(gre[j][rr], gim[j][rr]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 2. inner solver: two-sided cyclic Jacobi on a 64x64 Hermitian matrix in LDS
+// ---------------------------------------------------------------------------
+// offmax[prob] receives (atomicMax on the bit pattern of a non-negative double)
+// the largest relative off-diagonal |g_ij| / sqrt(g_ii g_jj) seen *before* the
+// solve: the sweep-level convergence measure.
+template <bool HERM>
+__global__ __launch_bounds__(256) void jac_inner_kernel(const jac_item* __restrict__ items,
+                                                        const int* __restrict__ active,
+                                                        const double* __restrict__ absfloor_p,
+                                                        const cplx* __restrict__ Gbuf, cplx* __restrict__ Qbuf,
+                                                        unsigned long long* __restrict__ offmax,
+                                                        int* __restrict__ skip, double tol_outer,
+                                                        double tol_inner) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  cplx* G = reinterpret_cast<cplx*>(smem);
+  cplx* Q = G + JP * GP;
+  double* rc = reinterpret_cast<double*>(Q + JP * GP);  // [32] cos
+  cplx* rs = reinterpret_cast<cplx*>(rc + 32);           // [32] sin * phase
+  int* ctl = reinterpret_cast<int*>(rs + 32);            // [0] rotations this sweep, [1..32] pair active
+  double* red = reinterpret_cast<double*>(ctl + 40);     // [4] reduction scratch
+
+  const jac_item it = items[blockIdx.x];
+  if (!active[it.prob]) return;
+  const int tid = threadIdx.x;
+  const double absfloor = absfloor_p ? absfloor_p[it.prob] : 0.0;
+
+  // ---- load G (Hermitian by construction), Q = I
+  for (int idx = tid; idx < JP * JP; idx += 256) {
+    int r = idx >> 6, c = idx & 63;
+    cplx v;
+    if (HERM) {
+      int gr = item_row(it, r), gc = item_row(it, c);
+      // two-sided: rows/cols index the same Hermitian matrix (column origin g0 - row origin folded by caller)
+      v = (gr >= 0 && gc >= 0) ? it.Z[(size_t)gr * it.ld + (it.g0 + gc)] : make_double2(0.0, 0.0);
+    } else {
+      v = Gbuf[(size_t)it.q * JP * JP + idx];
+    }
+    G[r * GP + c] = v;
+    Q[r * GP + c] = make_double2(r == c ? 1.0 : 0.0, 0.0);
+  }
+  __syncthreads();
+  if (HERM) {
+    // enforce exact Hermitian symmetry from the lower triangle
+    for (int idx = tid; idx < JP * JP; idx += 256) {
+      int r = idx >> 6, c = idx & 63;
+      if (r < c) {
+        cplx v = G[c * GP + r];
+        G[r * GP + c] = make_double2(v.x, -v.y);
+      } else if (r == c) {
+        G[r * GP + c].y = 0.0;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- convergence measure before the solve
+  double mo = 0.0;
+  for (int idx = tid; idx < JP * JP; idx += 256) {
+    int r = idx >> 6, c = idx & 63;
+    if (r < c) {
+      cplx g = G[r * GP + c];
+      double ag = sqrt(g.x * g.x + g.y * g.y);
+      double dd = fabs(G[r * GP + r].x * G[c * GP + c].x);
+      if (ag > absfloor && dd > 0.0) mo = fmax(mo, ag / sqrt(dd));
+    }
+  }
+  mo = dm_wave_max(mo);
+  if ((tid & 63) == 0) red[tid >> 6] = mo;
+  __syncthreads();
+  mo = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  if (tid == 0) {
+    atomicMax(&offmax[it.prob], (unsigned long long)__double_as_longlong(mo));
+    skip[it.q] = (mo <= tol_outer) ? 1 : 0;
+  }
+  if (mo <= tol_outer) return;  // uniform across the block
+
+  // ---- cyclic Jacobi, 63 parallel steps of 32 disjoint rotations per sweep
+  for (int sweep = 0; sweep < 24; ++sweep) {
+    if (tid == 0) ctl[0] = 0;
+    __syncthreads();
+    for (int step = 0; step < 63; ++step) {
+      // phase A: rotation parameters
+      if (tid < 32) {
+        int p, q;
+        if (tid == 0) { p = 63; q = step; }
+        else { p = (step + tid) % 63; q = (step + 63 - tid) % 63; }
+        cplx g = G[p * GP + q];
+        double a = G[p * GP + p].x, b = G[q * GP + q].x;
+        double ag = sqrt(g.x * g.x + g.y * g.y);
+        int act = 0;
+        double c = 1.0;
+        cplx sp = make_double2(0.0, 0.0);
+        if (ag > 0.0 && ag > absfloor && ag > tol_inner * sqrt(fabs(a * b))) {
+          double zeta = (b - a) / (2.0 * ag);
+          double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          c = 1.0 / sqrt(1.0 + t * t);
+          double s = c * t;
+          sp = make_double2(s * g.x / ag, s * g.y / ag);  // s * phase
+          act = 1;
+        }
+        rc[tid] = c;
+        rs[tid] = sp;
+        ctl[1 + tid] = act;
+        if (act) ctl[0] = 1;  // benign race: all writers store 1
+      }
+      __syncthreads();
+      // phase B: column rotation of G and Q:  col_p' = c col_p - conj(sp) col_q ; col_q' = sp col_p + c col_q
+#pragma unroll 2
+      for (int i = 0; i < 8; ++i) {
+        int u = tid + 256 * i;
+        int t = u & 31, r = u >> 5;
+        if (!ctl[1 + t]) continue;
+        int p, q;
+        if (t == 0) { p = 63; q = step; }
+        else { p = (step + t) % 63; q = (step + 63 - t) % 63; }
+        double c = rc[t];
+        cplx sp = rs[t];
+        cplx gp = G[r * GP + p], gq = G[r * GP + q];
+        G[r * GP + p] = csub(cscale(gp, c), cmulc(gq, sp));   // c gp - conj(sp) gq
+        G[r * GP + q] = cadd(cmul(sp, gp), cscale(gq, c));
+        cplx qp = Q[r * GP + p], qq = Q[r * GP + q];
+        Q[r * GP + p] = csub(cscale(qp, c), cmulc(qq, sp));
+        Q[r * GP + q] = cadd(cmul(sp, qp), cscale(qq, c));
+      }
+      __syncthreads();
+      // phase C: row rotation of G:  row_p' = c row_p - sp row_q ; row_q' = conj(sp) row_p + c row_q
+#pragma unroll 2
+      for (int i = 0; i < 8; ++i) {
+        int u = tid + 256 * i;
+        int t = u & 31, col = u >> 5;
+        if (!ctl[1 + t]) continue;
+        int p, q;
+        if (t == 0) { p = 63; q = step; }
+        else { p = (step + t) % 63; q = (step + 63 - t) % 63; }
+        double c = rc[t];
+        cplx sp = rs[t];
+        cplx gp = G[p * GP + col], gq = G[q * GP + col];
+        cplx np_ = csub(cscale(gp, c), cmul(sp, gq));
+        cplx nq_ = cadd(cmulc(gp, sp), cscale(gq, c));  // conj(sp) gp + c gq
+        if (col == p) { np_.y = 0.0; nq_ = make_double2(0.0, 0.0); }
+        if (col == q) { nq_.y = 0.0; np_ = make_double2(0.0, 0.0); }
+        G[p * GP + col] = np_;
+        G[q * GP + col] = nq_;
+      }
+      __syncthreads();
+    }
+    if (ctl[0] == 0) break;
+    __syncthreads();
+  }
+
+  cplx* Qo = Qbuf + (size_t)it.q * JP * JP;
+  for (int idx = tid; idx < JP * JP; idx += 256) {
+    int r = idx >> 6, c = idx & 63;
+    Qo[idx] = Q[r * GP + c];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 3. rows(pair) <- Q^H rows(pair), in place, all passenger columns
+// ---------------------------------------------------------------------------
+// grid = (items, column chunks).  Each wave takes 16 columns at a time: the
+// 64x16 strip is pulled into registers (it is the MFMA B operand as it stands),
+// multiplied by Q^H from LDS, and written back — so the update is in place.
+constexpr int APPLY_CHUNK = 256;  // columns per workgroup
+
+__global__ __launch_bounds__(256) void jac_apply_kernel(const jac_item* __restrict__ items,
+                                                        const int* __restrict__ active,
+                                                        const int* __restrict__ skip,
+                                                        const cplx* __restrict__ Qbuf) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* Are = reinterpret_cast<double*>(smem);  // A = Q^H : Are[k][i] = Re conj(Q[k][i]) = Re Q[k][i]
+  double* Aim = Are + JP * QP;                    //            Aim[k][i] = -Im Q[k][i]
+  const jac_item it = items[blockIdx.x];
+  if (!active[it.prob] || skip[it.q]) return;
+  const int cbeg = it.c0 + blockIdx.y * APPLY_CHUNK;
+  if (cbeg >= it.c1) return;
+  const int cend = min(it.c1, cbeg + APPLY_CHUNK);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  const cplx* Qi = Qbuf + (size_t)it.q * JP * JP;
+  for (int idx = tid; idx < JP * JP; idx += 256) {
+    int k = idx >> 6, i = idx & 63;
+    cplx v = Qi[idx];  // Q[k][i]
+    Are[k * QP + i] = v.x;
+    Aim[k * QP + i] = -v.y;
+  }
+  __syncthreads();
+
+  const int fj = lane & 15, fk = lane >> 4;
+  // global rows of the 16 k-steps this lane feeds (k = 4*ks + fk)
+  int krow[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) krow[ks] = item_row(it, ks * 4 + fk);
+
+  for (int c = cbeg + wave * 16; c < cend; c += 64) {
+    const int col = c + fj;
+    const bool cok = col < cend;
+    double bre[16], bim[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      cplx v = (cok && krow[ks] >= 0) ? it.Z[(size_t)krow[ks] * it.ld + col] : make_double2(0.0, 0.0);
+      bre[ks] = v.x;
+      bim[ks] = v.y;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      dm_f64x4 ore = {0, 0, 0, 0}, oim = {0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        int ra = (ks * 4 + fk) * QP + mt * 16 + fj;
+        double a_re = Are[ra], a_im = Aim[ra];
+        ore = dm_mfma(a_re, bre[ks], ore);
+        ore = dm_mfma(-a_im, bim[ks], ore);
+        oim = dm_mfma(a_re, bim[ks], oim);
+        oim = dm_mfma(a_im, bre[ks], oim);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        int grow = item_row(it, mt * 16 + (lane >> 4) + 4 * rr);
+        if (cok && grow >= 0) it.Z[(size_t)grow * it.ld + col] = make_double2(ore[rr], oim[rr]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// helpers: norms, ranking, row gather, transpose, diagonal
+// ---------------------------------------------------------------------------
+struct jac_pdesc {
+  cplx* Z; int ld; int row0; int nrows; int c0; int c1; int g0; int g1;
+};
+
+// one wave per row: sigma[p*stride + i] = || Z[row0+i, g0:g1] ||
+__global__ void jac_rownorm_kernel(const jac_pdesc* __restrict__ pd, double* __restrict__ sigma, int stride,
+                                   int maxrows) {
+  const int p = blockIdx.y;
+  const jac_pdesc d = pd[p];
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= d.nrows) return;
+  const cplx* z = d.Z + (size_t)(d.row0 + row) * d.ld;
+  // scaled accumulation is unnecessary: entries are O(1e4) at most and fp64 range is ample
+  double s = 0.0;
+  for (int c = d.g0 + lane; c < d.g1; c += 64) s += cabs2(z[c]);
+  s = dm_wave_sum(s);
+  if (lane == 0) sigma[(size_t)p * stride + row] = sqrt(s);
+}
+
+// floor[p] = factor * max_i key[p][i]^2  (rows whose mutual Gram entries fall below
+// this are numerical noise: singular values under ~4 eps sigma_max)
+__global__ void jac_floor_kernel(const double* __restrict__ key, int stride, const int* __restrict__ nrows_p,
+                                 double* __restrict__ floor_out, double factor) {
+  const int p = blockIdx.x;
+  const int n = nrows_p[p];
+  __shared__ double red[4];
+  double m = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmax(m, key[(size_t)p * stride + i]);
+  m = dm_wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double mm = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    floor_out[p] = factor * mm * mm;
+  }
+}
+
+// rank[i] = position of row i in descending (or ascending) order of key, stable
+__global__ void jac_rank_kernel(const double* __restrict__ key, int stride, const int* __restrict__ nrows_p,
+                                int* __restrict__ rank, int descending) {
+  const int p = blockIdx.y;
+  const int n = nrows_p[p];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* k = key + (size_t)p * stride;
+  const double ki = k[i];
+  int r = 0;
+  for (int j = 0; j < n; ++j) {
+    double kj = k[j];
+    bool before = descending ? (kj > ki) : (kj < ki);
+    if (before || (kj == ki && j < i)) ++r;
+  }
+  rank[(size_t)p * stride + i] = r;
+}
+
+// dst[p][rank[i], c0:c1] = src row i ; sorted keys written too
+__global__ void jac_gather_rows_kernel(const jac_pdesc* __restrict__ pd, const int* __restrict__ rank, int stride,
+                                       cplx* __restrict__ tmp, const size_t* __restrict__ tmp_off,
+                                       const double* __restrict__ key, double* __restrict__ key_sorted) {
+  const int p = blockIdx.z;
+  const jac_pdesc d = pd[p];
+  const int row = blockIdx.y;
+  if (row >= d.nrows) return;
+  const int w = d.c1 - d.c0;
+  const int dst = rank[(size_t)p * stride + row];
+  const cplx* s = d.Z + (size_t)(d.row0 + row) * d.ld + d.c0;
+  cplx* t = tmp + tmp_off[p] + (size_t)dst * w;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < w; c += gridDim.x * blockDim.x) t[c] = s[c];
+  if (blockIdx.x == 0 && threadIdx.x == 0) key_sorted[(size_t)p * stride + dst] = key[(size_t)p * stride + row];
+}
+
+__global__ void jac_scatter_back_kernel(const jac_pdesc* __restrict__ pd, const cplx* __restrict__ tmp,
+                                        const size_t* __restrict__ tmp_off) {
+  const int p = blockIdx.z;
+  const jac_pdesc d = pd[p];
+  const int row = blockIdx.y;
+  if (row >= d.nrows) return;
+  const int w = d.c1 - d.c0;
+  cplx* s = d.Z + (size_t)(d.row0 + row) * d.ld + d.c0;
+  const cplx* t = tmp + tmp_off[p] + (size_t)row * w;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < w; c += gridDim.x * blockDim.x) s[c] = t[c];
+}
+
+// out = conj(in)^T for square n x n blocks, batched through descriptors
+struct jac_tdesc {
+  const cplx* src; int lds; cplx* dst; int ldd; int n;
+};
+__global__ void jac_ctrans_kernel(const jac_tdesc* __restrict__ td, const int* __restrict__ active) {
+  __shared__ cplx tile[32][33];
+  const jac_tdesc d = td[blockIdx.z];
+  if (active && !active[blockIdx.z]) return;
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  if (bx >= d.n || by >= d.n) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    int r = by + j, c = bx + tx;
+    tile[j][tx] = (r < d.n && c < d.n) ? d.src[(size_t)r * d.lds + c] : make_double2(0.0, 0.0);
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int r = bx + j, c = by + tx;
+    if (r < d.n && c < d.n) {
+      cplx v = tile[tx][j];
+      d.dst[(size_t)r * d.ldd + c] = make_double2(v.x, -v.y);
+    }
+  }
+}
+
+// evals[p][i] = Re C[i][i]; also absfloor[p] = 8 eps max|diag| on first call
+__global__ void jac_diag_kernel(const jac_tdesc* __restrict__ td, double* __restrict__ evals, int stride) {
+  const jac_tdesc d = td[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < d.n) evals[(size_t)blockIdx.y * stride + i] = d.src[(size_t)i * d.lds + i].x;
+}
+
+__global__ void jac_absmax_kernel(const jac_tdesc* __restrict__ td, double* __restrict__ out, double factor) {
+  // one block per problem: max |C_ij| over the whole matrix, times factor
+  const jac_tdesc d = td[blockIdx.x];
+  __shared__ double red[4];
+  double m = 0.0;
+  for (size_t idx = threadIdx.x; idx < (size_t)d.n * d.n; idx += blockDim.x) {
+    int r = idx / d.n, c = idx % d.n;
+    cplx v = d.src[(size_t)r * d.lds + c];
+    m = fmax(m, fmax(fabs(v.x), fabs(v.y)));
+  }
+  m = dm_wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = factor * fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// round-robin tournament over nb (even) players; returns rounds x (nb/2) pairs
+void tournament(int nb, std::vector<std::vector<std::pair<int, int>>>& rounds) {
+  rounds.clear();
+  if (nb < 2) return;
+  std::vector<int> idx(nb);
+  for (int i = 0; i < nb; ++i) idx[i] = i;
+  for (int r = 0; r < nb - 1; ++r) {
+    std::vector<std::pair<int, int>> pr;
+    for (int i = 0; i < nb / 2; ++i) {
+      int a = idx[i], b = idx[nb - 1 - i];
+      pr.emplace_back(std::min(a, b), std::max(a, b));
+    }
+    rounds.push_back(pr);
+    int last = idx[nb - 1];
+    for (int i = nb - 1; i > 1; --i) idx[i] = idx[i - 1];
+    idx[1] = last;
+  }
+}
+
+constexpr size_t INNER_LDS = (size_t)2 * JP * GP * sizeof(cplx) + 32 * sizeof(double) + 32 * sizeof(cplx) +
+                             40 * sizeof(int) + 4 * sizeof(double) + 64;
+constexpr size_t APPLY_LDS = (size_t)2 * JP * QP * sizeof(double);
+
+bool g_attr_set = false;
+int set_attrs(dm_ctx* ctx) {
+  if (g_attr_set) return DM_OK;
+  DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(jac_inner_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)INNER_LDS));
+  DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(jac_inner_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)INNER_LDS));
+  DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(jac_apply_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)APPLY_LDS));
+  g_attr_set = true;
+  return DM_OK;
+}
+
+// Build the per-round item lists for a set of (possibly differently sized)
+// problems.  `make_item(prob, blockA, blockB_or_-1, slot)` fills one item.
+struct round_plan {
+  std::vector<jac_item> items;         // all rounds, concatenated
+  std::vector<int> round_begin;        // size nrounds + 1
+  int max_items_per_round = 0;
+};
+
+template <typename F>
+void plan_rounds(const std::vector<int>& nrows, F make_item, round_plan& plan) {
+  const int np = (int)nrows.size();
+  std::vector<std::vector<std::vector<std::pair<int, int>>>> sched(np);
+  int maxrounds = 0;
+  for (int p = 0; p < np; ++p) {
+    int nb = (nrows[p] + JB - 1) / JB;
+    if (nb <= 0) continue;
+    if (nb == 1) {
+      sched[p] = {{{0, -1}}};
+    } else {
+      int nbe = nb + (nb & 1);
+      tournament(nbe, sched[p]);
+      for (auto& rd : sched[p])
+        for (auto& pr : rd)
+          if (pr.second >= nb) pr.second = -1;  // phantom block
+    }
+    maxrounds = std::max(maxrounds, (int)sched[p].size());
+  }
+  plan.items.clear();
+  plan.round_begin.assign(1, 0);
+  plan.max_items_per_round = 0;
+  for (int r = 0; r < maxrounds; ++r) {
+    int slot = 0;
+    for (int p = 0; p < np; ++p) {
+      if (r >= (int)sched[p].size()) continue;
+      for (auto& pr : sched[p][r]) {
+        if (pr.second < 0 && sched[p].size() > 1) continue;  // bye: a lone block needs no work this round
+        plan.items.push_back(make_item(p, pr.first, pr.second, slot));
+        ++slot;
+      }
+    }
+    plan.max_items_per_round = std::max(plan.max_items_per_round, slot);
+    plan.round_begin.push_back((int)plan.items.size());
+  }
+}
+
+}  // namespace
+
+// ===========================================================================
+// one-sided driver
+// ===========================================================================
+int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double* sigma, int sigma_stride,
+                   int* sweeps_out) {
+  const int np = (int)probs.size();
+  if (sweeps_out) *sweeps_out = 0;
+  if (np == 0) return DM_OK;
+  DM_TRY(set_attrs(ctx));
+  const size_t mark = dm_ws_mark(ctx);
+
+  std::vector<int> nrows(np);
+  int maxrows = 0, maxcols = 0;
+  for (int p = 0; p < np; ++p) {
+    nrows[p] = probs[p].nrows;
+    maxrows = std::max(maxrows, nrows[p]);
+    maxcols = std::max(maxcols, probs[p].ncols);
+  }
+  DM_ARG(ctx, maxrows <= sigma_stride);
+
+  round_plan plan;
+  plan_rounds(nrows, [&](int p, int ba, int bb, int slot) {
+    const dm_jac_problem& P = probs[p];
+    jac_item it;
+    it.Z = P.Z; it.ld = P.ld;
+    it.ra = P.row0 + ba * JB; it.na = std::min(JB, P.nrows - ba * JB);
+    if (bb >= 0) { it.rb = P.row0 + bb * JB; it.nb = std::min(JB, P.nrows - bb * JB); }
+    else { it.rb = 0; it.nb = 0; }
+    it.c0 = 0; it.c1 = P.ncols; it.g0 = P.gc0; it.g1 = P.gc1;
+    it.prob = p; it.q = slot;
+    return it;
+  }, plan);
+
+  std::vector<jac_pdesc> pd(np);
+  std::vector<size_t> toff(np);
+  size_t ttot = 0;
+  for (int p = 0; p < np; ++p) {
+    pd[p] = jac_pdesc{probs[p].Z, probs[p].ld, probs[p].row0, probs[p].nrows, 0, probs[p].ncols, probs[p].gc0,
+                      probs[p].gc1};
+    toff[p] = ttot;
+    ttot += (size_t)probs[p].nrows * probs[p].ncols;
+  }
+
+  jac_item* d_items = dm_ws_upload(ctx, plan.items);
+  jac_pdesc* d_pd = dm_ws_upload(ctx, pd);
+  int* d_nrows = dm_ws_upload(ctx, nrows);
+  size_t* d_toff = dm_ws_upload(ctx, toff);
+  std::vector<int> active(np, 1);
+  int* d_active = dm_ws_upload(ctx, active);
+  unsigned long long* d_off = dm_ws_alloc_t<unsigned long long>(ctx, np);
+  const size_t nslots = (size_t)std::max(plan.max_items_per_round, 1);
+  cplx* d_G = dm_ws_alloc_t<cplx>(ctx, nslots * JP * JP);
+  cplx* d_Q = dm_ws_alloc_t<cplx>(ctx, nslots * JP * JP);
+  int* d_skip = dm_ws_alloc_t<int>(ctx, nslots);
+  int* d_rank = dm_ws_alloc_t<int>(ctx, (size_t)np * sigma_stride);
+  double* d_key = dm_ws_alloc_t<double>(ctx, (size_t)np * sigma_stride);
+  cplx* d_tmp = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(ttot, 1));
+  double* d_floor = dm_ws_alloc_t<double>(ctx, np);
+  if (!d_items || !d_pd || !d_nrows || !d_toff || !d_active || !d_off || !d_G || !d_Q || !d_skip || !d_rank ||
+      !d_key || !d_tmp || !d_floor)
+    return DM_ENOMEM;
+
+  // noise floor for Gram entries: (4 eps)^2 * (largest row norm)^2.  Rows that are pure
+  // rounding residue (rank-deficient inputs) can never be made mutually orthogonal to
+  // relative accuracy — there are more of them than dimensions left — so pairs of such
+  // rows are left alone, exactly the level at which LAPACK's backward error sits.
+  hipLaunchKernelGGL(jac_rownorm_kernel, dim3((maxrows + 3) / 4, np), dim3(256), 0, ctx->stream, d_pd, d_key,
+                     sigma_stride, maxrows);
+  {
+    const double e4 = 4.0 * 2.220446049250313e-16;
+    hipLaunchKernelGGL(jac_floor_kernel, dim3(np), dim3(256), 0, ctx->stream, d_key, sigma_stride, d_nrows,
+                       d_floor, e4 * e4);
+  }
+
+  const double tol_outer = 1e-13, tol_inner = 1e-15;
+  const int nrounds = (int)plan.round_begin.size() - 1;
+  const int chunks = (maxcols + APPLY_CHUNK - 1) / APPLY_CHUNK;
+  std::vector<unsigned long long> h_off(np);
+  int sweep = 0;
+  const int max_sweeps = 40;
+  bool any_pairs = false;
+  for (int p = 0; p < np; ++p) any_pairs |= nrows[p] > 1;
+  for (; any_pairs && sweep < max_sweeps; ++sweep) {
+    DM_HIP(ctx, hipMemsetAsync(d_off, 0, sizeof(unsigned long long) * np, ctx->stream));
+    for (int r = 0; r < nrounds; ++r) {
+      const int nb = plan.round_begin[r], ne = plan.round_begin[r + 1];
+      const int ni = ne - nb;
+      if (ni == 0) continue;
+      hipLaunchKernelGGL(jac_gram_kernel, dim3(ni), dim3(256), 0, ctx->stream, d_items + nb, d_active, d_G);
+      hipLaunchKernelGGL(jac_inner_kernel<false>, dim3(ni), dim3(256), INNER_LDS, ctx->stream, d_items + nb,
+                         d_active, (const double*)d_floor, d_G, d_Q, d_off, d_skip, tol_outer, tol_inner);
+      hipLaunchKernelGGL(jac_apply_kernel, dim3(ni, chunks), dim3(256), APPLY_LDS, ctx->stream, d_items + nb,
+                         d_active, d_skip, d_Q);
+    }
+    DM_HIP(ctx, hipGetLastError());
+    DM_TRY(dm_download(ctx, h_off.data(), d_off, sizeof(unsigned long long) * np));
+    bool any = false;
+    double dbg_max = 0.0;
+    for (int p = 0; p < np; ++p) {
+      double mo;
+      std::memcpy(&mo, &h_off[p], sizeof(double));
+      dbg_max = std::max(dbg_max, mo);
+      active[p] = (active[p] && mo > tol_outer) ? 1 : 0;
+      any |= active[p] != 0;
+    }
+    if (getenv("DM_DEBUG")) fprintf(stderr, "[jacobi_rows] sweep %d offmax %.3e\n", sweep, dbg_max);
+    if (!any) { ++sweep; break; }
+    DM_TRY(dm_upload(ctx, d_active, active.data(), sizeof(int) * np));
+  }
+  if (sweeps_out) *sweeps_out = sweep;
+
+  // sort rows by descending norm over the Gram columns
+  hipLaunchKernelGGL(jac_rownorm_kernel, dim3((maxrows + 3) / 4, np), dim3(256), 0, ctx->stream, d_pd, d_key,
+                     sigma_stride, maxrows);
+  hipLaunchKernelGGL(jac_rank_kernel, dim3((maxrows + 255) / 256, np), dim3(256), 0, ctx->stream, d_key,
+                     sigma_stride, d_nrows, d_rank, 1);
+  const int gx = std::max(1, std::min(8, (maxcols + 255) / 256));
+  hipLaunchKernelGGL(jac_gather_rows_kernel, dim3(gx, maxrows, np), dim3(256), 0, ctx->stream, d_pd, d_rank,
+                     sigma_stride, d_tmp, d_toff, d_key, sigma);
+  hipLaunchKernelGGL(jac_scatter_back_kernel, dim3(gx, maxrows, np), dim3(256), 0, ctx->stream, d_pd, d_tmp,
+                     d_toff);
+  DM_HIP(ctx, hipGetLastError());
+  DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  dm_ws_release(ctx, mark);
+  return DM_OK;
+}
+
+// ===========================================================================
+// two-sided (Hermitian) driver
+// ===========================================================================
+int dm_jacobi_herm(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, double* evals, int evals_stride,
+                   int* sweeps_out) {
+  const int np = (int)probs.size();
+  if (sweeps_out) *sweeps_out = 0;
+  if (np == 0) return DM_OK;
+  DM_TRY(set_attrs(ctx));
+  const size_t mark = dm_ws_mark(ctx);
+
+  std::vector<int> nrows(np);
+  int maxn = 0;
+  size_t ttot = 0;
+  std::vector<size_t> toff(np);
+  for (int p = 0; p < np; ++p) {
+    nrows[p] = probs[p].n;
+    maxn = std::max(maxn, probs[p].n);
+    toff[p] = ttot;
+    ttot += (size_t)probs[p].n * probs[p].n;
+  }
+  DM_ARG(ctx, maxn <= evals_stride);
+  cplx* d_T = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(ttot, 1));  // ping-pong partner of C
+  if (!d_T) return DM_ENOMEM;
+
+  // Items: for each round three lists share the Q slots —
+  //   (a) rows of the current C buffer, (b) rows of W, (c) rows of the transposed buffer.
+  // The matrix alternates between C (even rounds) and T (odd rounds): round r
+  // reads cur, row-updates it in place, transposes into oth, row-updates oth;
+  // oth then holds Q^H C Q and becomes cur.
+  round_plan planC, planT, planW;
+  auto mk = [&](int which) {
+    return [&, which](int p, int ba, int bb, int slot) {
+      const dm_jac_herm_problem& P = probs[p];
+      jac_item it;
+      if (which == 0) { it.Z = P.C; it.ld = P.ldc; }
+      else if (which == 1) { it.Z = d_T + toff[p]; it.ld = P.n; }
+      else { it.Z = P.W; it.ld = P.ldw; }
+      it.ra = ba * JB; it.na = std::min(JB, P.n - ba * JB);
+      if (bb >= 0) { it.rb = bb * JB; it.nb = std::min(JB, P.n - bb * JB); } else { it.rb = 0; it.nb = 0; }
+      it.c0 = 0; it.c1 = P.n; it.g0 = 0; it.g1 = P.n;
+      it.prob = p; it.q = slot;
+      return it;
+    };
+  };
+  plan_rounds(nrows, mk(0), planC);
+  plan_rounds(nrows, mk(1), planT);
+  plan_rounds(nrows, mk(2), planW);
+
+  std::vector<jac_tdesc> tdC(np), tdT(np);
+  for (int p = 0; p < np; ++p) {
+    tdC[p] = jac_tdesc{probs[p].C, probs[p].ldc, d_T + toff[p], probs[p].n, probs[p].n};
+    tdT[p] = jac_tdesc{d_T + toff[p], probs[p].n, probs[p].C, probs[p].ldc, probs[p].n};
+  }
+
+  jac_item* d_iC = dm_ws_upload(ctx, planC.items);
+  jac_item* d_iT = dm_ws_upload(ctx, planT.items);
+  jac_item* d_iW = dm_ws_upload(ctx, planW.items);
+  jac_tdesc* d_tdC = dm_ws_upload(ctx, tdC);
+  jac_tdesc* d_tdT = dm_ws_upload(ctx, tdT);
+  std::vector<int> active(np, 1);
+  int* d_active = dm_ws_upload(ctx, active);
+  unsigned long long* d_off = dm_ws_alloc_t<unsigned long long>(ctx, np);
+  double* d_floor = dm_ws_alloc_t<double>(ctx, np);
+  const size_t nslots = (size_t)std::max(planC.max_items_per_round, 1);
+  cplx* d_Q = dm_ws_alloc_t<cplx>(ctx, nslots * JP * JP);
+  int* d_skip = dm_ws_alloc_t<int>(ctx, nslots);
+  if (!d_iC || !d_iT || !d_iW || !d_tdC || !d_tdT || !d_active || !d_off || !d_floor || !d_Q || !d_skip)
+    return DM_ENOMEM;
+
+  // absolute rotation floor: 32 eps * max|C_ij| (a backward-stable solver cannot
+  // resolve off-diagonals below this; kltransform's LAPACK path is no different)
+  hipLaunchKernelGGL(jac_absmax_kernel, dim3(np), dim3(256), 0, ctx->stream, d_tdC, d_floor,
+                     32.0 * 2.220446049250313e-16);
+
+  const double tol_outer = 1e-13, tol_inner = 1e-15;
+  const int nrounds = (int)planC.round_begin.size() - 1;
+  const int chunks = (maxn + APPLY_CHUNK - 1) / APPLY_CHUNK;
+  const int tb = (maxn + 31) / 32;
+  std::vector<unsigned long long> h_off(np);
+  int sweep = 0;
+  const int max_sweeps = 40;
+  int cur = 0;  // 0: matrix lives in C, 1: in T
+  bool any_pairs = false;
+  for (int p = 0; p < np; ++p) any_pairs |= nrows[p] > 1;
+  for (; any_pairs && sweep < max_sweeps; ++sweep) {
+    DM_HIP(ctx, hipMemsetAsync(d_off, 0, sizeof(unsigned long long) * np, ctx->stream));
+    for (int r = 0; r < nrounds; ++r) {
+      const int nb = planC.round_begin[r], ne = planC.round_begin[r + 1];
+      const int ni = ne - nb;
+      if (ni == 0) continue;
+      jac_item* icur = (cur == 0 ? d_iC : d_iT) + nb;
+      jac_item* ioth = (cur == 0 ? d_iT : d_iC) + nb;
+      hipLaunchKernelGGL(jac_inner_kernel<true>, dim3(ni), dim3(256), INNER_LDS, ctx->stream, icur, d_active,
+                         d_floor, (const cplx*)nullptr, d_Q, d_off, d_skip, tol_outer, tol_inner);
+      hipLaunchKernelGGL(jac_apply_kernel, dim3(ni, chunks), dim3(256), APPLY_LDS, ctx->stream, icur, d_active,
+                         d_skip, d_Q);
+      hipLaunchKernelGGL(jac_apply_kernel, dim3(ni, chunks), dim3(256), APPLY_LDS, ctx->stream, d_iW + nb,
+                         d_active, d_skip, d_Q);
+      hipLaunchKernelGGL(jac_ctrans_kernel, dim3(tb, tb, np), dim3(256), 0, ctx->stream,
+                         cur == 0 ? d_tdC : d_tdT, d_active);
+      hipLaunchKernelGGL(jac_apply_kernel, dim3(ni, chunks), dim3(256), APPLY_LDS, ctx->stream, ioth, d_active,
+                         d_skip, d_Q);
+      cur ^= 1;
+    }
+    DM_HIP(ctx, hipGetLastError());
+    DM_TRY(dm_download(ctx, h_off.data(), d_off, sizeof(unsigned long long) * np));
+    bool any = false;
+    std::vector<int> newly_done;
+    double dbg_max = 0.0;
+    for (int p = 0; p < np; ++p) {
+      double mo;
+      std::memcpy(&mo, &h_off[p], sizeof(double));
+      dbg_max = std::max(dbg_max, mo);
+      int was = active[p];
+      active[p] = (was && mo > tol_outer) ? 1 : 0;
+      any |= active[p] != 0;
+      if (was && !active[p] && cur == 1) newly_done.push_back(p);
+    }
+    if (getenv("DM_DEBUG")) fprintf(stderr, "[jacobi_herm] sweep %d offmax %.3e\n", sweep, dbg_max);
+    // a problem that converged while its matrix lives in T: bring it home to C
+    // (the transpose of a Hermitian matrix's conjugate is itself)
+    if (!newly_done.empty()) {
+      std::vector<int> only(np, 0);
+      for (int p : newly_done) only[p] = 1;
+      int* d_only = dm_ws_upload(ctx, only);
+      if (!d_only) return DM_ENOMEM;
+      hipLaunchKernelGGL(jac_ctrans_kernel, dim3(tb, tb, np), dim3(256), 0, ctx->stream, d_tdT, d_only);
+    }
+    if (!any) { ++sweep; break; }
+    DM_TRY(dm_upload(ctx, d_active, active.data(), sizeof(int) * np));
+  }
+  // problems still active at the sweep cap and living in T: copy home as well
+  if (cur == 1) {
+    bool any_left = false;
+    for (int p = 0; p < np; ++p) any_left |= active[p] != 0;
+    if (any_left) {
+      int* d_act2 = dm_ws_upload(ctx, active);
+      if (!d_act2) return DM_ENOMEM;
+      hipLaunchKernelGGL(jac_ctrans_kernel, dim3(tb, tb, np), dim3(256), 0, ctx->stream, d_tdT, d_act2);
+    }
+  }
+  if (sweeps_out) *sweeps_out = sweep;
+  hipLaunchKernelGGL(jac_diag_kernel, dim3((maxn + 255) / 256, np), dim3(256), 0, ctx->stream, d_tdC, evals,
+                     evals_stride);
+  DM_HIP(ctx, hipGetLastError());
+  DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  dm_ws_release(ctx, mark);
+  return DM_OK;
+}
+
+// ===========================================================================
+// sort the rows of a batch of matrices by a per-row key (device), stable
+// ===========================================================================
+int dm_sort_rows_by_key(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double* key, int key_stride,
+                        bool descending) {
+  const int np = (int)probs.size();
+  if (np == 0) return DM_OK;
+  const size_t mark = dm_ws_mark(ctx);
+  std::vector<jac_pdesc> pd(np);
+  std::vector<size_t> toff(np);
+  std::vector<int> nrows(np);
+  size_t ttot = 0;
+  int maxrows = 0, maxcols = 0;
+  for (int p = 0; p < np; ++p) {
+    pd[p] = jac_pdesc{probs[p].Z, probs[p].ld, probs[p].row0, probs[p].nrows, 0, probs[p].ncols, 0, 0};
+    toff[p] = ttot;
+    ttot += (size_t)probs[p].nrows * probs[p].ncols;
+    nrows[p] = probs[p].nrows;
+    maxrows = std::max(maxrows, probs[p].nrows);
+    maxcols = std::max(maxcols, probs[p].ncols);
+  }
+  if (maxrows == 0) return DM_OK;
+  jac_pdesc* d_pd = dm_ws_upload(ctx, pd);
+  size_t* d_toff = dm_ws_upload(ctx, toff);
+  int* d_nrows = dm_ws_upload(ctx, nrows);
+  int* d_rank = dm_ws_alloc_t<int>(ctx, (size_t)np * key_stride);
+  double* d_ks = dm_ws_alloc_t<double>(ctx, (size_t)np * key_stride);
+  cplx* d_tmp = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(ttot, 1));
+  if (!d_pd || !d_toff || !d_nrows || !d_rank || !d_ks || !d_tmp) return DM_ENOMEM;
+  hipLaunchKernelGGL(jac_rank_kernel, dim3((maxrows + 255) / 256, np), dim3(256), 0, ctx->stream, key, key_stride,
+                     d_nrows, d_rank, descending ? 1 : 0);
+  const int gx = std::max(1, std::min(8, (maxcols + 255) / 256));
+  hipLaunchKernelGGL(jac_gather_rows_kernel, dim3(gx, maxrows, np), dim3(256), 0, ctx->stream, d_pd, d_rank,
+                     key_stride, d_tmp, d_toff, key, d_ks);
+  hipLaunchKernelGGL(jac_scatter_back_kernel, dim3(gx, maxrows, np), dim3(256), 0, ctx->stream, d_pd, d_tmp, d_toff);
+  // sorted keys back into `key` (only the first nrows entries of each problem)
+  for (int p = 0; p < np; ++p)
+    if (nrows[p] > 0)
+      DM_HIP(ctx, hipMemcpyAsync(key + (size_t)p * key_stride, d_ks + (size_t)p * key_stride,
+                                 sizeof(double) * nrows[p], hipMemcpyDeviceToDevice, ctx->stream));
+  DM_HIP(ctx, hipGetLastError());
+  dm_ws_release(ctx, mark);
+  return DM_OK;
+}

@@ -1,0 +1,112 @@
+// dm_kernels.h — internal (non-ABI) interfaces between the translation units of
+// libdriftmi.  All launches go to ctx->stream; nothing here synchronises unless
+// it says so.
+#pragma once
+
+#include "dm_common.h"
+
+// ---------------------------------------------------------------------------
+// grouped ZGEMM (dm_gemm.hip)
+// ---------------------------------------------------------------------------
+enum {
+  DM_GEMM_CONJ_A = 1,  // conjugate the elements of A as they are read
+  DM_GEMM_CONJ_B = 2,  // conjugate the elements of B as they are read
+  DM_GEMM_B_REAL = 4,  // B points at real doubles (complex x real product)
+  DM_GEMM_LOWER = 8,   // only compute 64x64 tiles on or below the block diagonal
+};
+
+struct dm_gemm_desc {
+  const void* A;         // cplx, viewed as (M x K) through (rsA, csA)
+  const void* B;         // cplx (or double with DM_GEMM_B_REAL), viewed as (K x N) through (rsB, csB)
+  void* C;               // cplx, row-major, leading dimension ldc
+  const double* kscale;  // optional real weights over K (applied to A), or nullptr
+  int M, N, K;
+  int rsA, csA, rsB, csB, ldc;
+  int flags;
+  double alpha, beta;
+};
+
+struct dm_gemm_tile {
+  int desc, tm, tn;
+};
+
+int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs);
+
+static inline dm_gemm_desc dm_gemm_make(const cplx* A, int rsA, int csA, bool conjA, const void* B, int rsB, int csB,
+                                        bool conjB, cplx* C, int ldc, int M, int N, int K, double alpha = 1.0,
+                                        double beta = 0.0, const double* kscale = nullptr, int extra_flags = 0) {
+  dm_gemm_desc d;
+  d.A = A; d.B = B; d.C = C; d.kscale = kscale;
+  d.M = M; d.N = N; d.K = K;
+  d.rsA = rsA; d.csA = csA; d.rsB = rsB; d.csB = csB; d.ldc = ldc;
+  d.flags = (conjA ? DM_GEMM_CONJ_A : 0) | (conjB ? DM_GEMM_CONJ_B : 0) | extra_flags;
+  d.alpha = alpha; d.beta = beta;
+  return d;
+}
+
+// ---------------------------------------------------------------------------
+// block Jacobi engines (dm_jacobi.hip)
+// ---------------------------------------------------------------------------
+// One "problem" = one matrix whose rows [row0, row0+nrows) are orthogonalised
+// (one-sided) with respect to the columns [gc0, gc1); the unitary row mixing is
+// applied to all ncols columns, so passengers (accumulated U^H, projected beams)
+// ride along.  For the two-sided (Hermitian) mode the matrix is nrows x nrows in
+// columns [gc0, gc0+nrows) and both rows and columns are transformed.
+struct dm_jac_problem {
+  cplx* Z;        // base of the row-major matrix
+  int ld;         // leading dimension (elements)
+  int row0;       // first participating row
+  int nrows;      // participating rows
+  int ncols;      // columns carried along by the row mixing
+  int gc0, gc1;   // Gram column range (one-sided) / Hermitian block origin (two-sided)
+};
+
+// Orthogonalise rows (one-sided).  On return sigma[p][0..nrows) holds the row
+// norms over the Gram columns, rows sorted by descending norm (rows physically
+// permuted).  `sigma` is a device array with `sigma_stride` doubles per problem.
+// Synchronises the stream (sweep control needs the convergence flags).
+int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double* sigma, int sigma_stride,
+                   int* sweeps_out = nullptr);
+
+// Diagonalise Hermitian matrices (two-sided): C <- W C W^H (diagonal), with the
+// unitary W (rows) accumulated into `W` (nrows x nrows, row-major, ld = ldw),
+// which must be initialised to the identity by the caller (or any unitary to
+// compose with).  evals[p][0..n) = diagonal, NOT sorted.  Synchronises.
+struct dm_jac_herm_problem {
+  cplx* C; int ldc;
+  cplx* W; int ldw;
+  int n;
+};
+int dm_jacobi_herm(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, double* evals, int evals_stride,
+                   int* sweeps_out = nullptr);
+
+// Permute the rows [row0, row0+nrows) x [0, ncols) of each problem so that the
+// device keys (key_stride doubles per problem) end up sorted; keys are sorted too.
+int dm_sort_rows_by_key(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double* key, int key_stride,
+                        bool descending);
+
+// ---------------------------------------------------------------------------
+// batched Cholesky / triangular solves (dm_chol.hip)
+// ---------------------------------------------------------------------------
+struct dm_mat {
+  cplx* p; int ld; int n;
+};
+// In-place lower Cholesky of Hermitian matrices (lower triangle referenced;
+// strictly-upper part is zeroed on exit).  info[i] (device ints) = 0 or the
+// 1-based order of the first non-positive leading minor, as LAPACK zpotrf.
+int dm_potrf_batched(dm_ctx* ctx, const std::vector<dm_mat>& mats, int* info_dev);
+// Solve L X = B (conjtrans=false) or L^H X = B (conjtrans=true) in place in B
+// (n x nrhs, row-major, ldb).
+struct dm_trsm_problem {
+  const cplx* L; int ldl; int n;
+  cplx* B; int ldb; int nrhs;
+};
+int dm_trsm_left_lower_batched(dm_ctx* ctx, const std::vector<dm_trsm_problem>& probs, bool conjtrans);
+
+// ---------------------------------------------------------------------------
+// small utility kernels (dm_util.hip)
+// ---------------------------------------------------------------------------
+int dm_conj_transpose(dm_ctx* ctx, const cplx* src, int lds, cplx* dst, int ldd, int rows, int cols);
+int dm_set_identity(dm_ctx* ctx, cplx* a, int ld, int n);
+int dm_hermitize(dm_ctx* ctx, cplx* a, int ld, int n);  // a <- (a + a^H)/2, real diagonal
+int dm_fill_zero(dm_ctx* ctx, void* p, size_t bytes);

@@ -1,0 +1,359 @@
+// dm_kl.hip — covariance projection into the SVD basis and the generalised
+// Hermitian eigenproblem of the KL transform, batched over m-blocks.
+//
+//   dm_project_cov   drift/core/beamtransfer.py:1135-1188  project_matrix_sky_to_svd
+//   dm_project_diag  drift/core/beamtransfer.py:1190-1231  project_matrix_diagonal_telescope_to_svd
+//   dm_regularise    drift/core/kltransform.py:288-290     diag += reg * max(N)
+//   dm_eigh_gen      drift/core/kltransform.py:55-121      eigh_gen (zhegvd + non-PD rescue)
+//
+// The projections are grouped ZGEMMs on the fp64 matrix cores: one 64x64-tiled
+// launch per non-zero polarisation pair covers every (f, f') block of every m.
+// The reference multiplies all P^2 pairs including the all-zero ones
+// (beamtransfer.py:1168-1169); the caller passes a mask of the non-zero pairs.
+#include "dm_common.h"
+#include "dm_kernels.h"
+#include "../../include/driftmi.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+struct blk_desc {
+  cplx* a; int n;
+};
+
+// numpy's max of a complex array is lexicographic in (re, im); one block per matrix
+__global__ void lexmax_adddiag_kernel(const blk_desc* __restrict__ bd, double reg) {
+  const blk_desc d = bd[blockIdx.x];
+  if (d.n == 0) return;
+  __shared__ double sre[256], sim[256];
+  double bre = -INFINITY, bim = -INFINITY;
+  const size_t tot = (size_t)d.n * d.n;
+  for (size_t i = threadIdx.x; i < tot; i += blockDim.x) {
+    cplx v = d.a[i];
+    if (v.x > bre || (v.x == bre && v.y > bim)) { bre = v.x; bim = v.y; }
+  }
+  sre[threadIdx.x] = bre;
+  sim[threadIdx.x] = bim;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      double ore = sre[threadIdx.x + s], oim = sim[threadIdx.x + s];
+      if (ore > sre[threadIdx.x] || (ore == sre[threadIdx.x] && oim > sim[threadIdx.x])) {
+        sre[threadIdx.x] = ore;
+        sim[threadIdx.x] = oim;
+      }
+    }
+    __syncthreads();
+  }
+  const double are = reg * sre[0], aim = reg * sim[0];
+  for (int i = threadIdx.x; i < d.n; i += blockDim.x) {
+    cplx v = d.a[(size_t)i * d.n + i];
+    d.a[(size_t)i * d.n + i] = make_double2(v.x + are, v.y + aim);
+  }
+}
+
+// flag[b] = 1 if every element of block b is exactly zero
+__global__ void allzero_kernel(const blk_desc* __restrict__ bd, int* __restrict__ flag) {
+  const blk_desc d = bd[blockIdx.x];
+  __shared__ int nz;
+  if (threadIdx.x == 0) nz = 0;
+  __syncthreads();
+  const size_t tot = (size_t)d.n * d.n;
+  int mine = 0;
+  for (size_t i = threadIdx.x; i < tot; i += blockDim.x) {
+    cplx v = d.a[i];
+    if (v.x != 0.0 || v.y != 0.0) mine = 1;
+  }
+  if (mine) nz = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) flag[blockIdx.x] = nz ? 0 : 1;
+}
+
+__global__ void add_diag_kernel(const blk_desc* __restrict__ bd, const double* __restrict__ val) {
+  const blk_desc d = bd[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < d.n) d.a[(size_t)i * d.n + i].x += val[blockIdx.y];
+}
+
+__global__ void copy_kernel(cplx* __restrict__ dst, const cplx* __restrict__ src, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
+int copy_async(dm_ctx* ctx, cplx* dst, const cplx* src, size_t n) {
+  if (n == 0) return DM_OK;
+  DM_HIP(ctx, hipMemcpyAsync(dst, src, n * sizeof(cplx), hipMemcpyDeviceToDevice, ctx->stream));
+  return DM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// out[b] (ndof_b x ndof_b, blocks laid out back to back) += sum over the masked pol pairs of
+//   (B[f,:n_f,pi,:] * cl[pi,pj,f,f',:]) B[f',:n_f',pj,:]^H
+int dm_project_cov(dm_ctx* ctx, int nblk, int F, int K, int P, int L, const void* beam_svd_dev,
+                   const int* svnum_host, const int* l0_host, const double* cl_pfl_dev, int npol,
+                   const int* polmask_host, void* out_dev, const int64_t* out_off_host, int zero_first) {
+  if (!ctx) return DM_EARG;
+  DM_ARG(ctx, nblk >= 0 && F > 0 && K > 0 && P > 0 && L > 0 && beam_svd_dev && svnum_host && cl_pfl_dev &&
+                  out_dev && out_off_host && npol >= 1 && npol <= P);
+  const size_t mark = dm_ws_mark(ctx);
+  const cplx* beam = reinterpret_cast<const cplx*>(beam_svd_dev);
+  cplx* out = reinterpret_cast<cplx*>(out_dev);
+  const int PL = P * L;
+  std::vector<std::vector<int>> bounds(nblk, std::vector<int>(F + 1, 0));
+  for (int b = 0; b < nblk; ++b) {
+    for (int f = 0; f < F; ++f) bounds[b][f + 1] = bounds[b][f] + svnum_host[b * F + f];
+    if (zero_first) {
+      const size_t n = bounds[b][F];
+      DM_TRY(dm_fill_zero(ctx, out + out_off_host[b], sizeof(cplx) * n * n));
+    }
+  }
+  for (int pi = 0; pi < npol; ++pi)
+    for (int pj = 0; pj < npol; ++pj) {
+      if (polmask_host && !polmask_host[pi * P + pj]) continue;
+      std::vector<dm_gemm_desc> g;
+      for (int b = 0; b < nblk; ++b) {
+        const int ndof = bounds[b][F];
+        if (ndof == 0) continue;
+        const int l0 = l0_host ? std::min(std::max(l0_host[b], 0), L) : 0;
+        if (L - l0 <= 0) continue;
+        cplx* ob = out + out_off_host[b];
+        for (int fi = 0; fi < F; ++fi) {
+          const int ni = svnum_host[b * F + fi];
+          if (ni == 0) continue;
+          const cplx* Ai = beam + (((size_t)b * F + fi) * K) * PL + (size_t)pi * L + l0;
+          for (int fj = 0; fj < F; ++fj) {
+            const int nj = svnum_host[b * F + fj];
+            if (nj == 0) continue;
+            const cplx* Bj = beam + (((size_t)b * F + fj) * K) * PL + (size_t)pj * L + l0;
+            const double* cl = cl_pfl_dev + ((((size_t)pi * P + pj) * F + fi) * F + fj) * L + l0;
+            g.push_back(dm_gemm_make(Ai, PL, 1, false, Bj, 1, PL, true,
+                                     ob + (size_t)bounds[b][fi] * ndof + bounds[b][fj], ndof, ni, nj, L - l0, 1.0,
+                                     1.0, cl));
+          }
+        }
+      }
+      DM_TRY(dm_gemm_grouped_launch(ctx, g));
+    }
+  dm_ws_release(ctx, mark);
+  return DM_OK;
+}
+
+// out[b] block-diagonal: block f (+)= alpha * (U[f,:n_f,:] * d[f,:]) U[f,:n_f,:]^H
+int dm_project_diag(dm_ctx* ctx, int nblk, int F, int K, int T, const void* beam_ut_dev, const int* svnum_host,
+                    const double* dmat_dev, double alpha, void* out_dev, const int64_t* out_off_host,
+                    int accumulate) {
+  if (!ctx) return DM_EARG;
+  DM_ARG(ctx, nblk >= 0 && F > 0 && K > 0 && T > 0 && beam_ut_dev && svnum_host && dmat_dev && out_dev &&
+                  out_off_host);
+  const size_t mark = dm_ws_mark(ctx);
+  const cplx* ut = reinterpret_cast<const cplx*>(beam_ut_dev);
+  cplx* out = reinterpret_cast<cplx*>(out_dev);
+  std::vector<dm_gemm_desc> g;
+  for (int b = 0; b < nblk; ++b) {
+    int ndof = 0;
+    for (int f = 0; f < F; ++f) ndof += svnum_host[b * F + f];
+    if (!accumulate) DM_TRY(dm_fill_zero(ctx, out + out_off_host[b], sizeof(cplx) * (size_t)ndof * ndof));
+    int off = 0;
+    for (int f = 0; f < F; ++f) {
+      const int n = svnum_host[b * F + f];
+      if (n == 0) continue;
+      const cplx* U = ut + (((size_t)b * F + f) * K) * T;
+      g.push_back(dm_gemm_make(U, T, 1, false, U, 1, T, true, out + out_off_host[b] + (size_t)off * ndof + off, ndof,
+                               n, n, T, alpha, accumulate ? 1.0 : 0.0, dmat_dev + (size_t)f * T));
+      off += n;
+    }
+  }
+  int rc = dm_gemm_grouped_launch(ctx, g);
+  dm_ws_release(ctx, mark);
+  return rc;
+}
+
+// diag(N_b) += reg * max(N_b)  with numpy's complex ordering (kltransform.py:289-290)
+int dm_regularise(dm_ctx* ctx, int nblk, const int* n_host, void* mats_dev, const int64_t* off_host, double reg) {
+  if (!ctx) return DM_EARG;
+  DM_ARG(ctx, nblk >= 0 && n_host && mats_dev && off_host);
+  if (nblk == 0) return DM_OK;
+  const size_t mark = dm_ws_mark(ctx);
+  std::vector<blk_desc> bd(nblk);
+  for (int b = 0; b < nblk; ++b) bd[b] = blk_desc{reinterpret_cast<cplx*>(mats_dev) + off_host[b], n_host[b]};
+  blk_desc* d = dm_ws_upload(ctx, bd);
+  if (!d) return DM_ENOMEM;
+  hipLaunchKernelGGL(lexmax_adddiag_kernel, dim3(nblk), dim3(256), 0, ctx->stream, d, reg);
+  DM_HIP(ctx, hipGetLastError());
+  dm_ws_release(ctx, mark);
+  return DM_OK;
+}
+
+// Generalised Hermitian-definite eigenproblem A v = lambda B v for a batch of pencils.
+// A and B are destroyed.  evals (ascending) at evals_dev + evoff[b]; evecs at
+// evecs_dev + off[b] as an (n x n) row-major matrix whose ROWS are the modes, i.e.
+// the reference's `evecs.T.conj()` (kltransform.py:345).  add_const_host[b] is the
+// diagonal shift applied to B by the non-positive-definite rescue (0 normally).
+// Synchronises.
+int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_dev, const int64_t* off_host,
+                double* evals_dev, const int64_t* evoff_host, void* evecs_dev, double* add_const_host,
+                int* sweeps_host) {
+  if (!ctx) return DM_EARG;
+  DM_ARG(ctx, nblk >= 0 && n_host && A_dev && B_dev && off_host && evals_dev && evoff_host && evecs_dev &&
+                  add_const_host);
+  if (sweeps_host) *sweeps_host = 0;
+  if (nblk == 0) return DM_OK;
+  const size_t mark = dm_ws_mark(ctx);
+  cplx* A = reinterpret_cast<cplx*>(A_dev);
+  cplx* B = reinterpret_cast<cplx*>(B_dev);
+  cplx* E = reinterpret_cast<cplx*>(evecs_dev);
+
+  size_t tot = 0;
+  int maxn = 0;
+  for (int b = 0; b < nblk; ++b) {
+    tot += (size_t)n_host[b] * n_host[b];
+    maxn = std::max(maxn, n_host[b]);
+    add_const_host[b] = 0.0;
+  }
+  // local offsets (dense, back to back) for the scratch copies
+  std::vector<size_t> loff(nblk);
+  {
+    size_t o = 0;
+    for (int b = 0; b < nblk; ++b) { loff[b] = o; o += (size_t)n_host[b] * n_host[b]; }
+  }
+  cplx* Lw = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(tot, 1));   // Cholesky factors
+  cplx* Tw = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(tot, 1));   // transposes / C
+  cplx* Ww = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(tot, 1));   // accumulated unitary
+  double* evw = dm_ws_alloc_t<double>(ctx, (size_t)nblk * std::max(maxn, 1));
+  int* info_dev = dm_ws_alloc_t<int>(ctx, nblk);
+  int* zflag_dev = dm_ws_alloc_t<int>(ctx, nblk);
+  if (!Lw || !Tw || !Ww || !evw || !info_dev || !zflag_dev) return DM_ENOMEM;
+
+  // ---- all-zero shortcut (kltransform.py:81-85)
+  std::vector<blk_desc> bdA(nblk);
+  for (int b = 0; b < nblk; ++b) bdA[b] = blk_desc{A + off_host[b], n_host[b]};
+  blk_desc* d_bdA = dm_ws_upload(ctx, bdA);
+  if (!d_bdA) return DM_ENOMEM;
+  hipLaunchKernelGGL(allzero_kernel, dim3(nblk), dim3(256), 0, ctx->stream, d_bdA, zflag_dev);
+  std::vector<int> zflag(nblk);
+  DM_TRY(dm_download(ctx, zflag.data(), zflag_dev, sizeof(int) * nblk));
+
+  std::vector<int> work;  // blocks that go through the solver
+  for (int b = 0; b < nblk; ++b) {
+    if (n_host[b] == 0) continue;
+    if (zflag[b]) {
+      DM_TRY(dm_fill_zero(ctx, evals_dev + evoff_host[b], sizeof(double) * n_host[b]));
+      DM_TRY(dm_set_identity(ctx, E + off_host[b], n_host[b], n_host[b]));
+    } else {
+      work.push_back(b);
+    }
+  }
+
+  // ---- Cholesky of B (on a copy, the rescue needs B itself)
+  auto factor = [&](const std::vector<int>& blks, std::vector<int>& info) -> int {
+    std::vector<dm_mat> mats;
+    for (int b : blks) {
+      DM_TRY(copy_async(ctx, Lw + loff[b], B + off_host[b], (size_t)n_host[b] * n_host[b]));
+      mats.push_back(dm_mat{Lw + loff[b], n_host[b], n_host[b]});
+    }
+    DM_TRY(dm_potrf_batched(ctx, mats, info_dev));
+    info.resize(blks.size());
+    if (!blks.empty()) DM_TRY(dm_download(ctx, info.data(), info_dev, sizeof(int) * blks.size()));
+    return DM_OK;
+  };
+  std::vector<int> info;
+  DM_TRY(factor(work, info));
+  std::vector<int> bad;
+  for (size_t i = 0; i < work.size(); ++i)
+    if (info[i] != 0) bad.push_back(work[i]);
+  if (!bad.empty()) {
+    // rescue (kltransform.py:101-111): add 1e-15 ev_max - 2 ev_min + 1e-60 to diag(B)
+    std::vector<dm_jac_herm_problem> hp;
+    for (int b : bad) {
+      DM_TRY(copy_async(ctx, Tw + loff[b], B + off_host[b], (size_t)n_host[b] * n_host[b]));
+      DM_TRY(dm_hermitize(ctx, Tw + loff[b], n_host[b], n_host[b]));
+      DM_TRY(dm_set_identity(ctx, Ww + loff[b], n_host[b], n_host[b]));
+      hp.push_back(dm_jac_herm_problem{Tw + loff[b], n_host[b], Ww + loff[b], n_host[b], n_host[b]});
+    }
+    DM_TRY(dm_jacobi_herm(ctx, hp, evw, std::max(maxn, 1), nullptr));
+    std::vector<double> hev((size_t)bad.size() * std::max(maxn, 1));
+    DM_TRY(dm_download(ctx, hev.data(), evw, sizeof(double) * hev.size()));
+    std::vector<double> shifts(nblk, 0.0);
+    for (size_t i = 0; i < bad.size(); ++i) {
+      const int b = bad[i];
+      const double* ev = &hev[i * std::max(maxn, 1)];
+      double mn = ev[0], mx = ev[0];
+      for (int k = 1; k < n_host[b]; ++k) { mn = std::min(mn, ev[k]); mx = std::max(mx, ev[k]); }
+      add_const_host[b] = 1e-15 * mx - 2.0 * mn + 1e-60;
+      shifts[b] = add_const_host[b];
+    }
+    std::vector<blk_desc> bdB(bad.size());
+    std::vector<double> sh(bad.size());
+    for (size_t i = 0; i < bad.size(); ++i) {
+      bdB[i] = blk_desc{B + off_host[bad[i]], n_host[bad[i]]};
+      sh[i] = shifts[bad[i]];
+    }
+    blk_desc* d_bdB = dm_ws_upload(ctx, bdB);
+    double* d_sh = dm_ws_upload(ctx, sh);
+    if (!d_bdB || !d_sh) return DM_ENOMEM;
+    hipLaunchKernelGGL(add_diag_kernel, dim3((maxn + 255) / 256, (unsigned)bad.size()), dim3(256), 0, ctx->stream,
+                       d_bdB, d_sh);
+    std::vector<int> info2;
+    DM_TRY(factor(bad, info2));
+    for (size_t i = 0; i < bad.size(); ++i)
+      if (info2[i] != 0) {
+        ctx->err = "dm_eigh_gen: B is not positive definite even after the diagonal rescue";
+        dm_ws_release(ctx, mark);
+        return info2[i];  // > 0: LAPACK-style numerical failure
+      }
+  }
+
+  // ---- C = L^-1 A L^-H
+  {
+    std::vector<dm_trsm_problem> t1, t2;
+    for (int b : work) t1.push_back(dm_trsm_problem{Lw + loff[b], n_host[b], n_host[b], A + off_host[b], n_host[b], n_host[b]});
+    DM_TRY(dm_trsm_left_lower_batched(ctx, t1, false));  // X = L^-1 A
+    for (int b : work) {
+      DM_TRY(dm_conj_transpose(ctx, A + off_host[b], n_host[b], Tw + loff[b], n_host[b], n_host[b], n_host[b]));
+      t2.push_back(dm_trsm_problem{Lw + loff[b], n_host[b], n_host[b], Tw + loff[b], n_host[b], n_host[b]});
+    }
+    DM_TRY(dm_trsm_left_lower_batched(ctx, t2, false));  // Y = L^-1 X^H = C^H = C
+    for (int b : work) DM_TRY(dm_hermitize(ctx, Tw + loff[b], n_host[b], n_host[b]));
+  }
+
+  // ---- Hermitian eigendecomposition C = W^H diag(ev) W
+  {
+    std::vector<dm_jac_herm_problem> hp;
+    for (int b : work) {
+      DM_TRY(dm_set_identity(ctx, Ww + loff[b], n_host[b], n_host[b]));
+      hp.push_back(dm_jac_herm_problem{Tw + loff[b], n_host[b], Ww + loff[b], n_host[b], n_host[b]});
+    }
+    DM_TRY(dm_jacobi_herm(ctx, hp, evw, std::max(maxn, 1), sweeps_host));
+    // ascending order (LAPACK convention), rows of W follow
+    std::vector<dm_jac_problem> sp;
+    for (int b : work) sp.push_back(dm_jac_problem{Ww + loff[b], n_host[b], 0, n_host[b], n_host[b], 0, 0});
+    DM_TRY(dm_sort_rows_by_key(ctx, sp, evw, std::max(maxn, 1), false));
+    for (size_t i = 0; i < work.size(); ++i) {
+      const int b = work[i];
+      DM_HIP(ctx, hipMemcpyAsync(evals_dev + evoff_host[b], evw + i * std::max(maxn, 1), sizeof(double) * n_host[b],
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+    }
+  }
+
+  // ---- back-transformation: rows of E = rows of W times L^-1  <=>  E^H = L^-H W^H
+  {
+    std::vector<dm_trsm_problem> t3;
+    for (int b : work) {
+      DM_TRY(dm_conj_transpose(ctx, Ww + loff[b], n_host[b], Tw + loff[b], n_host[b], n_host[b], n_host[b]));
+      t3.push_back(dm_trsm_problem{Lw + loff[b], n_host[b], n_host[b], Tw + loff[b], n_host[b], n_host[b]});
+    }
+    DM_TRY(dm_trsm_left_lower_batched(ctx, t3, true));
+    for (int b : work)
+      DM_TRY(dm_conj_transpose(ctx, Tw + loff[b], n_host[b], E + off_host[b], n_host[b], n_host[b], n_host[b]));
+  }
+  DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  dm_ws_release(ctx, mark);
+  return DM_OK;
+}
+
+}  // extern "C"

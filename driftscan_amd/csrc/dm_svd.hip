@@ -1,0 +1,236 @@
+// dm_svd.hip — the three-stage SVD compression of every (m, frequency) beam
+// block, batched over all blocks handed in (drift/core/beamtransfer.py:802-924,
+// BeamTransfer._generate_svdfile_m).
+//
+// The reference runs SVD1 -> project -> SVD2 (null space) -> project -> SVD3 ->
+// project -> pinv, each a LAPACK call plus numpy GEMMs.  Here the whole chain is
+// three phases of the one-sided block-Jacobi engine on ONE augmented matrix per
+// (m, f):
+//
+//        Z = [ noisew * beam_m(f)  |  I_T ]        (T rows, P*L + T columns)
+//
+//   phase 1  rows 0..T      orthogonalised over all P*L sky columns   (SVD1, rtol 1e-10)
+//   phase 2  rows 0..r1     orthogonalised over the polarised columns (SVD2, null space: rows cut2..r1)
+//   phase 3  rows cut2..r1  orthogonalised over the T (pol 0) columns (SVD3, rtol 0)
+//
+// Because the unitary row mixing is applied to every column, after phase 3 the
+// sky part of the surviving rows IS `beam = ut3 . bfr` (beamtransfer.py:877) and
+// the identity part IS `ut3` (:866) — the projection GEMMs of the reference
+// (:831, :850-851, :866, :877) disappear.  For unpolarised telescopes only
+// phase 3 runs (:821-823).
+//
+// The pseudo-inverse (:887-921, scipy.linalg.pinv) is one more one-sided pass on
+// [beam | I]: W beam = S V^H, so pinv(beam) = V S^-1 W = (S V^H)^H S^-2 W, a
+// single grouped ZGEMM with the 1/s^2 weights on the contraction index.
+#include "dm_common.h"
+#include "dm_kernels.h"
+#include "../../include/driftmi.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+// Z[c] = [ nw[f] .* beam[c] | I ]
+__global__ void svd_build_z_kernel(const cplx* __restrict__ beam, const double* __restrict__ noisew,
+                                   cplx* __restrict__ Z, int F, int T, int PL, int ldz) {
+  const int c = blockIdx.z;        // chain = blk * F + f
+  const int f = c % F;
+  const int row = blockIdx.y;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= ldz) return;
+  cplx v;
+  if (col < PL) {
+    const double w = noisew[(size_t)f * T + row];
+    cplx b = beam[((size_t)c * T + row) * PL + col];
+    v = make_double2(b.x * w, b.y * w);
+  } else {
+    v = make_double2((col - PL) == row ? 1.0 : 0.0, 0.0);
+  }
+  Z[((size_t)c * T + row) * ldz + col] = v;
+}
+
+// scatter the surviving rows into the (zero-initialised) output products
+__global__ void svd_extract_kernel(const cplx* __restrict__ Z, const int* __restrict__ row0,
+                                   const int* __restrict__ nmodes, const double* __restrict__ noisew,
+                                   const double* __restrict__ sig3, cplx* __restrict__ beam_svd,
+                                   cplx* __restrict__ beam_ut, double* __restrict__ sigma, int F, int T, int PL, int K,
+                                   int ldz) {
+  const int c = blockIdx.z;
+  const int f = c % F;
+  const int i = blockIdx.y;  // mode index
+  if (i >= nmodes[c]) return;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  const cplx* z = Z + ((size_t)c * T + row0[c] + i) * ldz;
+  if (col < PL) {
+    beam_svd[((size_t)c * K + i) * PL + col] = z[col];
+  } else if (col < PL + T) {
+    const int t = col - PL;
+    const double w = noisew[(size_t)f * T + t];
+    cplx u = z[col];
+    beam_ut[((size_t)c * K + i) * T + t] = make_double2(u.x * w, u.y * w);
+  }
+  if (col == 0) sigma[(size_t)c * K + i] = sig3[(size_t)c * T + i];
+}
+
+// Z2[c] = [ beam_svd[c][:nm] | I_nm ]   (K rows allocated per chain)
+__global__ void svd_build_pinv_kernel(const cplx* __restrict__ beam_svd, const int* __restrict__ nmodes,
+                                      cplx* __restrict__ Z2, int K, int PL, int ld2) {
+  const int c = blockIdx.z;
+  const int i = blockIdx.y;
+  if (i >= nmodes[c]) return;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= ld2) return;
+  cplx v;
+  if (col < PL) v = beam_svd[((size_t)c * K + i) * PL + col];
+  else v = make_double2((col - PL) == i ? 1.0 : 0.0, 0.0);
+  Z2[((size_t)c * K + i) * ld2 + col] = v;
+}
+
+// w[c][i] = 1/s^2 if s > rtol * s_max else 0   (scipy.linalg.pinv: rtol = max(M,N) eps)
+__global__ void svd_pinv_weights_kernel(const double* __restrict__ s4, const int* __restrict__ nmodes,
+                                        double* __restrict__ w, int K, double rtol) {
+  const int c = blockIdx.x;
+  const int nm = nmodes[c];
+  const double smax = nm > 0 ? s4[(size_t)c * K] : 0.0;  // sorted descending
+  for (int i = threadIdx.x; i < K; i += blockDim.x) {
+    double s = i < nm ? s4[(size_t)c * K + i] : 0.0;
+    w[(size_t)c * K + i] = (i < nm && s > rtol * smax && s > 0.0) ? 1.0 / (s * s) : 0.0;
+  }
+}
+
+}  // namespace
+
+extern "C" int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, const void* beam_m_dev,
+                            const double* noisew_dev, double polsvcut, void* beam_svd_dev, void* invbeam_svd_dev,
+                            void* beam_ut_dev, double* sigma_dev, int* nmodes_host, int* sweeps_host) {
+  if (!ctx) return DM_EARG;
+  DM_ARG(ctx, nblk >= 0 && F > 0 && T > 0 && P > 0 && L > 0 && beam_m_dev && noisew_dev && beam_svd_dev &&
+                  beam_ut_dev && sigma_dev && nmodes_host);
+  const int nch = nblk * F;
+  if (sweeps_host) { sweeps_host[0] = sweeps_host[1] = sweeps_host[2] = sweeps_host[3] = 0; }
+  if (nch == 0) return DM_OK;
+  const int PL = P * L;
+  const int K = std::min(L, T);
+  const int ldz = PL + T;
+  const size_t mark = dm_ws_mark(ctx);
+
+  const cplx* beam = reinterpret_cast<const cplx*>(beam_m_dev);
+  cplx* beam_svd = reinterpret_cast<cplx*>(beam_svd_dev);
+  cplx* beam_ut = reinterpret_cast<cplx*>(beam_ut_dev);
+  cplx* ibeam = reinterpret_cast<cplx*>(invbeam_svd_dev);
+
+  cplx* Z = dm_ws_alloc_t<cplx>(ctx, (size_t)nch * T * ldz);
+  double* sig = dm_ws_alloc_t<double>(ctx, (size_t)nch * T);
+  if (!Z || !sig) return DM_ENOMEM;
+  hipLaunchKernelGGL(svd_build_z_kernel, dim3((ldz + 255) / 256, T, nch), dim3(256), 0, ctx->stream, beam,
+                     noisew_dev, Z, F, T, PL, ldz);
+  DM_HIP(ctx, hipGetLastError());
+
+  std::vector<double> hs((size_t)nch * T);
+  std::vector<int> r1(nch, T), cut2(nch, 0), alive(nch, 1);
+  int sw = 0;
+
+  if (P > 1) {
+    // ---- phase 1: SVD1, image with rtol 1e-10 (beamtransfer.py:826, :98)
+    std::vector<dm_jac_problem> pr(nch);
+    for (int c = 0; c < nch; ++c) pr[c] = dm_jac_problem{Z + (size_t)c * T * ldz, ldz, 0, T, ldz, 0, PL};
+    DM_TRY(dm_jacobi_rows(ctx, pr, sig, T, &sw));
+    if (sweeps_host) sweeps_host[0] = sw;
+    DM_TRY(dm_download(ctx, hs.data(), sig, sizeof(double) * hs.size()));
+    for (int c = 0; c < nch; ++c) {
+      const double* s = &hs[(size_t)c * T];
+      int cnt = 0;
+      for (int i = 0; i < T; ++i) cnt += (s[i] > s[0] * 1e-10) ? 1 : 0;
+      r1[c] = cnt;
+      // the reference's guard `(s1 > 0.0).any()` (beamtransfer.py:855-857)
+      alive[c] = (s[0] > 0.0) ? 1 : 0;
+    }
+    // ---- phase 2: SVD2, left null space of the polarised columns, `>=` cut (:844-848, :137)
+    for (int c = 0; c < nch; ++c) pr[c] = dm_jac_problem{Z + (size_t)c * T * ldz, ldz, 0, r1[c], ldz, L, PL};
+    DM_TRY(dm_jacobi_rows(ctx, pr, sig, T, &sw));
+    if (sweeps_host) sweeps_host[1] = sw;
+    DM_TRY(dm_download(ctx, hs.data(), sig, sizeof(double) * hs.size()));
+    for (int c = 0; c < nch; ++c) {
+      const double* s = &hs[(size_t)c * T];
+      int cnt = 0;
+      for (int i = 0; i < r1[c]; ++i) cnt += (s[i] >= s[0] * polsvcut) ? 1 : 0;
+      cut2[c] = cnt;
+    }
+  }
+
+  // ---- phase 3: SVD3 on the total-intensity columns, rtol 0 (:859-865)
+  std::vector<int> row0(nch), nrow3(nch);
+  {
+    std::vector<dm_jac_problem> pr(nch);
+    for (int c = 0; c < nch; ++c) {
+      row0[c] = cut2[c];
+      nrow3[c] = alive[c] ? std::max(0, r1[c] - cut2[c]) : 0;
+      pr[c] = dm_jac_problem{Z + (size_t)c * T * ldz, ldz, row0[c], nrow3[c], ldz, 0, L};
+    }
+    DM_TRY(dm_jacobi_rows(ctx, pr, sig, T, &sw));
+    if (sweeps_host) sweeps_host[2] = sw;
+    DM_TRY(dm_download(ctx, hs.data(), sig, sizeof(double) * hs.size()));
+  }
+  std::vector<int> nmodes(nch, 0);
+  int maxnm = 0;
+  for (int c = 0; c < nch; ++c) {
+    const double* s = &hs[(size_t)c * T];
+    int cnt = 0;
+    const int lim = std::min(nrow3[c], K);
+    for (int i = 0; i < lim; ++i) cnt += (s[i] > 0.0) ? 1 : 0;  // rtol = 0.0: strictly positive
+    nmodes[c] = cnt;
+    nmodes_host[c] = cnt;
+    maxnm = std::max(maxnm, cnt);
+  }
+
+  // ---- products
+  int* d_row0 = dm_ws_upload(ctx, row0);
+  int* d_nm = dm_ws_upload(ctx, nmodes);
+  if (!d_row0 || !d_nm) return DM_ENOMEM;
+  DM_TRY(dm_fill_zero(ctx, beam_svd, sizeof(cplx) * (size_t)nch * K * PL));
+  DM_TRY(dm_fill_zero(ctx, beam_ut, sizeof(cplx) * (size_t)nch * K * T));
+  DM_TRY(dm_fill_zero(ctx, sigma_dev, sizeof(double) * (size_t)nch * K));
+  if (maxnm > 0) {
+    hipLaunchKernelGGL(svd_extract_kernel, dim3((ldz + 255) / 256, maxnm, nch), dim3(256), 0, ctx->stream, Z, d_row0,
+                       d_nm, noisew_dev, sig, beam_svd, beam_ut, sigma_dev, F, T, PL, K, ldz);
+    DM_HIP(ctx, hipGetLastError());
+  }
+
+  // ---- pseudo-inverse of `beam` (:887-921)
+  if (ibeam) {
+    DM_TRY(dm_fill_zero(ctx, ibeam, sizeof(cplx) * (size_t)nch * PL * K));
+    if (maxnm > 0) {
+      const int ld2 = PL + K;
+      // Z is no longer needed: reuse its storage when it is large enough
+      cplx* Z2 = ((size_t)K * ld2 <= (size_t)T * ldz) ? Z : dm_ws_alloc_t<cplx>(ctx, (size_t)nch * K * ld2);
+      double* s4 = dm_ws_alloc_t<double>(ctx, (size_t)nch * K);
+      double* w4 = dm_ws_alloc_t<double>(ctx, (size_t)nch * K);
+      if (!Z2 || !s4 || !w4) return DM_ENOMEM;
+      hipLaunchKernelGGL(svd_build_pinv_kernel, dim3((ld2 + 255) / 256, maxnm, nch), dim3(256), 0, ctx->stream,
+                         beam_svd, d_nm, Z2, K, PL, ld2);
+      std::vector<dm_jac_problem> pr(nch);
+      for (int c = 0; c < nch; ++c)
+        pr[c] = dm_jac_problem{Z2 + (size_t)c * K * ld2, ld2, 0, nmodes[c], PL + nmodes[c], 0, PL};
+      DM_TRY(dm_jacobi_rows(ctx, pr, s4, K, &sw));
+      if (sweeps_host) sweeps_host[3] = sw;
+      const double rtol = (double)std::max(PL, maxnm) * 2.220446049250313e-16;
+      hipLaunchKernelGGL(svd_pinv_weights_kernel, dim3(nch), dim3(256), 0, ctx->stream, s4, d_nm, w4, K, rtol);
+      std::vector<dm_gemm_desc> g;
+      g.reserve(nch);
+      for (int c = 0; c < nch; ++c) {
+        const int nm = nmodes[c];
+        if (nm == 0) continue;
+        const cplx* Y = Z2 + (size_t)c * K * ld2;           // (nm x PL): rows = s_k v_k^H
+        const cplx* W = Y + PL;                              // (nm x nm): rows of U_b^H
+        // ibeam (PL x nm) = Y^H diag(w) W ; destination is (P, L, K) with K the fastest axis
+        g.push_back(dm_gemm_make(Y, 1, ld2, true, W, ld2, 1, false, ibeam + (size_t)c * PL * K, K, PL, nm, nm, 1.0,
+                                 0.0, w4 + (size_t)c * K));
+      }
+      DM_TRY(dm_gemm_grouped_launch(ctx, g));
+    }
+  }
+  DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  dm_ws_release(ctx, mark);
+  return DM_OK;
+}

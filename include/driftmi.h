@@ -1,0 +1,139 @@
+/* driftmi.h — C ABI of libdriftmi, the MI355X (gfx950) implementation of
+ * driftscan's per-m hot path (beam-transfer generation, SVD compression,
+ * KL / DoubleKL).  This is the drop-in boundary: plain pointers and sizes, no
+ * torch / numpy types, `extern "C"`.  The reference has no FFI of its own (it is
+ * Python + LAPACK); each entry point therefore cites the reference *call site*
+ * whose arithmetic it replaces (paths relative to radiocosmology/driftscan).
+ *
+ * Conventions
+ *   - complex128 = interleaved (double re, double im); matrices are row-major.
+ *   - every pointer named *_dev is DEVICE memory owned by the caller (e.g. a
+ *     torch tensor's data_ptr()); pointers named *_host are host memory.
+ *   - every function returns int: 0 ok, <0 argument/runtime error (see
+ *     dm_last_error), >0 numerical status mirroring LAPACK `info`.
+ *   - a dm_ctx owns a device id, a HIP stream and a growable device workspace;
+ *     one context per GPU, one host thread per context.  All work is enqueued on
+ *     the context's stream; functions documented as "synchronises" block the
+ *     host until their results are complete.
+ *   - there is NO CPU fallback: without a GPU every compute entry point fails.
+ */
+#ifndef DRIFTMI_H
+#define DRIFTMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dm_ctx dm_ctx;
+
+/* ---- context ----------------------------------------------------------- */
+/* stream: an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)
+ * or NULL to let the context create its own. */
+int dm_ctx_create(int device, size_t workspace_bytes, void* stream, dm_ctx** out);
+int dm_ctx_destroy(dm_ctx* ctx);
+int dm_ctx_sync(dm_ctx* ctx);
+size_t dm_ctx_workspace_bytes(dm_ctx* ctx);
+const char* dm_last_error(dm_ctx* ctx);
+int dm_version(void);
+
+/* ---- dense building blocks (exposed for the parity tests) --------------- */
+/* C = alpha * op(A) diag(kscale) op(B) + beta C on the fp64 matrix cores.
+ * A is viewed as (M x K) through element strides (rsA, csA), B as (K x N)
+ * through (rsB, csB); conj* conjugate the elements.  `batch` problems at the
+ * given element strides between consecutive A/B/C/kscale.
+ * Replaces: np.dot at drift/core/beamtransfer.py:1186, :1226; doublekl.py:73-85. */
+int dm_zgemm_strided_batched(dm_ctx* ctx, int M, int N, int K, double alpha, const void* A_dev, int rsA, int csA,
+                             int conjA, int64_t strideA, const void* B_dev, int rsB, int csB, int conjB,
+                             int64_t strideB, double beta, void* C_dev, int ldc, int64_t strideC,
+                             const double* kscale_dev, int64_t stride_kscale, int batch);
+
+/* Batched lower Cholesky A = L L^H in place (n x n, row-major, ld), `batch`
+ * matrices `stride` elements apart.  info_host[i] = 0 or the order of the first
+ * non-positive-definite leading minor.  Synchronises.
+ * Replaces: the zpotrf inside scipy.linalg.eigh(A, B) at drift/core/kltransform.py:89. */
+int dm_zpotrf_batched(dm_ctx* ctx, int n, void* A_dev, int ld, int64_t stride, int batch, int* info_host);
+
+/* Batched triangular solve with the lower factor: L X = B (conjtrans = 0) or
+ * L^H X = B (conjtrans = 1), X overwrites B (n x nrhs row-major).
+ * Replaces: zhegst / ztrsm inside scipy.linalg.eigh(A, B), kltransform.py:89. */
+int dm_ztrsm_left_lower_batched(dm_ctx* ctx, int n, int nrhs, const void* L_dev, int ldl, int64_t strideL,
+                                void* B_dev, int ldb, int64_t strideB, int conjtrans, int batch);
+
+/* One-sided block-Jacobi SVD of `batch` row-major matrices (rows x cols, ld,
+ * `stride` elements apart): the rows of each matrix are unitarily mixed in place
+ * until mutually orthogonal with respect to the columns [gc0, gc1) and sorted by
+ * descending norm over those columns.  On return rows = diag(sigma) V^H padded
+ * with the passenger columns; sigma_dev gets `rows` doubles per matrix.
+ * Synchronises.  sweeps_host (optional) receives the sweep count.
+ * Replaces: scipy.linalg.svd at drift/core/beamtransfer.py:74, :113. */
+int dm_jacobi_rows_batched(dm_ctx* ctx, int rows, int cols, int gc0, int gc1, void* Z_dev, int ld, int64_t stride,
+                           int batch, double* sigma_dev, int* sweeps_host);
+
+/* Two-sided block-Jacobi eigendecomposition of `batch` Hermitian n x n matrices:
+ * on return C is diagonal (to working accuracy), W_dev (n x n per matrix, rows
+ * are eigenvectors^H) holds the accumulated unitary, evals_dev the unsorted
+ * diagonal.  Synchronises.
+ * Replaces: the zheevd inside scipy.linalg.eigh, kltransform.py:89, :107. */
+int dm_jacobi_herm_batched(dm_ctx* ctx, int n, void* C_dev, int ldc, int64_t strideC, void* W_dev, int ldw,
+                           int64_t strideW, int batch, double* evals_dev, int* sweeps_host);
+
+/* ---- SVD compression of beam-transfer blocks -------------------------------- */
+/* Three-stage SVD chain + pseudo-inverse for nblk m-blocks x F frequencies.
+ *   beam_m_dev   (nblk, F, T, P, L) c128   noise-unweighted beam_m blocks, T = 2*nbase
+ *                                         (the reference's (2, nbase) axes flattened), zero for l < m
+ *   noisew_dev   (F, T) f64               noisepower(b, f)^-1/2, duplicated for the two m signs
+ *   beam_svd_dev (nblk, F, K, P, L) c128  out, K = min(L, T); rows >= nmodes are zero
+ *   invbeam_svd_dev (nblk, F, P, L, K)    out or NULL (skip_svd_inv)
+ *   beam_ut_dev  (nblk, F, K, T) c128     out
+ *   sigma_dev    (nblk, F, K) f64         out
+ *   nmodes_host  (nblk*F) int             out
+ *   sweeps_host  optional int[4]: Jacobi sweeps used by SVD1, SVD2, SVD3, pinv
+ * Synchronises.
+ * Replaces: BeamTransfer._generate_svdfile_m, drift/core/beamtransfer.py:802-924
+ * (matrix_image :68-104, matrix_nullspace :107-143, scipy.linalg.pinv :891). */
+int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, const void* beam_m_dev,
+                 const double* noisew_dev, double polsvcut, void* beam_svd_dev, void* invbeam_svd_dev,
+                 void* beam_ut_dev, double* sigma_dev, int* nmodes_host, int* sweeps_host);
+
+/* ---- KL: covariance projection and generalised eigenproblem ---------------- */
+/* Project a sky covariance into the SVD basis for nblk m-blocks.
+ *   svnum_host   (nblk*F) int   kept modes per frequency (BeamTransfer._svd_num)
+ *   l0_host      (nblk) int or NULL: first non-zero l of each block (= m), columns below are skipped
+ *   cl_pfl_dev   (P, P, F, F, L) f64: the reference's (P,P,L,F,F) C_l array with l moved last
+ *   npol         pol pairs looped: P, or 1 for `temponly`
+ *   polmask_host (P*P) int or NULL: non-zero where cl[pi,pj] is not identically zero
+ *   out_dev      c128, block b is (ndof_b x ndof_b) row-major at element offset out_off_host[b]
+ *   zero_first   clear the outputs before accumulating
+ * Replaces: BeamTransfer.project_matrix_sky_to_svd, drift/core/beamtransfer.py:1135-1188. */
+int dm_project_cov(dm_ctx* ctx, int nblk, int F, int K, int P, int L, const void* beam_svd_dev,
+                   const int* svnum_host, const int* l0_host, const double* cl_pfl_dev, int npol,
+                   const int* polmask_host, void* out_dev, const int64_t* out_off_host, int zero_first);
+
+/* Block-diagonal projection of a diagonal telescope-basis matrix dmat (F, T):
+ * block f (+)= alpha (U_f * d_f) U_f^H.
+ * Replaces: project_matrix_diagonal_telescope_to_svd, drift/core/beamtransfer.py:1190-1231. */
+int dm_project_diag(dm_ctx* ctx, int nblk, int F, int K, int T, const void* beam_ut_dev, const int* svnum_host,
+                    const double* dmat_dev, double alpha, void* out_dev, const int64_t* out_off_host,
+                    int accumulate);
+
+/* diag(N_b) += reg * max(N_b), numpy's lexicographic complex max.
+ * Replaces: drift/core/kltransform.py:289-290. */
+int dm_regularise(dm_ctx* ctx, int nblk, const int* n_host, void* mats_dev, const int64_t* off_host, double reg);
+
+/* Generalised Hermitian-definite eigenproblems A v = lambda B v (A, B destroyed).
+ * evals ascending at evals_dev + evoff_host[b]; evecs_dev + off_host[b] holds an
+ * (n x n) matrix whose ROWS are the modes (the reference's evecs.T.conj()).
+ * add_const_host[b] = diagonal shift applied by the non-positive-definite rescue.
+ * Returns > 0 if a B stays indefinite after the rescue.  Synchronises.
+ * Replaces: eigh_gen, drift/core/kltransform.py:55-121. */
+int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_dev, const int64_t* off_host,
+                double* evals_dev, const int64_t* evoff_host, void* evecs_dev, double* add_const_host,
+                int* sweeps_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRIFTMI_H */

@@ -1,0 +1,154 @@
+"""GPU parity of the dense building blocks (through the C ABI) against numpy."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from driftscan_amd._lib import Context
+
+    c = Context(0, workspace_bytes=1 << 30)
+    yield c
+    c.close()
+
+
+def crand(rng, *shape):
+    return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (37, 91, 53), (130, 70, 129), (5, 3, 2), (200, 200, 1)])
+@pytest.mark.parametrize("mode", ["NN", "NC", "CN", "TN_strided"])
+def test_zgemm(ctx, M, N, K, mode):
+    rng = np.random.default_rng(M * 1000 + N * 10 + K)
+    if mode == "NN":
+        A, B = crand(rng, M, K), crand(rng, K, N)
+        ref = A @ B
+        args = dict(rsA=K, csA=1, rsB=N, csB=1)
+    elif mode == "NC":  # A B^H with B stored (N x K)
+        A, B = crand(rng, M, K), crand(rng, N, K)
+        ref = A @ B.conj().T
+        args = dict(rsA=K, csA=1, rsB=1, csB=K, conjB=True)
+    elif mode == "CN":  # A^H B with A stored (K x M)
+        A, B = crand(rng, K, M), crand(rng, K, N)
+        ref = A.conj().T @ B
+        args = dict(rsA=1, csA=M, rsB=N, csB=1, conjA=True)
+    else:  # A^T B (no conj), A stored (K x M)
+        A, B = crand(rng, K, M), crand(rng, K, N)
+        ref = A.T @ B
+        args = dict(rsA=1, csA=M, rsB=N, csB=1)
+    C0 = crand(rng, M, N)
+    dA, dB, dC = ctx.to_device(A), ctx.to_device(B), ctx.to_device(C0)
+    ctx.zgemm(dA, dB, dC, M, N, K, ldc=N, alpha=0.5, beta=-2.0, **args)
+    ctx.sync()
+    out = dC.cpu().numpy()
+    exp = 0.5 * ref - 2.0 * C0
+    assert np.abs(out - exp).max() <= 1e-12 * max(1.0, np.abs(exp).max())
+
+
+def test_zgemm_kscale_batched(ctx):
+    rng = np.random.default_rng(7)
+    nb, M, N, K = 5, 50, 40, 129
+    A, B = crand(rng, nb, M, K), crand(rng, nb, N, K)
+    s = rng.uniform(0.1, 2.0, (nb, K))
+    ref = np.einsum("bmk,bk,bnk->bmn", A, s, B.conj())
+    dA, dB, ds = ctx.to_device(A), ctx.to_device(B), ctx.to_device(s)
+    dC = ctx.zeros((nb, M, N), np.complex128)
+    ctx.zgemm(dA, dB, dC, M, N, K, rsA=K, csA=1, rsB=1, csB=K, conjB=True, ldc=N, kscale=ds, batch=nb,
+              strideA=M * K, strideB=N * K, strideC=M * N, stride_kscale=K)
+    ctx.sync()
+    assert np.abs(dC.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 100, 257])
+def test_potrf_trsm(ctx, n):
+    rng = np.random.default_rng(n)
+    nb = 3
+    X = crand(rng, nb, n, n + 3)
+    A = X @ X.conj().transpose(0, 2, 1) + 0.1 * np.eye(n)
+    dA = ctx.to_device(A)
+    info = ctx.zpotrf(dA, n, n, stride=n * n, batch=nb)
+    assert (info == 0).all()
+    L = dA.cpu().numpy()
+    assert np.abs(np.triu(L, 1)).max() == 0.0
+    assert np.abs(L @ L.conj().transpose(0, 2, 1) - A).max() <= 1e-12 * np.abs(A).max()
+    nrhs = 70
+    Bm = crand(rng, nb, n, nrhs)
+    for conjtrans in (False, True):
+        dB = ctx.to_device(Bm)
+        ctx.ztrsm(dA, dB, n, nrhs, n, nrhs, conjtrans=conjtrans, strideL=n * n, strideB=n * nrhs, batch=nb)
+        ctx.sync()
+        Xs = dB.cpu().numpy()
+        Lop = L.conj().transpose(0, 2, 1) if conjtrans else L
+        res = np.abs(Lop @ Xs - Bm).max() / np.abs(Bm).max()
+        assert res <= 1e-10
+
+
+def test_potrf_not_pd(ctx):
+    rng = np.random.default_rng(3)
+    n = 70
+    X = crand(rng, n, n - 5)
+    A = X @ X.conj().T - 1e-9 * np.eye(n)
+    dA = ctx.to_device(A[None])
+    info = ctx.zpotrf(dA, n, n, stride=n * n, batch=1)
+    assert 0 < info[0] <= n
+
+
+@pytest.mark.parametrize("rows,cols", [(20, 25), (92, 129), (33, 200), (104, 388 + 104), (70, 30)])
+def test_jacobi_rows(ctx, rows, cols):
+    rng = np.random.default_rng(rows * cols)
+    nb = 4
+    A = crand(rng, nb, rows, cols)
+    A *= np.exp(-np.arange(cols) / 8.0)  # graded columns -> spectrum spans decades
+    dZ = ctx.to_device(A)
+    sigma, sweeps = ctx.jacobi_rows(dZ, rows, cols, 0, cols, cols, stride=rows * cols, batch=nb)
+    Z = dZ.cpu().numpy()
+    s = sigma.cpu().numpy()
+    for b in range(nb):
+        ref = np.linalg.svd(A[b], compute_uv=False)
+        k = min(rows, cols)
+        assert np.abs(s[b, :k] - ref).max() <= 1e-12 * ref[0], (b, sweeps)
+        G = Z[b] @ Z[b].conj().T
+        assert np.abs(G - np.diag(np.diag(G))).max() <= 1e-11 * ref[0] ** 2
+        # same row space / Gram: Z^H Z == A^H A
+        assert np.abs(Z[b].conj().T @ Z[b] - A[b].conj().T @ A[b]).max() <= 1e-11 * ref[0] ** 2
+    assert sweeps < 30
+
+
+def test_jacobi_rows_passengers(ctx):
+    """Gram over a column subset; passenger columns carry the accumulated U^H."""
+    rng = np.random.default_rng(11)
+    rows, cols = 40, 60
+    A = crand(rng, rows, cols)
+    Z = np.concatenate([A, np.eye(rows)], axis=1)
+    dZ = ctx.to_device(Z[None])
+    sigma, sweeps = ctx.jacobi_rows(dZ, rows, cols + rows, 10, 50, cols + rows, stride=0, batch=1)
+    out = dZ.cpu().numpy()[0]
+    Y, W = out[:, :cols], out[:, cols:]
+    assert np.abs(W @ W.conj().T - np.eye(rows)).max() < 1e-12
+    assert np.abs(W @ A - Y).max() < 1e-11
+    ref = np.linalg.svd(A[:, 10:50], compute_uv=False)
+    assert np.abs(sigma.cpu().numpy()[0, :rows] - ref).max() <= 1e-12 * ref[0]
+
+
+@pytest.mark.parametrize("n", [5, 64, 80, 200])
+def test_jacobi_herm(ctx, n):
+    rng = np.random.default_rng(n)
+    nb = 3
+    X = crand(rng, nb, n, n)
+    lam = 10.0 ** rng.uniform(-12, 0, (nb, n))
+    Qm = np.linalg.qr(X)[0]
+    C = (Qm * lam[:, None, :]) @ Qm.conj().transpose(0, 2, 1)
+    C = 0.5 * (C + C.conj().transpose(0, 2, 1))
+    dC = ctx.to_device(C)
+    ev, W, sweeps = ctx.jacobi_herm(dC, n, n, strideC=n * n, batch=nb)
+    ev = ev.cpu().numpy()
+    W = W.cpu().numpy()
+    for b in range(nb):
+        ref = np.linalg.eigvalsh(C[b])
+        assert np.abs(np.sort(ev[b, :n]) - ref).max() <= 2e-12 * np.abs(ref).max(), sweeps
+        assert np.abs(W[b] @ W[b].conj().T - np.eye(n)).max() < 1e-12
+        D = W[b] @ C[b] @ W[b].conj().T
+        assert np.abs(D - np.diag(ev[b, :n])).max() <= 2e-12 * np.abs(ref).max()
+    assert sweeps < 30

@@ -1,0 +1,157 @@
+"""GPU parity of the SVD chain, covariance projections and generalised eigensolver
+(through the C ABI) against golden vectors produced by the unmodified reference."""
+import os
+
+import numpy as np
+import pytest
+
+from parity_util import assert_spectrum, pencil_sensitivity, pencil_tol, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from driftscan_amd._lib import Context
+
+    c = Context(0, workspace_bytes=2 << 30)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module", params=["unpol", "pol", "unpol_harsh"])
+def gold(request, golden_dir):
+    return np.load(os.path.join(golden_dir, "svdkl_%s.npz" % request.param))
+
+
+def _run_svd(ctx, g):
+    F, B, P, L = int(g["F"]), int(g["B"]), int(g["P"]), int(g["lmax"]) + 1
+    T = 2 * B
+    mlist = list(g["mlist"])
+    beam = np.stack([g["m%d_beam_m" % m].reshape(F, T, P, L) for m in mlist])
+    nw = np.concatenate([g["npower"], g["npower"]], axis=1) ** -0.5
+    res = ctx.svd_chain(ctx.to_device(beam), ctx.to_device(nw), float(g["polsvcut"]))
+    return mlist, res
+
+
+def test_svd_chain(ctx, gold):
+    g = gold
+    from oracle import svdchain as osvd
+
+    mlist, res = _run_svd(ctx, g)
+    F = int(g["F"])
+    sv = res["singularvalues"].cpu().numpy()
+    bs = res["beam_svd"].cpu().numpy()
+    ut = res["beam_ut"].cpu().numpy()
+    ib = res["invbeam_svd"].cpu().numpy()
+    assert max(res["sweeps"]) < 30
+    for bi, mi in enumerate(mlist):
+        pre = "m%d_" % mi
+        ref = g[pre + "singularvalues"]
+        assert_spectrum(sv[bi], ref, 1e-10, "singular values m=%d" % mi)
+        svnum, svbounds = osvd.svd_num(sv[bi], float(g["svcut"]))
+        assert (svnum == g[pre + "svnum"]).all()
+        for f in range(F):
+            n = svnum[f]
+            b0 = g[pre + "beam_svd"][f, :n].reshape(n, -1)
+            b1 = bs[bi, f, :n].reshape(n, -1)
+            assert relerr(b1.T.conj() @ b1, b0.T.conj() @ b0) < 1e-9
+            u0, u1 = g[pre + "beam_ut"][f, :n], ut[bi, f, :n]
+            assert relerr(u1.T.conj() @ u1, u0.T.conj() @ u0) < 1e-9
+            K = ib.shape[-1]
+            i0 = g[pre + "invbeam_svd"][f].reshape(-1, K)[:, :n]
+            i1 = ib[bi, f].reshape(-1, K)[:, :n]
+            assert relerr(i1 @ b1, i0 @ b0) < 1e-7
+            # rows past nmodes stay zero, like the reference's zero-initialised datasets
+            nm = res["nmodes"][bi, f]
+            assert np.abs(bs[bi, f, nm:]).max(initial=0.0) == 0.0
+
+
+def _projections(ctx, g, mlist, bsvd, but, svnum_all):
+    from driftscan_amd._lib import block_offsets
+
+    F, P, L = int(g["F"]), int(g["P"]), int(g["lmax"]) + 1
+    ndofs = svnum_all.sum(axis=1)
+    off, tot = block_offsets(ndofs)
+    return ndofs, off, tot
+
+
+def test_projections_and_eigh(ctx, gold):
+    g = gold
+    from driftscan_amd._lib import block_offsets
+
+    F, P, L = int(g["F"]), int(g["P"]), int(g["lmax"]) + 1
+    mlist = list(g["mlist"])
+    # feed the *reference's* SVD products so that this test isolates the projections
+    bsvd = ctx.to_device(np.stack([g["m%d_beam_svd" % m] for m in mlist]))
+    but = ctx.to_device(np.stack([g["m%d_beam_ut" % m] for m in mlist]))
+    svnum = np.stack([g["m%d_svnum" % m] for m in mlist])
+    ndofs = svnum.sum(axis=1)
+    off, tot = block_offsets(ndofs)
+    cl_sg = ctx.to_device(np.ascontiguousarray(g["cv_sg"].transpose(0, 1, 3, 4, 2)))
+    cl_fg = ctx.to_device(np.ascontiguousarray(g["cv_fg"].transpose(0, 1, 3, 4, 2)))
+    pm_sg = (np.abs(g["cv_sg"]).reshape(P, P, -1).max(axis=-1) > 0).astype(np.int32)
+    pm_fg = (np.abs(g["cv_fg"]).reshape(P, P, -1).max(axis=-1) > 0).astype(np.int32)
+    S = ctx.empty((tot,), np.complex128)
+    N = ctx.empty((tot,), np.complex128)
+    ctx.project_cov(bsvd, svnum, cl_sg, S, off, polmask=pm_sg, l0=np.array(mlist))
+    ctx.project_cov(bsvd, svnum, cl_fg, N, off, polmask=pm_fg, l0=np.array(mlist))
+    ctx.sync()
+    Sh, Nh = S.cpu().numpy(), N.cpu().numpy()
+    for bi, mi in enumerate(mlist):
+        n = ndofs[bi]
+        s = Sh[off[bi]: off[bi] + n * n].reshape(n, n)
+        f = Nh[off[bi]: off[bi] + n * n].reshape(n, n)
+        assert relerr(s, g["m%d_proj_sg" % mi]) < 1e-12
+        assert relerr(f, g["m%d_proj_fg" % mi]) < 1e-12
+    # N = fg + reg max + noise  -> compare with the reference's sn_covariance
+    ctx.regularise(N, ndofs, off, 1e-14)
+    npw = ctx.to_device(np.concatenate([g["npower"], g["npower"]], axis=1))
+    ctx.project_diag(but, svnum, npw, N, off, alpha=1.0, accumulate=True)
+    ctx.sync()
+    Nh = N.cpu().numpy()
+    for bi, mi in enumerate(mlist):
+        n = ndofs[bi]
+        assert relerr(Nh[off[bi]: off[bi] + n * n].reshape(n, n), g["m%d_kl_cn" % mi]) < 1e-12
+    # generalised eigenproblem, all m at once
+    evals, evoff, evecs, ac, sweeps = ctx.eigh_gen(S, N, ndofs, off)
+    ev = evals.cpu().numpy()
+    E = evecs.cpu().numpy()
+    assert (ac == 0.0).all()
+    for bi, mi in enumerate(mlist):
+        n = ndofs[bi]
+        ref = g["m%d_kl_evals" % mi]
+        cs, cn = g["m%d_kl_cs" % mi], g["m%d_kl_cn" % mi]
+        tol = pencil_tol(cn)
+        if tol > 1e-6:
+            # foreground-dominated pencil: use the measured sensitivity of LAPACK's own answer
+            tol = max(1e-10, 10.0 * pencil_sensitivity(cs, cn))
+        assert tol < 5e-2
+        assert_spectrum(ev[evoff[bi]: evoff[bi] + n], ref, tol, "kl evals m=%d" % mi)
+        Eb = E[off[bi]: off[bi] + n * n].reshape(n, n)
+        eref = g["m%d_kl_evecs" % mi]
+        rn_ref = relerr(eref @ cn @ eref.T.conj(), np.eye(n), 1.0)
+        rs_ref = relerr(eref @ cs @ eref.T.conj(), np.diag(ref), np.abs(ref).max())
+        assert relerr(Eb @ cn @ Eb.T.conj(), np.eye(n), 1.0) <= max(10 * rn_ref, 10 * tol, 1e-8)
+        assert relerr(Eb @ cs @ Eb.T.conj(), np.diag(ev[evoff[bi]: evoff[bi] + n]), np.abs(ref).max()) <= max(10 * rs_ref, 10 * tol, 1e-8)
+
+
+def test_eigh_gen_rescue_and_zero(ctx, golden_dir):
+    from driftscan_amd._lib import block_offsets
+
+    g = np.load(os.path.join(golden_dir, "eigh_gen.npz"))
+    cases = ["pd", "npd", "zero"]
+    ndofs = np.array([g[c + "_A"].shape[0] for c in cases])
+    off, tot = block_offsets(ndofs)
+    A = np.concatenate([g[c + "_A"].ravel() for c in cases])
+    B = np.concatenate([g[c + "_B"].ravel() for c in cases])
+    evals, evoff, evecs, ac, sweeps = ctx.eigh_gen(ctx.to_device(A), ctx.to_device(B), ndofs, off)
+    ev = evals.cpu().numpy()
+    for i, c in enumerate(cases):
+        n = ndofs[i]
+        Bc = g[c + "_B"] + float(g[c + "_ac"]) * np.eye(n)
+        tol = pencil_tol(Bc) if c != "zero" else 1e-12
+        assert_spectrum(ev[evoff[i]: evoff[i] + n], g[c + "_evals"], tol, c)
+    assert ac[0] == 0.0 and ac[2] == 0.0
+    # the shift is 1e-15 ev_max - 2 ev_min + 1e-60 with ev_min ~ -1e-9: well determined
+    assert np.isclose(ac[1], float(g["npd_ac"]), rtol=1e-5)
