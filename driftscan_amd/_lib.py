@@ -51,6 +51,15 @@ SIGNATURES = {
     "dm_eigh_gen": (
         c_int, [c_vp, c_int, ctypes.POINTER(c_int), c_vp, c_vp, ctypes.POINTER(c_i64), c_vp, ctypes.POINTER(c_i64),
                 c_vp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_int)]),
+    "dm_bt_beam_cyl": (
+        c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int,
+                ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_dbl, c_vp]),
+    "dm_bt_maps": (
+        c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_int, c_vp,
+                c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_vp]),
+    "dm_bt_sht": (
+        c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_int, c_int, c_int, c_int, c_int,
+                c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_vp, c_vp]),
 }
 
 _lib = None
@@ -265,3 +274,48 @@ Context.project_diag = _project_diag
 Context.regularise = _regularise
 Context.eigh_gen = _eigh_gen
 block_offsets = _block_offsets
+
+
+def _darr(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(ctypes.POINTER(c_dbl))
+
+
+def _bt_beam_cyl(self, nside, cth, sth, frame, kind, tab, fwhm_ns, out):
+    c, cp = _darr(cth)
+    s_, sp = _darr(sth)
+    fr, frp = _darr(frame)
+    tx, txp = _darr(tab[0])
+    ty, typ = _darr(tab[1])
+    t2, t2p = _darr(tab[2])
+    rc = self.lib.dm_bt_beam_cyl(self.h, int(nside), cp, sp, frp, int(kind), txp, typ, t2p, len(tx), float(fwhm_ns),
+                                 self.ptr(out))
+    self.check(rc, "dm_bt_beam_cyl")
+
+
+def _bt_maps(self, nside, cth, sth, frame, polarised, beams, uv, bi, bj, maps):
+    c, cp = _darr(cth)
+    s_, sp = _darr(sth)
+    fr, frp = _darr(frame)
+    u, up = _darr(uv)
+    i_, ip = _iarr(bi)
+    j_, jp = _iarr(bj)
+    rc = self.lib.dm_bt_maps(self.h, int(nside), cp, sp, frp, int(bool(polarised)), int(beams.shape[0]),
+                             self.ptr(beams), len(i_), up, ip, jp, self.ptr(maps))
+    self.check(rc, "dm_bt_maps")
+
+
+def _bt_sht(self, nside, cth, sth, polarised, lside, mmax, lmax_grp, F, B, col_f, col_b, col_lmax, maps, beam_m):
+    c, cp = _darr(cth)
+    s_, sp = _darr(sth)
+    f_, fp = _iarr(col_f)
+    b_, bp = _iarr(col_b)
+    l_, lp = _iarr(col_lmax)
+    rc = self.lib.dm_bt_sht(self.h, int(nside), cp, sp, int(bool(polarised)), int(lside), int(mmax), int(lmax_grp),
+                            int(F), int(B), len(f_), fp, bp, lp, self.ptr(maps), self.ptr(beam_m))
+    self.check(rc, "dm_bt_sht")
+
+
+Context.bt_beam_cyl = _bt_beam_cyl
+Context.bt_maps = _bt_maps
+Context.bt_sht = _bt_sht

@@ -1,0 +1,125 @@
+"""Host orchestration of beam-transfer generation on the GPU.
+
+Groups the requested (frequency, baseline) pairs by the HEALPix resolution the
+reference would pick for them (``nside_for_lmax`` of the per-baseline band limit,
+drift/core/telescope.py:1179-1184, :1288), evaluates the beams, synthesises the
+visibility response maps and transforms them straight into the m-ordered
+``beam_m`` blocks (``dm_bt_beam_cyl`` / ``dm_bt_maps`` / ``dm_bt_sht``).
+"""
+import numpy as np
+
+from . import healpix
+from .device import get_context
+
+
+def telescope_frame(zenith):
+    """xhat (East), yhat (North), zhat (up) in sky cartesian coordinates — the unrotated
+    cylinder frame of cylbeam.py:129 (phihat, -thetahat, zenith)."""
+    t, p = zenith
+    that = np.array([np.cos(t) * np.cos(p), np.cos(t) * np.sin(p), -np.sin(t)])
+    phat = np.array([-np.sin(p), np.cos(p), 0.0])
+    zhat = np.array([np.sin(t) * np.cos(p), np.sin(t) * np.sin(p), np.cos(t)])
+    return np.concatenate([phat, -that, zhat])
+
+
+def _nside_of(tel, lmax_bf):
+    boost = tel.accuracy_boost if tel.num_pol_sky == 1 else 1
+    return np.array([healpix.nside_for_lmax(int(l), boost) for l in lmax_bf], dtype=np.int64)
+
+
+def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=None, mmax=None,
+                max_bytes=6 << 30, ctx=None):
+    """Fill rows of the device array ``beam_m`` (mmax+1, F, 2, B, P, lside+1) for the
+    (frequency, baseline) pairs (f_list[i], b_list[i]); the destination row of pair i is
+    (row_f[i], row_b[i]) (defaults: the telescope indices themselves)."""
+    ctx = ctx or get_context()
+    f_list = np.asarray(f_list, dtype=np.int64).reshape(-1)
+    b_list = np.asarray(b_list, dtype=np.int64).reshape(-1)
+    row_f = f_list if row_f is None else np.asarray(row_f, dtype=np.int64).reshape(-1)
+    row_b = b_list if row_b is None else np.asarray(row_b, dtype=np.int64).reshape(-1)
+    F = tel.nfreq if F is None else F
+    B = tel.nbase if B is None else B
+    mmax = tel.mmax if mmax is None else mmax
+    lside = tel.lmax
+    pol = tel.num_pol_sky > 1
+    P = 4 if pol else 1
+    frame = telescope_frame(tel.zenith)
+    lmax_bf, _ = tel.baseline_lmax(b_list, f_list)
+    if (lmax_bf > lside).any():
+        raise ValueError("a baseline's natural lmax exceeds the telescope lmax (force_lmax too small)")
+    nsides = _nside_of(tel, lmax_bf)
+    pairs = tel.uniquepairs
+    cls = np.asarray(tel.beamclass)
+    wl = tel.wavelengths
+
+    for nside in np.unique(nsides):
+        sel = np.nonzero(nsides == nside)[0]
+        npix = healpix.npix(int(nside))
+        nring = 4 * int(nside) - 1
+        cth, sth = healpix.ring_trig(int(nside))
+        # chunk columns so that maps + ring-DFT output + twiddles stay within the budget
+        lgrp = int(lmax_bf[sel].max())
+        mtop = min(mmax, lgrp)
+        per_col = P * 16 * (npix + (2 * mtop + 1) * nring)
+        fixed = (2 * mtop + 1) * npix * 16
+        ncol_max = max(1, int((max_bytes - fixed) // per_col)) if max_bytes > fixed else 1
+        # keep all baselines of a frequency together and in order: dm_bt_sht merges such runs
+        order = sel[np.lexsort((row_b[sel], row_f[sel]))]
+        for c0 in range(0, order.size, ncol_max):
+            cols = order[c0 : c0 + ncol_max]
+            # distinct (frequency, beam class) beams of this chunk
+            keys = {}
+            bi = np.empty(cols.size, dtype=np.int32)
+            bj = np.empty(cols.size, dtype=np.int32)
+            for k, c in enumerate(cols):
+                fi_, fj_ = pairs[b_list[c]]
+                for which, feed in ((bi, fi_), (bj, fj_)):
+                    key = (int(f_list[c]), int(cls[feed]))
+                    if key not in keys:
+                        keys[key] = len(keys)
+                    which[k] = keys[key]
+            ncomp = 2 if pol else 1
+            beams = ctx.empty((len(keys), npix * ncomp), np.float64)
+            for (f, bc), idx in keys.items():
+                kind, tab, fwhm_ns = tel.beam_spec(bc, f)
+                ctx.bt_beam_cyl(int(nside), cth, sth, frame, kind, tab, fwhm_ns, beams[idx])
+            uv = tel.baselines[b_list[cols]] / wl[f_list[cols]][:, None]
+            maps = ctx.empty((cols.size, P, npix), np.complex128)
+            ctx.bt_maps(int(nside), cth, sth, frame, pol, beams, uv, bi, bj, maps)
+            ctx.bt_sht(int(nside), cth, sth, pol, lside, mmax, int(lmax_bf[cols].max()), F, B, row_f[cols],
+                       row_b[cols], lmax_bf[cols], maps, beam_m)
+            del maps, beams
+    return beam_m
+
+
+def beam_m_all(tel, ctx=None, max_bytes=6 << 30):
+    """Device tensor (mmax+1, F, 2, B, P, L) of every m-block of the telescope (zeros for
+    skipped frequencies / baselines, like the reference's beam_m accessor)."""
+    ctx = ctx or get_context()
+    F, B, P, L = tel.nfreq, tel.nbase, tel.num_pol_sky, tel.lmax + 1
+    beam_m = ctx.zeros((tel.mmax + 1, F, 2, B, P, L), np.complex128)
+    ff, bb = np.meshgrid(tel.included_freq, tel.included_baseline, indexing="ij")
+    fill_beam_m(tel, beam_m, ff.ravel(), bb.ravel(), ctx=ctx, max_bytes=max_bytes)
+    npol_inc = len(tel.included_pol)
+    if npol_inc < P:
+        beam_m[:, :, :, :, npol_inc:, :] = 0  # skip_pol / skip_V leave zero entries (telescope.py:1298-1314)
+    return beam_m
+
+
+def transfer_matrices(tel, bl, fi, global_lmax=True, ctx=None):
+    """numpy (nfb, P, lside+1, 2*lside+1): the reference's ``transfer_matrices`` layout,
+    rebuilt from the m-ordered device result (m >= 0 in column m, m < 0 wrapped to the end)."""
+    ctx = ctx or get_context()
+    lside = tel.lmax
+    P, L = tel.num_pol_sky, lside + 1
+    nfb = bl.size
+    bm = ctx.zeros((lside + 1, nfb, 2, 1, P, L), np.complex128)
+    fill_beam_m(tel, bm, fi, bl, row_f=np.arange(nfb), row_b=np.zeros(nfb, dtype=np.int64), F=nfb, B=1, mmax=lside,
+                ctx=ctx)
+    h = bm.cpu().numpy()  # (m, nfb, 2, 1, P, L)
+    out = np.zeros((nfb, P, L, 2 * lside + 1), dtype=np.complex128)
+    for m in range(lside + 1):
+        out[:, :, :, m] = h[m, :, 0, 0]
+        if m > 0:
+            out[:, :, :, -m] = (-1) ** m * h[m, :, 1, 0].conj()
+    return out

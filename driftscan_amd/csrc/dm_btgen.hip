@@ -1,0 +1,503 @@
+// dm_btgen.hip — beam-transfer matrix generation on the GPU (gfx950).
+//
+// Replaces, for cylinder telescopes:
+//   drift/telescope/cylbeam.py:101-212          beam_amp / beam_x / beam_y on HEALPix pixels
+//   drift/util/_fast_tools.pyx:18-164           fringe, _construct_pol_real (the OpenMP pixel kernels)
+//   drift/core/telescope.py:1156-1193, 1268-1316  _beam_map_single, _transfer_single (SHT via cora->healpy)
+//   drift/core/telescope.py:755-830             transfer_matrices
+//   drift/core/beamtransfer.py:620-624, :663    +/-m fold and compact m-ordered layout
+//
+// Pipeline for one group of (frequency, baseline) columns sharing a HEALPix nside:
+//   1. bt_beam     field pattern of every (frequency, beam class) on the pixel centres   (HBM-bound, sincos+exp)
+//   2. bt_omega    beam solid angles  (4 pi / n) sum h |b|^2                              (reduction)
+//   3. bt_maps     h * fringe * (b_i x b_j) / sqrt(O_i O_j) -> 1 or 4 Stokes maps         (HBM-bound)
+//   4. ring DFT    G[m, ring, col] = sum_j map[col, pix(ring, j)] e^{+i m phi_j}, -mmax <= m <= mmax
+//                  one grouped ZGEMM per ring against a twiddle table                      (MFMA)
+//   5. Legendre    beam_m[m][f, +/-, b, p, l] = sum_ring lambda_lm(ring) G[+/-m, ring, col]
+//                  real x complex grouped GEMM per (m, f, sign, Stokes term)               (MFMA)
+//      The reference's `conj(SHT(conj(map)))` (telescope.py:1189-1191) turns e^{-im phi} into
+//      e^{+im phi}; the (-1)^m conj fold of the -m half (beamtransfer.py:622) turns into
+//      "conjugate G[-m]" with the SAME real Legendre matrices as +m, so step 5 writes the
+//      reference's (F, 2, B, P, L) beam_m layout directly — no fold pass, no transpose.
+//   6. bt_mask     zero l > lmax(baseline, frequency) (telescope.py:792-802)
+//
+// The SHT itself is restated from the published HEALPix algorithm (equal weights,
+// no iterations): see oracle/btgen.py for the pinning status of that boundary.
+#include "dm_common.h"
+#include "dm_kernels.h"
+#include "../../include/driftmi.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+
+struct ring_geo {
+  const double* cth;   // cos(theta) per ring
+  const double* sth;   // sin(theta) per ring
+  const double* phi0;  // phi of first pixel
+  const int* nphi;     // pixels in ring
+  const int* start;    // first pixel index
+  int nring;
+  int npix;
+};
+
+__device__ __forceinline__ int ring_of_pixel(const ring_geo& g, int pix) {
+  // binary search over ring starts
+  int lo = 0, hi = g.nring - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (g.start[mid] <= pix) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+struct frame3 {
+  double x[3], y[3], z[3];  // East, North, up (telescope frame in sky cartesian coordinates)
+};
+
+// natural cubic spline evaluation with searchsorted(side="left") interval choice
+__device__ __forceinline__ double spline_eval(const double* __restrict__ x, const double* __restrict__ y,
+                                              const double* __restrict__ y2, int n, double xv) {
+  int lo = 0, hi = n;  // first index with x[idx] >= xv
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (x[mid] < xv) lo = mid + 1; else hi = mid;
+  }
+  int khi = min(max(lo, 1), n - 1);
+  int klo = khi - 1;
+  double h = x[khi] - x[klo];
+  double a = (x[khi] - xv) / h;
+  double b = (xv - x[klo]) / h;
+  return a * y[klo] + b * y[khi] + ((a * a * a - a) * y2[klo] + (b * b * b - b) * y2[khi]) * (h * h) / 6.0;
+}
+
+// kind 0: unpolarised amplitude (1 component); 1: X dipole; 2: Y dipole (2 components theta, phi)
+__global__ void bt_beam_kernel(ring_geo g, frame3 fr, int kind, const double* __restrict__ tx,
+                               const double* __restrict__ ty, const double* __restrict__ ty2, int ntab,
+                               double alpha_ns, double* __restrict__ out) {
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= g.npix) return;
+  const int r = ring_of_pixel(g, pix);
+  const int j = pix - g.start[r];
+  const double phi = g.phi0[r] + 2.0 * kPi * (double)j / (double)g.nphi[r];
+  double sp, cp;
+  sincos(phi, &sp, &cp);
+  const double st = g.sth[r], ct = g.cth[r];
+  const double n0 = st * cp, n1 = st * sp, n2 = ct;
+  const double dz = n0 * fr.z[0] + n1 * fr.z[1] + n2 * fr.z[2];
+  const double hz = dz > 0.0 ? 1.0 : 0.0;
+  const double dx = n0 * fr.x[0] + n1 * fr.x[1] + n2 * fr.x[2];
+  const double dy = n0 * fr.y[0] + n1 * fr.y[1] + n2 * fr.y[2];
+  const double ew = spline_eval(tx, ty, ty2, ntab, dx);
+  const double s2 = dy * dy;
+  const double ns = exp(-alpha_ns * s2 / (1.0 - s2 + 1e-100));
+  const double amp = ew * ns * hz;
+  if (kind == 0) {
+    out[pix] = amp;
+    return;
+  }
+  // dipole projected on (thetahat, phihat), normalised to unit length (cylbeam.polpattern)
+  const double* dip = (kind == 1) ? fr.x : fr.y;
+  const double t0 = ct * cp, t1 = ct * sp, t2 = -st;
+  const double p0 = -sp, p1 = cp;
+  double pt = t0 * dip[0] + t1 * dip[1] + t2 * dip[2];
+  double pp = p0 * dip[0] + p1 * dip[1];
+  double nrm = hypot(pt, pp);
+  if (nrm == 0.0) nrm = 1.0;
+  out[2 * (size_t)pix] = amp * pt / nrm;
+  out[2 * (size_t)pix + 1] = amp * pp / nrm;
+}
+
+// omega[b] = (4 pi / npix) sum_pix h |beam_b|^2 ; one block per beam (beams already carry h)
+__global__ void bt_omega_kernel(ring_geo g, frame3 fr, const double* __restrict__ beams, int ncomp, size_t bstride,
+                                double* __restrict__ omega) {
+  __shared__ double red[4];
+  const double* b = beams + (size_t)blockIdx.x * bstride;
+  double s = 0.0;
+  for (int pix = threadIdx.x; pix < g.npix; pix += blockDim.x) {
+    // the reference multiplies by the horizon again; beams are zero below it already, and h in {0,1}
+    double v = 0.0;
+    for (int c = 0; c < ncomp; ++c) {
+      double x = b[(size_t)pix * ncomp + c];
+      v += x * x;
+    }
+    s += v;
+  }
+  s = dm_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) omega[blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) * 4.0 * kPi / (double)g.npix;
+}
+
+// maps[col][p][pix]
+__global__ void bt_maps_kernel(ring_geo g, frame3 fr, int polarised, int ncol, const double* __restrict__ uv,
+                               const int* __restrict__ bi, const int* __restrict__ bj,
+                               const double* __restrict__ beams, size_t bstride, const double* __restrict__ omega,
+                               cplx* __restrict__ maps) {
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  const int col = blockIdx.y;
+  if (pix >= g.npix) return;
+  const int r = ring_of_pixel(g, pix);
+  const int j = pix - g.start[r];
+  const double phi = g.phi0[r] + 2.0 * kPi * (double)j / (double)g.nphi[r];
+  double sp, cp;
+  sincos(phi, &sp, &cp);
+  const double st = g.sth[r], ct = g.cth[r];
+  const double n0 = st * cp, n1 = st * sp, n2 = ct;
+  const double hz = (n0 * fr.z[0] + n1 * fr.z[1] + n2 * fr.z[2]) > 0.0 ? 1.0 : 0.0;
+  // uv3 = u * East + v * North
+  const double u = uv[2 * col], v = uv[2 * col + 1];
+  const double du = n0 * (u * fr.x[0] + v * fr.y[0]) + n1 * (u * fr.x[1] + v * fr.y[1]) + n2 * (u * fr.x[2] + v * fr.y[2]);
+  double sf, cf;
+  sincos(2.0 * kPi * du, &sf, &cf);
+  const int ib = bi[col], jb = bj[col];
+  const double pre = hz / sqrt(omega[ib] * omega[jb]);
+  const double tre = pre * cf, tim = pre * sf;
+  if (!polarised) {
+    const double bb = beams[(size_t)ib * bstride + pix] * beams[(size_t)jb * bstride + pix];
+    maps[(size_t)col * g.npix + pix] = make_double2(tre * bb, tim * bb);
+  } else {
+    const double* a = beams + (size_t)ib * bstride + 2 * (size_t)pix;
+    const double* b = beams + (size_t)jb * bstride + 2 * (size_t)pix;
+    const double a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+    const double sI = a0 * b0 + a1 * b1, sQ = a0 * b0 - a1 * b1, sU = a0 * b1 + a1 * b0, sV = a0 * b1 - a1 * b0;
+    cplx* m = maps + (size_t)col * 4 * g.npix + pix;
+    m[0] = make_double2(tre * sI, tim * sI);
+    m[(size_t)g.npix] = make_double2(tre * sQ, tim * sQ);
+    m[2 * (size_t)g.npix] = make_double2(tre * sU, tim * sU);
+    m[3 * (size_t)g.npix] = make_double2(-tim * sV, tre * sV);  // 1j * tc * sV
+  }
+}
+
+// tw[pix][mm] laid out per ring as (2*mmax+1) x nphi row-major: tw[off_r + mm*nphi + j] = exp(i (mm - mmax) phi_j)
+__global__ void bt_twiddle_kernel(ring_geo g, int mmax, const size_t* __restrict__ toff, cplx* __restrict__ tw) {
+  const int r = blockIdx.y;
+  const int nphi = g.nphi[r];
+  const int nm = 2 * mmax + 1;
+  const size_t tot = (size_t)nm * nphi;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
+    const int mm = (int)(idx / nphi), j = (int)(idx % nphi);
+    const int m = mm - mmax;
+    // reduce the argument exactly: m*j mod nphi keeps the phase in [0, 2 pi)
+    const long long mj = ((long long)m * j) % nphi;
+    const double ph = (double)m * g.phi0[r] + 2.0 * kPi * (double)mj / (double)nphi;
+    double s, c;
+    sincos(ph, &s, &c);
+    tw[toff[r] + idx] = make_double2(c, s);
+  }
+}
+
+// Legendre tables: lam[loff[m] + (l-m)*nring + r] = w * lambda_lm(theta_r), same for W and X (polarised)
+__global__ void bt_legendre_kernel(ring_geo g, int lmax, int mmax, double w, const size_t* __restrict__ loff,
+                                   double* __restrict__ lam, double* __restrict__ Wt, double* __restrict__ Xt) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = blockIdx.y;
+  if (r >= g.nring || m > mmax || m > lmax) return;
+  const double z = g.cth[r], st = g.sth[r];
+  const double s2 = st * st;
+  double logpre = 0.5 * (log(2.0 * m + 1.0) - log(4.0 * kPi));
+  for (int k = 1; k <= m; ++k) logpre += 0.5 * log((2.0 * k - 1.0) / (2.0 * k));
+  double lmm = (m > 0) ? exp(logpre + (double)m * log(st)) : exp(logpre);
+  if (m & 1) lmm = -lmm;
+  double* out = lam + loff[m];
+  const size_t nr = g.nring;
+  double pm2 = 0.0, pm1 = lmm;  // lambda_{l-2}, lambda_{l-1} as l advances
+  out[r] = w * lmm;
+  if (Wt) {
+    double* wo = Wt + loff[m];
+    double* xo = Xt + loff[m];
+    // l = m term (needs lambda_{m-1,m} = 0)
+    if (m >= 2) {
+      const double l = m;
+      const double nl = 2.0 * sqrt(1.0 / ((l - 1.0) * l * (l + 1.0) * (l + 2.0)));
+      wo[r] = -w * nl * (-((l - l * l) / s2 + 0.5 * l * (l - 1.0)) * lmm);
+      xo[r] = w * nl * (l / s2) * ((l - 1.0) * z * lmm);
+    } else {
+      wo[r] = 0.0;
+      xo[r] = 0.0;
+    }
+  }
+  for (int l = m + 1; l <= lmax; ++l) {
+    double cur;
+    if (l == m + 1) {
+      cur = sqrt(2.0 * m + 3.0) * z * pm1;
+    } else {
+      const double a = sqrt((4.0 * l * l - 1.0) / ((double)l * l - (double)m * m));
+      const double b = sqrt(((l - 1.0) * (l - 1.0) - (double)m * m) / (4.0 * (l - 1.0) * (l - 1.0) - 1.0));
+      cur = a * (z * pm1 - b * pm2);
+    }
+    out[(size_t)(l - m) * nr + r] = w * cur;
+    if (Wt) {
+      double wv = 0.0, xv = 0.0;
+      if (l >= 2) {
+        const double dl = l, dm = m;
+        const double nl = 2.0 * sqrt(1.0 / ((dl - 1.0) * dl * (dl + 1.0) * (dl + 2.0)));
+        const double c = sqrt((2.0 * dl + 1.0) / (2.0 * dl - 1.0) * (dl * dl - dm * dm));
+        wv = -nl * (-((dl - dm * dm) / s2 + 0.5 * dl * (dl - 1.0)) * cur + c * z / s2 * pm1);
+        xv = nl * (dm / s2) * ((dl - 1.0) * z * cur - c * pm1);
+      }
+      (Wt + loff[m])[(size_t)(l - m) * nr + r] = w * wv;
+      (Xt + loff[m])[(size_t)(l - m) * nr + r] = w * xv;
+    }
+    pm2 = pm1;
+    pm1 = cur;
+  }
+}
+
+// zero l > lmax_col for the rows written by this group
+__global__ void bt_mask_kernel(cplx* __restrict__ beam_m, int F, int B, int P, int L, int mmax, int ncol,
+                               const int* __restrict__ colf, const int* __restrict__ colb,
+                               const int* __restrict__ collmax) {
+  const int col = blockIdx.y;
+  const int m = blockIdx.z;
+  const int lm = collmax[col];
+  const int f = colf[col], b = colb[col];
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over (s, p, l)
+  const int tot = 2 * P * L;
+  if (idx >= tot) return;
+  const int l = idx % L, p = (idx / L) % P, s = idx / (L * P);
+  if (l <= lm) return;
+  beam_m[((((size_t)m * F + f) * 2 + s) * B + b) * P * L + (size_t)p * L + l] = make_double2(0.0, 0.0);
+}
+
+struct geo_host {
+  ring_geo g;
+  std::vector<double> cth, sth, phi0;
+  std::vector<int> nphi, start;
+};
+
+int upload_geo(dm_ctx* ctx, int nside, const double* cth, const double* sth, geo_host& gh) {
+  const int nring = 4 * nside - 1;
+  gh.cth.assign(cth, cth + nring);
+  gh.sth.assign(sth, sth + nring);
+  gh.phi0.resize(nring);
+  gh.nphi.resize(nring);
+  gh.start.resize(nring);
+  int acc = 0;
+  for (int r = 0; r < nring; ++r) {
+    const int i = r + 1;
+    int np_;
+    double p0;
+    if (i < nside) { np_ = 4 * i; p0 = kPi / (4.0 * i); }
+    else if (i <= 3 * nside) { np_ = 4 * nside; p0 = (((i + nside) & 1) == 0) ? kPi / (4.0 * nside) : 0.0; }
+    else { const int j = 4 * nside - i; np_ = 4 * j; p0 = kPi / (4.0 * j); }
+    gh.nphi[r] = np_;
+    gh.phi0[r] = p0;
+    gh.start[r] = acc;
+    acc += np_;
+  }
+  gh.g.nring = nring;
+  gh.g.npix = acc;
+  gh.g.cth = dm_ws_upload(ctx, gh.cth);
+  gh.g.sth = dm_ws_upload(ctx, gh.sth);
+  gh.g.phi0 = dm_ws_upload(ctx, gh.phi0);
+  gh.g.nphi = dm_ws_upload(ctx, gh.nphi);
+  gh.g.start = dm_ws_upload(ctx, gh.start);
+  if (!gh.g.cth || !gh.g.sth || !gh.g.phi0 || !gh.g.nphi || !gh.g.start) return DM_ENOMEM;
+  return DM_OK;
+}
+
+frame3 make_frame(const double* xhat, const double* yhat, const double* zhat) {
+  frame3 f;
+  for (int i = 0; i < 3; ++i) { f.x[i] = xhat[i]; f.y[i] = yhat[i]; f.z[i] = zhat[i]; }
+  return f;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Cylinder field pattern on the pixel centres of a HEALPix map.
+//   ring_cth/ring_sth (4 nside - 1) host: cos/sin of the ring colatitudes (host geometry)
+//   frame_host (9): xhat (East), yhat (North), zhat (zenith) in sky cartesian coordinates
+//   kind 0: amplitude only (npix doubles out); 1 / 2: X / Y dipole (npix x 2 doubles out)
+//   tab_* (ntab) host: knots of the E-W Fraunhofer pattern spline (x, y, y'')
+//   fwhm_ns: FWHM of the exptan N-S pattern
+int dm_bt_beam_cyl(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host,
+                   const double* frame_host, int kind, const double* tab_x_host, const double* tab_y_host,
+                   const double* tab_y2_host, int ntab, double fwhm_ns, double* out_dev) {
+  if (!ctx) return DM_EARG;
+  DM_ARG(ctx, nside > 0 && ring_cth_host && ring_sth_host && frame_host && kind >= 0 && kind <= 2 && tab_x_host &&
+                  tab_y_host && tab_y2_host && ntab >= 2 && out_dev);
+  const size_t mark = dm_ws_mark(ctx);
+  geo_host gh;
+  DM_TRY(upload_geo(ctx, nside, ring_cth_host, ring_sth_host, gh));
+  std::vector<double> tx(tab_x_host, tab_x_host + ntab), ty(tab_y_host, tab_y_host + ntab),
+      ty2(tab_y2_host, tab_y2_host + ntab);
+  double* dx = dm_ws_upload(ctx, tx);
+  double* dy = dm_ws_upload(ctx, ty);
+  double* dy2 = dm_ws_upload(ctx, ty2);
+  if (!dx || !dy || !dy2) return DM_ENOMEM;
+  const double th = tan(fwhm_ns / 2.0);
+  const double alpha = log(2.0) / (2.0 * th * th);
+  frame3 fr = make_frame(frame_host, frame_host + 3, frame_host + 6);
+  hipLaunchKernelGGL(bt_beam_kernel, dim3((gh.g.npix + 255) / 256), dim3(256), 0, ctx->stream, gh.g, fr, kind, dx, dy,
+                     dy2, ntab, alpha, out_dev);
+  DM_HIP(ctx, hipGetLastError());
+  dm_ws_release(ctx, mark);
+  return DM_OK;
+}
+
+// Visibility response maps of `ncol` (frequency, baseline) columns.
+//   beams_dev: nbeam maps of npix*ncomp doubles (ncomp = 2 if polarised else 1), as written by dm_bt_beam_cyl
+//   uv_host (ncol x 2): baseline / wavelength;  bi_host, bj_host (ncol): beam index of the two feeds
+//   maps_dev out: (ncol, P, npix) complex128, P = 4 (I,Q,U,V) if polarised else 1
+int dm_bt_maps(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host,
+               const double* frame_host, int polarised, int nbeam, const double* beams_dev, int ncol,
+               const double* uv_host, const int* bi_host, const int* bj_host, void* maps_dev) {
+  if (!ctx) return DM_EARG;
+  DM_ARG(ctx, nside > 0 && ring_cth_host && ring_sth_host && frame_host && nbeam > 0 && beams_dev && ncol >= 0 &&
+                  uv_host && bi_host && bj_host && maps_dev);
+  if (ncol == 0) return DM_OK;
+  const size_t mark = dm_ws_mark(ctx);
+  geo_host gh;
+  DM_TRY(upload_geo(ctx, nside, ring_cth_host, ring_sth_host, gh));
+  const int ncomp = polarised ? 2 : 1;
+  const size_t bstride = (size_t)gh.g.npix * ncomp;
+  frame3 fr = make_frame(frame_host, frame_host + 3, frame_host + 6);
+  double* omega = dm_ws_alloc_t<double>(ctx, nbeam);
+  std::vector<double> uv(uv_host, uv_host + 2 * (size_t)ncol);
+  std::vector<int> bi(bi_host, bi_host + ncol), bj(bj_host, bj_host + ncol);
+  for (int c = 0; c < ncol; ++c) DM_ARG(ctx, bi[c] >= 0 && bi[c] < nbeam && bj[c] >= 0 && bj[c] < nbeam);
+  double* duv = dm_ws_upload(ctx, uv);
+  int* dbi = dm_ws_upload(ctx, bi);
+  int* dbj = dm_ws_upload(ctx, bj);
+  if (!omega || !duv || !dbi || !dbj) return DM_ENOMEM;
+  hipLaunchKernelGGL(bt_omega_kernel, dim3(nbeam), dim3(256), 0, ctx->stream, gh.g, fr, beams_dev, ncomp, bstride,
+                     omega);
+  hipLaunchKernelGGL(bt_maps_kernel, dim3((gh.g.npix + 255) / 256, ncol), dim3(256), 0, ctx->stream, gh.g, fr,
+                     polarised, ncol, duv, dbi, dbj, beams_dev, bstride, omega, reinterpret_cast<cplx*>(maps_dev));
+  DM_HIP(ctx, hipGetLastError());
+  dm_ws_release(ctx, mark);
+  return DM_OK;
+}
+
+// Spherical-harmonic transform of the maps of one nside group straight into the m-ordered
+// beam_m blocks: beam_m_dev is (mmax+1, F, 2, B, P, L) complex128, L = lside + 1; the rows
+// (f, :, b, :, :) of the group's columns are overwritten (zero for l < m and l > lmax_col).
+//   lmax_grp: largest per-column lmax in the group (<= lside) — tables are built up to it
+int dm_bt_sht(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised,
+              int lside, int mmax, int lmax_grp, int F, int B, int ncol, const int* col_f_host,
+              const int* col_b_host, const int* col_lmax_host, const void* maps_dev, void* beam_m_dev) {
+  if (!ctx) return DM_EARG;
+  DM_ARG(ctx, nside > 0 && ring_cth_host && ring_sth_host && lside >= 0 && mmax >= 0 && lmax_grp >= 0 &&
+                  lmax_grp <= lside && F > 0 && B > 0 && ncol >= 0 && col_f_host && col_b_host && col_lmax_host &&
+                  maps_dev && beam_m_dev);
+  if (ncol == 0) return DM_OK;
+  const size_t mark = dm_ws_mark(ctx);
+  geo_host gh;
+  DM_TRY(upload_geo(ctx, nside, ring_cth_host, ring_sth_host, gh));
+  const int P = polarised ? 4 : 1;
+  const int L = lside + 1;
+  const int nring = gh.g.nring, npix = gh.g.npix;
+  const int mtop = std::min(mmax, lmax_grp);  // no (l, m) content above the group's band limit
+  const int nm = 2 * mtop + 1;
+  const int ncp = ncol * P;  // map columns
+
+  // ---- twiddles and ring DFT: G[mm][ring][colp]
+  std::vector<size_t> toff(nring);
+  size_t ttot = 0;
+  for (int r = 0; r < nring; ++r) { toff[r] = ttot; ttot += (size_t)nm * gh.nphi[r]; }
+  size_t* d_toff = dm_ws_upload(ctx, toff);
+  cplx* tw = dm_ws_alloc_t<cplx>(ctx, ttot);
+  cplx* G = dm_ws_alloc_t<cplx>(ctx, (size_t)nm * nring * ncp);
+  if (!d_toff || !tw || !G) return DM_ENOMEM;
+  hipLaunchKernelGGL(bt_twiddle_kernel, dim3(8, nring), dim3(256), 0, ctx->stream, gh.g, mtop, d_toff, tw);
+  {
+    const cplx* maps = reinterpret_cast<const cplx*>(maps_dev);
+    std::vector<dm_gemm_desc> g;
+    g.reserve(nring);
+    for (int r = 0; r < nring; ++r) {
+      // C[mm][colp] (ld = nring*ncp, origin at ring r) = tw_r[mm][j] * maps[colp][start_r + j]
+      g.push_back(dm_gemm_make(tw + toff[r], gh.nphi[r], 1, false, maps + gh.start[r], 1, npix, false,
+                               G + (size_t)r * ncp, nring * ncp, nm, ncp, gh.nphi[r]));
+    }
+    DM_TRY(dm_gemm_grouped_launch(ctx, g));
+  }
+
+  // ---- Legendre tables up to lmax_grp
+  std::vector<size_t> loff(mtop + 1);
+  size_t ltot = 0;
+  for (int m = 0; m <= mtop; ++m) { loff[m] = ltot; ltot += (size_t)(lmax_grp + 1 - m) * nring; }
+  size_t* d_loff = dm_ws_upload(ctx, loff);
+  double* lam = dm_ws_alloc_t<double>(ctx, ltot);
+  double* Wt = polarised ? dm_ws_alloc_t<double>(ctx, ltot) : nullptr;
+  double* Xt = polarised ? dm_ws_alloc_t<double>(ctx, ltot) : nullptr;
+  if (!d_loff || !lam || (polarised && (!Wt || !Xt))) return DM_ENOMEM;
+  hipLaunchKernelGGL(bt_legendre_kernel, dim3((nring + 63) / 64, mtop + 1), dim3(64), 0, ctx->stream, gh.g, lmax_grp,
+                     mtop, 4.0 * kPi / (double)npix, d_loff, lam, Wt, Xt);
+  DM_HIP(ctx, hipGetLastError());
+
+  // ---- clear the destination rows of this group for every m (then GEMMs fill l in [m, lmax_grp])
+  cplx* bm = reinterpret_cast<cplx*>(beam_m_dev);
+  std::vector<int> cf(col_f_host, col_f_host + ncol), cb(col_b_host, col_b_host + ncol),
+      cl(col_lmax_host, col_lmax_host + ncol);
+  for (int c = 0; c < ncol; ++c) DM_ARG(ctx, cf[c] >= 0 && cf[c] < F && cb[c] >= 0 && cb[c] < B && cl[c] <= lmax_grp);
+  int* d_cf = dm_ws_upload(ctx, cf);
+  int* d_cb = dm_ws_upload(ctx, cb);
+  int* d_cl = dm_ws_upload(ctx, cl);
+  std::vector<int> neg1(ncol, -1);
+  int* d_neg = dm_ws_upload(ctx, neg1);
+  if (!d_cf || !d_cb || !d_cl || !d_neg) return DM_ENOMEM;
+  hipLaunchKernelGGL(bt_mask_kernel, dim3((2 * P * L + 255) / 256, ncol, mmax + 1), dim3(256), 0, ctx->stream, bm, F, B,
+                     P, L, mmax, ncol, d_cf, d_cb, d_neg);
+
+  // ---- Legendre products.  Columns of a group are arbitrary (f, b) pairs, so one GEMM row per
+  // column would be wasteful; instead consecutive columns with the same f and consecutive b are
+  // merged into runs (the usual case: all baselines of a frequency in order).
+  struct run { int c0, n, f, b0; };
+  std::vector<run> runs;
+  for (int c = 0; c < ncol;) {
+    int e = c + 1;
+    while (e < ncol && cf[e] == cf[c] && cb[e] == cb[e - 1] + 1) ++e;
+    runs.push_back(run{c, e - c, cf[c], cb[c]});
+    c = e;
+  }
+  // Terms whose outputs accumulate (E and B each take two products) go in separate launches
+  // so that no two tiles of one launch touch the same C entries.
+  for (int pass = 0; pass < (polarised ? 2 : 1); ++pass) {
+    std::vector<dm_gemm_desc> g;
+    for (int m = 0; m <= mtop; ++m) {
+      const int Lm = lmax_grp + 1 - m;
+      for (int s = 0; s < 2; ++s) {
+        if (m == 0 && s == 1) continue;  // the -m slot of m = 0 stays zero (beamtransfer.py:624)
+        const int mm = (s == 0) ? (mtop + m) : (mtop - m);
+        const cplx* Gm = G + (size_t)mm * nring * ncp;
+        for (const run& rn : runs) {
+          cplx* out = bm + ((((size_t)m * F + rn.f) * 2 + s) * B + rn.b0) * P * L + m;
+          auto add = [&](int pa, const double* tab, int pout, double are, double aim, double beta) {
+            dm_gemm_desc d = dm_gemm_make(Gm + (size_t)rn.c0 * P + pa, P, ncp, s == 1, tab + loff[m], 1, nring, false,
+                                          out + (size_t)pout * L, P * L, rn.n, Lm, nring, are, beta, nullptr,
+                                          DM_GEMM_B_REAL);
+            d.alpha_im = aim;
+            g.push_back(d);
+          };
+          if (!polarised) {
+            add(0, lam, 0, 1.0, 0.0, 0.0);
+          } else if (pass == 0) {
+            add(0, lam, 0, 1.0, 0.0, 0.0);  // T = lam . G^I
+            add(3, lam, 3, 1.0, 0.0, 0.0);  // V = lam . G^V
+            add(1, Wt, 1, 1.0, 0.0, 0.0);   // E  = W . G^Q ...
+            add(2, Wt, 2, 1.0, 0.0, 0.0);   // B  = W . G^U ...
+          } else {
+            add(2, Xt, 1, 0.0, -1.0, 1.0);  // E -= i X . G^U
+            add(1, Xt, 2, 0.0, 1.0, 1.0);   // B += i X . G^Q
+          }
+        }
+      }
+    }
+    DM_TRY(dm_gemm_grouped_launch(ctx, g));
+  }
+  // ---- per-column band limit
+  hipLaunchKernelGGL(bt_mask_kernel, dim3((2 * P * L + 255) / 256, ncol, mmax + 1), dim3(256), 0, ctx->stream, bm, F, B,
+                     P, L, mmax, ncol, d_cf, d_cb, d_cl);
+  DM_HIP(ctx, hipGetLastError());
+  DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  dm_ws_release(ctx, mark);
+  return DM_OK;
+}
+
+}  // extern "C"

@@ -51,8 +51,8 @@ __global__ __launch_bounds__(256) void zgemm_grouped_kernel(const dm_gemm_desc* 
   const bool conjA = d.flags & DM_GEMM_CONJ_A;
   const bool conjB = d.flags & DM_GEMM_CONJ_B;
   // loader mapping: walk the contiguous direction with consecutive lanes
-  const bool a_kfast = (d.csA == 1) || (d.rsA != 1);
-  const bool b_kfast = (d.rsB == 1) && (d.csB != 1);
+  const bool a_kfast = d.csA <= d.rsA;
+  const bool b_kfast = d.rsB <= d.csB;
 
   dm_f64x4 acc_re[2][2], acc_im[2][2];
 #pragma unroll
@@ -170,7 +170,8 @@ __global__ __launch_bounds__(256) void zgemm_grouped_kernel(const dm_gemm_desc* 
         int gn = n0 + wn * 32 + j * 16 + ccol;
         if (gm < d.M && gn < d.N) {
           size_t off = (size_t)gm * d.ldc + gn;
-          cplx v = make_double2(d.alpha * acc_re[i][j][r], d.alpha * acc_im[i][j][r]);
+          const double are = acc_re[i][j][r], aim = acc_im[i][j][r];
+          cplx v = make_double2(d.alpha * are - d.alpha_im * aim, d.alpha * aim + d.alpha_im * are);
           if (d.beta != 0.0) {
             cplx c = C[off];
             v.x += d.beta * c.x;

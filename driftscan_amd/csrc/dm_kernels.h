@@ -24,6 +24,7 @@ struct dm_gemm_desc {
   int rsA, csA, rsB, csB, ldc;
   int flags;
   double alpha, beta;
+  double alpha_im;  // imaginary part of alpha (0 for the usual real scaling)
 };
 
 struct dm_gemm_tile {
@@ -40,7 +41,7 @@ static inline dm_gemm_desc dm_gemm_make(const cplx* A, int rsA, int csA, bool co
   d.M = M; d.N = N; d.K = K;
   d.rsA = rsA; d.csA = csA; d.rsB = rsB; d.csB = csB; d.ldc = ldc;
   d.flags = (conjA ? DM_GEMM_CONJ_A : 0) | (conjB ? DM_GEMM_CONJ_B : 0) | extra_flags;
-  d.alpha = alpha; d.beta = beta;
+  d.alpha = alpha; d.beta = beta; d.alpha_im = 0.0;
   return d;
 }
 

@@ -1,0 +1,112 @@
+"""Process-level parallelism over independent m-blocks.
+
+The reference distributes m over MPI ranks through ``caput.mpiutil``
+(drift/core/beamtransfer.py:720, kltransform.py:496, :21-46).  Here one process
+drives one GPU and the ranks talk through ``torch.distributed`` — backend "nccl"
+(= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.  m-blocks need no data-path
+collective at all: only small spectra are gathered to rank 0 and the Fisher
+matrix is all-reduced, exactly the reference's pattern.
+"""
+import os
+
+import numpy as np
+
+
+def _dist():
+    import torch.distributed as dist
+
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+def rank():
+    d = _dist()
+    return d.get_rank() if d else 0
+
+
+def size():
+    d = _dist()
+    return d.get_world_size() if d else 1
+
+
+def rank0():
+    return rank() == 0
+
+
+def barrier():
+    d = _dist()
+    if d:
+        d.barrier()
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* if a launcher set them."""
+    import torch
+    import torch.distributed as dist
+
+    if dist.is_initialized() or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    dist.init_process_group(backend=backend)
+
+
+def partition(items, costs=None):
+    """The items this rank owns.
+
+    Without costs: the reference's contiguous split (``partition_list_mpi``).  With
+    costs: longest-processing-time greedy assignment — the cost of an m-block falls
+    steeply with m, so the contiguous split leaves most ranks idle at the end; any
+    assignment yields the same products, so this is a pure scheduling choice.
+    """
+    items = list(items)
+    n, r = size(), rank()
+    if n == 1:
+        return items
+    if costs is None:
+        base, rem = divmod(len(items), n)
+        start = r * base + min(r, rem)
+        return items[start : start + base + (1 if r < rem else 0)]
+    order = np.argsort(-np.asarray(costs, dtype=np.float64), kind="stable")
+    load = np.zeros(n)
+    mine = []
+    for idx in order:
+        tgt = int(np.argmin(load))
+        load[tgt] += costs[idx]
+        if tgt == r:
+            mine.append(items[idx])
+    return sorted(mine, key=items.index)
+
+
+def gather_objects(obj):
+    """Gather picklable objects to rank 0 (list over ranks there, None elsewhere)."""
+    d = _dist()
+    if not d:
+        return [obj]
+    out = [None] * size() if rank0() else None
+    d.gather_object(obj, out, dst=0)
+    return out
+
+
+def bcast_object(obj):
+    d = _dist()
+    if not d:
+        return obj
+    box = [obj]
+    d.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def allreduce_sum(arr):
+    """Sum a numpy float64 array over ranks (the Fisher assembly, psestimation.py:506-507)."""
+    d = _dist()
+    if not d:
+        return arr
+    import torch
+
+    t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64))
+    if d.get_backend() == "nccl":
+        t = t.cuda()
+    d.all_reduce(t)
+    return t.cpu().numpy()

@@ -133,6 +133,42 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
                 double* evals_dev, const int64_t* evoff_host, void* evecs_dev, double* add_const_host,
                 int* sweeps_host);
 
+/* ---- beam-transfer generation (cylinder telescopes) --------------------------- */
+/* Host geometry shared by the three calls below: ring_cth_host / ring_sth_host hold
+ * cos / sin of the colatitude of the 4*nside-1 HEALPix rings; frame_host (9 doubles)
+ * holds xhat (East), yhat (North), zhat (zenith) in sky cartesian coordinates.
+ *
+ * dm_bt_beam_cyl: field pattern of one (frequency, beam class) on all pixel centres.
+ *   kind 0: unpolarised amplitude, out (npix) f64; 1 / 2: X / Y dipole, out (npix, 2) f64
+ *   tab_*_host (ntab): knots (x, y, y'') of the natural cubic spline of the E-W
+ *   Fraunhofer pattern; fwhm_ns: FWHM of the exptan N-S pattern.
+ * Replaces: cylbeam.beam_amp / beam_x / beam_y, drift/telescope/cylbeam.py:101-212,
+ *           _fast_tools.beam_exptan, drift/util/_fast_tools.pyx:248-282. */
+int dm_bt_beam_cyl(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host,
+                   const double* frame_host, int kind, const double* tab_x_host, const double* tab_y_host,
+                   const double* tab_y2_host, int ntab, double fwhm_ns, double* out_dev);
+
+/* dm_bt_maps: complex visibility response maps for ncol (frequency, baseline) columns:
+ * h * fringe * (b_i x b_j) / sqrt(Omega_i Omega_j) -> (ncol, P, npix) c128 with P = 4
+ * (I, Q, U, V) if polarised else 1.  beams_dev: nbeam maps from dm_bt_beam_cyl;
+ * uv_host (ncol, 2) = baseline / wavelength; bi_host / bj_host (ncol) beam indices.
+ * Replaces: _fast_tools.fringe, _construct_pol_real (drift/util/_fast_tools.pyx:18-164),
+ *           Unpolarised/PolarisedTelescope._beam_map_single (drift/core/telescope.py:1156-1176, :1268-1283). */
+int dm_bt_maps(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host,
+               const double* frame_host, int polarised, int nbeam, const double* beams_dev, int ncol,
+               const double* uv_host, const int* bi_host, const int* bj_host, void* maps_dev);
+
+/* dm_bt_sht: spherical-harmonic transform of the maps straight into the m-ordered
+ * blocks beam_m_dev (mmax+1, F, 2, B, P, lside+1) c128 (the reference's beam_m layout
+ * with l padded from 0): rows (f, :, b) of the given columns are overwritten, zero for
+ * l < m and l > col_lmax.  lmax_grp = max(col_lmax) <= lside.  Synchronises.
+ * Replaces: _transfer_single / transfer_matrices (drift/core/telescope.py:755-830,
+ *           :1178-1193, :1287-1316, i.e. cora.util.hputil.sphtrans_complex[_pol]) and the
+ *           +/-m fold of BeamTransfer._generate_mfiles (drift/core/beamtransfer.py:620-624). */
+int dm_bt_sht(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised,
+              int lside, int mmax, int lmax_grp, int F, int B, int ncol, const int* col_f_host,
+              const int* col_b_host, const int* col_lmax_host, const void* maps_dev, void* beam_m_dev);
+
 #ifdef __cplusplus
 }
 #endif

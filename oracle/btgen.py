@@ -1,0 +1,402 @@
+"""CPU restatement (numpy) of driftscan's beam-transfer generation for cylinder
+telescopes: HEALPix geometry, cylinder beams, the pixel kernels of
+``_fast_tools.pyx``, the spherical-harmonic quadrature and the +/-m fold.
+
+TEST INFRASTRUCTURE: the checker for the HIP path and the timed ``cpu_baseline``
+of bench.py.  Never imported by the product.
+
+Pinning status
+  * ``fringe``, ``horizon``, ``beam_exptan``, ``construct_pol_real``, ``beam_amp``,
+    ``beam_x/y``, ``fraunhofer_cylinder``: PINNED against the reference's own compiled
+    Cython extension and Python (tests/golden/pixel_kernels.npz, and live against
+    oracle/_ref when present).
+  * ``sht_*`` (map -> a_lm): PARITY UNPINNED.  The reference calls
+    cora.util.hputil.sphtrans_complex[_pol] -> healpy.map2alm (libsharp); neither is
+    vendored or installed and the reference's golden tarball is network-only
+    (SURVEY.md §8c).  Restated here from the published HEALPix algorithm
+    (Gorski et al. 2005): RING pixel centres, equal pixel weights 4 pi / npix, no
+    Jacobi iterations (``iter=0``), E/B in the HEALPix convention
+    a^E = -(a_2 + a_-2)/2, a^B = i (a_2 - a_-2)/2.  Checked against brute-force sums
+    over explicitly constructed (spin-weighted) spherical harmonics instead
+    (tests/test_oracle_sht.py).
+
+Follows (paths relative to the reference tree):
+  * pixel kernels          drift/util/_fast_tools.pyx:18-282
+  * horizon                drift/core/visibility.py:27-46
+  * cylinder beams         drift/telescope/cylbeam.py:10-212, cylinder.py:171-218
+  * per-(baseline,freq) maps   drift/core/telescope.py:1156-1176 (unpol), :1268-1283 (pol)
+  * transfer_single        drift/core/telescope.py:1178-1193 (unpol), :1287-1316 (pol)
+  * transfer_matrices      drift/core/telescope.py:755-830
+  * fold to m-order        drift/core/beamtransfer.py:620-624, :663
+"""
+import numpy as np
+
+
+# ----------------------------------------------------------------------------
+# HEALPix RING geometry
+# ----------------------------------------------------------------------------
+def nside_for_lmax(lmax, accuracy_boost=1):
+    """cora.util.hputil.nside_for_lmax (restated)."""
+    return int(2 ** (accuracy_boost + np.ceil(np.log((lmax + 1) / 3.0) / np.log(2.0))))
+
+
+def ring_info(nside):
+    """Per-ring z = cos(theta), number of pixels, phi of the first pixel, first pixel index."""
+    nring = 4 * nside - 1
+    i = np.arange(1, nring + 1)
+    z = np.empty(nring)
+    nphi = np.empty(nring, dtype=np.int64)
+    phi0 = np.empty(nring)
+    north = i < nside
+    south = i > 3 * nside
+    eq = ~(north | south)
+    z[north] = 1.0 - i[north] ** 2 / (3.0 * nside**2)
+    nphi[north] = 4 * i[north]
+    phi0[north] = np.pi / (4.0 * i[north])
+    ie = i[eq]
+    z[eq] = (2.0 * nside - ie) * 2.0 / (3.0 * nside)
+    nphi[eq] = 4 * nside
+    shifted = ((ie + nside) % 2) == 0
+    phi0[eq] = np.where(shifted, np.pi / (4.0 * nside), 0.0)
+    js = 4 * nside - i[south]
+    z[south] = -(1.0 - js**2 / (3.0 * nside**2))
+    nphi[south] = 4 * js
+    phi0[south] = np.pi / (4.0 * js)
+    start = np.concatenate([[0], np.cumsum(nphi)[:-1]])
+    return z, nphi, phi0, start
+
+
+def ang_positions(nside):
+    """(npix, 2) array of (theta, phi) pixel centres in RING order
+    (cora.util.hputil.ang_positions = healpy.pix2ang)."""
+    z, nphi, phi0, start = ring_info(nside)
+    npix = 12 * nside**2
+    out = np.empty((npix, 2))
+    for r in range(z.size):
+        sl = slice(start[r], start[r] + nphi[r])
+        out[sl, 0] = np.arccos(z[r])
+        out[sl, 1] = phi0[r] + 2.0 * np.pi * np.arange(nphi[r]) / nphi[r]
+    return out
+
+
+# ----------------------------------------------------------------------------
+# coordinate helpers (cora.util.coord, restated)
+# ----------------------------------------------------------------------------
+def sph_to_cart(sph):
+    sph = np.asarray(sph)
+    st = np.sin(sph[..., 0])
+    return np.stack([st * np.cos(sph[..., 1]), st * np.sin(sph[..., 1]), np.cos(sph[..., 0])], axis=-1)
+
+
+def thetaphi_plane_cart(sph):
+    sph = np.asarray(sph)
+    t, p = sph[..., 0], sph[..., 1]
+    that = np.stack([np.cos(t) * np.cos(p), np.cos(t) * np.sin(p), -np.sin(t)], axis=-1)
+    phat = np.stack([-np.sin(p), np.cos(p), np.zeros_like(p)], axis=-1)
+    return that, phat
+
+
+# ----------------------------------------------------------------------------
+# pixel kernels (_fast_tools.pyx)
+# ----------------------------------------------------------------------------
+def fringe(angpos, zenith, uv):
+    """exp(2 pi i n.(u uhat + v vhat)), uhat = phihat(zenith), vhat = -thetahat(zenith)
+    (_fast_tools.pyx:18-82)."""
+    that, phat = thetaphi_plane_cart(zenith)
+    uv3 = uv[0] * phat + uv[1] * (-that)
+    phase = 2.0 * np.pi * (sph_to_cart(angpos) @ uv3)
+    return np.cos(phase) + 1j * np.sin(phase)
+
+
+def horizon(angpos, zenith):
+    """signbit(-n.zenith): True above the horizon (visibility.py:27-46)."""
+    proj = np.sum(sph_to_cart(angpos) * sph_to_cart(zenith), axis=-1)
+    return np.signbit(-proj)
+
+
+def beam_exptan(sintheta, fwhm):
+    """exp(-alpha s^2 / (1 - s^2 + 1e-100)), alpha = ln2 / (2 tan^2(fwhm/2))
+    (_fast_tools.pyx:248-282)."""
+    alpha = np.log(2.0) / (2.0 * np.tan(fwhm / 2.0) ** 2)
+    s2 = sintheta**2
+    return np.exp(-alpha * s2 / (1.0 - s2 + 1e-100))
+
+
+def construct_pol_real(beami, beamj, fr, hz):
+    """Four Stokes response maps for real field patterns (_fast_tools.pyx:96-164)."""
+    n = beami.shape[0]
+    om_i = np.sum(hz * (beami[:, 0] ** 2 + beami[:, 1] ** 2)) * 4.0 * np.pi / n
+    om_j = np.sum(hz * (beamj[:, 0] ** 2 + beamj[:, 1] ** 2)) * 4.0 * np.pi / n
+    tc = fr * hz / np.sqrt(om_i * om_j)
+    out = np.empty((4, n), dtype=np.complex128)
+    out[0] = tc * (beami[:, 0] * beamj[:, 0] + beami[:, 1] * beamj[:, 1])
+    out[1] = tc * (beami[:, 0] * beamj[:, 0] - beami[:, 1] * beamj[:, 1])
+    out[2] = tc * (beami[:, 0] * beamj[:, 1] + beami[:, 1] * beamj[:, 0])
+    out[3] = 1j * tc * (beami[:, 0] * beamj[:, 1] - beami[:, 1] * beamj[:, 0])
+    return out
+
+
+# ----------------------------------------------------------------------------
+# cylinder beam model (cylbeam.py)
+# ----------------------------------------------------------------------------
+def natural_spline(x, y):
+    """Second derivatives of the natural cubic spline through (x, y) — the published
+    algorithm behind cora.util.cubicspline.Interpolater."""
+    n = x.size
+    y2 = np.zeros(n)
+    u = np.zeros(n)
+    for i in range(1, n - 1):
+        sig = (x[i] - x[i - 1]) / (x[i + 1] - x[i - 1])
+        p = sig * y2[i - 1] + 2.0
+        y2[i] = (sig - 1.0) / p
+        u[i] = (y[i + 1] - y[i]) / (x[i + 1] - x[i]) - (y[i] - y[i - 1]) / (x[i] - x[i - 1])
+        u[i] = (6.0 * u[i] / (x[i + 1] - x[i - 1]) - sig * u[i - 1]) / p
+    for k in range(n - 2, -1, -1):
+        y2[k] = y2[k] * y2[k + 1] + u[k]
+    return y2
+
+
+def spline_eval(x, y, y2, xv):
+    khi = np.clip(np.searchsorted(x, xv, side="left"), 1, x.size - 1)
+    klo = khi - 1
+    h = x[khi] - x[klo]
+    a = (x[khi] - xv) / h
+    b = (xv - x[klo]) / h
+    return a * y[klo] + b * y[khi] + ((a**3 - a) * y2[klo] + (b**3 - b) * y2[khi]) * (h * h) / 6.0
+
+
+def fraunhofer_cylinder(fwhm, width):
+    """1-D Fraunhofer pattern of an exptan-illuminated cylinder of `width` wavelengths:
+    spline knots (kx, fx, fx'') (cylbeam.py:52-95)."""
+    res = 16
+    num = 512
+    hnum = 512 // 2 - 1
+    ua = -1.0 * np.linspace(-1.0, 1.0, num, endpoint=False)[::-1]
+    ax = beam_exptan(2 * ua / (1 + ua**2), fwhm)
+    axe = np.zeros(res * num)
+    axe[: (hnum + 2)] = ax[hnum:]
+    axe[-hnum:] = ax[:hnum]
+    fx = np.fft.fft(axe).real
+    kx = 2 * np.fft.fftfreq(res * num, ua[1] - ua[0]) / width
+    fx = np.fft.fftshift(fx) / fx.max()
+    kx = np.fft.fftshift(kx)
+    sel = np.abs(kx) < 1.1
+    fx, kx = np.ascontiguousarray(fx[sel]), np.ascontiguousarray(kx[sel])
+    return kx, fx, natural_spline(kx, fx)
+
+
+def telescope_frame(zenith):
+    """xhat (East), yhat (North), zhat (up) for an unrotated cylinder (cylbeam.py:129)."""
+    that, phat = thetaphi_plane_cart(zenith)
+    return phat, -that, sph_to_cart(zenith)
+
+
+def beam_amp(angpos, zenith, width, fwhm_x, fwhm_y):
+    """Cylinder amplitude pattern (cylbeam.py:101-147)."""
+    xhat, yhat, zhat = telescope_frame(zenith)
+    kx, fx, f2 = fraunhofer_cylinder(fwhm_x, width)
+    cvec = sph_to_cart(angpos)
+    hz = (cvec @ zhat > 0.0).astype(np.float64)
+    return spline_eval(kx, fx, f2, cvec @ xhat) * beam_exptan(cvec @ yhat, fwhm_y) * hz
+
+
+def polpattern(angpos, dipole):
+    """Unit polarisation vectors of a dipole in the (thetahat, phihat) basis (cylbeam.py:10-42)."""
+    that, phat = thetaphi_plane_cart(angpos)
+    pv = np.stack([that @ dipole, phat @ dipole], axis=-1)
+    nrm = np.hypot(pv[..., 0], pv[..., 1])
+    nrm = np.where(nrm == 0.0, 1.0, nrm)
+    return pv / nrm[..., None]
+
+
+def beam_x(angpos, zenith, width, fwhm_e, fwhm_h):
+    xhat, yhat, zhat = telescope_frame(zenith)
+    return beam_amp(angpos, zenith, width, fwhm_e, fwhm_h)[:, None] * polpattern(angpos, xhat)
+
+
+def beam_y(angpos, zenith, width, fwhm_e, fwhm_h):
+    xhat, yhat, zhat = telescope_frame(zenith)
+    return beam_amp(angpos, zenith, width, fwhm_h, fwhm_e)[:, None] * polpattern(angpos, yhat)
+
+
+# ----------------------------------------------------------------------------
+# spherical harmonic quadrature (restated HEALPix map2alm, iter = 0, equal weights)
+# ----------------------------------------------------------------------------
+def lambda_lm(lmax, m, z):
+    """Normalised associated Legendre functions lambda_lm(z) = Y_lm(theta, 0) for
+    l = m..lmax at every z; shape (lmax+1-m, z.size).  Standard three-term recurrence."""
+    z = np.asarray(z, dtype=np.float64)
+    st = np.sqrt((1.0 - z) * (1.0 + z))
+    out = np.zeros((lmax + 1 - m, z.size))
+    if m > lmax:
+        return out
+    # log of the sectoral prefactor to dodge underflow of sin^m for large m
+    logpre = 0.5 * (np.log(2.0 * m + 1.0) - np.log(4.0 * np.pi))
+    if m > 0:
+        k = np.arange(1, m + 1)
+        logpre += 0.5 * np.sum(np.log((2.0 * k - 1.0) / (2.0 * k)))
+    with np.errstate(divide="ignore"):
+        lmm = ((-1.0) ** m) * np.exp(logpre + m * np.log(st)) if m > 0 else np.full(z.size, np.exp(logpre))
+    out[0] = lmm
+    if lmax > m:
+        out[1] = np.sqrt(2.0 * m + 3.0) * z * lmm
+    for l in range(m + 2, lmax + 1):
+        a = np.sqrt((4.0 * l * l - 1.0) / (l * l - m * m))
+        b = np.sqrt(((l - 1.0) ** 2 - m * m) / (4.0 * (l - 1.0) ** 2 - 1.0))
+        out[l - m] = a * (z * out[l - m - 1] - b * out[l - m - 2])
+    return out
+
+
+XSIGN = 1.0
+
+
+def wx_lm(lmax, m, z):
+    """Spin-2 ring functions W_lm, X_lm (HEALPix: W = -(2lam + -2lam)/2, X = -(2lam - -2lam)/2)
+    for l = m..lmax; zero for l < 2.  Closed forms in lambda_lm, lambda_{l-1,m}
+    (Kamionkowski, Kosowsky & Stebbins 1997, eq. 2.25 rewritten for normalised functions)."""
+    lam = lambda_lm(lmax, m, z)
+    z = np.asarray(z, dtype=np.float64)
+    s2 = (1.0 - z) * (1.0 + z)
+    W = np.zeros_like(lam)
+    X = np.zeros_like(lam)
+    for l in range(max(m, 2), lmax + 1):
+        nl = 2.0 * np.sqrt(1.0 / ((l - 1.0) * l * (l + 1.0) * (l + 2.0)))
+        lam_l = lam[l - m]
+        lam_lm1 = lam[l - m - 1] if l - 1 >= m else np.zeros_like(z)
+        c = np.sqrt((2.0 * l + 1.0) / (2.0 * l - 1.0) * (l * l - m * m))
+        W[l - m] = -nl * (-((l - m * m) / s2 + 0.5 * l * (l - 1.0)) * lam_l + c * z / s2 * lam_lm1)
+        X[l - m] = XSIGN * nl * (m / s2) * ((l - 1.0) * z * lam_l - c * lam_lm1)
+    return W, X
+
+
+def ring_dft(maps, nside, mlist, sign=+1):
+    """G[m, ring, ...] = sum_j maps[..., pix(ring, j)] exp(sign i m phi_j) for every m in mlist."""
+    z, nphi, phi0, start = ring_info(nside)
+    maps = np.asarray(maps)
+    lead = maps.shape[:-1]
+    mlist = np.asarray(mlist)
+    out = np.zeros((mlist.size, z.size) + lead, dtype=np.complex128)
+    for r in range(z.size):
+        phi = phi0[r] + 2.0 * np.pi * np.arange(nphi[r]) / nphi[r]
+        tw = np.exp(sign * 1j * np.outer(mlist, phi))  # (nm, nphi)
+        seg = maps[..., start[r] : start[r] + nphi[r]]
+        out[:, r] = np.tensordot(tw, seg, axes=([1], [-1]))
+    return out
+
+
+def transfer_single(maps, nside, lmax, lside, polarised):
+    """The reference's ``_transfer_single``: conj(SHT(conj(map))) zero-embedded into
+    (P, lside+1, 2*lside+1) with non-centred m (negative m wrapped to the end).
+
+    maps: (npix,) complex for unpolarised, (4, npix) [I, Q, U, V] for polarised.
+    """
+    z, nphi, phi0, start = ring_info(nside)
+    npix = 12 * nside**2
+    w = 4.0 * np.pi / npix
+    P = 4 if polarised else 1
+    maps = np.asarray(maps).reshape(P, npix)
+    out = np.zeros((P, lside + 1, 2 * lside + 1), dtype=np.complex128)
+    ms = np.arange(-lmax, lmax + 1)
+    G = ring_dft(maps, nside, ms, sign=+1)  # (nm, nring, P): conj-trick turns e^{-im phi} into e^{+im phi}
+    for mi, m in enumerate(ms):
+        am = abs(m)
+        lam = lambda_lm(lmax, am, z) * w  # (L-am, nring)
+        sgn = (-1.0) ** am if m < 0 else 1.0
+        g = G[mi]  # (nring, P)
+        col = m if m >= 0 else 2 * lside + 1 + m
+        out[0, am : lmax + 1, col] = sgn * (lam @ g[:, 0])
+        if polarised:
+            W, X = wx_lm(lmax, am, z)
+            W = W * w
+            X = X * w
+            # lambda_{l,-m} = (-1)^m lambda_lm ; W_{l,-m} = (-1)^m W_lm ; X_{l,-m} = -(-1)^m X_lm
+            sx = -sgn if m < 0 else 1.0
+            gq, gu = g[:, 1], g[:, 2]
+            out[1, am : lmax + 1, col] = sgn * (W @ gq) - 1j * sx * (X @ gu)
+            out[2, am : lmax + 1, col] = sgn * (W @ gu) + 1j * sx * (X @ gq)
+            out[3, am : lmax + 1, col] = sgn * (lam @ g[:, 3])
+    return out
+
+
+def fold_to_m(tarray, mmax):
+    """(nfb, P, L, 2L-1) non-centred a_lm -> (mmax+1) arrays of (nfb, 2, P, L - m) in the
+    reference's beam_m convention (beamtransfer.py:620-624, :663)."""
+    nfb, P, L, _ = tarray.shape
+    out = []
+    for m in range(mmax + 1):
+        blk = np.zeros((nfb, 2, P, L - m), dtype=np.complex128)
+        blk[:, 0] = tarray[:, :, m:, m]
+        if m > 0:
+            blk[:, 1] = (-1) ** m * tarray[:, :, m:, -m].conj()
+        out.append(blk)
+    return out
+
+
+# ----------------------------------------------------------------------------
+# whole-telescope beam transfer generation for cylinder arrays
+# ----------------------------------------------------------------------------
+def max_lm(baselines, wavelengths, uwidth, vwidth=0.0):
+    """drift/core/telescope.py:99-122."""
+    umax = (np.abs(baselines[:, 0]) + uwidth) / wavelengths
+    vmax = (np.abs(baselines[:, 1]) + vwidth) / wavelengths
+    mmax = np.ceil(2 * np.pi * umax).astype(np.int64)
+    lmax = np.ceil((mmax**2 + (2 * np.pi * vmax) ** 2) ** 0.5).astype(np.int64)
+    return lmax, mmax
+
+
+def beam_transfer_m(tel, mlist=None):
+    """Generate beam_m blocks for a cylinder telescope description ``tel`` (a dict):
+
+      polarised (bool), zenith (2,), baselines (B,2), uniquepairs (B,2), beamclass (nfeed,),
+      wavelengths (F,), cylinder_width, fwhm_e, fwhm_h, lmax, mmax, l_boost,
+      included_freq, included_baseline, accuracy_boost
+
+    Returns {m: (F, 2, B, P, L) complex128} with the reference's ``beam_m`` layout
+    (zero for l < m and for skipped frequencies / baselines).
+    """
+    pol = tel["polarised"]
+    P = 4 if pol else 1
+    F, B = tel["wavelengths"].size, tel["baselines"].shape[0]
+    lside, mmax = int(tel["lmax"]), int(tel["mmax"])
+    L = lside + 1
+    mlist = list(range(mmax + 1)) if mlist is None else list(mlist)
+    out = {m: np.zeros((F, 2, B, P, L), dtype=np.complex128) for m in mlist}
+    cache = {}
+    geo = {}
+    for f in tel["included_freq"]:
+        for b in tel["included_baseline"]:
+            lm, _ = max_lm(tel["baselines"][b : b + 1], tel["wavelengths"][f], tel["cylinder_width"], 0.0)
+            lmax_bf = int(np.ceil(tel.get("l_boost", 1.0) * lm[0]))
+            nside = nside_for_lmax(lmax_bf, tel.get("accuracy_boost", 1) if not pol else 1)
+            if nside not in geo:
+                ap = ang_positions(nside)
+                geo[nside] = (ap, horizon(ap, tel["zenith"]).astype(np.float64))
+            ap, hz = geo[nside]
+            fi, fj = tel["uniquepairs"][b]
+            beams = []
+            for feed in (fi, fj):
+                key = (nside, f, int(tel["beamclass"][feed]))
+                if key not in cache:
+                    width = tel["cylinder_width"] / tel["wavelengths"][f]
+                    if not pol:
+                        cache[key] = beam_amp(ap, tel["zenith"], width, tel["fwhm_h"], tel["fwhm_h"])
+                    elif tel["beamclass"][feed] % 2 == 0:
+                        cache[key] = beam_x(ap, tel["zenith"], width, tel["fwhm_e"], tel["fwhm_h"])
+                    else:
+                        cache[key] = beam_y(ap, tel["zenith"], width, tel["fwhm_e"], tel["fwhm_h"])
+                beams.append(cache[key])
+            uv = tel["baselines"][b] / tel["wavelengths"][f]
+            fr = fringe(ap, tel["zenith"], uv)
+            if pol:
+                maps = construct_pol_real(beams[0], beams[1], fr, hz)
+            else:
+                pxarea = 4 * np.pi / ap.shape[0]
+                om_i = np.sum(np.abs(beams[0]) ** 2 * hz) * pxarea
+                om_j = np.sum(np.abs(beams[1]) ** 2 * hz) * pxarea
+                maps = hz * fr * beams[0] * beams[1].conjugate() / np.sqrt(om_i * om_j)
+            t = transfer_single(maps, nside, lmax_bf, lside, pol)
+            for m in mlist:
+                out[m][f, 0, b, :, m:] = t[:, m:, m]
+                if m > 0:
+                    out[m][f, 1, b, :, m:] = (-1) ** m * t[:, m:, -m].conj()
+    return out

@@ -1,0 +1,101 @@
+"""GPU parity of beam-transfer generation (through the C ABI) against the numpy oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from driftscan_amd._lib import Context
+
+    c = Context(0, workspace_bytes=2 << 30)
+    yield c
+    c.close()
+
+
+def _tel(pol, **kw):
+    from driftscan_amd import cylinder
+
+    cfg = dict(num_freq=2, freq_start=400.0, freq_end=450.0, freq_mode="edge", num_cylinders=2, cylinder_width=2.0,
+               num_feeds=3, feed_spacing=0.4, tsys=1.0)
+    cfg.update(kw)
+    klass = cylinder.PolarisedCylinderTelescope if pol else cylinder.UnpolarisedCylinderTelescope
+    return klass.from_config(cfg)
+
+
+def _oracle_desc(t):
+    return dict(polarised=t.num_pol_sky > 1, zenith=t.zenith, baselines=t.baselines, uniquepairs=t.uniquepairs,
+                beamclass=t.beamclass, wavelengths=t.wavelengths, cylinder_width=t.cylinder_width, fwhm_e=t.fwhm_e,
+                fwhm_h=t.fwhm_h, lmax=t.lmax, mmax=t.mmax, l_boost=t.l_boost, included_freq=t.included_freq,
+                included_baseline=t.included_baseline, accuracy_boost=t.accuracy_boost)
+
+
+def test_beam_and_maps_kernels(ctx):
+    """Pixel kernels alone: beams and Stokes maps on a small nside."""
+    from driftscan_amd import btgen, healpix
+    from oracle import btgen as ob
+
+    t = _tel(True)
+    nside = 16
+    cth, sth = healpix.ring_trig(nside)
+    frame = btgen.telescope_frame(t.zenith)
+    ap = ob.ang_positions(nside)
+    npix = ap.shape[0]
+    beams = ctx.empty((2, npix * 2), np.float64)
+    for bc in (0, 1):
+        kind, tab, fw = t.beam_spec(bc, 0)
+        ctx.bt_beam_cyl(nside, cth, sth, frame, kind, tab, fw, beams[bc])
+    ctx.sync()
+    hb = beams.cpu().numpy().reshape(2, npix, 2)
+    w = t.cylinder_width / t.wavelengths[0]
+    rx = ob.beam_x(ap, t.zenith, w, t.fwhm_e, t.fwhm_h)
+    ry = ob.beam_y(ap, t.zenith, w, t.fwhm_e, t.fwhm_h)
+    assert np.abs(hb[0] - rx).max() < 1e-12 and np.abs(hb[1] - ry).max() < 1e-12
+    uv = np.array([[3.1, -2.2], [0.0, 1.7]])
+    maps = ctx.empty((2, 4, npix), np.complex128)
+    ctx.bt_maps(nside, cth, sth, frame, True, beams, uv, np.array([0, 1]), np.array([1, 1]), maps)
+    ctx.sync()
+    hm = maps.cpu().numpy()
+    hz = ob.horizon(ap, t.zenith).astype(np.float64)
+    for k, (bi, bj) in enumerate(((rx, ry), (ry, ry))):
+        ref = ob.construct_pol_real(bi, bj, ob.fringe(ap, t.zenith, uv[k]), hz)
+        assert np.abs(hm[k] - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("pol", [False, True])
+def test_beam_m_vs_oracle(ctx, pol):
+    from driftscan_amd import btgen
+    from oracle import btgen as ob
+
+    t = _tel(pol)
+    bm = btgen.beam_m_all(t, ctx=ctx).cpu().numpy()
+    ref = ob.beam_transfer_m(_oracle_desc(t))
+    scale = max(np.abs(ref[m]).max() for m in ref)
+    worst = 0.0
+    for m in range(t.mmax + 1):
+        worst = max(worst, np.abs(bm[m] - ref[m]).max() / scale)
+        assert np.abs(bm[m][..., :m]).max(initial=0.0) == 0.0  # compact-storage region is exactly zero
+    assert worst < 1e-10, worst
+
+
+def test_skips_and_transfer_matrices(ctx):
+    from driftscan_amd import btgen
+    from oracle import btgen as ob
+
+    t = _tel(False, skip_freq=[0], skip_baselines=[1, 4])
+    bm = btgen.beam_m_all(t, ctx=ctx).cpu().numpy()
+    assert np.abs(bm[:, 0]).max() == 0.0 and np.abs(bm[:, :, :, [1, 4]]).max() == 0.0
+    ref = ob.beam_transfer_m(_oracle_desc(t), mlist=[0, 3, t.mmax])
+    scale = np.abs(ref[0]).max()
+    for m in ref:
+        assert np.abs(bm[m] - ref[m]).max() < 1e-10 * scale
+    # the (l, m) "transfer_matrices" view of the same numbers
+    bl, fi = np.array([0, 2]), np.array([1, 1])
+    tm = t.transfer_matrices(bl, fi)
+    full = ob.beam_transfer_m(_oracle_desc(_tel(False)), mlist=range(t.mmax + 1))
+    for k in range(2):
+        for m in (0, 2, t.mmax):
+            assert np.abs(tm[k, 0, :, m] - full[m][fi[k], 0, bl[k], 0]).max() < 1e-10 * scale
+            if m:
+                assert np.abs(tm[k, 0, :, -m] - (-1) ** m * full[m][fi[k], 1, bl[k], 0].conj()).max() < 1e-10 * scale

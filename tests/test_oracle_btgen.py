@@ -1,0 +1,136 @@
+"""Pin oracle/btgen.py: pixel kernels and beams against the reference's own outputs
+(golden), the SHT against brute-force (spin-weighted) spherical-harmonic sums."""
+import math
+import os
+
+import numpy as np
+import pytest
+import scipy.special as sp
+
+from oracle import btgen as ob
+
+
+@pytest.fixture(scope="module")
+def pk(golden_dir):
+    return np.load(os.path.join(golden_dir, "pixel_kernels.npz"))
+
+
+def test_pixel_kernels_vs_reference(pk):
+    ap, zen, uv = pk["angpos"], pk["zenith"], pk["uv"]
+    assert np.abs(ob.fringe(ap, zen, uv) - pk["fringe"]).max() < 1e-12
+    assert (ob.horizon(ap, zen) == pk["horizon"]).all()
+    assert np.abs(ob.beam_exptan(pk["exptan_in"], float(pk["exptan_fwhm"])) - pk["exptan"]).max() < 1e-15
+    hz = pk["horizon"].astype(np.float64)
+    for key, bi, bj in (("pol_real_xy", "beam_x", "beam_y"), ("pol_real_xx", "beam_x", "beam_x")):
+        out = ob.construct_pol_real(pk[bi], pk[bj], pk["fringe"], hz)
+        assert np.abs(out - pk[key]).max() <= 1e-13 * np.abs(pk[key]).max()
+
+
+def test_cylinder_beams_vs_reference(pk):
+    ap, zen = pk["angpos"], pk["zenith"]
+    w, fe, fh = float(pk["cyl_width"]), float(pk["cyl_fwhm_e"]), float(pk["cyl_fwhm_h"])
+    kx, fx, f2 = ob.fraunhofer_cylinder(fh, w)
+    assert np.abs(kx - pk["fraunhofer_x"]).max() < 1e-14
+    assert np.abs(fx - pk["fraunhofer_y"]).max() < 1e-13
+    assert np.abs(f2 - pk["fraunhofer_y2"]).max() < 1e-9 * np.abs(pk["fraunhofer_y2"]).max()
+    assert np.abs(ob.beam_amp(ap, zen, w, fh, fh) - pk["beam_amp"]).max() < 1e-12
+    assert np.abs(ob.beam_x(ap, zen, w, fe, fh) - pk["beam_x"]).max() < 1e-12
+    assert np.abs(ob.beam_y(ap, zen, w, fe, fh) - pk["beam_y"]).max() < 1e-12
+
+
+def test_ring_geometry():
+    for nside in (1, 2, 4, 8):
+        ap = ob.ang_positions(nside)
+        assert ap.shape == (12 * nside**2, 2)
+        # equal-area pixels: the z-moments of the pixel centres integrate low polynomials exactly
+        z = np.cos(ap[:, 0])
+        assert abs(z.mean()) < 1e-14
+        assert abs((z**2).mean() - 1.0 / 3.0) < 0.05 / nside**2 + 1e-14
+    # nside = 1: four pixels at z = 2/3 (phi = 45 deg + k 90), four on the equator (phi = k 90), four at z = -2/3
+    ap = ob.ang_positions(1)
+    assert np.allclose(np.cos(ap[:4, 0]), 2.0 / 3.0) and np.allclose(ap[:4, 1], np.pi / 4 + np.arange(4) * np.pi / 2)
+    assert np.allclose(np.cos(ap[4:8, 0]), 0.0) and np.allclose(ap[4:8, 1], np.arange(4) * np.pi / 2)
+    assert np.allclose(np.cos(ap[8:, 0]), -2.0 / 3.0)
+
+
+def test_lambda_vs_scipy():
+    z = np.linspace(-0.97, 0.97, 23)
+    lmax = 40
+    for m in (0, 1, 2, 7, 23, 40):
+        lam = ob.lambda_lm(lmax, m, z)
+        for l in (m, min(m + 1, lmax), min(m + 9, lmax), lmax):
+            ref = sp.sph_harm_y(l, m, np.arccos(z), 0.0).real
+            assert np.abs(lam[l - m] - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
+
+
+def spin_ylm(s, l, m, theta, phi):
+    """Goldberg et al. (1967) closed form of the spin-weighted spherical harmonics."""
+    pref = (-1.0) ** m * math.sqrt(
+        math.factorial(l + m) * math.factorial(l - m) * (2 * l + 1) / (4 * math.pi * math.factorial(l + s) * math.factorial(l - s))
+    )
+    out = np.zeros_like(theta, dtype=np.complex128)
+    for r in range(0, l - s + 1):
+        k = r + s - m
+        if k < 0 or k > l + s:
+            continue
+        out += math.comb(l - s, r) * math.comb(l + s, k) * (-1.0) ** (l - r - s) * (1.0 / np.tan(theta / 2.0)) ** (2 * r + s - m)
+    return pref * np.sin(theta / 2.0) ** (2 * l) * out * np.exp(1j * m * phi)
+
+
+def test_spin2_functions_vs_goldberg():
+    z = np.linspace(-0.9, 0.9, 11)
+    th = np.arccos(z)
+    lmax = 9
+    for m in range(0, lmax + 1):
+        W, X = ob.wx_lm(lmax, m, z)
+        for l in range(max(m, 2), lmax + 1):
+            f_p = spin_ylm(2, l, m, th, np.zeros_like(th)).real
+            f_m = spin_ylm(-2, l, m, th, np.zeros_like(th)).real
+            assert np.abs(W[l - m] + 0.5 * (f_p + f_m)).max() < 1e-11, (l, m)
+            assert np.abs(X[l - m] + 0.5 * (f_p - f_m)).max() < 1e-11, (l, m)
+
+
+def test_transfer_single_bruteforce_scalar():
+    nside, lmax = 4, 7
+    rng = np.random.default_rng(0)
+    ap = ob.ang_positions(nside)
+    npix = ap.shape[0]
+    mp = rng.standard_normal(npix) + 1j * rng.standard_normal(npix)
+    t = ob.transfer_single(mp, nside, lmax, lmax, False)[0]
+    w = 4 * np.pi / npix
+    for l in range(lmax + 1):
+        for m in range(-l, l + 1):
+            ylm = sp.sph_harm_y(l, m, ap[:, 0], ap[:, 1])
+            # btrans = conj( sum w conj(map) conj(Y) ) = sum w map Y
+            ref = w * np.sum(mp * ylm)
+            assert abs(t[l, m] - ref) < 1e-12, (l, m)
+
+
+def test_transfer_single_bruteforce_pol():
+    nside, lmax = 4, 6
+    rng = np.random.default_rng(1)
+    ap = ob.ang_positions(nside)
+    npix = ap.shape[0]
+    maps = rng.standard_normal((4, npix)) + 1j * rng.standard_normal((4, npix))
+    t = ob.transfer_single(maps, nside, lmax, lmax, True)
+    w = 4 * np.pi / npix
+    cm = maps.conj()  # the reference transforms the conjugated maps, real and imaginary parts separately
+    for l in range(2, lmax + 1):
+        for m in range(-l, l + 1):
+            y2 = spin_ylm(2, l, m, ap[:, 0], ap[:, 1])
+            ym2 = spin_ylm(-2, l, m, ap[:, 0], ap[:, 1])
+            aE = aB = 0.0
+            for part, fac in ((cm.real, 1.0), (cm.imag, 1.0j)):
+                q, u = part[1], part[2]
+                a2 = w * np.sum((q + 1j * u) * y2.conj())
+                am2 = w * np.sum((q - 1j * u) * ym2.conj())
+                aE = aE + fac * (-(a2 + am2) / 2.0)
+                aB = aB + fac * (1j * (a2 - am2) / 2.0)
+            assert abs(t[1, l, m] - np.conj(aE)) < 1e-11, ("E", l, m)
+            assert abs(t[2, l, m] - np.conj(aB)) < 1e-11, ("B", l, m)
+    # T and V are plain scalar transforms
+    for p in (0, 3):
+        for l in (0, 3, lmax):
+            for m in (-l, 0, l):
+                ref = w * np.sum(maps[p] * sp.sph_harm_y(l, m, ap[:, 0], ap[:, 1]))
+                assert abs(t[p, l, m] - ref) < 1e-12
