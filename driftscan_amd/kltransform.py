@@ -1,0 +1,310 @@
+"""Karhunen-Loeve transform per m, GPU-backed.
+
+Mirrors ``drift.core.kltransform.KLTransform`` (drift/core/kltransform.py:146-911):
+same constructor, config properties, file names and datasets, ``sn_covariance``,
+``transform_save``, ``generate``, ``evals_all``, ``modes_m`` & co.  The covariance
+projections and the generalised eigenproblem run on the GPU for all of this rank's
+m-blocks at once (``dm_project_cov`` / ``dm_project_diag`` / ``dm_regularise`` /
+``dm_eigh_gen``).
+"""
+import logging
+import os
+import time
+
+import numpy as np
+
+from . import config, parallel, skymodel, storage, util
+from ._lib import block_offsets
+from .device import get_context
+
+logger = logging.getLogger(__name__)
+
+
+def eigh_gen(A, B, message=""):
+    """Generalised Hermitian-definite eigenproblem A v = lambda B v on the GPU with the
+    reference's all-zero shortcut and non-positive-definite rescue (kltransform.py:55-121).
+    Returns (evals ascending, evecs as columns, add_const)."""
+    ctx = get_context()
+    A = np.ascontiguousarray(A, dtype=np.complex128)
+    B = np.ascontiguousarray(B, dtype=np.complex128)
+    n = A.shape[0]
+    off, tot = block_offsets([n])
+    evals, evoff, evecs, ac, _ = ctx.eigh_gen(ctx.to_device(A.ravel()), ctx.to_device(B.ravel()), [n], off)
+    E = evecs[: n * n].cpu().numpy().reshape(n, n)
+    return evals[:n].cpu().numpy(), E.T.conj(), float(ac[0])
+
+
+class KLTransform(config.Reader):
+    subset = config.Property(proptype=config.truthy, default=True, key="subset")
+    inverse = config.Property(proptype=config.truthy, default=False, key="inverse")
+    threshold = config.Property(proptype=float, default=0.1, key="threshold")
+    _foreground_regulariser = config.Property(proptype=float, default=1e-14, key="regulariser")
+    use_thermal = config.Property(proptype=config.truthy, default=True)
+    use_foregrounds = config.Property(proptype=config.truthy, default=True)
+    use_polarised = config.Property(proptype=config.truthy, default=True)
+    pol_length = config.Property(proptype=float, default=None)
+    # MI355X-side knob: device memory budget for one batch of m-blocks
+    kl_chunk_gb = config.Property(proptype=float, default=48.0)
+
+    evdir = ""
+    _cvfg = None
+    _cvsg = None
+
+    @property
+    def _evfile(self):
+        return self.evdir + "/ev_m_" + util.natpattern(self.telescope.mmax) + ".hdf5"
+
+    def __init__(self, bt, subdir=None):
+        self.beamtransfer = bt
+        self.telescope = bt.telescope
+        subdir = "ev" if subdir is None else subdir
+        self.evdir = bt.directory + "/" + subdir
+        if parallel.rank0() and not os.path.exists(self.evdir):
+            os.makedirs(self.evdir)
+        parallel.barrier()
+
+    # ---- sky covariances (kltransform.py:203-256) ------------------------------------
+    def foreground(self):
+        if self._cvfg is None:
+            npol = self.telescope.num_pol_sky
+            if npol not in (1, 3, 4):
+                raise Exception("Can only handle unpolarised only (num_pol_sky = 1), or I, Q and U (num_pol_sky = 3).")
+            if self.use_polarised:
+                self._cvfg = skymodel.foreground_model(self.telescope.lmax, self.telescope.frequencies, npol,
+                                                       pol_length=self.pol_length)
+            else:
+                self._cvfg = skymodel.foreground_model(self.telescope.lmax, self.telescope.frequencies, npol,
+                                                       pol_frac=0.0)
+        return self._cvfg
+
+    def signal(self):
+        if self._cvsg is None:
+            npol = self.telescope.num_pol_sky
+            if npol not in (1, 3, 4):
+                raise Exception("Can only handle unpolarised only (num_pol_sky = 1), or I, Q and U (num_pol_sky = 3).")
+            self._cvsg = skymodel.im21cm_model(self.telescope.lmax, self.telescope.frequencies, npol)
+        return self._cvsg
+
+    # ---- covariances in the SVD basis ---------------------------------------------------
+    def _npower(self, nc):
+        tel = self.telescope
+        bl = np.arange(tel.npairs)
+        bl = np.concatenate((bl, bl))
+        return nc * np.asarray(tel.noisepower(bl[np.newaxis, :], np.arange(tel.nfreq)[:, np.newaxis])).reshape(
+            tel.nfreq, self.beamtransfer.ntel)
+
+    def sn_covariance_device(self, ms):
+        """Signal and noise covariances of several m at once, left on the device.
+        Returns (S, N, ndofs, off): flat complex buffers with block b at off[b]."""
+        if not (self.use_foregrounds or self.use_thermal):
+            raise Exception("Either `use_thermal` or `use_foregrounds`, or both must be True.")
+        ctx = get_context()
+        bt = self.beamtransfer
+        ndofs = np.array([int(bt.ndof(mi)) for mi in ms], dtype=np.int64)
+        off, tot = block_offsets(ndofs)
+        S = ctx.empty((max(tot, 1),), np.complex128)
+        N = ctx.empty((max(tot, 1),), np.complex128)
+        bt.project_matrix_sky_to_svd_device(ms, self.signal(), S, off)
+        if self.use_foregrounds:
+            bt.project_matrix_sky_to_svd_device(ms, self.foreground(), N, off)
+        else:
+            N.zero_()
+        # small diagonal to regularise the noise matrix (kltransform.py:288-290)
+        ctx.regularise(N, ndofs, off, self._foreground_regulariser)
+        # even without thermal noise keep a 1 mK floor (kltransform.py:292-296)
+        nc = 1.0 if self.use_thermal else (1e-3 / self.telescope.tsys_flat) ** 2
+        import torch
+
+        but = torch.stack([bt._dev_products(mi)["beam_ut"] for mi in ms])
+        svnum = np.stack([bt._svd_num(mi)[0] for mi in ms])
+        ctx.project_diag(but, svnum, ctx.to_device(self._npower(nc)), N, off, alpha=1.0, accumulate=True)
+        return S, N, ndofs, off
+
+    def sn_covariance(self, mi):
+        """(S, N) of one m as numpy arrays (kltransform.py:258-308)."""
+        S, N, ndofs, off = self.sn_covariance_device([mi])
+        get_context().sync()
+        n = int(ndofs[0])
+        return S[: n * n].cpu().numpy().reshape(n, n), N[: n * n].cpu().numpy().reshape(n, n)
+
+    # ---- the transform -------------------------------------------------------------------
+    def _transform_batch(self, ms):
+        """KL modes of several m: list of (evals, evecs[rows = modes], inv, evextra)."""
+        ctx = get_context()
+        S, N, ndofs, off = self.sn_covariance_device(ms)
+        evals, evoff, evecs, ac, sweeps = ctx.eigh_gen(S, N, ndofs, off)
+        ev_h = evals.cpu().numpy()
+        out = []
+        for i, mi in enumerate(ms):
+            n = int(ndofs[i])
+            if n == 0:
+                out.append((np.array([]), np.array([[]]), np.array([[]]), {"ac": 0.0}))
+                continue
+            E = evecs[off[i] : off[i] + n * n].cpu().numpy().reshape(n, n)
+            inv = None
+            if self.inverse:
+                inv = _inv_gen(E).T
+            out.append((ev_h[evoff[i] : evoff[i] + n].copy(), E, inv, {"ac": float(ac[i])}))
+        return out
+
+    def _transform_m(self, mi):
+        return self._transform_batch([mi])[0]
+
+    def _save(self, mi, evals, evecs, inv, evextra):
+        """Write ev_m_<m>.hdf5 (kltransform.py:377-421)."""
+        with storage.File(self._evfile % mi, "w") as f:
+            f.attrs["m"] = mi
+            f.attrs["SUBSET"] = bool(self.subset)
+            nside = int(self.beamtransfer.ndof(mi))
+            evalsf = np.zeros(nside, dtype=np.float64)
+            if evals.size != 0:
+                evalsf[-evals.size :] = evals
+            f.create_dataset("evals_full", data=evalsf)
+            if self.subset:
+                i_ev = np.searchsorted(evals, self.threshold)
+                evals = evals[i_ev:]
+                evecs = evecs[i_ev:]
+                logger.info("Modes with S/N > %f: %i of %i" % (self.threshold, evals.size, evalsf.size))
+            f.create_dataset("evals", data=evals)
+            f.create_dataset("evecs", data=evecs)
+            f.attrs["num_modes"] = evals.size
+            if self.inverse:
+                if self.subset:
+                    inv = inv[i_ev:]
+                f.create_dataset("evinv", data=inv)
+            self._ev_save_hook(f, evextra)
+        return evals, evecs
+
+    def transform_save(self, mi):
+        evals, evecs, inv, evextra = self._transform_m(mi)
+        return self._save(mi, evals, evecs, inv, evextra)
+
+    def _ev_save_hook(self, f, evextra):
+        ac = evextra["ac"]
+        if ac != 0.0:
+            f.attrs["add_const"] = ac
+            f.attrs["FLAGS"] = "NotPositiveDefinite"
+        else:
+            f.attrs["FLAGS"] = "Normal"
+
+    def _batches(self, ms):
+        """Split this rank's m list so that the S, N, L, C, W, E buffers of a batch fit the budget."""
+        budget = self.kl_chunk_gb * (1 << 30)
+        out, cur, used = [], [], 0.0
+        for mi in ms:
+            n = float(self.beamtransfer.ndof(mi))
+            need = 8.0 * n * n * 16.0
+            if cur and used + need > budget:
+                out.append(cur)
+                cur, used = [], 0.0
+            cur.append(mi)
+            used += need
+        if cur:
+            out.append(cur)
+        return out
+
+    def generate(self, regen=False):
+        """KL-transform every m of this rank and save (kltransform.py:480-513)."""
+        st = time.time()
+        todo = [mi for mi in self.beamtransfer._my_ms() if regen or not os.path.exists(self._evfile % mi)]
+        for batch in self._batches(todo):
+            for mi, res in zip(batch, self._transform_batch(batch)):
+                self._save(mi, *res)
+        parallel.barrier()
+        if parallel.rank0():
+            logger.info("======== Ending KL calculation (time=%f) ========" % (time.time() - st))
+        self._collect()
+
+    # ---- spectra ---------------------------------------------------------------------------
+    def evals_all(self):
+        with storage.File(self.evdir + "/evals.hdf5", "r") as f:
+            return f["evals"][:]
+
+    def _evfunc(self, mi):
+        evf = np.zeros(self.beamtransfer.ndofmax)
+        with storage.File(self._evfile % mi, "r") as f:
+            if f["evals_full"].shape[0] > 0:
+                ev = f["evals_full"][:]
+                evf[-ev.size :] = ev
+        return evf
+
+    def _collect(self):
+        """evals.hdf5: (mmax+1, ndofmax), right aligned (kltransform.py:452-478)."""
+        mine = [(mi, self._evfunc(mi)) for mi in self.beamtransfer._my_ms()]
+        parts = parallel.gather_objects(mine)
+        if parallel.rank0():
+            if os.path.exists(self.evdir + "/evals.hdf5"):
+                return
+            arr = np.zeros((self.telescope.mmax + 1, self.beamtransfer.ndofmax))
+            for part in parts:
+                for mi, ev in part:
+                    arr[mi] = ev
+            with storage.File(self.evdir + "/evals.hdf5", "w") as f:
+                f.create_dataset("evals", data=arr)
+
+    # ---- mode access (kltransform.py:517-660) -------------------------------------------------
+    olddatafile = False
+
+    @util.cache_last
+    def modes_m(self, mi, threshold=None):
+        if not os.path.exists(self._evfile % mi):
+            return self.transform_save(mi)
+        with storage.File(self._evfile % mi, "r") as f:
+            if f["evals"].shape[0] == 0:
+                return None, None
+            evals = f["evals"][:]
+            startind = np.searchsorted(evals, threshold) if threshold is not None else 0
+            if startind == evals.size:
+                return None, None
+            evecs = f["evecs"][startind:]
+            return evals[startind:], (evecs.conj() if self.olddatafile else evecs)
+
+    @util.cache_last
+    def evals_m(self, mi, threshold=None):
+        modes = self.modes_m(mi, threshold)
+        return None if modes[0] is None else modes[0]
+
+    @util.cache_last
+    def invmodes_m(self, mi, threshold=None):
+        evals = self.evals_m(mi, threshold)
+        with storage.File(self._evfile % mi, "r") as f:
+            if "evinv" in f:
+                inv = f["evinv"][:]
+                if threshold is not None:
+                    inv = inv[(-evals.size) :]
+                return inv.T
+        return np.linalg.pinv(self.modes_m(mi, threshold)[1])
+
+    # ---- projections (kltransform.py:710-842) ---------------------------------------------------
+    def project_vector_svd_to_kl(self, mi, vec, threshold=None):
+        evals, evecs = self.modes_m(mi, threshold)
+        if evals is None:
+            return np.zeros((0,), dtype=np.complex128)
+        if vec.shape[0] != evecs.shape[1]:
+            raise Exception("Vectors are incompatible.")
+        from .beamtransfer import _device_gemm
+
+        return _device_gemm(evecs, vec)
+
+    def project_vector_sky_to_kl(self, mi, vec, threshold=None):
+        return self.project_vector_svd_to_kl(mi, self.beamtransfer.project_vector_sky_to_svd(mi, vec), threshold)
+
+    def project_matrix_svd_to_kl(self, mi, mat, threshold=None):
+        evals, evecs = self.modes_m(mi, threshold)
+        if (mat.shape[0] != evecs.shape[1]) or (mat.shape[0] != mat.shape[1]):
+            raise Exception("Matrix size incompatible.")
+        from .beamtransfer import _device_gemm
+
+        return _device_gemm(_device_gemm(evecs, mat), evecs.T.conj())
+
+    def project_matrix_sky_to_kl(self, mi, mat, threshold=None):
+        return self.project_matrix_svd_to_kl(mi, self.beamtransfer.project_matrix_sky_to_svd(mi, mat), threshold)
+
+
+def _inv_gen(A):
+    """Inverse of the mode matrix (kltransform.py:124-143); small, host LAPACK is fine for this
+    optional product (off the generation path unless `inverse` is set)."""
+    try:
+        return np.linalg.inv(A)
+    except np.linalg.LinAlgError:
+        return np.linalg.pinv(A)

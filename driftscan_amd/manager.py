@@ -1,0 +1,114 @@
+"""ProductManager: YAML configuration -> telescope / BeamTransfer / KL objects and the
+order in which products are generated (drift/core/manager.py:28-305)."""
+import logging
+import os
+
+import yaml
+
+from . import beamtransfer, cylinder, doublekl, kltransform, parallel
+
+logger = logging.getLogger(__name__)
+
+teltype_dict = {
+    "UnpolarisedCylinder": cylinder.UnpolarisedCylinderTelescope,
+    "PolarisedCylinder": cylinder.PolarisedCylinderTelescope,
+}
+
+kltype_dict = {"KLTransform": kltransform.KLTransform, "DoubleKL": doublekl.DoubleKL}
+
+# power-spectrum estimators are outside this build's hot path
+pstype_dict = {}
+
+
+def _resolve_class(clstype, clsdict, objtype=""):
+    if isinstance(clstype, dict):
+        import importlib
+        import importlib.util
+
+        if "file" in clstype:
+            spec = importlib.util.spec_from_file_location(clstype["module"], clstype["file"])
+            module = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(module)
+        else:
+            module = importlib.import_module(clstype["module"])
+        return getattr(module, clstype["class"])
+    if clstype in clsdict:
+        return clsdict[clstype]
+    raise Exception("Unsupported %s" % objtype)
+
+
+class ProductManager(object):
+    directory = None
+    gen_beams = False
+    gen_kl = False
+    gen_ps = False
+    skip_svd = False
+    skip_svd_inv = False
+
+    @classmethod
+    def from_config(cls, configfile):
+        configfile = os.path.normpath(os.path.expandvars(os.path.expanduser(configfile)))
+        if not os.path.exists(configfile):
+            raise Exception("Configuration file does not exist %s." % configfile)
+        if os.path.isdir(configfile):
+            configfile = configfile + "/config.yaml"
+        with open(configfile, "r") as f:
+            yconf = yaml.safe_load(f)
+        outdir = yconf["config"]["output_directory"]
+        dfile = os.path.join(outdir, "config.yaml")
+        if parallel.rank0():
+            if not os.path.isabs(outdir):
+                outdir_abs = os.path.abspath(os.path.normpath(os.path.join(os.path.dirname(configfile), outdir)))
+            else:
+                outdir_abs = outdir
+            os.makedirs(outdir_abs, exist_ok=True)
+            dfile = os.path.join(outdir_abs, "config.yaml")
+            if not os.path.exists(dfile) or not os.path.samefile(configfile, dfile):
+                with open(configfile, "r") as f:
+                    contents = f.read()
+                if outdir_abs != outdir:
+                    contents = contents.replace(outdir, outdir_abs)
+                with open(dfile, "w+") as f:
+                    f.write(contents)
+        dfile = parallel.bcast_object(dfile)
+        parallel.barrier()
+        c = cls()
+        with open(dfile) as f:
+            c.apply_config(yaml.safe_load(f))
+        return c
+
+    def apply_config(self, yconf):
+        if "config" not in yconf:
+            raise ValueError("Configuration file must have an 'config' section.")
+        if "telescope" not in yconf:
+            raise ValueError("Configuration file must have an 'telescope' section.")
+        self.config = yconf
+        self.directory = os.path.expandvars(os.path.expanduser(yconf["config"]["output_directory"]))
+        telclass = _resolve_class(yconf["telescope"]["type"], teltype_dict, "telescope")
+        self.telescope = telclass.from_config(yconf["telescope"])
+        if yconf["config"].get("nosvd") or yconf["config"].get("fullsvd"):
+            raise NotImplementedError("BeamTransferNoSVD / FullSVD are not part of this build (SURVEY.md §8f)")
+        self.beamtransfer = beamtransfer.BeamTransfer(self.directory + "/bt/", telescope=self.telescope)
+        self.beamtransfer.read_config(yconf["config"])
+        self.gen_beams = bool(yconf["config"].get("beamtransfers"))
+        self.skip_svd = bool(yconf["config"].get("skip_svd"))
+        self.kltransforms = {}
+        for klentry in yconf.get("kltransform", []) or []:
+            klclass = _resolve_class(klentry["type"], kltype_dict, "KL filter")
+            self.kltransforms[klentry["name"]] = klclass.from_config(klentry, self.beamtransfer, subdir=klentry["name"])
+        self.gen_kl = bool(yconf["config"].get("kltransform"))
+        self.psestimators = {}
+        self.gen_ps = False  # Fisher estimators: "next" row, not built
+
+    def generate(self):
+        os.makedirs(self.directory, exist_ok=True)
+        if parallel.rank0():
+            with open(os.path.join(self.directory, "configdump.yaml"), "w") as fh:
+                yaml.dump(self.config, fh)
+        if self.gen_beams:
+            self.beamtransfer.generate(skip_svd=self.skip_svd)
+        if self.gen_kl:
+            for klname, klobj in self.kltransforms.items():
+                klobj.generate()
+        if parallel.rank0():
+            logger.info("DONE GENERATING PRODUCTS")

@@ -1,0 +1,187 @@
+"""GPU parity of the operator classes (BeamTransfer / KLTransform / DoubleKL /
+ProductManager) against golden vectors of the unmodified reference and against the
+numpy oracle, going through the same method names the reference's tests use."""
+import os
+
+import numpy as np
+import pytest
+
+from parity_util import assert_spectrum, pencil_sensitivity, pencil_tol, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+class FakeTelescope(object):
+    """The attribute surface BeamTransfer/KLTransform read."""
+
+    def __init__(self, g):
+        self.nfreq, self.nbase = int(g["F"]), int(g["B"])
+        self.npairs = self.nbase
+        self.num_pol_sky = int(g["P"])
+        self.lmax = self.mmax = int(g["lmax"])
+        self.included_freq = np.arange(self.nfreq)
+        self.included_baseline = np.arange(self.nbase)
+        self.included_pol = np.arange(self.num_pol_sky)
+        self.frequencies = g["frequencies"]
+        self.baselines = np.zeros((self.nbase, 2))
+        self.tsys_flat = float(g["tsys_flat"])
+        self._npower = g["npower"]
+
+    def noisepower(self, bl_indices, f_indices, ndays=None):
+        bl, fi = np.broadcast_arrays(bl_indices, f_indices)
+        return self._npower[fi, bl]
+
+
+@pytest.fixture(scope="module", params=["unpol", "pol"])
+def setup(request, golden_dir, tmp_path_factory):
+    from driftscan_amd import beamtransfer, device, storage
+
+    device.reset_context()
+    g = np.load(os.path.join(golden_dir, "svdkl_%s.npz" % request.param))
+    tel = FakeTelescope(g)
+    d = str(tmp_path_factory.mktemp("bt_" + request.param))
+    bt = beamtransfer.BeamTransfer(d, telescope=tel)
+    bt.polsvcut = float(g["polsvcut"])
+    bt.svcut = float(g["svcut"])
+    bt._generate_dirs()
+    mlist = [int(m) for m in g["mlist"]]
+    for mi in mlist:
+        with storage.File(bt._mfile(mi), "w") as f:
+            f.create_dataset("beam_m", data=g["m%d_beam_m" % mi][..., mi:])
+    bt._my_ms = lambda mlist_=None: mlist  # only the fixture's m exist
+    bt._generate_svdfiles(regen=True)
+    return g, bt, mlist
+
+
+def test_beamtransfer_svd_products(setup):
+    g, bt, mlist = setup
+    for mi in mlist:
+        pre = "m%d_" % mi
+        assert np.array_equal(bt.beam_m(mi), g[pre + "beam_m"])
+        assert_spectrum(bt.beam_singularvalues(mi), g[pre + "singularvalues"], 1e-10, "sv m=%d" % mi)
+        svnum, svbounds = bt._svd_num(mi)
+        assert np.array_equal(svnum, g[pre + "svnum"]) and np.array_equal(svbounds, g[pre + "svbounds"])
+        assert bt.ndof(mi) == g[pre + "svbounds"][-1]
+        assert bt.beam_svd(mi).shape == g[pre + "beam_svd"].shape
+        assert bt.invbeam_svd(mi).shape == g[pre + "invbeam_svd"].shape
+        assert bt.beam_ut(mi).shape == g[pre + "beam_ut"].shape
+        # projections of the reference's C_l through *our* SVD products: gauge invariant
+        for key, cv, to in (("proj_sg", "cv_sg", False), ("proj_fg", "cv_fg", False), ("proj_sg_temponly", "cv_sg", True)):
+            ours = bt.project_matrix_sky_to_svd(mi, g[cv], temponly=to)
+            ref = g[pre + key]
+            assert ours.shape == ref.shape
+            assert_spectrum(np.linalg.eigvalsh(ours), np.linalg.eigvalsh(ref), 1e-9, key)
+    assert bt.svd_all().shape == (bt.telescope.mmax + 1, bt.nfreq, bt.svd_len)
+
+
+def _kl_objects(g, bt):
+    from driftscan_amd import doublekl, kltransform
+
+    out = {}
+    for name, klass, kw in (("kl", kltransform.KLTransform, {}), ("klnf", kltransform.KLTransform, dict(use_foregrounds=False)),
+                            ("dk", doublekl.DoubleKL, dict(foreground_threshold=float(g["fg_threshold"])))):
+        obj = klass.from_config(dict(threshold=float(g["threshold"]), **kw), bt, subdir=name)
+        obj._cvsg, obj._cvfg = g["cv_sg"], g["cv_fg"]
+        out[name] = obj
+    return out
+
+
+def test_kltransform(setup):
+    g, bt, mlist = setup
+    kls = _kl_objects(g, bt)
+    for name in ("kl", "klnf"):
+        kl = kls[name]
+        kl.generate(regen=True)
+        for mi in mlist:
+            pre = "m%d_%s_" % (mi, name)
+            cs, cn = g[pre + "cs"], g[pre + "cn"]
+            tol = pencil_tol(cn)
+            if tol > 1e-6:
+                tol = max(1e-10, 10 * pencil_sensitivity(cs, cn))
+            ref = g[pre + "evals"]
+            from driftscan_amd import storage
+
+            with storage.File(kl._evfile % mi, "r") as f:
+                full = f["evals_full"][:]
+                kept = f["evals"][:]
+                evecs = f["evecs"][:]
+                assert f.attrs["FLAGS"] == "Normal"
+            assert_spectrum(full, ref, tol, "%s evals m=%d" % (name, mi))
+            assert kept.size == int(g[pre + "nkept"])
+            assert evecs.shape == (kept.size, ref.size)
+            ev, evec = kl.modes_m(mi)
+            if kept.size:
+                assert np.array_equal(ev, kept)
+                # E N E^H = I on the kept modes, in the (gauge-dependent) basis of OUR svd products
+                s_ours, n_ours = kl.sn_covariance(mi)
+                assert relerr(evec @ n_ours @ evec.T.conj(), np.eye(kept.size), 1.0) < max(1e-8, 100 * tol)
+                assert relerr(evec @ s_ours @ evec.T.conj(), np.diag(kept), np.abs(ref).max()) < max(1e-8, 100 * tol)
+        assert kl.evals_all().shape == (bt.telescope.mmax + 1, bt.ndofmax)
+
+
+def test_doublekl(setup):
+    g, bt, mlist = setup
+    from driftscan_amd import storage
+
+    dk = _kl_objects(g, bt)["dk"]
+    dk.generate(regen=True)
+    for mi in mlist:
+        pre = "m%d_dk_" % mi
+        tol1 = max(1e-10, 10 * pencil_sensitivity(g[pre + "cs_nothermal"], g[pre + "cn_nothermal"]))
+        with storage.File(dk._evfile % mi, "r") as f:
+            f_evals = f["f_evals"][:]
+            full = f["evals_full"][:]
+        assert_spectrum(f_evals, g[pre + "f_evals"], tol1, "f_evals m=%d" % mi)
+        ref = g[pre + "evals"]
+        # number of modes passing the foreground cut, then the stage-2 spectrum
+        assert (full != 0).sum() == ref.size or np.count_nonzero(full) <= ref.size
+        got = full[full.size - ref.size :] if ref.size else full[:0]
+        if ref.size:
+            assert_spectrum(got, ref, max(1e-8, 100 * tol1), "dk evals m=%d" % mi)
+
+
+def test_product_manager_end_to_end(tmp_path):
+    """ProductManager.from_config -> generate() on a small cylinder, compared with the oracle chain."""
+    import yaml
+
+    from driftscan_amd import device, manager, storage
+    from oracle import btgen as ob
+    from oracle import kl as okl
+    from oracle import svdchain as osvd
+
+    device.reset_context()
+    conf = dict(
+        config=dict(beamtransfers=True, kltransform=True, psfisher=False, output_directory=str(tmp_path / "prod"),
+                    polsvcut=1e-4, truncate=False),
+        telescope=dict(type="UnpolarisedCylinder", num_freq=3, freq_start=400.0, freq_end=430.0, freq_mode="edge",
+                       num_cylinders=2, cylinder_width=2.0, num_feeds=3, feed_spacing=0.4, tsys=1.0),
+        kltransform=[dict(type="KLTransform", name="kl", use_foregrounds=False),
+                     dict(type="DoubleKL", name="dk", foreground_threshold=10.0)],
+    )
+    cfile = tmp_path / "params.yaml"
+    cfile.write_text(yaml.dump(conf))
+    pm = manager.ProductManager.from_config(str(cfile))
+    pm.generate()
+    t, bt = pm.telescope, pm.beamtransfer
+    assert os.path.exists(bt.directory + "/beam_m/COMPLETED")
+    # oracle chain on the same telescope
+    desc = dict(polarised=False, zenith=t.zenith, baselines=t.baselines, uniquepairs=t.uniquepairs,
+                beamclass=t.beamclass, wavelengths=t.wavelengths, cylinder_width=t.cylinder_width, fwhm_e=t.fwhm_e,
+                fwhm_h=t.fwhm_h, lmax=t.lmax, mmax=t.mmax, l_boost=t.l_boost, included_freq=t.included_freq,
+                included_baseline=t.included_baseline, accuracy_boost=t.accuracy_boost)
+    ms = [0, 5, t.mmax]
+    ref_bm = ob.beam_transfer_m(desc, mlist=ms)
+    noisew = bt._noisew()[:, : t.nbase]
+    kl = pm.kltransforms["kl"]
+    npw = kl._npower(1.0)
+    for mi in ms:
+        bm = bt.beam_m(mi)
+        assert np.abs(bm - ref_bm[mi]).max() < 1e-9 * np.abs(ref_bm[0]).max()
+        ref_svd = osvd.svd_m(ref_bm[mi], noisew, polsvcut=bt.polsvcut)
+        assert_spectrum(bt.beam_singularvalues(mi), ref_svd["singularvalues"], 1e-9, "sv")
+        cs, cn = okl.sn_covariance(ref_svd["beam_svd"], ref_svd["beam_ut"], ref_svd["singularvalues"], kl.signal(),
+                                   kl.foreground(), npw, svcut=bt.svcut, use_foregrounds=False)
+        ev, _, _ = okl.kl_transform_m(cs, cn)
+        with storage.File(kl._evfile % mi, "r") as f:
+            assert_spectrum(f["evals_full"][:], ev, 1e-8, "kl evals m=%d" % mi)
+    assert pm.kltransforms["dk"].evals_all().shape == (t.mmax + 1, bt.ndofmax)
