@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py — m-blocks/sec of the per-m hot path (BT-gen + SVD + KL) on MI355X.
+
+Workload (BASELINE.json configs[1]): 32-feed unpolarised cylinder
+(2 cylinders x 16 feeds, width 5 m, spacing 0.4 m), 16 channels 400-450 MHz (edge),
+force_lmax = force_mmax = 128  =>  nbase 46, ntel 92, 129 m-blocks, ndofmax 1472.
+One "step" = one pass of the whole hot path over all 129 m-blocks with the telescope
+description resident (beam-transfer generation -> three-stage SVD compression + pinv ->
+covariance projection + generalised eigenproblem of the KL transform); products stay in
+HBM, file output is not part of the timed region.  With N > 1 ranks every GPU runs the
+same 129-block workload (independent m-blocks, no data-path collective): weak scaling,
+value = N * 129 * steps / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (see the README of the driver contract).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CFG2 = dict(num_freq=16, freq_start=400.0, freq_end=450.0, freq_mode="edge", num_cylinders=2, cylinder_width=5.0,
+            num_feeds=16, feed_spacing=0.4, tsys=1.0, force_lmax=128, force_mmax=128)
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (AMD datasheet)
+
+
+def build_objects(tmpdir):
+    from driftscan_amd import beamtransfer, cylinder, kltransform
+
+    tel = cylinder.UnpolarisedCylinderTelescope.from_config(CFG2)
+    bt = beamtransfer.BeamTransfer(tmpdir, telescope=tel)
+    kl = kltransform.KLTransform.from_config(dict(threshold=0.1), bt, subdir="kl")
+    return tel, bt, kl
+
+
+def hot_path_step(tel, bt, kl, ctx, stage_times=None):
+    """One pass over all m-blocks; everything stays on the device."""
+    import torch
+
+    from driftscan_amd import btgen
+
+    def mark():
+        if stage_times is not None:
+            torch.cuda.synchronize()
+            return time.perf_counter()
+        return 0.0
+
+    t0 = mark()
+    beam_all = btgen.beam_m_all(tel, ctx=ctx)                       # (mmax+1, F, 2, B, P, L)
+    t1 = mark()
+    res = bt.svd_device(beam_all)                                   # SVD chain + pinv, all m at once
+    t2 = mark()
+    ms = list(range(tel.mmax + 1))
+    sv = res["singularvalues"].cpu().numpy()
+    bt._dev = {mi: dict(beam_svd=res["beam_svd"][mi], beam_ut=res["beam_ut"][mi], singularvalues=sv[mi]) for mi in ms}
+    out = None
+    for batch in kl._batches(ms):
+        out = kl._transform_batch(batch)                            # projections + eigh_gen
+    t3 = mark()
+    if stage_times is not None:
+        stage_times.append((t1 - t0, t2 - t1, t3 - t2))
+    return out
+
+
+def cpu_baseline(tel, bt, kl, budget_s=25.0):
+    """The oracle (numpy/scipy restatement, kind = "port") timed on the host cores for a
+    bounded sample of m-blocks of the same workload: SVD chain + KL for m in a spread of
+    values, plus BT-gen for a handful of (f, b) columns scaled to the full count."""
+    import scipy
+
+    from oracle import btgen as ob
+    from oracle import kl as okl
+    from oracle import svdchain as osvd
+
+    ncores = os.cpu_count() or 1
+    desc = dict(polarised=False, zenith=tel.zenith, baselines=tel.baselines, uniquepairs=tel.uniquepairs,
+                beamclass=tel.beamclass, wavelengths=tel.wavelengths, cylinder_width=tel.cylinder_width,
+                fwhm_e=tel.fwhm_e, fwhm_h=tel.fwhm_h, lmax=tel.lmax, mmax=tel.mmax, l_boost=tel.l_boost,
+                included_freq=np.array([0]), included_baseline=np.array([0, tel.nbase - 1]),
+                accuracy_boost=tel.accuracy_boost)
+    t0 = time.perf_counter()
+    ob.beam_transfer_m(desc)  # 2 of the F*B columns, all m
+    t_bt_cols = time.perf_counter() - t0
+    t_bt_full = t_bt_cols / 2.0 * tel.nfreq * tel.nbase
+    # SVD + KL on synthetic blocks of the right shape (random full-rank, like SURVEY §6's probe)
+    rng = np.random.default_rng(1000)
+    F, B, L = tel.nfreq, tel.nbase, tel.lmax + 1
+    noisew = bt._noisew()[:, :B]
+    npw = kl._npower(1.0)
+    sample_m = [0, tel.mmax // 4, tel.mmax // 2, 3 * tel.mmax // 4]
+    t_svdkl = 0.0
+    done = 0
+    for mi in sample_m:
+        blk = np.zeros((F, 2, B, 1, L), dtype=np.complex128)
+        blk[..., mi:] = (rng.standard_normal((F, 2, B, 1, L - mi)) + 1j * rng.standard_normal((F, 2, B, 1, L - mi))) \
+            * np.exp(-np.arange(L - mi) / 20.0)
+        t0 = time.perf_counter()
+        o = osvd.svd_m(blk, noisew, polsvcut=bt.polsvcut)
+        cs, cn = okl.sn_covariance(o["beam_svd"], o["beam_ut"], o["singularvalues"], kl.signal(), kl.foreground(),
+                                   npw, svcut=bt.svcut)
+        okl.kl_transform_m(cs, cn)
+        t_svdkl += time.perf_counter() - t0
+        done += 1
+        if t_svdkl + t_bt_cols > budget_s:
+            break
+    per_m = t_svdkl / done + t_bt_full / (tel.mmax + 1)
+    return dict(value=1.0 / per_m, unit="m-blocks/s", cores=ncores, kind="port",
+                sample="oracle (numpy %s / scipy %s, threaded BLAS on %d cores): SVD chain + KL on %d m-blocks "
+                       "(m = %s) of the config-2 shape, BT-gen on 2 of %d (f,b) columns scaled to all"
+                       % (np.__version__, scipy.__version__, ncores, done, sample_m[:done], tel.nfreq * tel.nbase))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import tempfile
+
+    import torch
+
+    from driftscan_amd import device, parallel
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        parallel.init_from_env("nccl")
+    rank = parallel.rank()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    ctx = device.get_context(workspace_bytes=24 << 30)
+
+    with tempfile.TemporaryDirectory() as tmp:
+        tel, bt, kl = build_objects(tmp)
+        for _ in range(args.warmup):
+            hot_path_step(tel, bt, kl, ctx)
+        ctx.prof_reset(True)
+        stage = []
+        parallel.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            hot_path_step(tel, bt, kl, ctx, stage_times=stage)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        dt = time.perf_counter() - t0
+        prof = ctx.prof_report()
+        if world > 1:
+            import torch.distributed as dist
+
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        nblocks = tel.mmax + 1
+        value = world * nblocks * args.steps / dt
+        if rank == 0:
+            st = np.array(stage).mean(axis=0)
+            dom = max(prof, key=lambda k: prof[k]["ms"]) if prof else None
+            roofline = None
+            if dom is not None:
+                p = prof[dom]
+                ach = p["flops"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
+                roofline = dict(bound="mfma", kernel=dom, achieved=ach, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                                frac=ach / FP64_MFMA_PEAK_TFLOPS, traffic=None, launches=p["launches"],
+                                avg_launch_us=1e3 * p["ms"] / max(p["launches"], 1),
+                                flops_per_launch=p["flops"] / max(p["launches"], 1))
+            line = {
+                "metric": "m-blocks/sec (BT-gen + SVD + KL)",
+                "value": value,
+                "unit": "m-blocks/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": 1e3 * dt / args.steps,
+                "higher_is_better": True,
+                "scaling": "weak",
+                "vs_baseline": None,
+                "dtype": "f64",
+                "data": "synthetic",
+                "config": {"workload": "configs[1]: 32-feed unpolarised cylinder, nfreq=16, nbase=46, lmax=mmax=128, "
+                                       "129 m-blocks per GPU per step, KLTransform with foregrounds",
+                           "nfreq": 16, "nbase": 46, "lmax": 128, "mmax": 128, "sharding": "m-blocks, replicas per GPU"},
+                "stage_ms": {"btgen": 1e3 * st[0], "svd": 1e3 * st[1], "kl": 1e3 * st[2]},
+                "kernels_ms": {k: v["ms"] / args.steps for k, v in prof.items()},
+                "roofline": roofline,
+                "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(tel, bt, kl),
+            }
+            print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -26,6 +26,8 @@ SIGNATURES = {
     "dm_ctx_workspace_bytes": (c_sz, [c_vp]),
     "dm_last_error": (ctypes.c_char_p, [c_vp]),
     "dm_version": (c_int, []),
+    "dm_prof_reset": (c_int, [c_vp, c_int]),
+    "dm_prof_report": (c_int, [c_vp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(ctypes.c_longlong)]),
     "dm_zgemm_strided_batched": (
         c_int,
         [c_vp, c_int, c_int, c_int, c_dbl, c_vp, c_int, c_int, c_int, c_i64, c_vp, c_int, c_int, c_int, c_i64,
@@ -319,3 +321,22 @@ def _bt_sht(self, nside, cth, sth, polarised, lside, mmax, lmax_grp, F, B, col_f
 Context.bt_beam_cyl = _bt_beam_cyl
 Context.bt_maps = _bt_maps
 Context.bt_sht = _bt_sht
+
+
+PROF_CLASSES = ["zgemm_grouped", "gemm_grouped_realB", "jac_gram", "jac_inner", "jac_apply"]
+
+
+def _prof_reset(self, enable=True):
+    self.check(self.lib.dm_prof_reset(self.h, int(enable)), "dm_prof_reset")
+
+
+def _prof_report(self):
+    ms = (c_dbl * 8)()
+    fl = (c_dbl * 8)()
+    ln = (ctypes.c_longlong * 8)()
+    self.check(self.lib.dm_prof_report(self.h, ms, fl, ln), "dm_prof_report")
+    return {name: dict(ms=ms[i], flops=fl[i], launches=int(ln[i])) for i, name in enumerate(PROF_CLASSES) if ln[i] > 0}
+
+
+Context.prof_reset = _prof_reset
+Context.prof_report = _prof_report

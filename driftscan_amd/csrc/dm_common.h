@@ -31,6 +31,31 @@ struct dm_ctx {
   char* hpin = nullptr;
   size_t hpin_cap = 0;
   std::string err;
+  // optional per-kernel-class timing (HIP events on ctx->stream) and flop accounting
+  bool prof_on = false;
+  struct prof_rec { int cls; hipEvent_t a, b; double flops; };
+  std::vector<prof_rec> prof;
+  std::vector<hipEvent_t> ev_pool;
+  unsigned long long* prof_dev = nullptr;  // device flop counters, one per class
+};
+
+enum { DM_PROF_GEMM = 0, DM_PROF_GEMM_REAL = 1, DM_PROF_JAC_GRAM = 2, DM_PROF_JAC_INNER = 3, DM_PROF_JAC_APPLY = 4,
+       DM_PROF_NCLASS = 8 };
+
+hipEvent_t dm_prof_event(dm_ctx* ctx);
+// bracket one launch: DM_PROF(ctx, cls, flops) { launch; }
+struct dm_prof_scope {
+  dm_ctx* c; int cls; double flops; hipEvent_t a = nullptr;
+  dm_prof_scope(dm_ctx* ctx, int cls_, double fl) : c(ctx), cls(cls_), flops(fl) {
+    if (c->prof_on) { a = dm_prof_event(c); (void)hipEventRecord(a, c->stream); }
+  }
+  ~dm_prof_scope() {
+    if (c->prof_on && a) {
+      hipEvent_t b = dm_prof_event(c);
+      (void)hipEventRecord(b, c->stream);
+      c->prof.push_back(dm_ctx::prof_rec{cls, a, b, flops});
+    }
+  }
 };
 
 #define DM_OK 0

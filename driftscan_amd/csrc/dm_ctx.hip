@@ -87,7 +87,49 @@ int dm_download(dm_ctx* ctx, void* dst, const void* src, size_t bytes) {
   return DM_OK;
 }
 
+hipEvent_t dm_prof_event(dm_ctx* ctx) {
+  if (!ctx->ev_pool.empty()) {
+    hipEvent_t e = ctx->ev_pool.back();
+    ctx->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
 extern "C" {
+
+int dm_prof_reset(dm_ctx* ctx, int enable) {
+  if (!ctx) return DM_EARG;
+  DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto& r : ctx->prof) { ctx->ev_pool.push_back(r.a); ctx->ev_pool.push_back(r.b); }
+  ctx->prof.clear();
+  if (!ctx->prof_dev) DM_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->prof_dev), sizeof(unsigned long long) * DM_PROF_NCLASS));
+  DM_HIP(ctx, hipMemset(ctx->prof_dev, 0, sizeof(unsigned long long) * DM_PROF_NCLASS));
+  ctx->prof_on = enable != 0;
+  return DM_OK;
+}
+
+// ms[c], flops[c], launches[c] for c < DM_PROF_NCLASS (= 8): summed event time, algorithmic
+// flops and launch count of each kernel class since dm_prof_reset.
+int dm_prof_report(dm_ctx* ctx, double* ms, double* flops, long long* launches) {
+  if (!ctx || !ms || !flops || !launches) return DM_EARG;
+  DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int c = 0; c < DM_PROF_NCLASS; ++c) { ms[c] = 0.0; flops[c] = 0.0; launches[c] = 0; }
+  for (auto& r : ctx->prof) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ms[r.cls] += t;
+    flops[r.cls] += r.flops;
+    launches[r.cls] += 1;
+  }
+  if (ctx->prof_dev) {
+    unsigned long long h[DM_PROF_NCLASS];
+    DM_HIP(ctx, hipMemcpy(h, ctx->prof_dev, sizeof(h), hipMemcpyDeviceToHost));
+    for (int c = 0; c < DM_PROF_NCLASS; ++c) flops[c] += (double)h[c];
+  }
+  return DM_OK;
+}
 
 int dm_ctx_create(int device, size_t workspace_bytes, void* stream, dm_ctx** out) {
   if (!out) return DM_EARG;
@@ -139,6 +181,9 @@ int dm_ctx_destroy(dm_ctx* ctx) {
   for (void* p : ctx->retired) (void)hipFree(p);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->hpin) (void)hipHostFree(ctx->hpin);
+  if (ctx->prof_dev) (void)hipFree(ctx->prof_dev);
+  for (auto& r : ctx->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return DM_OK;

@@ -24,6 +24,8 @@
 #include "dm_common.h"
 #include "dm_kernels.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int BM = 64, BN = 64, BK = 16, LDP = 17;
@@ -189,6 +191,7 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
   if (descs.empty()) return DM_OK;
   std::vector<dm_gemm_tile> tiles;
   std::vector<dm_gemm_tile> tiles_real;
+  double fl_c = 0.0, fl_r = 0.0;
   for (size_t i = 0; i < descs.size(); ++i) {
     const dm_gemm_desc& d = descs[i];
     if (d.M <= 0 || d.N <= 0) continue;
@@ -197,7 +200,9 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
       for (int b = 0; b < tn; ++b) {
         if ((d.flags & DM_GEMM_LOWER) && b > a) continue;
         dm_gemm_tile t{(int)i, a, b};
-        ((d.flags & DM_GEMM_B_REAL) ? tiles_real : tiles).push_back(t);
+        const double rows = std::min(BM, d.M - a * BM), cols = std::min(BN, d.N - b * BN);
+        if (d.flags & DM_GEMM_B_REAL) { tiles_real.push_back(t); fl_r += 4.0 * rows * cols * d.K; }
+        else { tiles.push_back(t); fl_c += 8.0 * rows * cols * d.K; }
       }
   }
   size_t mark = dm_ws_mark(ctx);
@@ -206,12 +211,14 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
   if (!tiles.empty()) {
     dm_gemm_tile* dt = dm_ws_upload(ctx, tiles);
     if (!dt) return DM_ENOMEM;
+    dm_prof_scope ps(ctx, DM_PROF_GEMM, fl_c);
     hipLaunchKernelGGL(zgemm_grouped_kernel<false>, dim3((unsigned)tiles.size()), dim3(256), 0, ctx->stream, dd,
                        dt, (int)tiles.size());
   }
   if (!tiles_real.empty()) {
     dm_gemm_tile* dt = dm_ws_upload(ctx, tiles_real);
     if (!dt) return DM_ENOMEM;
+    dm_prof_scope ps(ctx, DM_PROF_GEMM_REAL, fl_r);
     hipLaunchKernelGGL(zgemm_grouped_kernel<true>, dim3((unsigned)tiles_real.size()), dim3(256), 0, ctx->stream,
                        dd, dt, (int)tiles_real.size());
   }

@@ -59,12 +59,17 @@ __device__ __forceinline__ int item_row(const jac_item& it, int k) {
 // 1. Gram of a row-block pair (one-sided mode)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void jac_gram_kernel(const jac_item* __restrict__ items,
-                                                       const int* __restrict__ active, cplx* __restrict__ Gbuf) {
+                                                       const int* __restrict__ active, cplx* __restrict__ Gbuf,
+                                                       unsigned long long* __restrict__ flopctr) {
   __shared__ double Xre[JP * XP], Xim[JP * XP];
   const jac_item it = items[blockIdx.x];
   if (!active[it.prob]) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fi = lane & 15, fk = lane >> 4;
+  if (flopctr && tid == 0) {
+    const unsigned long long nr = it.na + it.nb;
+    atomicAdd(flopctr, 8ull * nr * nr * (unsigned long long)(it.g1 - it.g0));
+  }
 
   dm_f64x4 gre[4], gim[4];
 #pragma unroll
@@ -297,7 +302,8 @@ constexpr int APPLY_CHUNK = 256;  // columns per workgroup
 __global__ __launch_bounds__(256) void jac_apply_kernel(const jac_item* __restrict__ items,
                                                         const int* __restrict__ active,
                                                         const int* __restrict__ skip,
-                                                        const cplx* __restrict__ Qbuf) {
+                                                        const cplx* __restrict__ Qbuf,
+                                                        unsigned long long* __restrict__ flopctr) {
   extern __shared__ __align__(16) unsigned char smem[];
   double* Are = reinterpret_cast<double*>(smem);  // A = Q^H : Are[k][i] = Re conj(Q[k][i]) = Re Q[k][i]
   double* Aim = Are + JP * QP;                    //            Aim[k][i] = -Im Q[k][i]
@@ -307,6 +313,10 @@ __global__ __launch_bounds__(256) void jac_apply_kernel(const jac_item* __restri
   if (cbeg >= it.c1) return;
   const int cend = min(it.c1, cbeg + APPLY_CHUNK);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (flopctr && tid == 0) {
+    const unsigned long long nr = it.na + it.nb;
+    atomicAdd(flopctr, 8ull * nr * nr * (unsigned long long)(cend - cbeg));
+  }
 
   const cplx* Qi = Qbuf + (size_t)it.q * JP * JP;
   for (int idx = tid; idx < JP * JP; idx += 256) {
@@ -660,11 +670,22 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
       const int nb = plan.round_begin[r], ne = plan.round_begin[r + 1];
       const int ni = ne - nb;
       if (ni == 0) continue;
-      hipLaunchKernelGGL(jac_gram_kernel, dim3(ni), dim3(256), 0, ctx->stream, d_items + nb, d_active, d_G);
-      hipLaunchKernelGGL(jac_inner_kernel<false>, dim3(ni), dim3(256), INNER_LDS, ctx->stream, d_items + nb,
-                         d_active, (const double*)d_floor, d_G, d_Q, d_off, d_skip, tol_outer, tol_inner);
-      hipLaunchKernelGGL(jac_apply_kernel, dim3(ni, chunks), dim3(256), APPLY_LDS, ctx->stream, d_items + nb,
-                         d_active, d_skip, d_Q);
+      unsigned long long* fc = ctx->prof_on ? ctx->prof_dev : nullptr;
+      {
+        dm_prof_scope ps(ctx, DM_PROF_JAC_GRAM, 0.0);
+        hipLaunchKernelGGL(jac_gram_kernel, dim3(ni), dim3(256), 0, ctx->stream, d_items + nb, d_active, d_G,
+                           fc ? fc + DM_PROF_JAC_GRAM : nullptr);
+      }
+      {
+        dm_prof_scope ps(ctx, DM_PROF_JAC_INNER, 0.0);
+        hipLaunchKernelGGL(jac_inner_kernel<false>, dim3(ni), dim3(256), INNER_LDS, ctx->stream, d_items + nb,
+                           d_active, (const double*)d_floor, d_G, d_Q, d_off, d_skip, tol_outer, tol_inner);
+      }
+      {
+        dm_prof_scope ps(ctx, DM_PROF_JAC_APPLY, 0.0);
+        hipLaunchKernelGGL(jac_apply_kernel, dim3(ni, chunks), dim3(256), APPLY_LDS, ctx->stream, d_items + nb,
+                           d_active, d_skip, d_Q, fc ? fc + DM_PROF_JAC_APPLY : nullptr);
+      }
     }
     DM_HIP(ctx, hipGetLastError());
     DM_TRY(dm_download(ctx, h_off.data(), d_off, sizeof(unsigned long long) * np));
@@ -792,16 +813,29 @@ int dm_jacobi_herm(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, d
       if (ni == 0) continue;
       jac_item* icur = (cur == 0 ? d_iC : d_iT) + nb;
       jac_item* ioth = (cur == 0 ? d_iT : d_iC) + nb;
-      hipLaunchKernelGGL(jac_inner_kernel<true>, dim3(ni), dim3(256), INNER_LDS, ctx->stream, icur, d_active,
-                         d_floor, (const cplx*)nullptr, d_Q, d_off, d_skip, tol_outer, tol_inner);
-      hipLaunchKernelGGL(jac_apply_kernel, dim3(ni, chunks), dim3(256), APPLY_LDS, ctx->stream, icur, d_active,
-                         d_skip, d_Q);
-      hipLaunchKernelGGL(jac_apply_kernel, dim3(ni, chunks), dim3(256), APPLY_LDS, ctx->stream, d_iW + nb,
-                         d_active, d_skip, d_Q);
+      unsigned long long* fc = ctx->prof_on ? ctx->prof_dev + DM_PROF_JAC_APPLY : nullptr;
+      {
+        dm_prof_scope ps(ctx, DM_PROF_JAC_INNER, 0.0);
+        hipLaunchKernelGGL(jac_inner_kernel<true>, dim3(ni), dim3(256), INNER_LDS, ctx->stream, icur, d_active,
+                           d_floor, (const cplx*)nullptr, d_Q, d_off, d_skip, tol_outer, tol_inner);
+      }
+      {
+        dm_prof_scope ps(ctx, DM_PROF_JAC_APPLY, 0.0);
+        hipLaunchKernelGGL(jac_apply_kernel, dim3(ni, chunks), dim3(256), APPLY_LDS, ctx->stream, icur, d_active,
+                           d_skip, d_Q, fc);
+      }
+      {
+        dm_prof_scope ps(ctx, DM_PROF_JAC_APPLY, 0.0);
+        hipLaunchKernelGGL(jac_apply_kernel, dim3(ni, chunks), dim3(256), APPLY_LDS, ctx->stream, d_iW + nb,
+                           d_active, d_skip, d_Q, fc);
+      }
       hipLaunchKernelGGL(jac_ctrans_kernel, dim3(tb, tb, np), dim3(256), 0, ctx->stream,
                          cur == 0 ? d_tdC : d_tdT, d_active);
-      hipLaunchKernelGGL(jac_apply_kernel, dim3(ni, chunks), dim3(256), APPLY_LDS, ctx->stream, ioth, d_active,
-                         d_skip, d_Q);
+      {
+        dm_prof_scope ps(ctx, DM_PROF_JAC_APPLY, 0.0);
+        hipLaunchKernelGGL(jac_apply_kernel, dim3(ni, chunks), dim3(256), APPLY_LDS, ctx->stream, ioth, d_active,
+                           d_skip, d_Q, fc);
+      }
       cur ^= 1;
     }
     DM_HIP(ctx, hipGetLastError());

@@ -39,6 +39,14 @@ size_t dm_ctx_workspace_bytes(dm_ctx* ctx);
 const char* dm_last_error(dm_ctx* ctx);
 int dm_version(void);
 
+/* Per-kernel-class instrumentation for bench.py: when enabled every launch of the
+ * MFMA kernels is bracketed by HIP events on the context's stream.  dm_prof_report
+ * fills 8-entry arrays (class 0 grouped ZGEMM, 1 real-B GEMM, 2 Jacobi Gram,
+ * 3 Jacobi inner solver, 4 Jacobi apply) with summed event time [ms], algorithmic
+ * flops actually executed, and launch counts since the last reset. */
+int dm_prof_reset(dm_ctx* ctx, int enable);
+int dm_prof_report(dm_ctx* ctx, double* ms, double* flops, long long* launches);
+
 /* ---- dense building blocks (exposed for the parity tests) --------------- */
 /* C = alpha * op(A) diag(kscale) op(B) + beta C on the fp64 matrix cores.
  * A is viewed as (M x K) through element strides (rsA, csA), B as (K x N)
