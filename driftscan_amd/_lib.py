@@ -40,6 +40,7 @@ SIGNATURES = {
         c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_i64, c_int, c_vp, ctypes.POINTER(c_int)]),
     "dm_jacobi_herm_batched": (
         c_int, [c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_int, c_i64, c_int, c_vp, ctypes.POINTER(c_int)]),
+    "dm_herm_eig_batched": (c_int, [c_vp, c_int, c_vp, c_int, c_i64, c_vp, c_int, c_i64, c_int, c_vp]),
     "dm_svd_chain": (
         c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp,
                 ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
@@ -266,7 +267,8 @@ def _eigh_gen(self, A, B, ndofs, off):
                               self.ptr(evecs), ac, ctypes.byref(sw))
     self.check(rc, "dm_eigh_gen")
     if rc > 0:
-        raise DriftMIError("dm_eigh_gen: B not positive definite even after the diagonal rescue (info=%d)" % rc)
+        msg = self.lib.dm_last_error(self.h)
+        raise DriftMIError("dm_eigh_gen: numerical failure (info=%d): %s" % (rc, msg.decode() if msg else ""))
     return evals, evoff, evecs, np.array(ac[: len(n)], dtype=np.float64), sw.value
 
 
@@ -340,3 +342,16 @@ def _prof_report(self):
 
 Context.prof_reset = _prof_reset
 Context.prof_report = _prof_report
+
+
+def _herm_eig(self, C, n, ldc, strideC=0, batch=1):
+    W = self.empty((batch, n, n), np.complex128)
+    ev = self.empty((batch, max(n, 1)), np.float64)
+    rc = self.lib.dm_herm_eig_batched(self.h, n, self.ptr(C), ldc, strideC, self.ptr(W), n, n * n, batch, self.ptr(ev))
+    self.check(rc, "dm_herm_eig_batched")
+    if rc > 0:
+        raise DriftMIError("dm_herm_eig_batched: QL failure (%d)" % rc)
+    return ev, W
+
+
+Context.herm_eig = _herm_eig

@@ -75,4 +75,15 @@ int dm_jacobi_herm_batched(dm_ctx* ctx, int n, void* C, int ldc, int64_t strideC
   return dm_jacobi_herm(ctx, ps, evals_dev, n > 0 ? n : 1, sweeps_host);
 }
 
+int dm_herm_eig_batched(dm_ctx* ctx, int n, void* C, int ldc, int64_t strideC, void* W, int ldw, int64_t strideW,
+                        int batch, double* evals_dev) {
+  if (!ctx) return DM_EARG;
+  DM_ARG(ctx, n >= 0 && C && W && evals_dev && batch >= 0);
+  std::vector<dm_jac_herm_problem> ps(batch);
+  for (int b = 0; b < batch; ++b)
+    ps[b] = dm_jac_herm_problem{reinterpret_cast<cplx*>(C) + b * strideC, ldc,
+                                reinterpret_cast<cplx*>(W) + b * strideW, ldw, n};
+  return dm_herm_eig_tridiag(ctx, ps, evals_dev, n > 0 ? n : 1);
+}
+
 }  // extern "C"

@@ -81,6 +81,11 @@ struct dm_jac_herm_problem {
 int dm_jacobi_herm(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, double* evals, int evals_stride,
                    int* sweeps_out = nullptr);
 
+// Same contract as dm_jacobi_herm (C destroyed, W rows = eigenvectors^H, evals unsorted;
+// W need not be initialised) through Householder tridiagonalisation + implicit QL +
+// compact-WY back-transformation (dm_tridiag.hip).  Returns > 0 if QL fails.  Synchronises.
+int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, double* evals, int evals_stride);
+
 // Permute the rows [row0, row0+nrows) x [0, ncols) of each problem so that the
 // device keys (key_stride doubles per problem) end up sorted; keys are sorted too.
 int dm_sort_rows_by_key(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double* key, int key_stride,

@@ -272,10 +272,9 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
     for (int b : bad) {
       DM_TRY(copy_async(ctx, Tw + loff[b], B + off_host[b], (size_t)n_host[b] * n_host[b]));
       DM_TRY(dm_hermitize(ctx, Tw + loff[b], n_host[b], n_host[b]));
-      DM_TRY(dm_set_identity(ctx, Ww + loff[b], n_host[b], n_host[b]));
       hp.push_back(dm_jac_herm_problem{Tw + loff[b], n_host[b], Ww + loff[b], n_host[b], n_host[b]});
     }
-    DM_TRY(dm_jacobi_herm(ctx, hp, evw, std::max(maxn, 1), nullptr));
+    DM_TRY(dm_herm_eig_tridiag(ctx, hp, evw, std::max(maxn, 1)));
     std::vector<double> hev((size_t)bad.size() * std::max(maxn, 1));
     DM_TRY(dm_download(ctx, hev.data(), evw, sizeof(double) * hev.size()));
     std::vector<double> shifts(nblk, 0.0);
@@ -325,10 +324,9 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
   {
     std::vector<dm_jac_herm_problem> hp;
     for (int b : work) {
-      DM_TRY(dm_set_identity(ctx, Ww + loff[b], n_host[b], n_host[b]));
       hp.push_back(dm_jac_herm_problem{Tw + loff[b], n_host[b], Ww + loff[b], n_host[b], n_host[b]});
     }
-    DM_TRY(dm_jacobi_herm(ctx, hp, evw, std::max(maxn, 1), sweeps_host));
+    DM_TRY(dm_herm_eig_tridiag(ctx, hp, evw, std::max(maxn, 1)));
     // ascending order (LAPACK convention), rows of W follow
     std::vector<dm_jac_problem> sp;
     for (int b : work) sp.push_back(dm_jac_problem{Ww + loff[b], n_host[b], 0, n_host[b], n_host[b], 0, 0});

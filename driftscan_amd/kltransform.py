@@ -193,7 +193,7 @@ class KLTransform(config.Reader):
         out, cur, used = [], [], 0.0
         for mi in ms:
             n = float(self.beamtransfer.ndof(mi))
-            need = 8.0 * n * n * 16.0
+            need = 16.0 * n * n * 16.0  # S, N, E, L, C, W, V, Z, recorded rotations, staging
             if cur and used + need > budget:
                 out.append(cur)
                 cur, used = [], 0.0

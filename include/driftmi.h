@@ -88,6 +88,14 @@ int dm_jacobi_rows_batched(dm_ctx* ctx, int rows, int cols, int gc0, int gc1, vo
 int dm_jacobi_herm_batched(dm_ctx* ctx, int n, void* C_dev, int ldc, int64_t strideC, void* W_dev, int ldw,
                            int64_t strideW, int batch, double* evals_dev, int* sweeps_host);
 
+/* Hermitian eigendecomposition of `batch` n x n matrices by Householder
+ * tridiagonalisation + implicit QL + blocked back-transformation (the production
+ * path of dm_eigh_gen).  C is destroyed; W_dev rows are eigenvectors^H; evals_dev
+ * (n per matrix) is NOT sorted.  Returns > 0 if the QL iteration fails.  Synchronises.
+ * Replaces: the zheevd inside scipy.linalg.eigh, drift/core/kltransform.py:89, :107. */
+int dm_herm_eig_batched(dm_ctx* ctx, int n, void* C_dev, int ldc, int64_t strideC, void* W_dev, int ldw,
+                        int64_t strideW, int batch, double* evals_dev);
+
 /* ---- SVD compression of beam-transfer blocks -------------------------------- */
 /* Three-stage SVD chain + pseudo-inverse for nblk m-blocks x F frequencies.
  *   beam_m_dev   (nblk, F, T, P, L) c128   noise-unweighted beam_m blocks, T = 2*nbase

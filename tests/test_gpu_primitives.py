@@ -152,3 +152,51 @@ def test_jacobi_herm(ctx, n):
         D = W[b] @ C[b] @ W[b].conj().T
         assert np.abs(D - np.diag(ev[b, :n])).max() <= 2e-12 * np.abs(ref).max()
     assert sweeps < 30
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 33, 64, 80, 200, 517])
+def test_herm_eig_tridiag(ctx, n):
+    """Householder tridiagonalisation + QL + back-transformation (the production eigensolver)."""
+    rng = np.random.default_rng(n)
+    nb = 3
+    X = crand(rng, nb, n, n)
+    lam = 10.0 ** rng.uniform(-12, 0, (nb, n)) * rng.choice([1.0, 1.0, -1.0], (nb, n))
+    Qm = np.linalg.qr(X)[0]
+    C = (Qm * lam[:, None, :]) @ Qm.conj().transpose(0, 2, 1)
+    C = 0.5 * (C + C.conj().transpose(0, 2, 1))
+    dC = ctx.to_device(C)
+    ev, W = ctx.herm_eig(dC, n, n, strideC=n * n, batch=nb)
+    ev = ev.cpu().numpy()
+    W = W.cpu().numpy()
+    for b in range(nb):
+        ref = np.linalg.eigvalsh(C[b])
+        scale = np.abs(ref).max()
+        assert np.abs(np.sort(ev[b, :n]) - ref).max() <= 5e-14 * scale
+        assert np.abs(W[b] @ W[b].conj().T - np.eye(n)).max() < 5e-13
+        D = W[b] @ C[b] @ W[b].conj().T
+        assert np.abs(D - np.diag(ev[b, :n])).max() <= 5e-13 * scale
+
+
+def test_herm_eig_mixed_sizes_via_eigh_gen(ctx):
+    """Different n in one batch (the KL use: ndof varies with m)."""
+    from driftscan_amd._lib import block_offsets
+    import scipy.linalg as la
+
+    rng = np.random.default_rng(5)
+    ns = [70, 3, 129, 1, 40]
+    off, tot = block_offsets(ns)
+    As, Bs = [], []
+    for n in ns:
+        X, Y = crand(rng, n, n), crand(rng, n, n)
+        As.append(X @ X.conj().T)
+        Bs.append(Y @ Y.conj().T + n * np.eye(n))
+    A = np.concatenate([a.ravel() for a in As])
+    B = np.concatenate([b.ravel() for b in Bs])
+    evals, evoff, evecs, ac, _ = ctx.eigh_gen(ctx.to_device(A), ctx.to_device(B), ns, off)
+    ev = evals.cpu().numpy()
+    E = evecs.cpu().numpy()
+    for i, n in enumerate(ns):
+        ref = la.eigh(As[i], Bs[i], eigvals_only=True)
+        assert np.abs(ev[evoff[i]: evoff[i] + n] - ref).max() <= 1e-11 * ref.max()
+        Ei = E[off[i]: off[i] + n * n].reshape(n, n)
+        assert np.abs(Ei @ Bs[i] @ Ei.conj().T - np.eye(n)).max() < 1e-10
