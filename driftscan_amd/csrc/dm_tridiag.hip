@@ -199,10 +199,14 @@ __device__ __forceinline__ void dev_lartg(double f, double g, double& c, double&
   if (g == 0.0) { c = 1.0; s = 0.0; r = f; }
   else if (f == 0.0) { c = 0.0; s = 1.0; r = g; }
   else {
-    const double dnorm = hypot(f, g);
-    c = fabs(f) / dnorm;
+    const double h = f * f + g * g;
+    // the matrix is scaled to unit max-norm, so overflow cannot happen; fall back to hypot
+    // only when the squares underflow
+    const double dnorm = h > 1e-290 ? sqrt(h) : hypot(f, g);
+    const double inv = 1.0 / dnorm;
+    c = fabs(f) * inv;
     r = copysign(dnorm, f);
-    s = g / r;
+    s = g * copysign(inv, f);
   }
 }
 
@@ -228,12 +232,23 @@ __device__ void dev_laev2(double a, double b, double c, double& rt1, double& rt2
   if (sgn1 == sgn2) { const double tn = cs1; cs1 = -sn1; sn1 = tn; }
 }
 
+template <bool USE_LDS>
 __global__ __launch_bounds__(64) void ql_kernel(const ql_mat* __restrict__ qs) {
-  if (threadIdx.x != 0) return;
+  extern __shared__ __align__(16) unsigned char ql_smem[];
   const ql_mat Q = qs[blockIdx.x];
   const int n = Q.n;
   double* d = Q.d;
   double* e = Q.e;
+  if (USE_LDS) {
+    // the serial chain below touches d and e at every rotation: keep them in LDS
+    double* ld = reinterpret_cast<double*>(ql_smem);
+    double* le = ld + n;
+    for (int i = threadIdx.x; i < n; i += 64) { ld[i] = Q.d[i]; le[i] = (i + 1 < n) ? Q.e[i] : 0.0; }
+    __syncthreads();
+    d = ld;
+    e = le;
+  }
+  if (threadIdx.x != 0) return;
   int ns = 0;
   long long nr = 0;
   int status = 0;
@@ -300,16 +315,23 @@ __global__ __launch_bounds__(64) void ql_kernel(const ql_mat* __restrict__ qs) {
           p = 0.0;
           if (!record(0, l, mq - l)) break;
           double2* rot = Q.rot + (nr - (mq - l));
+          double dup = d[mq];            // d[i+1], carried in a register
+          double ei = e[mq - 1], di = d[mq - 1];
           for (int i = mq - 1; i >= l; --i) {
-            const double f = s * e[i], b = c * e[i];
+            // prefetch the next plane's entries: independent of the dependency chain below
+            const double en = (i > l) ? e[i - 1] : 0.0, dn = (i > l) ? d[i - 1] : 0.0;
+            const double f = s * ei, b = c * ei;
             dev_lartg(g, f, c, s, r);
             if (i != mq - 1) e[i + 1] = r;
-            g = d[i + 1] - p;
-            r = (d[i] - g) * s + 2.0 * c * b;
+            g = dup - p;
+            r = (di - g) * s + 2.0 * c * b;
             p = s * r;
             d[i + 1] = g + p;
             g = c * r - b;
             rot[i - l] = make_double2(c, -s);
+            dup = di;
+            ei = en;
+            di = dn;
           }
           d[l] -= p;
           e[l] = g;
@@ -343,23 +365,29 @@ __global__ __launch_bounds__(64) void ql_kernel(const ql_mat* __restrict__ qs) {
           p = 0.0;
           if (!record(1, mq, l - mq)) break;
           double2* rot = Q.rot + (nr - (l - mq));
+          double dlo = d[mq];            // d[i], carried in a register
+          double ei = e[mq], di1 = d[mq + 1];
           for (int i = mq; i <= l - 1; ++i) {
-            const double f = s * e[i], b = c * e[i];
+            const double en = (i < l - 1) ? e[i + 1] : 0.0, dn = (i < l - 1) ? d[i + 2] : 0.0;
+            const double f = s * ei, b = c * ei;
             dev_lartg(g, f, c, s, r);
             if (i != mq) e[i - 1] = r;
-            g = d[i] - p;
-            r = (d[i + 1] - g) * s + 2.0 * c * b;
+            g = dlo - p;
+            r = (di1 - g) * s + 2.0 * c * b;
             p = s * r;
             d[i] = g + p;
             g = c * r - b;
             rot[i - mq] = make_double2(c, s);
+            dlo = di1;
+            ei = en;
+            di1 = dn;
           }
           d[l] -= p;
           e[l - 1] = g;
         }
       }
     }
-    for (int i = 0; i < n; ++i) d[i] *= anorm > 0.0 ? anorm : 1.0;
+    for (int i = 0; i < n; ++i) Q.d[i] = d[i] * (anorm > 0.0 ? anorm : 1.0);
   }
   *Q.nsweeps = ns;
   *Q.status = status;
@@ -611,7 +639,17 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
   ql_mat* d_qm = dm_ws_upload(ctx, qm);
   rot_mat* d_rm = dm_ws_upload(ctx, rm);
   if (!d_qm || !d_rm) return DM_ENOMEM;
-  hipLaunchKernelGGL(ql_kernel, dim3(np), dim3(64), 0, ctx->stream, d_qm);
+  if ((size_t)maxn * 16 <= 120u * 1024u) {
+    static bool attr = false;
+    if (!attr) {
+      DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(ql_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+      attr = true;
+    }
+    hipLaunchKernelGGL(ql_kernel<true>, dim3(np), dim3(64), (size_t)maxn * 16, ctx->stream, d_qm);
+  } else {
+    hipLaunchKernelGGL(ql_kernel<false>, dim3(np), dim3(64), 0, ctx->stream, d_qm);
+  }
   // ---- T3
   hipLaunchKernelGGL(zt_identity_kernel, dim3((maxn + 255) / 256, maxn, np), dim3(256), 0, ctx->stream, d_rm);
   hipLaunchKernelGGL(rot_apply_kernel, dim3((maxn + 255) / 256, np), dim3(256), 0, ctx->stream, d_rm);

@@ -1,0 +1,126 @@
+"""CPU-only host logic: config properties, file patterns, storage shim, sky model shapes,
+m-partitioning (serial and 2-rank gloo)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from driftscan_amd import config, parallel, skymodel, storage, util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_patterns():
+    assert util.natpattern(94) % 7 == "07"
+    assert util.natpattern(512) % 3 == "003"
+    assert util.natpattern(9) % 3 == "3"
+    assert util.intpattern(94) % 7 == "+07"
+
+
+def test_cache_last():
+    calls = []
+
+    @util.cache_last
+    def f(a, b=1):
+        calls.append((a, b))
+        return [a, b]
+
+    r1 = f(1)
+    assert f(1) is r1 and len(calls) == 1
+    f(2)
+    assert len(calls) == 2
+
+
+def test_config_reader():
+    class A(config.Reader):
+        x = config.Property(proptype=float, default=2.0)
+        flag = config.Property(proptype=config.truthy, default=False, key="my_flag")
+        mode = config.enum(["a", "b"], default="a")
+        lst = config.list_type(type_=int, default=[])
+
+    a = A.from_config(dict(x="3.5", my_flag="Yes", mode="b", lst=[1, "2"]))
+    assert a.x == 3.5 and a.flag is True and a.mode == "b" and a.lst == [1, 2]
+    assert A().x == 2.0
+    with pytest.raises(ValueError):
+        A.from_config(dict(mode="c"))
+
+
+def test_storage_roundtrip(tmp_path):
+    p = str(tmp_path / "x.hdf5")
+    with storage.File(p, "w") as f:
+        d = f.create_dataset("beam_m", shape=(2, 3), dtype=np.complex128)
+        d[0] = [1, 2j, 3]
+        f.create_dataset("sv", data=np.arange(4.0))
+        f.attrs["m"] = 5
+        f.attrs["FLAGS"] = "Normal"
+    assert storage.can_open(p)
+    with storage.File(p, "r") as f:
+        assert "beam_m" in f and f["beam_m"].shape == (2, 3)
+        assert np.allclose(f["beam_m"][0], [1, 2j, 3]) and np.allclose(f["sv"][1:3], [1, 2])
+        assert int(f.attrs["m"]) == 5 and str(f.attrs["FLAGS"]) == "Normal"
+    assert not storage.can_open(str(tmp_path / "missing.hdf5"))
+
+
+def test_skymodel_shapes():
+    nu = np.linspace(400, 450, 5)
+    s = skymodel.im21cm_model(10, nu, 4)
+    f = skymodel.foreground_model(10, nu, 4)
+    assert s.shape == f.shape == (4, 4, 11, 5, 5)
+    assert np.abs(s[1:]).max() == 0 and np.abs(f[0, 0]).min() > 0 and np.abs(f[3, 3]).max() == 0
+    assert np.allclose(f, f.transpose(0, 1, 2, 4, 3))
+    for l in (0, 5, 10):  # covariance in frequency must be positive semi-definite
+        assert np.linalg.eigvalsh(f[0, 0, l]).min() > -1e-12 * np.abs(f[0, 0, l]).max()
+
+
+def test_partition_serial():
+    items = list(range(10))
+    assert parallel.partition(items) == items
+    assert parallel.partition(items, costs=[1.0] * 10) == items
+
+
+WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from driftscan_amd import parallel
+dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
+ms = list(range(11))
+costs = [float(12 - m) for m in ms]
+mine = parallel.partition(ms, costs)
+plain = parallel.partition(ms)
+parts = parallel.gather_objects((parallel.rank(), mine, plain))
+tot = parallel.allreduce_sum(np.array([float(sum(mine)), 1.0]))
+word = parallel.bcast_object("hello" if parallel.rank0() else None)
+parallel.barrier()
+if parallel.rank0():
+    print(json.dumps(dict(parts=parts, tot=tot.tolist(), word=word)))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo(tmp_path):
+    """world_size = 2 on CPU: m-blocks are sharded without overlap, spectra gather to rank 0,
+    the Fisher-style all-reduce sums over ranks."""
+    import json
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % dict(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1].decode()[-2000:] for o in outs]
+    res = json.loads(outs[0][0].decode().strip().splitlines()[-1])
+    by_rank = {r: (mine, plain) for r, mine, plain in res["parts"]}
+    assert sorted(by_rank[0][0] + by_rank[1][0]) == list(range(11))      # LPT: disjoint cover
+    assert by_rank[0][1] == list(range(6)) and by_rank[1][1] == list(range(6, 11))  # the reference's contiguous split
+    load = [sum(12 - m for m in by_rank[r][0]) for r in (0, 1)]
+    assert abs(load[0] - load[1]) <= 12                                     # balanced
+    assert res["tot"] == [float(sum(range(11))), 2.0] and res["word"] == "hello"
