@@ -681,7 +681,11 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
     }
     if (!hp.empty()) {
       DM_TRY(dm_gemm_grouped_launch(ctx, g));
-      for (auto& h : hp) DM_TRY(dm_hermitize(ctx, h.C, h.ldc, h.n));
+      {
+        std::vector<dm_mat> hm;
+        for (auto& h : hp) hm.push_back(dm_mat{h.C, h.ldc, h.n});
+        DM_TRY(dm_hermitize_batched(ctx, hm));
+      }
       // evals land at consecutive strides of the *compacted* problem list
       DM_TRY(dm_herm_eig_tridiag(ctx, hp, evp, sigma_stride));
       std::vector<dm_jac_problem> sp;
@@ -974,10 +978,13 @@ int dm_sort_rows_by_key(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, d
                      key_stride, d_tmp, d_toff, key, d_ks);
   hipLaunchKernelGGL(jac_scatter_back_kernel, dim3(gx, maxrows, np), dim3(256), 0, ctx->stream, d_pd, d_tmp, d_toff);
   // sorted keys back into `key` (only the first nrows entries of each problem)
-  for (int p = 0; p < np; ++p)
-    if (nrows[p] > 0)
-      DM_HIP(ctx, hipMemcpyAsync(key + (size_t)p * key_stride, d_ks + (size_t)p * key_stride,
-                                 sizeof(double) * nrows[p], hipMemcpyDeviceToDevice, ctx->stream));
+  {
+    std::vector<dm_cdesc> cp;
+    for (int p = 0; p < np; ++p)
+      if (nrows[p] > 0)
+        cp.push_back(dm_cdesc{d_ks + (size_t)p * key_stride, key + (size_t)p * key_stride, sizeof(double) * nrows[p]});
+    DM_TRY(dm_copy_batched(ctx, cp));
+  }
   DM_HIP(ctx, hipGetLastError());
   dm_ws_release(ctx, mark);
   return DM_OK;

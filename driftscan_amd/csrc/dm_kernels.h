@@ -116,3 +116,10 @@ int dm_conj_transpose(dm_ctx* ctx, const cplx* src, int lds, cplx* dst, int ldd,
 int dm_set_identity(dm_ctx* ctx, cplx* a, int ld, int n);
 int dm_hermitize(dm_ctx* ctx, cplx* a, int ld, int n);  // a <- (a + a^H)/2, real diagonal
 int dm_fill_zero(dm_ctx* ctx, void* p, size_t bytes);
+// one-launch versions for lists of matrices / buffers
+struct dm_tdesc { const cplx* src; int lds; cplx* dst; int ldd; int rows; int cols; };
+struct dm_cdesc { const void* src; void* dst; size_t bytes; };
+int dm_conj_transpose_batched(dm_ctx* ctx, const std::vector<dm_tdesc>& v);
+int dm_set_identity_batched(dm_ctx* ctx, const std::vector<dm_mat>& v);
+int dm_hermitize_batched(dm_ctx* ctx, const std::vector<dm_mat>& v);
+int dm_copy_batched(dm_ctx* ctx, const std::vector<dm_cdesc>& v);

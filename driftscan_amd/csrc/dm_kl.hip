@@ -252,10 +252,12 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
   // ---- Cholesky of B (on a copy, the rescue needs B itself)
   auto factor = [&](const std::vector<int>& blks, std::vector<int>& info) -> int {
     std::vector<dm_mat> mats;
+    std::vector<dm_cdesc> cp;
     for (int b : blks) {
-      DM_TRY(copy_async(ctx, Lw + loff[b], B + off_host[b], (size_t)n_host[b] * n_host[b]));
+      cp.push_back(dm_cdesc{B + off_host[b], Lw + loff[b], sizeof(cplx) * (size_t)n_host[b] * n_host[b]});
       mats.push_back(dm_mat{Lw + loff[b], n_host[b], n_host[b]});
     }
+    DM_TRY(dm_copy_batched(ctx, cp));
     DM_TRY(dm_potrf_batched(ctx, mats, info_dev));
     info.resize(blks.size());
     if (!blks.empty()) DM_TRY(dm_download(ctx, info.data(), info_dev, sizeof(int) * blks.size()));
@@ -312,12 +314,16 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
     std::vector<dm_trsm_problem> t1, t2;
     for (int b : work) t1.push_back(dm_trsm_problem{Lw + loff[b], n_host[b], n_host[b], A + off_host[b], n_host[b], n_host[b]});
     DM_TRY(dm_trsm_left_lower_batched(ctx, t1, false));  // X = L^-1 A
+    std::vector<dm_tdesc> tr;
+    std::vector<dm_mat> hm;
     for (int b : work) {
-      DM_TRY(dm_conj_transpose(ctx, A + off_host[b], n_host[b], Tw + loff[b], n_host[b], n_host[b], n_host[b]));
+      tr.push_back(dm_tdesc{A + off_host[b], n_host[b], Tw + loff[b], n_host[b], n_host[b], n_host[b]});
       t2.push_back(dm_trsm_problem{Lw + loff[b], n_host[b], n_host[b], Tw + loff[b], n_host[b], n_host[b]});
+      hm.push_back(dm_mat{Tw + loff[b], n_host[b], n_host[b]});
     }
+    DM_TRY(dm_conj_transpose_batched(ctx, tr));
     DM_TRY(dm_trsm_left_lower_batched(ctx, t2, false));  // Y = L^-1 X^H = C^H = C
-    for (int b : work) DM_TRY(dm_hermitize(ctx, Tw + loff[b], n_host[b], n_host[b]));
+    DM_TRY(dm_hermitize_batched(ctx, hm));
   }
 
   // ---- Hermitian eigendecomposition C = W^H diag(ev) W
@@ -331,23 +337,26 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
     std::vector<dm_jac_problem> sp;
     for (int b : work) sp.push_back(dm_jac_problem{Ww + loff[b], n_host[b], 0, n_host[b], n_host[b], 0, 0});
     DM_TRY(dm_sort_rows_by_key(ctx, sp, evw, std::max(maxn, 1), false));
+    std::vector<dm_cdesc> cp;
     for (size_t i = 0; i < work.size(); ++i) {
       const int b = work[i];
-      DM_HIP(ctx, hipMemcpyAsync(evals_dev + evoff_host[b], evw + i * std::max(maxn, 1), sizeof(double) * n_host[b],
-                                 hipMemcpyDeviceToDevice, ctx->stream));
+      cp.push_back(dm_cdesc{evw + i * std::max(maxn, 1), evals_dev + evoff_host[b], sizeof(double) * n_host[b]});
     }
+    DM_TRY(dm_copy_batched(ctx, cp));
   }
 
   // ---- back-transformation: rows of E = rows of W times L^-1  <=>  E^H = L^-H W^H
   {
     std::vector<dm_trsm_problem> t3;
+    std::vector<dm_tdesc> tr1, tr2;
     for (int b : work) {
-      DM_TRY(dm_conj_transpose(ctx, Ww + loff[b], n_host[b], Tw + loff[b], n_host[b], n_host[b], n_host[b]));
+      tr1.push_back(dm_tdesc{Ww + loff[b], n_host[b], Tw + loff[b], n_host[b], n_host[b], n_host[b]});
       t3.push_back(dm_trsm_problem{Lw + loff[b], n_host[b], n_host[b], Tw + loff[b], n_host[b], n_host[b]});
+      tr2.push_back(dm_tdesc{Tw + loff[b], n_host[b], E + off_host[b], n_host[b], n_host[b], n_host[b]});
     }
+    DM_TRY(dm_conj_transpose_batched(ctx, tr1));
     DM_TRY(dm_trsm_left_lower_batched(ctx, t3, true));
-    for (int b : work)
-      DM_TRY(dm_conj_transpose(ctx, Tw + loff[b], n_host[b], E + off_host[b], n_host[b], n_host[b], n_host[b]));
+    DM_TRY(dm_conj_transpose_batched(ctx, tr2));
   }
   DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   dm_ws_release(ctx, mark);

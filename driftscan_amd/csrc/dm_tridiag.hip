@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -37,6 +38,7 @@ struct trd_mat {
   cplx* Vp;      // TNB x n panel of V (row j = vector of panel column j)
   cplx* Wp;      // TNB x n panel of W
   cplx* p;       // n scratch (hemv result)
+  cplx* ab;      // 2*TNB scratch: panel dot products W^H v, V^H v
   double* d;     // n
   double* e;     // n
   cplx* tau;     // n
@@ -111,11 +113,27 @@ __global__ __launch_bounds__(256) void trd_col_kernel(const trd_mat* __restrict_
 __global__ __launch_bounds__(256) void trd_hemv_kernel(const trd_mat* __restrict__ ms, int k, int j) {
   const trd_mat M = ms[blockIdx.y];
   const int n = M.n;
-  const int row = k + 1 + blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (k >= n - 1 || row >= n) return;
+  if (k >= n - 1) return;
   const int lane = threadIdx.x & 63;
-  const cplx* __restrict__ a = M.A + (size_t)row * M.lda;
+  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
   const cplx* __restrict__ v = M.Vp + (size_t)j * n;
+  if (slot < 2 * j) {
+    // panel dot products a[q] = W_q^H v, b[q] = V_q^H v (needed by trd_w): ride along with the HEMV
+    const cplx* x = (slot < j ? M.Wp + (size_t)slot * n : M.Vp + (size_t)(slot - j) * n);
+    double sr = 0.0, si = 0.0;
+    for (int i = k + 1 + lane; i < n; i += 64) {
+      cplx xx = x[i], vv = v[i];  // conj(x) * v
+      sr += xx.x * vv.x + xx.y * vv.y;
+      si += xx.x * vv.y - xx.y * vv.x;
+    }
+    sr = dm_wave_sum(sr);
+    si = dm_wave_sum(si);
+    if (lane == 0) M.ab[slot] = make_double2(sr, si);
+    return;
+  }
+  const int row = k + 1 + (slot - 2 * j);
+  if (row >= n) return;
+  const cplx* __restrict__ a = M.A + (size_t)row * M.lda;
   double sr = 0.0, si = 0.0;
   for (int c = k + 1 + lane; c < n; c += 64) {
     cplx x = a[c], y = v[c];
@@ -136,20 +154,8 @@ __global__ __launch_bounds__(256) void trd_w_kernel(const trd_mat* __restrict__ 
   __shared__ double redr[4], redi[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const cplx* __restrict__ v = M.Vp + (size_t)j * n;
-  // 2j dot products of length n-k-1: waves take them in turn
-  for (int q = wave; q < 2 * j; q += 4) {
-    const cplx* x = (q < j ? M.Wp + (size_t)q * n : M.Vp + (size_t)(q - j) * n);
-    double sr = 0.0, si = 0.0;
-    for (int i = k + 1 + lane; i < n; i += 64) {
-      cplx xx = x[i], vv = v[i];  // conj(x) * v
-      sr += xx.x * vv.x + xx.y * vv.y;
-      si += xx.x * vv.y - xx.y * vv.x;
-    }
-    sr = dm_wave_sum(sr);
-    si = dm_wave_sum(si);
-    if (lane == 0) {
-      if (q < j) sa[q] = make_double2(sr, si); else sb[q - j] = make_double2(sr, si);
-    }
+  if (tid < 2 * j) {
+    if (tid < j) sa[tid] = M.ab[tid]; else sb[tid - j] = M.ab[tid];
   }
   __syncthreads();
   const cplx tau = M.tau[k];
@@ -200,10 +206,22 @@ __device__ __forceinline__ void dev_lartg(double f, double g, double& c, double&
   else if (f == 0.0) { c = 0.0; s = 1.0; r = g; }
   else {
     const double h = f * f + g * g;
-    // the matrix is scaled to unit max-norm, so overflow cannot happen; fall back to hypot
-    // only when the squares underflow
-    const double dnorm = h > 1e-290 ? sqrt(h) : hypot(f, g);
-    const double inv = 1.0 / dnorm;
+    // The matrix is scaled to unit max-norm, so h cannot overflow; when the squares underflow
+    // fall back to the safe path.  1/sqrt(h) from the hardware estimate plus two Newton steps
+    // (error ~ 1 ulp) replaces a sqrt and a division on the serial critical path.
+    double dnorm, inv;
+    if (h > 1e-290) {
+      double y = __builtin_amdgcn_rsq(h);
+      y = y * (1.5 - 0.5 * h * y * y);
+      y = y * (1.5 - 0.5 * h * y * y);
+      inv = y;
+      dnorm = h * y;
+      // one correction step on dnorm so that dnorm^2 = h to working accuracy
+      dnorm = dnorm + 0.5 * y * (h - dnorm * dnorm);
+    } else {
+      dnorm = hypot(f, g);
+      inv = 1.0 / dnorm;
+    }
     c = fabs(f) * inv;
     r = copysign(dnorm, f);
     s = g * copysign(inv, f);
@@ -536,6 +554,26 @@ __global__ __launch_bounds__(64) void larft_kernel(const tf_mat* __restrict__ ts
 // ===========================================================================
 // driver: C (destroyed) -> evals (unsorted), W rows = eigenvectors^H
 // ===========================================================================
+// The batch is cut into up to four chunks (largest matrices first) that move through
+// T1 -> T2 -> T3/T4 as a software pipeline: the serial QL recurrence of chunk c runs on a
+// side stream while the main stream tridiagonalises chunk c+1 and back-transforms chunk c-1,
+// so the only latency-bound kernel of the solver is hidden behind HBM- and MFMA-bound work.
+namespace {
+struct tri_side {
+  hipStream_t s = nullptr;
+  std::vector<hipEvent_t> ev;
+};
+tri_side g_side;
+hipEvent_t side_event(size_t i) {
+  while (g_side.ev.size() <= i) {
+    hipEvent_t e = nullptr;
+    (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    g_side.ev.push_back(e);
+  }
+  return g_side.ev[i];
+}
+}  // namespace
+
 int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, double* evals, int evals_stride) {
   const int np = (int)probs.size();
   if (np == 0) return DM_OK;
@@ -552,67 +590,15 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
   DM_ARG(ctx, maxn <= evals_stride);
   if (maxn == 0) return DM_OK;
 
+  // ---- storage for every problem (all chunks are in flight at once)
   cplx* Vt = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(tot, 1));
   cplx* Vp = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * TNB, 1));
   cplx* Wp = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * TNB, 1));
   cplx* pv = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn, 1));
+  cplx* abv = dm_ws_alloc_t<cplx>(ctx, (size_t)np * 2 * TNB);
   double* dd = dm_ws_alloc_t<double>(ctx, std::max<size_t>(totn, 1));
   double* ee = dm_ws_alloc_t<double>(ctx, std::max<size_t>(totn, 1));
   cplx* tau = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn, 1));
-  if (!Vt || !Vp || !Wp || !pv || !dd || !ee || !tau) return DM_ENOMEM;
-  DM_TRY(dm_fill_zero(ctx, Vp, sizeof(cplx) * totn * TNB));
-  DM_TRY(dm_fill_zero(ctx, Wp, sizeof(cplx) * totn * TNB));
-  DM_TRY(dm_fill_zero(ctx, tau, sizeof(cplx) * totn));
-
-  std::vector<trd_mat> tm(np);
-  for (int p = 0; p < np; ++p)
-    tm[p] = trd_mat{probs[p].C, probs[p].ldc, probs[p].n, Vt + off[p], Vp + offn[p] * TNB, Wp + offn[p] * TNB,
-                    pv + offn[p], dd + offn[p], ee + offn[p], tau + offn[p]};
-  trd_mat* d_tm = dm_ws_upload(ctx, tm);
-  if (!d_tm) return DM_ENOMEM;
-
-  // ---- T1
-  for (int k0 = 0; k0 < maxn; k0 += TNB) {
-    const int k1 = std::min(k0 + TNB, maxn);
-    for (int k = k0; k < k1; ++k) {
-      const int j = k - k0;
-      hipLaunchKernelGGL(trd_col_kernel, dim3(np), dim3(256), 0, ctx->stream, d_tm, k, j);
-      if (k < maxn - 1) {
-        const int rt = (maxn - k - 1 + 3) / 4;
-        hipLaunchKernelGGL(trd_hemv_kernel, dim3(rt, np), dim3(256), 0, ctx->stream, d_tm, k, j);
-        hipLaunchKernelGGL(trd_w_kernel, dim3(np), dim3(256), 0, ctx->stream, d_tm, k, j);
-      }
-    }
-    // her2k on the trailing block: A[k1:, k1:] -= V W^H + W V^H  (two launches: they hit the same C)
-    if (k1 < maxn) {
-      for (int pass = 0; pass < 2; ++pass) {
-        std::vector<dm_gemm_desc> g;
-        for (int p = 0; p < np; ++p) {
-          const int n = probs[p].n;
-          const int rem = n - k1;
-          if (rem <= 0) continue;
-          const int kb = std::min(k1, n - 1) - k0;  // reflectors actually generated in this panel
-          if (kb <= 0) continue;
-          const cplx* Vb = Vp + offn[p] * TNB + k1;
-          const cplx* Wb = Wp + offn[p] * TNB + k1;
-          const cplx* Aop = pass == 0 ? Vb : Wb;
-          const cplx* Bop = pass == 0 ? Wb : Vb;
-          // A-operand (rem x kb): element (i, jj) = X[jj][k1 + i]; B-operand (kb x rem): conj(Y[jj][k1 + c])
-          g.push_back(dm_gemm_make(Aop, 1, n, false, Bop, n, 1, true, probs[p].C + (size_t)k1 * probs[p].ldc + k1,
-                                   probs[p].ldc, rem, rem, kb, -1.0, 1.0));
-        }
-        DM_TRY(dm_gemm_grouped_launch(ctx, g));
-      }
-      // the next panel starts from clean V, W (rows beyond its own are read before written otherwise)
-      DM_TRY(dm_fill_zero(ctx, Vp, sizeof(cplx) * totn * TNB));
-      DM_TRY(dm_fill_zero(ctx, Wp, sizeof(cplx) * totn * TNB));
-    }
-  }
-  DM_HIP(ctx, hipGetLastError());
-
-  // ---- T2
-  std::vector<ql_mat> qm(np);
-  std::vector<rot_mat> rm(np);
   size_t totsw = 0, totrot = 0;
   std::vector<size_t> swoff(np), rotoff(np);
   for (int p = 0; p < np; ++p) {
@@ -628,95 +614,223 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
   int* nsw = dm_ws_alloc_t<int>(ctx, np);
   int* stat = dm_ws_alloc_t<int>(ctx, np);
   double* Zt = dm_ws_alloc_t<double>(ctx, std::max<size_t>(tot, 1));
-  if (!sw_dir || !sw_lo || !sw_cnt || !sw_off || !rot || !nsw || !stat || !Zt) return DM_ENOMEM;
-  for (int p = 0; p < np; ++p) {
-    const int n = probs[p].n;
-    qm[p] = ql_mat{dd + offn[p], ee + offn[p], n, sw_dir + swoff[p], sw_lo + swoff[p], sw_cnt + swoff[p],
-                   sw_off + swoff[p], rot + rotoff[p], 4 * n + 8, 2LL * n * n + 8, nsw + p, stat + p};
-    rm[p] = rot_mat{Zt + off[p], n, sw_dir + swoff[p], sw_lo + swoff[p], sw_cnt + swoff[p], sw_off + swoff[p],
-                    rot + rotoff[p], nsw + p};
-  }
-  ql_mat* d_qm = dm_ws_upload(ctx, qm);
-  rot_mat* d_rm = dm_ws_upload(ctx, rm);
-  if (!d_qm || !d_rm) return DM_ENOMEM;
-  if ((size_t)maxn * 16 <= 120u * 1024u) {
-    static bool attr = false;
-    if (!attr) {
-      DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(ql_kernel<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-      attr = true;
+  cplx* Gb = dm_ws_alloc_t<cplx>(ctx, (size_t)np * TNB * TNB);
+  cplx* Tb = dm_ws_alloc_t<cplx>(ctx, (size_t)np * TNB * TNB);
+  cplx* W1 = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * TNB, 1));
+  cplx* W2 = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * TNB, 1));
+  if (!Vt || !Vp || !Wp || !pv || !abv || !dd || !ee || !tau || !sw_dir || !sw_lo || !sw_cnt || !sw_off || !rot || !nsw ||
+      !stat || !Zt || !Gb || !Tb || !W1 || !W2)
+    return DM_ENOMEM;
+  DM_TRY(dm_fill_zero(ctx, Vp, sizeof(cplx) * totn * TNB));
+  DM_TRY(dm_fill_zero(ctx, Wp, sizeof(cplx) * totn * TNB));
+  DM_TRY(dm_fill_zero(ctx, tau, sizeof(cplx) * totn));
+  DM_TRY(dm_fill_zero(ctx, stat, sizeof(int) * np));
+
+  // ---- chunks: by decreasing size, balanced in n^3
+  std::vector<int> order(np);
+  for (int p = 0; p < np; ++p) order[p] = p;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return probs[a].n > probs[b].n; });
+  // One chunk by default: T1 is a latency-bound chain of ~3 n small launches whose cost hardly
+  // depends on the batch size, so splitting the batch multiplies it (measured: 4 chunks = +40 %).
+  // DM_TRIDIAG_CHUNKS > 1 enables the side-stream pipeline for experiments.
+  int nch = 1;
+  if (const char* e = getenv("DM_TRIDIAG_CHUNKS")) nch = std::max(1, std::min(8, atoi(e)));
+  if (maxn < 256 || np < 2 * nch) nch = 1;
+  std::vector<std::vector<int>> chunks(nch);
+  {
+    double total = 0.0;
+    for (int p = 0; p < np; ++p) total += std::pow((double)probs[p].n, 3);
+    double acc = 0.0;
+    int c = 0;
+    for (int idx : order) {
+      chunks[c].push_back(idx);
+      acc += std::pow((double)probs[idx].n, 3);
+      if (c + 1 < nch && acc >= total * (c + 1) / nch) ++c;
     }
-    hipLaunchKernelGGL(ql_kernel<true>, dim3(np), dim3(64), (size_t)maxn * 16, ctx->stream, d_qm);
-  } else {
-    hipLaunchKernelGGL(ql_kernel<false>, dim3(np), dim3(64), 0, ctx->stream, d_qm);
   }
-  // ---- T3
-  hipLaunchKernelGGL(zt_identity_kernel, dim3((maxn + 255) / 256, maxn, np), dim3(256), 0, ctx->stream, d_rm);
-  hipLaunchKernelGGL(rot_apply_kernel, dim3((maxn + 255) / 256, np), dim3(256), 0, ctx->stream, d_rm);
-  DM_HIP(ctx, hipGetLastError());
+  if (nch > 1 && !g_side.s) DM_HIP(ctx, hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking));
+
+  auto phase_T1 = [&](const std::vector<int>& ch) -> int {
+    if (ch.empty()) return DM_OK;
+    const int nc = (int)ch.size();
+    int cmax = 0;
+    std::vector<trd_mat> tm(nc);
+    for (int i = 0; i < nc; ++i) {
+      const int p = ch[i];
+      cmax = std::max(cmax, probs[p].n);
+      tm[i] = trd_mat{probs[p].C, probs[p].ldc, probs[p].n, Vt + off[p], Vp + offn[p] * TNB, Wp + offn[p] * TNB,
+                      pv + offn[p], abv + (size_t)p * 2 * TNB, dd + offn[p], ee + offn[p], tau + offn[p]};
+    }
+    trd_mat* d_tm = dm_ws_upload(ctx, tm);
+    if (!d_tm) return DM_ENOMEM;
+    for (int k0 = 0; k0 < cmax; k0 += TNB) {
+      const int k1 = std::min(k0 + TNB, cmax);
+      for (int k = k0; k < k1; ++k) {
+        const int j = k - k0;
+        hipLaunchKernelGGL(trd_col_kernel, dim3(nc), dim3(256), 0, ctx->stream, d_tm, k, j);
+        if (k < cmax - 1) {
+          const int rt = (cmax - k - 1 + 2 * j + 3) / 4;
+          hipLaunchKernelGGL(trd_hemv_kernel, dim3(rt, nc), dim3(256), 0, ctx->stream, d_tm, k, j);
+          hipLaunchKernelGGL(trd_w_kernel, dim3(nc), dim3(256), 0, ctx->stream, d_tm, k, j);
+        }
+      }
+      if (k1 < cmax) {
+        for (int pass = 0; pass < 2; ++pass) {
+          std::vector<dm_gemm_desc> g;
+          for (int p : ch) {
+            const int n = probs[p].n;
+            const int rem = n - k1;
+            if (rem <= 0) continue;
+            const int kb = std::min(k1, n - 1) - k0;
+            if (kb <= 0) continue;
+            const cplx* Vb = Vp + offn[p] * TNB + k1;
+            const cplx* Wb = Wp + offn[p] * TNB + k1;
+            const cplx* Aop = pass == 0 ? Vb : Wb;
+            const cplx* Bop = pass == 0 ? Wb : Vb;
+            g.push_back(dm_gemm_make(Aop, 1, n, false, Bop, n, 1, true, probs[p].C + (size_t)k1 * probs[p].ldc + k1,
+                                     probs[p].ldc, rem, rem, kb, -1.0, 1.0));
+          }
+          DM_TRY(dm_gemm_grouped_launch(ctx, g));
+        }
+        // next panel starts from clean V, W
+        std::vector<dm_cdesc> none;
+        for (int p : ch) {
+          DM_TRY(dm_fill_zero(ctx, Vp + offn[p] * TNB, sizeof(cplx) * (size_t)probs[p].n * TNB));
+          DM_TRY(dm_fill_zero(ctx, Wp + offn[p] * TNB, sizeof(cplx) * (size_t)probs[p].n * TNB));
+        }
+      }
+    }
+    DM_HIP(ctx, hipGetLastError());
+    return DM_OK;
+  };
+
+  std::vector<rot_mat*> d_rm_of(nch, nullptr);
+  auto phase_T2 = [&](int c, hipStream_t st) -> int {
+    const std::vector<int>& ch = chunks[c];
+    if (ch.empty()) return DM_OK;
+    const int nc = (int)ch.size();
+    int cmax = 0;
+    std::vector<ql_mat> qm(nc);
+    std::vector<rot_mat> rm(nc);
+    for (int i = 0; i < nc; ++i) {
+      const int p = ch[i];
+      const int n = probs[p].n;
+      cmax = std::max(cmax, n);
+      qm[i] = ql_mat{dd + offn[p], ee + offn[p], n, sw_dir + swoff[p], sw_lo + swoff[p], sw_cnt + swoff[p],
+                     sw_off + swoff[p], rot + rotoff[p], 4 * n + 8, 2LL * n * n + 8, nsw + p, stat + p};
+      rm[i] = rot_mat{Zt + off[p], n, sw_dir + swoff[p], sw_lo + swoff[p], sw_cnt + swoff[p], sw_off + swoff[p],
+                      rot + rotoff[p], nsw + p};
+    }
+    // descriptors are uploaded on the main stream; the caller orders `st` after them with an event
+    ql_mat* d_qm = dm_ws_upload(ctx, qm);
+    d_rm_of[c] = dm_ws_upload(ctx, rm);
+    if (!d_qm || !d_rm_of[c]) return DM_ENOMEM;
+    if (st != ctx->stream) {
+      hipEvent_t e = side_event(2 * c);
+      DM_HIP(ctx, hipEventRecord(e, ctx->stream));
+      DM_HIP(ctx, hipStreamWaitEvent(st, e, 0));
+    }
+    if ((size_t)cmax * 16 <= 120u * 1024u) {
+      static bool attr = false;
+      if (!attr) {
+        DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(ql_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+        attr = true;
+      }
+      hipLaunchKernelGGL(ql_kernel<true>, dim3(nc), dim3(64), (size_t)cmax * 16, st, d_qm);
+    } else {
+      hipLaunchKernelGGL(ql_kernel<false>, dim3(nc), dim3(64), 0, st, d_qm);
+    }
+    if (st != ctx->stream) DM_HIP(ctx, hipEventRecord(side_event(2 * c + 1), st));
+    DM_HIP(ctx, hipGetLastError());
+    return DM_OK;
+  };
+
+  auto phase_T34 = [&](int c, bool waited_on_side) -> int {
+    const std::vector<int>& ch = chunks[c];
+    if (ch.empty()) return DM_OK;
+    const int nc = (int)ch.size();
+    if (waited_on_side) DM_HIP(ctx, hipStreamWaitEvent(ctx->stream, side_event(2 * c + 1), 0));
+    int cmax = 0;
+    for (int p : ch) cmax = std::max(cmax, probs[p].n);
+    // T3
+    hipLaunchKernelGGL(zt_identity_kernel, dim3((cmax + 255) / 256, cmax, nc), dim3(256), 0, ctx->stream, d_rm_of[c]);
+    hipLaunchKernelGGL(rot_apply_kernel, dim3((cmax + 255) / 256, nc), dim3(256), 0, ctx->stream, d_rm_of[c]);
+    {
+      std::vector<dm_cdesc> cp;
+      for (int p : ch)
+        if (probs[p].n > 0)
+          cp.push_back(dm_cdesc{dd + offn[p], evals + (size_t)p * evals_stride, sizeof(double) * probs[p].n});
+      DM_TRY(dm_copy_batched(ctx, cp));
+    }
+    // T4: X = Q Z into the (now free) storage of C, block reflectors applied last to first
+    std::vector<cvt_mat> cm(nc);
+    for (int i = 0; i < nc; ++i) cm[i] = cvt_mat{Zt + off[ch[i]], probs[ch[i]].C, probs[ch[i]].ldc, probs[ch[i]].n};
+    cvt_mat* d_cm = dm_ws_upload(ctx, cm);
+    if (!d_cm) return DM_ENOMEM;
+    const int tb = (cmax + 31) / 32;
+    hipLaunchKernelGGL(zt_to_x_kernel, dim3(tb, tb, nc), dim3(256), 0, ctx->stream, d_cm);
+    const int nblk = (std::max(cmax - 1, 0) + TNB - 1) / TNB;
+    for (int b = nblk - 1; b >= 0; --b) {
+      const int k0 = b * TNB;
+      std::vector<dm_gemm_desc> g1, g2, g3, g4;
+      std::vector<tf_mat> tf;
+      for (int p : ch) {
+        const int n = probs[p].n;
+        const int kb = std::min(k0 + TNB, n - 1) - k0;
+        if (kb <= 0) continue;
+        const cplx* Vb = Vt + off[p] + (size_t)k0 * n;
+        cplx* G = Gb + (size_t)p * TNB * TNB;
+        cplx* T = Tb + (size_t)p * TNB * TNB;
+        cplx* X = probs[p].C;
+        cplx* w1 = W1 + offn[p] * TNB;
+        cplx* w2 = W2 + offn[p] * TNB;
+        g1.push_back(dm_gemm_make(Vb, n, 1, true, Vb, 1, n, false, G, TNB, kb, kb, n));
+        tf.push_back(tf_mat{G, tau + offn[p] + k0, T, kb});
+        g2.push_back(dm_gemm_make(Vb, n, 1, true, X, probs[p].ldc, 1, false, w1, n, kb, n, n));
+        g3.push_back(dm_gemm_make(T, TNB, 1, false, w1, n, 1, false, w2, n, kb, n, kb));
+        g4.push_back(dm_gemm_make(Vb, 1, n, false, w2, n, 1, false, X, probs[p].ldc, n, n, kb, -1.0, 1.0));
+      }
+      if (g1.empty()) continue;
+      DM_TRY(dm_gemm_grouped_launch(ctx, g1));
+      tf_mat* d_tf = dm_ws_upload(ctx, tf);
+      if (!d_tf) return DM_ENOMEM;
+      hipLaunchKernelGGL(larft_kernel, dim3((unsigned)tf.size()), dim3(64), 0, ctx->stream, d_tf);
+      DM_TRY(dm_gemm_grouped_launch(ctx, g2));
+      DM_TRY(dm_gemm_grouped_launch(ctx, g3));
+      DM_TRY(dm_gemm_grouped_launch(ctx, g4));
+    }
+    {
+      std::vector<dm_tdesc> tr;
+      for (int p : ch) tr.push_back(dm_tdesc{probs[p].C, probs[p].ldc, probs[p].W, probs[p].ldw, probs[p].n, probs[p].n});
+      DM_TRY(dm_conj_transpose_batched(ctx, tr));
+    }
+    DM_HIP(ctx, hipGetLastError());
+    return DM_OK;
+  };
+
+  if (nch == 1) {
+    DM_TRY(phase_T1(chunks[0]));
+    DM_TRY(phase_T2(0, ctx->stream));
+    DM_TRY(phase_T34(0, false));
+  } else {
+    for (int c = 0; c < nch; ++c) {
+      DM_TRY(phase_T1(chunks[c]));
+      DM_TRY(phase_T2(c, g_side.s));
+      if (c > 0) DM_TRY(phase_T34(c - 1, true));
+    }
+    DM_TRY(phase_T34(nch - 1, true));
+  }
+
   std::vector<int> hstat(np);
   DM_TRY(dm_download(ctx, hstat.data(), stat, sizeof(int) * np));
+  if (nch > 1) DM_HIP(ctx, hipStreamSynchronize(g_side.s));
   for (int p = 0; p < np; ++p)
     if (hstat[p] != 0) {
       ctx->err = hstat[p] == 1 ? "tridiagonal QL iteration did not converge" : "QL rotation storage exhausted";
       dm_ws_release(ctx, mark);
       return 1000 + p;  // > 0: numerical failure
     }
-  for (int p = 0; p < np; ++p)
-    if (probs[p].n > 0)
-      DM_HIP(ctx, hipMemcpyAsync(evals + (size_t)p * evals_stride, dd + offn[p], sizeof(double) * probs[p].n,
-                                 hipMemcpyDeviceToDevice, ctx->stream));
-
-  // ---- T4: X = Q Z into the (now free) storage of C, block reflectors applied last to first
-  std::vector<cvt_mat> cm(np);
-  for (int p = 0; p < np; ++p) cm[p] = cvt_mat{Zt + off[p], probs[p].C, probs[p].ldc, probs[p].n};
-  cvt_mat* d_cm = dm_ws_upload(ctx, cm);
-  if (!d_cm) return DM_ENOMEM;
-  const int tb = (maxn + 31) / 32;
-  hipLaunchKernelGGL(zt_to_x_kernel, dim3(tb, tb, np), dim3(256), 0, ctx->stream, d_cm);
-  cplx* Gb = dm_ws_alloc_t<cplx>(ctx, (size_t)np * TNB * TNB);
-  cplx* Tb = dm_ws_alloc_t<cplx>(ctx, (size_t)np * TNB * TNB);
-  cplx* W1 = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * TNB, 1));
-  cplx* W2 = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * TNB, 1));
-  if (!Gb || !Tb || !W1 || !W2) return DM_ENOMEM;
-  const int nblk = (std::max(maxn - 1, 0) + TNB - 1) / TNB;
-  for (int b = nblk - 1; b >= 0; --b) {
-    const int k0 = b * TNB;
-    std::vector<dm_gemm_desc> g1, g2, g3, g4;
-    std::vector<tf_mat> tf;
-    for (int p = 0; p < np; ++p) {
-      const int n = probs[p].n;
-      const int kb = std::min(k0 + TNB, n - 1) - k0;
-      if (kb <= 0) continue;
-      const cplx* Vb = Vt + off[p] + (size_t)k0 * n;  // kb rows of length n
-      cplx* G = Gb + (size_t)p * TNB * TNB;
-      cplx* T = Tb + (size_t)p * TNB * TNB;
-      cplx* X = probs[p].C;
-      cplx* w1 = W1 + offn[p] * TNB;
-      cplx* w2 = W2 + offn[p] * TNB;
-      // G = Vb^H Vb  in the (row = reflector) convention: G[a][c] = sum_i conj(V[a][i]) V[c][i]
-      g1.push_back(dm_gemm_make(Vb, n, 1, true, Vb, 1, n, false, G, TNB, kb, kb, n));
-      tf.push_back(tf_mat{G, tau + offn[p] + k0, T, kb});
-      // W1 = Vb^H X   (kb x n)
-      g2.push_back(dm_gemm_make(Vb, n, 1, true, X, probs[p].ldc, 1, false, w1, n, kb, n, n));
-      // W2 = T W1     (kb x n)
-      g3.push_back(dm_gemm_make(T, TNB, 1, false, w1, n, 1, false, w2, n, kb, n, kb));
-      // X -= Vb W2    (n x n): A element (i, a) = V[a][i]
-      g4.push_back(dm_gemm_make(Vb, 1, n, false, w2, n, 1, false, X, probs[p].ldc, n, n, kb, -1.0, 1.0));
-    }
-    if (g1.empty()) continue;
-    DM_TRY(dm_gemm_grouped_launch(ctx, g1));
-    tf_mat* d_tf = dm_ws_upload(ctx, tf);
-    if (!d_tf) return DM_ENOMEM;
-    hipLaunchKernelGGL(larft_kernel, dim3((unsigned)tf.size()), dim3(64), 0, ctx->stream, d_tf);
-    DM_TRY(dm_gemm_grouped_launch(ctx, g2));
-    DM_TRY(dm_gemm_grouped_launch(ctx, g3));
-    DM_TRY(dm_gemm_grouped_launch(ctx, g4));
-  }
-  // ---- W = X^H (rows = eigenvectors^H)
-  for (int p = 0; p < np; ++p)
-    DM_TRY(dm_conj_transpose(ctx, probs[p].C, probs[p].ldc, probs[p].W, probs[p].ldw, probs[p].n, probs[p].n));
-  DM_HIP(ctx, hipGetLastError());
   DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   dm_ws_release(ctx, mark);
   return DM_OK;
