@@ -131,8 +131,16 @@ def main():
     from driftscan_amd import device, parallel
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        parallel.init_from_env("nccl")
+    force_dist = os.environ.get("DRIFT_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path on one GPU
+    if world > 1 or force_dist:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend="nccl")
     rank = parallel.rank()
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -153,7 +161,7 @@ def main():
         parallel.barrier()
         dt = time.perf_counter() - t0
         prof = ctx.prof_report()
-        if world > 1:
+        if world > 1 or force_dist:
             import torch.distributed as dist
 
             tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -194,7 +202,7 @@ def main():
                 "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(tel, bt, kl),
             }
             print(json.dumps(line))
-    if world > 1:
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         dist.destroy_process_group()

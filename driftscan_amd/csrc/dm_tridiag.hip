@@ -29,8 +29,9 @@
 
 namespace {
 
-constexpr int TNB = 32;  // reflectors per panel
+constexpr int TNB = 64;  // reflectors per panel (her2k and compact-WY updates run at K = 64)
 constexpr int KS = 16;   // QL sweeps pipelined per pass in rot_apply
+constexpr int PF = 8;    // columns prefetched ahead of the window in rot_apply
 
 struct trd_mat {
   cplx* A; int lda; int n;
@@ -464,6 +465,13 @@ __global__ __launch_bounds__(256) void rot_apply_kernel(const rot_mat* __restric
       w[j] = (live && col <= cmax && col >= cmin) ? z[(size_t)phys(col) * n] : 0.0;
     }
     const int tend = top - cmin + 2 * (KS - 1);
+    // prefetch queue: pre[q] = logical column (top - 1 - q), i.e. the next PF columns below the window
+    double pre[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int col = top - 1 - q;
+      pre[q] = (live && col >= cmin) ? z[(size_t)phys(col) * n] : 0.0;
+    }
     for (int t = 0; t <= tend; ++t) {
       const int base = top - t;  // logical column of w[0]
 #pragma unroll
@@ -486,8 +494,11 @@ __global__ __launch_bounds__(256) void rot_apply_kernel(const rot_mat* __restric
       if (live && ctop <= cmax && ctop >= cmin) z[(size_t)phys(ctop) * n] = w[2 * KS - 1];
 #pragma unroll
       for (int j = 2 * KS - 1; j > 0; --j) w[j] = w[j - 1];
-      const int cnew = base - 1;
-      w[0] = (live && cnew >= cmin) ? z[(size_t)phys(cnew) * n] : 0.0;
+      w[0] = pre[0];  // column base - 1
+#pragma unroll
+      for (int q = 0; q + 1 < PF; ++q) pre[q] = pre[q + 1];
+      const int cpre = base - 1 - PF;  // keeps the queue PF columns ahead
+      pre[PF - 1] = (live && cpre >= cmin) ? z[(size_t)phys(cpre) * n] : 0.0;
     }
     {
       const int base = top - tend - 1;
@@ -530,7 +541,8 @@ __global__ void zt_to_x_kernel(const cvt_mat* __restrict__ cs) {
 struct tf_mat { const cplx* G; const cplx* tau; cplx* T; int kb; };  // G, T: TNB x TNB row-major
 __global__ __launch_bounds__(64) void larft_kernel(const tf_mat* __restrict__ ts) {
   const tf_mat F = ts[blockIdx.x];
-  __shared__ cplx T[TNB][TNB + 1];
+  extern __shared__ __align__(16) unsigned char larft_smem[];
+  cplx (*T)[TNB + 1] = reinterpret_cast<cplx (*)[TNB + 1]>(larft_smem);
   const int tid = threadIdx.x;
   for (int idx = tid; idx < TNB * TNB; idx += 64) T[idx / TNB][idx % TNB] = make_double2(0.0, 0.0);
   __syncthreads();
@@ -693,10 +705,14 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
           DM_TRY(dm_gemm_grouped_launch(ctx, g));
         }
         // next panel starts from clean V, W
-        std::vector<dm_cdesc> none;
-        for (int p : ch) {
-          DM_TRY(dm_fill_zero(ctx, Vp + offn[p] * TNB, sizeof(cplx) * (size_t)probs[p].n * TNB));
-          DM_TRY(dm_fill_zero(ctx, Wp + offn[p] * TNB, sizeof(cplx) * (size_t)probs[p].n * TNB));
+        if ((int)ch.size() == np) {
+          DM_TRY(dm_fill_zero(ctx, Vp, sizeof(cplx) * totn * TNB));
+          DM_TRY(dm_fill_zero(ctx, Wp, sizeof(cplx) * totn * TNB));
+        } else {
+          for (int p : ch) {
+            DM_TRY(dm_fill_zero(ctx, Vp + offn[p] * TNB, sizeof(cplx) * (size_t)probs[p].n * TNB));
+            DM_TRY(dm_fill_zero(ctx, Wp + offn[p] * TNB, sizeof(cplx) * (size_t)probs[p].n * TNB));
+          }
         }
       }
     }
@@ -795,7 +811,16 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
       DM_TRY(dm_gemm_grouped_launch(ctx, g1));
       tf_mat* d_tf = dm_ws_upload(ctx, tf);
       if (!d_tf) return DM_ENOMEM;
-      hipLaunchKernelGGL(larft_kernel, dim3((unsigned)tf.size()), dim3(64), 0, ctx->stream, d_tf);
+      {
+        static bool attr = false;
+        const size_t lds = sizeof(cplx) * TNB * (TNB + 1);
+        if (!attr) {
+          DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(larft_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          attr = true;
+        }
+        hipLaunchKernelGGL(larft_kernel, dim3((unsigned)tf.size()), dim3(64), lds, ctx->stream, d_tf);
+      }
       DM_TRY(dm_gemm_grouped_launch(ctx, g2));
       DM_TRY(dm_gemm_grouped_launch(ctx, g3));
       DM_TRY(dm_gemm_grouped_launch(ctx, g4));
