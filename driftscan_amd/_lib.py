@@ -325,7 +325,7 @@ Context.bt_maps = _bt_maps
 Context.bt_sht = _bt_sht
 
 
-PROF_CLASSES = ["zgemm_grouped", "gemm_grouped_realB", "jac_gram", "jac_inner", "jac_apply"]
+PROF_CLASSES = ["zgemm_grouped", "gemm_grouped_realB", "jac_gram", "jac_inner", "jac_apply", "dgemm_grouped"]
 
 
 def _prof_reset(self, enable=True):

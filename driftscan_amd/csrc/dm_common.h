@@ -40,7 +40,7 @@ struct dm_ctx {
 };
 
 enum { DM_PROF_GEMM = 0, DM_PROF_GEMM_REAL = 1, DM_PROF_JAC_GRAM = 2, DM_PROF_JAC_INNER = 3, DM_PROF_JAC_APPLY = 4,
-       DM_PROF_NCLASS = 8 };
+       DM_PROF_DGEMM = 5, DM_PROF_NCLASS = 8 };
 
 hipEvent_t dm_prof_event(dm_ctx* ctx);
 // bracket one launch: DM_PROF(ctx, cls, flops) { launch; }

@@ -184,6 +184,101 @@ __global__ __launch_bounds__(256) void zgemm_grouped_kernel(const dm_gemm_desc* 
       }
 }
 
+// ---- all-real variant: C[M x N] (double) = alpha * A * B + beta * C, same tiling, one MFMA per
+// (tile, k-step).  Used by the divide & conquer eigenvector updates (real orthogonal matrices).
+__global__ __launch_bounds__(256) void dgemm_grouped_kernel(const dm_gemm_desc* __restrict__ descs,
+                                                            const dm_gemm_tile* __restrict__ tiles, int ntiles) {
+  __shared__ double As[BM * LDP], Bs[BN * LDP];
+  const int bid = dm_xcd_remap(blockIdx.x, ntiles);
+  const dm_gemm_tile t = tiles[bid];
+  const dm_gemm_desc d = descs[t.desc];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = t.tm * BM, n0 = t.tn * BN;
+  const double* __restrict__ A = reinterpret_cast<const double*>(d.A);
+  const double* __restrict__ B = reinterpret_cast<const double*>(d.B);
+  const bool a_kfast = d.csA <= d.rsA;
+  const bool b_kfast = d.rsB <= d.csB;
+  dm_f64x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = dm_f64x4{0, 0, 0, 0};
+  double ra[4], rb[4];
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int idx = tid + 256 * i;
+      int m, k;
+      if (a_kfast) { k = idx & 15; m = idx >> 4; } else { m = idx & 63; k = idx >> 6; }
+      int gm = m0 + m, gk = k0 + k;
+      ra[i] = (gm < d.M && gk < d.K) ? A[(size_t)gm * d.rsA + (size_t)gk * d.csA] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int idx = tid + 256 * i;
+      int n, k;
+      if (b_kfast) { k = idx & 15; n = idx >> 4; } else { n = idx & 63; k = idx >> 6; }
+      int gn = n0 + n, gk = k0 + k;
+      rb[i] = (gn < d.N && gk < d.K) ? B[(size_t)gk * d.rsB + (size_t)gn * d.csB] : 0.0;
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int idx = tid + 256 * i;
+      int m, k;
+      if (a_kfast) { k = idx & 15; m = idx >> 4; } else { m = idx & 63; k = idx >> 6; }
+      As[m * LDP + k] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int idx = tid + 256 * i;
+      int n, k;
+      if (b_kfast) { k = idx & 15; n = idx >> 4; } else { n = idx & 63; k = idx >> 6; }
+      Bs[n * LDP + k] = rb[i];
+    }
+  };
+  const int fi = lane & 15, fk = lane >> 4;
+  const int nk = (d.K + BK - 1) / BK;
+  if (nk > 0) load_tiles(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    store_tiles();
+    __syncthreads();
+    if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      double a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[(wm * 32 + i * 16 + fi) * LDP + kk * 4 + fk];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bs[(wn * 32 + j * 16 + fi) * LDP + kk * 4 + fk];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = dm_mfma(a[i], b[j], acc[i][j]);
+    }
+  }
+  double* __restrict__ C = reinterpret_cast<double*>(d.C);
+  const int crow = lane >> 4, ccol = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int gm = m0 + wm * 32 + i * 16 + crow + 4 * r;
+        int gn = n0 + wn * 32 + j * 16 + ccol;
+        if (gm < d.M && gn < d.N) {
+          size_t off = (size_t)gm * d.ldc + gn;
+          double v = d.alpha * acc[i][j][r];
+          if (d.beta != 0.0) v += d.beta * C[off];
+          C[off] = v;
+        }
+      }
+}
+
 }  // namespace
 
 // Host side: flatten descriptors into tiles, upload, launch.
@@ -191,7 +286,8 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
   if (descs.empty()) return DM_OK;
   std::vector<dm_gemm_tile> tiles;
   std::vector<dm_gemm_tile> tiles_real;
-  double fl_c = 0.0, fl_r = 0.0;
+  std::vector<dm_gemm_tile> tiles_dd;
+  double fl_c = 0.0, fl_r = 0.0, fl_d = 0.0;
   for (size_t i = 0; i < descs.size(); ++i) {
     const dm_gemm_desc& d = descs[i];
     if (d.M <= 0 || d.N <= 0) continue;
@@ -201,7 +297,8 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
         if ((d.flags & DM_GEMM_LOWER) && b > a) continue;
         dm_gemm_tile t{(int)i, a, b};
         const double rows = std::min(BM, d.M - a * BM), cols = std::min(BN, d.N - b * BN);
-        if (d.flags & DM_GEMM_B_REAL) { tiles_real.push_back(t); fl_r += 4.0 * rows * cols * d.K; }
+        if (d.flags & DM_GEMM_ALL_REAL) { tiles_dd.push_back(t); fl_d += 2.0 * rows * cols * d.K; }
+        else if (d.flags & DM_GEMM_B_REAL) { tiles_real.push_back(t); fl_r += 4.0 * rows * cols * d.K; }
         else { tiles.push_back(t); fl_c += 8.0 * rows * cols * d.K; }
       }
   }
@@ -221,6 +318,13 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
     dm_prof_scope ps(ctx, DM_PROF_GEMM_REAL, fl_r);
     hipLaunchKernelGGL(zgemm_grouped_kernel<true>, dim3((unsigned)tiles_real.size()), dim3(256), 0, ctx->stream,
                        dd, dt, (int)tiles_real.size());
+  }
+  if (!tiles_dd.empty()) {
+    dm_gemm_tile* dt = dm_ws_upload(ctx, tiles_dd);
+    if (!dt) return DM_ENOMEM;
+    dm_prof_scope ps(ctx, DM_PROF_DGEMM, fl_d);
+    hipLaunchKernelGGL(dgemm_grouped_kernel, dim3((unsigned)tiles_dd.size()), dim3(256), 0, ctx->stream, dd, dt,
+                       (int)tiles_dd.size());
   }
   DM_HIP(ctx, hipGetLastError());
   // descriptors live in the bump arena until the caller's enclosing mark is

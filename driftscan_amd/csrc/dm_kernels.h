@@ -13,6 +13,7 @@ enum {
   DM_GEMM_CONJ_B = 2,  // conjugate the elements of B as they are read
   DM_GEMM_B_REAL = 4,  // B points at real doubles (complex x real product)
   DM_GEMM_LOWER = 8,   // only compute 64x64 tiles on or below the block diagonal
+  DM_GEMM_ALL_REAL = 16,  // A, B and C are arrays of doubles (strides in doubles)
 };
 
 struct dm_gemm_desc {

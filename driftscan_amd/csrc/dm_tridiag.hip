@@ -414,7 +414,7 @@ __global__ __launch_bounds__(64) void ql_kernel(const ql_mat* __restrict__ qs) {
 
 // ---- T3: apply the recorded rotations to the rows of Z (stored column-major: Zt[col*n + row]) ----
 struct rot_mat {
-  double* Zt; int n;
+  double* Zt; int n; int ldz;  // Zt[col * ldz + row]
   const int* sw_dir; const int* sw_lo; const int* sw_cnt; const long long* sw_off; const double2* rot;
   const int* nsweeps;
 };
@@ -431,6 +431,7 @@ __global__ __launch_bounds__(256) void rot_apply_kernel(const rot_mat* __restric
   const bool live = row < n;
   const int ns = *R.nsweeps;
   double* __restrict__ z = R.Zt + (live ? row : 0);
+  const size_t ldz = (size_t)R.ldz;
   int s0 = 0;
   while (s0 < ns) {
     const int dir = R.sw_dir[s0];
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(256) void rot_apply_kernel(const rot_mat* __restric
 #pragma unroll
     for (int j = 0; j < 2 * KS; ++j) {
       const int col = top + j;
-      w[j] = (live && col <= cmax && col >= cmin) ? z[(size_t)phys(col) * n] : 0.0;
+      w[j] = (live && col <= cmax && col >= cmin) ? z[(size_t)phys(col) * ldz] : 0.0;
     }
     const int tend = top - cmin + 2 * (KS - 1);
     // prefetch queue: pre[q] = logical column (top - 1 - q), i.e. the next PF columns below the window
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(256) void rot_apply_kernel(const rot_mat* __restric
 #pragma unroll
     for (int q = 0; q < PF; ++q) {
       const int col = top - 1 - q;
-      pre[q] = (live && col >= cmin) ? z[(size_t)phys(col) * n] : 0.0;
+      pre[q] = (live && col >= cmin) ? z[(size_t)phys(col) * ldz] : 0.0;
     }
     for (int t = 0; t <= tend; ++t) {
       const int base = top - t;  // logical column of w[0]
@@ -491,21 +492,21 @@ __global__ __launch_bounds__(256) void rot_apply_kernel(const rot_mat* __restric
         }
       }
       const int ctop = base + 2 * KS - 1;
-      if (live && ctop <= cmax && ctop >= cmin) z[(size_t)phys(ctop) * n] = w[2 * KS - 1];
+      if (live && ctop <= cmax && ctop >= cmin) z[(size_t)phys(ctop) * ldz] = w[2 * KS - 1];
 #pragma unroll
       for (int j = 2 * KS - 1; j > 0; --j) w[j] = w[j - 1];
       w[0] = pre[0];  // column base - 1
 #pragma unroll
       for (int q = 0; q + 1 < PF; ++q) pre[q] = pre[q + 1];
       const int cpre = base - 1 - PF;  // keeps the queue PF columns ahead
-      pre[PF - 1] = (live && cpre >= cmin) ? z[(size_t)phys(cpre) * n] : 0.0;
+      pre[PF - 1] = (live && cpre >= cmin) ? z[(size_t)phys(cpre) * ldz] : 0.0;
     }
     {
       const int base = top - tend - 1;
 #pragma unroll
       for (int j = 0; j < 2 * KS; ++j) {
         const int col = base + j;
-        if (live && col >= cmin && col <= cmax) z[(size_t)phys(col) * n] = w[j];
+        if (live && col >= cmin && col <= cmax) z[(size_t)phys(col) * ldz] = w[j];
       }
     }
   }
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(256) void rot_apply_kernel(const rot_mat* __restric
 __global__ void zt_identity_kernel(const rot_mat* __restrict__ rs) {
   const rot_mat R = rs[blockIdx.z];
   const int col = blockIdx.y, row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col < R.n && row < R.n) R.Zt[(size_t)col * R.n + row] = (row == col) ? 1.0 : 0.0;
+  if (col < R.n && row < R.n) R.Zt[(size_t)col * R.ldz + row] = (row == col) ? 1.0 : 0.0;
 }
 
 // X[row][col] (complex row-major, ld) = Zt[col*n + row]
@@ -561,7 +562,548 @@ __global__ __launch_bounds__(64) void larft_kernel(const tf_mat* __restrict__ ts
   for (int idx = tid; idx < TNB * TNB; idx += 64) F.T[idx] = T[idx / TNB][idx % TNB];
 }
 
+
+// ===========================================================================
+// T2/T3 alternative: divide & conquer on the tridiagonal (Cuppen; deflation, secular equation
+// and Gu-Eisenstat vectors as in LAPACK dlaed2/3/4).  The tridiagonal is torn into leaves of
+// <= DC_LEAF rows, the leaves are solved by the QL kernels above, and the tree is merged level
+// by level with every node of a level (all matrices) in the same launches:
+//   dc_setup    z vector, sort, deflation (tiny z / close poles via Givens)      1 WG / node
+//   dc_permute  rotate + gather the non-deflated eigenvectors, copy the deflated ones
+//   dc_secular  one thread per root: safeguarded rational iteration, root kept as (origin, mu)
+//   dc_zhat     Loewner formula for z-hat (numerical orthogonality)
+//   dc_unorm / dc_ubuild   eigenvectors of the rank-one modified diagonal
+//   grouped DGEMM         Z_parent = U^T Z_children                                (MFMA)
+// Parallel depth O(log n) instead of the ~1.1 n^2 serial rotations of QL.
+// ===========================================================================
+constexpr int DC_LEAF = 64;
+constexpr int DC_MAXNODE = 4096;  // LDS-resident setup; larger problems use the QL path
+
+struct dc_mat {
+  int n;
+  double* lamA; double* lamB;   // eigenvalues of the current / next level (ping-pong)
+  double* ZA; double* ZB;       // eigenvector-major: Z[c * n + r]
+  double* Zp;                   // gathered non-deflated eigenvectors
+  double* dk; double* zk;       // packed poles / weights of each node (at offset lo)
+  int* keepcol; int* deflcol;   // local column indices
+  double* defld;
+  double4* rots;                // (colA, colB, c, s) with the column indices stored as doubles
+  int* org; double* mu; double* zhat; double* inv;
+  double* U;                    // n x n scratch: node block at U + lo * n, leading dimension n
+};
+
+struct dc_node {
+  int mat, lo, n1, n2;
+  const double* pbeta;  // off-diagonal element torn at this node
+  int flip;             // 0: current = A buffers, 1: current = B buffers
+};
+
+struct dc_nodeout { int k, ndefl, nrot; double rho; };
+
+__global__ __launch_bounds__(256) void dc_setup_kernel(const dc_mat* __restrict__ ms, const dc_node* __restrict__ nodes,
+                                                       dc_nodeout* __restrict__ outs) {
+  extern __shared__ __align__(16) unsigned char dc_smem[];
+  const dc_node nd = nodes[blockIdx.x];
+  const dc_mat M = ms[nd.mat];
+  const int nn = nd.n1 + nd.n2, lo = nd.lo, n = M.n;
+  double* sd = reinterpret_cast<double*>(dc_smem);   // sorted poles
+  double* sz = sd + nn;                              // sorted weights
+  double* ud = sz + nn;                              // unsorted copies
+  double* uz = ud + nn;
+  int* sidx = reinterpret_cast<int*>(uz + nn);       // sorted position -> local column
+  __shared__ double red[4];
+  __shared__ double s_norm, s_zmax, s_dmax;
+  const int tid = threadIdx.x;
+  const double* lam = nd.flip ? M.lamB : M.lamA;
+  const double* Z = nd.flip ? M.ZB : M.ZA;
+  const double beta = *nd.pbeta;
+  const double sgn = beta >= 0.0 ? 1.0 : -1.0;
+  double part = 0.0;
+  for (int i = tid; i < nn; i += 256) {
+    ud[i] = lam[lo + i];
+    const double zi = (i < nd.n1) ? Z[(size_t)(lo + i) * n + (lo + nd.n1 - 1)] : sgn * Z[(size_t)(lo + i) * n + (lo + nd.n1)];
+    uz[i] = zi;
+    part += zi * zi;
+  }
+  part = dm_wave_sum(part);
+  if ((tid & 63) == 0) red[tid >> 6] = part;
+  __syncthreads();
+  if (tid == 0) s_norm = sqrt(red[0] + red[1] + red[2] + red[3]);
+  __syncthreads();
+  const double zn = s_norm;
+  const double rho = fabs(beta) * zn * zn;
+  // rank by counting (stable), scatter into sorted order
+  double zmax = 0.0, dmax = 0.0;
+  for (int i = tid; i < nn; i += 256) {
+    const double di = ud[i];
+    int r = 0;
+    for (int j = 0; j < nn; ++j) {
+      const double dj = ud[j];
+      r += (dj < di || (dj == di && j < i)) ? 1 : 0;
+    }
+    const double zi = zn > 0.0 ? uz[i] / zn : 0.0;
+    sd[r] = di;
+    sz[r] = zi;
+    sidx[r] = i;
+    zmax = fmax(zmax, fabs(zi));
+    dmax = fmax(dmax, fabs(di));
+  }
+  zmax = dm_wave_max(zmax);
+  dmax = dm_wave_max(dmax);
+  __syncthreads();
+  if ((tid & 63) == 0) { red[tid >> 6] = zmax; }
+  __syncthreads();
+  if (tid == 0) s_zmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  __syncthreads();
+  if ((tid & 63) == 0) { red[tid >> 6] = dmax; }
+  __syncthreads();
+  if (tid == 0) s_dmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  __syncthreads();
+  if (tid != 0) return;
+  // ---- serial deflation scan (dlaed2)
+  const double eps = 1.1102230246251565e-16;
+  const double tol = 8.0 * eps * fmax(s_dmax, s_zmax);
+  int k = 0, ndefl = 0, nrot = 0;
+  int* keeppos = reinterpret_cast<int*>(ud);  // reuse: positions (in sorted order) of kept entries
+  if (rho * s_zmax <= tol) {
+    for (int i = 0; i < nn; ++i) { M.deflcol[lo + ndefl] = sidx[i]; M.defld[lo + ndefl] = sd[i]; ++ndefl; }
+  } else {
+    int prev = -1;
+    for (int i = 0; i < nn; ++i) {
+      if (rho * fabs(sz[i]) <= tol) {
+        M.deflcol[lo + ndefl] = sidx[i]; M.defld[lo + ndefl] = sd[i]; ++ndefl;
+        continue;
+      }
+      if (prev >= 0) {
+        double s = sz[prev], c = sz[i];
+        const double tau = hypot(c, s);
+        const double t = sd[i] - sd[prev];
+        c /= tau;
+        s = -s / tau;
+        if (fabs(t * c * s) <= tol) {
+          sz[i] = tau;
+          sz[prev] = 0.0;
+          M.rots[lo + nrot] = make_double4((double)sidx[prev], (double)sidx[i], c, s);
+          ++nrot;
+          const double dp = sd[prev], di = sd[i];
+          sd[prev] = dp * c * c + di * s * s;
+          sd[i] = dp * s * s + di * c * c;
+          M.deflcol[lo + ndefl] = sidx[prev]; M.defld[lo + ndefl] = sd[prev]; ++ndefl;
+          keeppos[k - 1] = i;
+          prev = i;
+          continue;
+        }
+      }
+      keeppos[k++] = i;
+      prev = i;
+    }
+    // poles must increase: the rotations can perturb the order by a few ulp -> insertion sort
+    for (int a = 1; a < k; ++a) {
+      const int pa = keeppos[a];
+      const double da = sd[pa];
+      int b = a - 1;
+      while (b >= 0 && sd[keeppos[b]] > da) { keeppos[b + 1] = keeppos[b]; --b; }
+      keeppos[b + 1] = pa;
+    }
+    for (int j = 0; j < k; ++j) {
+      const int pos = keeppos[j];
+      M.dk[lo + j] = sd[pos];
+      M.zk[lo + j] = sz[pos];
+      M.keepcol[lo + j] = sidx[pos];
+    }
+  }
+  outs[blockIdx.x] = dc_nodeout{k, ndefl, nrot, rho};
+}
+
+__global__ __launch_bounds__(256) void dc_permute_kernel(const dc_mat* __restrict__ ms, const dc_node* __restrict__ nodes,
+                                                         const dc_nodeout* __restrict__ outs) {
+  const dc_node nd = nodes[blockIdx.x];
+  const dc_mat M = ms[nd.mat];
+  const dc_nodeout o = outs[blockIdx.x];
+  const int nn = nd.n1 + nd.n2, lo = nd.lo, n = M.n;
+  double* Zc = nd.flip ? M.ZB : M.ZA;
+  double* Zn = nd.flip ? M.ZA : M.ZB;
+  double* lamn = nd.flip ? M.lamA : M.lamB;
+  const int tid = threadIdx.x;
+  // chained Givens rotations on pairs of eigenvectors (in place)
+  for (int r = 0; r < o.nrot; ++r) {
+    const double4 rt = M.rots[lo + r];
+    double* qa = Zc + (size_t)(lo + (int)rt.x) * n + lo;
+    double* qb = Zc + (size_t)(lo + (int)rt.y) * n + lo;
+    for (int i = tid; i < nn; i += 256) {
+      const double a = qa[i], b = qb[i];
+      qa[i] = rt.z * a + rt.w * b;
+      qb[i] = -rt.w * a + rt.z * b;
+    }
+    __syncthreads();
+  }
+  // gather the non-deflated vectors for the GEMM, copy the deflated ones to their final place
+  for (int j = 0; j < o.k; ++j) {
+    const double* src = Zc + (size_t)(lo + M.keepcol[lo + j]) * n + lo;
+    double* dst = M.Zp + (size_t)(lo + j) * n + lo;
+    for (int i = tid; i < nn; i += 256) dst[i] = src[i];
+  }
+  for (int t = 0; t < o.ndefl; ++t) {
+    const double* src = Zc + (size_t)(lo + M.deflcol[lo + t]) * n + lo;
+    double* dst = Zn + (size_t)(lo + o.k + t) * n + lo;
+    for (int i = tid; i < nn; i += 256) dst[i] = src[i];
+    if (tid == 0) lamn[lo + o.k + t] = M.defld[lo + t];
+  }
+}
+
+// grid = (root tiles of 256, nodes); dynamic LDS: 2 * kmax doubles
+__global__ __launch_bounds__(256) void dc_secular_kernel(const dc_mat* __restrict__ ms, const dc_node* __restrict__ nodes,
+                                                         const dc_nodeout* __restrict__ outs) {
+  extern __shared__ __align__(16) unsigned char dc_smem[];
+  const dc_node nd = nodes[blockIdx.y];
+  const dc_mat M = ms[nd.mat];
+  const dc_nodeout o = outs[blockIdx.y];
+  const int k = o.k, lo = nd.lo;
+  if ((int)(blockIdx.x * 256) >= k) return;
+  double* d = reinterpret_cast<double*>(dc_smem);
+  double* z2 = d + k;
+  for (int i = threadIdx.x; i < k; i += 256) {
+    d[i] = M.dk[lo + i];
+    const double z = M.zk[lo + i];
+    z2[i] = z * z;
+  }
+  __syncthreads();
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= k) return;
+  const double rho = o.rho;
+  const double eps = 2.220446049250313e-16;
+  double* lamn = nd.flip ? M.lamA : M.lamB;
+  if (k == 1) {
+    M.org[lo] = 0;
+    M.mu[lo] = rho * z2[0];
+    lamn[lo] = d[0] + rho * z2[0];
+    return;
+  }
+  const bool last = (j == k - 1);
+  int og;
+  double lo_b, hi_b;
+  if (!last) {
+    const double mid = 0.5 * (d[j + 1] - d[j]);
+    double f = 1.0;
+    for (int i = 0; i < k; ++i) f += rho * z2[i] / ((d[i] - d[j]) - mid);
+    if (f > 0.0) { og = j; lo_b = 0.0; hi_b = mid; } else { og = j + 1; lo_b = -mid; hi_b = 0.0; }
+  } else {
+    og = j;
+    double sz = 0.0;
+    for (int i = 0; i < k; ++i) sz += z2[i];
+    lo_b = 0.0;
+    hi_b = rho * sz;
+  }
+  const double dorg = d[og];
+  double mu = 0.5 * (lo_b + hi_b);
+  for (int it = 0; it < 100; ++it) {
+    double psi = 0.0, phi = 0.0, dpsi = 0.0, dphi = 0.0;
+    for (int i = 0; i <= j; ++i) {
+      const double t = 1.0 / ((d[i] - dorg) - mu);
+      const double term = rho * z2[i] * t;
+      psi += term;
+      dpsi += term * t;
+    }
+    for (int i = j + 1; i < k; ++i) {
+      const double t = 1.0 / ((d[i] - dorg) - mu);
+      const double term = rho * z2[i] * t;
+      phi += term;
+      dphi += term * t;
+    }
+    const double fv = 1.0 + psi + phi;
+    const double erretm = 8.0 * (fabs(psi) + fabs(phi)) + 1.0 + fabs(mu) * (dpsi + dphi);
+    if (fabs(fv) <= eps * erretm) break;
+    if (fv > 0.0) hi_b = mu; else lo_b = mu;
+    double eta;
+    if (!last) {
+      const double dj = (d[j] - dorg) - mu, dj1 = (d[j + 1] - dorg) - mu;
+      const double a = (dj + dj1) * fv - dj * dj1 * (dpsi + dphi);
+      const double b = dj * dj1 * fv;
+      const double c = fv - dj * dpsi - dj1 * dphi;
+      if (c == 0.0) {
+        eta = a != 0.0 ? b / a : 0.0;
+      } else {
+        const double disc = sqrt(fmax(a * a - 4.0 * b * c, 0.0));
+        eta = (a <= 0.0) ? (a - disc) / (2.0 * c) : 2.0 * b / (a + disc);
+      }
+    } else {
+      const double tq = (d[j] - dorg) - mu, tp = (d[j - 1] - dorg) - mu;
+      const double dphil = rho * z2[j] / (tq * tq);
+      const double dpsil = dpsi + dphi - dphil;
+      double c = fv - tp * dpsil - tq * dphil;
+      const double a = (tp + tq) * fv - tp * tq * (dpsil + dphil);
+      const double b = tp * tq * fv;
+      if (c < 0.0) c = -c;
+      if (c == 0.0) eta = hi_b - mu;
+      else if (a >= 0.0) eta = (a + sqrt(fabs(a * a - 4.0 * b * c))) / (2.0 * c);
+      else eta = 2.0 * b / (a - sqrt(fabs(a * a - 4.0 * b * c)));
+      if (fv * eta > 0.0) eta = -fv / (dpsi + dphi);
+    }
+    double nw = mu + eta;
+    if (!(nw > lo_b && nw < hi_b) || !isfinite(nw)) nw = 0.5 * (lo_b + hi_b);
+    if (nw == mu || (hi_b - lo_b) <= 2.0 * eps * fabs(nw)) { mu = nw; break; }
+    mu = nw;
+  }
+  M.org[lo + j] = og;
+  M.mu[lo + j] = mu;
+  lamn[lo + j] = dorg + mu;
+}
+
+// zhat_i = sign(z_i) sqrt( prod_j (lam_j - d_i) / (rho prod_{j != i} (d_j - d_i)) )
+__global__ __launch_bounds__(256) void dc_zhat_kernel(const dc_mat* __restrict__ ms, const dc_node* __restrict__ nodes,
+                                                      const dc_nodeout* __restrict__ outs) {
+  const dc_node nd = nodes[blockIdx.y];
+  const dc_mat M = ms[nd.mat];
+  const dc_nodeout o = outs[blockIdx.y];
+  const int k = o.k, lo = nd.lo;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= k) return;
+  const double di = M.dk[lo + i];
+  double prod = 1.0;
+  for (int j = 0; j < k; ++j) {
+    const double num = M.mu[lo + j] - (di - M.dk[lo + M.org[lo + j]]);  // lam_j - d_i
+    if (j == i) prod *= num;
+    else prod *= num / (M.dk[lo + j] - di);
+  }
+  const double zh = sqrt(fabs(prod) / o.rho);
+  M.zhat[lo + i] = M.zk[lo + i] >= 0.0 ? zh : -zh;
+}
+
+// inv[j] = 1 / || zhat_i / (d_i - lam_j) ||_i
+__global__ __launch_bounds__(256) void dc_unorm_kernel(const dc_mat* __restrict__ ms, const dc_node* __restrict__ nodes,
+                                                       const dc_nodeout* __restrict__ outs) {
+  const dc_node nd = nodes[blockIdx.y];
+  const dc_mat M = ms[nd.mat];
+  const dc_nodeout o = outs[blockIdx.y];
+  const int k = o.k, lo = nd.lo;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= k) return;
+  const double dor = M.dk[lo + M.org[lo + j]], mu = M.mu[lo + j];
+  double s = 0.0;
+  for (int i = 0; i < k; ++i) {
+    const double u = M.zhat[lo + i] / ((M.dk[lo + i] - dor) - mu);
+    s += u * u;
+  }
+  M.inv[lo + j] = 1.0 / sqrt(s);
+}
+
+// Ut[j][i] = zhat_i / (d_i - lam_j) * inv_j   (row j = eigenvector j of the rank-one problem)
+__global__ __launch_bounds__(256) void dc_ubuild_kernel(const dc_mat* __restrict__ ms, const dc_node* __restrict__ nodes,
+                                                        const dc_nodeout* __restrict__ outs) {
+  const dc_node nd = nodes[blockIdx.z];
+  const dc_mat M = ms[nd.mat];
+  const dc_nodeout o = outs[blockIdx.z];
+  const int k = o.k, lo = nd.lo;
+  const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+  if (i >= k || j >= k) return;
+  const double dor = M.dk[lo + M.org[lo + j]], mu = M.mu[lo + j];
+  M.U[(size_t)lo * M.n + (size_t)j * M.n + i] = M.zhat[lo + i] / ((M.dk[lo + i] - dor) - mu) * M.inv[lo + j];
+}
+
+struct dc_tear { double* d; const double* e; int b; };
+__global__ void dc_tear_kernel(const dc_tear* __restrict__ ts, int nt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nt) return;
+  const dc_tear t = ts[i];
+  const double ab = fabs(t.e[t.b - 1]);
+  t.d[t.b - 1] -= ab;
+  t.d[t.b] -= ab;
+}
+
 }  // namespace
+
+
+// ---- D&C driver: on entry dd/ee hold the tridiagonals (offsets offn); on return dd holds the
+// eigenvalues (unsorted) and zfinal[p] points at the eigenvector-major n x n eigenvector array.
+static int dc_solve(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, double* dd, double* ee,
+                    const std::vector<size_t>& offn, const std::vector<size_t>& off, size_t tot, size_t totn,
+                    std::vector<double*>& zfinal) {
+  const int np = (int)probs.size();
+  double* ZA = dm_ws_alloc_t<double>(ctx, std::max<size_t>(tot, 1));
+  double* ZB = dm_ws_alloc_t<double>(ctx, std::max<size_t>(tot, 1));
+  double* Zp = dm_ws_alloc_t<double>(ctx, std::max<size_t>(tot, 1));
+  double* Uw = dm_ws_alloc_t<double>(ctx, std::max<size_t>(tot, 1));
+  double* lamB = dm_ws_alloc_t<double>(ctx, std::max<size_t>(totn, 1));
+  double* dk = dm_ws_alloc_t<double>(ctx, std::max<size_t>(totn, 1));
+  double* zk = dm_ws_alloc_t<double>(ctx, std::max<size_t>(totn, 1));
+  double* defld = dm_ws_alloc_t<double>(ctx, std::max<size_t>(totn, 1));
+  double* muv = dm_ws_alloc_t<double>(ctx, std::max<size_t>(totn, 1));
+  double* zhat = dm_ws_alloc_t<double>(ctx, std::max<size_t>(totn, 1));
+  double* inv = dm_ws_alloc_t<double>(ctx, std::max<size_t>(totn, 1));
+  int* keepcol = dm_ws_alloc_t<int>(ctx, std::max<size_t>(totn, 1));
+  int* deflcol = dm_ws_alloc_t<int>(ctx, std::max<size_t>(totn, 1));
+  int* org = dm_ws_alloc_t<int>(ctx, std::max<size_t>(totn, 1));
+  double4* rots = dm_ws_alloc_t<double4>(ctx, std::max<size_t>(totn, 1));
+  if (!ZA || !ZB || !Zp || !Uw || !lamB || !dk || !zk || !defld || !muv || !zhat || !inv || !keepcol || !deflcol ||
+      !org || !rots)
+    return DM_ENOMEM;
+  DM_TRY(dm_fill_zero(ctx, ZA, sizeof(double) * tot));
+  DM_TRY(dm_fill_zero(ctx, ZB, sizeof(double) * tot));
+
+  std::vector<dc_mat> dm(np);
+  std::vector<int> depth(np, 0);
+  int dmax = 0;
+  for (int p = 0; p < np; ++p) {
+    const int n = probs[p].n;
+    int D = 0;
+    while (((n + (1 << D) - 1) >> D) > DC_LEAF) ++D;
+    depth[p] = D;
+    dmax = std::max(dmax, D);
+    dm[p] = dc_mat{n, dd + offn[p], lamB + offn[p], ZA + off[p], ZB + off[p], Zp + off[p], dk + offn[p], zk + offn[p],
+                   keepcol + offn[p], deflcol + offn[p], defld + offn[p], rots + offn[p], org + offn[p],
+                   muv + offn[p], zhat + offn[p], inv + offn[p], Uw + off[p]};
+  }
+  dc_mat* d_dm = dm_ws_upload(ctx, dm);
+  if (!d_dm) return DM_ENOMEM;
+  auto bound = [&](int p, int D, int i) { return (int)(((long long)i * probs[p].n) >> D); };
+
+  // ---- tear at every leaf boundary, then solve the leaves with the QL kernels
+  {
+    std::vector<dc_tear> tears;
+    std::vector<ql_mat> qm;
+    std::vector<rot_mat> rm;
+    size_t totsw = 0, totrot = 0;
+    int maxleaf = 0;
+    for (int p = 0; p < np; ++p) {
+      const int n = probs[p].n, D = depth[p];
+      if (n == 0) continue;
+      for (int i = 0; i < (1 << D); ++i) {
+        const int lo = bound(p, D, i), hi = bound(p, D, i + 1);
+        if (i > 0) tears.push_back(dc_tear{dd + offn[p], ee + offn[p], lo});
+        const int nl = hi - lo;
+        maxleaf = std::max(maxleaf, nl);
+        totsw += 4 * (size_t)nl + 8;
+        totrot += 2 * (size_t)nl * nl + 8;
+      }
+    }
+    int* sw_dir = dm_ws_alloc_t<int>(ctx, std::max<size_t>(totsw, 1));
+    int* sw_lo = dm_ws_alloc_t<int>(ctx, std::max<size_t>(totsw, 1));
+    int* sw_cnt = dm_ws_alloc_t<int>(ctx, std::max<size_t>(totsw, 1));
+    long long* sw_off = dm_ws_alloc_t<long long>(ctx, std::max<size_t>(totsw, 1));
+    double2* rot = dm_ws_alloc_t<double2>(ctx, std::max<size_t>(totrot, 1));
+    size_t so = 0, ro = 0;
+    std::vector<int> leafmat;
+    for (int p = 0; p < np; ++p) {
+      const int n = probs[p].n, D = depth[p];
+      if (n == 0) continue;
+      for (int i = 0; i < (1 << D); ++i) {
+        const int lo = bound(p, D, i), hi = bound(p, D, i + 1), nl = hi - lo;
+        leafmat.push_back(p);
+        qm.push_back(ql_mat{dd + offn[p] + lo, ee + offn[p] + lo, nl, sw_dir + so, sw_lo + so, sw_cnt + so, sw_off + so,
+                            rot + ro, 4 * nl + 8, 2LL * nl * nl + 8, nullptr, nullptr});
+        rm.push_back(rot_mat{ZA + off[p] + (size_t)lo * n + lo, nl, n, sw_dir + so, sw_lo + so, sw_cnt + so,
+                             sw_off + so, rot + ro, nullptr});
+        so += 4 * (size_t)nl + 8;
+        ro += 2 * (size_t)nl * nl + 8;
+      }
+    }
+    const int nleaf = (int)qm.size();
+    int* nsw = dm_ws_alloc_t<int>(ctx, std::max(nleaf, 1));
+    int* stat = dm_ws_alloc_t<int>(ctx, std::max(nleaf, 1));
+    if (!sw_dir || !sw_lo || !sw_cnt || !sw_off || !rot || !nsw || !stat) return DM_ENOMEM;
+    for (int i = 0; i < nleaf; ++i) {
+      qm[i].nsweeps = nsw + i; qm[i].status = stat + i;
+      rm[i].nsweeps = nsw + i;
+    }
+    if (!tears.empty()) {
+      dc_tear* d_t = dm_ws_upload(ctx, tears);
+      if (!d_t) return DM_ENOMEM;
+      hipLaunchKernelGGL(dc_tear_kernel, dim3(((unsigned)tears.size() + 255) / 256), dim3(256), 0, ctx->stream, d_t,
+                         (int)tears.size());
+    }
+    if (nleaf > 0) {
+      ql_mat* d_qm = dm_ws_upload(ctx, qm);
+      rot_mat* d_rm = dm_ws_upload(ctx, rm);
+      if (!d_qm || !d_rm) return DM_ENOMEM;
+      static bool attr = false;
+      if (!attr) {
+        DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(ql_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+        attr = true;
+      }
+      hipLaunchKernelGGL(ql_kernel<true>, dim3(nleaf), dim3(64), (size_t)maxleaf * 16, ctx->stream, d_qm);
+      hipLaunchKernelGGL(zt_identity_kernel, dim3((maxleaf + 255) / 256, maxleaf, nleaf), dim3(256), 0, ctx->stream,
+                         d_rm);
+      hipLaunchKernelGGL(rot_apply_kernel, dim3((maxleaf + 255) / 256, nleaf), dim3(256), 0, ctx->stream, d_rm);
+      DM_HIP(ctx, hipGetLastError());
+      std::vector<int> hs(nleaf);
+      DM_TRY(dm_download(ctx, hs.data(), stat, sizeof(int) * nleaf));
+      for (int i = 0; i < nleaf; ++i)
+        if (hs[i] != 0) {
+          ctx->err = "tridiagonal QL iteration (D&C leaf) did not converge";
+          return 1000 + leafmat[i];
+        }
+    }
+  }
+
+  // ---- merge level by level
+  static bool attr2 = false;
+  if (!attr2) {
+    DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dc_setup_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 36 * DC_MAXNODE + 64));
+    DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dc_secular_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 16 * DC_MAXNODE + 64));
+    attr2 = true;
+  }
+  for (int l = dmax - 1; l >= 0; --l) {
+    std::vector<dc_node> nodes;
+    int maxnn = 0;
+    for (int p = 0; p < np; ++p) {
+      const int D = depth[p];
+      if (D <= l || probs[p].n == 0) continue;
+      for (int j = 0; j < (1 << l); ++j) {
+        const int lo = bound(p, l, j), hi = bound(p, l, j + 1), mid = bound(p, l + 1, 2 * j + 1);
+        nodes.push_back(dc_node{p, lo, mid - lo, hi - mid, ee + offn[p] + mid - 1, (D - 1 - l) & 1});
+        maxnn = std::max(maxnn, hi - lo);
+      }
+    }
+    if (nodes.empty()) continue;
+    const int nn_nodes = (int)nodes.size();
+    dc_node* d_nodes = dm_ws_upload(ctx, nodes);
+    dc_nodeout* d_out = dm_ws_alloc_t<dc_nodeout>(ctx, nn_nodes);
+    if (!d_nodes || !d_out) return DM_ENOMEM;
+    hipLaunchKernelGGL(dc_setup_kernel, dim3(nn_nodes), dim3(256), (size_t)36 * maxnn + 64, ctx->stream, d_dm, d_nodes,
+                       d_out);
+    hipLaunchKernelGGL(dc_permute_kernel, dim3(nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
+    DM_HIP(ctx, hipGetLastError());
+    std::vector<dc_nodeout> ho(nn_nodes);
+    DM_TRY(dm_download(ctx, ho.data(), d_out, sizeof(dc_nodeout) * nn_nodes));
+    int kmax = 0;
+    for (auto& o : ho) kmax = std::max(kmax, o.k);
+    if (kmax == 0) continue;
+    const int kt = (kmax + 255) / 256;
+    hipLaunchKernelGGL(dc_secular_kernel, dim3(kt, nn_nodes), dim3(256), (size_t)16 * kmax + 64, ctx->stream, d_dm,
+                       d_nodes, d_out);
+    hipLaunchKernelGGL(dc_zhat_kernel, dim3(kt, nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
+    hipLaunchKernelGGL(dc_unorm_kernel, dim3(kt, nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
+    hipLaunchKernelGGL(dc_ubuild_kernel, dim3(kt, kmax, nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
+    DM_HIP(ctx, hipGetLastError());
+    std::vector<dm_gemm_desc> g;
+    for (int i = 0; i < nn_nodes; ++i) {
+      const dc_node& nd = nodes[i];
+      const int k = ho[i].k;
+      if (k == 0) continue;
+      const int n = probs[nd.mat].n, nn = nd.n1 + nd.n2;
+      double* Zn = (nd.flip ? ZA : ZB) + off[nd.mat];
+      dm_gemm_desc d = dm_gemm_make(reinterpret_cast<const cplx*>(Uw + off[nd.mat] + (size_t)nd.lo * n), n, 1, false,
+                                    Zp + off[nd.mat] + (size_t)nd.lo * n + nd.lo, n, 1, false,
+                                    reinterpret_cast<cplx*>(Zn + (size_t)nd.lo * n + nd.lo), n, k, nn, k, 1.0, 0.0,
+                                    nullptr, DM_GEMM_ALL_REAL);
+      g.push_back(d);
+    }
+    DM_TRY(dm_gemm_grouped_launch(ctx, g));
+  }
+  // ---- results: eigenvalues back into dd, eigenvector buffer per matrix
+  zfinal.assign(np, nullptr);
+  std::vector<dm_cdesc> cp;
+  for (int p = 0; p < np; ++p) {
+    const bool inB = depth[p] > 0 && (depth[p] & 1);
+    zfinal[p] = (inB ? ZB : ZA) + off[p];
+    if (inB && probs[p].n > 0) cp.push_back(dm_cdesc{lamB + offn[p], dd + offn[p], sizeof(double) * probs[p].n});
+  }
+  DM_TRY(dm_copy_batched(ctx, cp));
+  return DM_OK;
+}
 
 // ===========================================================================
 // driver: C (destroyed) -> evals (unsorted), W rows = eigenvectors^H
@@ -734,7 +1276,7 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
       cmax = std::max(cmax, n);
       qm[i] = ql_mat{dd + offn[p], ee + offn[p], n, sw_dir + swoff[p], sw_lo + swoff[p], sw_cnt + swoff[p],
                      sw_off + swoff[p], rot + rotoff[p], 4 * n + 8, 2LL * n * n + 8, nsw + p, stat + p};
-      rm[i] = rot_mat{Zt + off[p], n, sw_dir + swoff[p], sw_lo + swoff[p], sw_cnt + swoff[p], sw_off + swoff[p],
+      rm[i] = rot_mat{Zt + off[p], n, n, sw_dir + swoff[p], sw_lo + swoff[p], sw_cnt + swoff[p], sw_off + swoff[p],
                       rot + rotoff[p], nsw + p};
     }
     // descriptors are uploaded on the main stream; the caller orders `st` after them with an event
@@ -762,6 +1304,7 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
     return DM_OK;
   };
 
+  std::vector<double*> zfinal;  // set by the divide & conquer path
   auto phase_T34 = [&](int c, bool waited_on_side) -> int {
     const std::vector<int>& ch = chunks[c];
     if (ch.empty()) return DM_OK;
@@ -769,9 +1312,12 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
     if (waited_on_side) DM_HIP(ctx, hipStreamWaitEvent(ctx->stream, side_event(2 * c + 1), 0));
     int cmax = 0;
     for (int p : ch) cmax = std::max(cmax, probs[p].n);
-    // T3
-    hipLaunchKernelGGL(zt_identity_kernel, dim3((cmax + 255) / 256, cmax, nc), dim3(256), 0, ctx->stream, d_rm_of[c]);
-    hipLaunchKernelGGL(rot_apply_kernel, dim3((cmax + 255) / 256, nc), dim3(256), 0, ctx->stream, d_rm_of[c]);
+    // T3 (QL path only: D&C delivers the eigenvectors directly)
+    if (zfinal.empty()) {
+      hipLaunchKernelGGL(zt_identity_kernel, dim3((cmax + 255) / 256, cmax, nc), dim3(256), 0, ctx->stream,
+                         d_rm_of[c]);
+      hipLaunchKernelGGL(rot_apply_kernel, dim3((cmax + 255) / 256, nc), dim3(256), 0, ctx->stream, d_rm_of[c]);
+    }
     {
       std::vector<dm_cdesc> cp;
       for (int p : ch)
@@ -781,7 +1327,8 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
     }
     // T4: X = Q Z into the (now free) storage of C, block reflectors applied last to first
     std::vector<cvt_mat> cm(nc);
-    for (int i = 0; i < nc; ++i) cm[i] = cvt_mat{Zt + off[ch[i]], probs[ch[i]].C, probs[ch[i]].ldc, probs[ch[i]].n};
+    for (int i = 0; i < nc; ++i)
+      cm[i] = cvt_mat{zfinal.empty() ? Zt + off[ch[i]] : zfinal[ch[i]], probs[ch[i]].C, probs[ch[i]].ldc, probs[ch[i]].n};
     cvt_mat* d_cm = dm_ws_upload(ctx, cm);
     if (!d_cm) return DM_ENOMEM;
     const int tb = (cmax + 31) / 32;
@@ -834,7 +1381,12 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
     return DM_OK;
   };
 
-  if (nch == 1) {
+  const bool use_dc = nch == 1 && maxn > DC_LEAF && maxn <= DC_MAXNODE && !getenv("DM_EIG_QL");
+  if (use_dc) {
+    DM_TRY(phase_T1(chunks[0]));
+    DM_TRY(dc_solve(ctx, probs, dd, ee, offn, off, tot, totn, zfinal));
+    DM_TRY(phase_T34(0, false));
+  } else if (nch == 1) {
     DM_TRY(phase_T1(chunks[0]));
     DM_TRY(phase_T2(0, ctx->stream));
     DM_TRY(phase_T34(0, false));
