@@ -61,7 +61,7 @@ def hot_path_step(tel, bt, kl, ctx, stage_times=None):
     bt._dev = {mi: dict(beam_svd=res["beam_svd"][mi], beam_ut=res["beam_ut"][mi], singularvalues=sv[mi]) for mi in ms}
     out = None
     for batch in kl._batches(ms):
-        out = kl._transform_batch(batch)                            # projections + eigh_gen
+        out = kl._transform_batch(batch, to_host=False)             # projections + eigh_gen, products stay in HBM
     t3 = mark()
     if stage_times is not None:
         stage_times.append((t1 - t0, t2 - t1, t3 - t2))

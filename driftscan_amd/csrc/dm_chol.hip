@@ -200,24 +200,45 @@ int dm_potrf_batched(dm_ctx* ctx, const std::vector<dm_mat>& mats, int* info_dev
   chol_desc* dd = dm_ws_upload(ctx, ds);
   if (!dd) return DM_ENOMEM;
   DM_HIP(ctx, hipMemsetAsync(info_dev, 0, sizeof(int) * nbatch, ctx->stream));
-  for (int k0 = 0; k0 < maxn; k0 += NB) {
-    hipLaunchKernelGGL(potf2_kernel, dim3(nbatch), dim3(256), 0, ctx->stream, dd, k0, info_dev);
-    if (k0 + NB >= maxn) break;
-    const int rt = (maxn - k0 - NB + 63) / 64;
-    hipLaunchKernelGGL(panel_trsm_kernel, dim3(rt, nbatch), dim3(256), 0, ctx->stream, dd, k0, info_dev);
-    // trailing update A22 -= L21 L21^H (lower tiles).  A failed matrix is updated
-    // too (harmless: its factor is discarded by the caller).
-    std::vector<dm_gemm_desc> g;
-    g.reserve(nbatch);
-    for (int i = 0; i < nbatch; ++i) {
-      const int rem = mats[i].n - k0 - NB;
-      if (rem <= 0) continue;
-      cplx* L21 = mats[i].p + (size_t)(k0 + NB) * mats[i].ld + k0;
-      cplx* A22 = mats[i].p + (size_t)(k0 + NB) * mats[i].ld + (k0 + NB);
-      g.push_back(dm_gemm_make(L21, mats[i].ld, 1, false, L21, 1, mats[i].ld, true, A22, mats[i].ld, rem, rem, NB,
-                               -1.0, 1.0, nullptr, DM_GEMM_LOWER));
+  // Two-level blocking: the LDS factor/substitution kernels work on 32-wide blocks, but the big
+  // trailing update runs once per 64 columns so that the MFMA GEMM sees K = 64 and full tiles.
+  for (int k0 = 0; k0 < maxn; k0 += 2 * NB) {
+    for (int half = 0; half < 2; ++half) {
+      const int kk = k0 + half * NB;
+      if (kk >= maxn) break;
+      hipLaunchKernelGGL(potf2_kernel, dim3(nbatch), dim3(256), 0, ctx->stream, dd, kk, info_dev);
+      if (kk + NB >= maxn) break;
+      const int rt = (maxn - kk - NB + 63) / 64;
+      hipLaunchKernelGGL(panel_trsm_kernel, dim3(rt, nbatch), dim3(256), 0, ctx->stream, dd, kk, info_dev);
+      if (half == 0) {
+        // update only the next 32 columns so that the second factor step sees current data:
+        // A[kk+NB:, kk+NB:kk+2NB] -= L[kk+NB:, kk:kk+NB] L[kk+NB:kk+2NB, kk:kk+NB]^H
+        std::vector<dm_gemm_desc> g;
+        for (int i = 0; i < nbatch; ++i) {
+          const int rem = mats[i].n - kk - NB;
+          if (rem <= 0) continue;
+          cplx* L21 = mats[i].p + (size_t)(kk + NB) * mats[i].ld + kk;
+          cplx* A22 = mats[i].p + (size_t)(kk + NB) * mats[i].ld + (kk + NB);
+          g.push_back(dm_gemm_make(L21, mats[i].ld, 1, false, L21, 1, mats[i].ld, true, A22, mats[i].ld, rem,
+                                   std::min(NB, rem), NB, -1.0, 1.0));
+        }
+        DM_TRY(dm_gemm_grouped_launch(ctx, g));
+      }
     }
-    DM_TRY(dm_gemm_grouped_launch(ctx, g));
+    // trailing update with both 32-wide panels at once (K = 64), lower tiles only
+    const int k2 = k0 + 2 * NB;
+    if (k2 < maxn) {
+      std::vector<dm_gemm_desc> g;
+      for (int i = 0; i < nbatch; ++i) {
+        const int rem = mats[i].n - k2;
+        if (rem <= 0) continue;
+        cplx* L21 = mats[i].p + (size_t)k2 * mats[i].ld + k0;
+        cplx* A22 = mats[i].p + (size_t)k2 * mats[i].ld + k2;
+        g.push_back(dm_gemm_make(L21, mats[i].ld, 1, false, L21, 1, mats[i].ld, true, A22, mats[i].ld, rem, rem,
+                                 2 * NB, -1.0, 1.0, nullptr, DM_GEMM_LOWER));
+      }
+      DM_TRY(dm_gemm_grouped_launch(ctx, g));
+    }
   }
   hipLaunchKernelGGL(zero_upper_kernel, dim3((maxn + 255) / 256, maxn, nbatch), dim3(256), 0, ctx->stream, dd);
   DM_HIP(ctx, hipGetLastError());
@@ -238,39 +259,72 @@ int dm_trsm_left_lower_batched(dm_ctx* ctx, const std::vector<dm_trsm_problem>& 
   if (maxn == 0 || maxrhs == 0) return DM_OK;
   trsm_desc* dd = dm_ws_upload(ctx, ds);
   if (!dd) return DM_ENOMEM;
-  const int nblk = (maxn + NB - 1) / NB;
   const int ct = (maxrhs + 63) / 64;
+  const int NB2 = 2 * NB;
+  const int nblk = (maxn + NB2 - 1) / NB2;   // 64-row super blocks
+  const int nblk32 = (maxn + NB - 1) / NB;   // the substitution kernels still count 32-row blocks
   for (int s = 0; s < nblk; ++s) {
+    // (1) one GEMM brings in everything outside the 64-row super block (full 64x64 MFMA tiles)
     std::vector<dm_gemm_desc> g;
-    g.reserve(nbatch);
     for (int i = 0; i < nbatch; ++i) {
       const dm_trsm_problem& P = probs[i];
-      const int pn = (P.n + NB - 1) / NB;
+      const int pn = (P.n + NB2 - 1) / NB2;
       if (!conjtrans) {
-        // forward: block row k = s ; B_k -= L[k, 0:k0] X[0:k0]
-        const int k0 = s * NB;
+        const int k0 = s * NB2;
         if (k0 >= P.n || k0 == 0) continue;
-        const int nb = std::min(NB, P.n - k0);
+        const int nb = std::min(NB2, P.n - k0);
         g.push_back(dm_gemm_make(P.L + (size_t)k0 * P.ldl, P.ldl, 1, false, P.B, P.ldb, 1, false,
                                  P.B + (size_t)k0 * P.ldb, P.ldb, nb, P.nrhs, k0, -1.0, 1.0));
       } else {
-        // backward: block row k = pn-1-s (per problem) ; B_k -= (L[k1:, k])^H X[k1:]
-        const int kb = pn - 1 - (s - (nblk - pn));
         if (s < nblk - pn) continue;  // smaller problems start later so that all finish together
-        const int k0 = kb * NB;
-        const int nb = std::min(NB, P.n - k0);
+        const int kb = pn - 1 - (s - (nblk - pn));
+        const int k0 = kb * NB2;
+        const int nb = std::min(NB2, P.n - k0);
         const int k1 = k0 + nb;
         if (k1 >= P.n) continue;
-        // A = (L[k1:n, k0:k0+nb])^H viewed as (nb x (n-k1)): element (i, j) = conj(L[k1+j][k0+i])
         g.push_back(dm_gemm_make(P.L + (size_t)k1 * P.ldl + k0, 1, P.ldl, true, P.B + (size_t)k1 * P.ldb, P.ldb, 1,
                                  false, P.B + (size_t)k0 * P.ldb, P.ldb, nb, P.nrhs, P.n - k1, -1.0, 1.0));
       }
     }
     DM_TRY(dm_gemm_grouped_launch(ctx, g));
-    if (!conjtrans)
-      hipLaunchKernelGGL(diag_solve_kernel<false>, dim3(ct, nbatch), dim3(64), 0, ctx->stream, dd, s, nblk);
-    else
-      hipLaunchKernelGGL(diag_solve_kernel<true>, dim3(ct, nbatch), dim3(64), 0, ctx->stream, dd, s, nblk);
+    // (2) inside the super block: substitution on one 32-row half, a small GEMM, the other half
+    for (int half = 0; half < 2; ++half) {
+      // forward: halves in order 0, 1 ; backward: 1, 0
+      const int h = conjtrans ? 1 - half : half;
+      // 32-block step index understood by diag_solve_kernel
+      int s32;
+      if (!conjtrans) s32 = 2 * s + h;
+      else s32 = 2 * s + half;  // backward kernel maps its step to the block row itself
+      if (!conjtrans)
+        hipLaunchKernelGGL(diag_solve_kernel<false>, dim3(ct, nbatch), dim3(64), 0, ctx->stream, dd, s32, nblk32);
+      else
+        hipLaunchKernelGGL(diag_solve_kernel<true>, dim3(ct, nbatch), dim3(64), 0, ctx->stream, dd, s32, 2 * nblk);
+      if (half == 0) {
+        std::vector<dm_gemm_desc> g2;
+        for (int i = 0; i < nbatch; ++i) {
+          const dm_trsm_problem& P = probs[i];
+          const int pn = (P.n + NB2 - 1) / NB2;
+          if (!conjtrans) {
+            const int k0 = s * NB2, k1 = k0 + NB;
+            if (k1 >= P.n) continue;
+            const int nb = std::min(NB, P.n - k1);
+            // B[k1:k1+nb] -= L[k1:k1+nb, k0:k1] X[k0:k1]
+            g2.push_back(dm_gemm_make(P.L + (size_t)k1 * P.ldl + k0, P.ldl, 1, false, P.B + (size_t)k0 * P.ldb, P.ldb,
+                                      1, false, P.B + (size_t)k1 * P.ldb, P.ldb, nb, P.nrhs, NB, -1.0, 1.0));
+          } else {
+            if (s < nblk - pn) continue;
+            const int kb = pn - 1 - (s - (nblk - pn));
+            const int k0 = kb * NB2, k1 = k0 + NB;
+            if (k1 >= P.n) continue;
+            const int nb2 = std::min(NB, P.n - k1);
+            // B[k0:k1] -= (L[k1:k1+nb2, k0:k1])^H X[k1:k1+nb2]
+            g2.push_back(dm_gemm_make(P.L + (size_t)k1 * P.ldl + k0, 1, P.ldl, true, P.B + (size_t)k1 * P.ldb, P.ldb,
+                                      1, false, P.B + (size_t)k0 * P.ldb, P.ldb, NB, P.nrhs, nb2, -1.0, 1.0));
+          }
+        }
+        DM_TRY(dm_gemm_grouped_launch(ctx, g2));
+      }
+    }
   }
   DM_HIP(ctx, hipGetLastError());
   return DM_OK;

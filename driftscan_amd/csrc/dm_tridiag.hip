@@ -46,8 +46,7 @@ struct trd_mat {
 };
 
 // ---- T1a: column k of A_lazy = A - V W^H - W V^H, Householder vector ----------------
-__global__ __launch_bounds__(256) void trd_col_kernel(const trd_mat* __restrict__ ms, int k, int j) {
-  const trd_mat M = ms[blockIdx.x];
+__device__ __forceinline__ void trd_col_body(const trd_mat& M, int k, int j) {
   const int n = M.n;
   if (k >= n) return;
   __shared__ double red[4];
@@ -147,8 +146,7 @@ __global__ __launch_bounds__(256) void trd_hemv_kernel(const trd_mat* __restrict
 }
 
 // ---- T1c: panel corrections and w -------------------------------------------------------
-__global__ __launch_bounds__(256) void trd_w_kernel(const trd_mat* __restrict__ ms, int k, int j) {
-  const trd_mat M = ms[blockIdx.x];
+__device__ __forceinline__ void trd_w_body(const trd_mat& M, int k, int j) {
   const int n = M.n;
   if (k >= n - 1) return;
   __shared__ cplx sa[TNB], sb[TNB];  // a = W^H v, b = V^H v
@@ -186,6 +184,22 @@ __global__ __launch_bounds__(256) void trd_w_kernel(const trd_mat* __restrict__ 
   // w = p - (tau/2) (p^H v) v
   const cplx coef = cscale(cmul(tau, dot), 0.5);
   for (int i = k + 1 + tid; i < n; i += 256) w[i] = csub(w[i], cmul(coef, v[i]));
+}
+
+__global__ __launch_bounds__(256) void trd_col_kernel(const trd_mat* __restrict__ ms, int k, int j) {
+  trd_col_body(ms[blockIdx.x], k, j);
+}
+__global__ __launch_bounds__(256) void trd_w_kernel(const trd_mat* __restrict__ ms, int k, int j) {
+  trd_w_body(ms[blockIdx.x], k, j);
+}
+// w of column k followed by the Householder vector of column k+1 (same panel): one launch less
+// on the latency-bound critical path of the tridiagonalisation.
+__global__ __launch_bounds__(256) void trd_wcol_kernel(const trd_mat* __restrict__ ms, int k, int j) {
+  const trd_mat M = ms[blockIdx.x];
+  trd_w_body(M, k, j);
+  __threadfence_block();
+  __syncthreads();
+  trd_col_body(M, k + 1, j + 1);
 }
 
 // ---- T2: implicit QL/QR on the tridiagonal (LAPACK dsteqr scheme), recording rotations ------
@@ -1219,13 +1233,16 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
     if (!d_tm) return DM_ENOMEM;
     for (int k0 = 0; k0 < cmax; k0 += TNB) {
       const int k1 = std::min(k0 + TNB, cmax);
+      hipLaunchKernelGGL(trd_col_kernel, dim3(nc), dim3(256), 0, ctx->stream, d_tm, k0, 0);
       for (int k = k0; k < k1; ++k) {
         const int j = k - k0;
-        hipLaunchKernelGGL(trd_col_kernel, dim3(nc), dim3(256), 0, ctx->stream, d_tm, k, j);
         if (k < cmax - 1) {
           const int rt = (cmax - k - 1 + 2 * j + 3) / 4;
           hipLaunchKernelGGL(trd_hemv_kernel, dim3(rt, nc), dim3(256), 0, ctx->stream, d_tm, k, j);
-          hipLaunchKernelGGL(trd_w_kernel, dim3(nc), dim3(256), 0, ctx->stream, d_tm, k, j);
+          if (k + 1 < k1)
+            hipLaunchKernelGGL(trd_wcol_kernel, dim3(nc), dim3(256), 0, ctx->stream, d_tm, k, j);
+          else
+            hipLaunchKernelGGL(trd_w_kernel, dim3(nc), dim3(256), 0, ctx->stream, d_tm, k, j);
         }
       }
       if (k1 < cmax) {

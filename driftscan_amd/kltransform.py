@@ -128,11 +128,16 @@ class KLTransform(config.Reader):
         return S[: n * n].cpu().numpy().reshape(n, n), N[: n * n].cpu().numpy().reshape(n, n)
 
     # ---- the transform -------------------------------------------------------------------
-    def _transform_batch(self, ms):
-        """KL modes of several m: list of (evals, evecs[rows = modes], inv, evextra)."""
+    def _transform_batch(self, ms, to_host=True):
+        """KL modes of several m: list of (evals, evecs[rows = modes], inv, evextra).
+        With ``to_host=False`` the eigenvectors stay on the device (views into one flat tensor)."""
         ctx = get_context()
         S, N, ndofs, off = self.sn_covariance_device(ms)
         evals, evoff, evecs, ac, sweeps = ctx.eigh_gen(S, N, ndofs, off)
+        if not to_host:
+            return [(evals[evoff[i] : evoff[i] + int(ndofs[i])],
+                     evecs[off[i] : off[i] + int(ndofs[i]) ** 2].view(int(ndofs[i]), int(ndofs[i])), None,
+                     {"ac": float(ac[i])}) for i in range(len(ms))]
         ev_h = evals.cpu().numpy()
         out = []
         for i, mi in enumerate(ms):
