@@ -23,16 +23,22 @@ struct blk_desc {
   cplx* a; int n;
 };
 
-// numpy's max of a complex array is lexicographic in (re, im); one block per matrix
-__global__ void lexmax_adddiag_kernel(const blk_desc* __restrict__ bd, double reg) {
-  const blk_desc d = bd[blockIdx.x];
-  if (d.n == 0) return;
+constexpr int BLK_SPLIT = 16;  // workgroups per matrix for the streaming reductions below
+
+__device__ __forceinline__ bool lex_gt(double are, double aim, double bre, double bim) {
+  return are > bre || (are == bre && aim > bim);
+}
+
+// numpy's max of a complex array is lexicographic in (re, im).  Stage 1: BLK_SPLIT partial
+// maxima per matrix; stage 2 folds them and shifts the diagonal.
+__global__ __launch_bounds__(256) void lexmax_partial_kernel(const blk_desc* __restrict__ bd, double2* __restrict__ part) {
+  const blk_desc d = bd[blockIdx.y];
   __shared__ double sre[256], sim[256];
   double bre = -INFINITY, bim = -INFINITY;
   const size_t tot = (size_t)d.n * d.n;
-  for (size_t i = threadIdx.x; i < tot; i += blockDim.x) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (size_t)BLK_SPLIT * 256) {
     cplx v = d.a[i];
-    if (v.x > bre || (v.x == bre && v.y > bim)) { bre = v.x; bim = v.y; }
+    if (lex_gt(v.x, v.y, bre, bim)) { bre = v.x; bim = v.y; }
   }
   sre[threadIdx.x] = bre;
   sim[threadIdx.x] = bim;
@@ -40,35 +46,47 @@ __global__ void lexmax_adddiag_kernel(const blk_desc* __restrict__ bd, double re
   for (int s = 128; s > 0; s >>= 1) {
     if (threadIdx.x < s) {
       double ore = sre[threadIdx.x + s], oim = sim[threadIdx.x + s];
-      if (ore > sre[threadIdx.x] || (ore == sre[threadIdx.x] && oim > sim[threadIdx.x])) {
+      if (lex_gt(ore, oim, sre[threadIdx.x], sim[threadIdx.x])) {
         sre[threadIdx.x] = ore;
         sim[threadIdx.x] = oim;
       }
     }
     __syncthreads();
   }
-  const double are = reg * sre[0], aim = reg * sim[0];
-  for (int i = threadIdx.x; i < d.n; i += blockDim.x) {
+  if (threadIdx.x == 0) part[(size_t)blockIdx.y * BLK_SPLIT + blockIdx.x] = make_double2(sre[0], sim[0]);
+}
+
+__global__ __launch_bounds__(256) void lexmax_adddiag_kernel(const blk_desc* __restrict__ bd, const double2* __restrict__ part,
+                                                             double reg) {
+  const blk_desc d = bd[blockIdx.y];
+  if (d.n == 0) return;
+  double bre = -INFINITY, bim = -INFINITY;
+  for (int s = 0; s < BLK_SPLIT; ++s) {
+    const double2 v = part[(size_t)blockIdx.y * BLK_SPLIT + s];
+    if (lex_gt(v.x, v.y, bre, bim)) { bre = v.x; bim = v.y; }
+  }
+  const double are = reg * bre, aim = reg * bim;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < d.n) {
     cplx v = d.a[(size_t)i * d.n + i];
     d.a[(size_t)i * d.n + i] = make_double2(v.x + are, v.y + aim);
   }
 }
 
-// flag[b] = 1 if every element of block b is exactly zero
-__global__ void allzero_kernel(const blk_desc* __restrict__ bd, int* __restrict__ flag) {
-  const blk_desc d = bd[blockIdx.x];
-  __shared__ int nz;
-  if (threadIdx.x == 0) nz = 0;
-  __syncthreads();
+// flag[b] stays 1 only if every element of block b is exactly zero (flag preset to 1)
+__global__ __launch_bounds__(256) void flag_set_kernel(int* __restrict__ flag, int n, int val) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) flag[i] = val;
+}
+__global__ __launch_bounds__(256) void allzero_kernel(const blk_desc* __restrict__ bd, int* __restrict__ flag) {
+  const blk_desc d = bd[blockIdx.y];
   const size_t tot = (size_t)d.n * d.n;
   int mine = 0;
-  for (size_t i = threadIdx.x; i < tot; i += blockDim.x) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (size_t)BLK_SPLIT * 256) {
     cplx v = d.a[i];
     if (v.x != 0.0 || v.y != 0.0) mine = 1;
   }
-  if (mine) nz = 1;
-  __syncthreads();
-  if (threadIdx.x == 0) flag[blockIdx.x] = nz ? 0 : 1;
+  if (mine) flag[blockIdx.y] = 0;  // benign race: every writer stores the same value
 }
 
 __global__ void add_diag_kernel(const blk_desc* __restrict__ bd, const double* __restrict__ val) {
@@ -107,20 +125,23 @@ int dm_project_cov(dm_ctx* ctx, int nblk, int F, int K, int P, int L, const void
   std::vector<std::vector<int>> bounds(nblk, std::vector<int>(F + 1, 0));
   for (int b = 0; b < nblk; ++b) {
     for (int f = 0; f < F; ++f) bounds[b][f + 1] = bounds[b][f] + svnum_host[b * F + f];
-    if (zero_first) {
-      const size_t n = bounds[b][F];
-      DM_TRY(dm_fill_zero(ctx, out + out_off_host[b], sizeof(cplx) * n * n));
-    }
   }
+  // The (f, f') tiles of one pol pair cover the whole block, so the first pair can overwrite
+  // (beta = 0) instead of zero-fill + accumulate; blocks without any l in range are cleared.
+  bool first_pair = zero_first != 0;
   for (int pi = 0; pi < npol; ++pi)
     for (int pj = 0; pj < npol; ++pj) {
       if (polmask_host && !polmask_host[pi * P + pj]) continue;
+      const double beta = first_pair ? 0.0 : 1.0;
       std::vector<dm_gemm_desc> g;
       for (int b = 0; b < nblk; ++b) {
         const int ndof = bounds[b][F];
         if (ndof == 0) continue;
         const int l0 = l0_host ? std::min(std::max(l0_host[b], 0), L) : 0;
-        if (L - l0 <= 0) continue;
+        if (L - l0 <= 0) {
+          if (first_pair) DM_TRY(dm_fill_zero(ctx, out + out_off_host[b], sizeof(cplx) * (size_t)ndof * ndof));
+          continue;
+        }
         cplx* ob = out + out_off_host[b];
         for (int fi = 0; fi < F; ++fi) {
           const int ni = svnum_host[b * F + fi];
@@ -133,12 +154,17 @@ int dm_project_cov(dm_ctx* ctx, int nblk, int F, int K, int P, int L, const void
             const double* cl = cl_pfl_dev + ((((size_t)pi * P + pj) * F + fi) * F + fj) * L + l0;
             g.push_back(dm_gemm_make(Ai, PL, 1, false, Bj, 1, PL, true,
                                      ob + (size_t)bounds[b][fi] * ndof + bounds[b][fj], ndof, ni, nj, L - l0, 1.0,
-                                     1.0, cl));
+                                     beta, cl));
           }
         }
       }
       DM_TRY(dm_gemm_grouped_launch(ctx, g));
+      first_pair = false;
     }
+  if (first_pair)  // every pair masked: the contract is still out = 0
+    for (int b = 0; b < nblk; ++b)
+      if (bounds[b][F] > 0)
+        DM_TRY(dm_fill_zero(ctx, out + out_off_host[b], sizeof(cplx) * (size_t)bounds[b][F] * bounds[b][F]));
   dm_ws_release(ctx, mark);
   return DM_OK;
 }
@@ -183,7 +209,13 @@ int dm_regularise(dm_ctx* ctx, int nblk, const int* n_host, void* mats_dev, cons
   for (int b = 0; b < nblk; ++b) bd[b] = blk_desc{reinterpret_cast<cplx*>(mats_dev) + off_host[b], n_host[b]};
   blk_desc* d = dm_ws_upload(ctx, bd);
   if (!d) return DM_ENOMEM;
-  hipLaunchKernelGGL(lexmax_adddiag_kernel, dim3(nblk), dim3(256), 0, ctx->stream, d, reg);
+  double2* part = dm_ws_alloc_t<double2>(ctx, (size_t)nblk * BLK_SPLIT);
+  if (!part) return DM_ENOMEM;
+  int maxn = 0;
+  for (int b = 0; b < nblk; ++b) maxn = std::max(maxn, n_host[b]);
+  hipLaunchKernelGGL(lexmax_partial_kernel, dim3(BLK_SPLIT, nblk), dim3(256), 0, ctx->stream, d, part);
+  hipLaunchKernelGGL(lexmax_adddiag_kernel, dim3((std::max(maxn, 1) + 255) / 256, nblk), dim3(256), 0, ctx->stream, d,
+                     part, reg);
   DM_HIP(ctx, hipGetLastError());
   dm_ws_release(ctx, mark);
   return DM_OK;
@@ -234,7 +266,8 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
   for (int b = 0; b < nblk; ++b) bdA[b] = blk_desc{A + off_host[b], n_host[b]};
   blk_desc* d_bdA = dm_ws_upload(ctx, bdA);
   if (!d_bdA) return DM_ENOMEM;
-  hipLaunchKernelGGL(allzero_kernel, dim3(nblk), dim3(256), 0, ctx->stream, d_bdA, zflag_dev);
+  hipLaunchKernelGGL(flag_set_kernel, dim3((nblk + 255) / 256), dim3(256), 0, ctx->stream, zflag_dev, nblk, 1);
+  hipLaunchKernelGGL(allzero_kernel, dim3(BLK_SPLIT, nblk), dim3(256), 0, ctx->stream, d_bdA, zflag_dev);
   std::vector<int> zflag(nblk);
   DM_TRY(dm_download(ctx, zflag.data(), zflag_dev, sizeof(int) * nblk));
 

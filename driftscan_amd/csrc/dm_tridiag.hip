@@ -1365,11 +1365,14 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
         cplx* X = probs[p].C;
         cplx* w1 = W1 + offn[p] * TNB;
         cplx* w2 = W2 + offn[p] * TNB;
-        g1.push_back(dm_gemm_make(Vb, n, 1, true, Vb, 1, n, false, G, TNB, kb, kb, n));
+        // reflectors k >= k0 vanish on rows <= k0: only rows r0.. of X take part
+        const int r0 = k0 + 1, nr = n - r0;
+        cplx* Xr = X + (size_t)r0 * probs[p].ldc;
+        g1.push_back(dm_gemm_make(Vb + r0, n, 1, true, Vb + r0, 1, n, false, G, TNB, kb, kb, nr));
         tf.push_back(tf_mat{G, tau + offn[p] + k0, T, kb});
-        g2.push_back(dm_gemm_make(Vb, n, 1, true, X, probs[p].ldc, 1, false, w1, n, kb, n, n));
+        g2.push_back(dm_gemm_make(Vb + r0, n, 1, true, Xr, probs[p].ldc, 1, false, w1, n, kb, n, nr));
         g3.push_back(dm_gemm_make(T, TNB, 1, false, w1, n, 1, false, w2, n, kb, n, kb));
-        g4.push_back(dm_gemm_make(Vb, 1, n, false, w2, n, 1, false, X, probs[p].ldc, n, n, kb, -1.0, 1.0));
+        g4.push_back(dm_gemm_make(Vb + r0, 1, n, false, w2, n, 1, false, Xr, probs[p].ldc, nr, n, kb, -1.0, 1.0));
       }
       if (g1.empty()) continue;
       DM_TRY(dm_gemm_grouped_launch(ctx, g1));
