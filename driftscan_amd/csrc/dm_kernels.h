@@ -14,6 +14,7 @@ enum {
   DM_GEMM_B_REAL = 4,  // B points at real doubles (complex x real product)
   DM_GEMM_LOWER = 8,   // only compute 64x64 tiles on or below the block diagonal
   DM_GEMM_ALL_REAL = 16,  // A, B and C are arrays of doubles (strides in doubles)
+  DM_GEMM_UPPER = 32,  // only compute 64x64 tiles on or above the block diagonal
 };
 
 struct dm_gemm_desc {

@@ -5,11 +5,10 @@
 // for every m-block at once.  All matrices of the batch advance in lock-step, so a
 // launch always carries (#matrices x #row tiles) workgroups:
 //
-//   T1  tridiagonalisation (LAPACK zhetrd/zlatrd scheme, panels of 32 reflectors):
-//         trd_col   Householder vector of column k of the lazily updated matrix   (1 WG / matrix)
-//         trd_hemv  p = A v over the trailing block, one wave per row              (HBM-bound: the roofline of T1)
-//         trd_w     panel corrections, w = tau p - (tau/2)(p^H v) v                (1 WG / matrix)
-//         her2k     A -= V W^H + W V^H once per panel                              (grouped ZGEMM, MFMA)
+//   T1  tridiagonalisation (LAPACK zhetrd/zlatrd recurrences, panels of 64 reflectors, upper triangle only):
+//         trd_symv  p = A v reading each stored element once + Householder scalars  (HBM-bound: the roofline of T1)
+//         trd_wx    w = tau p - (tau/2)(p^H v) v and the next column, one pass over the panel
+//         her2k     A -= [V W][W V]^H once per panel, K = 128                      (grouped ZGEMM, MFMA)
 //   T2  ql_kernel   implicit QL with Wilkinson shifts, one wave (lane 0) per matrix; the
 //                   Givens rotations are recorded sweep by sweep instead of being applied
 //   T3  rot_apply   the recorded rotations are applied to Z = I, one thread per ROW of Z,
@@ -37,92 +36,86 @@ struct trd_mat {
   cplx* A; int lda; int n;
   cplx* Vt;      // n x n: row k = Householder vector k (zero for index <= k, 1 at k+1)
   cplx* Vp;      // TNB x n panel of V (row j = vector of panel column j)
-  cplx* Wp;      // TNB x n panel of W
-  cplx* p;       // n scratch (hemv result)
+  cplx* Wp;      // TNB x n panel of W, stored right behind Vp ...
+  cplx* Vp2;     // ... and a second copy of V behind W: [V; W] and [W; V] are both contiguous (her2k at K = 2 TNB)
+  cplx* x;       // n: unnormalised Householder column of the current step
+  cplx* p;       // n: row part of A v
+  cplx* Pc;      // (n / SYG + 1) x n: mirrored (column) parts of A v, one row per SYG-row group
+  double* Sp;    // n / SYG + 1: partial sums of v^H A v
+  double* Np;    // n / WXR + 1: partial sums of |x|^2
   cplx* ab;      // 2*TNB scratch: panel dot products W^H v, V^H v
   double* d;     // n
   double* e;     // n
   cplx* tau;     // n
 };
 
-// ---- T1a: column k of A_lazy = A - V W^H - W V^H, Householder vector ----------------
-__device__ __forceinline__ void trd_col_body(const trd_mat& M, int k, int j) {
-  const int n = M.n;
-  if (k >= n) return;
-  __shared__ double red[4];
-  __shared__ cplx sh_alpha;
-  __shared__ cplx wk[TNB], vk[TNB];  // W[k][jj], V[k][jj] of the panel (row k entries)
-  const int tid = threadIdx.x;
-  if (tid < j) {
-    wk[tid] = M.Wp[(size_t)tid * n + k];
-    vk[tid] = M.Vp[(size_t)tid * n + k];
-  }
-  __syncthreads();
-  cplx* vrow = M.Vp + (size_t)j * n;  // will hold v (also used as scratch for the column)
-  // col[i] = conj(A[k][i]) - sum_jj V[i][jj] conj(W[k][jj]) + W[i][jj] conj(V[k][jj])   (i >= k)
-  double part = 0.0;
-  for (int i = k + tid; i < n; i += 256) {
-    cplx a = M.A[(size_t)k * M.lda + i];
-    cplx c = make_double2(a.x, -a.y);
-    for (int jj = 0; jj < j; ++jj) {
-      c = csub(c, cmulc(M.Vp[(size_t)jj * n + i], wk[jj]));
-      c = csub(c, cmulc(M.Wp[(size_t)jj * n + i], vk[jj]));
-    }
-    vrow[i] = c;
-    if (i > k + 1) part += cabs2(c);
-    if (i == k + 1) sh_alpha = c;
-    if (i == k) M.d[k] = c.x;
-  }
-  if (k == n - 1) return;  // last diagonal entry only (uniform: whole block)
-  part = dm_wave_sum(part);
-  if ((tid & 63) == 0) red[tid >> 6] = part;
-  __syncthreads();
-  const double xnorm2 = red[0] + red[1] + red[2] + red[3];
-  const cplx alpha = sh_alpha;
-  double beta;
-  cplx tau, scal;
+// ---- T1: one column of the reduction = two launches, both spread over (row tiles x matrices) ----
+//
+// Only the UPPER triangle of the trailing matrix is kept up to date (her2k writes tiles on or
+// above the block diagonal) and the matrix-vector product reads each stored element once:
+//
+//   trd_symv(k)  every wave derives the Householder scalars (beta, tau, 1/(alpha-beta)) of column k
+//                from the partial norms left by trd_wx and forms v on the fly from the unnormalised
+//                column x.  A wave owns SYR = 8 consecutive rows r and streams them in 64-column
+//                chunks c >= r: the row part  sum_c A[r][c] v[c]  is accumulated per row, the
+//                mirrored part  conj(A[r][c]) v[r]  per column, and written as one partial row
+//                Pc[group][c] (no atomics: the consumer adds the partial rows in a fixed order).
+//                It also writes v, e[k], tau[k], the panel dot products a = W^H v, b = V^H v and the
+//                partial sums of v^H A v (which give p^H v without another pass over p).
+//   trd_wx(k)    finishes w_k = tau (A v - V a - W b) - (tau/2)(p^H v) v  for its 128 rows and, in
+//                the same pass over the panel rows V[:, i], W[:, i], forms the next column
+//                x_{k+1} = conj(A[k+1][i]) - V conj(W[k+1]) - W conj(V[k+1])  and its partial norms.
+//
+// HBM traffic per column: (n-k)^2/2 matrix elements + one pass over the panel (the zlatrd scheme
+// reads the full square and the panel twice).
+constexpr int SYR = 8;     // rows per wave in trd_symv
+constexpr int SYG = 4 * SYR;  // rows per workgroup = rows behind one partial row of Pc
+constexpr int WXR = 128;   // rows per workgroup in trd_wx
+
+struct trd_refl { cplx tau, scal; double beta; };
+
+__device__ __forceinline__ trd_refl trd_reflector(const trd_mat& M, int k) {
+  const int np = (M.n - k + WXR - 1) / WXR;
+  double xnorm2 = 0.0;
+  for (int t = 0; t < np; ++t) xnorm2 += M.Np[t];
+  const cplx alpha = M.x[k + 1];
+  trd_refl R;
   if (xnorm2 == 0.0 && alpha.y == 0.0) {
-    tau = make_double2(0.0, 0.0);
-    beta = alpha.x;
-    scal = make_double2(0.0, 0.0);
+    R.tau = make_double2(0.0, 0.0);
+    R.beta = alpha.x;
+    R.scal = make_double2(0.0, 0.0);
   } else {
-    beta = -copysign(sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xnorm2), alpha.x);
-    tau = make_double2((beta - alpha.x) / beta, -alpha.y / beta);
-    // 1 / (alpha - beta)
-    const double dr = alpha.x - beta, di = alpha.y;
+    R.beta = -copysign(sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xnorm2), alpha.x);
+    R.tau = make_double2((R.beta - alpha.x) / R.beta, -alpha.y / R.beta);
+    const double dr = alpha.x - R.beta, di = alpha.y;  // 1 / (alpha - beta)
     const double den = dr * dr + di * di;
-    scal = make_double2(dr / den, -di / den);
+    R.scal = make_double2(dr / den, -di / den);
   }
-  __syncthreads();
-  cplx* vt = M.Vt + (size_t)k * n;
-  for (int i = tid; i < n; i += 256) {
-    cplx v;
-    if (i <= k) v = make_double2(0.0, 0.0);
-    else if (i == k + 1) v = make_double2(1.0, 0.0);
-    else v = cmul(vrow[i], scal);
-    vrow[i] = v;
-    vt[i] = v;
-  }
-  if (tid == 0) {
-    M.e[k] = beta;
-    M.tau[k] = tau;
-  }
+  return R;
 }
 
-// ---- T1b: p[i] = sum_c A[i][c] v[c], rows and columns > k; one wave per row ---------------
-__global__ __launch_bounds__(256) void trd_hemv_kernel(const trd_mat* __restrict__ ms, int k, int j) {
+// v[c] for c > k (v[k+1] = 1, the rest is the scaled column)
+__device__ __forceinline__ cplx trd_v_at(const trd_mat& M, const trd_refl& R, int k, int c) {
+  const cplx t = cmul(M.x[c], R.scal);
+  return c == k + 1 ? make_double2(1.0, 0.0) : t;
+}
+
+__global__ __launch_bounds__(256) void trd_symv_kernel(const trd_mat* __restrict__ ms, int k, int j) {
   const trd_mat M = ms[blockIdx.y];
   const int n = M.n;
   if (k >= n - 1) return;
   const int lane = threadIdx.x & 63;
-  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const cplx* __restrict__ v = M.Vp + (size_t)j * n;
-  if (slot < 2 * j) {
-    // panel dot products a[q] = W_q^H v, b[q] = V_q^H v (needed by trd_w): ride along with the HEMV
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: row bases stay in SGPRs
+  const trd_refl R = trd_reflector(M, k);
+  const int nslotblk = (2 * j + 3) / 4;
+  if ((int)blockIdx.x < nslotblk) {
+    // panel dot products a[q] = W_q^H v, b[q] = V_q^H v (needed by trd_wx): one wave each
+    const int slot = blockIdx.x * 4 + wave;
+    if (slot >= 2 * j) return;
     const cplx* x = (slot < j ? M.Wp + (size_t)slot * n : M.Vp + (size_t)(slot - j) * n);
     double sr = 0.0, si = 0.0;
     for (int i = k + 1 + lane; i < n; i += 64) {
-      cplx xx = x[i], vv = v[i];  // conj(x) * v
+      const cplx xx = x[i], vv = trd_v_at(M, R, k, i);  // conj(x) * v
       sr += xx.x * vv.x + xx.y * vv.y;
       si += xx.x * vv.y - xx.y * vv.x;
     }
@@ -131,75 +124,354 @@ __global__ __launch_bounds__(256) void trd_hemv_kernel(const trd_mat* __restrict
     if (lane == 0) M.ab[slot] = make_double2(sr, si);
     return;
   }
-  const int row = k + 1 + (slot - 2 * j);
-  if (row >= n) return;
-  const cplx* __restrict__ a = M.A + (size_t)row * M.lda;
-  double sr = 0.0, si = 0.0;
-  for (int c = k + 1 + lane; c < n; c += 64) {
-    cplx x = a[c], y = v[c];
-    sr += x.x * y.x - x.y * y.y;
-    si += x.x * y.y + x.y * y.x;
-  }
-  sr = dm_wave_sum(sr);
-  si = dm_wave_sum(si);
-  if (lane == 0) M.p[row] = make_double2(sr, si);
-}
+  // ---- a workgroup owns SYG = 4 SYR consecutive rows; its four waves walk the same 64-column
+  // chunks (starting at the group's first row) so that the mirrored column sums of the whole
+  // group can be folded through LDS into ONE partial row Pc[g][:]
+  const int g = blockIdx.x - nslotblk;
+  const int R0 = k + 1 + SYG * g;
+  if (R0 >= n) return;
+  __shared__ cplx colbuf[2][4][64];
+  __shared__ double sbuf[4];
+  const int rstart = R0 + SYR * wave;
+  const int dl = SYR * wave;  // lane of this wave's first diagonal element in chunk 0
+  const cplx* __restrict__ A = M.A;
+  const size_t lda = M.lda;
+  cplx* __restrict__ pc = M.Pc + (size_t)g * n;
+  const cplx zero = make_double2(0.0, 0.0);
 
-// ---- T1c: panel corrections and w -------------------------------------------------------
-__device__ __forceinline__ void trd_w_body(const trd_mat& M, int k, int j) {
-  const int n = M.n;
-  if (k >= n - 1) return;
-  __shared__ cplx sa[TNB], sb[TNB];  // a = W^H v, b = V^H v
-  __shared__ double redr[4], redi[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const cplx* __restrict__ v = M.Vp + (size_t)j * n;
-  if (tid < 2 * j) {
-    if (tid < j) sa[tid] = M.ab[tid]; else sb[tid - j] = M.ab[tid];
-  }
-  __syncthreads();
-  const cplx tau = M.tau[k];
-  cplx* w = M.Wp + (size_t)j * n;
-  // p <- tau * (p_raw - V a - W b);  accumulate p^H v
-  double dr = 0.0, di = 0.0;
-  for (int i = tid; i < n; i += 256) {
-    cplx pv = make_double2(0.0, 0.0);
-    if (i > k) {
-      pv = M.p[i];
-      for (int jj = 0; jj < j; ++jj) {
-        pv = csub(pv, cmul(M.Vp[(size_t)jj * n + i], sa[jj]));
-        pv = csub(pv, cmul(M.Wp[(size_t)jj * n + i], sb[jj]));
-      }
-      pv = cmul(tau, pv);
-      cplx vv = v[i];  // conj(p) * v
-      dr += pv.x * vv.x + pv.y * vv.y;
-      di += pv.x * vv.y - pv.y * vv.x;
+  // Loads always hit a valid address (indices clamped) and are masked afterwards, so the row
+  // loads of a chunk are issued back to back instead of one branch each.
+  int c = R0 + lane;
+  bool valid = c < n;
+  int cc = min(c, n - 1);
+  const cplx vc0t = trd_v_at(M, R, k, cc);
+  const cplx vc0 = valid ? vc0t : zero;
+  if (wave == 0) {
+    if (lane < SYG && valid) {
+      M.Vp[(size_t)j * n + c] = vc0;
+      M.Vp2[(size_t)j * n + c] = vc0;
+      M.Vt[(size_t)k * n + c] = vc0;
     }
-    w[i] = pv;
+    if (g == 0 && lane == 0) {
+      M.e[k] = R.beta;
+      M.tau[k] = R.tau;
+    }
   }
-  dr = dm_wave_sum(dr);
-  di = dm_wave_sum(di);
-  if (lane == 0) { redr[wave] = dr; redi[wave] = di; }
+  cplx vr[SYR];
+#pragma unroll
+  for (int rr = 0; rr < SYR; ++rr) vr[rr] = make_double2(__shfl(vc0.x, dl + rr, 64), __shfl(vc0.y, dl + rr, 64));
+  double acc[2 * SYR];
+#pragma unroll
+  for (int q = 0; q < 2 * SYR; ++q) acc[q] = 0.0;
+  double adiag = 0.0;
+  int t = 0;
+  {
+    cplx a[SYR];
+#pragma unroll
+    for (int rr = 0; rr < SYR; ++rr) {
+      const int r = rstart + rr;
+      const cplx v = A[(size_t)min(r, n - 1) * lda + cc];
+      a[rr] = (valid && r < n && c >= r) ? v : zero;
+    }
+    cplx col = zero;
+#pragma unroll
+    for (int rr = 0; rr < SYR; ++rr) {
+      if (lane == dl + rr) adiag = a[rr].x;
+      acc[2 * rr] += a[rr].x * vc0.x - a[rr].y * vc0.y;
+      acc[2 * rr + 1] += a[rr].x * vc0.y + a[rr].y * vc0.x;
+      if (lane > dl + rr) {  // strictly above the diagonal: mirrored contribution conj(a) * v[r]
+        col.x += a[rr].x * vr[rr].x + a[rr].y * vr[rr].y;
+        col.y += a[rr].x * vr[rr].y - a[rr].y * vr[rr].x;
+      }
+    }
+    colbuf[0][wave][lane] = col;
+    __syncthreads();
+    if (wave == 0 && valid)
+      pc[c] = cadd(cadd(colbuf[0][0][lane], colbuf[0][1][lane]), cadd(colbuf[0][2][lane], colbuf[0][3][lane]));
+    t = 1;
+  }
+#pragma unroll 1
+  for (int c0 = R0 + 64; c0 < n; c0 += 64, ++t) {
+    c = c0 + lane;
+    valid = c < n;
+    cc = min(c, n - 1);
+    const cplx vct = trd_v_at(M, R, k, cc);
+    const cplx vc = valid ? vct : zero;
+    cplx a[SYR];
+#pragma unroll
+    for (int rr = 0; rr < SYR; ++rr) {
+      const int r = rstart + rr;
+      const cplx v = A[(size_t)min(r, n - 1) * lda + cc];
+      a[rr] = (valid && r < n) ? v : zero;
+    }
+    cplx col = zero;
+#pragma unroll
+    for (int rr = 0; rr < SYR; ++rr) {
+      acc[2 * rr] += a[rr].x * vc.x - a[rr].y * vc.y;
+      acc[2 * rr + 1] += a[rr].x * vc.y + a[rr].y * vc.x;
+      col.x += a[rr].x * vr[rr].x + a[rr].y * vr[rr].y;
+      col.y += a[rr].x * vr[rr].y - a[rr].y * vr[rr].x;
+    }
+    const int pb = t & 1;  // double buffer: the reader of chunk t-1 may still be summing
+    colbuf[pb][wave][lane] = col;
+    __syncthreads();
+    if (wave == (t & 3) && valid)
+      pc[c] = cadd(cadd(colbuf[pb][0][lane], colbuf[pb][1][lane]), cadd(colbuf[pb][2][lane], colbuf[pb][3][lane]));
+  }
+  // Transposing butterfly: the 2 SYR per-lane partial sums are folded so that lane L ends up with
+  // the wave total of entry L / PER (2 SYR + log2(PER) shuffles instead of 2 SYR full reductions).
+  constexpr int PER = 64 / (2 * SYR);
+#pragma unroll
+  for (int o = 32, cnt = 2 * SYR; cnt > 1; o >>= 1, cnt >>= 1) {
+    const bool lo = (lane & o) == 0;
+    const int h = cnt >> 1;
+#pragma unroll
+    for (int q = 0; q < h; ++q) {
+      const double send = lo ? acc[q + h] : acc[q];
+      const double keep = lo ? acc[q] : acc[q + h];
+      acc[q] = keep + __shfl_xor(send, o, 64);
+    }
+  }
+  double tot = acc[0];
+#pragma unroll
+  for (int o = PER / 2; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+  const double tim = __shfl_down(tot, PER, 64);  // lane 2 PER rr: tot = re, tim = im of row rr
+  const int rr = lane / (2 * PER);
+  const double vrx = __shfl(vc0.x, dl + rr, 64), vry = __shfl(vc0.y, dl + rr, 64), ad = __shfl(adiag, dl + rr, 64);
+  double s = 0.0;
+  if (lane % (2 * PER) == 0 && rstart + rr < n) {
+    M.p[rstart + rr] = make_double2(tot, tim);
+    s = 2.0 * (vrx * tot + vry * tim) - ad * (vrx * vrx + vry * vry);  // v^H A v, upper storage
+  }
+  s = dm_wave_sum(s);
+  if (lane == 0) sbuf[wave] = s;
   __syncthreads();
-  const cplx dot = make_double2(redr[0] + redr[1] + redr[2] + redr[3], redi[0] + redi[1] + redi[2] + redi[3]);
-  // w = p - (tau/2) (p^H v) v
-  const cplx coef = cscale(cmul(tau, dot), 0.5);
-  for (int i = k + 1 + tid; i < n; i += 256) w[i] = csub(w[i], cmul(coef, v[i]));
+  if (threadIdx.x == 0) M.Sp[g] = (sbuf[0] + sbuf[1]) + (sbuf[2] + sbuf[3]);
 }
 
-__global__ __launch_bounds__(256) void trd_col_kernel(const trd_mat* __restrict__ ms, int k, int j) {
-  trd_col_body(ms[blockIdx.x], k, j);
-}
-__global__ __launch_bounds__(256) void trd_w_kernel(const trd_mat* __restrict__ ms, int k, int j) {
-  trd_w_body(ms[blockIdx.x], k, j);
-}
-// w of column k followed by the Householder vector of column k+1 (same panel): one launch less
-// on the latency-bound critical path of the tridiagonalisation.
-__global__ __launch_bounds__(256) void trd_wcol_kernel(const trd_mat* __restrict__ ms, int k, int j) {
-  const trd_mat M = ms[blockIdx.x];
-  trd_w_body(M, k, j);
-  __threadfence_block();
+__global__ __launch_bounds__(WXR) void trd_wx_kernel(const trd_mat* __restrict__ ms, int k, int j, int do_w, int do_x) {
+  const trd_mat M = ms[blockIdx.y];
+  const int n = M.n;
+  const bool w_on = do_w && k < n - 1;
+  const int kx = do_w ? k + 1 : k;  // column whose x is formed; also the first row handled
+  const bool x_on = do_x && kx < n;
+  if (!w_on && !x_on) return;
+  if (kx + (int)blockIdx.x * WXR >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = kx + blockIdx.x * WXR + tid;
+  const int npan = do_w ? j : 0;  // finished panel vectors
+  __shared__ cplx sa[TNB], sb[TNB], swk[TNB], svk[TNB];
+  __shared__ double s_coef, s_part[WXR / 64];
+  __shared__ cplx s_wk1;
+  if (tid < npan) {
+    sa[tid] = M.ab[tid];
+    sb[tid] = M.ab[j + tid];
+    if (x_on) {
+      swk[tid] = M.Wp[(size_t)tid * n + kx];
+      svk[tid] = M.Vp[(size_t)tid * n + kx];
+    }
+  }
   __syncthreads();
-  trd_col_body(M, k + 1, j + 1);
+  cplx tau = make_double2(0.0, 0.0), wk1 = make_double2(0.0, 0.0);
+  double coef = 0.0;
+  if (w_on) {
+    tau = M.tau[k];
+    if (wave == 0) {
+      const int ng = (n - k - 1 + SYG - 1) / SYG;
+      double s = 0.0, ab = 0.0, cr = 0.0, ci = 0.0;
+      for (int t = lane; t < ng; t += 64) s += M.Sp[t];
+      for (int t = lane; t < npan; t += 64) {
+        ab += sa[t].x * sb[t].x + sa[t].y * sb[t].y;  // Re(conj(a) b)
+        if (x_on) {
+          const cplx u = cadd(cmul(svk[t], sa[t]), cmul(swk[t], sb[t]));
+          cr += u.x;
+          ci += u.y;
+        }
+      }
+      s = dm_wave_sum(s);
+      ab = dm_wave_sum(ab);
+      cr = dm_wave_sum(cr);
+      ci = dm_wave_sum(ci);
+      if (lane == 0) {
+        // p^H v = conj(tau) (v^H A v - a^H b - b^H a)  (real);  coef = (tau/2) p^H v
+        const double c0 = 0.5 * (tau.x * tau.x + tau.y * tau.y) * (s - 2.0 * ab);
+        s_coef = c0;
+        if (x_on) {  // w_k[k+1]: the mirrored part of p vanishes on the first trailing row
+          const cplx q = csub(M.p[kx], make_double2(cr, ci));
+          cplx w1 = cmul(tau, q);
+          w1.x -= c0;
+          s_wk1 = w1;
+        }
+      }
+    }
+    __syncthreads();
+    coef = s_coef;
+    wk1 = s_wk1;
+  }
+  double part = 0.0;
+  if (i < n) {
+    cplx q = make_double2(0.0, 0.0), vv = make_double2(0.0, 0.0), xacc = make_double2(0.0, 0.0);
+    if (w_on) {
+      q = M.p[i];
+      const int gi = (i - k - 1) / SYG;
+      const cplx* __restrict__ pc = M.Pc + i;
+#pragma unroll 4
+      for (int g = 0; g <= gi; ++g) q = cadd(q, pc[(size_t)g * n]);
+      vv = M.Vp[(size_t)j * n + i];
+    }
+    const cplx* __restrict__ vp = M.Vp + i;
+    const cplx* __restrict__ wp = M.Wp + i;
+#pragma unroll 4
+    for (int jj = 0; jj < npan; ++jj) {
+      const cplx vji = vp[(size_t)jj * n], wji = wp[(size_t)jj * n];
+      q = csub(q, cadd(cmul(vji, sa[jj]), cmul(wji, sb[jj])));
+      if (x_on) xacc = csub(xacc, cadd(cmulc(vji, swk[jj]), cmulc(wji, svk[jj])));
+    }
+    cplx wv = make_double2(0.0, 0.0);
+    if (w_on) {
+      wv = cmul(tau, q);
+      wv.x -= coef * vv.x;
+      wv.y -= coef * vv.y;
+      M.Wp[(size_t)j * n + i] = wv;
+    }
+    if (x_on) {
+      const cplx a = M.A[(size_t)kx * M.lda + i];
+      cplx xx = make_double2(a.x + xacc.x, -a.y + xacc.y);
+      if (w_on) xx = csub(xx, cadd(cmulc(vv, wk1), wv));  // panel vector j: V[j][kx] = 1
+      M.x[i] = xx;
+      if (i == kx) M.d[kx] = xx.x;
+      if (i > kx + 1) part = cabs2(xx);
+    }
+  }
+  if (x_on) {
+    part = dm_wave_sum(part);
+    if (lane == 0) s_part[wave] = part;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < WXR / 64; ++w) t += s_part[w];
+      M.Np[blockIdx.x] = t;
+    }
+  }
+}
+
+// ---- T1 for small matrices (n <= TSM): the whole reduction in one launch, one workgroup per
+// matrix with the matrix resident in LDS (96 x 97 complex = 146 KB of the 160 KB).  Same
+// recurrences and conventions as the panel path with a panel of one vector (zhetd2): the
+// Gram-matrix eigenproblems of the SVD preconditioner (n <= ntel, thousands per launch) would
+// otherwise pay 2 n latency-bound launches for a few hundred KB of work.
+constexpr int TSM = 96;
+constexpr int TSP = TSM + 1;  // row pitch in complex elements: conflict-free column walks
+
+__global__ __launch_bounds__(256) void trd_small_kernel(const trd_mat* __restrict__ ms) {
+  const trd_mat M = ms[blockIdx.x];
+  const int n = M.n;
+  if (n <= 0) return;
+  extern __shared__ __align__(16) unsigned char trd_smem[];
+  cplx* As = reinterpret_cast<cplx*>(trd_smem);          // TSM x TSP
+  cplx* vs = As + TSM * TSP;                              // TSM
+  cplx* ws = vs + TSM;                                    // TSM
+  cplx* ph = ws + TSM;                                    // 2 x TSM partial matvec
+  double* red = reinterpret_cast<double*>(ph + 2 * TSM);  // 8
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the upper triangle is the reference (as in the panel path); mirror it
+  for (int idx = tid; idx < n * n; idx += 256) {
+    const int r = idx / n, c = idx - r * n;
+    if (c >= r) {
+      const cplx a = M.A[(size_t)r * M.lda + c];
+      As[r * TSP + c] = (c == r) ? make_double2(a.x, 0.0) : a;
+      if (c > r) As[c * TSP + r] = make_double2(a.x, -a.y);
+    }
+  }
+  __syncthreads();
+  const int r2 = tid % TSM, half = tid / TSM;  // matvec: two threads per row (tid < 2 TSM)
+  for (int k = 0; k < n - 1; ++k) {
+    // --- Householder vector of column k: x_i = conj(A[k][i]), i > k
+    cplx xi = make_double2(0.0, 0.0);
+    double part = 0.0;
+    if (tid < n && tid > k) {
+      const cplx a = As[k * TSP + tid];
+      xi = make_double2(a.x, -a.y);
+      if (tid > k + 1) part = cabs2(xi);
+    }
+    part = dm_wave_sum(part);
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    const double xnorm2 = (red[0] + red[1]) + (red[2] + red[3]);
+    const cplx al = As[k * TSP + k + 1];
+    const cplx alpha = make_double2(al.x, -al.y);
+    double beta;
+    cplx tau, scal;
+    if (xnorm2 == 0.0 && alpha.y == 0.0) {
+      tau = make_double2(0.0, 0.0);
+      beta = alpha.x;
+      scal = make_double2(0.0, 0.0);
+    } else {
+      beta = -copysign(sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xnorm2), alpha.x);
+      tau = make_double2((beta - alpha.x) / beta, -alpha.y / beta);
+      const double dr = alpha.x - beta, di = alpha.y;
+      const double den = dr * dr + di * di;
+      scal = make_double2(dr / den, -di / den);
+    }
+    cplx vi = make_double2(0.0, 0.0);
+    if (tid < n) {
+      if (tid == k + 1) vi = make_double2(1.0, 0.0);
+      else if (tid > k + 1) vi = cmul(xi, scal);
+      vs[tid] = vi;
+      if (tid > k) M.Vt[(size_t)k * n + tid] = vi;
+    }
+    if (tid == 0) {
+      M.d[k] = As[k * TSP + k].x;
+      M.e[k] = beta;
+      M.tau[k] = tau;
+    }
+    __syncthreads();
+    // --- p = A v over the trailing block (two half-rows per row)
+    if (tid < 2 * TSM && r2 < n && r2 > k) {
+      const int h0 = half ? (k + 1 + n + 1) / 2 : k + 1, h1 = half ? n : (k + 1 + n + 1) / 2;
+      double pr = 0.0, pi = 0.0;
+      const cplx* arow = As + r2 * TSP;
+      for (int c = h0; c < h1; ++c) {
+        const cplx a = arow[c], v = vs[c];
+        pr += a.x * v.x - a.y * v.y;
+        pi += a.x * v.y + a.y * v.x;
+      }
+      ph[half * TSM + r2] = make_double2(pr, pi);
+    }
+    __syncthreads();
+    cplx pt = make_double2(0.0, 0.0);
+    double dr = 0.0, di = 0.0;
+    if (tid < n && tid > k) {
+      pt = cmul(tau, cadd(ph[tid], ph[TSM + tid]));
+      dr = pt.x * vi.x + pt.y * vi.y;  // conj(p) * v
+      di = pt.x * vi.y - pt.y * vi.x;
+    }
+    dr = dm_wave_sum(dr);
+    di = dm_wave_sum(di);
+    if (lane == 0) { red[4 + wave] = dr; red[8 + wave] = di; }
+    __syncthreads();
+    const cplx dot = make_double2((red[4] + red[5]) + (red[6] + red[7]), (red[8] + red[9]) + (red[10] + red[11]));
+    const cplx coef = cscale(cmul(tau, dot), 0.5);
+    if (tid < n) ws[tid] = tid > k ? csub(pt, cmul(coef, vi)) : make_double2(0.0, 0.0);
+    __syncthreads();
+    // --- A -= v w^H + w v^H on the trailing block (full storage keeps the matvec simple)
+    {
+      const int tx = tid & 31, ty = tid >> 5;
+      for (int i = k + 1 + ty; i < n; i += 8) {
+        const cplx v_i = vs[i], w_i = ws[i];
+        cplx* arow = As + i * TSP;
+        for (int c = k + 1 + tx; c < n; c += 32) {
+          const cplx u = cadd(cmulc(v_i, ws[c]), cmulc(w_i, vs[c]));
+          cplx a = arow[c];
+          a.x -= u.x;
+          a.y -= u.y;
+          arow[c] = a;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) M.d[n - 1] = As[(n - 1) * TSP + n - 1].x;
 }
 
 // ---- T2: implicit QL/QR on the tridiagonal (LAPACK dsteqr scheme), recording rotations ------
@@ -1160,9 +1432,21 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
 
   // ---- storage for every problem (all chunks are in flight at once)
   cplx* Vt = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(tot, 1));
-  cplx* Vp = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * TNB, 1));
-  cplx* Wp = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * TNB, 1));
+  // panels: per problem 3 TNB rows of n: V, W, V again (see trd_mat)
+  cplx* PP = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * 3 * TNB, 1));
   cplx* pv = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn, 1));
+  cplx* xv = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn, 1));
+  size_t totpc = 0, totsp = 0, totnp = 0;
+  std::vector<size_t> offpc(np), offsp(np), offnp(np);
+  for (int p = 0; p < np; ++p) {
+    const size_t n = probs[p].n;
+    offpc[p] = totpc; totpc += (n / SYG + 1) * n;
+    offsp[p] = totsp; totsp += n / SYG + 1;
+    offnp[p] = totnp; totnp += n / WXR + 1;
+  }
+  cplx* Pcv = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totpc, 1));
+  double* Spv = dm_ws_alloc_t<double>(ctx, std::max<size_t>(totsp, 1));
+  double* Npv = dm_ws_alloc_t<double>(ctx, std::max<size_t>(totnp, 1));
   cplx* abv = dm_ws_alloc_t<cplx>(ctx, (size_t)np * 2 * TNB);
   double* dd = dm_ws_alloc_t<double>(ctx, std::max<size_t>(totn, 1));
   double* ee = dm_ws_alloc_t<double>(ctx, std::max<size_t>(totn, 1));
@@ -1186,11 +1470,11 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
   cplx* Tb = dm_ws_alloc_t<cplx>(ctx, (size_t)np * TNB * TNB);
   cplx* W1 = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * TNB, 1));
   cplx* W2 = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * TNB, 1));
-  if (!Vt || !Vp || !Wp || !pv || !abv || !dd || !ee || !tau || !sw_dir || !sw_lo || !sw_cnt || !sw_off || !rot || !nsw ||
+  if (!Vt || !PP || !pv || !xv || !Pcv || !Spv || !Npv || !abv || !dd || !ee || !tau || !sw_dir || !sw_lo || !sw_cnt || !sw_off || !rot || !nsw ||
       !stat || !Zt || !Gb || !Tb || !W1 || !W2)
     return DM_ENOMEM;
-  DM_TRY(dm_fill_zero(ctx, Vp, sizeof(cplx) * totn * TNB));
-  DM_TRY(dm_fill_zero(ctx, Wp, sizeof(cplx) * totn * TNB));
+  DM_TRY(dm_fill_zero(ctx, PP, sizeof(cplx) * totn * 3 * TNB));
+  DM_TRY(dm_fill_zero(ctx, Vt, sizeof(cplx) * tot));  // trd_symv only writes the non-zero part of each vector
   DM_TRY(dm_fill_zero(ctx, tau, sizeof(cplx) * totn));
   DM_TRY(dm_fill_zero(ctx, stat, sizeof(int) * np));
 
@@ -1226,52 +1510,59 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
     for (int i = 0; i < nc; ++i) {
       const int p = ch[i];
       cmax = std::max(cmax, probs[p].n);
-      tm[i] = trd_mat{probs[p].C, probs[p].ldc, probs[p].n, Vt + off[p], Vp + offn[p] * TNB, Wp + offn[p] * TNB,
-                      pv + offn[p], abv + (size_t)p * 2 * TNB, dd + offn[p], ee + offn[p], tau + offn[p]};
+      cplx* pp = PP + offn[p] * 3 * TNB;
+      const size_t n = probs[p].n;
+      tm[i] = trd_mat{probs[p].C, probs[p].ldc, probs[p].n, Vt + off[p], pp, pp + n * TNB, pp + 2 * n * TNB,
+                      xv + offn[p], pv + offn[p], Pcv + offpc[p], Spv + offsp[p], Npv + offnp[p],
+                      abv + (size_t)p * 2 * TNB, dd + offn[p], ee + offn[p], tau + offn[p]};
     }
     trd_mat* d_tm = dm_ws_upload(ctx, tm);
     if (!d_tm) return DM_ENOMEM;
+    if (cmax <= TSM && !getenv("DM_TRD_NOSMALL")) {
+      const size_t lds = sizeof(cplx) * (TSM * TSP + 4 * TSM) + sizeof(double) * 16;
+      static bool attr = false;
+      if (!attr) {
+        DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(trd_small_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+      }
+      hipLaunchKernelGGL(trd_small_kernel, dim3(nc), dim3(256), lds, ctx->stream, d_tm);
+      DM_HIP(ctx, hipGetLastError());
+      return DM_OK;
+    }
     for (int k0 = 0; k0 < cmax; k0 += TNB) {
       const int k1 = std::min(k0 + TNB, cmax);
-      hipLaunchKernelGGL(trd_col_kernel, dim3(nc), dim3(256), 0, ctx->stream, d_tm, k0, 0);
+      // first column of the panel: plain row of the (just updated) matrix
+      hipLaunchKernelGGL(trd_wx_kernel, dim3((cmax - k0 + WXR - 1) / WXR, nc), dim3(WXR), 0, ctx->stream, d_tm, k0, 0,
+                         0, 1);
       for (int k = k0; k < k1; ++k) {
         const int j = k - k0;
         if (k < cmax - 1) {
-          const int rt = (cmax - k - 1 + 2 * j + 3) / 4;
-          hipLaunchKernelGGL(trd_hemv_kernel, dim3(rt, nc), dim3(256), 0, ctx->stream, d_tm, k, j);
-          if (k + 1 < k1)
-            hipLaunchKernelGGL(trd_wcol_kernel, dim3(nc), dim3(256), 0, ctx->stream, d_tm, k, j);
-          else
-            hipLaunchKernelGGL(trd_w_kernel, dim3(nc), dim3(256), 0, ctx->stream, d_tm, k, j);
+          const int ng = (cmax - k - 1 + SYG - 1) / SYG;
+          hipLaunchKernelGGL(trd_symv_kernel, dim3((2 * j + 3) / 4 + ng, nc), dim3(256), 0, ctx->stream, d_tm, k, j);
+          hipLaunchKernelGGL(trd_wx_kernel, dim3((cmax - k - 1 + WXR - 1) / WXR, nc), dim3(WXR), 0, ctx->stream, d_tm,
+                             k, j, 1, k + 1 < k1 ? 1 : 0);
         }
       }
       if (k1 < cmax) {
-        for (int pass = 0; pass < 2; ++pass) {
-          std::vector<dm_gemm_desc> g;
-          for (int p : ch) {
-            const int n = probs[p].n;
-            const int rem = n - k1;
-            if (rem <= 0) continue;
-            const int kb = std::min(k1, n - 1) - k0;
-            if (kb <= 0) continue;
-            const cplx* Vb = Vp + offn[p] * TNB + k1;
-            const cplx* Wb = Wp + offn[p] * TNB + k1;
-            const cplx* Aop = pass == 0 ? Vb : Wb;
-            const cplx* Bop = pass == 0 ? Wb : Vb;
-            g.push_back(dm_gemm_make(Aop, 1, n, false, Bop, n, 1, true, probs[p].C + (size_t)k1 * probs[p].ldc + k1,
-                                     probs[p].ldc, rem, rem, kb, -1.0, 1.0));
-          }
-          DM_TRY(dm_gemm_grouped_launch(ctx, g));
+        // her2k on the upper triangle in one pass: C -= [V W] [W V]^H  (K = 2 TNB; unused panel rows are zero)
+        std::vector<dm_gemm_desc> g;
+        for (int p : ch) {
+          const int n = probs[p].n;
+          const int rem = n - k1;
+          if (rem <= 0) continue;
+          const cplx* pp = PP + offn[p] * 3 * TNB;
+          g.push_back(dm_gemm_make(pp + k1, 1, n, false, pp + (size_t)n * TNB + k1, n, 1, true,
+                                   probs[p].C + (size_t)k1 * probs[p].ldc + k1, probs[p].ldc, rem, rem, 2 * TNB, -1.0,
+                                   1.0, nullptr, DM_GEMM_UPPER));
         }
+        DM_TRY(dm_gemm_grouped_launch(ctx, g));
         // next panel starts from clean V, W
         if ((int)ch.size() == np) {
-          DM_TRY(dm_fill_zero(ctx, Vp, sizeof(cplx) * totn * TNB));
-          DM_TRY(dm_fill_zero(ctx, Wp, sizeof(cplx) * totn * TNB));
+          DM_TRY(dm_fill_zero(ctx, PP, sizeof(cplx) * totn * 3 * TNB));
         } else {
-          for (int p : ch) {
-            DM_TRY(dm_fill_zero(ctx, Vp + offn[p] * TNB, sizeof(cplx) * (size_t)probs[p].n * TNB));
-            DM_TRY(dm_fill_zero(ctx, Wp + offn[p] * TNB, sizeof(cplx) * (size_t)probs[p].n * TNB));
-          }
+          for (int p : ch)
+            DM_TRY(dm_fill_zero(ctx, PP + offn[p] * 3 * TNB, sizeof(cplx) * (size_t)probs[p].n * 3 * TNB));
         }
       }
     }
