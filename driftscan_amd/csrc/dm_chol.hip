@@ -264,26 +264,33 @@ int dm_trsm_left_lower_batched(dm_ctx* ctx, const std::vector<dm_trsm_problem>& 
   const int nblk = (maxn + NB2 - 1) / NB2;   // 64-row super blocks
   const int nblk32 = (maxn + NB - 1) / NB;   // the substitution kernels still count 32-row blocks
   for (int s = 0; s < nblk; ++s) {
-    // (1) one GEMM brings in everything outside the 64-row super block (full 64x64 MFMA tiles)
+    // (1) GEMM updates in the order of the recursive algorithm (solve the first half, update the
+    // second half with ONE product, solve the second half), unrolled: before super block u is
+    // solved, the 2^ctz(u) blocks starting at u receive the contribution of the 2^ctz(u) blocks
+    // solved just before.  Same flops as the left-looking sweep, but half of them sit in one
+    // (n/2 x nrhs x n/2) product, a quarter in two (n/4 x nrhs x n/4) products, ... instead of
+    // n/64 skinny 64-row products with K up to n.
     std::vector<dm_gemm_desc> g;
     for (int i = 0; i < nbatch; ++i) {
       const dm_trsm_problem& P = probs[i];
       const int pn = (P.n + NB2 - 1) / NB2;
       if (!conjtrans) {
-        const int k0 = s * NB2;
-        if (k0 >= P.n || k0 == 0) continue;
-        const int nb = std::min(NB2, P.n - k0);
-        g.push_back(dm_gemm_make(P.L + (size_t)k0 * P.ldl, P.ldl, 1, false, P.B, P.ldb, 1, false,
-                                 P.B + (size_t)k0 * P.ldb, P.ldb, nb, P.nrhs, k0, -1.0, 1.0));
+        if (s == 0 || s >= pn) continue;
+        const int size = s & -s;                  // 2^ctz(s)
+        const int r0 = s * NB2, r1 = std::min((s + size) * NB2, P.n);
+        const int c0 = (s - size) * NB2;
+        g.push_back(dm_gemm_make(P.L + (size_t)r0 * P.ldl + c0, P.ldl, 1, false, P.B + (size_t)c0 * P.ldb, P.ldb, 1,
+                                 false, P.B + (size_t)r0 * P.ldb, P.ldb, r1 - r0, P.nrhs, size * NB2, -1.0, 1.0));
       } else {
         if (s < nblk - pn) continue;  // smaller problems start later so that all finish together
-        const int kb = pn - 1 - (s - (nblk - pn));
-        const int k0 = kb * NB2;
-        const int nb = std::min(NB2, P.n - k0);
-        const int k1 = k0 + nb;
-        if (k1 >= P.n) continue;
-        g.push_back(dm_gemm_make(P.L + (size_t)k1 * P.ldl + k0, 1, P.ldl, true, P.B + (size_t)k1 * P.ldb, P.ldb, 1,
-                                 false, P.B + (size_t)k0 * P.ldb, P.ldb, nb, P.nrhs, P.n - k1, -1.0, 1.0));
+        const int u = s - (nblk - pn);
+        if (u == 0) continue;
+        const int kb = pn - 1 - u;
+        const int size = u & -u;
+        const int t0 = std::max(kb - size + 1, 0) * NB2, t1 = (kb + 1) * NB2;  // target rows
+        const int k1 = t1, k2 = std::min((kb + 1 + size) * NB2, P.n);         // rows solved just before
+        g.push_back(dm_gemm_make(P.L + (size_t)k1 * P.ldl + t0, 1, P.ldl, true, P.B + (size_t)k1 * P.ldb, P.ldb, 1,
+                                 false, P.B + (size_t)t0 * P.ldb, P.ldb, t1 - t0, P.nrhs, k2 - k1, -1.0, 1.0));
       }
     }
     DM_TRY(dm_gemm_grouped_launch(ctx, g));

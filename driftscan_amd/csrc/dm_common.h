@@ -116,6 +116,28 @@ static inline T* dm_ws_upload(dm_ctx* ctx, const std::vector<T>& v) {
 
 typedef double dm_f64x4 __attribute__((ext_vector_type(4)));
 
+// Pointers that come out of descriptor structs are generic to the compiler, which then emits
+// flat_load/flat_store; those count on LGKM as well as VM, so every LDS wait (lgkmcnt) also
+// drains the global loads in flight and prefetching stops overlapping.  Going through the
+// global address space gives global_load/global_store (VM counter only).
+typedef double dm_d2 __attribute__((ext_vector_type(2)));
+typedef const dm_d2 __attribute__((address_space(1)))* dm_gd2_c;
+typedef dm_d2 __attribute__((address_space(1)))* dm_gd2;
+typedef const double __attribute__((address_space(1)))* dm_gd_c;
+typedef double __attribute__((address_space(1)))* dm_gd;
+__device__ __forceinline__ cplx dm_ldg(const cplx* p, size_t i = 0) {
+  const dm_d2 v = ((dm_gd2_c)p)[i];
+  return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ double dm_ldg(const double* p, size_t i = 0) { return ((dm_gd_c)p)[i]; }
+__device__ __forceinline__ void dm_stg(cplx* p, size_t i, cplx v) {
+  dm_d2 t;
+  t.x = v.x;
+  t.y = v.y;
+  ((dm_gd2)p)[i] = t;
+}
+__device__ __forceinline__ void dm_stg(double* p, size_t i, double v) { ((dm_gd)p)[i] = v; }
+
 // v_mfma_f64_16x16x4_f64: D(16x16) += A(16x4) * B(4x16), one f64 per lane for A and B.
 //   A: lane l holds A[i = l & 15][k = l >> 4]
 //   B: lane l holds B[k = l >> 4][j = l & 15]

@@ -76,9 +76,9 @@ __global__ __launch_bounds__(256) void zgemm_grouped_kernel(const dm_gemm_desc* 
       int gm = m0 + m, gk = k0 + k;
       cplx v = make_double2(0.0, 0.0);
       if (gm < d.M && gk < d.K) {
-        v = A[(size_t)gm * d.rsA + (size_t)gk * d.csA];
+        v = dm_ldg(A, (size_t)gm * d.rsA + (size_t)gk * d.csA);
         if (conjA) v.y = -v.y;
-        if (d.kscale) { double s = d.kscale[gk]; v.x *= s; v.y *= s; }
+        if (d.kscale) { double s = dm_ldg(d.kscale, gk); v.x *= s; v.y *= s; }
       }
       ra[i] = v;
     }
@@ -92,9 +92,9 @@ __global__ __launch_bounds__(256) void zgemm_grouped_kernel(const dm_gemm_desc* 
       if (gn < d.N && gk < d.K) {
         size_t off = (size_t)gk * d.rsB + (size_t)gn * d.csB;
         if (B_REAL) {
-          v.x = Br[off];
+          v.x = dm_ldg(Br, off);
         } else {
-          v = Bc[off];
+          v = dm_ldg(Bc, off);
           if (conjB) v.y = -v.y;
         }
       }
@@ -159,9 +159,25 @@ __global__ __launch_bounds__(256) void zgemm_grouped_kernel(const dm_gemm_desc* 
     }
   }
 
-  // epilogue: lane l, reg r -> row (l>>4) + 4r, col l&15 of each 16x16 tile
+  // epilogue: lane l, reg r -> row (l>>4) + 4r, col l&15 of each 16x16 tile.  For beta != 0 the
+  // sixteen C values are fetched back to back from clamped (always valid) addresses before any
+  // of them is used: one exposed memory latency per tile instead of sixteen.
   cplx* __restrict__ C = reinterpret_cast<cplx*>(d.C);
   const int crow = lane >> 4, ccol = lane & 15;
+  const bool rmw = d.beta != 0.0;
+  cplx cold[2][2][4];
+  if (rmw) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gm = min(m0 + wm * 32 + i * 16 + crow + 4 * r, d.M - 1);
+          const int gn = min(n0 + wn * 32 + j * 16 + ccol, d.N - 1);
+          cold[i][j][r] = dm_ldg(C, (size_t)gm * d.ldc + gn);
+        }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -170,17 +186,13 @@ __global__ __launch_bounds__(256) void zgemm_grouped_kernel(const dm_gemm_desc* 
       for (int r = 0; r < 4; ++r) {
         int gm = m0 + wm * 32 + i * 16 + crow + 4 * r;
         int gn = n0 + wn * 32 + j * 16 + ccol;
-        if (gm < d.M && gn < d.N) {
-          size_t off = (size_t)gm * d.ldc + gn;
-          const double are = acc_re[i][j][r], aim = acc_im[i][j][r];
-          cplx v = make_double2(d.alpha * are - d.alpha_im * aim, d.alpha * aim + d.alpha_im * are);
-          if (d.beta != 0.0) {
-            cplx c = C[off];
-            v.x += d.beta * c.x;
-            v.y += d.beta * c.y;
-          }
-          C[off] = v;
+        const double are = acc_re[i][j][r], aim = acc_im[i][j][r];
+        cplx v = make_double2(d.alpha * are - d.alpha_im * aim, d.alpha * aim + d.alpha_im * are);
+        if (rmw) {
+          v.x += d.beta * cold[i][j][r].x;
+          v.y += d.beta * cold[i][j][r].y;
         }
+        if (gm < d.M && gn < d.N) dm_stg(C, (size_t)gm * d.ldc + gn, v);
       }
 }
 
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(256) void dgemm_grouped_kernel(const dm_gemm_desc* 
       int m, k;
       if (a_kfast) { k = idx & 15; m = idx >> 4; } else { m = idx & 63; k = idx >> 6; }
       int gm = m0 + m, gk = k0 + k;
-      ra[i] = (gm < d.M && gk < d.K) ? A[(size_t)gm * d.rsA + (size_t)gk * d.csA] : 0.0;
+      ra[i] = (gm < d.M && gk < d.K) ? dm_ldg(A, (size_t)gm * d.rsA + (size_t)gk * d.csA) : 0.0;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -220,7 +232,7 @@ __global__ __launch_bounds__(256) void dgemm_grouped_kernel(const dm_gemm_desc* 
       int n, k;
       if (b_kfast) { k = idx & 15; n = idx >> 4; } else { n = idx & 63; k = idx >> 6; }
       int gn = n0 + n, gk = k0 + k;
-      rb[i] = (gn < d.N && gk < d.K) ? B[(size_t)gk * d.rsB + (size_t)gn * d.csB] : 0.0;
+      rb[i] = (gn < d.N && gk < d.K) ? dm_ldg(B, (size_t)gk * d.rsB + (size_t)gn * d.csB) : 0.0;
     }
   };
   auto store_tiles = [&]() {
@@ -262,6 +274,20 @@ __global__ __launch_bounds__(256) void dgemm_grouped_kernel(const dm_gemm_desc* 
   }
   double* __restrict__ C = reinterpret_cast<double*>(d.C);
   const int crow = lane >> 4, ccol = lane & 15;
+  const bool rmw = d.beta != 0.0;
+  double cold[2][2][4];
+  if (rmw) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gm = min(m0 + wm * 32 + i * 16 + crow + 4 * r, d.M - 1);
+          const int gn = min(n0 + wn * 32 + j * 16 + ccol, d.N - 1);
+          cold[i][j][r] = dm_ldg(C, (size_t)gm * d.ldc + gn);
+        }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -270,12 +296,9 @@ __global__ __launch_bounds__(256) void dgemm_grouped_kernel(const dm_gemm_desc* 
       for (int r = 0; r < 4; ++r) {
         int gm = m0 + wm * 32 + i * 16 + crow + 4 * r;
         int gn = n0 + wn * 32 + j * 16 + ccol;
-        if (gm < d.M && gn < d.N) {
-          size_t off = (size_t)gm * d.ldc + gn;
-          double v = d.alpha * acc[i][j][r];
-          if (d.beta != 0.0) v += d.beta * C[off];
-          C[off] = v;
-        }
+        double v = d.alpha * acc[i][j][r];
+        if (rmw) v += d.beta * cold[i][j][r];
+        if (gm < d.M && gn < d.N) dm_stg(C, (size_t)gm * d.ldc + gn, v);
       }
 }
 

@@ -77,8 +77,8 @@ struct trd_refl { cplx tau, scal; double beta; };
 __device__ __forceinline__ trd_refl trd_reflector(const trd_mat& M, int k) {
   const int np = (M.n - k + WXR - 1) / WXR;
   double xnorm2 = 0.0;
-  for (int t = 0; t < np; ++t) xnorm2 += M.Np[t];
-  const cplx alpha = M.x[k + 1];
+  for (int t = 0; t < np; ++t) xnorm2 += dm_ldg(M.Np, t);
+  const cplx alpha = dm_ldg(M.x, k + 1);
   trd_refl R;
   if (xnorm2 == 0.0 && alpha.y == 0.0) {
     R.tau = make_double2(0.0, 0.0);
@@ -96,7 +96,7 @@ __device__ __forceinline__ trd_refl trd_reflector(const trd_mat& M, int k) {
 
 // v[c] for c > k (v[k+1] = 1, the rest is the scaled column)
 __device__ __forceinline__ cplx trd_v_at(const trd_mat& M, const trd_refl& R, int k, int c) {
-  const cplx t = cmul(M.x[c], R.scal);
+  const cplx t = cmul(dm_ldg(M.x, c), R.scal);
   return c == k + 1 ? make_double2(1.0, 0.0) : t;
 }
 
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const trd_mat* __restrict
     const cplx* x = (slot < j ? M.Wp + (size_t)slot * n : M.Vp + (size_t)(slot - j) * n);
     double sr = 0.0, si = 0.0;
     for (int i = k + 1 + lane; i < n; i += 64) {
-      const cplx xx = x[i], vv = trd_v_at(M, R, k, i);  // conj(x) * v
+      const cplx xx = dm_ldg(x, i), vv = trd_v_at(M, R, k, i);  // conj(x) * v
       sr += xx.x * vv.x + xx.y * vv.y;
       si += xx.x * vv.y - xx.y * vv.x;
     }
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const trd_mat* __restrict
 #pragma unroll
     for (int rr = 0; rr < SYR; ++rr) {
       const int r = rstart + rr;
-      const cplx v = A[(size_t)min(r, n - 1) * lda + cc];
+      const cplx v = dm_ldg(A, (size_t)min(r, n - 1) * lda + cc);
       a[rr] = (valid && r < n && c >= r) ? v : zero;
     }
     cplx col = zero;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const trd_mat* __restrict
     colbuf[0][wave][lane] = col;
     __syncthreads();
     if (wave == 0 && valid)
-      pc[c] = cadd(cadd(colbuf[0][0][lane], colbuf[0][1][lane]), cadd(colbuf[0][2][lane], colbuf[0][3][lane]));
+      dm_stg(pc, c, cadd(cadd(colbuf[0][0][lane], colbuf[0][1][lane]), cadd(colbuf[0][2][lane], colbuf[0][3][lane])));
     t = 1;
   }
 #pragma unroll 1
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const trd_mat* __restrict
 #pragma unroll
     for (int rr = 0; rr < SYR; ++rr) {
       const int r = rstart + rr;
-      const cplx v = A[(size_t)min(r, n - 1) * lda + cc];
+      const cplx v = dm_ldg(A, (size_t)min(r, n - 1) * lda + cc);
       a[rr] = (valid && r < n) ? v : zero;
     }
     cplx col = zero;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const trd_mat* __restrict
     colbuf[pb][wave][lane] = col;
     __syncthreads();
     if (wave == (t & 3) && valid)
-      pc[c] = cadd(cadd(colbuf[pb][0][lane], colbuf[pb][1][lane]), cadd(colbuf[pb][2][lane], colbuf[pb][3][lane]));
+      dm_stg(pc, c, cadd(cadd(colbuf[pb][0][lane], colbuf[pb][1][lane]), cadd(colbuf[pb][2][lane], colbuf[pb][3][lane])));
   }
   // Transposing butterfly: the 2 SYR per-lane partial sums are folded so that lane L ends up with
   // the wave total of entry L / PER (2 SYR + log2(PER) shuffles instead of 2 SYR full reductions).
@@ -316,14 +316,14 @@ __global__ __launch_bounds__(WXR) void trd_wx_kernel(const trd_mat* __restrict__
       const int gi = (i - k - 1) / SYG;
       const cplx* __restrict__ pc = M.Pc + i;
 #pragma unroll 4
-      for (int g = 0; g <= gi; ++g) q = cadd(q, pc[(size_t)g * n]);
+      for (int g = 0; g <= gi; ++g) q = cadd(q, dm_ldg(pc, (size_t)g * n));
       vv = M.Vp[(size_t)j * n + i];
     }
     const cplx* __restrict__ vp = M.Vp + i;
     const cplx* __restrict__ wp = M.Wp + i;
 #pragma unroll 4
     for (int jj = 0; jj < npan; ++jj) {
-      const cplx vji = vp[(size_t)jj * n], wji = wp[(size_t)jj * n];
+      const cplx vji = dm_ldg(vp, (size_t)jj * n), wji = dm_ldg(wp, (size_t)jj * n);
       q = csub(q, cadd(cmul(vji, sa[jj]), cmul(wji, sb[jj])));
       if (x_on) xacc = csub(xacc, cadd(cmulc(vji, swk[jj]), cmulc(wji, svk[jj])));
     }
