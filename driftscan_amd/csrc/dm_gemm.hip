@@ -122,13 +122,10 @@ __global__ __launch_bounds__(256) void zgemm_grouped_kernel(const dm_gemm_desc* 
   };
 
   const int fi = lane & 15, fk = lane >> 4;
-  const int nk = (d.K + BK - 1) / BK;
-  if (nk > 0) load_tiles(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();  // previous panel fully consumed
-    store_tiles();
-    __syncthreads();
-    if (kt + 1 < nk) load_tiles((kt + 1) * BK);  // in flight during the MFMAs below
+  // MFMAs of one staged panel.  The two products that feed the same accumulator are issued eight
+  // MFMAs apart (all "first" products, then all "second" ones): a dependent MFMA right behind its
+  // producer stalls on the 16-pass f64 pipeline.
+  auto compute_panel = [&]() {
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
       double a_re[2], a_im[2], a_imn[2], b_re[2], b_im[2];
@@ -151,22 +148,26 @@ __global__ __launch_bounds__(256) void zgemm_grouped_kernel(const dm_gemm_desc* 
         for (int j = 0; j < 2; ++j) {
           acc_re[i][j] = dm_mfma(a_re[i], b_re[j], acc_re[i][j]);
           acc_im[i][j] = dm_mfma(a_im[i], b_re[j], acc_im[i][j]);
-          if (!B_REAL) {
+        }
+      if (!B_REAL) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
             acc_re[i][j] = dm_mfma(a_imn[i], b_im[j], acc_re[i][j]);
             acc_im[i][j] = dm_mfma(a_re[i], b_im[j], acc_im[i][j]);
           }
-        }
+      }
     }
-  }
+  };
 
-  // epilogue: lane l, reg r -> row (l>>4) + 4r, col l&15 of each 16x16 tile.  For beta != 0 the
-  // sixteen C values are fetched back to back from clamped (always valid) addresses before any
-  // of them is used: one exposed memory latency per tile instead of sixteen.
   cplx* __restrict__ C = reinterpret_cast<cplx*>(d.C);
   const int crow = lane >> 4, ccol = lane & 15;
   const bool rmw = d.beta != 0.0;
   cplx cold[2][2][4];
-  if (rmw) {
+  // For beta != 0 the sixteen C values are fetched back to back from clamped (always valid)
+  // addresses, and BEFORE the MFMAs of the last panel, so that their latency is covered.
+  auto load_c = [&]() {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -177,7 +178,28 @@ __global__ __launch_bounds__(256) void zgemm_grouped_kernel(const dm_gemm_desc* 
           const int gn = min(n0 + wn * 32 + j * 16 + ccol, d.N - 1);
           cold[i][j][r] = dm_ldg(C, (size_t)gm * d.ldc + gn);
         }
+  };
+
+  const int nk = (d.K + BK - 1) / BK;
+  if (nk > 0) load_tiles(0);
+  for (int kt = 0; kt < nk - 1; ++kt) {
+    __syncthreads();  // previous panel fully consumed
+    store_tiles();
+    __syncthreads();
+    load_tiles((kt + 1) * BK);  // in flight during the MFMAs below
+    compute_panel();
   }
+  if (nk > 0) {
+    __syncthreads();
+    store_tiles();
+    __syncthreads();
+    if (rmw) load_c();
+    compute_panel();
+  } else if (rmw) {
+    load_c();
+  }
+
+  // epilogue: lane l, reg r -> row (l>>4) + 4r, col l&15 of each 16x16 tile
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll

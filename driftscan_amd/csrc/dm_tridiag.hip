@@ -825,7 +825,7 @@ __global__ void zt_to_x_kernel(const cvt_mat* __restrict__ cs) {
 }
 
 // ---- T4 helper: T factor of a block of reflectors from its Gram matrix (zlarft, forward/columnwise) ----
-struct tf_mat { const cplx* G; const cplx* tau; cplx* T; int kb; };  // G, T: TNB x TNB row-major
+struct tf_mat { const cplx* G; const cplx* tau; cplx* T; int kb; int ldt; };  // G: TNB x TNB row-major; T: leading dimension ldt
 __global__ __launch_bounds__(64) void larft_kernel(const tf_mat* __restrict__ ts) {
   const tf_mat F = ts[blockIdx.x];
   extern __shared__ __align__(16) unsigned char larft_smem[];
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(64) void larft_kernel(const tf_mat* __restrict__ ts
     if (tid == 0) T[j][j] = tj;
     __syncthreads();
   }
-  for (int idx = tid; idx < TNB * TNB; idx += 64) F.T[idx] = T[idx / TNB][idx % TNB];
+  for (int idx = tid; idx < TNB * TNB; idx += 64) F.T[(size_t)(idx / TNB) * F.ldt + idx % TNB] = T[idx / TNB][idx % TNB];
 }
 
 
@@ -1466,12 +1466,31 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
   int* nsw = dm_ws_alloc_t<int>(ctx, np);
   int* stat = dm_ws_alloc_t<int>(ctx, np);
   double* Zt = dm_ws_alloc_t<double>(ctx, std::max<size_t>(tot, 1));
-  cplx* Gb = dm_ws_alloc_t<cplx>(ctx, (size_t)np * TNB * TNB);
-  cplx* Tb = dm_ws_alloc_t<cplx>(ctx, (size_t)np * TNB * TNB);
-  cplx* W1 = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * TNB, 1));
-  cplx* W2 = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * TNB, 1));
+  // back-transformation in compact-WY blocks of NBB reflectors (merged from the TNB-wide panels)
+  int NBB = 2 * TNB;
+  if (const char* e = getenv("DM_WY_BLOCK")) {
+    const int v = atoi(e);
+    if (v == TNB || v == 2 * TNB || v == 4 * TNB) NBB = v;
+  }
+  size_t tottb = 0;
+  std::vector<size_t> offtb(np);
+  for (int p = 0; p < np; ++p) {
+    offtb[p] = tottb;
+    tottb += (size_t)((probs[p].n + NBB - 1) / NBB) * NBB * NBB;
+  }
+  cplx* Tbig = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(tottb, 1));       // T factors, NBB x NBB per block
+  size_t totg = 0;
+  std::vector<size_t> offg(np);
+  for (int p = 0; p < np; ++p) {
+    offg[p] = totg;
+    totg += (size_t)(probs[p].n / TNB + 1) * TNB * TNB + (size_t)NBB * NBB;  // enough for every merge level
+  }
+  cplx* Gs = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totg, 1));          // Gram scratch
+  cplx* Gt = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totg, 1));          // T_left * Gram scratch
+  cplx* Ut = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(tot, 1));           // T V^H, same layout as Vt
+  cplx* W1 = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * NBB, 1));
   if (!Vt || !PP || !pv || !xv || !Pcv || !Spv || !Npv || !abv || !dd || !ee || !tau || !sw_dir || !sw_lo || !sw_cnt || !sw_off || !rot || !nsw ||
-      !stat || !Zt || !Gb || !Tb || !W1 || !W2)
+      !stat || !Zt || !Tbig || !Gs || !Gt || !Ut || !W1)
     return DM_ENOMEM;
   DM_TRY(dm_fill_zero(ctx, PP, sizeof(cplx) * totn * 3 * TNB));
   DM_TRY(dm_fill_zero(ctx, Vt, sizeof(cplx) * tot));  // trd_symv only writes the non-zero part of each vector
@@ -1641,35 +1660,30 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
     if (!d_cm) return DM_ENOMEM;
     const int tb = (cmax + 31) / 32;
     hipLaunchKernelGGL(zt_to_x_kernel, dim3(tb, tb, nc), dim3(256), 0, ctx->stream, d_cm);
-    const int nblk = (std::max(cmax - 1, 0) + TNB - 1) / TNB;
-    for (int b = nblk - 1; b >= 0; --b) {
-      const int k0 = b * TNB;
-      std::vector<dm_gemm_desc> g1, g2, g3, g4;
+    // ---- T factors of all blocks up front (they depend on V only), batched over blocks and matrices:
+    //   level 0: T of every TNB-wide panel from its Gram matrix (zlarft)
+    //   merge:   [T_l, -T_l (V_l^H V_r) T_r; 0, T_r] for neighbouring blocks until NBB is reached
+    //   U^H = T V^H per block, so that applying a block is two products: W = U^H X, X -= V W
+    DM_TRY(dm_fill_zero(ctx, Tbig, sizeof(cplx) * tottb));
+    {
+      std::vector<dm_gemm_desc> g;
       std::vector<tf_mat> tf;
       for (int p : ch) {
         const int n = probs[p].n;
-        const int kb = std::min(k0 + TNB, n - 1) - k0;
-        if (kb <= 0) continue;
-        const cplx* Vb = Vt + off[p] + (size_t)k0 * n;
-        cplx* G = Gb + (size_t)p * TNB * TNB;
-        cplx* T = Tb + (size_t)p * TNB * TNB;
-        cplx* X = probs[p].C;
-        cplx* w1 = W1 + offn[p] * TNB;
-        cplx* w2 = W2 + offn[p] * TNB;
-        // reflectors k >= k0 vanish on rows <= k0: only rows r0.. of X take part
-        const int r0 = k0 + 1, nr = n - r0;
-        cplx* Xr = X + (size_t)r0 * probs[p].ldc;
-        g1.push_back(dm_gemm_make(Vb + r0, n, 1, true, Vb + r0, 1, n, false, G, TNB, kb, kb, nr));
-        tf.push_back(tf_mat{G, tau + offn[p] + k0, T, kb});
-        g2.push_back(dm_gemm_make(Vb + r0, n, 1, true, Xr, probs[p].ldc, 1, false, w1, n, kb, n, nr));
-        g3.push_back(dm_gemm_make(T, TNB, 1, false, w1, n, 1, false, w2, n, kb, n, kb));
-        g4.push_back(dm_gemm_make(Vb + r0, 1, n, false, w2, n, 1, false, Xr, probs[p].ldc, nr, n, kb, -1.0, 1.0));
+        for (int k0 = 0; k0 < n - 1; k0 += TNB) {
+          const int kb = std::min(k0 + TNB, n - 1) - k0;
+          const int r0 = k0 + 1, nr = n - r0;
+          const cplx* Vb = Vt + off[p] + (size_t)k0 * n + r0;
+          cplx* G = Gs + offg[p] + (size_t)(k0 / TNB) * TNB * TNB;
+          cplx* T = Tbig + offtb[p] + (size_t)(k0 / NBB) * NBB * NBB + (size_t)(k0 % NBB) * NBB + (k0 % NBB);
+          g.push_back(dm_gemm_make(Vb, n, 1, true, Vb, 1, n, false, G, TNB, kb, kb, nr));
+          tf.push_back(tf_mat{G, tau + offn[p] + k0, T, kb, NBB});
+        }
       }
-      if (g1.empty()) continue;
-      DM_TRY(dm_gemm_grouped_launch(ctx, g1));
-      tf_mat* d_tf = dm_ws_upload(ctx, tf);
-      if (!d_tf) return DM_ENOMEM;
-      {
+      if (!g.empty()) {
+        DM_TRY(dm_gemm_grouped_launch(ctx, g));
+        tf_mat* d_tf = dm_ws_upload(ctx, tf);
+        if (!d_tf) return DM_ENOMEM;
         static bool attr = false;
         const size_t lds = sizeof(cplx) * TNB * (TNB + 1);
         if (!attr) {
@@ -1679,8 +1693,67 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
         }
         hipLaunchKernelGGL(larft_kernel, dim3((unsigned)tf.size()), dim3(64), lds, ctx->stream, d_tf);
       }
+    }
+    for (int sz = TNB; sz < NBB; sz *= 2) {
+      std::vector<dm_gemm_desc> ga, gb, gc;
+      for (int p : ch) {
+        const int n = probs[p].n;
+        for (int k0 = 0; k0 + sz < n - 1; k0 += 2 * sz) {  // left block [k0, k0+sz), right block [k0+sz, ...)
+          const int kr0 = k0 + sz;
+          const int kl = sz, kr = std::min(kr0 + sz, n - 1) - kr0;
+          const int r0 = kr0 + 1, nr = n - r0;             // rows where the right block is non-zero
+          const cplx* Vl = Vt + off[p] + (size_t)k0 * n + r0;
+          const cplx* Vr = Vt + off[p] + (size_t)kr0 * n + r0;
+          cplx* G = Gs + offg[p] + (size_t)(k0 / (2 * sz)) * sz * sz;
+          cplx* H = Gt + offg[p] + (size_t)(k0 / (2 * sz)) * sz * sz;
+          cplx* Tblk = Tbig + offtb[p] + (size_t)(k0 / NBB) * NBB * NBB;
+          const int o = k0 % NBB;
+          cplx* Tl = Tblk + (size_t)o * NBB + o;
+          cplx* Tr = Tblk + (size_t)(o + sz) * NBB + (o + sz);
+          cplx* T12 = Tblk + (size_t)o * NBB + (o + sz);
+          ga.push_back(dm_gemm_make(Vl, n, 1, true, Vr, 1, n, false, G, sz, kl, kr, nr));
+          gb.push_back(dm_gemm_make(Tl, NBB, 1, false, G, sz, 1, false, H, sz, kl, kr, kl));
+          gc.push_back(dm_gemm_make(H, sz, 1, false, Tr, NBB, 1, false, T12, NBB, kl, kr, kr, -1.0, 0.0));
+        }
+      }
+      DM_TRY(dm_gemm_grouped_launch(ctx, ga));
+      DM_TRY(dm_gemm_grouped_launch(ctx, gb));
+      DM_TRY(dm_gemm_grouped_launch(ctx, gc));
+    }
+    {
+      std::vector<dm_gemm_desc> g;
+      for (int p : ch) {
+        const int n = probs[p].n;
+        for (int k0 = 0; k0 < n - 1; k0 += NBB) {
+          const int kb = std::min(k0 + NBB, n - 1) - k0;
+          const int r0 = k0 + 1, nr = n - r0;
+          const cplx* T = Tbig + offtb[p] + (size_t)(k0 / NBB) * NBB * NBB;
+          g.push_back(dm_gemm_make(T, NBB, 1, false, Vt + off[p] + (size_t)k0 * n + r0, n, 1, true,
+                                   Ut + off[p] + (size_t)k0 * n + r0, n, kb, nr, kb));
+        }
+      }
+      DM_TRY(dm_gemm_grouped_launch(ctx, g));
+    }
+    // ---- apply the blocks, last to first
+    const int nblk = (std::max(cmax - 1, 0) + NBB - 1) / NBB;
+    for (int b = nblk - 1; b >= 0; --b) {
+      const int k0 = b * NBB;
+      std::vector<dm_gemm_desc> g2, g4;
+      for (int p : ch) {
+        const int n = probs[p].n;
+        const int kb = std::min(k0 + NBB, n - 1) - k0;
+        if (kb <= 0) continue;
+        // reflectors k >= k0 vanish on rows <= k0: only rows r0.. of X take part
+        const int r0 = k0 + 1, nr = n - r0;
+        cplx* Xr = probs[p].C + (size_t)r0 * probs[p].ldc;
+        cplx* w1 = W1 + offn[p] * NBB;
+        g2.push_back(dm_gemm_make(Ut + off[p] + (size_t)k0 * n + r0, n, 1, false, Xr, probs[p].ldc, 1, false, w1, n, kb,
+                                  n, nr));
+        g4.push_back(dm_gemm_make(Vt + off[p] + (size_t)k0 * n + r0, 1, n, false, w1, n, 1, false, Xr, probs[p].ldc, nr,
+                                  n, kb, -1.0, 1.0));
+      }
+      if (g2.empty()) continue;
       DM_TRY(dm_gemm_grouped_launch(ctx, g2));
-      DM_TRY(dm_gemm_grouped_launch(ctx, g3));
       DM_TRY(dm_gemm_grouped_launch(ctx, g4));
     }
     {
