@@ -180,11 +180,30 @@ def main():
             st = np.array(stage).mean(axis=0)
             dom = max(prof, key=lambda k: prof[k]["ms"]) if prof else None
             roofline = None
+            # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this
+            # process, so the figure comes from the committed rocprofv3 --pmc passes of this same
+            # command (profiles/*_pmc_traffic.json, made by scratch/run_profiles.sh + make_traffic_json.py).
+            traffic, traffic_src = None, None
+            try:
+                import glob
+
+                tj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+                if tj and dom is not None:
+                    rec = json.load(open(tj[-1]))
+                    key = {"zgemm_grouped": "zgemm_grouped_kernel<false>", "gemm_grouped_realB": "zgemm_grouped_kernel<true>",
+                           "dgemm_grouped": "dgemm_grouped_kernel", "jac_inner": "jac_inner_kernel<false>",
+                           "jac_gram": "jac_gram_kernel", "jac_apply": "jac_apply_kernel"}.get(dom)
+                    if key in rec:
+                        traffic = rec[key]["fetch_bytes_per_launch"] + rec[key]["write_bytes_per_launch"]
+                        traffic_src = os.path.relpath(tj[-1], ROOT)
+            except Exception:
+                traffic, traffic_src = None, None
             if dom is not None:
                 p = prof[dom]
                 ach = p["flops"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
                 roofline = dict(bound="mfma", kernel=dom, achieved=ach, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                                frac=ach / FP64_MFMA_PEAK_TFLOPS, traffic=None, launches=p["launches"],
+                                frac=ach / FP64_MFMA_PEAK_TFLOPS, traffic=traffic, traffic_unit="bytes/launch",
+                                traffic_source=traffic_src, launches=p["launches"],
                                 avg_launch_us=1e3 * p["ms"] / max(p["launches"], 1),
                                 flops_per_launch=p["flops"] / max(p["launches"], 1))
             line = {
