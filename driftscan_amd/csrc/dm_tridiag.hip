@@ -62,7 +62,7 @@ struct trd_mat {
 //                Pc[group][c] (no atomics: the consumer adds the partial rows in a fixed order).
 //                It also writes v, e[k], tau[k], the panel dot products a = W^H v, b = V^H v and the
 //                partial sums of v^H A v (which give p^H v without another pass over p).
-//   trd_wx(k)    finishes w_k = tau (A v - V a - W b) - (tau/2)(p^H v) v  for its 128 rows and, in
+//   trd_wx(k)    finishes w_k = tau (A v - V a - W b) - (tau/2)(p^H v) v  for its 64 rows and, in
 //                the same pass over the panel rows V[:, i], W[:, i], forms the next column
 //                x_{k+1} = conj(A[k+1][i]) - V conj(W[k+1]) - W conj(V[k+1])  and its partial norms.
 //
@@ -70,7 +70,7 @@ struct trd_mat {
 // reads the full square and the panel twice).
 constexpr int SYR = 8;     // rows per wave in trd_symv
 constexpr int SYG = 4 * SYR;  // rows per workgroup = rows behind one partial row of Pc
-constexpr int WXR = 128;   // rows per workgroup in trd_wx
+constexpr int WXR = 64;    // rows per workgroup in trd_wx
 
 struct trd_refl { cplx tau, scal; double beta; };
 
@@ -106,22 +106,39 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const trd_mat* __restrict
   if (k >= n - 1) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: row bases stay in SGPRs
+  // the panel dot products take SLV vectors per wave: v is formed once per element and reused
+  constexpr int SLV = 4;
+  const int nslot = (2 * j + SLV - 1) / SLV;
+  const int nslotblk = (nslot + 3) / 4;
+  if ((int)blockIdx.x >= nslotblk && k + 1 + SYG * ((int)blockIdx.x - nslotblk) >= n) return;  // no rows left
+  if ((int)blockIdx.x < nslotblk && (int)blockIdx.x * 4 + wave >= nslot) return;
   const trd_refl R = trd_reflector(M, k);
-  const int nslotblk = (2 * j + 3) / 4;
   if ((int)blockIdx.x < nslotblk) {
-    // panel dot products a[q] = W_q^H v, b[q] = V_q^H v (needed by trd_wx): one wave each
-    const int slot = blockIdx.x * 4 + wave;
-    if (slot >= 2 * j) return;
-    const cplx* x = (slot < j ? M.Wp + (size_t)slot * n : M.Vp + (size_t)(slot - j) * n);
-    double sr = 0.0, si = 0.0;
-    for (int i = k + 1 + lane; i < n; i += 64) {
-      const cplx xx = dm_ldg(x, i), vv = trd_v_at(M, R, k, i);  // conj(x) * v
-      sr += xx.x * vv.x + xx.y * vv.y;
-      si += xx.x * vv.y - xx.y * vv.x;
+    // a[q] = W_q^H v, b[q] = V_q^H v (needed by trd_wx); vector index q < j: W_q, else V_{q-j}
+    const int q0 = (blockIdx.x * 4 + wave) * SLV;
+    const cplx* xs[SLV];
+#pragma unroll
+    for (int u = 0; u < SLV; ++u) {
+      const int q = min(q0 + u, 2 * j - 1);
+      xs[u] = (q < j ? M.Wp + (size_t)q * n : M.Vp + (size_t)(q - j) * n);
     }
-    sr = dm_wave_sum(sr);
-    si = dm_wave_sum(si);
-    if (lane == 0) M.ab[slot] = make_double2(sr, si);
+    double sr[SLV], si[SLV];
+#pragma unroll
+    for (int u = 0; u < SLV; ++u) sr[u] = si[u] = 0.0;
+    for (int i = k + 1 + lane; i < n; i += 64) {
+      const cplx vv = trd_v_at(M, R, k, i);
+#pragma unroll
+      for (int u = 0; u < SLV; ++u) {
+        const cplx xx = dm_ldg(xs[u], i);  // conj(x) * v
+        sr[u] += xx.x * vv.x + xx.y * vv.y;
+        si[u] += xx.x * vv.y - xx.y * vv.x;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < SLV; ++u) {
+      const double tr = dm_wave_sum(sr[u]), ti = dm_wave_sum(si[u]);
+      if (lane == 0 && q0 + u < 2 * j) M.ab[q0 + u] = make_double2(tr, ti);
+    }
     return;
   }
   // ---- a workgroup owns SYG = 4 SYR consecutive rows; its four waves walk the same 64-column
@@ -249,7 +266,7 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const trd_mat* __restrict
   if (threadIdx.x == 0) M.Sp[g] = (sbuf[0] + sbuf[1]) + (sbuf[2] + sbuf[3]);
 }
 
-__global__ __launch_bounds__(WXR) void trd_wx_kernel(const trd_mat* __restrict__ ms, int k, int j, int do_w, int do_x) {
+__global__ __launch_bounds__(256) void trd_wx_kernel(const trd_mat* __restrict__ ms, int k, int j, int do_w, int do_x) {
   const trd_mat M = ms[blockIdx.y];
   const int n = M.n;
   const bool w_on = do_w && k < n - 1;
@@ -257,12 +274,14 @@ __global__ __launch_bounds__(WXR) void trd_wx_kernel(const trd_mat* __restrict__
   const bool x_on = do_x && kx < n;
   if (!w_on && !x_on) return;
   if (kx + (int)blockIdx.x * WXR >= n) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i = kx + blockIdx.x * WXR + tid;
+  // 64 rows per workgroup, four waves per row block: wave q takes the panel vectors and the
+  // partial rows of A v with index = q (mod 4); wave 0 folds the four partial results and finishes.
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = kx + blockIdx.x * WXR + lane;
   const int npan = do_w ? j : 0;  // finished panel vectors
   __shared__ cplx sa[TNB], sb[TNB], swk[TNB], svk[TNB];
-  __shared__ double s_coef, s_part[WXR / 64];
-  __shared__ cplx s_wk1;
+  __shared__ cplx qbuf[3][WXR], xbuf[3][WXR];
   if (tid < npan) {
     sa[tid] = M.ab[tid];
     sb[tid] = M.ab[j + tid];
@@ -272,63 +291,64 @@ __global__ __launch_bounds__(WXR) void trd_wx_kernel(const trd_mat* __restrict__
     }
   }
   __syncthreads();
-  cplx tau = make_double2(0.0, 0.0), wk1 = make_double2(0.0, 0.0);
-  double coef = 0.0;
-  if (w_on) {
-    tau = M.tau[k];
-    if (wave == 0) {
-      const int ng = (n - k - 1 + SYG - 1) / SYG;
-      double s = 0.0, ab = 0.0, cr = 0.0, ci = 0.0;
-      for (int t = lane; t < ng; t += 64) s += M.Sp[t];
-      for (int t = lane; t < npan; t += 64) {
-        ab += sa[t].x * sb[t].x + sa[t].y * sb[t].y;  // Re(conj(a) b)
-        if (x_on) {
-          const cplx u = cadd(cmul(svk[t], sa[t]), cmul(swk[t], sb[t]));
-          cr += u.x;
-          ci += u.y;
-        }
-      }
-      s = dm_wave_sum(s);
-      ab = dm_wave_sum(ab);
-      cr = dm_wave_sum(cr);
-      ci = dm_wave_sum(ci);
-      if (lane == 0) {
-        // p^H v = conj(tau) (v^H A v - a^H b - b^H a)  (real);  coef = (tau/2) p^H v
-        const double c0 = 0.5 * (tau.x * tau.x + tau.y * tau.y) * (s - 2.0 * ab);
-        s_coef = c0;
-        if (x_on) {  // w_k[k+1]: the mirrored part of p vanishes on the first trailing row
-          const cplx q = csub(M.p[kx], make_double2(cr, ci));
-          cplx w1 = cmul(tau, q);
-          w1.x -= c0;
-          s_wk1 = w1;
-        }
-      }
-    }
-    __syncthreads();
-    coef = s_coef;
-    wk1 = s_wk1;
-  }
-  double part = 0.0;
+  cplx q = make_double2(0.0, 0.0), xacc = make_double2(0.0, 0.0);
   if (i < n) {
-    cplx q = make_double2(0.0, 0.0), vv = make_double2(0.0, 0.0), xacc = make_double2(0.0, 0.0);
     if (w_on) {
-      q = M.p[i];
+      if (wave == 0) q = M.p[i];
       const int gi = (i - k - 1) / SYG;
       const cplx* __restrict__ pc = M.Pc + i;
 #pragma unroll 4
-      for (int g = 0; g <= gi; ++g) q = cadd(q, dm_ldg(pc, (size_t)g * n));
-      vv = M.Vp[(size_t)j * n + i];
+      for (int g = wave; g <= gi; g += 4) q = cadd(q, dm_ldg(pc, (size_t)g * n));
     }
     const cplx* __restrict__ vp = M.Vp + i;
     const cplx* __restrict__ wp = M.Wp + i;
 #pragma unroll 4
-    for (int jj = 0; jj < npan; ++jj) {
+    for (int jj = wave; jj < npan; jj += 4) {
       const cplx vji = dm_ldg(vp, (size_t)jj * n), wji = dm_ldg(wp, (size_t)jj * n);
       q = csub(q, cadd(cmul(vji, sa[jj]), cmul(wji, sb[jj])));
       if (x_on) xacc = csub(xacc, cadd(cmulc(vji, swk[jj]), cmulc(wji, svk[jj])));
     }
-    cplx wv = make_double2(0.0, 0.0);
+  }
+  if (wave > 0) {
+    qbuf[wave - 1][lane] = q;
+    xbuf[wave - 1][lane] = xacc;
+  }
+  __syncthreads();
+  if (wave > 0) return;
+  q = cadd(cadd(q, qbuf[0][lane]), cadd(qbuf[1][lane], qbuf[2][lane]));
+  xacc = cadd(cadd(xacc, xbuf[0][lane]), cadd(xbuf[1][lane], xbuf[2][lane]));
+  cplx tau = make_double2(0.0, 0.0), wk1 = make_double2(0.0, 0.0);
+  double coef = 0.0;
+  if (w_on) {
+    tau = M.tau[k];
+    const int ng = (n - k - 1 + SYG - 1) / SYG;
+    double s = 0.0, ab = 0.0, cr = 0.0, ci = 0.0;
+    for (int t = lane; t < ng; t += 64) s += M.Sp[t];
+    for (int t = lane; t < npan; t += 64) {
+      ab += sa[t].x * sb[t].x + sa[t].y * sb[t].y;  // Re(conj(a) b)
+      if (x_on) {
+        const cplx u = cadd(cmul(svk[t], sa[t]), cmul(swk[t], sb[t]));
+        cr += u.x;
+        ci += u.y;
+      }
+    }
+    s = dm_wave_sum(s);
+    ab = dm_wave_sum(ab);
+    cr = dm_wave_sum(cr);
+    ci = dm_wave_sum(ci);
+    // p^H v = conj(tau) (v^H A v - a^H b - b^H a)  (real);  coef = (tau/2) p^H v
+    coef = 0.5 * (tau.x * tau.x + tau.y * tau.y) * (s - 2.0 * ab);
+    if (x_on) {  // w_k[k+1]: the mirrored part of p vanishes on the first trailing row
+      const cplx q1 = csub(M.p[kx], make_double2(cr, ci));
+      wk1 = cmul(tau, q1);
+      wk1.x -= coef;
+    }
+  }
+  double part = 0.0;
+  if (i < n) {
+    cplx wv = make_double2(0.0, 0.0), vv = make_double2(0.0, 0.0);
     if (w_on) {
+      vv = M.Vp[(size_t)j * n + i];
       wv = cmul(tau, q);
       wv.x -= coef * vv.x;
       wv.y -= coef * vv.y;
@@ -345,13 +365,7 @@ __global__ __launch_bounds__(WXR) void trd_wx_kernel(const trd_mat* __restrict__
   }
   if (x_on) {
     part = dm_wave_sum(part);
-    if (lane == 0) s_part[wave] = part;
-    __syncthreads();
-    if (tid == 0) {
-      double t = 0.0;
-      for (int w = 0; w < WXR / 64; ++w) t += s_part[w];
-      M.Np[blockIdx.x] = t;
-    }
+    if (lane == 0) M.Np[blockIdx.x] = part;
   }
 }
 
@@ -1552,14 +1566,15 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
     for (int k0 = 0; k0 < cmax; k0 += TNB) {
       const int k1 = std::min(k0 + TNB, cmax);
       // first column of the panel: plain row of the (just updated) matrix
-      hipLaunchKernelGGL(trd_wx_kernel, dim3((cmax - k0 + WXR - 1) / WXR, nc), dim3(WXR), 0, ctx->stream, d_tm, k0, 0,
+      hipLaunchKernelGGL(trd_wx_kernel, dim3((cmax - k0 + WXR - 1) / WXR, nc), dim3(256), 0, ctx->stream, d_tm, k0, 0,
                          0, 1);
       for (int k = k0; k < k1; ++k) {
         const int j = k - k0;
         if (k < cmax - 1) {
           const int ng = (cmax - k - 1 + SYG - 1) / SYG;
-          hipLaunchKernelGGL(trd_symv_kernel, dim3((2 * j + 3) / 4 + ng, nc), dim3(256), 0, ctx->stream, d_tm, k, j);
-          hipLaunchKernelGGL(trd_wx_kernel, dim3((cmax - k - 1 + WXR - 1) / WXR, nc), dim3(WXR), 0, ctx->stream, d_tm,
+          const int nslotblk = ((2 * j + 3) / 4 + 3) / 4;  // 4 vectors per wave, 4 waves per workgroup
+          hipLaunchKernelGGL(trd_symv_kernel, dim3(nslotblk + ng, nc), dim3(256), 0, ctx->stream, d_tm, k, j);
+          hipLaunchKernelGGL(trd_wx_kernel, dim3((cmax - k - 1 + WXR - 1) / WXR, nc), dim3(256), 0, ctx->stream, d_tm,
                              k, j, 1, k + 1 < k1 ? 1 : 0);
         }
       }
