@@ -56,7 +56,7 @@ struct trd_mat {
 //
 //   trd_symv(k)  every wave derives the Householder scalars (beta, tau, 1/(alpha-beta)) of column k
 //                from the partial norms left by trd_wx and forms v on the fly from the unnormalised
-//                column x.  A wave owns SYR = 8 consecutive rows r and streams them in 64-column
+//                column x.  A wave owns SYR = 4 consecutive rows r and streams them in 64-column
 //                chunks c >= r: the row part  sum_c A[r][c] v[c]  is accumulated per row, the
 //                mirrored part  conj(A[r][c]) v[r]  per column, and written as one partial row
 //                Pc[group][c] (no atomics: the consumer adds the partial rows in a fixed order).
@@ -68,17 +68,22 @@ struct trd_mat {
 //
 // HBM traffic per column: (n-k)^2/2 matrix elements + one pass over the panel (the zlatrd scheme
 // reads the full square and the panel twice).
-constexpr int SYR = 8;     // rows per wave in trd_symv
+constexpr int SYR = 4;     // rows per wave in trd_symv
 constexpr int SYG = 4 * SYR;  // rows per workgroup = rows behind one partial row of Pc
+constexpr int SYC = 2;        // 64-column chunks per loop iteration of trd_symv
 constexpr int WXR = 64;    // rows per workgroup in trd_wx
 
 struct trd_refl { cplx tau, scal; double beta; };
 
 __device__ __forceinline__ trd_refl trd_reflector(const trd_mat& M, int k) {
+  // the partial norms are fetched one per lane and folded with shuffles: a serial scalar loop
+  // over up to n/64 partials would put that many dependent load latencies in front of every wave
   const int np = (M.n - k + WXR - 1) / WXR;
+  const int lane = threadIdx.x & 63;
   double xnorm2 = 0.0;
-  for (int t = 0; t < np; ++t) xnorm2 += dm_ldg(M.Np, t);
+  for (int t = lane; t < np; t += 64) xnorm2 += dm_ldg(M.Np, t);
   const cplx alpha = dm_ldg(M.x, k + 1);
+  xnorm2 = dm_wave_sum(xnorm2);
   trd_refl R;
   if (xnorm2 == 0.0 && alpha.y == 0.0) {
     R.tau = make_double2(0.0, 0.0);
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const trd_mat* __restrict
   const int g = blockIdx.x - nslotblk;
   const int R0 = k + 1 + SYG * g;
   if (R0 >= n) return;
-  __shared__ cplx colbuf[2][4][64];
+  __shared__ cplx colbuf[2][SYC][4][64];
   __shared__ double sbuf[4];
   const int rstart = R0 + SYR * wave;
   const int dl = SYR * wave;  // lane of this wave's first diagonal element in chunk 0
@@ -201,39 +206,52 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const trd_mat* __restrict
         col.y += a[rr].x * vr[rr].y - a[rr].y * vr[rr].x;
       }
     }
-    colbuf[0][wave][lane] = col;
+    colbuf[0][0][wave][lane] = col;
     __syncthreads();
     if (wave == 0 && valid)
-      dm_stg(pc, c, cadd(cadd(colbuf[0][0][lane], colbuf[0][1][lane]), cadd(colbuf[0][2][lane], colbuf[0][3][lane])));
+      dm_stg(pc, c,
+             cadd(cadd(colbuf[0][0][0][lane], colbuf[0][0][1][lane]), cadd(colbuf[0][0][2][lane], colbuf[0][0][3][lane])));
     t = 1;
   }
+  // main loop: SYC chunks (64 SYC columns) per iteration -> SYC * SYR row loads in flight per lane;
+  // HBM latency under load is ~5 us, so the bytes in flight per CU set the streaming rate
 #pragma unroll 1
-  for (int c0 = R0 + 64; c0 < n; c0 += 64, ++t) {
-    c = c0 + lane;
-    valid = c < n;
-    cc = min(c, n - 1);
-    const cplx vct = trd_v_at(M, R, k, cc);
-    const cplx vc = valid ? vct : zero;
-    cplx a[SYR];
+  for (int c0 = R0 + 64; c0 < n; c0 += 64 * SYC, ++t) {
+    cplx a[SYC][SYR], vcu[SYC];
+    bool vld[SYC];
 #pragma unroll
-    for (int rr = 0; rr < SYR; ++rr) {
-      const int r = rstart + rr;
-      const cplx v = dm_ldg(A, (size_t)min(r, n - 1) * lda + cc);
-      a[rr] = (valid && r < n) ? v : zero;
-    }
-    cplx col = zero;
+    for (int u = 0; u < SYC; ++u) {
+      const int cu = c0 + 64 * u + lane;
+      vld[u] = cu < n;
+      const int ccu = min(cu, n - 1);
+      const cplx vct = trd_v_at(M, R, k, ccu);
+      vcu[u] = vld[u] ? vct : zero;
 #pragma unroll
-    for (int rr = 0; rr < SYR; ++rr) {
-      acc[2 * rr] += a[rr].x * vc.x - a[rr].y * vc.y;
-      acc[2 * rr + 1] += a[rr].x * vc.y + a[rr].y * vc.x;
-      col.x += a[rr].x * vr[rr].x + a[rr].y * vr[rr].y;
-      col.y += a[rr].x * vr[rr].y - a[rr].y * vr[rr].x;
+      for (int rr = 0; rr < SYR; ++rr) {
+        const int r = rstart + rr;
+        const cplx v = dm_ldg(A, (size_t)min(r, n - 1) * lda + ccu);
+        a[u][rr] = (vld[u] && r < n) ? v : zero;
+      }
     }
-    const int pb = t & 1;  // double buffer: the reader of chunk t-1 may still be summing
-    colbuf[pb][wave][lane] = col;
+    const int pb = t & 1;  // double buffer: the reader of iteration t-1 may still be summing
+#pragma unroll
+    for (int u = 0; u < SYC; ++u) {
+      cplx col = zero;
+#pragma unroll
+      for (int rr = 0; rr < SYR; ++rr) {
+        acc[2 * rr] += a[u][rr].x * vcu[u].x - a[u][rr].y * vcu[u].y;
+        acc[2 * rr + 1] += a[u][rr].x * vcu[u].y + a[u][rr].y * vcu[u].x;
+        col.x += a[u][rr].x * vr[rr].x + a[u][rr].y * vr[rr].y;
+        col.y += a[u][rr].x * vr[rr].y - a[u][rr].y * vr[rr].x;
+      }
+      colbuf[pb][u][wave][lane] = col;
+    }
     __syncthreads();
-    if (wave == (t & 3) && valid)
-      dm_stg(pc, c, cadd(cadd(colbuf[pb][0][lane], colbuf[pb][1][lane]), cadd(colbuf[pb][2][lane], colbuf[pb][3][lane])));
+#pragma unroll
+    for (int u = 0; u < SYC; ++u)
+      if (wave == ((t * SYC + u) & 3) && vld[u])
+        dm_stg(pc, c0 + 64 * u + lane,
+               cadd(cadd(colbuf[pb][u][0][lane], colbuf[pb][u][1][lane]), cadd(colbuf[pb][u][2][lane], colbuf[pb][u][3][lane])));
   }
   // Transposing butterfly: the 2 SYR per-lane partial sums are folded so that lane L ends up with
   // the wave total of entry L / PER (2 SYR + log2(PER) shuffles instead of 2 SYR full reductions).
