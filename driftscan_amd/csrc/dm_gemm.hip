@@ -25,13 +25,15 @@
 #include "dm_kernels.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
 constexpr int BM = 64, BN = 64, BK = 16, LDP = 17;
 
 template <bool B_REAL>
-__global__ __launch_bounds__(256) void zgemm_grouped_kernel(const dm_gemm_desc* __restrict__ descs,
+__global__ __launch_bounds__(256, 3) void zgemm_grouped_kernel(const dm_gemm_desc* __restrict__ descs,
                                                             const dm_gemm_tile* __restrict__ tiles,
                                                             int ntiles) {
   __shared__ double As_re[BM * LDP], As_im[BM * LDP];
@@ -43,9 +45,17 @@ __global__ __launch_bounds__(256) void zgemm_grouped_kernel(const dm_gemm_desc* 
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = t.tm * BM, n0 = t.tn * BN;
+  // 16x16 MFMA blocks of this wave that lie inside the matrix: ragged edges (the per-frequency
+  // blocks of the covariance projections are <= 92 wide) skip the MFMAs of the padding
+  bool vi[2], vj[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    vi[i] = m0 + wm * 32 + i * 16 < d.M;
+    vj[i] = n0 + wn * 32 + i * 16 < d.N;
+  }
 
   const cplx* __restrict__ A = reinterpret_cast<const cplx*>(d.A);
   const cplx* __restrict__ Bc = reinterpret_cast<const cplx*>(d.B);
@@ -145,18 +155,20 @@ __global__ __launch_bounds__(256) void zgemm_grouped_kernel(const dm_gemm_desc* 
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc_re[i][j] = dm_mfma(a_re[i], b_re[j], acc_re[i][j]);
-          acc_im[i][j] = dm_mfma(a_im[i], b_re[j], acc_im[i][j]);
-        }
+        for (int j = 0; j < 2; ++j)
+          if (vi[i] && vj[j]) {
+            acc_re[i][j] = dm_mfma(a_re[i], b_re[j], acc_re[i][j]);
+            acc_im[i][j] = dm_mfma(a_im[i], b_re[j], acc_im[i][j]);
+          }
       if (!B_REAL) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            acc_re[i][j] = dm_mfma(a_imn[i], b_im[j], acc_re[i][j]);
-            acc_im[i][j] = dm_mfma(a_re[i], b_im[j], acc_im[i][j]);
-          }
+          for (int j = 0; j < 2; ++j)
+            if (vi[i] && vj[j]) {
+              acc_re[i][j] = dm_mfma(a_imn[i], b_im[j], acc_re[i][j]);
+              acc_im[i][j] = dm_mfma(a_re[i], b_im[j], acc_im[i][j]);
+            }
       }
     }
   };
@@ -348,15 +360,49 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
         else { tiles.push_back(t); fl_c += 8.0 * rows * cols * d.K; }
       }
   }
+  // longest tiles first: a launch mixes problems of very different K, and a long tile that
+  // starts last sets the duration of the launch (stable, so tiles of one problem stay together)
+  auto by_k = [&](const dm_gemm_tile& a, const dm_gemm_tile& b) { return descs[a.desc].K > descs[b.desc].K; };
+  std::stable_sort(tiles.begin(), tiles.end(), by_k);
+  std::stable_sort(tiles_real.begin(), tiles_real.end(), by_k);
+  std::stable_sort(tiles_dd.begin(), tiles_dd.end(), by_k);
   size_t mark = dm_ws_mark(ctx);
   dm_gemm_desc* dd = dm_ws_upload(ctx, descs);
   if (!dd) return DM_ENOMEM;
   if (!tiles.empty()) {
     dm_gemm_tile* dt = dm_ws_upload(ctx, tiles);
     if (!dt) return DM_ENOMEM;
-    dm_prof_scope ps(ctx, DM_PROF_GEMM, fl_c);
-    hipLaunchKernelGGL(zgemm_grouped_kernel<false>, dim3((unsigned)tiles.size()), dim3(256), 0, ctx->stream, dd,
-                       dt, (int)tiles.size());
+    static const bool log = getenv("DM_GEMM_LOG") != nullptr;  // debugging aid: per-launch shape and rate
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (log) {
+      (void)hipEventCreate(&e0);
+      (void)hipEventCreate(&e1);
+      (void)hipEventRecord(e0, ctx->stream);
+    }
+    {
+      dm_prof_scope ps(ctx, DM_PROF_GEMM, fl_c);
+      hipLaunchKernelGGL(zgemm_grouped_kernel<false>, dim3((unsigned)tiles.size()), dim3(256), 0, ctx->stream, dd,
+                         dt, (int)tiles.size());
+    }
+    if (log) {
+      (void)hipEventRecord(e1, ctx->stream);
+      (void)hipEventSynchronize(e1);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      int kmin = 1 << 30, kmax = 0, mmax = 0, nmax = 0, rmw = 0;
+      double full = 0.0;
+      for (const auto& d : descs) {
+        if (d.M <= 0 || d.N <= 0 || (d.flags & (DM_GEMM_ALL_REAL | DM_GEMM_B_REAL))) continue;
+        kmin = std::min(kmin, d.K); kmax = std::max(kmax, d.K);
+        mmax = std::max(mmax, d.M); nmax = std::max(nmax, d.N);
+        rmw |= d.beta != 0.0;
+      }
+      for (const auto& t : tiles) full += 8.0 * BM * BN * descs[t.desc].K;
+      fprintf(stderr, "GEMMLOG tiles %6zu descs %5zu Mmax %5d Nmax %5d K %4d..%4d rmw %d  %8.3f ms  %6.2f TF (padded %6.2f)\n",
+              tiles.size(), descs.size(), mmax, nmax, kmin, kmax, rmw, ms, fl_c / ms / 1e9, full / ms / 1e9);
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+    }
   }
   if (!tiles_real.empty()) {
     dm_gemm_tile* dt = dm_ws_upload(ctx, tiles_real);
