@@ -387,27 +387,35 @@ __global__ __launch_bounds__(256) void trd_wx_kernel(const trd_mat* __restrict__
   }
 }
 
-// ---- T1 for small matrices (n <= TSM): the whole reduction in one launch, one workgroup per
-// matrix with the matrix resident in LDS (96 x 97 complex = 146 KB of the 160 KB).  Same
-// recurrences and conventions as the panel path with a panel of one vector (zhetd2): the
-// Gram-matrix eigenproblems of the SVD preconditioner (n <= ntel, thousands per launch) would
-// otherwise pay 2 n latency-bound launches for a few hundred KB of work.
+// ---- T1 + Q for small matrices (n <= TSM): one launch, one workgroup per matrix, the matrix
+// resident in LDS (96 x 97 complex = 146 KB of the 160 KB).  Same recurrences and conventions as
+// the panel path with a panel of one vector (zhetd2); the reflectors stay in the dead columns of
+// the LDS copy and the unitary Q = H_0 ... H_{n-2} is then accumulated in place (zung2r order)
+// and written out, so the back-transformation of these problems is a single product X = Q Z.
+// The Gram-matrix eigenproblems of the SVD preconditioner (n <= ntel, thousands per launch) would
+// otherwise pay 2 n latency-bound launches plus the whole compact-WY machinery for a few hundred
+// KB of work each.
 constexpr int TSM = 96;
 constexpr int TSP = TSM + 1;  // row pitch in complex elements: conflict-free column walks
+constexpr int TST = 512;      // threads
 
-__global__ __launch_bounds__(256) void trd_small_kernel(const trd_mat* __restrict__ ms) {
-  const trd_mat M = ms[blockIdx.x];
+struct trs_mat { const cplx* A; int lda; int n; cplx* Q; int ldq; double* d; double* e; };
+
+__global__ __launch_bounds__(TST) void trd_small_kernel(const trs_mat* __restrict__ ms) {
+  const trs_mat M = ms[blockIdx.x];
   const int n = M.n;
   if (n <= 0) return;
   extern __shared__ __align__(16) unsigned char trd_smem[];
   cplx* As = reinterpret_cast<cplx*>(trd_smem);          // TSM x TSP
   cplx* vs = As + TSM * TSP;                              // TSM
   cplx* ws = vs + TSM;                                    // TSM
-  cplx* ph = ws + TSM;                                    // 2 x TSM partial matvec
-  double* red = reinterpret_cast<double*>(ph + 2 * TSM);  // 8
+  cplx* ph = ws + TSM;                                    // 4 x TSM partial matvec
+  cplx* taus = ph + 4 * TSM;                              // TSM
+  double* red = reinterpret_cast<double*>(taus + TSM);    // 3 x 8
+  constexpr int NW = TST / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // the upper triangle is the reference (as in the panel path); mirror it
-  for (int idx = tid; idx < n * n; idx += 256) {
+  for (int idx = tid; idx < n * n; idx += TST) {
     const int r = idx / n, c = idx - r * n;
     if (c >= r) {
       const cplx a = M.A[(size_t)r * M.lda + c];
@@ -415,8 +423,9 @@ __global__ __launch_bounds__(256) void trd_small_kernel(const trd_mat* __restric
       if (c > r) As[c * TSP + r] = make_double2(a.x, -a.y);
     }
   }
+  if (tid < n) taus[tid] = make_double2(0.0, 0.0);
   __syncthreads();
-  const int r2 = tid % TSM, half = tid / TSM;  // matvec: two threads per row (tid < 2 TSM)
+  const int r2 = tid % TSM, part4 = tid / TSM;  // matvec: four threads per row (tid < 4 TSM)
   for (int k = 0; k < n - 1; ++k) {
     // --- Householder vector of column k: x_i = conj(A[k][i]), i > k
     cplx xi = make_double2(0.0, 0.0);
@@ -429,7 +438,9 @@ __global__ __launch_bounds__(256) void trd_small_kernel(const trd_mat* __restric
     part = dm_wave_sum(part);
     if (lane == 0) red[wave] = part;
     __syncthreads();
-    const double xnorm2 = (red[0] + red[1]) + (red[2] + red[3]);
+    double xnorm2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) xnorm2 += red[w];
     const cplx al = As[k * TSP + k + 1];
     const cplx alpha = make_double2(al.x, -al.y);
     double beta;
@@ -450,17 +461,17 @@ __global__ __launch_bounds__(256) void trd_small_kernel(const trd_mat* __restric
       if (tid == k + 1) vi = make_double2(1.0, 0.0);
       else if (tid > k + 1) vi = cmul(xi, scal);
       vs[tid] = vi;
-      if (tid > k) M.Vt[(size_t)k * n + tid] = vi;
     }
     if (tid == 0) {
       M.d[k] = As[k * TSP + k].x;
       M.e[k] = beta;
-      M.tau[k] = tau;
+      taus[k] = tau;
     }
     __syncthreads();
-    // --- p = A v over the trailing block (two half-rows per row)
-    if (tid < 2 * TSM && r2 < n && r2 > k) {
-      const int h0 = half ? (k + 1 + n + 1) / 2 : k + 1, h1 = half ? n : (k + 1 + n + 1) / 2;
+    // --- p = A v over the trailing block (four quarter-rows per row)
+    if (tid < 4 * TSM && r2 < n && r2 > k) {
+      const int len = n - (k + 1);
+      const int h0 = k + 1 + (len * part4) / 4, h1 = k + 1 + (len * (part4 + 1)) / 4;
       double pr = 0.0, pi = 0.0;
       const cplx* arow = As + r2 * TSP;
       for (int c = h0; c < h1; ++c) {
@@ -468,28 +479,31 @@ __global__ __launch_bounds__(256) void trd_small_kernel(const trd_mat* __restric
         pr += a.x * v.x - a.y * v.y;
         pi += a.x * v.y + a.y * v.x;
       }
-      ph[half * TSM + r2] = make_double2(pr, pi);
+      ph[part4 * TSM + r2] = make_double2(pr, pi);
     }
     __syncthreads();
     cplx pt = make_double2(0.0, 0.0);
     double dr = 0.0, di = 0.0;
     if (tid < n && tid > k) {
-      pt = cmul(tau, cadd(ph[tid], ph[TSM + tid]));
+      pt = cmul(tau, cadd(cadd(ph[tid], ph[TSM + tid]), cadd(ph[2 * TSM + tid], ph[3 * TSM + tid])));
       dr = pt.x * vi.x + pt.y * vi.y;  // conj(p) * v
       di = pt.x * vi.y - pt.y * vi.x;
     }
     dr = dm_wave_sum(dr);
     di = dm_wave_sum(di);
-    if (lane == 0) { red[4 + wave] = dr; red[8 + wave] = di; }
+    if (lane == 0) { red[8 + wave] = dr; red[16 + wave] = di; }
     __syncthreads();
-    const cplx dot = make_double2((red[4] + red[5]) + (red[6] + red[7]), (red[8] + red[9]) + (red[10] + red[11]));
-    const cplx coef = cscale(cmul(tau, dot), 0.5);
+    double dre = 0.0, dim = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { dre += red[8 + w]; dim += red[16 + w]; }
+    const cplx coef = cscale(cmul(tau, make_double2(dre, dim)), 0.5);
     if (tid < n) ws[tid] = tid > k ? csub(pt, cmul(coef, vi)) : make_double2(0.0, 0.0);
     __syncthreads();
-    // --- A -= v w^H + w v^H on the trailing block (full storage keeps the matvec simple)
+    // --- A -= v w^H + w v^H on the trailing block (full storage keeps the matvec simple);
+    //     column k below the subdiagonal is dead from here on and keeps v_k for the Q accumulation
     {
       const int tx = tid & 31, ty = tid >> 5;
-      for (int i = k + 1 + ty; i < n; i += 8) {
+      for (int i = k + 1 + ty; i < n; i += TST / 32) {
         const cplx v_i = vs[i], w_i = ws[i];
         cplx* arow = As + i * TSP;
         for (int c = k + 1 + tx; c < n; c += 32) {
@@ -500,10 +514,49 @@ __global__ __launch_bounds__(256) void trd_small_kernel(const trd_mat* __restric
           arow[c] = a;
         }
       }
+      if (tid < n && tid > k + 1) As[tid * TSP + k] = vi;
     }
     __syncthreads();
   }
   if (tid == 0) M.d[n - 1] = As[(n - 1) * TSP + n - 1].x;
+  // ---- Q = H_0 ... H_{n-2} in place (reflector i: 1 at row i+1, As[r][i] for r >= i+2)
+  // step i (descending): apply H_i to the finished columns c >= i+2 (rows >= i+1), then form column i+1
+  const int csub4 = tid & 3, ccol = tid >> 2;  // four threads per column
+  for (int i = n - 2; i >= 0; --i) {
+    const cplx tau = taus[i];
+    const int c = i + 2 + ccol;
+    if (c < n) {
+      double sr = 0.0, si = 0.0;
+      for (int r = i + 1 + csub4; r < n; r += 4) {
+        const cplx v = (r == i + 1) ? make_double2(1.0, 0.0) : As[r * TSP + i];
+        const cplx a = As[r * TSP + c];  // conj(v) * a
+        sr += v.x * a.x + v.y * a.y;
+        si += v.x * a.y - v.y * a.x;
+      }
+      sr += __shfl_xor(sr, 1, 64); si += __shfl_xor(si, 1, 64);
+      sr += __shfl_xor(sr, 2, 64); si += __shfl_xor(si, 2, 64);
+      const cplx ts = cmul(tau, make_double2(sr, si));
+      for (int r = i + 1 + csub4; r < n; r += 4) {
+        const cplx v = (r == i + 1) ? make_double2(1.0, 0.0) : As[r * TSP + i];
+        As[r * TSP + c] = csub(As[r * TSP + c], cmul(v, ts));
+      }
+    }
+    __syncthreads();
+    if (tid < n) {
+      cplx q;
+      if (tid <= i) q = make_double2(0.0, 0.0);
+      else if (tid == i + 1) q = make_double2(1.0 - tau.x, -tau.y);
+      else { const cplx v = As[tid * TSP + i]; q = cmul(make_double2(-tau.x, -tau.y), v); }
+      As[tid * TSP + i + 1] = q;
+    }
+    __syncthreads();
+  }
+  if (tid < n) As[tid * TSP] = make_double2(tid == 0 ? 1.0 : 0.0, 0.0);
+  __syncthreads();
+  for (int idx = tid; idx < n * n; idx += TST) {
+    const int r = idx / n, c = idx - r * n;
+    M.Q[(size_t)r * M.ldq + c] = As[r * TSP + c];
+  }
 }
 
 // ---- T2: implicit QL/QR on the tridiagonal (LAPACK dsteqr scheme), recording rotations ------
@@ -1553,6 +1606,7 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
   }
   if (nch > 1 && !g_side.s) DM_HIP(ctx, hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking));
 
+  bool small_path = false;  // set by phase_T1 when the chunk went through trd_small (explicit Q in Ut)
   auto phase_T1 = [&](const std::vector<int>& ch) -> int {
     if (ch.empty()) return DM_OK;
     const int nc = (int)ch.size();
@@ -1570,15 +1624,24 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
     trd_mat* d_tm = dm_ws_upload(ctx, tm);
     if (!d_tm) return DM_ENOMEM;
     if (cmax <= TSM && !getenv("DM_TRD_NOSMALL")) {
-      const size_t lds = sizeof(cplx) * (TSM * TSP + 4 * TSM) + sizeof(double) * 16;
+      // small matrices: tridiagonal form and the explicit Q in one launch (Q into Ut, leading dimension n)
+      std::vector<trs_mat> sm(nc);
+      for (int i = 0; i < nc; ++i) {
+        const int p = ch[i];
+        sm[i] = trs_mat{probs[p].C, probs[p].ldc, probs[p].n, Ut + off[p], probs[p].n, dd + offn[p], ee + offn[p]};
+      }
+      trs_mat* d_sm = dm_ws_upload(ctx, sm);
+      if (!d_sm) return DM_ENOMEM;
+      const size_t lds = sizeof(cplx) * (TSM * TSP + 7 * TSM) + sizeof(double) * 24;
       static bool attr = false;
       if (!attr) {
         DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(trd_small_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
       }
-      hipLaunchKernelGGL(trd_small_kernel, dim3(nc), dim3(256), lds, ctx->stream, d_tm);
+      hipLaunchKernelGGL(trd_small_kernel, dim3(nc), dim3(TST), lds, ctx->stream, d_sm);
       DM_HIP(ctx, hipGetLastError());
+      small_path = true;
       return DM_OK;
     }
     for (int k0 = 0; k0 < cmax; k0 += TNB) {
@@ -1691,6 +1754,24 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
       cm[i] = cvt_mat{zfinal.empty() ? Zt + off[ch[i]] : zfinal[ch[i]], probs[ch[i]].C, probs[ch[i]].ldc, probs[ch[i]].n};
     cvt_mat* d_cm = dm_ws_upload(ctx, cm);
     if (!d_cm) return DM_ENOMEM;
+    if (small_path) {
+      // X = Q Z with the explicit Q of trd_small and the real eigenvectors Z of the tridiagonal
+      // (Z[c * n + r], eigenvector-major) as one complex x real product per matrix
+      std::vector<dm_gemm_desc> g;
+      for (int i = 0; i < nc; ++i) {
+        const int p = ch[i];
+        const int n = probs[p].n;
+        if (n <= 0) continue;
+        g.push_back(dm_gemm_make(Ut + off[p], n, 1, false, cm[i].Zt, 1, n, false, probs[p].C, probs[p].ldc, n, n, n, 1.0,
+                                 0.0, nullptr, DM_GEMM_B_REAL));
+      }
+      DM_TRY(dm_gemm_grouped_launch(ctx, g));
+      std::vector<dm_tdesc> tr;
+      for (int p : ch) tr.push_back(dm_tdesc{probs[p].C, probs[p].ldc, probs[p].W, probs[p].ldw, probs[p].n, probs[p].n});
+      DM_TRY(dm_conj_transpose_batched(ctx, tr));
+      DM_HIP(ctx, hipGetLastError());
+      return DM_OK;
+    }
     const int tb = (cmax + 31) / 32;
     hipLaunchKernelGGL(zt_to_x_kernel, dim3(tb, tb, nc), dim3(256), 0, ctx->stream, d_cm);
     // ---- T factors of all blocks up front (they depend on V only), batched over blocks and matrices:
