@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void jac_inner_kernel(const jac_item* __restri
                                                         const cplx* __restrict__ Gbuf, cplx* __restrict__ Qbuf,
                                                         unsigned long long* __restrict__ offmax,
                                                         int* __restrict__ skip, double tol_outer,
-                                                        double tol_inner) {
+                                                        double tol_inner, int measure_only) {
   extern __shared__ __align__(16) unsigned char smem[];
   cplx* G = reinterpret_cast<cplx*>(smem);
   cplx* Q = G + JP * GP;
@@ -206,9 +206,9 @@ __global__ __launch_bounds__(256) void jac_inner_kernel(const jac_item* __restri
   mo = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
   if (tid == 0) {
     atomicMax(&offmax[it.prob], (unsigned long long)__double_as_longlong(mo));
-    skip[it.q] = (mo <= tol_outer) ? 1 : 0;
+    skip[it.q] = (mo <= tol_outer || measure_only) ? 1 : 0;
   }
-  if (mo <= tol_outer) return;  // uniform across the block
+  if (mo <= tol_outer || measure_only) return;  // uniform across the block
 
   // ---- cyclic Jacobi, 63 parallel steps of 32 disjoint rotations per sweep
   for (int sweep = 0; sweep < 24; ++sweep) {
@@ -655,8 +655,34 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
     hipLaunchKernelGGL(jac_floor_kernel, dim3(np), dim3(256), 0, ctx->stream, d_key, sigma_stride, d_nrows,
                        d_floor, e4 * e4);
   }
+  const double tol_outer = 1e-13, tol_inner = 1e-15;
+  const int nrounds = (int)plan.round_begin.size() - 1;
+  std::vector<unsigned long long> h_off(np);
+  // Measuring pass (no rotations): problems whose rows are already orthogonal to tolerance — the
+  // pseudo-inverse pass of an unpolarised telescope sees exactly the rows the previous pass
+  // produced — skip the preconditioner and the sweeps.  (Re-diagonalising their Gram matrix would
+  // even hurt: it is only accurate to eps sigma_1^2 and disturbs the small rows.)
+  {
+    DM_HIP(ctx, hipMemsetAsync(d_off, 0, sizeof(unsigned long long) * np, ctx->stream));
+    for (int r = 0; r < nrounds; ++r) {
+      const int nb = plan.round_begin[r], ni = plan.round_begin[r + 1] - nb;
+      if (ni == 0) continue;
+      hipLaunchKernelGGL(jac_gram_kernel, dim3(ni), dim3(256), 0, ctx->stream, d_items + nb, d_active, d_G,
+                         (unsigned long long*)nullptr);
+      hipLaunchKernelGGL(jac_inner_kernel<false>, dim3(ni), dim3(256), INNER_LDS, ctx->stream, d_items + nb, d_active,
+                         (const double*)d_floor, d_G, d_Q, d_off, d_skip, tol_outer, tol_inner, 1);
+    }
+    DM_HIP(ctx, hipGetLastError());
+    DM_TRY(dm_download(ctx, h_off.data(), d_off, sizeof(unsigned long long) * np));
+    for (int p = 0; p < np; ++p) {
+      double mo;
+      std::memcpy(&mo, &h_off[p], sizeof(double));
+      active[p] = (nrows[p] > 1 && mo > tol_outer) ? 1 : 0;
+    }
+    DM_TRY(dm_upload(ctx, d_active, active.data(), sizeof(int) * np));
+  }
   // Preconditioner: one Hermitian eigendecomposition of the full Gram matrix G = X X^H of every
-  // problem (batched tridiagonal solver) followed by Z <- W Z.  On its own this would only be
+  // (still active) problem (batched tridiagonal solver) followed by Z <- W Z.  On its own this would only be
   // accurate to eps ||X||^2 (the Gram squares the condition number), but it brings every pair of
   // rows to |cos| <~ eps sigma_1 / sigma_i, from where the Jacobi sweeps below — which recompute
   // the Gram blocks from the rows themselves and therefore keep full relative accuracy — converge
@@ -673,7 +699,7 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
     std::vector<dm_jac_herm_problem> hp;
     for (int p = 0; p < np; ++p) {
       const dm_jac_problem& P = probs[p];
-      if (P.nrows < 1) continue;
+      if (P.nrows < 1 || !active[p]) continue;
       const cplx* X = P.Z + (size_t)P.row0 * P.ld + P.gc0;
       g.push_back(dm_gemm_make(X, P.ld, 1, false, X, 1, P.ld, true, Gm + goff[p], P.nrows, P.nrows, P.nrows,
                                P.gc1 - P.gc0));
@@ -693,29 +719,33 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
       DM_TRY(dm_sort_rows_by_key(ctx, sp, evp, sigma_stride, true));  // largest eigenvalue first
       // Z <- W Z through the temporary, then back
       std::vector<dm_gemm_desc> ga;
+      std::vector<jac_pdesc> pda;   // the scatter only touches the problems that were transformed
+      std::vector<size_t> toffa;
       size_t k = 0;
       for (int p = 0; p < np; ++p) {
         const dm_jac_problem& P = probs[p];
-        if (P.nrows < 1) continue;
+        if (P.nrows < 1 || !active[p]) continue;
         ga.push_back(dm_gemm_make(hp[k].W, P.nrows, 1, false, P.Z + (size_t)P.row0 * P.ld, P.ld, 1, false,
                                   d_tmp + toff[p], P.ncols, P.nrows, P.ncols, P.nrows));
+        pda.push_back(pd[p]);
+        toffa.push_back(toff[p]);
         ++k;
       }
       DM_TRY(dm_gemm_grouped_launch(ctx, ga));
+      jac_pdesc* d_pda = dm_ws_upload(ctx, pda);
+      size_t* d_toffa = dm_ws_upload(ctx, toffa);
+      if (!d_pda || !d_toffa) return DM_ENOMEM;
       const int gx0 = std::max(1, std::min(8, (maxcols + 255) / 256));
-      hipLaunchKernelGGL(jac_scatter_back_kernel, dim3(gx0, maxrows, np), dim3(256), 0, ctx->stream, d_pd, d_tmp,
-                         d_toff);
+      hipLaunchKernelGGL(jac_scatter_back_kernel, dim3(gx0, maxrows, (unsigned)pda.size()), dim3(256), 0, ctx->stream,
+                         d_pda, d_tmp, d_toffa);
     }
   }
 
-  const double tol_outer = 1e-13, tol_inner = 1e-15;
-  const int nrounds = (int)plan.round_begin.size() - 1;
   const int chunks = (maxcols + APPLY_CHUNK - 1) / APPLY_CHUNK;
-  std::vector<unsigned long long> h_off(np);
   int sweep = 0;
   const int max_sweeps = 40;
   bool any_pairs = false;
-  for (int p = 0; p < np; ++p) any_pairs |= nrows[p] > 1;
+  for (int p = 0; p < np; ++p) any_pairs |= active[p] != 0;
   for (; any_pairs && sweep < max_sweeps; ++sweep) {
     DM_HIP(ctx, hipMemsetAsync(d_off, 0, sizeof(unsigned long long) * np, ctx->stream));
     for (int r = 0; r < nrounds; ++r) {
@@ -731,7 +761,7 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
       {
         dm_prof_scope ps(ctx, DM_PROF_JAC_INNER, 0.0);
         hipLaunchKernelGGL(jac_inner_kernel<false>, dim3(ni), dim3(256), INNER_LDS, ctx->stream, d_items + nb,
-                           d_active, (const double*)d_floor, d_G, d_Q, d_off, d_skip, tol_outer, tol_inner);
+                           d_active, (const double*)d_floor, d_G, d_Q, d_off, d_skip, tol_outer, tol_inner, 0);
       }
       {
         dm_prof_scope ps(ctx, DM_PROF_JAC_APPLY, 0.0);
@@ -875,7 +905,7 @@ int dm_jacobi_herm(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, d
       {
         dm_prof_scope ps(ctx, DM_PROF_JAC_INNER, 0.0);
         hipLaunchKernelGGL(jac_inner_kernel<true>, dim3(ni), dim3(256), INNER_LDS, ctx->stream, icur, d_active,
-                           d_floor, (const cplx*)nullptr, d_Q, d_off, d_skip, tol_outer, tol_inner);
+                           d_floor, (const cplx*)nullptr, d_Q, d_off, d_skip, tol_outer, tol_inner, 0);
       }
       {
         dm_prof_scope ps(ctx, DM_PROF_JAC_APPLY, 0.0);
