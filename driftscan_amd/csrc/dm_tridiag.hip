@@ -947,7 +947,7 @@ __global__ __launch_bounds__(64) void larft_kernel(const tf_mat* __restrict__ ts
 //   grouped DGEMM         Z_parent = U^T Z_children                                (MFMA)
 // Parallel depth O(log n) instead of the ~1.1 n^2 serial rotations of QL.
 // ===========================================================================
-constexpr int DC_LEAF = 64;
+constexpr int DC_LEAF = 32;
 constexpr int DC_MAXNODE = 4096;  // LDS-resident setup; larger problems use the QL path
 
 struct dc_mat {
@@ -1108,17 +1108,38 @@ __global__ __launch_bounds__(256) void dc_permute_kernel(const dc_mat* __restric
     }
     __syncthreads();
   }
-  // gather the non-deflated vectors for the GEMM, copy the deflated ones to their final place
-  for (int j = 0; j < o.k; ++j) {
-    const double* src = Zc + (size_t)(lo + M.keepcol[lo + j]) * n + lo;
-    double* dst = M.Zp + (size_t)(lo + j) * n + lo;
-    for (int i = tid; i < nn; i += 256) dst[i] = src[i];
-  }
-  for (int t = 0; t < o.ndefl; ++t) {
-    const double* src = Zc + (size_t)(lo + M.deflcol[lo + t]) * n + lo;
-    double* dst = Zn + (size_t)(lo + o.k + t) * n + lo;
-    for (int i = tid; i < nn; i += 256) dst[i] = src[i];
-    if (tid == 0) lamn[lo + o.k + t] = M.defld[lo + t];
+}
+
+// gather the non-deflated vectors for the GEMM, copy the deflated ones to their final place;
+// grid = (vector tiles of DCG, nodes), one wave per vector
+constexpr int DCG = 16;
+__global__ __launch_bounds__(256) void dc_gather_kernel(const dc_mat* __restrict__ ms, const dc_node* __restrict__ nodes,
+                                                        const dc_nodeout* __restrict__ outs) {
+  const dc_node nd = nodes[blockIdx.y];
+  const dc_mat M = ms[nd.mat];
+  const dc_nodeout o = outs[blockIdx.y];
+  const int nn = nd.n1 + nd.n2, lo = nd.lo, n = M.n;
+  if ((int)blockIdx.x * DCG >= nn) return;
+  const double* Zc = nd.flip ? M.ZB : M.ZA;
+  double* Zn = nd.flip ? M.ZA : M.ZB;
+  double* lamn = nd.flip ? M.lamA : M.lamB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int u = wave; u < DCG; u += 4) {
+    const int j = blockIdx.x * DCG + u;
+    if (j >= nn) break;
+    const double* src;
+    double* dst;
+    if (j < o.k) {
+      src = Zc + (size_t)(lo + M.keepcol[lo + j]) * n + lo;
+      dst = M.Zp + (size_t)(lo + j) * n + lo;
+    } else {
+      const int t = j - o.k;
+      if (t >= o.ndefl) break;
+      src = Zc + (size_t)(lo + M.deflcol[lo + t]) * n + lo;
+      dst = Zn + (size_t)(lo + o.k + t) * n + lo;
+      if (lane == 0) lamn[lo + o.k + t] = M.defld[lo + t];
+    }
+    for (int i = lane; i < nn; i += 64) dst[i] = src[i];
   }
 }
 
@@ -1436,6 +1457,8 @@ static int dc_solve(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, 
     hipLaunchKernelGGL(dc_setup_kernel, dim3(nn_nodes), dim3(256), (size_t)36 * maxnn + 64, ctx->stream, d_dm, d_nodes,
                        d_out);
     hipLaunchKernelGGL(dc_permute_kernel, dim3(nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
+    hipLaunchKernelGGL(dc_gather_kernel, dim3((maxnn + DCG - 1) / DCG, nn_nodes), dim3(256), 0, ctx->stream, d_dm,
+                       d_nodes, d_out);
     DM_HIP(ctx, hipGetLastError());
     std::vector<dc_nodeout> ho(nn_nodes);
     DM_TRY(dm_download(ctx, ho.data(), d_out, sizeof(dc_nodeout) * nn_nodes));
