@@ -39,33 +39,65 @@ def build_objects(tmpdir):
     return tel, bt, kl
 
 
-def hot_path_step(tel, bt, kl, ctx, stage_times=None):
-    """One pass over all m-blocks; everything stays on the device."""
+_pool = None
+
+
+def _svd_kl_group(bt, kl, beam_all, ms):
+    """SVD chain + KL for one group of m-blocks on the calling thread's context; returns
+    (seconds in SVD, seconds in KL) as seen by this thread."""
+    import torch
+
+    from driftscan_amd import device
+
+    ctx = device.get_context()
+    t0 = time.perf_counter()
+    idx = torch.as_tensor(ms, device=beam_all.device)
+    res = bt.svd_device(beam_all.index_select(0, idx))                # SVD chain + pinv, the whole group at once
+    sv = res["singularvalues"].cpu().numpy()
+    ctx.sync()
+    t1 = time.perf_counter()
+    for i, mi in enumerate(ms):
+        bt._dev[mi] = dict(beam_svd=res["beam_svd"][i], beam_ut=res["beam_ut"][i], singularvalues=sv[i])
+    out = None
+    for batch in kl._batches(list(ms)):
+        out = kl._transform_batch(batch, to_host=False)               # projections + eigh_gen, products stay in HBM
+    ctx.sync()
+    return t1 - t0, time.perf_counter() - t1, out
+
+
+def hot_path_step(tel, bt, kl, ctx, stage_times=None, streams=1):
+    """One pass over all m-blocks; everything stays on the device.  After the beam-transfer
+    generation the m-blocks are dealt round-robin into `streams` groups, each driven by its own
+    thread / libdriftmi context / HIP stream, so that the launch-latency-bound phases of one
+    group (Jacobi sweeps, the tail of the tridiagonalisation) overlap with the MFMA- and
+    HBM-bound phases of the other."""
     import torch
 
     from driftscan_amd import btgen
 
-    def mark():
-        if stage_times is not None:
-            torch.cuda.synchronize()
-            return time.perf_counter()
-        return 0.0
-
-    t0 = mark()
-    beam_all = btgen.beam_m_all(tel, ctx=ctx)                       # (mmax+1, F, 2, B, P, L)
-    t1 = mark()
-    res = bt.svd_device(beam_all)                                   # SVD chain + pinv, all m at once
-    t2 = mark()
+    global _pool
+    t0 = time.perf_counter()
+    beam_all = btgen.beam_m_all(tel, ctx=ctx)                         # (mmax+1, F, 2, B, P, L)
+    ctx.sync()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
     ms = list(range(tel.mmax + 1))
-    sv = res["singularvalues"].cpu().numpy()
-    bt._dev = {mi: dict(beam_svd=res["beam_svd"][mi], beam_ut=res["beam_ut"][mi], singularvalues=sv[mi]) for mi in ms}
-    out = None
-    for batch in kl._batches(ms):
-        out = kl._transform_batch(batch, to_host=False)             # projections + eigh_gen, products stay in HBM
-    t3 = mark()
+    groups = [ms[g::streams] for g in range(streams)]
+    if streams == 1:
+        parts = [_svd_kl_group(bt, kl, beam_all, groups[0])]
+    else:
+        if _pool is None or _pool._max_workers != streams:
+            from concurrent.futures import ThreadPoolExecutor
+
+            _pool = ThreadPoolExecutor(max_workers=streams)
+        futs = [_pool.submit(_svd_kl_group, bt, kl, beam_all, g) for g in groups]
+        parts = [f.result() for f in futs]
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
     if stage_times is not None:
-        stage_times.append((t1 - t0, t2 - t1, t3 - t2))
-    return out
+        tsvd = max(p[0] for p in parts)
+        stage_times.append((t1 - t0, tsvd, (t3 - t1) - tsvd))
+    return parts[0][2]
 
 
 def cpu_baseline(tel, bt, kl, budget_s=25.0):
@@ -122,6 +154,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DRIFT_BENCH_STREAMS", "1")),
+                    help="concurrent m-block groups per GPU (threads x HIP streams); 2 gives +7 %% m-blocks/s but the "
+                         "per-kernel durations (and so the roofline figure) then include the interference")
     args = ap.parse_args()
 
     import tempfile
@@ -149,7 +184,7 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         tel, bt, kl = build_objects(tmp)
         for _ in range(args.warmup):
-            hot_path_step(tel, bt, kl, ctx)
+            hot_path_step(tel, bt, kl, ctx, streams=args.streams)
         # A full (generation-2) cycle collection walks every object torch/numpy created at import
         # (~45 ms here) and would land at a random point of the timed region: collect now and move
         # the survivors to the permanent generation, as a long-running pipeline process would.
@@ -157,17 +192,22 @@ def main():
 
         gc.collect()
         gc.freeze()
-        ctx.prof_reset(True)
+        for c in list(device._all):  # every context (main thread + stream workers)
+            c.prof_reset(True)
         stage = []
         parallel.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            hot_path_step(tel, bt, kl, ctx, stage_times=stage)
+            hot_path_step(tel, bt, kl, ctx, stage_times=stage, streams=args.streams)
         torch.cuda.synchronize()
         parallel.barrier()
         dt = time.perf_counter() - t0
-        prof = ctx.prof_report()
+        prof = {}
+        for c in list(device._all):
+            for k, v in c.prof_report().items():
+                a = prof.setdefault(k, dict(ms=0.0, flops=0.0, launches=0))
+                a["ms"] += v["ms"]; a["flops"] += v["flops"]; a["launches"] += v["launches"]
         if world > 1 or force_dist:
             import torch.distributed as dist
 
@@ -221,7 +261,7 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": "configs[1]: 32-feed unpolarised cylinder, nfreq=16, nbase=46, lmax=mmax=128, "
                                        "129 m-blocks per GPU per step, KLTransform with foregrounds",
-                           "nfreq": 16, "nbase": 46, "lmax": 128, "mmax": 128, "sharding": "m-blocks, replicas per GPU"},
+                           "nfreq": 16, "nbase": 46, "lmax": 128, "mmax": 128, "sharding": "m-blocks, replicas per GPU", "streams_per_gpu": args.streams},
                 "stage_ms": {"btgen": 1e3 * st[0], "svd": 1e3 * st[1], "kl": 1e3 * st[2]},
                 "kernels_ms": {k: v["ms"] / args.steps for k, v in prof.items()},
                 "roofline": roofline,

@@ -30,6 +30,7 @@ struct dm_ctx {
   // pinned host staging for small descriptor uploads / flag read-backs
   char* hpin = nullptr;
   size_t hpin_cap = 0;
+  size_t hpin_used = 0;  // ring offset (per context: contexts may be driven from different threads)
   std::string err;
   // optional per-kernel-class timing (HIP events on ctx->stream) and flop accounting
   bool prof_on = false;

@@ -6,7 +6,6 @@
 namespace {
 constexpr size_t kAlign = 256;
 constexpr size_t kPinned = 64u << 20;  // staging ring for descriptor uploads
-size_t g_pin_used = 0;                 // per-process is fine: one ctx per process/GPU in practice
 inline size_t align_up(size_t x) { return (x + kAlign - 1) & ~(kAlign - 1); }
 }  // namespace
 
@@ -68,13 +67,13 @@ int dm_upload(dm_ctx* ctx, void* dst, const void* src, size_t bytes) {
     return DM_OK;
   }
   size_t need = align_up(bytes);
-  if (g_pin_used + need > ctx->hpin_cap) {
+  if (ctx->hpin_used + need > ctx->hpin_cap) {
     // wrap the ring: make sure every earlier staged copy has been consumed
     DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    g_pin_used = 0;
+    ctx->hpin_used = 0;
   }
-  char* stage = ctx->hpin + g_pin_used;
-  g_pin_used += need;
+  char* stage = ctx->hpin + ctx->hpin_used;
+  ctx->hpin_used += need;
   std::memcpy(stage, src, bytes);
   DM_HIP(ctx, hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, ctx->stream));
   return DM_OK;

@@ -1,24 +1,50 @@
-"""Process-wide libdriftmi context (one GPU per process)."""
-import os
+"""libdriftmi contexts: one per (process, thread).
 
-_ctx = None
+One process drives one GPU (LOCAL_RANK selects it).  A context owns a HIP stream and a workspace
+arena; independent groups of m-blocks can be pushed through the library from different Python
+threads (ctypes releases the GIL during the calls), each on its own context, so that the
+latency-bound phases of one group overlap with the bandwidth- or MFMA-bound phases of another."""
+import os
+import threading
+
+_local = threading.local()
+_all = []
+_lock = threading.Lock()
+_default_ws = None
+_gen = 0  # bumped by reset_context so that every thread drops its closed context
 
 
 def get_context(workspace_bytes=None):
-    """The Context bound to this process's GPU (LOCAL_RANK selects it).  Raises if no GPU."""
-    global _ctx
-    if _ctx is None:
+    """The Context of the calling thread (created on first use).  Raises if no GPU."""
+    global _default_ws
+    ctx = getattr(_local, "ctx", None)
+    if ctx is not None and getattr(_local, "gen", -1) != _gen:
+        ctx = None
+    if ctx is None:
         from ._lib import Context
 
         dev = int(os.environ.get("LOCAL_RANK", "0"))
         if workspace_bytes is None:
+            workspace_bytes = _default_ws
+        if workspace_bytes is None:
             workspace_bytes = int(float(os.environ.get("DRIFTMI_WORKSPACE_GB", "8")) * (1 << 30))
-        _ctx = Context(dev, workspace_bytes=workspace_bytes)
-    return _ctx
+        if _default_ws is None:
+            _default_ws = workspace_bytes
+        ctx = Context(dev, workspace_bytes=workspace_bytes)
+        _local.ctx = ctx
+        _local.gen = _gen
+        with _lock:
+            _all.append(ctx)
+    return ctx
 
 
 def reset_context():
-    global _ctx
-    if _ctx is not None:
-        _ctx.close()
-    _ctx = None
+    """Close every context created so far (all threads)."""
+    global _default_ws, _gen
+    with _lock:
+        for c in _all:
+            c.close()
+        del _all[:]
+        _gen += 1
+    _local.ctx = None
+    _default_ws = None
