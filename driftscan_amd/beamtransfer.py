@@ -171,6 +171,8 @@ class BeamTransfer(config.Reader):
 
     generate_cache = generate
 
+    generate_cache = generate  # beamtransfer.py: old name kept by the reference
+
     def _generate_dirs(self):
         if parallel.rank0():
             os.makedirs(self.directory, exist_ok=True)
@@ -352,6 +354,85 @@ class BeamTransfer(config.Reader):
                          out, off, alpha=1.0, accumulate=False)
         ctx.sync()
         return out[: n * n].cpu().numpy().reshape(n, n)
+
+    # ---- pseudo-inverse of the full beam, map-making operators -------------------------------
+    noise_weight = True  # beamtransfer.py:314
+
+    def invbeam_m(self, mi):
+        """Moore-Penrose pseudo-inverse of the beam of one m, (nfreq, npol_sky, lmax+1, ntel)
+        (beamtransfer.py:317-358: pinv with rcond 1e-6 of the blocks weighted by the noise of
+        frequency 0).  On the device: one-sided Jacobi on [w B | I] gives W (w B) = S V^H with the
+        accumulated W riding along, so pinv = (S V^H)^H S^-2 W, one grouped ZGEMM with the cut
+        sigma > 1e-6 sigma_max folded into the contraction weights."""
+        tel = self.telescope
+        ctx = get_context()
+        F, T, S = self.nfreq, self.ntel, self.nsky
+        beam = self.beam_m(mi).reshape(F, 2, tel.npairs, S)
+        noisew = None
+        if self.noise_weight:
+            noisew = np.asarray(tel.noisepower(np.arange(tel.npairs), 0)).flatten() ** (-0.5)
+            beam = beam * noisew[np.newaxis, np.newaxis, :, np.newaxis]
+        beam = beam.reshape(F, T, S)
+        Z = np.zeros((F, T, S + T), dtype=np.complex128)
+        Z[:, :, :S] = beam
+        Z[:, :, S:] = np.eye(T)
+        dZ = ctx.to_device(Z)
+        sigma, _ = ctx.jacobi_rows(dZ, T, S + T, 0, S, S + T, stride=T * (S + T), batch=F)
+        ctx.sync()
+        sg = sigma.cpu().numpy()[:, :T]
+        smax = sg.max(axis=1, keepdims=True)
+        wts = np.where((sg > 1e-6 * smax) & (sg > 0.0), 1.0 / np.where(sg > 0.0, sg, 1.0) ** 2, 0.0)
+        dW = ctx.to_device(np.ascontiguousarray(wts))
+        out = ctx.empty((F, S, T), np.complex128)
+        # out[f] = (S V^H)^H diag(w) W :  A(m = sky, k = row) = conj(Z[f, k, m]),  B(k, n) = Z[f, k, S + n]
+        ctx.zgemm(dZ, dZ[:, :, S:], out, S, T, T, rsA=1, csA=S + T, rsB=S + T, csB=1, ldc=T, conjA=True, kscale=dW,
+                  batch=F, strideA=T * (S + T), strideB=T * (S + T), strideC=S * T, stride_kscale=T)
+        ctx.sync()
+        ib = out.cpu().numpy()
+        if self.noise_weight:
+            ib = (ib.reshape(-1, tel.npairs) * noisew).reshape(F, S, T)
+        return ib.reshape(F, tel.num_pol_sky, tel.lmax + 1, T)
+
+    def project_vector_telescope_to_sky(self, mi, vec):
+        """Map-making: [nfreq, ntel] -> [nfreq, npol, lmax+1] (beamtransfer.py:1014-1046)."""
+        tel = self.telescope
+        vec = np.asarray(vec).reshape(self.nfreq, self.ntel)
+        if np.all(vec == 0):
+            return np.zeros((self.nfreq, tel.num_pol_sky, tel.lmax + 1), dtype=np.complex128)
+        ib = self.invbeam_m(mi).reshape(self.nfreq, self.nsky, self.ntel)
+        return _device_bgemv(ib, vec).reshape(self.nfreq, tel.num_pol_sky, tel.lmax + 1)
+
+    project_vector_backward = project_vector_telescope_to_sky
+
+    def project_vector_backward_dirty(self, mi, vec):
+        """Dirty back-projection B^H (v / diag(B B^H)) (beamtransfer.py:1050-1072)."""
+        tel = self.telescope
+        vec = np.asarray(vec).reshape(self.nfreq, self.ntel)
+        if np.all(vec == 0):
+            return np.zeros((self.nfreq, tel.num_pol_sky, tel.lmax + 1), dtype=np.complex128)
+        beam = self.beam_m(mi).reshape(self.nfreq, self.ntel, self.nsky)
+        norm = np.einsum("ftk,ftk->ft", beam, beam.conj())
+        norm = np.where(norm < 1e-6, 0.0, 1.0 / np.where(norm == 0.0, 1.0, norm))
+        dbeam = np.ascontiguousarray(beam.transpose(0, 2, 1).conj())
+        return _device_bgemv(dbeam, vec * norm).reshape(self.nfreq, tel.num_pol_sky, tel.lmax + 1)
+
+    def project_matrix_sky_to_telescope(self, mi, mat, temponly=False):
+        """Sky covariance [pol, pol, l, f, f'] -> visibility basis [nfreq, ntel, nfreq, ntel]
+        (beamtransfer.py:1074-1112): the same grouped projection as the SVD-basis one with the
+        un-compressed beam (every frequency keeps all ntel rows)."""
+        tel = self.telescope
+        ctx = get_context()
+        F, T, P, L = self.nfreq, self.ntel, tel.num_pol_sky, tel.lmax + 1
+        n = F * T
+        off, tot = block_offsets([n])
+        out = ctx.empty((max(tot, 1),), np.complex128)
+        beam = ctx.to_device(np.ascontiguousarray(self.beam_m(mi).reshape(1, F, T, P, L)))
+        svnum = np.full((1, F), T, dtype=np.int32)
+        cl, mask = self._cl_device(mat)
+        ctx.project_cov(beam, svnum, cl, out, off, npol=1 if temponly else None, polmask=mask, l0=np.array([mi]),
+                        zero_first=True)
+        ctx.sync()
+        return out[: n * n].cpu().numpy().reshape(F, T, F, T)
 
     # ---- vector projections (light, host-side views of stored blocks) -----------------------
     def project_vector_sky_to_telescope(self, mi, vec):

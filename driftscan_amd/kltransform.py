@@ -291,6 +291,34 @@ class KLTransform(config.Reader):
 
         return _device_gemm(evecs, vec)
 
+    def project_vector_kl_to_svd(self, mi, vec, threshold=None):
+        """Eigenbasis vector back into the SVD (telescope) basis through the stored inverse
+        modes (kltransform.py:739-769)."""
+        evals, evecs = self.modes_m(mi, threshold)
+        if evals is None:
+            return np.zeros(self.beamtransfer.ndofmax, dtype=np.complex128)
+        if vec.shape[0] != evecs.shape[0]:
+            raise Exception("Vectors are incompatible.")
+        from .beamtransfer import _device_gemm
+
+        return _device_gemm(self.invmodes_m(mi, threshold), vec)
+
+    def skymodes_m(self, mi, threshold=None):
+        """KL modes rotated onto the sky, [nmodes, nfreq, nsky] (kltransform.py:663-708; like the
+        reference this assumes un-compressed modes of length nfreq * ntel)."""
+        evals, evecs = self.modes_m(mi, threshold=threshold)
+        if evals is None:
+            raise Exception("Don't seem to be any evals to use.")
+        bt = self.beamtransfer
+        beam = bt.beam_m(mi).reshape((bt.nfreq, bt.ntel, bt.nsky))
+        evecs = evecs.reshape((-1, bt.nfreq, bt.ntel))
+        evsky = np.zeros((evecs.shape[0], bt.nfreq, bt.nsky), dtype=np.complex128)
+        from .beamtransfer import _device_gemm
+
+        for fi in range(bt.nfreq):
+            evsky[:, fi, :] = _device_gemm(evecs[:, fi, :], beam[fi])
+        return evsky
+
     def project_vector_sky_to_kl(self, mi, vec, threshold=None):
         return self.project_vector_svd_to_kl(mi, self.beamtransfer.project_vector_sky_to_svd(mi, vec), threshold)
 

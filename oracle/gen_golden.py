@@ -354,13 +354,69 @@ def gen_pixel_kernels(ref):
 FGT_UNPOL, FGT_POL, THR_POL = 1.0, 1e-2, 1e-3
 
 
+def gen_projections(ref):
+    """A17 operators that do not depend on the SVD basis, by the reference: invbeam_m,
+    telescope->sky (map-making), dirty back-projection, sky covariance -> telescope, sky -> telescope."""
+    btmod = ref["beamtransfer"]
+    # The reference calls scipy.linalg.pinv(..., rcond=1e-6) (blockla.py:136 via beamtransfer.py:344);
+    # the scipy in this image (>= 1.14) dropped that keyword in favour of its documented successor
+    # `rtol` (same meaning: cutoff relative to the largest singular value).  Translate it for the
+    # duration of this generator so that the unmodified reference function runs.
+    import scipy.linalg as _sla
+
+    _pinv = _sla.pinv
+
+    def _pinv_compat(a, *args, rcond=None, **kw):
+        if rcond is not None:
+            kw["rtol"] = rcond
+        return _pinv(a, *args, **kw)
+
+    _sla.pinv = _pinv_compat
+    out = {}
+    for tag, F, B, P, lmax, mlist, seed in (("unpol", 3, 6, 1, 14, [0, 4], 3101), ("pol", 2, 5, 4, 10, [0, 3], 3102)):
+        rng = np.random.default_rng(seed)
+        L = lmax + 1
+        redundancy = rng.integers(1, 6, size=B).astype(np.float64)
+        npower = (2.5e-7 * (1.0 + 0.1 * np.arange(F))[:, None] / redundancy[None, :]).astype(np.float64)
+        tel = FakeTelescope(F, B, P, lmax, lmax, npower, tsys_flat=1.0)
+        bt = btmod.BeamTransfer("/mem/proj_%s/bt" % tag, telescope=tel)
+        cv = analytic_cl(tel.frequencies, L, P, "signal")
+        out[tag + "_dims"] = np.array([F, B, P, lmax])
+        out[tag + "_mlist"] = np.array(mlist)
+        out[tag + "_npower"] = npower
+        out[tag + "_cv"] = cv
+        for mi in mlist:
+            beam = synth_beam_m(rng, F, B, P, L, mi)
+            write_beam_file(ref, bt, mi, beam)
+            pre = "%s_m%d_" % (tag, mi)
+            vt = rng.standard_normal((F, 2 * B)) + 1j * rng.standard_normal((F, 2 * B))
+            vs = rng.standard_normal((F, P, L)) + 1j * rng.standard_normal((F, P, L))
+            vs[..., :mi] = 0.0
+            out[pre + "beam_m"] = beam
+            out[pre + "vec_tel"] = vt
+            out[pre + "vec_sky"] = vs
+            out[pre + "invbeam_m"] = bt.invbeam_m(mi)
+            out[pre + "tel_to_sky"] = bt.project_vector_telescope_to_sky(mi, vt)
+            out[pre + "backward_dirty"] = bt.project_vector_backward_dirty(mi, vt)
+            out[pre + "sky_to_tel"] = bt.project_vector_sky_to_telescope(mi, vs)
+            out[pre + "mat_sky_to_tel"] = bt.project_matrix_sky_to_telescope(mi, cv)
+            out[pre + "mat_sky_to_tel_temponly"] = bt.project_matrix_sky_to_telescope(mi, cv, temponly=True)
+    _sla.pinv = _pinv
+    np.savez_compressed(os.path.join(OUT, "projections.npz"), **out)
+    print("projections.npz")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = refimport.load()
+    if len(sys.argv) > 1 and sys.argv[1] == "projections":
+        gen_projections(ref)
+        return
     gen_matrix_ops(ref)
     gen_eigh_gen(ref)
     gen_geometry(ref)
     gen_pixel_kernels(ref)
+    gen_projections(ref)
     # moderately conditioned pencils (cond(N) ~ 1e5): 1e-10 parity is attainable by any
     # backward-stable solver
     gen_svd_kl(ref, "unpol", F=4, B=10, P=1, lmax=24, mlist=[0, 5, 20], polsvcut=1e-4,

@@ -138,3 +138,27 @@ def test_eigh_gen(golden_dir):
         assert_spectrum(ev, g[case + "_evals"], 1e-10, case)
         assert np.isclose(ac, float(g[case + "_ac"]), rtol=1e-6, atol=0.0) or ac == float(g[case + "_ac"])
     assert float(g["npd_ac"]) > 0.0
+
+
+# ---- A17 operators that do not depend on the SVD basis (oracle/projections.py) -----------------
+def test_projection_operators_match_reference(golden_dir):
+    from oracle import projections as op
+
+    g = np.load(os.path.join(golden_dir, "projections.npz"))
+    for tag in ("unpol", "pol"):
+        npw, cv = g[tag + "_npower"], g[tag + "_cv"]
+        nw0 = npw[0] ** -0.5
+        for mi in g[tag + "_mlist"]:
+            pre = "%s_m%d_" % (tag, mi)
+            bm = g[pre + "beam_m"]
+
+            def rel(a, b):
+                return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+            # bit-for-bit the same arithmetic as the reference -> 1e-13 is generous
+            assert rel(op.invbeam_m(bm, nw0), g[pre + "invbeam_m"]) < 1e-13
+            assert rel(op.project_vector_telescope_to_sky(bm, g[pre + "vec_tel"], nw0), g[pre + "tel_to_sky"]) < 1e-13
+            assert rel(op.project_vector_backward_dirty(bm, g[pre + "vec_tel"]), g[pre + "backward_dirty"]) < 1e-13
+            assert rel(op.project_vector_sky_to_telescope(bm, g[pre + "vec_sky"]), g[pre + "sky_to_tel"]) < 1e-13
+            assert rel(op.project_matrix_sky_to_telescope(bm, cv), g[pre + "mat_sky_to_tel"]) < 1e-13
+            assert rel(op.project_matrix_sky_to_telescope(bm, cv, True), g[pre + "mat_sky_to_tel_temponly"]) < 1e-13
