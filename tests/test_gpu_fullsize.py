@@ -1,0 +1,123 @@
+"""Parity at the FULL size of BASELINE.json configs[1] (32-feed unpolarised cylinder, 16 channels,
+lmax = mmax = 128, 129 m-blocks, ndof up to ~1200) through size-independent properties — the
+oracle would need minutes per m here:
+
+  BT-gen   one (f, b) column of a few m against the oracle's pixel-space restatement;
+  SVD      beam_svd = U^H (w B) with orthogonal rows whose norms are the singular values,
+           U^H (w^-1 scaling undone) orthonormal, beam_svd . invbeam_svd = I on the kept modes;
+  KL       E N E^H = I and E S E^H = diag(lambda), lambda ascending, against the covariances
+           the same step projected (tolerance from the conditioning of N, as LAPACK's own bound).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope="module")
+def step(tmp_path_factory):
+    import torch
+
+    import bench
+    from driftscan_amd import btgen, device
+
+    device.reset_context()
+    ctx = device.get_context(workspace_bytes=24 << 30)
+    tel, bt, kl = bench.build_objects(str(tmp_path_factory.mktemp("full")))
+    beam_all = btgen.beam_m_all(tel, ctx=ctx)
+    ctx.sync()
+    res = bt.svd_device(beam_all)
+    ctx.sync()
+    torch.cuda.synchronize()
+    return tel, bt, kl, ctx, beam_all, res
+
+
+def test_btgen_columns_against_oracle(step):
+    from oracle import btgen as ob
+
+    tel, bt, kl, ctx, beam_all, res = step
+    fsel, bsel = np.array([0, tel.nfreq - 1]), np.array([0, tel.nbase // 2, tel.nbase - 1])
+    desc = dict(polarised=False, zenith=tel.zenith, baselines=tel.baselines, uniquepairs=tel.uniquepairs,
+                beamclass=tel.beamclass, wavelengths=tel.wavelengths, cylinder_width=tel.cylinder_width,
+                fwhm_e=tel.fwhm_e, fwhm_h=tel.fwhm_h, lmax=tel.lmax, mmax=tel.mmax, l_boost=tel.l_boost,
+                included_freq=fsel, included_baseline=bsel, accuracy_boost=tel.accuracy_boost)
+    ms = [0, 37, 90, tel.mmax]  # the last one lies above the natural band limit: an all-zero block
+    ref = ob.beam_transfer_m(desc, mlist=ms)  # (F, 2, B, 1, L) per m, non-zero on the selected (f, b)
+    got = beam_all.cpu().numpy()
+    scale = np.abs(ref[0]).max()
+    for mi in ms:
+        g = got[mi][fsel][:, :, bsel]
+        r = ref[mi][fsel][:, :, bsel]
+        assert (np.abs(r).max() > 0) == (mi < tel.mmax)
+        # fp64 pixel sums over 196 608 pixels in a different order: 1e-10 of the block scale
+        assert np.abs(g - r).max() < 1e-10 * scale, mi
+
+
+def test_svd_properties_all_m(step):
+    tel, bt, kl, ctx, beam_all, res = step
+    sv = res["singularvalues"].cpu().numpy()           # (M, F, K)
+    bsvd = res["beam_svd"].cpu().numpy()                # (M, F, K, P, L)
+    but = res["beam_ut"].cpu().numpy()                  # (M, F, K, T)
+    ibs = res["invbeam_svd"].cpu().numpy()              # (M, F, P, L, K)
+    beam = beam_all.cpu().numpy()
+    M, F, K = sv.shape
+    T, L = bt.ntel, tel.lmax + 1
+    noisew = bt._noisew()
+    worst = dict(rows=0.0, proj=0.0, pinv=0.0, orth=0.0)
+    for mi in range(0, M, 8):
+        for fi in (0, F // 2, F - 1):
+            s = sv[mi, fi]
+            n = int((s > s.max() * bt.svcut).sum()) if s.max() > 0 else 0
+            if n == 0:
+                continue
+            B = (beam[mi, fi].reshape(T, L)) * noisew[fi][:, None]
+            U = but[mi, fi, :n] / noisew[fi][None, :]            # beam_ut = ut * noisew
+            X = bsvd[mi, fi, :n].reshape(n, L)
+            # rows of beam_svd: mutually orthogonal, norms = singular values
+            G = X @ X.conj().T
+            d = np.sqrt(np.abs(np.diag(G)))
+            worst["rows"] = max(worst["rows"], np.abs(d - s[:n]).max() / s[0])
+            off = G - np.diag(np.diag(G))
+            worst["orth"] = max(worst["orth"], np.abs(off / np.outer(d, d)).max())
+            worst["proj"] = max(worst["proj"], np.abs(U @ B - X).max() / s[0])
+            I = X @ ibs[mi, fi].reshape(L, K)[:, :n]
+            worst["pinv"] = max(worst["pinv"], np.abs(I - np.eye(n)).max())
+    assert worst["rows"] < 1e-12, worst
+    assert worst["orth"] < 1e-11, worst    # Jacobi stops at |cos| <= 1e-13 per 64-row block pair
+    assert worst["proj"] < 1e-12, worst
+    assert worst["pinv"] < 1e-8, worst     # kappa(beam_svd) = 1/svcut = 1e6 amplifies eps
+
+
+def test_kl_properties_sample_m(step):
+    import torch
+
+    tel, bt, kl, ctx, beam_all, res = step
+    sv = res["singularvalues"].cpu().numpy()
+    ms = [0, 16, 48, 96, tel.mmax]
+    for mi in range(tel.mmax + 1):
+        bt._dev[mi] = dict(beam_svd=res["beam_svd"][mi], beam_ut=res["beam_ut"][mi], singularvalues=sv[mi])
+    S, N, ndofs, off = kl.sn_covariance_device(ms)
+    ctx.sync()
+    Sh, Nh = S.cpu().numpy(), N.cpu().numpy()
+    out = kl._transform_batch(ms, to_host=True)
+    for i, mi in enumerate(ms):
+        n = int(ndofs[i])
+        if n == 0:
+            continue
+        ev, E = out[i][0], out[i][1]
+        Sm = Sh[off[i] : off[i] + n * n].reshape(n, n)
+        Nm = Nh[off[i] : off[i] + n * n].reshape(n, n)
+        assert np.all(np.diff(ev) >= 0)
+        lam = np.linalg.eigvalsh((Nm + Nm.conj().T) / 2)
+        cond = lam[-1] / max(lam[0], 1e-300)
+        tol = max(50 * np.finfo(float).eps * cond, 1e-10)  # LAPACK's bound for zhegvd residuals
+        ENE = E @ Nm @ E.conj().T
+        ESE = E @ Sm @ E.conj().T
+        assert np.abs(ENE - np.eye(n)).max() < tol, (mi, n, cond)
+        assert np.abs(ESE - np.diag(ev)).max() < tol * max(1.0, np.abs(ev).max()), (mi, n, cond)
