@@ -54,6 +54,9 @@ SIGNATURES = {
     "dm_eigh_gen": (
         c_int, [c_vp, c_int, ctypes.POINTER(c_int), c_vp, c_vp, ctypes.POINTER(c_i64), c_vp, ctypes.POINTER(c_i64),
                 c_vp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_int)]),
+    "dm_fisher": (
+        c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int,
+                c_vp, c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_int), c_vp, ctypes.POINTER(c_i64), c_vp]),
     "dm_bt_beam_cyl": (
         c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int,
                 ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_dbl, c_vp]),
@@ -235,6 +238,25 @@ def _project_cov(self, beam_svd, svnum, cl_pfl, out, out_off, npol=None, polmask
     rc = self.lib.dm_project_cov(self.h, nblk, F, K, P, L, self.ptr(beam_svd), svp, l0p, self.ptr(cl_pfl), npol, pmp,
                                  self.ptr(out), offp, int(zero_first))
     self.check(rc, "dm_project_cov")
+
+
+def _fisher(self, beam_svd, svnum, l0, cl_bands, evecs, evecs_off, nmodes, evals, evals_off):
+    """Per-m Fisher matrices (nblk, nbands, nbands) complex; see dm_fisher in include/driftmi.h."""
+    nblk, F, K, P, L = [int(x) for x in beam_svd.shape]
+    nbands = int(cl_bands.shape[0])
+    sv, svp = _iarr(svnum)
+    l0a, l0p = _iarr(l0)
+    eo, eop = _larr(evecs_off)
+    vo, vop = _larr(evals_off)
+    nm, nmp = _iarr(nmodes)
+    out = self.empty((nblk, nbands, nbands), np.complex128)
+    rc = self.lib.dm_fisher(self.h, nblk, F, K, P, L, self.ptr(beam_svd), svp, l0p, nbands, self.ptr(cl_bands),
+                            self.ptr(evecs), eop, nmp, self.ptr(evals), vop, self.ptr(out))
+    self.check(rc, "dm_fisher")
+    return out
+
+
+Context.fisher = _fisher
 
 
 def _project_diag(self, beam_ut, svnum, dmat, out, out_off, alpha=1.0, accumulate=False):

@@ -5,7 +5,7 @@ import os
 
 import yaml
 
-from . import beamtransfer, cylinder, doublekl, kltransform, parallel
+from . import beamtransfer, cylinder, doublekl, kltransform, parallel, psestimation
 
 logger = logging.getLogger(__name__)
 
@@ -15,9 +15,8 @@ teltype_dict = {
 }
 
 kltype_dict = {"KLTransform": kltransform.KLTransform, "DoubleKL": doublekl.DoubleKL}
+pstype_dict = {"Full": psestimation.PSExact}  # the Monte-Carlo estimators of the reference are not part of this build
 
-# power-spectrum estimators are outside this build's hot path
-pstype_dict = {}
 
 
 def _resolve_class(clstype, clsdict, objtype=""):
@@ -97,8 +96,22 @@ class ProductManager(object):
             klclass = _resolve_class(klentry["type"], kltype_dict, "KL filter")
             self.kltransforms[klentry["name"]] = klclass.from_config(klentry, self.beamtransfer, subdir=klentry["name"])
         self.gen_kl = bool(yconf["config"].get("kltransform"))
+        # power-spectrum estimators (manager.py:251-277)
         self.psestimators = {}
-        self.gen_ps = False  # Fisher estimators: "next" row, not built
+        self.gen_ps = bool(yconf["config"].get("psfisher"))
+        if self.gen_ps and "psfisher" not in yconf:
+            raise Exception("Require a psfisher section if config: psfisher is Yes.")
+        for psentry in yconf.get("psfisher", []) or []:
+            psclass = _resolve_class(psentry["type"], pstype_dict, "PS estimator")
+            klname = psentry["klname"]
+            psname = psentry.get("name", "ps")
+            if klname not in self.kltransforms:
+                import warnings
+
+                warnings.warn("Desired KL object (name: %s) does not exist." % klname)
+                self.psestimators[psname] = None
+            else:
+                self.psestimators[psname] = psclass.from_config(psentry, self.kltransforms[klname], subdir=psname)
 
     def generate(self):
         os.makedirs(self.directory, exist_ok=True)
@@ -110,5 +123,11 @@ class ProductManager(object):
         if self.gen_kl:
             for klname, klobj in self.kltransforms.items():
                 klobj.generate()
+        if self.gen_ps:
+            for psname, psobj in self.psestimators.items():
+                if psobj is None:
+                    continue
+                psobj.generate()
+                psobj.delbands()
         if parallel.rank0():
             logger.info("DONE GENERATING PRODUCTS")

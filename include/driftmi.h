@@ -149,6 +149,21 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
                 double* evals_dev, const int64_t* evoff_host, void* evecs_dev, double* add_const_host,
                 int* sweeps_host);
 
+/* Exact per-m Fisher matrices of the band powers for nblk m-blocks:
+ *   C_a = E (B C_l^a B^H) E^H,  F[a][b] = sum_ij C_a[i][j] C_b[j][i] / ((lam_i + 1)(lam_j + 1)).
+ *   beam_svd_dev, svnum_host, l0_host   as for dm_project_cov
+ *   cl_bands_dev (nbands, F, F, L) f64  band angular power spectra (temperature block), an INPUT
+ *   evecs_dev + evecs_off_host[b]       (nmodes_host[b] x ndof_b) c128, rows = KL modes above the threshold
+ *   evals_dev + evals_off_host[b]       their eigenvalues (f64)
+ *   fisher_dev (nblk, nbands, nbands) c128  out (zero for blocks without modes)
+ * Synchronises.
+ * Replaces: PSExact.makeproj + _work_fisher_bias_m, drift/core/psestimation.py:672-699, :775-815
+ * (the bias of PSExact is identically zero, :797). */
+int dm_fisher(dm_ctx* ctx, int nblk, int F, int K, int P, int L, const void* beam_svd_dev, const int* svnum_host,
+              const int* l0_host, int nbands, const double* cl_bands_dev, const void* evecs_dev,
+              const int64_t* evecs_off_host, const int* nmodes_host, const double* evals_dev,
+              const int64_t* evals_off_host, void* fisher_dev);
+
 /* ---- beam-transfer generation (cylinder telescopes) --------------------------- */
 /* Host geometry shared by the three calls below: ring_cth_host / ring_sth_host hold
  * cos / sin of the colatitude of the 4*nside-1 HEALPix rings; frame_host (9 doubles)

@@ -406,9 +406,72 @@ def gen_projections(ref):
     print("projections.npz")
 
 
+def gen_psfisher(ref):
+    """G8: PSExact._work_fisher_bias_m with injected band C_l arrays (the cora band generator is
+    not available; the bands are inputs).  Inputs are the products of svdkl_unpol.npz."""
+    btmod, klmod, psmod = ref["beamtransfer"], ref["kltransform"], ref["psestimation"]
+    from oracle import psfisher as opf
+
+    g = np.load(os.path.join(OUT, "svdkl_unpol.npz"))
+    F, B, P, lmax = int(g["F"]), int(g["B"]), int(g["P"]), int(g["lmax"])
+    L = lmax + 1
+    tel = FakeTelescope(F, B, P, lmax, lmax, g["npower"], tsys_flat=1.0)
+    tel.frequencies = g["frequencies"]
+    bt = btmod.BeamTransfer("/mem/psf/bt", telescope=tel)
+    bt.polsvcut, bt.svcut = float(g["polsvcut"]), float(g["svcut"])
+    kl = klmod.KLTransform(bt, subdir="kl")
+    kl._cvsg, kl._cvfg = g["cv_sg"], g["cv_fg"]
+    kl.threshold = float(g["threshold"])
+    kl.inverse = False
+    l_edges = np.array([0, 4, 9, 15, L])
+    clarray = opf.band_clarray(tel.frequencies, L, l_edges)
+    # the h5py stand-in keeps files in memory: let the reference's `os.path.exists` checks see them
+    import h5py as _h5
+
+    class _OsShim(object):
+        def __getattr__(self, name):
+            return getattr(os, name)
+
+    class _PathShim(object):
+        def __getattr__(self, name):
+            return getattr(os.path, name)
+
+        @staticmethod
+        def exists(path):
+            return _h5.exists(path) or os.path.exists(path)
+
+    shim = _OsShim()
+    shim.path = _PathShim()
+    klmod.os = shim
+    psmod.os = shim
+    ps = psmod.PSExact(kl, subdir="ps")
+    ps.clarray = clarray
+    ps.k_center = np.arange(clarray.shape[0], dtype=np.float64)  # nbands = k_center.size
+    ps.bands = list(range(clarray.shape[0] + 1))  # only its length is read (cache-file pattern, psestimation.py:668)
+    ps.threshold = 0.0
+    out = dict(l_edges=l_edges, clarray=clarray, ps_threshold=ps.threshold)
+    for mi in [int(m) for m in g["mlist"]]:
+        write_beam_file(ref, bt, mi, g["m%d_beam_m" % mi])
+        bt._generate_svdfile_m(mi)
+        kl.transform_save(mi)
+        fisher, bias = ps.fisher_bias_m(mi)
+        evals, evecs = kl.modes_m(mi, threshold=ps.threshold)
+        out["m%d_fisher" % mi] = fisher
+        out["m%d_bias" % mi] = bias
+        out["m%d_nmodes" % mi] = 0 if evals is None else evals.size
+        print("psfisher m", mi, "modes", out["m%d_nmodes" % mi], "diag", np.real(np.diag(fisher)))
+    klmod.os = os
+    psmod.os = os
+    np.savez_compressed(os.path.join(OUT, "psfisher.npz"), **out)
+    print("psfisher.npz")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = refimport.load()
+    if len(sys.argv) > 1 and sys.argv[1] == "psfisher":
+        gen_psfisher(ref)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "projections":
         gen_projections(ref)
         return
@@ -427,6 +490,7 @@ def main():
     # ill-conditioned and LAPACK's own answer carries an eps*cond error bar
     gen_svd_kl(ref, "unpol_harsh", F=4, B=10, P=1, lmax=24, mlist=[5], polsvcut=1e-4,
                seed=2001, fg_threshold=1.0, threshold=0.1, fg_amp=10.0)
+    gen_psfisher(ref)
 
 
 if __name__ == "__main__":

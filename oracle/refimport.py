@@ -51,13 +51,14 @@ def load():
 
     sys.modules["drift.util._fast_tools"] = ft
     sys.modules["drift.util"]._fast_tools = ft
-    from drift.core import beamtransfer, doublekl, kltransform, telescope, visibility
+    from drift.core import beamtransfer, doublekl, kltransform, psestimation, telescope, visibility
     from drift.telescope import cylbeam, cylinder
 
     return dict(
         beamtransfer=beamtransfer,
         kltransform=kltransform,
         doublekl=doublekl,
+        psestimation=psestimation,
         telescope=telescope,
         cylinder=cylinder,
         cylbeam=cylbeam,

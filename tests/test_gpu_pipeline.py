@@ -151,8 +151,10 @@ def test_product_manager_end_to_end(tmp_path):
 
     device.reset_context()
     conf = dict(
-        config=dict(beamtransfers=True, kltransform=True, psfisher=False, output_directory=str(tmp_path / "prod"),
+        config=dict(beamtransfers=True, kltransform=True, psfisher=True, output_directory=str(tmp_path / "prod"),
                     polsvcut=1e-4, truncate=False),
+        psfisher=[dict(type="Full", name="ps", klname="kl", threshold=0.0, bandtype="polar", num_theta=1,
+                       k_bands=[dict(spacing="linear", start=0.0, stop=0.006, num=4)])],
         telescope=dict(type="UnpolarisedCylinder", num_freq=3, freq_start=400.0, freq_end=430.0, freq_mode="edge",
                        num_cylinders=2, cylinder_width=2.0, num_feeds=3, feed_spacing=0.4, tsys=1.0),
         kltransform=[dict(type="KLTransform", name="kl", use_foregrounds=False),
@@ -185,3 +187,23 @@ def test_product_manager_end_to_end(tmp_path):
         with storage.File(kl._evfile % mi, "r") as f:
             assert_spectrum(f["evals_full"][:], ev, 1e-8, "kl evals m=%d" % mi)
     assert pm.kltransforms["dk"].evals_all().shape == (t.mmax + 1, bt.ndofmax)
+    # Fisher matrix of the (stand-in) multipole bands: the file of the manager run against the
+    # oracle chain summed over every m
+    from driftscan_amd import psestimation
+    from oracle import psfisher as opf
+
+    ps = pm.psestimators["ps"]
+    fisher, bias = ps.fisher_bias()
+    kb = np.linspace(0.0, 0.006, 4)
+    clarray = psestimation.band_clarray_standin(t.lmax, t.frequencies, kb[:-1], kb[1:])
+    assert clarray.shape[0] == 3 and np.abs(clarray).max() > 0
+    ref = np.zeros((3, 3))
+    for mi in range(t.mmax + 1):
+        ev, E = kl.modes_m(mi, threshold=0.0)
+        if ev is None:
+            continue
+        svnum, svb = bt._svd_num(mi)
+        ref += opf.fisher_m(bt.beam_svd(mi), svnum, svb, ev, E, clarray)[0].real
+    assert np.abs(ref).max() > 0
+    assert relerr(fisher, ref) < 1e-8
+    assert not bias.any()

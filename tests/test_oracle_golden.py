@@ -162,3 +162,21 @@ def test_projection_operators_match_reference(golden_dir):
             assert rel(op.project_vector_sky_to_telescope(bm, g[pre + "vec_sky"]), g[pre + "sky_to_tel"]) < 1e-13
             assert rel(op.project_matrix_sky_to_telescope(bm, cv), g[pre + "mat_sky_to_tel"]) < 1e-13
             assert rel(op.project_matrix_sky_to_telescope(bm, cv, True), g[pre + "mat_sky_to_tel_temponly"]) < 1e-13
+
+
+# ---- G8: exact per-m Fisher matrix (oracle/psfisher.py) ------------------------------------------
+def test_psfisher_matches_reference(golden_dir):
+    from oracle import psfisher as opf
+
+    g = np.load(os.path.join(golden_dir, "svdkl_unpol.npz"))
+    p = np.load(os.path.join(golden_dir, "psfisher.npz"))
+    for mi in g["mlist"]:
+        pre = "m%d_" % mi
+        ev, E = g[pre + "kl_evals"], g[pre + "kl_evecs"]
+        i0 = np.searchsorted(ev, float(g["threshold"]))  # transform_save keeps the modes above the KL threshold
+        fisher, bias = opf.fisher_m(g[pre + "beam_svd"], g[pre + "svnum"], g[pre + "svbounds"], ev[i0:], E[i0:],
+                                    p["clarray"])
+        ref = p[pre + "fisher"]
+        assert ev[i0:].size == int(p[pre + "nmodes"])
+        assert np.abs(fisher - ref).max() <= 1e-13 * np.abs(ref).max()
+        assert not bias.any() and not p[pre + "bias"].any()
