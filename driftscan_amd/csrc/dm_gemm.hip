@@ -32,7 +32,7 @@ namespace {
 
 constexpr int BM = 64, BN = 64, BK = 16, LDP = 17;
 
-template <bool B_REAL>
+template <bool B_REAL, bool B_GATHER>
 __global__ __launch_bounds__(256, 3) void zgemm_grouped_kernel(const dm_gemm_desc* __restrict__ descs,
                                                             const dm_gemm_tile* __restrict__ tiles,
                                                             int ntiles) {
@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256, 3) void zgemm_grouped_kernel(const dm_gemm_des
   const double* __restrict__ Br = reinterpret_cast<const double*>(d.B);
   const bool conjA = d.flags & DM_GEMM_CONJ_A;
   const bool conjB = d.flags & DM_GEMM_CONJ_B;
+  constexpr bool gatherB = B_GATHER;  // separate instantiation: the common kernel keeps its register budget
   // loader mapping: walk the contiguous direction with consecutive lanes
   const bool a_kfast = d.csA <= d.rsA;
   const bool b_kfast = d.rsB <= d.csB;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256, 3) void zgemm_grouped_kernel(const dm_gemm_des
       if (gm < d.M && gk < d.K) {
         v = dm_ldg(A, (size_t)gm * d.rsA + (size_t)gk * d.csA);
         if (conjA) v.y = -v.y;
-        if (d.kscale) { double s = dm_ldg(d.kscale, gk); v.x *= s; v.y *= s; }
+        if (d.kscale && !gatherB) { double s = dm_ldg(d.kscale, gk); v.x *= s; v.y *= s; }
       }
       ra[i] = v;
     }
@@ -103,6 +104,13 @@ __global__ __launch_bounds__(256, 3) void zgemm_grouped_kernel(const dm_gemm_des
         size_t off = (size_t)gk * d.rsB + (size_t)gn * d.csB;
         if (B_REAL) {
           v.x = dm_ldg(Br, off);
+        } else if (gatherB) {
+          const int2 g = d.bgather[gn];
+          v = dm_ldg(Bc, (size_t)g.x + (size_t)gk * d.rsB);
+          if (conjB) v.y = -v.y;
+          const double s = dm_ldg(d.kscale, (size_t)g.y + gk);
+          v.x *= s;
+          v.y *= s;
         } else {
           v = dm_ldg(Bc, off);
           if (conjB) v.y = -v.y;
@@ -344,6 +352,8 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
   std::vector<dm_gemm_tile> tiles;
   std::vector<dm_gemm_tile> tiles_real;
   std::vector<dm_gemm_tile> tiles_dd;
+  std::vector<dm_gemm_tile> tiles_gat;
+  double fl_g = 0.0;
   double fl_c = 0.0, fl_r = 0.0, fl_d = 0.0;
   for (size_t i = 0; i < descs.size(); ++i) {
     const dm_gemm_desc& d = descs[i];
@@ -357,15 +367,15 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
         const double rows = std::min(BM, d.M - a * BM), cols = std::min(BN, d.N - b * BN);
         if (d.flags & DM_GEMM_ALL_REAL) { tiles_dd.push_back(t); fl_d += 2.0 * rows * cols * d.K; }
         else if (d.flags & DM_GEMM_B_REAL) { tiles_real.push_back(t); fl_r += 4.0 * rows * cols * d.K; }
+        else if (d.flags & DM_GEMM_B_GATHER) { tiles_gat.push_back(t); fl_g += 8.0 * rows * cols * d.K; }
         else { tiles.push_back(t); fl_c += 8.0 * rows * cols * d.K; }
       }
   }
   // longest tiles first: a launch mixes problems of very different K, and a long tile that
   // starts last sets the duration of the launch (stable, so tiles of one problem stay together)
   auto by_k = [&](const dm_gemm_tile& a, const dm_gemm_tile& b) { return descs[a.desc].K > descs[b.desc].K; };
-  std::stable_sort(tiles.begin(), tiles.end(), by_k);
-  std::stable_sort(tiles_real.begin(), tiles_real.end(), by_k);
-  std::stable_sort(tiles_dd.begin(), tiles_dd.end(), by_k);
+  for (auto* tl : {&tiles, &tiles_real, &tiles_dd, &tiles_gat})
+    if (!std::is_sorted(tl->begin(), tl->end(), by_k)) std::stable_sort(tl->begin(), tl->end(), by_k);
   size_t mark = dm_ws_mark(ctx);
   dm_gemm_desc* dd = dm_ws_upload(ctx, descs);
   if (!dd) return DM_ENOMEM;
@@ -381,7 +391,7 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
     }
     {
       dm_prof_scope ps(ctx, DM_PROF_GEMM, fl_c);
-      hipLaunchKernelGGL(zgemm_grouped_kernel<false>, dim3((unsigned)tiles.size()), dim3(256), 0, ctx->stream, dd,
+      hipLaunchKernelGGL((zgemm_grouped_kernel<false, false>), dim3((unsigned)tiles.size()), dim3(256), 0, ctx->stream, dd,
                          dt, (int)tiles.size());
     }
     if (log) {
@@ -404,11 +414,18 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
       (void)hipEventDestroy(e1);
     }
   }
+  if (!tiles_gat.empty()) {
+    dm_gemm_tile* dt = dm_ws_upload(ctx, tiles_gat);
+    if (!dt) return DM_ENOMEM;
+    dm_prof_scope ps(ctx, DM_PROF_GEMM, fl_g);
+    hipLaunchKernelGGL((zgemm_grouped_kernel<false, true>), dim3((unsigned)tiles_gat.size()), dim3(256), 0, ctx->stream,
+                       dd, dt, (int)tiles_gat.size());
+  }
   if (!tiles_real.empty()) {
     dm_gemm_tile* dt = dm_ws_upload(ctx, tiles_real);
     if (!dt) return DM_ENOMEM;
     dm_prof_scope ps(ctx, DM_PROF_GEMM_REAL, fl_r);
-    hipLaunchKernelGGL(zgemm_grouped_kernel<true>, dim3((unsigned)tiles_real.size()), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL((zgemm_grouped_kernel<true, false>), dim3((unsigned)tiles_real.size()), dim3(256), 0, ctx->stream,
                        dd, dt, (int)tiles_real.size());
   }
   if (!tiles_dd.empty()) {

@@ -15,6 +15,7 @@ enum {
   DM_GEMM_LOWER = 8,   // only compute 64x64 tiles on or below the block diagonal
   DM_GEMM_ALL_REAL = 16,  // A, B and C are arrays of doubles (strides in doubles)
   DM_GEMM_UPPER = 32,  // only compute 64x64 tiles on or above the block diagonal
+  DM_GEMM_B_GATHER = 64,  // columns of B are gathered through desc.bgather and carry their own K weights
 };
 
 struct dm_gemm_desc {
@@ -22,6 +23,8 @@ struct dm_gemm_desc {
   const void* B;         // cplx (or double with DM_GEMM_B_REAL), viewed as (K x N) through (rsB, csB)
   void* C;               // cplx, row-major, leading dimension ldc
   const double* kscale;  // optional real weights over K (applied to A), or nullptr
+  const int2* bgather;   // DM_GEMM_B_GATHER: per column n of B, (x = element offset of its K-run relative to B,
+                         //   y = offset of its weight run relative to kscale): B(k, n) = B[x + k rsB] * kscale[y + k]
   int M, N, K;
   int rsA, csA, rsB, csB, ldc;
   int flags;
@@ -44,6 +47,7 @@ static inline dm_gemm_desc dm_gemm_make(const cplx* A, int rsA, int csA, bool co
   d.rsA = rsA; d.csA = csA; d.rsB = rsB; d.csB = csB; d.ldc = ldc;
   d.flags = (conjA ? DM_GEMM_CONJ_A : 0) | (conjB ? DM_GEMM_CONJ_B : 0) | extra_flags;
   d.alpha = alpha; d.beta = beta; d.alpha_im = 0.0;
+  d.bgather = nullptr;
   return d;
 }
 

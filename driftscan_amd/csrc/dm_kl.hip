@@ -126,8 +126,24 @@ int dm_project_cov(dm_ctx* ctx, int nblk, int F, int K, int P, int L, const void
   for (int b = 0; b < nblk; ++b) {
     for (int f = 0; f < F; ++f) bounds[b][f + 1] = bounds[b][f] + svnum_host[b * F + f];
   }
-  // The (f, f') tiles of one pol pair cover the whole block, so the first pair can overwrite
-  // (beta = 0) instead of zero-fill + accumulate; blocks without any l in range are cleared.
+  // One product per (block, row frequency): the columns run over ALL frequencies of the block
+  // (N = ndof) and are gathered from the (f', mode) rows of beam_svd, each carrying the weights
+  // C_l(f, f') of its own frequency on the contraction index.  Against one product per (f, f')
+  // pair this is F times fewer descriptors and tiles that are full in N (the per-frequency
+  // blocks are only <= K <= 92 wide).  The first pol pair overwrites (beta = 0).
+  std::vector<int2> gat;
+  std::vector<size_t> goff((size_t)nblk * npol, 0);
+  for (int b = 0; b < nblk; ++b) {
+    const int l0 = l0_host ? std::min(std::max(l0_host[b], 0), L) : 0;
+    for (int pj = 0; pj < npol; ++pj) {
+      goff[(size_t)b * npol + pj] = gat.size();
+      for (int fj = 0; fj < F; ++fj)
+        for (int r = 0; r < svnum_host[b * F + fj]; ++r)
+          gat.push_back(make_int2((int)(((size_t)fj * K + r) * PL + (size_t)pj * L + l0), fj * L + l0));
+    }
+  }
+  int2* d_gat = dm_ws_upload(ctx, gat);
+  if (!d_gat) return DM_ENOMEM;
   bool first_pair = zero_first != 0;
   for (int pi = 0; pi < npol; ++pi)
     for (int pj = 0; pj < npol; ++pj) {
@@ -143,19 +159,16 @@ int dm_project_cov(dm_ctx* ctx, int nblk, int F, int K, int P, int L, const void
           continue;
         }
         cplx* ob = out + out_off_host[b];
+        const cplx* Bb = beam + ((size_t)b * F * K) * PL;
         for (int fi = 0; fi < F; ++fi) {
           const int ni = svnum_host[b * F + fi];
           if (ni == 0) continue;
           const cplx* Ai = beam + (((size_t)b * F + fi) * K) * PL + (size_t)pi * L + l0;
-          for (int fj = 0; fj < F; ++fj) {
-            const int nj = svnum_host[b * F + fj];
-            if (nj == 0) continue;
-            const cplx* Bj = beam + (((size_t)b * F + fj) * K) * PL + (size_t)pj * L + l0;
-            const double* cl = cl_pfl_dev + ((((size_t)pi * P + pj) * F + fi) * F + fj) * L + l0;
-            g.push_back(dm_gemm_make(Ai, PL, 1, false, Bj, 1, PL, true,
-                                     ob + (size_t)bounds[b][fi] * ndof + bounds[b][fj], ndof, ni, nj, L - l0, 1.0,
-                                     beta, cl));
-          }
+          const double* cl = cl_pfl_dev + (((size_t)pi * P + pj) * F + fi) * F * L;
+          dm_gemm_desc d = dm_gemm_make(Ai, PL, 1, false, Bb, 1, PL, true, ob + (size_t)bounds[b][fi] * ndof, ndof, ni,
+                                        ndof, L - l0, 1.0, beta, cl, DM_GEMM_B_GATHER);
+          d.bgather = d_gat + goff[(size_t)b * npol + pj];
+          g.push_back(d);
         }
       }
       DM_TRY(dm_gemm_grouped_launch(ctx, g));
