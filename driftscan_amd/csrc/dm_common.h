@@ -148,6 +148,18 @@ __device__ __forceinline__ dm_f64x4 dm_mfma(double a, double b, dm_f64x4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per instruction (decoded with
+// indicator inputs, scratch/mfma4_layout.hip; cbsz/abid have no effect for f64).  With
+// k = l >> 4, g = (l >> 2) & 3, t = l & 3:
+//   A: lane l holds A_g[i = t][k];  B: lane l holds B_g[k][j = t];  D_g[i][j] lands in lane 16 i + 4 g + j.
+// It issues at 71 TFLOP/s on MI355X against 49 for the 16x16x4 form (scratch/mfma_peak2.hip):
+// a 16x16 tile is built from it by putting row block g of A in slot g and column block
+// (g + s) & 3 of B in slot g for the four rotations s (the rotated B fragments are four LDS
+// reads with different addresses, no shuffles).
+__device__ __forceinline__ double dm_mfma4(double a, double b, double c) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
   return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
