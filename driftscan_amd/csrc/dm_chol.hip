@@ -131,7 +131,7 @@ struct trsm_desc {
 // Solve L_kk X_k = B_k (forward) or L_kk^H X_k = B_k (backward) for one block row.
 // grid = (column tiles of 64, batch); one thread per right-hand-side column.
 template <bool CONJTRANS>
-__global__ __launch_bounds__(64) void diag_solve_kernel(const trsm_desc* __restrict__ ds, int s, int nblk) {
+__global__ __launch_bounds__(64) void diag_solve_kernel(const trsm_desc* __restrict__ ds, int s, int nblk, int upper_only) {
   __shared__ cplx Lk[NB][NB + 1];
   const trsm_desc d = ds[blockIdx.y];
   int k0;
@@ -146,6 +146,8 @@ __global__ __launch_bounds__(64) void diag_solve_kernel(const trsm_desc* __restr
   if (k0 >= d.n || k0 < 0) return;
   const int nb = min(NB, d.n - k0);
   const int col = blockIdx.x * 64 + threadIdx.x;
+  // upper_only: only the columns >= the first row of the 64-row super block are wanted (and valid)
+  if (upper_only && (int)(blockIdx.x + 1) * 64 <= (k0 / (2 * NB)) * (2 * NB)) return;
   for (int idx = threadIdx.x; idx < NB * NB; idx += 64) {
     int r = idx / NB, c = idx % NB;
     Lk[r][c] = (r < nb && c < nb) ? d.L[(size_t)(k0 + r) * d.ldl + k0 + c] : make_double2(0.0, 0.0);
@@ -246,7 +248,11 @@ int dm_potrf_batched(dm_ctx* ctx, const std::vector<dm_mat>& mats, int* info_dev
   return DM_OK;
 }
 
-int dm_trsm_left_lower_batched(dm_ctx* ctx, const std::vector<dm_trsm_problem>& probs, bool conjtrans) {
+int dm_trsm_left_lower_batched(dm_ctx* ctx, const std::vector<dm_trsm_problem>& probs, bool conjtrans, bool upper_only) {
+  // upper_only (forward solves with nrhs == n only): X = L^-1 B is wanted on and above the diagonal only —
+  // row block i then needs the rows j < i at columns >= i, which lie above the diagonal too, so
+  // every update and substitution simply starts at the first column of its row block (1/3 of the flops).
+  if (conjtrans) upper_only = false;
   const int nbatch = (int)probs.size();
   if (nbatch == 0) return DM_OK;
   std::vector<trsm_desc> ds(nbatch);
@@ -279,8 +285,11 @@ int dm_trsm_left_lower_batched(dm_ctx* ctx, const std::vector<dm_trsm_problem>& 
         const int size = s & -s;                  // 2^ctz(s)
         const int r0 = s * NB2, r1 = std::min((s + size) * NB2, P.n);
         const int c0 = (s - size) * NB2;
-        g.push_back(dm_gemm_make(P.L + (size_t)r0 * P.ldl + c0, P.ldl, 1, false, P.B + (size_t)c0 * P.ldb, P.ldb, 1,
-                                 false, P.B + (size_t)r0 * P.ldb, P.ldb, r1 - r0, P.nrhs, size * NB2, -1.0, 1.0));
+        const int j0 = upper_only ? std::min(r0, P.nrhs) : 0;  // first right-hand-side column that matters
+        if (P.nrhs - j0 <= 0) continue;
+        g.push_back(dm_gemm_make(P.L + (size_t)r0 * P.ldl + c0, P.ldl, 1, false, P.B + (size_t)c0 * P.ldb + j0, P.ldb, 1,
+                                 false, P.B + (size_t)r0 * P.ldb + j0, P.ldb, r1 - r0, P.nrhs - j0, size * NB2, -1.0,
+                                 1.0));
       } else {
         if (s < nblk - pn) continue;  // smaller problems start later so that all finish together
         const int u = s - (nblk - pn);
@@ -303,9 +312,10 @@ int dm_trsm_left_lower_batched(dm_ctx* ctx, const std::vector<dm_trsm_problem>& 
       if (!conjtrans) s32 = 2 * s + h;
       else s32 = 2 * s + half;  // backward kernel maps its step to the block row itself
       if (!conjtrans)
-        hipLaunchKernelGGL(diag_solve_kernel<false>, dim3(ct, nbatch), dim3(64), 0, ctx->stream, dd, s32, nblk32);
+        hipLaunchKernelGGL(diag_solve_kernel<false>, dim3(ct, nbatch), dim3(64), 0, ctx->stream, dd, s32, nblk32,
+                           upper_only ? 1 : 0);
       else
-        hipLaunchKernelGGL(diag_solve_kernel<true>, dim3(ct, nbatch), dim3(64), 0, ctx->stream, dd, s32, 2 * nblk);
+        hipLaunchKernelGGL(diag_solve_kernel<true>, dim3(ct, nbatch), dim3(64), 0, ctx->stream, dd, s32, 2 * nblk, 0);
       if (half == 0) {
         std::vector<dm_gemm_desc> g2;
         for (int i = 0; i < nbatch; ++i) {
@@ -316,8 +326,11 @@ int dm_trsm_left_lower_batched(dm_ctx* ctx, const std::vector<dm_trsm_problem>& 
             if (k1 >= P.n) continue;
             const int nb = std::min(NB, P.n - k1);
             // B[k1:k1+nb] -= L[k1:k1+nb, k0:k1] X[k0:k1]
-            g2.push_back(dm_gemm_make(P.L + (size_t)k1 * P.ldl + k0, P.ldl, 1, false, P.B + (size_t)k0 * P.ldb, P.ldb,
-                                      1, false, P.B + (size_t)k1 * P.ldb, P.ldb, nb, P.nrhs, NB, -1.0, 1.0));
+            const int j0 = upper_only ? std::min(k0, P.nrhs) : 0;
+            if (P.nrhs - j0 <= 0) continue;
+            g2.push_back(dm_gemm_make(P.L + (size_t)k1 * P.ldl + k0, P.ldl, 1, false, P.B + (size_t)k0 * P.ldb + j0,
+                                      P.ldb, 1, false, P.B + (size_t)k1 * P.ldb + j0, P.ldb, nb, P.nrhs - j0, NB, -1.0,
+                                      1.0));
           } else {
             if (s < nblk - pn) continue;
             const int kb = pn - 1 - (s - (nblk - pn));

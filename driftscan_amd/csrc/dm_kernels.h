@@ -113,7 +113,7 @@ struct dm_trsm_problem {
   const cplx* L; int ldl; int n;
   cplx* B; int ldb; int nrhs;
 };
-int dm_trsm_left_lower_batched(dm_ctx* ctx, const std::vector<dm_trsm_problem>& probs, bool conjtrans);
+int dm_trsm_left_lower_batched(dm_ctx* ctx, const std::vector<dm_trsm_problem>& probs, bool conjtrans, bool upper_only = false);
 
 // ---------------------------------------------------------------------------
 // small utility kernels (dm_util.hip)

@@ -368,8 +368,10 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
       hm.push_back(dm_mat{Tw + loff[b], n_host[b], n_host[b]});
     }
     DM_TRY(dm_conj_transpose_batched(ctx, tr));
-    DM_TRY(dm_trsm_left_lower_batched(ctx, t2, false));  // Y = L^-1 X^H = C^H = C
-    DM_TRY(dm_hermitize_batched(ctx, hm));
+    // Y = L^-1 X^H = C^H = C, on and above the diagonal only: the eigensolver reads the upper
+    // triangle (LAPACK's zhegst/zheevd with one `uplo` do the same), so no symmetrisation pass either
+    DM_TRY(dm_trsm_left_lower_batched(ctx, t2, false, true));
+    (void)hm;
   }
 
   // ---- Hermitian eigendecomposition C = W^H diag(ev) W
