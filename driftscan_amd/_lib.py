@@ -53,7 +53,7 @@ SIGNATURES = {
     "dm_regularise": (c_int, [c_vp, c_int, ctypes.POINTER(c_int), c_vp, ctypes.POINTER(c_i64), c_dbl]),
     "dm_eigh_gen": (
         c_int, [c_vp, c_int, ctypes.POINTER(c_int), c_vp, c_vp, ctypes.POINTER(c_i64), c_vp, ctypes.POINTER(c_i64),
-                c_vp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_int)]),
+                c_vp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_int), c_int, c_dbl, ctypes.POINTER(c_int)]),
     "dm_fisher": (
         c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int,
                 c_vp, c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_int), c_vp, ctypes.POINTER(c_i64), c_vp]),
@@ -274,9 +274,12 @@ def _regularise(self, mats, ndofs, off, reg):
     self.check(self.lib.dm_regularise(self.h, len(n), np_, self.ptr(mats), op, float(reg)), "dm_regularise")
 
 
-def _eigh_gen(self, A, B, ndofs, off):
+def _eigh_gen(self, A, B, ndofs, off, cut=None):
     """A, B: flat device c128 buffers holding the (n_b x n_b) blocks at `off`.  Destroys both.
-    Returns (evals flat device f64 [offsets evoff], evoff, evecs flat device c128 [same off], add_const, sweeps)."""
+    cut: None, ("upper", thr) — only the modes with eigenvalue >= thr (rows i >= searchsorted(evals, thr))
+    are formed — or ("lower", thr) for the rows below; the other rows of a block are zero.
+    Returns (evals flat device f64 [offsets evoff], evoff, evecs flat device c128 [same off], add_const, sweeps);
+    the number of rows formed per block is left in ``self.last_nkeep``."""
     n, np_ = _iarr(ndofs)
     o, op = _larr(off)
     evoff = np.concatenate([[0], np.cumsum(n.astype(np.int64))])
@@ -284,13 +287,19 @@ def _eigh_gen(self, A, B, ndofs, off):
     evals = self.empty((max(int(evoff[-1]), 1),), np.float64)
     evecs = self.empty((max(int(A.numel()), 1),), np.complex128)
     ac = (c_dbl * max(len(n), 1))()
+    nk = (c_int * max(len(n), 1))()
     sw = c_int(0)
+    mode, thr = 0, 0.0
+    if cut is not None:
+        mode = {"upper": 1, "lower": 2}[cut[0]]
+        thr = float(cut[1])
     rc = self.lib.dm_eigh_gen(self.h, len(n), np_, self.ptr(A), self.ptr(B), op, self.ptr(evals), eop,
-                              self.ptr(evecs), ac, ctypes.byref(sw))
+                              self.ptr(evecs), ac, ctypes.byref(sw), mode, thr, nk)
     self.check(rc, "dm_eigh_gen")
     if rc > 0:
         msg = self.lib.dm_last_error(self.h)
         raise DriftMIError("dm_eigh_gen: numerical failure (info=%d): %s" % (rc, msg.decode() if msg else ""))
+    self.last_nkeep = np.array(nk[: len(n)], dtype=np.int64)
     return evals, evoff, evecs, np.array(ac[: len(n)], dtype=np.float64), sw.value
 
 

@@ -5,6 +5,8 @@
 
 #include "dm_common.h"
 
+#include <functional>
+
 // ---------------------------------------------------------------------------
 // grouped ZGEMM (dm_gemm.hip)
 // ---------------------------------------------------------------------------
@@ -90,7 +92,17 @@ int dm_jacobi_herm(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, d
 // Same contract as dm_jacobi_herm (C destroyed, W rows = eigenvectors^H, evals unsorted;
 // W need not be initialised) through Householder tridiagonalisation + implicit QL +
 // compact-WY back-transformation (dm_tridiag.hip).  Returns > 0 if QL fails.  Synchronises.
-int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, double* evals, int evals_stride);
+// Optional eigenvector selection: after the tridiagonal eigen-solve the eigenvalues of problem p
+// (natural, unsorted order) are handed to `pick`, which returns the indices of the eigenvectors to
+// back-transform in the order the rows of W shall have.  Only those rows of W are written
+// (rows [0, nsel[p])); the back-transformation and everything downstream then cost nsel/n of the
+// full amount.  `evals` still receives ALL eigenvalues in natural order.
+struct dm_eig_select {
+  std::function<void(int p, const double* ev, int n, std::vector<int>& cols)> pick;
+  std::vector<int> nsel;  // out
+};
+int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, double* evals, int evals_stride,
+                        dm_eig_select* sel = nullptr);
 
 // Permute the rows [row0, row0+nrows) x [0, ncols) of each problem so that the
 // device keys (key_stride doubles per problem) end up sorted; keys are sorted too.

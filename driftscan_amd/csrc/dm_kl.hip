@@ -242,11 +242,13 @@ int dm_regularise(dm_ctx* ctx, int nblk, const int* n_host, void* mats_dev, cons
 // Synchronises.
 int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_dev, const int64_t* off_host,
                 double* evals_dev, const int64_t* evoff_host, void* evecs_dev, double* add_const_host,
-                int* sweeps_host) {
+                int* sweeps_host, int cut_mode, double cut_value, int* nkeep_host) {
   if (!ctx) return DM_EARG;
   DM_ARG(ctx, nblk >= 0 && n_host && A_dev && B_dev && off_host && evals_dev && evoff_host && evecs_dev &&
-                  add_const_host);
+                  add_const_host && cut_mode >= 0 && cut_mode <= 2);
   if (sweeps_host) *sweeps_host = 0;
+  if (nkeep_host)
+    for (int b = 0; b < nblk; ++b) nkeep_host[b] = n_host[b];
   if (nblk == 0) return DM_OK;
   const size_t mark = dm_ws_mark(ctx);
   cplx* A = reinterpret_cast<cplx*>(A_dev);
@@ -290,6 +292,10 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
     if (zflag[b]) {
       DM_TRY(dm_fill_zero(ctx, evals_dev + evoff_host[b], sizeof(double) * n_host[b]));
       DM_TRY(dm_set_identity(ctx, E + off_host[b], n_host[b], n_host[b]));
+      if (nkeep_host && cut_mode) {  // all eigenvalues are 0: searchsorted gives 0 or n
+        const int cut = 0.0 >= cut_value ? 0 : n_host[b];
+        nkeep_host[b] = cut_mode == 1 ? n_host[b] - cut : cut;
+      }
     } else {
       work.push_back(b);
     }
@@ -374,33 +380,53 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
     (void)hm;
   }
 
-  // ---- Hermitian eigendecomposition C = W^H diag(ev) W
+  // ---- Hermitian eigendecomposition C = W^H diag(ev) W.  The eigenvalues come back to the host
+  // once (natural order); the selection callback sorts them ascending (LAPACK convention), applies
+  // the optional threshold cut and tells the solver which eigenvectors to back-transform and in
+  // which order, so W arrives sorted and — with a cut — only nkeep rows are ever formed.
+  std::vector<int> i_ev(nblk, 0);              // first kept row (cut_mode 1) / one past the last kept row (cut_mode 2)
+  std::vector<std::vector<double>> evsorted(nblk);
   {
     std::vector<dm_jac_herm_problem> hp;
-    for (int b : work) {
-      hp.push_back(dm_jac_herm_problem{Tw + loff[b], n_host[b], Ww + loff[b], n_host[b], n_host[b]});
-    }
-    DM_TRY(dm_herm_eig_tridiag(ctx, hp, evw, std::max(maxn, 1)));
-    // ascending order (LAPACK convention), rows of W follow
-    std::vector<dm_jac_problem> sp;
-    for (int b : work) sp.push_back(dm_jac_problem{Ww + loff[b], n_host[b], 0, n_host[b], n_host[b], 0, 0});
-    DM_TRY(dm_sort_rows_by_key(ctx, sp, evw, std::max(maxn, 1), false));
-    std::vector<dm_cdesc> cp;
+    for (int b : work) hp.push_back(dm_jac_herm_problem{Tw + loff[b], n_host[b], Ww + loff[b], n_host[b], n_host[b]});
+    dm_eig_select sel;
+    sel.pick = [&](int p, const double* ev, int n, std::vector<int>& cols) {
+      const int b = work[p];
+      std::vector<int> order(n);
+      for (int i = 0; i < n; ++i) order[i] = i;
+      std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return ev[x] < ev[y]; });
+      evsorted[b].resize(n);
+      for (int i = 0; i < n; ++i) evsorted[b][i] = ev[order[i]];
+      // np.searchsorted(evals, cut_value): first index with evals[i] >= cut_value
+      const int cut = (int)(std::lower_bound(evsorted[b].begin(), evsorted[b].end(), cut_value) - evsorted[b].begin());
+      i_ev[b] = cut;
+      if (cut_mode == 1) cols.assign(order.begin() + cut, order.end());
+      else if (cut_mode == 2) cols.assign(order.begin(), order.begin() + cut);
+      else cols = order;
+    };
+    DM_TRY(dm_herm_eig_tridiag(ctx, hp, evw, std::max(maxn, 1), &sel));
     for (size_t i = 0; i < work.size(); ++i) {
       const int b = work[i];
-      cp.push_back(dm_cdesc{evw + i * std::max(maxn, 1), evals_dev + evoff_host[b], sizeof(double) * n_host[b]});
+      if (nkeep_host) nkeep_host[b] = sel.nsel[i];
+      DM_TRY(dm_upload(ctx, evals_dev + evoff_host[b], evsorted[b].data(), sizeof(double) * n_host[b]));
     }
-    DM_TRY(dm_copy_batched(ctx, cp));
   }
 
-  // ---- back-transformation: rows of E = rows of W times L^-1  <=>  E^H = L^-H W^H
+  // ---- back-transformation: rows of E = rows of W times L^-1  <=>  E^H = L^-H W^H, kept rows only;
+  // they land at their sorted positions ([i_ev, n) or [0, i_ev)), the other rows of E are zeroed
   {
     std::vector<dm_trsm_problem> t3;
     std::vector<dm_tdesc> tr1, tr2;
-    for (int b : work) {
-      tr1.push_back(dm_tdesc{Ww + loff[b], n_host[b], Tw + loff[b], n_host[b], n_host[b], n_host[b]});
-      t3.push_back(dm_trsm_problem{Lw + loff[b], n_host[b], n_host[b], Tw + loff[b], n_host[b], n_host[b]});
-      tr2.push_back(dm_tdesc{Tw + loff[b], n_host[b], E + off_host[b], n_host[b], n_host[b], n_host[b]});
+    for (size_t i = 0; i < work.size(); ++i) {
+      const int b = work[i];
+      const int n = n_host[b];
+      const int nk = cut_mode == 1 ? n - i_ev[b] : (cut_mode == 2 ? i_ev[b] : n);
+      const int row0 = cut_mode == 1 ? i_ev[b] : 0;
+      if (nk < n) DM_TRY(dm_fill_zero(ctx, E + off_host[b], sizeof(cplx) * (size_t)n * n));
+      if (nk <= 0) continue;
+      tr1.push_back(dm_tdesc{Ww + loff[b], n, Tw + loff[b], nk, nk, n});           // W (nk x n) -> W^H (n x nk)
+      t3.push_back(dm_trsm_problem{Lw + loff[b], n, n, Tw + loff[b], nk, nk});
+      tr2.push_back(dm_tdesc{Tw + loff[b], nk, E + off_host[b] + (size_t)row0 * n, n, n, nk});  // -> rows of E
     }
     DM_TRY(dm_conj_transpose_batched(ctx, tr1));
     DM_TRY(dm_trsm_left_lower_batched(ctx, t3, true));

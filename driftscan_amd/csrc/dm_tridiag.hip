@@ -890,22 +890,34 @@ __global__ void zt_identity_kernel(const rot_mat* __restrict__ rs) {
   if (col < R.n && row < R.n) R.Zt[(size_t)col * R.ldz + row] = (row == col) ? 1.0 : 0.0;
 }
 
+// Zsel[c'][:] = Z[idx[c']][:]  (eigenvector-major: one vector = n contiguous doubles); grid (vector tiles, problems)
+struct zsel_mat { const double* Z; double* Zsel; const int* idx; int n; int nsel; };
+__global__ __launch_bounds__(256) void zsel_gather_kernel(const zsel_mat* __restrict__ zs) {
+  const zsel_mat S = zs[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= S.nsel) return;
+  const double* src = S.Z + (size_t)S.idx[c] * S.n;
+  double* dst = S.Zsel + (size_t)c * S.n;
+  for (int i = lane; i < S.n; i += 64) dst[i] = src[i];
+}
+
 // X[row][col] (complex row-major, ld) = Zt[col*n + row]
-struct cvt_mat { const double* Zt; cplx* X; int ldx; int n; };
+struct cvt_mat { const double* Zt; cplx* X; int ldx; int n; int ncol; };  // X is n x ncol
 __global__ void zt_to_x_kernel(const cvt_mat* __restrict__ cs) {
   __shared__ double tile[32][33];
   const cvt_mat C = cs[blockIdx.z];
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;  // bx: rows of X, by: cols of X
-  if (bx >= C.n || by >= C.n) return;
+  if (bx >= C.n || by >= C.ncol) return;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int jj = ty; jj < 32; jj += 8) {
     const int col = by + jj, row = bx + tx;  // read Zt[col][row], row fastest
-    tile[jj][tx] = (col < C.n && row < C.n) ? C.Zt[(size_t)col * C.n + row] : 0.0;
+    tile[jj][tx] = (col < C.ncol && row < C.n) ? C.Zt[(size_t)col * C.n + row] : 0.0;
   }
   __syncthreads();
   for (int jj = ty; jj < 32; jj += 8) {
     const int row = bx + jj, col = by + tx;
-    if (row < C.n && col < C.n) C.X[(size_t)row * C.ldx + col] = make_double2(tile[tx][jj], 0.0);
+    if (row < C.n && col < C.ncol) C.X[(size_t)row * C.ldx + col] = make_double2(tile[tx][jj], 0.0);
   }
 }
 
@@ -1522,7 +1534,8 @@ hipEvent_t side_event(size_t i) {
 }
 }  // namespace
 
-int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, double* evals, int evals_stride) {
+int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, double* evals, int evals_stride,
+                        dm_eig_select* sel) {
   const int np = (int)probs.size();
   if (np == 0) return DM_OK;
   const size_t mark = dm_ws_mark(ctx);
@@ -1771,10 +1784,53 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
           cp.push_back(dm_cdesc{dd + offn[p], evals + (size_t)p * evals_stride, sizeof(double) * probs[p].n});
       DM_TRY(dm_copy_batched(ctx, cp));
     }
+    // optional selection of the eigenvectors that are back-transformed at all
+    std::vector<const double*> zsrc(np, nullptr);
+    std::vector<int> ncolv(np, 0);
+    for (int p : ch) {
+      zsrc[p] = zfinal.empty() ? Zt + off[p] : zfinal[p];
+      ncolv[p] = probs[p].n;
+    }
+    if (sel) {
+      std::vector<double> hev(totn);
+      DM_TRY(dm_download(ctx, hev.data(), dd, sizeof(double) * totn));
+      if ((int)sel->nsel.size() != np) sel->nsel.assign(np, 0);
+      std::vector<int> hidx;
+      std::vector<size_t> ioff(np, 0), zoff(np, 0);
+      size_t ztot = 0;
+      std::vector<int> cols;
+      for (int p : ch) {
+        const int n = probs[p].n;
+        cols.clear();
+        if (n > 0) sel->pick(p, hev.data() + offn[p], n, cols);
+        for (int c : cols) DM_ARG(ctx, c >= 0 && c < n);
+        ioff[p] = hidx.size();
+        hidx.insert(hidx.end(), cols.begin(), cols.end());
+        sel->nsel[p] = (int)cols.size();
+        zoff[p] = ztot;
+        ztot += cols.size() * (size_t)n;
+      }
+      int* d_idx = dm_ws_upload(ctx, hidx);
+      double* Zsel = dm_ws_alloc_t<double>(ctx, std::max<size_t>(ztot, 1));
+      if (!d_idx || !Zsel) return DM_ENOMEM;
+      std::vector<zsel_mat> zm;
+      int maxsel = 0;
+      for (int p : ch) {
+        if (sel->nsel[p] > 0) zm.push_back(zsel_mat{zsrc[p], Zsel + zoff[p], d_idx + ioff[p], probs[p].n, sel->nsel[p]});
+        maxsel = std::max(maxsel, sel->nsel[p]);
+        zsrc[p] = Zsel + zoff[p];
+        ncolv[p] = sel->nsel[p];
+      }
+      if (!zm.empty()) {
+        zsel_mat* d_zm = dm_ws_upload(ctx, zm);
+        if (!d_zm) return DM_ENOMEM;
+        hipLaunchKernelGGL(zsel_gather_kernel, dim3((maxsel + 3) / 4, (unsigned)zm.size()), dim3(256), 0, ctx->stream, d_zm);
+      }
+    }
     // T4: X = Q Z into the (now free) storage of C, block reflectors applied last to first
     std::vector<cvt_mat> cm(nc);
     for (int i = 0; i < nc; ++i)
-      cm[i] = cvt_mat{zfinal.empty() ? Zt + off[ch[i]] : zfinal[ch[i]], probs[ch[i]].C, probs[ch[i]].ldc, probs[ch[i]].n};
+      cm[i] = cvt_mat{zsrc[ch[i]], probs[ch[i]].C, probs[ch[i]].ldc, probs[ch[i]].n, ncolv[ch[i]]};
     cvt_mat* d_cm = dm_ws_upload(ctx, cm);
     if (!d_cm) return DM_ENOMEM;
     if (small_path) {
@@ -1785,12 +1841,13 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
         const int p = ch[i];
         const int n = probs[p].n;
         if (n <= 0) continue;
-        g.push_back(dm_gemm_make(Ut + off[p], n, 1, false, cm[i].Zt, 1, n, false, probs[p].C, probs[p].ldc, n, n, n, 1.0,
-                                 0.0, nullptr, DM_GEMM_B_REAL));
+        if (ncolv[p] <= 0) continue;
+        g.push_back(dm_gemm_make(Ut + off[p], n, 1, false, cm[i].Zt, 1, n, false, probs[p].C, probs[p].ldc, n, ncolv[p], n,
+                                 1.0, 0.0, nullptr, DM_GEMM_B_REAL));
       }
       DM_TRY(dm_gemm_grouped_launch(ctx, g));
       std::vector<dm_tdesc> tr;
-      for (int p : ch) tr.push_back(dm_tdesc{probs[p].C, probs[p].ldc, probs[p].W, probs[p].ldw, probs[p].n, probs[p].n});
+      for (int p : ch) tr.push_back(dm_tdesc{probs[p].C, probs[p].ldc, probs[p].W, probs[p].ldw, probs[p].n, ncolv[p]});
       DM_TRY(dm_conj_transpose_batched(ctx, tr));
       DM_HIP(ctx, hipGetLastError());
       return DM_OK;
@@ -1884,10 +1941,12 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
         const int r0 = k0 + 1, nr = n - r0;
         cplx* Xr = probs[p].C + (size_t)r0 * probs[p].ldc;
         cplx* w1 = W1 + offn[p] * NBB;
+        const int nx = ncolv[p];  // columns of X = eigenvectors being back-transformed
+        if (nx <= 0) continue;
         g2.push_back(dm_gemm_make(Ut + off[p] + (size_t)k0 * n + r0, n, 1, false, Xr, probs[p].ldc, 1, false, w1, n, kb,
-                                  n, nr));
+                                  nx, nr));
         g4.push_back(dm_gemm_make(Vt + off[p] + (size_t)k0 * n + r0, 1, n, false, w1, n, 1, false, Xr, probs[p].ldc, nr,
-                                  n, kb, -1.0, 1.0));
+                                  nx, kb, -1.0, 1.0));
       }
       if (g2.empty()) continue;
       DM_TRY(dm_gemm_grouped_launch(ctx, g2));
@@ -1895,7 +1954,7 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
     }
     {
       std::vector<dm_tdesc> tr;
-      for (int p : ch) tr.push_back(dm_tdesc{probs[p].C, probs[p].ldc, probs[p].W, probs[p].ldw, probs[p].n, probs[p].n});
+      for (int p : ch) tr.push_back(dm_tdesc{probs[p].C, probs[p].ldc, probs[p].W, probs[p].ldw, probs[p].n, ncolv[p]});
       DM_TRY(dm_conj_transpose_batched(ctx, tr));
     }
     DM_HIP(ctx, hipGetLastError());

@@ -47,6 +47,7 @@ class KLTransform(config.Reader):
     kl_chunk_gb = config.Property(proptype=float, default=48.0)
 
     evdir = ""
+    _cut_ok = True  # subclasses whose _transform needs every mode (DoubleKL) turn the early cut off
     _cvfg = None
     _cvsg = None
 
@@ -133,7 +134,11 @@ class KLTransform(config.Reader):
         With ``to_host=False`` the eigenvectors stay on the device (views into one flat tensor)."""
         ctx = get_context()
         S, N, ndofs, off = self.sn_covariance_device(ms)
-        evals, evoff, evecs, ac, sweeps = ctx.eigh_gen(S, N, ndofs, off)
+        # With `subset` only the modes above the S/N threshold are ever saved (kltransform.py:388-398)
+        # and without `inverse` nothing else needs the discarded ones: they are not back-transformed
+        # (their rows of the returned matrix are zero; `evals` is complete either way).
+        cut = ("upper", self.threshold) if (self.subset and not self.inverse and self._cut_ok) else None
+        evals, evoff, evecs, ac, sweeps = ctx.eigh_gen(S, N, ndofs, off, cut=cut)
         if not to_host:
             return [(evals[evoff[i] : evoff[i] + int(ndofs[i])],
                      evecs[off[i] : off[i] + int(ndofs[i]) ** 2].view(int(ndofs[i]), int(ndofs[i])), None,

@@ -140,14 +140,21 @@ int dm_project_diag(dm_ctx* ctx, int nblk, int F, int K, int T, const void* beam
 int dm_regularise(dm_ctx* ctx, int nblk, const int* n_host, void* mats_dev, const int64_t* off_host, double reg);
 
 /* Generalised Hermitian-definite eigenproblems A v = lambda B v (A, B destroyed).
- * evals ascending at evals_dev + evoff_host[b]; evecs_dev + off_host[b] holds an
- * (n x n) matrix whose ROWS are the modes (the reference's evecs.T.conj()).
- * add_const_host[b] = diagonal shift applied by the non-positive-definite rescue.
+ * evals (ALL of them) ascending at evals_dev + evoff_host[b]; evecs_dev + off_host[b] holds an
+ * (n x n) matrix whose ROWS are the modes (the reference's evecs.T.conj()), row i belonging to
+ * eigenvalue i.  add_const_host[b] = diagonal shift applied by the non-positive-definite rescue.
+ * cut_mode selects which modes are formed at all (the back-transformation and the final
+ * triangular solve are 2/3 of the vector work):
+ *   0  all rows;
+ *   1  only rows i >= i_ev, i_ev = first index with evals[i] >= cut_value (numpy searchsorted) —
+ *      what KLTransform keeps with `subset` (kltransform.py:388-398);
+ *   2  only rows i < i_ev — the foreground-clean modes DoubleKL keeps in its first stage (doublekl.py:54-60).
+ * The other rows of the block are zero.  nkeep_host[b] (may be NULL) receives the number of rows formed.
  * Returns > 0 if a B stays indefinite after the rescue.  Synchronises.
- * Replaces: eigh_gen, drift/core/kltransform.py:55-121. */
+ * Replaces: eigh_gen, drift/core/kltransform.py:55-121 (+ the threshold cuts cited above). */
 int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_dev, const int64_t* off_host,
                 double* evals_dev, const int64_t* evoff_host, void* evecs_dev, double* add_const_host,
-                int* sweeps_host);
+                int* sweeps_host, int cut_mode, double cut_value, int* nkeep_host);
 
 /* Exact per-m Fisher matrices of the band powers for nblk m-blocks:
  *   C_a = E (B C_l^a B^H) E^H,  F[a][b] = sum_ij C_a[i][j] C_b[j][i] / ((lam_i + 1)(lam_j + 1)).

@@ -117,7 +117,28 @@ def test_kl_properties_sample_m(step):
         lam = np.linalg.eigvalsh((Nm + Nm.conj().T) / 2)
         cond = lam[-1] / max(lam[0], 1e-300)
         tol = max(50 * np.finfo(float).eps * cond, 1e-10)  # LAPACK's bound for zhegvd residuals
-        ENE = E @ Nm @ E.conj().T
-        ESE = E @ Sm @ E.conj().T
-        assert np.abs(ENE - np.eye(n)).max() < tol, (mi, n, cond)
-        assert np.abs(ESE - np.diag(ev)).max() < tol * max(1.0, np.abs(ev).max()), (mi, n, cond)
+        # with `subset` (the default) only the modes above the S/N threshold are formed
+        i_ev = int(np.searchsorted(ev, kl.threshold))
+        assert not E[:i_ev].any()
+        Ek, evk = E[i_ev:], ev[i_ev:]
+        if evk.size == 0:
+            continue
+        ENE = Ek @ Nm @ Ek.conj().T
+        ESE = Ek @ Sm @ Ek.conj().T
+        assert np.abs(ENE - np.eye(evk.size)).max() < tol, (mi, n, cond)
+        assert np.abs(ESE - np.diag(evk)).max() < tol * max(1.0, np.abs(evk).max()), (mi, n, cond)
+    # the early cut changes nothing on the kept modes: same step with every mode formed
+    kl.subset = False
+    full = kl._transform_batch(ms, to_host=True)
+    kl.subset = True
+    for i, mi in enumerate(ms):
+        ev, E = out[i][0], out[i][1]
+        if ev.size == 0:
+            continue
+        i_ev = int(np.searchsorted(ev, kl.threshold))
+        assert np.abs(full[i][0] - ev).max() <= 1e-12 * max(np.abs(ev).max(), 1e-300)
+        # same projector onto the kept subspace (rows may differ by phases / rotations in clusters)
+        Nm = Nh[off[i] : off[i] + ev.size**2].reshape(ev.size, ev.size)
+        Pk = E[i_ev:].conj().T @ E[i_ev:] @ Nm
+        Pf = full[i][1][i_ev:].conj().T @ full[i][1][i_ev:] @ Nm
+        assert np.abs(Pk - Pf).max() < 1e-6 * max(np.abs(Pf).max(), 1e-300), mi
