@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--all-modes", action="store_true",
+                    help="form every KL mode (subset = False) instead of only the ones transform_save keeps")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DRIFT_BENCH_STREAMS", "1")),
                     help="concurrent m-block groups per GPU (threads x HIP streams); 2 gives +7 %% m-blocks/s but the "
                          "per-kernel durations (and so the roofline figure) then include the interference")
@@ -183,6 +185,8 @@ def main():
 
     with tempfile.TemporaryDirectory() as tmp:
         tel, bt, kl = build_objects(tmp)
+        if args.all_modes:
+            kl.subset = False
         for _ in range(args.warmup):
             hot_path_step(tel, bt, kl, ctx, streams=args.streams)
         # A full (generation-2) cycle collection walks every object torch/numpy created at import
@@ -261,7 +265,9 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": "configs[1]: 32-feed unpolarised cylinder, nfreq=16, nbase=46, lmax=mmax=128, "
                                        "129 m-blocks per GPU per step, KLTransform with foregrounds",
-                           "nfreq": 16, "nbase": 46, "lmax": 128, "mmax": 128, "sharding": "m-blocks, replicas per GPU", "streams_per_gpu": args.streams},
+                           "nfreq": 16, "nbase": 46, "lmax": 128, "mmax": 128, "sharding": "m-blocks, replicas per GPU", "streams_per_gpu": args.streams,
+                           "kl_products": "all eigenvalues + every mode" if args.all_modes else
+                           "all eigenvalues + the modes with S/N >= threshold (subset = True, what transform_save writes)"},
                 "stage_ms": {"btgen": 1e3 * st[0], "svd": 1e3 * st[1], "kl": 1e3 * st[2]},
                 "kernels_ms": {k: v["ms"] / args.steps for k, v in prof.items()},
                 "roofline": roofline,
