@@ -356,7 +356,8 @@ Context.bt_maps = _bt_maps
 Context.bt_sht = _bt_sht
 
 
-PROF_CLASSES = ["zgemm_grouped", "gemm_grouped_realB", "jac_gram", "jac_inner", "jac_apply", "dgemm_grouped"]
+PROF_CLASSES = ["zgemm_grouped", "gemm_grouped_realB", "jac_gram", "jac_inner", "jac_apply", "dgemm_grouped",
+                "trd_symv", "trd_wx"]  # the last two report algorithmic BYTES in the "flops" field (HBM-bound kernels)
 
 
 def _prof_reset(self, enable=True):

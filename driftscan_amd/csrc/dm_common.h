@@ -40,8 +40,10 @@ struct dm_ctx {
   unsigned long long* prof_dev = nullptr;  // device flop counters, one per class
 };
 
+constexpr int DM_PROF_TRD_STRIDE = 8;  // every 8th column of the tridiagonalisation is timed
+// classes 0-5 carry algorithmic FLOPs, 6-7 (the HBM-bound tridiagonalisation kernels) algorithmic BYTES
 enum { DM_PROF_GEMM = 0, DM_PROF_GEMM_REAL = 1, DM_PROF_JAC_GRAM = 2, DM_PROF_JAC_INNER = 3, DM_PROF_JAC_APPLY = 4,
-       DM_PROF_DGEMM = 5, DM_PROF_NCLASS = 8 };
+       DM_PROF_DGEMM = 5, DM_PROF_TRD_SYMV = 6, DM_PROF_TRD_WX = 7, DM_PROF_NCLASS = 8 };
 
 hipEvent_t dm_prof_event(dm_ctx* ctx);
 // bracket one launch: DM_PROF(ctx, cls, flops) { launch; }

@@ -1690,9 +1690,36 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
         if (k < cmax - 1) {
           const int ng = (cmax - k - 1 + SYG - 1) / SYG;
           const int nslotblk = ((2 * j + 3) / 4 + 3) / 4;  // 4 vectors per wave, 4 waves per workgroup
+          // algorithmic HBM bytes of this column: half of every trailing matrix (symv), one pass over
+          // the panel rows of V and W (wx)
+          // Timed with events on every DM_PROF_TRD_STRIDE-th column only (event records on a chain of
+          // ~2400 short launches are not free: all of them cost 7 % of the step); columns are sampled
+          // uniformly, so the ratio bytes / time of the sample estimates the average of the kernel.
+          const bool timed = ctx->prof_on && (k % DM_PROF_TRD_STRIDE) == 0;
+          double by_symv = 0.0, by_wx = 0.0;
+          if (timed)
+            for (int p : ch) {
+              const double r = probs[p].n - k - 1;
+              if (r > 0) { by_symv += 8.0 * r * r; by_wx += 32.0 * r * j; }
+            }
+          hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+          if (timed) { e0 = dm_prof_event(ctx); (void)hipEventRecord(e0, ctx->stream); }
           hipLaunchKernelGGL(trd_symv_kernel, dim3(nslotblk + ng, nc), dim3(256), 0, ctx->stream, d_tm, k, j);
+          hipEvent_t e1b = nullptr;  // a record owns both of its events: end of symv and start of wx are two events
+          if (timed) {
+            e1 = dm_prof_event(ctx);
+            (void)hipEventRecord(e1, ctx->stream);
+            e1b = dm_prof_event(ctx);
+            (void)hipEventRecord(e1b, ctx->stream);
+          }
           hipLaunchKernelGGL(trd_wx_kernel, dim3((cmax - k - 1 + WXR - 1) / WXR, nc), dim3(256), 0, ctx->stream, d_tm,
                              k, j, 1, k + 1 < k1 ? 1 : 0);
+          if (timed) {
+            e2 = dm_prof_event(ctx);
+            (void)hipEventRecord(e2, ctx->stream);
+            ctx->prof.push_back(dm_ctx::prof_rec{DM_PROF_TRD_SYMV, e0, e1, by_symv});
+            ctx->prof.push_back(dm_ctx::prof_rec{DM_PROF_TRD_WX, e1b, e2, by_wx});
+          }
         }
       }
       if (k1 < cmax) {
