@@ -34,6 +34,7 @@ namespace {
 constexpr int JB = 32;       // rows per block
 constexpr int JP = 64;       // rows per pair
 constexpr int GP = 65;       // LDS pitch (complex elements) of the 64x64 inner matrices
+constexpr int JNT = 1024;    // threads of jac_inner: 2 waves/SIMD hide the LDS latency of the rotation updates (1 WG/CU fits)
 constexpr int QP = 80;       // LDS pitch (doubles) of the Q^H planes in jac_apply
 constexpr int XP = 17;       // LDS pitch (doubles) of the gram staging planes
 
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void jac_gram_kernel(const jac_item* __restric
 // the largest relative off-diagonal |g_ij| / sqrt(g_ii g_jj) seen *before* the
 // solve: the sweep-level convergence measure.
 template <bool HERM>
-__global__ __launch_bounds__(256) void jac_inner_kernel(const jac_item* __restrict__ items,
+__global__ __launch_bounds__(JNT) void jac_inner_kernel(const jac_item* __restrict__ items,
                                                         const int* __restrict__ active,
                                                         const double* __restrict__ absfloor_p,
                                                         const cplx* __restrict__ Gbuf, cplx* __restrict__ Qbuf,
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void jac_inner_kernel(const jac_item* __restri
   const double absfloor = absfloor_p ? absfloor_p[it.prob] : 0.0;
 
   // ---- load G (Hermitian by construction), Q = I
-  for (int idx = tid; idx < JP * JP; idx += 256) {
+  for (int idx = tid; idx < JP * JP; idx += JNT) {
     int r = idx >> 6, c = idx & 63;
     cplx v;
     if (HERM) {
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void jac_inner_kernel(const jac_item* __restri
   __syncthreads();
   if (HERM) {
     // enforce exact Hermitian symmetry from the lower triangle
-    for (int idx = tid; idx < JP * JP; idx += 256) {
+    for (int idx = tid; idx < JP * JP; idx += JNT) {
       int r = idx >> 6, c = idx & 63;
       if (r < c) {
         cplx v = G[c * GP + r];
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256) void jac_inner_kernel(const jac_item* __restri
 
   // ---- convergence measure before the solve
   double mo = 0.0;
-  for (int idx = tid; idx < JP * JP; idx += 256) {
+  for (int idx = tid; idx < JP * JP; idx += JNT) {
     int r = idx >> 6, c = idx & 63;
     if (r < c) {
       cplx g = G[r * GP + c];
@@ -203,7 +204,11 @@ __global__ __launch_bounds__(256) void jac_inner_kernel(const jac_item* __restri
   mo = dm_wave_max(mo);
   if ((tid & 63) == 0) red[tid >> 6] = mo;
   __syncthreads();
-  mo = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  {
+    double m2 = red[0];
+    for (int w = 1; w < JNT / 64; ++w) m2 = fmax(m2, red[w]);
+    mo = m2;
+  }
   if (tid == 0) {
     atomicMax(&offmax[it.prob], (unsigned long long)__double_as_longlong(mo));
     skip[it.q] = (mo <= tol_outer || measure_only) ? 1 : 0;
@@ -240,43 +245,70 @@ __global__ __launch_bounds__(256) void jac_inner_kernel(const jac_item* __restri
         if (act) ctl[0] = 1;  // benign race: all writers store 1
       }
       __syncthreads();
-      // phase B: column rotation of G and Q:  col_p' = c col_p - conj(sp) col_q ; col_q' = sp col_p + c col_q
+      // phase B: G <- J^H G J and Q <- Q J for the 32 disjoint rotations of this step, with
+      //   J restricted to pair t = [[c, sp], [-conj(sp), c]].  G is updated by 2x2 blocks:
+      //   G'[A][B] = J_A^H G[A][B] J_B touches only the block itself, so the pairs A <= B are
+      //   transformed once and mirrored (Hermitian) — a quarter of the LDS reads of separate
+      //   column and row passes, and one barrier less per step.
+      auto pair_of = [&](int t, int& pp, int& qq) {
+        if (t == 0) { pp = 63; qq = step; }
+        else { pp = (step + t) % 63; qq = (step + 63 - t) % 63; }
+      };
 #pragma unroll 2
-      for (int i = 0; i < 8; ++i) {
-        int u = tid + 256 * i;
+      for (int i = 0; i < 1024 / JNT; ++i) {
+        const int u = tid + JNT * i;
+        const int ta = u >> 5, tb = u & 31;
+        if (ta > tb) continue;
+        const int aa = ctl[1 + ta], ab = ctl[1 + tb];
+        if (!aa && !ab) continue;
+        int pa, qa, pb, qb;
+        pair_of(ta, pa, qa);
+        pair_of(tb, pb, qb);
+        const double ca = rc[ta], cb = rc[tb];
+        const cplx sa = rs[ta], sb = rs[tb];
+        if (ta == tb) {
+          // diagonal block of an active pair: the rotation annihilates the off-diagonal element
+          const cplx gpp = G[pa * GP + pa], gqq = G[qa * GP + qa], gpq = G[pa * GP + qa];
+          // (J^H X J)_pp = c^2 gpp + |s|^2 gqq - 2 c Re(conj(sp) ... ) — formed through the two half steps
+          // X1 = X J (columns), X2 = J^H X1 (rows), keeping only the real diagonal
+          const cplx gqp = make_double2(gpq.x, -gpq.y);
+          const cplx x_pp = csub(cscale(gpp, ca), cmulc(gpq, sa));   // c gpp - conj(sp) gpq
+          const cplx x_pq = cadd(cmul(sa, gpp), cscale(gpq, ca));     // sp gpp + c gpq
+          const cplx x_qp = csub(cscale(gqp, ca), cmulc(gqq, sa));   // c gqp - conj(sp) gqq
+          const cplx x_qq = cadd(cmul(sa, gqp), cscale(gqq, ca));     // sp gqp + c gqq
+          const cplx n_pp = csub(cscale(x_pp, ca), cmul(sa, x_qp));   // c x_pp - sp x_qp
+          const cplx n_qq = cadd(cmulc(x_pq, sa), cscale(x_qq, ca));  // conj(sp) x_pq + c x_qq
+          G[pa * GP + pa] = make_double2(n_pp.x, 0.0);
+          G[qa * GP + qa] = make_double2(n_qq.x, 0.0);
+          G[pa * GP + qa] = make_double2(0.0, 0.0);
+          G[qa * GP + pa] = make_double2(0.0, 0.0);
+          continue;
+        }
+        const cplx g00 = G[pa * GP + pb], g01 = G[pa * GP + qb], g10 = G[qa * GP + pb], g11 = G[qa * GP + qb];
+        // columns: [x0 x1] = [g0 g1] J_B
+        const cplx x00 = csub(cscale(g00, cb), cmulc(g01, sb)), x01 = cadd(cmul(sb, g00), cscale(g01, cb));
+        const cplx x10 = csub(cscale(g10, cb), cmulc(g11, sb)), x11 = cadd(cmul(sb, g10), cscale(g11, cb));
+        // rows: [n0; n1] = J_A^H [x0; x1] :  n0 = c x0 - sp x1,  n1 = conj(sp) x0 + c x1
+        const cplx n00 = csub(cscale(x00, ca), cmul(sa, x10)), n01 = csub(cscale(x01, ca), cmul(sa, x11));
+        const cplx n10 = cadd(cmulc(x00, sa), cscale(x10, ca)), n11 = cadd(cmulc(x01, sa), cscale(x11, ca));
+        G[pa * GP + pb] = n00; G[pa * GP + qb] = n01; G[qa * GP + pb] = n10; G[qa * GP + qb] = n11;
+        G[pb * GP + pa] = make_double2(n00.x, -n00.y);
+        G[qb * GP + pa] = make_double2(n01.x, -n01.y);
+        G[pb * GP + qa] = make_double2(n10.x, -n10.y);
+        G[qb * GP + qa] = make_double2(n11.x, -n11.y);
+      }
+#pragma unroll 2
+      for (int i = 0; i < 2048 / JNT; ++i) {
+        int u = tid + JNT * i;
         int t = u & 31, r = u >> 5;
         if (!ctl[1 + t]) continue;
-        int p, q;
-        if (t == 0) { p = 63; q = step; }
-        else { p = (step + t) % 63; q = (step + 63 - t) % 63; }
+        int pp, qq;
+        pair_of(t, pp, qq);
         double c = rc[t];
         cplx sp = rs[t];
-        cplx gp = G[r * GP + p], gq = G[r * GP + q];
-        G[r * GP + p] = csub(cscale(gp, c), cmulc(gq, sp));   // c gp - conj(sp) gq
-        G[r * GP + q] = cadd(cmul(sp, gp), cscale(gq, c));
-        cplx qp = Q[r * GP + p], qq = Q[r * GP + q];
-        Q[r * GP + p] = csub(cscale(qp, c), cmulc(qq, sp));
-        Q[r * GP + q] = cadd(cmul(sp, qp), cscale(qq, c));
-      }
-      __syncthreads();
-      // phase C: row rotation of G:  row_p' = c row_p - sp row_q ; row_q' = conj(sp) row_p + c row_q
-#pragma unroll 2
-      for (int i = 0; i < 8; ++i) {
-        int u = tid + 256 * i;
-        int t = u & 31, col = u >> 5;
-        if (!ctl[1 + t]) continue;
-        int p, q;
-        if (t == 0) { p = 63; q = step; }
-        else { p = (step + t) % 63; q = (step + 63 - t) % 63; }
-        double c = rc[t];
-        cplx sp = rs[t];
-        cplx gp = G[p * GP + col], gq = G[q * GP + col];
-        cplx np_ = csub(cscale(gp, c), cmul(sp, gq));
-        cplx nq_ = cadd(cmulc(gp, sp), cscale(gq, c));  // conj(sp) gp + c gq
-        if (col == p) { np_.y = 0.0; nq_ = make_double2(0.0, 0.0); }
-        if (col == q) { nq_.y = 0.0; np_ = make_double2(0.0, 0.0); }
-        G[p * GP + col] = np_;
-        G[q * GP + col] = nq_;
+        cplx qp = Q[r * GP + pp], qv = Q[r * GP + qq];
+        Q[r * GP + pp] = csub(cscale(qp, c), cmulc(qv, sp));
+        Q[r * GP + qq] = cadd(cmul(sp, qp), cscale(qv, c));
       }
       __syncthreads();
     }
@@ -285,7 +317,7 @@ __global__ __launch_bounds__(256) void jac_inner_kernel(const jac_item* __restri
   }
 
   cplx* Qo = Qbuf + (size_t)it.q * JP * JP;
-  for (int idx = tid; idx < JP * JP; idx += 256) {
+  for (int idx = tid; idx < JP * JP; idx += JNT) {
     int r = idx >> 6, c = idx & 63;
     Qo[idx] = Q[r * GP + c];
   }
@@ -519,7 +551,7 @@ void tournament(int nb, std::vector<std::vector<std::pair<int, int>>>& rounds) {
 }
 
 constexpr size_t INNER_LDS = (size_t)2 * JP * GP * sizeof(cplx) + 32 * sizeof(double) + 32 * sizeof(cplx) +
-                             40 * sizeof(int) + 4 * sizeof(double) + 64;
+                             40 * sizeof(int) + 4 * sizeof(double) + 64 + 16 * sizeof(double);  // + room for JNT / 64 reduction slots
 constexpr size_t APPLY_LDS = (size_t)2 * JP * QP * sizeof(double);
 
 bool g_attr_set = false;
@@ -669,7 +701,7 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
       if (ni == 0) continue;
       hipLaunchKernelGGL(jac_gram_kernel, dim3(ni), dim3(256), 0, ctx->stream, d_items + nb, d_active, d_G,
                          (unsigned long long*)nullptr);
-      hipLaunchKernelGGL(jac_inner_kernel<false>, dim3(ni), dim3(256), INNER_LDS, ctx->stream, d_items + nb, d_active,
+      hipLaunchKernelGGL(jac_inner_kernel<false>, dim3(ni), dim3(JNT), INNER_LDS, ctx->stream, d_items + nb, d_active,
                          (const double*)d_floor, d_G, d_Q, d_off, d_skip, tol_outer, tol_inner, 1);
     }
     DM_HIP(ctx, hipGetLastError());
@@ -760,7 +792,7 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
       }
       {
         dm_prof_scope ps(ctx, DM_PROF_JAC_INNER, 0.0);
-        hipLaunchKernelGGL(jac_inner_kernel<false>, dim3(ni), dim3(256), INNER_LDS, ctx->stream, d_items + nb,
+        hipLaunchKernelGGL(jac_inner_kernel<false>, dim3(ni), dim3(JNT), INNER_LDS, ctx->stream, d_items + nb,
                            d_active, (const double*)d_floor, d_G, d_Q, d_off, d_skip, tol_outer, tol_inner, 0);
       }
       {
@@ -904,7 +936,7 @@ int dm_jacobi_herm(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, d
       unsigned long long* fc = ctx->prof_on ? ctx->prof_dev + DM_PROF_JAC_APPLY : nullptr;
       {
         dm_prof_scope ps(ctx, DM_PROF_JAC_INNER, 0.0);
-        hipLaunchKernelGGL(jac_inner_kernel<true>, dim3(ni), dim3(256), INNER_LDS, ctx->stream, icur, d_active,
+        hipLaunchKernelGGL(jac_inner_kernel<true>, dim3(ni), dim3(JNT), INNER_LDS, ctx->stream, icur, d_active,
                            d_floor, (const cplx*)nullptr, d_Q, d_off, d_skip, tol_outer, tol_inner, 0);
       }
       {
