@@ -411,7 +411,7 @@ __global__ __launch_bounds__(TST) void trd_small_kernel(const trs_mat* __restric
   cplx* ws = vs + TSM;                                    // TSM
   cplx* ph = ws + TSM;                                    // 4 x TSM partial matvec
   cplx* taus = ph + 4 * TSM;                              // TSM
-  double* red = reinterpret_cast<double*>(taus + TSM);    // 3 x 8
+  double* red = reinterpret_cast<double*>(taus + TSM);    // 3 x NW
   constexpr int NW = TST / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // the upper triangle is the reference (as in the panel path); mirror it
@@ -491,11 +491,11 @@ __global__ __launch_bounds__(TST) void trd_small_kernel(const trs_mat* __restric
     }
     dr = dm_wave_sum(dr);
     di = dm_wave_sum(di);
-    if (lane == 0) { red[8 + wave] = dr; red[16 + wave] = di; }
+    if (lane == 0) { red[NW + wave] = dr; red[2 * NW + wave] = di; }
     __syncthreads();
     double dre = 0.0, dim = 0.0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) { dre += red[8 + w]; dim += red[16 + w]; }
+    for (int w = 0; w < NW; ++w) { dre += red[NW + w]; dim += red[2 * NW + w]; }
     const cplx coef = cscale(cmul(tau, make_double2(dre, dim)), 0.5);
     if (tid < n) ws[tid] = tid > k ? csub(pt, cmul(coef, vi)) : make_double2(0.0, 0.0);
     __syncthreads();
@@ -1668,7 +1668,7 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
       }
       trs_mat* d_sm = dm_ws_upload(ctx, sm);
       if (!d_sm) return DM_ENOMEM;
-      const size_t lds = sizeof(cplx) * (TSM * TSP + 7 * TSM) + sizeof(double) * 24;
+      const size_t lds = sizeof(cplx) * (TSM * TSP + 7 * TSM) + sizeof(double) * 3 * (TST / 64);
       static bool attr = false;
       if (!attr) {
         DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(trd_small_kernel),
