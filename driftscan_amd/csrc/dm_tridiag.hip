@@ -75,15 +75,9 @@ constexpr int WXR = 64;    // rows per workgroup in trd_wx
 
 struct trd_refl { cplx tau, scal; double beta; };
 
-__device__ __forceinline__ trd_refl trd_reflector(const trd_mat& M, int k) {
-  // the partial norms are fetched one per lane and folded with shuffles: a serial scalar loop
-  // over up to n/64 partials would put that many dependent load latencies in front of every wave
-  const int np = (M.n - k + WXR - 1) / WXR;
-  const int lane = threadIdx.x & 63;
-  double xnorm2 = 0.0;
-  for (int t = lane; t < np; t += 64) xnorm2 += dm_ldg(M.Np, t);
-  const cplx alpha = dm_ldg(M.x, k + 1);
-  xnorm2 = dm_wave_sum(xnorm2);
+// Householder scalars of column k from this lane's share of the partial norms and alpha = x[k+1]
+__device__ __forceinline__ trd_refl trd_reflector_from(double npart_lane, cplx alpha) {
+  const double xnorm2 = dm_wave_sum(npart_lane);
   trd_refl R;
   if (xnorm2 == 0.0 && alpha.y == 0.0) {
     R.tau = make_double2(0.0, 0.0);
@@ -97,6 +91,21 @@ __device__ __forceinline__ trd_refl trd_reflector(const trd_mat& M, int k) {
     R.scal = make_double2(dr / den, -di / den);
   }
   return R;
+}
+
+// the partial norms are fetched one per lane and folded with shuffles: a serial scalar loop
+// over up to n/64 partials would put that many dependent load latencies in front of every wave
+__device__ __forceinline__ double trd_npart_lane(const trd_mat& M, int k) {
+  const int np = (M.n - k + WXR - 1) / WXR;
+  double s = 0.0;
+  for (int t = threadIdx.x & 63; t < np; t += 64) s += dm_ldg(M.Np, t);
+  return s;
+}
+
+__device__ __forceinline__ trd_refl trd_reflector(const trd_mat& M, int k) {
+  const double npart = trd_npart_lane(M, k);
+  const cplx alpha = dm_ldg(M.x, k + 1);
+  return trd_reflector_from(npart, alpha);
 }
 
 // v[c] for c > k (v[k+1] = 1, the rest is the scaled column)
@@ -117,8 +126,8 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const trd_mat* __restrict
   const int nslotblk = (nslot + 3) / 4;
   if ((int)blockIdx.x >= nslotblk && k + 1 + SYG * ((int)blockIdx.x - nslotblk) >= n) return;  // no rows left
   if ((int)blockIdx.x < nslotblk && (int)blockIdx.x * 4 + wave >= nslot) return;
-  const trd_refl R = trd_reflector(M, k);
   if ((int)blockIdx.x < nslotblk) {
+    const trd_refl R = trd_reflector(M, k);
     // a[q] = W_q^H v, b[q] = V_q^H v (needed by trd_wx); vector index q < j: W_q, else V_{q-j}
     const int q0 = (blockIdx.x * 4 + wave) * SLV;
     const cplx* xs[SLV];
@@ -166,7 +175,17 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const trd_mat* __restrict
   int c = R0 + lane;
   bool valid = c < n;
   int cc = min(c, n - 1);
-  const cplx vc0t = trd_v_at(M, R, k, cc);
+  // Every load of the prologue is issued before anything waits: the partial norms, alpha, the
+  // column values under this chunk and the SYR matrix rows are independent of each other, only
+  // their USE needs the Householder scalars — one exposed memory latency instead of three.
+  const double npart = trd_npart_lane(M, k);
+  const cplx alpha = dm_ldg(M.x, k + 1);
+  const cplx xraw0 = dm_ldg(M.x, cc);
+  cplx araw[SYR];
+#pragma unroll
+  for (int rr = 0; rr < SYR; ++rr) araw[rr] = dm_ldg(A, (size_t)min(rstart + rr, n - 1) * lda + cc);
+  const trd_refl R = trd_reflector_from(npart, alpha);
+  const cplx vc0t = (cc == k + 1) ? make_double2(1.0, 0.0) : cmul(xraw0, R.scal);
   const cplx vc0 = valid ? vc0t : zero;
   if (wave == 0) {
     if (lane < SYG && valid) {
@@ -192,8 +211,7 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const trd_mat* __restrict
 #pragma unroll
     for (int rr = 0; rr < SYR; ++rr) {
       const int r = rstart + rr;
-      const cplx v = dm_ldg(A, (size_t)min(r, n - 1) * lda + cc);
-      a[rr] = (valid && r < n && c >= r) ? v : zero;
+      a[rr] = (valid && r < n && c >= r) ? araw[rr] : zero;
     }
     cplx col = zero;
 #pragma unroll
