@@ -318,6 +318,21 @@ __global__ __launch_bounds__(256) void trd_wx_kernel(const trd_mat* __restrict__
   const int npan = do_w ? j : 0;  // finished panel vectors
   __shared__ cplx sa[TNB], sb[TNB], swk[TNB], svk[TNB];
   __shared__ cplx qbuf[3][WXR], xbuf[3][WXR];
+  // wave 0 finishes the rows: everything it will need from global memory that does not depend on
+  // the other waves is requested now, so that its tail pays no further memory latency
+  cplx e_tau = make_double2(0.0, 0.0), e_vv = make_double2(0.0, 0.0), e_a = make_double2(0.0, 0.0),
+       e_pkx = make_double2(0.0, 0.0);
+  double e_s = 0.0;
+  if (wave == 0) {
+    if (w_on) {
+      e_tau = dm_ldg(M.tau, k);
+      const int ng = (n - k - 1 + SYG - 1) / SYG;
+      for (int t = lane; t < ng; t += 64) e_s += dm_ldg(M.Sp, t);
+      if (i < n) e_vv = dm_ldg(M.Vp, (size_t)j * n + i);
+      if (x_on) e_pkx = dm_ldg(M.p, kx);
+    }
+    if (x_on && i < n) e_a = dm_ldg(M.A, (size_t)kx * M.lda + i);
+  }
   if (tid < npan) {
     sa[tid] = M.ab[tid];
     sb[tid] = M.ab[j + tid];
@@ -356,10 +371,8 @@ __global__ __launch_bounds__(256) void trd_wx_kernel(const trd_mat* __restrict__
   cplx tau = make_double2(0.0, 0.0), wk1 = make_double2(0.0, 0.0);
   double coef = 0.0;
   if (w_on) {
-    tau = M.tau[k];
-    const int ng = (n - k - 1 + SYG - 1) / SYG;
-    double s = 0.0, ab = 0.0, cr = 0.0, ci = 0.0;
-    for (int t = lane; t < ng; t += 64) s += M.Sp[t];
+    tau = e_tau;
+    double s = e_s, ab = 0.0, cr = 0.0, ci = 0.0;
     for (int t = lane; t < npan; t += 64) {
       ab += sa[t].x * sb[t].x + sa[t].y * sb[t].y;  // Re(conj(a) b)
       if (x_on) {
@@ -375,7 +388,7 @@ __global__ __launch_bounds__(256) void trd_wx_kernel(const trd_mat* __restrict__
     // p^H v = conj(tau) (v^H A v - a^H b - b^H a)  (real);  coef = (tau/2) p^H v
     coef = 0.5 * (tau.x * tau.x + tau.y * tau.y) * (s - 2.0 * ab);
     if (x_on) {  // w_k[k+1]: the mirrored part of p vanishes on the first trailing row
-      const cplx q1 = csub(M.p[kx], make_double2(cr, ci));
+      const cplx q1 = csub(e_pkx, make_double2(cr, ci));
       wk1 = cmul(tau, q1);
       wk1.x -= coef;
     }
@@ -384,14 +397,14 @@ __global__ __launch_bounds__(256) void trd_wx_kernel(const trd_mat* __restrict__
   if (i < n) {
     cplx wv = make_double2(0.0, 0.0), vv = make_double2(0.0, 0.0);
     if (w_on) {
-      vv = M.Vp[(size_t)j * n + i];
+      vv = e_vv;
       wv = cmul(tau, q);
       wv.x -= coef * vv.x;
       wv.y -= coef * vv.y;
       M.Wp[(size_t)j * n + i] = wv;
     }
     if (x_on) {
-      const cplx a = M.A[(size_t)kx * M.lda + i];
+      const cplx a = e_a;
       cplx xx = make_double2(a.x + xacc.x, -a.y + xacc.y);
       if (w_on) xx = csub(xx, cadd(cmulc(vv, wk1), wv));  // panel vector j: V[j][kx] = 1
       M.x[i] = xx;
