@@ -505,6 +505,95 @@ class BeamTransfer(config.Reader):
         return vecf
 
 
+class BeamTransferFullSVD(BeamTransfer):
+    """One SVD of the full (all sky polarisations) noise-weighted beam per (m, frequency) instead of
+    the three-stage chain (beamtransfer.py:1595-1733): the same device chain run on the blocks with
+    the (pol, l) axes flattened into one, i.e. SVD3 alone on an (ntel x npol*(lmax+1)) matrix.
+    (The reference keeps rows whose singular value is exactly zero; they are null rows here.)"""
+
+    @property
+    def svd_len(self):
+        return min((self.telescope.lmax + 1) * self.telescope.num_pol_sky, self.ntel)
+
+    def svd_device(self, beam_blocks, skip_svd_inv=False):
+        ctx = get_context()
+        nblk, F = int(beam_blocks.shape[0]), int(beam_blocks.shape[1])
+        T, P, L = self.ntel, self.telescope.num_pol_sky, self.telescope.lmax + 1
+        nw = ctx.to_device(self._noisew())
+        res = ctx.svd_chain(beam_blocks.reshape(nblk, F, T, 1, P * L), nw, self.polsvcut, skip_svd_inv=skip_svd_inv)
+        K = int(res["beam_svd"].shape[2])
+        res["beam_svd"] = res["beam_svd"].reshape(nblk, F, K, P, L)
+        if res.get("invbeam_svd") is not None:
+            res["invbeam_svd"] = res["invbeam_svd"].reshape(nblk, F, P, L, K)
+        return res
+
+
+class BeamTransferNoSVD(BeamTransfer):
+    """No SVD compression: the "SVD basis" is the telescope basis itself, ndof = nfreq * ntel
+    (beamtransfer.py:1736-1968).  The batched device paths of the KL transform see the
+    un-compressed beam as `beam_svd` and an identity as `beam_ut`."""
+
+    svcut = 0.0
+    noise_weight = False
+
+    def _svd_num(self, mi):
+        svnum = (np.ones(self.nfreq) * self.ntel).astype(int)
+        return svnum, np.cumsum(np.insert(svnum, 0, 0))
+
+    def _generate_svdfiles(self, regen=False, skip_svd_inv=False):
+        logger.info("======== Skipping telescope SVD step ========")
+
+    def _dev_products(self, mi):
+        ctx = get_context()
+        if mi not in self._dev:
+            tel = self.telescope
+            F, T = self.nfreq, self.ntel
+            beam = np.ascontiguousarray(self.beam_m(mi).reshape(F, T, tel.num_pol_sky, tel.lmax + 1))
+            eye = np.ascontiguousarray(np.broadcast_to(np.eye(T, dtype=np.complex128), (F, T, T)))
+            self._dev[mi] = dict(beam_svd=ctx.to_device(beam), beam_ut=ctx.to_device(eye), singularvalues=None)
+        return self._dev[mi]
+
+    def project_matrix_sky_to_svd(self, mi, mat, temponly=False):
+        return self.project_matrix_sky_to_telescope(mi, mat, temponly=temponly).reshape(self.ndof(mi), self.ndof(mi))
+
+    def project_vector_sky_to_svd(self, mi, vec, *args, **kwargs):
+        return self.project_vector_sky_to_telescope(mi, vec).flatten()
+
+    def project_matrix_telescope_to_svd(self, mi, mat):
+        return np.asarray(mat).reshape(self.ndof(mi), self.ndof(mi))
+
+    def project_matrix_diagonal_telescope_to_svd(self, mi, dmat, *args, **kwargs):
+        return np.diag(np.asarray(dmat).flatten())
+
+    def project_vector_telescope_to_svd(self, mi, vec, *args, **kwargs):
+        return np.asarray(vec).flatten()
+
+    def project_vector_svd_to_sky(self, mi, vec, temponly=False, conj=False):
+        if temponly:
+            raise NotImplementedError("temponly not implemented for no-SVD project_vector_svd_to_sky!")
+        tel = self.telescope
+        vec = np.asarray(vec)
+        svec = np.zeros((self.nfreq, tel.num_pol_sky, tel.lmax + 1) + vec.shape[1:], dtype=np.complex128)
+        v = vec.reshape(self.nfreq, self.ntel, -1)
+        if conj:
+            mats = self.beam_m(mi).reshape(self.nfreq, self.ntel, self.nsky).transpose(0, 2, 1).conj()
+        else:
+            mats = self.invbeam_m(mi).reshape(self.nfreq, self.nsky, self.ntel)
+        for fi in range(self.nfreq):
+            svec[fi] = _device_gemm(mats[fi], v[fi]).reshape((tel.num_pol_sky, tel.lmax + 1) + vec.shape[1:])
+        return svec
+
+    def beam_svd(self, mi, *args, **kwargs):
+        return self.beam_m(mi)
+
+    def ndof(self, mi, *args, **kwargs):
+        return self.ntel * self.nfreq
+
+    @property
+    def ndofmax(self):
+        return self.ntel * self.nfreq
+
+
 def _device_gemm(A, B):
     """A @ B through the grouped ZGEMM of libdriftmi (small helper for the vector projections)."""
     ctx = get_context()

@@ -85,9 +85,12 @@ class ProductManager(object):
         self.directory = os.path.expandvars(os.path.expanduser(yconf["config"]["output_directory"]))
         telclass = _resolve_class(yconf["telescope"]["type"], teltype_dict, "telescope")
         self.telescope = telclass.from_config(yconf["telescope"])
-        if yconf["config"].get("nosvd") or yconf["config"].get("fullsvd"):
-            raise NotImplementedError("BeamTransferNoSVD / FullSVD are not part of this build (SURVEY.md §8f)")
-        self.beamtransfer = beamtransfer.BeamTransfer(self.directory + "/bt/", telescope=self.telescope)
+        btclass = beamtransfer.BeamTransfer
+        if yconf["config"].get("nosvd"):
+            btclass = beamtransfer.BeamTransferNoSVD
+        if yconf["config"].get("fullsvd"):
+            btclass = beamtransfer.BeamTransferFullSVD
+        self.beamtransfer = btclass(self.directory + "/bt/", telescope=self.telescope)
         self.beamtransfer.read_config(yconf["config"])
         self.gen_beams = bool(yconf["config"].get("beamtransfers"))
         self.skip_svd = bool(yconf["config"].get("skip_svd"))

@@ -466,9 +466,68 @@ def gen_psfisher(ref):
     print("psfisher.npz")
 
 
+def gen_bt_variants(ref):
+    """BeamTransferNoSVD (covariances + KL spectrum in the telescope basis) and BeamTransferFullSVD
+    (one SVD of the full polarised beam per frequency), by the reference."""
+    btmod, klmod = ref["beamtransfer"], ref["kltransform"]
+    out = {}
+    # ---- NoSVD, unpolarised
+    F, B, P, lmax, seed = 3, 5, 1, 10, 4101
+    rng = np.random.default_rng(seed)
+    L = lmax + 1
+    redundancy = rng.integers(1, 6, size=B).astype(np.float64)
+    npower = (2.5e-7 * (1.0 + 0.1 * np.arange(F))[:, None] / redundancy[None, :]).astype(np.float64)
+    tel = FakeTelescope(F, B, P, lmax, lmax, npower, tsys_flat=1.0)
+    bt = btmod.BeamTransferNoSVD("/mem/nosvd/bt", telescope=tel)
+    cv_sg = analytic_cl(tel.frequencies, L, P, "signal")
+    cv_fg = analytic_cl(tel.frequencies, L, P, "foreground", fg_amp=3e-9)
+    kl = klmod.KLTransform(bt, subdir="kl")
+    kl._cvsg, kl._cvfg = cv_sg, cv_fg
+    kl.threshold = 0.1
+    out.update(nosvd_dims=np.array([F, B, P, lmax]), nosvd_npower=npower, nosvd_cv_sg=cv_sg, nosvd_cv_fg=cv_fg,
+               nosvd_mlist=np.array([0, 3]))
+    for mi in [0, 3]:
+        beam = synth_beam_m(rng, F, B, P, L, mi)
+        write_beam_file(ref, bt, mi, beam)
+        cs, cn = kl.sn_covariance(mi)
+        evals, evecs, inv, extra = kl._transform_m(mi)
+        vec = rng.standard_normal((F, P, L)) + 1j * rng.standard_normal((F, P, L))
+        vec[..., :mi] = 0
+        pre = "nosvd_m%d_" % mi
+        out[pre + "beam_m"] = beam
+        out[pre + "cs"], out[pre + "cn"], out[pre + "evals"] = cs, cn, evals
+        out[pre + "vec_sky"] = vec
+        out[pre + "sky_to_svd"] = bt.project_vector_sky_to_svd(mi, vec)
+        out[pre + "svd_to_sky_conj"] = bt.project_vector_svd_to_sky(mi, bt.project_vector_sky_to_svd(mi, vec), conj=True)
+        out[pre + "ndof"] = bt.ndof(mi)
+    # ---- FullSVD, polarised: needs every m file
+    F, B, P, lmax, seed = 2, 4, 4, 8, 4102
+    rng = np.random.default_rng(seed)
+    L = lmax + 1
+    redundancy = rng.integers(1, 6, size=B).astype(np.float64)
+    npower = (2.5e-7 * (1.0 + 0.1 * np.arange(F))[:, None] / redundancy[None, :]).astype(np.float64)
+    tel = FakeTelescope(F, B, P, lmax, lmax, npower, tsys_flat=1.0)
+    bt = btmod.BeamTransferFullSVD("/mem/fullsvd/bt", telescope=tel)
+    out.update(fullsvd_dims=np.array([F, B, P, lmax]), fullsvd_npower=npower)
+    for mi in range(lmax + 1):
+        beam = synth_beam_m(rng, F, B, P, L, mi, polrank=None, polscale=0.3)
+        write_beam_file(ref, bt, mi, beam)
+        out["fullsvd_m%d_beam_m" % mi] = beam
+    bt._generate_svdfiles()
+    for mi in range(lmax + 1):
+        svd = read_svd_file(bt, mi)
+        for k, v in svd.items():
+            out["fullsvd_m%d_%s" % (mi, k)] = v
+    np.savez_compressed(os.path.join(OUT, "bt_variants.npz"), **out)
+    print("bt_variants.npz")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = refimport.load()
+    if len(sys.argv) > 1 and sys.argv[1] == "variants":
+        gen_bt_variants(ref)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "psfisher":
         gen_psfisher(ref)
         return
