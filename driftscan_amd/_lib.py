@@ -66,6 +66,9 @@ SIGNATURES = {
     "dm_bt_sht": (
         c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_int, c_int, c_int, c_int, c_int,
                 c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_vp, c_vp]),
+    "dm_bt_sht_range": (
+        c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_int, c_int, c_int, c_int, c_int,
+                c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_vp, c_vp]),
 }
 
 _lib = None
@@ -340,14 +343,21 @@ def _bt_maps(self, nside, cth, sth, frame, polarised, beams, uv, bi, bj, maps):
     self.check(rc, "dm_bt_maps")
 
 
-def _bt_sht(self, nside, cth, sth, polarised, lside, mmax, lmax_grp, F, B, col_f, col_b, col_lmax, maps, beam_m):
+def _bt_sht(self, nside, cth, sth, polarised, lside, mmax, lmax_grp, F, B, col_f, col_b, col_lmax, maps, beam_m,
+            m_range=None):
+    """m_range = (m_lo, m_hi): only those m-blocks are produced and `beam_m` has m_hi - m_lo + 1 of them."""
     c, cp = _darr(cth)
     s_, sp = _darr(sth)
     f_, fp = _iarr(col_f)
     b_, bp = _iarr(col_b)
     l_, lp = _iarr(col_lmax)
-    rc = self.lib.dm_bt_sht(self.h, int(nside), cp, sp, int(bool(polarised)), int(lside), int(mmax), int(lmax_grp),
-                            int(F), int(B), len(f_), fp, bp, lp, self.ptr(maps), self.ptr(beam_m))
+    if m_range is None:
+        rc = self.lib.dm_bt_sht(self.h, int(nside), cp, sp, int(bool(polarised)), int(lside), int(mmax), int(lmax_grp),
+                                int(F), int(B), len(f_), fp, bp, lp, self.ptr(maps), self.ptr(beam_m))
+    else:
+        rc = self.lib.dm_bt_sht_range(self.h, int(nside), cp, sp, int(bool(polarised)), int(lside), int(m_range[0]),
+                                      int(m_range[1]), int(lmax_grp), int(F), int(B), len(f_), fp, bp, lp,
+                                      self.ptr(maps), self.ptr(beam_m))
     self.check(rc, "dm_bt_sht")
 
 

@@ -199,13 +199,26 @@ class BeamTransfer(config.Reader):
         tel = self.telescope
         ctx = get_context()
         st = time.time()
-        beam_all = btgen.beam_m_all(tel, ctx=ctx, max_bytes=int(self.device_chunk_gb * (1 << 30)))
-        self._beam_all = beam_all  # (mmax+1, F, 2, B, P, L), kept for the SVD stage
         finc, binc, pinc = tel.included_freq, tel.included_baseline, tel.included_pol
-        for mi in self._my_ms():
+        nranks, r = parallel.size(), parallel.rank()
+        if nranks == 1:
+            beam_all = btgen.beam_m_all(tel, ctx=ctx, max_bytes=int(self.device_chunk_gb * (1 << 30)))
+            self._beam_all = beam_all  # (mmax+1, F, 2, B, P, L), kept for the SVD stage
+            m_lo, mine = 0, list(range(tel.mmax + 1))
+        else:
+            # BT-gen costs about the same for every m: contiguous ranges, each rank transforms only its
+            # own blocks (dm_bt_sht_range); the SVD / KL stages re-read the files under their own
+            # cost-balanced assignment
+            M = tel.mmax + 1
+            m_lo, m_hi = (M * r) // nranks, (M * (r + 1)) // nranks - 1
+            mine = list(range(m_lo, m_hi + 1))
+            self._beam_all = None
+            beam_all = (btgen.beam_m_all(tel, ctx=ctx, max_bytes=int(self.device_chunk_gb * (1 << 30)),
+                                         m_range=(m_lo, m_hi)) if mine else None)
+        for mi in mine:
             if os.path.exists(self._mfile(mi)) and not regen:
                 continue
-            blk = beam_all[mi].cpu().numpy()
+            blk = beam_all[mi - m_lo].cpu().numpy()
             with storage.File(self._mfile(mi), "w") as f:
                 data = blk[np.ix_(finc, np.arange(2), binc, pinc, np.arange(mi, tel.lmax + 1))]
                 f.create_dataset("beam_m", data=data)

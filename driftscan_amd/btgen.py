@@ -28,10 +28,11 @@ def _nside_of(tel, lmax_bf):
 
 
 def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=None, mmax=None,
-                max_bytes=6 << 30, ctx=None):
+                max_bytes=6 << 30, ctx=None, m_range=None):
     """Fill rows of the device array ``beam_m`` (mmax+1, F, 2, B, P, lside+1) for the
     (frequency, baseline) pairs (f_list[i], b_list[i]); the destination row of pair i is
-    (row_f[i], row_b[i]) (defaults: the telescope indices themselves)."""
+    (row_f[i], row_b[i]) (defaults: the telescope indices themselves).  With ``m_range = (m_lo, m_hi)``
+    only those m-blocks are transformed and ``beam_m`` holds m_hi - m_lo + 1 blocks."""
     ctx = ctx or get_context()
     f_list = np.asarray(f_list, dtype=np.int64).reshape(-1)
     b_list = np.asarray(b_list, dtype=np.int64).reshape(-1)
@@ -60,8 +61,9 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
         # chunk columns so that maps + ring-DFT output + twiddles stay within the budget
         lgrp = int(lmax_bf[sel].max())
         mtop = min(mmax, lgrp)
-        per_col = P * 16 * (npix + (2 * mtop + 1) * nring)
-        fixed = (2 * mtop + 1) * npix * 16
+        nmr = (2 * mtop + 1) if m_range is None else 2 * max(min(m_range[1], mtop) - m_range[0] + 1, 1)
+        per_col = P * 16 * (npix + nmr * nring)
+        fixed = nmr * npix * 16
         ncol_max = max(1, int((max_bytes - fixed) // per_col)) if max_bytes > fixed else 1
         # keep all baselines of a frequency together and in order: dm_bt_sht merges such runs
         order = sel[np.lexsort((row_b[sel], row_f[sel]))]
@@ -87,19 +89,21 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
             maps = ctx.empty((cols.size, P, npix), np.complex128)
             ctx.bt_maps(int(nside), cth, sth, frame, pol, beams, uv, bi, bj, maps)
             ctx.bt_sht(int(nside), cth, sth, pol, lside, mmax, int(lmax_bf[cols].max()), F, B, row_f[cols],
-                       row_b[cols], lmax_bf[cols], maps, beam_m)
+                       row_b[cols], lmax_bf[cols], maps, beam_m, m_range=m_range)
             del maps, beams
     return beam_m
 
 
-def beam_m_all(tel, ctx=None, max_bytes=6 << 30):
+def beam_m_all(tel, ctx=None, max_bytes=6 << 30, m_range=None):
     """Device tensor (mmax+1, F, 2, B, P, L) of every m-block of the telescope (zeros for
-    skipped frequencies / baselines, like the reference's beam_m accessor)."""
+    skipped frequencies / baselines, like the reference's beam_m accessor), or of the blocks
+    m_range = (m_lo, m_hi) only."""
     ctx = ctx or get_context()
     F, B, P, L = tel.nfreq, tel.nbase, tel.num_pol_sky, tel.lmax + 1
-    beam_m = ctx.zeros((tel.mmax + 1, F, 2, B, P, L), np.complex128)
+    nm = tel.mmax + 1 if m_range is None else m_range[1] - m_range[0] + 1
+    beam_m = ctx.zeros((nm, F, 2, B, P, L), np.complex128)
     ff, bb = np.meshgrid(tel.included_freq, tel.included_baseline, indexing="ij")
-    fill_beam_m(tel, beam_m, ff.ravel(), bb.ravel(), ctx=ctx, max_bytes=max_bytes)
+    fill_beam_m(tel, beam_m, ff.ravel(), bb.ravel(), ctx=ctx, max_bytes=max_bytes, m_range=m_range)
     npol_inc = len(tel.included_pol)
     if npol_inc < P:
         beam_m[:, :, :, :, npol_inc:, :] = 0  # skip_pol / skip_V leave zero entries (telescope.py:1298-1314)

@@ -173,14 +173,15 @@ __global__ void bt_maps_kernel(ring_geo g, frame3 fr, int polarised, int ncol, c
 }
 
 // tw[pix][mm] laid out per ring as (2*mmax+1) x nphi row-major: tw[off_r + mm*nphi + j] = exp(i (mm - mmax) phi_j)
-__global__ void bt_twiddle_kernel(ring_geo g, int mmax, const size_t* __restrict__ toff, cplx* __restrict__ tw) {
+__global__ void bt_twiddle_kernel(ring_geo g, int m_lo, int cnt, const size_t* __restrict__ toff, cplx* __restrict__ tw) {
+  // rows [0, cnt): m = +m_lo .. +(m_lo + cnt - 1);  rows [cnt, 2 cnt): the same with a minus sign
   const int r = blockIdx.y;
   const int nphi = g.nphi[r];
-  const int nm = 2 * mmax + 1;
+  const int nm = 2 * cnt;
   const size_t tot = (size_t)nm * nphi;
   for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
     const int mm = (int)(idx / nphi), j = (int)(idx % nphi);
-    const int m = mm - mmax;
+    const int m = mm < cnt ? m_lo + mm : -(m_lo + mm - cnt);
     // reduce the argument exactly: m*j mod nphi keeps the phase in [0, 2 pi)
     const long long mj = ((long long)m * j) % nphi;
     const double ph = (double)m * g.phi0[r] + 2.0 * kPi * (double)mj / (double)nphi;
@@ -191,10 +192,11 @@ __global__ void bt_twiddle_kernel(ring_geo g, int mmax, const size_t* __restrict
 }
 
 // Legendre tables: lam[loff[m] + (l-m)*nring + r] = w * lambda_lm(theta_r), same for W and X (polarised)
-__global__ void bt_legendre_kernel(ring_geo g, int lmax, int mmax, double w, const size_t* __restrict__ loff,
+__global__ void bt_legendre_kernel(ring_geo g, int lmax, int m_lo, int mmax, double w, const size_t* __restrict__ loff_,
                                    double* __restrict__ lam, double* __restrict__ Wt, double* __restrict__ Xt) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  const int m = blockIdx.y;
+  const int m = m_lo + blockIdx.y;
+  const size_t* loff = loff_ - m_lo;  // tables are stored for m_lo .. mmax
   if (r >= g.nring || m > mmax || m > lmax) return;
   const double z = g.cth[r], st = g.sth[r];
   const double s2 = st * st;
@@ -379,11 +381,13 @@ int dm_bt_maps(dm_ctx* ctx, int nside, const double* ring_cth_host, const double
 // beam_m blocks: beam_m_dev is (mmax+1, F, 2, B, P, L) complex128, L = lside + 1; the rows
 // (f, :, b, :, :) of the group's columns are overwritten (zero for l < m and l > lmax_col).
 //   lmax_grp: largest per-column lmax in the group (<= lside) — tables are built up to it
-int dm_bt_sht(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised,
-              int lside, int mmax, int lmax_grp, int F, int B, int ncol, const int* col_f_host,
-              const int* col_b_host, const int* col_lmax_host, const void* maps_dev, void* beam_m_dev) {
+//   m_lo .. m_hi: only these m-blocks are produced; beam_m_dev is then (m_hi - m_lo + 1, F, 2, B, P, L)
+//   (a rank that owns a range of m synthesises the maps but transforms and stores its own m only)
+int dm_bt_sht_range(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised,
+                    int lside, int m_lo, int m_hi, int lmax_grp, int F, int B, int ncol, const int* col_f_host,
+                    const int* col_b_host, const int* col_lmax_host, const void* maps_dev, void* beam_m_dev) {
   if (!ctx) return DM_EARG;
-  DM_ARG(ctx, nside > 0 && ring_cth_host && ring_sth_host && lside >= 0 && mmax >= 0 && lmax_grp >= 0 &&
+  DM_ARG(ctx, nside > 0 && ring_cth_host && ring_sth_host && lside >= 0 && m_lo >= 0 && m_hi >= m_lo && lmax_grp >= 0 &&
                   lmax_grp <= lside && F > 0 && B > 0 && ncol >= 0 && col_f_host && col_b_host && col_lmax_host &&
                   maps_dev && beam_m_dev);
   if (ncol == 0) return DM_OK;
@@ -393,9 +397,11 @@ int dm_bt_sht(dm_ctx* ctx, int nside, const double* ring_cth_host, const double*
   const int P = polarised ? 4 : 1;
   const int L = lside + 1;
   const int nring = gh.g.nring, npix = gh.g.npix;
-  const int mtop = std::min(mmax, lmax_grp);  // no (l, m) content above the group's band limit
-  const int nm = 2 * mtop + 1;
+  const int mtop = std::min(m_hi, lmax_grp);  // no (l, m) content above the group's band limit
+  const int cnt = std::max(mtop - m_lo + 1, 0);  // m values with content in this range
+  const int nm = 2 * std::max(cnt, 1);
   const int ncp = ncol * P;  // map columns
+  const int nmblk = m_hi - m_lo + 1;
 
   // ---- twiddles and ring DFT: G[mm][ring][colp]
   std::vector<size_t> toff(nring);
@@ -405,8 +411,9 @@ int dm_bt_sht(dm_ctx* ctx, int nside, const double* ring_cth_host, const double*
   cplx* tw = dm_ws_alloc_t<cplx>(ctx, ttot);
   cplx* G = dm_ws_alloc_t<cplx>(ctx, (size_t)nm * nring * ncp);
   if (!d_toff || !tw || !G) return DM_ENOMEM;
-  hipLaunchKernelGGL(bt_twiddle_kernel, dim3(8, nring), dim3(256), 0, ctx->stream, gh.g, mtop, d_toff, tw);
-  {
+  hipLaunchKernelGGL(bt_twiddle_kernel, dim3(8, nring), dim3(256), 0, ctx->stream, gh.g, m_lo, std::max(cnt, 1), d_toff,
+                     tw);
+  if (cnt > 0) {
     const cplx* maps = reinterpret_cast<const cplx*>(maps_dev);
     std::vector<dm_gemm_desc> g;
     g.reserve(nring);
@@ -419,16 +426,17 @@ int dm_bt_sht(dm_ctx* ctx, int nside, const double* ring_cth_host, const double*
   }
 
   // ---- Legendre tables up to lmax_grp
-  std::vector<size_t> loff(mtop + 1);
+  std::vector<size_t> loff(std::max(cnt, 1), 0);  // loff[m - m_lo]
   size_t ltot = 0;
-  for (int m = 0; m <= mtop; ++m) { loff[m] = ltot; ltot += (size_t)(lmax_grp + 1 - m) * nring; }
+  for (int m = m_lo; m <= mtop; ++m) { loff[m - m_lo] = ltot; ltot += (size_t)(lmax_grp + 1 - m) * nring; }
   size_t* d_loff = dm_ws_upload(ctx, loff);
-  double* lam = dm_ws_alloc_t<double>(ctx, ltot);
-  double* Wt = polarised ? dm_ws_alloc_t<double>(ctx, ltot) : nullptr;
-  double* Xt = polarised ? dm_ws_alloc_t<double>(ctx, ltot) : nullptr;
+  double* lam = dm_ws_alloc_t<double>(ctx, std::max<size_t>(ltot, 1));
+  double* Wt = polarised ? dm_ws_alloc_t<double>(ctx, std::max<size_t>(ltot, 1)) : nullptr;
+  double* Xt = polarised ? dm_ws_alloc_t<double>(ctx, std::max<size_t>(ltot, 1)) : nullptr;
   if (!d_loff || !lam || (polarised && (!Wt || !Xt))) return DM_ENOMEM;
-  hipLaunchKernelGGL(bt_legendre_kernel, dim3((nring + 63) / 64, mtop + 1), dim3(64), 0, ctx->stream, gh.g, lmax_grp,
-                     mtop, 4.0 * kPi / (double)npix, d_loff, lam, Wt, Xt);
+  if (cnt > 0)
+    hipLaunchKernelGGL(bt_legendre_kernel, dim3((nring + 63) / 64, cnt), dim3(64), 0, ctx->stream, gh.g, lmax_grp, m_lo,
+                       mtop, 4.0 * kPi / (double)npix, d_loff, lam, Wt, Xt);
   DM_HIP(ctx, hipGetLastError());
 
   // ---- clear the destination rows of this group for every m (then GEMMs fill l in [m, lmax_grp])
@@ -442,8 +450,8 @@ int dm_bt_sht(dm_ctx* ctx, int nside, const double* ring_cth_host, const double*
   std::vector<int> neg1(ncol, -1);
   int* d_neg = dm_ws_upload(ctx, neg1);
   if (!d_cf || !d_cb || !d_cl || !d_neg) return DM_ENOMEM;
-  hipLaunchKernelGGL(bt_mask_kernel, dim3((2 * P * L + 255) / 256, ncol, mmax + 1), dim3(256), 0, ctx->stream, bm, F, B,
-                     P, L, mmax, ncol, d_cf, d_cb, d_neg);
+  hipLaunchKernelGGL(bt_mask_kernel, dim3((2 * P * L + 255) / 256, ncol, nmblk), dim3(256), 0, ctx->stream, bm, F, B,
+                     P, L, m_hi, ncol, d_cf, d_cb, d_neg);
 
   // ---- Legendre products.  Columns of a group are arbitrary (f, b) pairs, so one GEMM row per
   // column would be wasteful; instead consecutive columns with the same f and consecutive b are
@@ -460,16 +468,16 @@ int dm_bt_sht(dm_ctx* ctx, int nside, const double* ring_cth_host, const double*
   // so that no two tiles of one launch touch the same C entries.
   for (int pass = 0; pass < (polarised ? 2 : 1); ++pass) {
     std::vector<dm_gemm_desc> g;
-    for (int m = 0; m <= mtop; ++m) {
+    for (int m = m_lo; m <= mtop; ++m) {
       const int Lm = lmax_grp + 1 - m;
       for (int s = 0; s < 2; ++s) {
         if (m == 0 && s == 1) continue;  // the -m slot of m = 0 stays zero (beamtransfer.py:624)
-        const int mm = (s == 0) ? (mtop + m) : (mtop - m);
+        const int mm = (s == 0) ? (m - m_lo) : (cnt + m - m_lo);
         const cplx* Gm = G + (size_t)mm * nring * ncp;
         for (const run& rn : runs) {
-          cplx* out = bm + ((((size_t)m * F + rn.f) * 2 + s) * B + rn.b0) * P * L + m;
+          cplx* out = bm + ((((size_t)(m - m_lo) * F + rn.f) * 2 + s) * B + rn.b0) * P * L + m;
           auto add = [&](int pa, const double* tab, int pout, double are, double aim, double beta) {
-            dm_gemm_desc d = dm_gemm_make(Gm + (size_t)rn.c0 * P + pa, P, ncp, s == 1, tab + loff[m], 1, nring, false,
+            dm_gemm_desc d = dm_gemm_make(Gm + (size_t)rn.c0 * P + pa, P, ncp, s == 1, tab + loff[m - m_lo], 1, nring, false,
                                           out + (size_t)pout * L, P * L, rn.n, Lm, nring, are, beta, nullptr,
                                           DM_GEMM_B_REAL);
             d.alpha_im = aim;
@@ -492,12 +500,22 @@ int dm_bt_sht(dm_ctx* ctx, int nside, const double* ring_cth_host, const double*
     DM_TRY(dm_gemm_grouped_launch(ctx, g));
   }
   // ---- per-column band limit
-  hipLaunchKernelGGL(bt_mask_kernel, dim3((2 * P * L + 255) / 256, ncol, mmax + 1), dim3(256), 0, ctx->stream, bm, F, B,
-                     P, L, mmax, ncol, d_cf, d_cb, d_cl);
+  hipLaunchKernelGGL(bt_mask_kernel, dim3((2 * P * L + 255) / 256, ncol, nmblk), dim3(256), 0, ctx->stream, bm, F, B,
+                     P, L, m_hi, ncol, d_cf, d_cb, d_cl);
   DM_HIP(ctx, hipGetLastError());
   DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   dm_ws_release(ctx, mark);
   return DM_OK;
+}
+
+// all m-blocks 0 .. mmax
+int dm_bt_sht(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised,
+              int lside, int mmax, int lmax_grp, int F, int B, int ncol, const int* col_f_host,
+              const int* col_b_host, const int* col_lmax_host, const void* maps_dev, void* beam_m_dev) {
+  if (!ctx) return DM_EARG;
+  DM_ARG(ctx, mmax >= 0);
+  return dm_bt_sht_range(ctx, nside, ring_cth_host, ring_sth_host, polarised, lside, 0, mmax, lmax_grp, F, B, ncol,
+                         col_f_host, col_b_host, col_lmax_host, maps_dev, beam_m_dev);
 }
 
 }  // extern "C"

@@ -207,6 +207,14 @@ int dm_bt_sht(dm_ctx* ctx, int nside, const double* ring_cth_host, const double*
               int lside, int mmax, int lmax_grp, int F, int B, int ncol, const int* col_f_host,
               const int* col_b_host, const int* col_lmax_host, const void* maps_dev, void* beam_m_dev);
 
+/* dm_bt_sht_range: the same for the m-blocks m_lo .. m_hi only; beam_m_dev is then
+ * (m_hi - m_lo + 1, F, 2, B, P, L).  A rank that owns a range of m synthesises the maps
+ * (replicated, a few per cent of the per-m cost) but transforms and stores only its own blocks —
+ * this replaces the reference's (f, b) -> m all-to-all (drift/core/beamtransfer.py:626-640). */
+int dm_bt_sht_range(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised,
+                    int lside, int m_lo, int m_hi, int lmax_grp, int F, int B, int ncol, const int* col_f_host,
+                    const int* col_b_host, const int* col_lmax_host, const void* maps_dev, void* beam_m_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,3 +99,24 @@ def test_skips_and_transfer_matrices(ctx):
             assert np.abs(tm[k, 0, :, m] - full[m][fi[k], 0, bl[k], 0]).max() < 1e-10 * scale
             if m:
                 assert np.abs(tm[k, 0, :, -m] - (-1) ** m * full[m][fi[k], 1, bl[k], 0].conj()).max() < 1e-10 * scale
+
+
+def test_sht_m_range_matches_full():
+    """dm_bt_sht_range over a partition of m reproduces the all-m result block by block."""
+    from driftscan_amd import btgen, cylinder, device
+
+    device.reset_context()
+    ctx = device.get_context()
+    for cfg in (dict(num_freq=2, freq_start=400.0, freq_end=420.0, freq_mode="edge", num_cylinders=2, cylinder_width=4.0,
+                     num_feeds=3, feed_spacing=0.5, tsys=1.0),):
+        for cls in (cylinder.UnpolarisedCylinderTelescope, cylinder.PolarisedCylinderTelescope):
+            tel = cls.from_config(cfg)
+            full = btgen.beam_m_all(tel, ctx=ctx).cpu().numpy()
+            M = tel.mmax + 1
+            edges = [0, 1, M // 3, (2 * M) // 3 + 1, M]
+            for lo, hi in zip(edges[:-1], edges[1:]):
+                if hi <= lo:
+                    continue
+                part = btgen.beam_m_all(tel, ctx=ctx, m_range=(lo, hi - 1)).cpu().numpy()
+                assert part.shape[0] == hi - lo
+                assert np.array_equal(part, full[lo:hi]), (cls.__name__, lo, hi)
