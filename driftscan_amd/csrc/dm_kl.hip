@@ -405,10 +405,21 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
       else cols = order;
     };
     DM_TRY(dm_herm_eig_tridiag(ctx, hp, evw, std::max(maxn, 1), &sel));
+    // sorted eigenvalues back to the device: one copy when the blocks are laid out back to back
+    // (the usual case), else one per block
+    bool contiguous = !work.empty();
+    for (size_t i = 0; i + 1 < work.size() && contiguous; ++i)
+      contiguous = evoff_host[work[i + 1]] == evoff_host[work[i]] + n_host[work[i]];
+    if (contiguous) {
+      std::vector<double> flat;
+      for (int b : work) flat.insert(flat.end(), evsorted[b].begin(), evsorted[b].end());
+      DM_TRY(dm_upload(ctx, evals_dev + evoff_host[work.front()], flat.data(), sizeof(double) * flat.size()));
+    }
     for (size_t i = 0; i < work.size(); ++i) {
       const int b = work[i];
       if (nkeep_host) nkeep_host[b] = sel.nsel[i];
-      DM_TRY(dm_upload(ctx, evals_dev + evoff_host[b], evsorted[b].data(), sizeof(double) * n_host[b]));
+      if (!contiguous)
+        DM_TRY(dm_upload(ctx, evals_dev + evoff_host[b], evsorted[b].data(), sizeof(double) * n_host[b]));
     }
   }
 
@@ -417,12 +428,22 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
   {
     std::vector<dm_trsm_problem> t3;
     std::vector<dm_tdesc> tr1, tr2;
+    // rows that are not formed are zero: one memset over the span of the blocks when they are
+    // stored back to back, else one per block
+    bool span_ok = cut_mode != 0 && !work.empty();
+    for (size_t i = 0; i + 1 < work.size() && span_ok; ++i)
+      span_ok = off_host[work[i + 1]] == off_host[work[i]] + (int64_t)n_host[work[i]] * n_host[work[i]];
+    if (span_ok) {
+      const int bl = work.back();
+      DM_TRY(dm_fill_zero(ctx, E + off_host[work.front()],
+                          sizeof(cplx) * (size_t)(off_host[bl] + (int64_t)n_host[bl] * n_host[bl] - off_host[work.front()])));
+    }
     for (size_t i = 0; i < work.size(); ++i) {
       const int b = work[i];
       const int n = n_host[b];
       const int nk = cut_mode == 1 ? n - i_ev[b] : (cut_mode == 2 ? i_ev[b] : n);
       const int row0 = cut_mode == 1 ? i_ev[b] : 0;
-      if (nk < n) DM_TRY(dm_fill_zero(ctx, E + off_host[b], sizeof(cplx) * (size_t)n * n));
+      if (nk < n && !span_ok) DM_TRY(dm_fill_zero(ctx, E + off_host[b], sizeof(cplx) * (size_t)n * n));
       if (nk <= 0) continue;
       tr1.push_back(dm_tdesc{Ww + loff[b], n, Tw + loff[b], nk, nk, n});           // W (nk x n) -> W^H (n x nk)
       t3.push_back(dm_trsm_problem{Lw + loff[b], n, n, Tw + loff[b], nk, nk});
