@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 
 namespace {
@@ -377,11 +378,30 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
   for (auto* tl : {&tiles, &tiles_real, &tiles_dd, &tiles_gat})
     if (!std::is_sorted(tl->begin(), tl->end(), by_k)) std::stable_sort(tl->begin(), tl->end(), by_k);
   size_t mark = dm_ws_mark(ctx);
-  dm_gemm_desc* dd = dm_ws_upload(ctx, descs);
-  if (!dd) return DM_ENOMEM;
+  // descriptors and all tile lists travel in ONE host-to-device copy: on the chains of short
+  // dependent products (triangular solves, Cholesky) the API calls per launch are what the GPU waits for
+  const size_t nd = descs.size(), n0 = tiles.size(), n1 = tiles_real.size(), n2 = tiles_dd.size(), n3 = tiles_gat.size();
+  const size_t desc_bytes = (nd * sizeof(dm_gemm_desc) + 15) & ~size_t(15);
+  const size_t tile_bytes = (n0 + n1 + n2 + n3) * sizeof(dm_gemm_tile);
+  std::vector<char> blob(desc_bytes + tile_bytes);
+  std::memcpy(blob.data(), descs.data(), nd * sizeof(dm_gemm_desc));
+  {
+    char* tp = blob.data() + desc_bytes;
+    for (const auto* tl : {&tiles, &tiles_real, &tiles_dd, &tiles_gat}) {
+      if (!tl->empty()) std::memcpy(tp, tl->data(), tl->size() * sizeof(dm_gemm_tile));
+      tp += tl->size() * sizeof(dm_gemm_tile);
+    }
+  }
+  char* dblob = dm_ws_upload(ctx, blob);
+  if (!dblob) return DM_ENOMEM;
+  dm_gemm_desc* dd = reinterpret_cast<dm_gemm_desc*>(dblob);
+  dm_gemm_tile* dtiles = reinterpret_cast<dm_gemm_tile*>(dblob + desc_bytes);
+  dm_gemm_tile* const dt_c = dtiles;
+  dm_gemm_tile* const dt_r = dtiles + n0;
+  dm_gemm_tile* const dt_d = dtiles + n0 + n1;
+  dm_gemm_tile* const dt_g = dtiles + n0 + n1 + n2;
   if (!tiles.empty()) {
-    dm_gemm_tile* dt = dm_ws_upload(ctx, tiles);
-    if (!dt) return DM_ENOMEM;
+    dm_gemm_tile* dt = dt_c;
     static const bool log = getenv("DM_GEMM_LOG") != nullptr;  // debugging aid: per-launch shape and rate
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (log) {
@@ -415,22 +435,19 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
     }
   }
   if (!tiles_gat.empty()) {
-    dm_gemm_tile* dt = dm_ws_upload(ctx, tiles_gat);
-    if (!dt) return DM_ENOMEM;
+    dm_gemm_tile* dt = dt_g;
     dm_prof_scope ps(ctx, DM_PROF_GEMM, fl_g);
     hipLaunchKernelGGL((zgemm_grouped_kernel<false, true>), dim3((unsigned)tiles_gat.size()), dim3(256), 0, ctx->stream,
                        dd, dt, (int)tiles_gat.size());
   }
   if (!tiles_real.empty()) {
-    dm_gemm_tile* dt = dm_ws_upload(ctx, tiles_real);
-    if (!dt) return DM_ENOMEM;
+    dm_gemm_tile* dt = dt_r;
     dm_prof_scope ps(ctx, DM_PROF_GEMM_REAL, fl_r);
     hipLaunchKernelGGL((zgemm_grouped_kernel<true, false>), dim3((unsigned)tiles_real.size()), dim3(256), 0, ctx->stream,
                        dd, dt, (int)tiles_real.size());
   }
   if (!tiles_dd.empty()) {
-    dm_gemm_tile* dt = dm_ws_upload(ctx, tiles_dd);
-    if (!dt) return DM_ENOMEM;
+    dm_gemm_tile* dt = dt_d;
     dm_prof_scope ps(ctx, DM_PROF_DGEMM, fl_d);
     hipLaunchKernelGGL(dgemm_grouped_kernel, dim3((unsigned)tiles_dd.size()), dim3(256), 0, ctx->stream, dd, dt,
                        (int)tiles_dd.size());
