@@ -299,9 +299,16 @@ class BeamTransfer(config.Reader):
 
     # ---- SVD bookkeeping (beamtransfer.py:1116-1133) ------------------------------------
     def _svd_num(self, mi):
+        """(svnum, svbounds) of one m (beamtransfer.py:1116-1133); memoised per singular-value array,
+        the KL stage asks for it several times per m."""
         sv = self._dev[mi]["singularvalues"] if mi in self._dev else self.beam_singularvalues(mi)
+        memo = self.__dict__.setdefault("_svnum_memo", {})
+        hit = memo.get(mi)
+        if hit is not None and hit[0] is sv and hit[1] == self.svcut:
+            return hit[2], hit[3]
         svnum = (sv > sv.max() * self.svcut).sum(axis=1)
         svbounds = np.cumsum(np.insert(svnum, 0, 0))
+        memo[mi] = (sv, self.svcut, svnum, svbounds)
         return svnum, svbounds
 
     def _svd_freq_iter(self, mi):
