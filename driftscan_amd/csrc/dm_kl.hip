@@ -95,10 +95,6 @@ __global__ void add_diag_kernel(const blk_desc* __restrict__ bd, const double* _
   if (i < d.n) d.a[(size_t)i * d.n + i].x += val[blockIdx.y];
 }
 
-__global__ void copy_kernel(cplx* __restrict__ dst, const cplx* __restrict__ src, size_t n) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    dst[i] = src[i];
-}
 
 int copy_async(dm_ctx* ctx, cplx* dst, const cplx* src, size_t n) {
   if (n == 0) return DM_OK;

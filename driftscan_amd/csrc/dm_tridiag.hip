@@ -1136,8 +1136,6 @@ __global__ __launch_bounds__(256) void dc_permute_kernel(const dc_mat* __restric
   const dc_nodeout o = outs[blockIdx.x];
   const int nn = nd.n1 + nd.n2, lo = nd.lo, n = M.n;
   double* Zc = nd.flip ? M.ZB : M.ZA;
-  double* Zn = nd.flip ? M.ZA : M.ZB;
-  double* lamn = nd.flip ? M.lamA : M.lamB;
   const int tid = threadIdx.x;
   // chained Givens rotations on pairs of eigenvectors (in place)
   for (int r = 0; r < o.nrot; ++r) {
