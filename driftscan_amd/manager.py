@@ -15,7 +15,9 @@ teltype_dict = {
 }
 
 kltype_dict = {"KLTransform": kltransform.KLTransform, "DoubleKL": doublekl.DoubleKL}
-pstype_dict = {"Full": psestimation.PSExact}  # the Monte-Carlo estimators of the reference are not part of this build
+# The reference's Monte-Carlo estimators ("MonteCarlo", "MonteCarloAlt") estimate the same Fisher matrix from
+# random realisations; here they resolve to the exact computation (the expectation they converge to), with a warning.
+pstype_dict = {"Full": psestimation.PSExact, "MonteCarlo": psestimation.PSExact, "MonteCarloAlt": psestimation.PSExact}
 
 
 
@@ -106,6 +108,9 @@ class ProductManager(object):
             raise Exception("Require a psfisher section if config: psfisher is Yes.")
         for psentry in yconf.get("psfisher", []) or []:
             psclass = _resolve_class(psentry["type"], pstype_dict, "PS estimator")
+            if isinstance(psentry["type"], str) and psentry["type"].startswith("MonteCarlo"):
+                logger.warning("psfisher type %s: computing the exact Fisher matrix instead of a Monte-Carlo estimate"
+                               % psentry["type"])
             klname = psentry["klname"]
             psname = psentry.get("name", "ps")
             if klname not in self.kltransforms:

@@ -20,7 +20,6 @@ import time
 import numpy as np
 
 from . import config, parallel, skymodel, storage
-from ._lib import block_offsets
 from .device import get_context
 
 logger = logging.getLogger(__name__)
@@ -222,6 +221,11 @@ class PSEstimation(config.Reader):
             return f["fisher"][:], f["bias"][:]
 
 
+def _linear_offsets(sizes):
+    off = np.concatenate([[0], np.cumsum(np.asarray(sizes, dtype=np.int64))])
+    return off[:-1].copy(), int(off[-1])
+
+
 class PSExact(PSEstimation):
     """Exact Fisher matrix by forward projection of every band (psestimation.py:657-815)."""
 
@@ -244,8 +248,8 @@ class PSExact(PSEstimation):
         bsvd = torch.stack([p["beam_svd"] for p in prods])
         svnum = np.stack([bt._svd_num(mi)[0] for mi in ms])
         ndofs = svnum.sum(axis=1)
-        eoff, etot = block_offsets(nmodes * ndofs)
-        voff, vtot = block_offsets(nmodes)
+        eoff, etot = _linear_offsets(nmodes * ndofs)
+        voff, vtot = _linear_offsets(nmodes)
         Eh = np.zeros(max(etot, 1), dtype=np.complex128)
         Vh = np.zeros(max(vtot, 1), dtype=np.float64)
         for i, (ev, E) in enumerate(modes):
