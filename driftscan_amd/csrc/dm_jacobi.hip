@@ -231,6 +231,8 @@ __global__ __launch_bounds__(JNT) void jac_inner_kernel(const jac_item* __restri
         int act = 0;
         double c = 1.0;
         cplx sp = make_double2(0.0, 0.0);
+        // (A norm-wise test |g|^2 <= floor max(a, b) — LAPACK's level of accuracy — was tried here and is NOT
+        // enough: beam_svd . pinv(beam_svd) = I needs the small rows to relative accuracy, kappa = 1/svcut.)
         if (ag > 0.0 && ag > absfloor && ag > tol_inner * sqrt(fabs(a * b))) {
           double zeta = (b - a) / (2.0 * ag);
           double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -716,9 +718,14 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
   // Preconditioner: one Hermitian eigendecomposition of the full Gram matrix G = X X^H of every
   // (still active) problem (batched tridiagonal solver) followed by Z <- W Z.  On its own this would only be
   // accurate to eps ||X||^2 (the Gram squares the condition number), but it brings every pair of
-  // rows to |cos| <~ eps sigma_1 / sigma_i, from where the Jacobi sweeps below — which recompute
+  // rows to |cos| <~ eps sigma_1^2 / (sigma_i sigma_j), from where the Jacobi sweeps below — which recompute
   // the Gram blocks from the rows themselves and therefore keep full relative accuracy — converge
   // in two or three sweeps instead of a dozen on the graded spectra of beam matrices.
+  // That bound says nothing about pairs with sigma_i sigma_j <~ eps sigma_1^2: the directions below
+  // ~1e-8 sigma_1 come out of the first level as an arbitrary mixture (a polarised beam block has several
+  // hundred of them, spread over 8 more decades: 30 sweeps).  So the preconditioner is applied again to
+  // just those rows — their own Gram matrix resolves another 8 decades relative to THEIR largest norm —
+  // and once more below that; each level costs a fraction of one sweep.
   {
     std::vector<size_t> goff(np);
     size_t gtot = 0;
@@ -727,17 +734,25 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
     cplx* Wm = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(gtot, 1));
     double* evp = dm_ws_alloc_t<double>(ctx, (size_t)np * sigma_stride);
     if (!Gm || !Wm || !evp) return DM_ENOMEM;
-    std::vector<dm_gemm_desc> g;
-    std::vector<dm_jac_herm_problem> hp;
-    for (int p = 0; p < np; ++p) {
-      const dm_jac_problem& P = probs[p];
-      if (P.nrows < 1 || !active[p]) continue;
-      const cplx* X = P.Z + (size_t)P.row0 * P.ld + P.gc0;
-      g.push_back(dm_gemm_make(X, P.ld, 1, false, X, 1, P.ld, true, Gm + goff[p], P.nrows, P.nrows, P.nrows,
-                               P.gc1 - P.gc0));
-      hp.push_back(dm_jac_herm_problem{Gm + goff[p], P.nrows, Wm + goff[p], P.nrows, P.nrows});
-    }
-    if (!hp.empty()) {
+    std::vector<int> sub0(np, 0), lvl_on(active);  // first row of the current level's sub-block, per problem
+    std::vector<double> ev0(np, 0.0);              // largest Gram eigenvalue of level 0 (sigma_1^2)
+    std::vector<double> hev;
+    int max_levels = 3;
+    if (const char* e = getenv("DM_JAC_PRECOND_LEVELS")) max_levels = std::max(0, std::min(4, atoi(e)));
+    for (int level = 0; level < max_levels; ++level) {
+      std::vector<dm_gemm_desc> g;
+      std::vector<dm_jac_herm_problem> hp;
+      std::vector<int> who;
+      for (int p = 0; p < np; ++p) {
+        const dm_jac_problem& P = probs[p];
+        const int ns = P.nrows - sub0[p];
+        if (!lvl_on[p] || ns < 1) continue;
+        const cplx* X = P.Z + (size_t)(P.row0 + sub0[p]) * P.ld + P.gc0;
+        g.push_back(dm_gemm_make(X, P.ld, 1, false, X, 1, P.ld, true, Gm + goff[p], ns, ns, ns, P.gc1 - P.gc0));
+        hp.push_back(dm_jac_herm_problem{Gm + goff[p], ns, Wm + goff[p], ns, ns});
+        who.push_back(p);
+      }
+      if (hp.empty()) break;
       DM_TRY(dm_gemm_grouped_launch(ctx, g));
       {
         std::vector<dm_mat> hm;
@@ -751,25 +766,61 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
       DM_TRY(dm_sort_rows_by_key(ctx, sp, evp, sigma_stride, true));  // largest eigenvalue first
       // Z <- W Z through the temporary, then back
       std::vector<dm_gemm_desc> ga;
-      std::vector<jac_pdesc> pda;   // the scatter only touches the problems that were transformed
+      std::vector<jac_pdesc> pda;   // the scatter only touches the rows that were transformed
       std::vector<size_t> toffa;
-      size_t k = 0;
-      for (int p = 0; p < np; ++p) {
+      int subrows = 0;
+      for (size_t k = 0; k < who.size(); ++k) {
+        const int p = who[k];
         const dm_jac_problem& P = probs[p];
-        if (P.nrows < 1 || !active[p]) continue;
-        ga.push_back(dm_gemm_make(hp[k].W, P.nrows, 1, false, P.Z + (size_t)P.row0 * P.ld, P.ld, 1, false,
-                                  d_tmp + toff[p], P.ncols, P.nrows, P.ncols, P.nrows));
-        pda.push_back(pd[p]);
+        const int ns = hp[k].n;
+        ga.push_back(dm_gemm_make(hp[k].W, ns, 1, false, P.Z + (size_t)(P.row0 + sub0[p]) * P.ld, P.ld, 1, false,
+                                  d_tmp + toff[p], P.ncols, ns, P.ncols, ns));
+        jac_pdesc d = pd[p];
+        d.row0 = P.row0 + sub0[p];
+        d.nrows = ns;
+        pda.push_back(d);
         toffa.push_back(toff[p]);
-        ++k;
+        subrows = std::max(subrows, ns);
       }
       DM_TRY(dm_gemm_grouped_launch(ctx, ga));
       jac_pdesc* d_pda = dm_ws_upload(ctx, pda);
       size_t* d_toffa = dm_ws_upload(ctx, toffa);
       if (!d_pda || !d_toffa) return DM_ENOMEM;
       const int gx0 = std::max(1, std::min(8, (maxcols + 255) / 256));
-      hipLaunchKernelGGL(jac_scatter_back_kernel, dim3(gx0, maxrows, (unsigned)pda.size()), dim3(256), 0, ctx->stream,
+      hipLaunchKernelGGL(jac_scatter_back_kernel, dim3(gx0, subrows, (unsigned)pda.size()), dim3(256), 0, ctx->stream,
                          d_pda, d_tmp, d_toffa);
+      DM_HIP(ctx, hipGetLastError());
+      if (level + 1 == max_levels) break;
+      // next level: the rows whose Gram eigenvalue fell below 1e-12 of this level's largest (sigma below
+      // 1e-6 of it: a margin of two decades above what this level resolves), unless they already sit
+      // at the rounding floor of the whole matrix
+      hev.resize(who.size() * (size_t)sigma_stride);
+      DM_TRY(dm_download(ctx, hev.data(), evp, sizeof(double) * hev.size()));
+      bool more = false;
+      for (size_t k = 0; k < who.size(); ++k) {
+        const int p = who[k];
+        const double* ev = &hev[k * (size_t)sigma_stride];
+        const int ns = hp[k].n;
+        if (level == 0) ev0[p] = ev[0];
+        lvl_on[p] = 0;
+        if (!(ev[0] > 0.0)) continue;
+        int i = 0;
+        while (i < ns && ev[i] >= 1e-12 * ev[0]) ++i;
+        const double e4 = 4.0 * 2.220446049250313e-16;
+        if (ns - i <= JP || i == 0) continue;  // up to one row pair the inner Jacobi solver sorts them out in LDS anyway
+        if (1e-12 * ev[0] <= e4 * e4 * ev0[p]) continue;  // what is left is rounding residue of the largest rows
+        sub0[p] += i;
+        lvl_on[p] = 1;
+        more = true;
+      }
+      if (getenv("DM_DEBUG")) {
+        int cnt = 0, lo = 1 << 30, hi = 0;
+        for (int p = 0; p < np; ++p)
+          if (lvl_on[p]) { ++cnt; lo = std::min(lo, probs[p].nrows - sub0[p]); hi = std::max(hi, probs[p].nrows - sub0[p]); }
+        fprintf(stderr, "[jacobi_rows] preconditioner level %d done; %d problems go one level down (%d..%d rows)\n", level,
+                cnt, cnt ? lo : 0, hi);
+      }
+      if (!more) break;
     }
   }
 

@@ -28,6 +28,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -146,6 +148,19 @@ extern "C" int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, c
       // the reference's guard `(s1 > 0.0).any()` (beamtransfer.py:855-857)
       alive[c] = (s[0] > 0.0) ? 1 : 0;
     }
+    if (getenv("DM_DEBUG")) {
+      // decades of the SVD1 spectrum of the first chain, and the rank range over the batch
+      const double* s = &hs[0];
+      int dec[20] = {0};
+      for (int i = 0; i < T; ++i) {
+        const double r = s[i] > 0.0 ? -std::log10(s[i] / s[0]) : 19.0;
+        dec[std::min(19, std::max(0, (int)r))]++;
+      }
+      fprintf(stderr, "[svd_chain] SVD1 sweeps %d, r1 %d..%d, chain 0 per-decade counts:", sw,
+              *std::min_element(r1.begin(), r1.end()), *std::max_element(r1.begin(), r1.end()));
+      for (int d = 0; d < 20; ++d) fprintf(stderr, " %d", dec[d]);
+      fprintf(stderr, "\n");
+    }
     // ---- phase 2: SVD2, left null space of the polarised columns, `>=` cut (:844-848, :137)
     for (int c = 0; c < nch; ++c) pr[c] = dm_jac_problem{Z + (size_t)c * T * ldz, ldz, 0, r1[c], ldz, L, PL};
     DM_TRY(dm_jacobi_rows(ctx, pr, sig, T, &sw));
@@ -157,6 +172,9 @@ extern "C" int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, c
       for (int i = 0; i < r1[c]; ++i) cnt += (s[i] >= s[0] * polsvcut) ? 1 : 0;
       cut2[c] = cnt;
     }
+    if (getenv("DM_DEBUG"))
+      fprintf(stderr, "[svd_chain] SVD2 sweeps %d, cut2 %d..%d\n", sw, *std::min_element(cut2.begin(), cut2.end()),
+              *std::max_element(cut2.begin(), cut2.end()));
   }
 
   // ---- phase 3: SVD3 on the total-intensity columns, rtol 0 (:859-865)
@@ -183,6 +201,9 @@ extern "C" int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, c
     nmodes_host[c] = cnt;
     maxnm = std::max(maxnm, cnt);
   }
+  if (getenv("DM_DEBUG"))
+    fprintf(stderr, "[svd_chain] SVD3 sweeps %d, nmodes %d..%d\n", sw, *std::min_element(nmodes.begin(), nmodes.end()),
+            maxnm);
 
   // ---- products
   int* d_row0 = dm_ws_upload(ctx, row0);

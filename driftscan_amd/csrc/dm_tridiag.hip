@@ -991,7 +991,7 @@ __global__ __launch_bounds__(64) void larft_kernel(const tf_mat* __restrict__ ts
 // Parallel depth O(log n) instead of the ~1.1 n^2 serial rotations of QL.
 // ===========================================================================
 constexpr int DC_LEAF = 32;
-constexpr int DC_MAXNODE = 4096;  // LDS-resident setup; larger problems use the QL path
+constexpr int DC_MAXNODE = 4096;  // LDS-resident setup / secular kernels up to here, global-scratch variants beyond
 
 struct dc_mat {
   int n;
@@ -1004,6 +1004,7 @@ struct dc_mat {
   double4* rots;                // (colA, colB, c, s) with the column indices stored as doubles
   int* org; double* mu; double* zhat; double* inv;
   double* U;                    // n x n scratch: node block at U + lo * n, leading dimension n
+  double* gs; int* gi;          // 4 n doubles + n ints: setup scratch of nodes too large for LDS (node at 4 lo / lo)
 };
 
 struct dc_node {
@@ -1014,17 +1015,20 @@ struct dc_node {
 
 struct dc_nodeout { int k, ndefl, nrot; double rho; };
 
+// BIG = false: the node's work arrays live in LDS (nn <= DC_MAXNODE); BIG = true: in the global scratch
+// M.gs / M.gi (any nn), the counting sort then broadcasts 64 keys at a time through lane reads.
+template <bool BIG>
 __global__ __launch_bounds__(256) void dc_setup_kernel(const dc_mat* __restrict__ ms, const dc_node* __restrict__ nodes,
                                                        dc_nodeout* __restrict__ outs) {
   extern __shared__ __align__(16) unsigned char dc_smem[];
   const dc_node nd = nodes[blockIdx.x];
   const dc_mat M = ms[nd.mat];
   const int nn = nd.n1 + nd.n2, lo = nd.lo, n = M.n;
-  double* sd = reinterpret_cast<double*>(dc_smem);   // sorted poles
+  double* sd = BIG ? M.gs + 4 * (size_t)lo : reinterpret_cast<double*>(dc_smem);   // sorted poles
   double* sz = sd + nn;                              // sorted weights
   double* ud = sz + nn;                              // unsorted copies
   double* uz = ud + nn;
-  int* sidx = reinterpret_cast<int*>(uz + nn);       // sorted position -> local column
+  int* sidx = BIG ? M.gi + lo : reinterpret_cast<int*>(uz + nn);       // sorted position -> local column
   __shared__ double red[4];
   __shared__ double s_norm, s_zmax, s_dmax;
   const int tid = threadIdx.x;
@@ -1048,19 +1052,35 @@ __global__ __launch_bounds__(256) void dc_setup_kernel(const dc_mat* __restrict_
   const double rho = fabs(beta) * zn * zn;
   // rank by counting (stable), scatter into sorted order
   double zmax = 0.0, dmax = 0.0;
-  for (int i = tid; i < nn; i += 256) {
-    const double di = ud[i];
+  if (BIG) __syncthreads();  // ud / uz of the other waves (global scratch)
+  for (int i0 = 0; i0 < nn; i0 += 256) {
+    const int i = i0 + tid;  // the loop is wave-uniform: lanes past the end only help with the broadcasts
+    const double di = i < nn ? ud[i] : 0.0;
     int r = 0;
-    for (int j = 0; j < nn; ++j) {
-      const double dj = ud[j];
-      r += (dj < di || (dj == di && j < i)) ? 1 : 0;
+    if (BIG) {
+      const int lane = tid & 63;
+      for (int j0 = 0; j0 < nn; j0 += 64) {
+        const double mine = (j0 + lane < nn) ? ud[j0 + lane] : __builtin_inf();
+#pragma unroll 16
+        for (int t = 0; t < 64; ++t) {
+          const double dj = __shfl(mine, t, 64);
+          r += (dj < di || (dj == di && j0 + t < i)) ? 1 : 0;
+        }
+      }
+    } else {
+      for (int j = 0; j < nn; ++j) {
+        const double dj = ud[j];
+        r += (dj < di || (dj == di && j < i)) ? 1 : 0;
+      }
     }
-    const double zi = zn > 0.0 ? uz[i] / zn : 0.0;
-    sd[r] = di;
-    sz[r] = zi;
-    sidx[r] = i;
-    zmax = fmax(zmax, fabs(zi));
-    dmax = fmax(dmax, fabs(di));
+    if (i < nn) {
+      const double zi = zn > 0.0 ? uz[i] / zn : 0.0;
+      sd[r] = di;
+      sz[r] = zi;
+      sidx[r] = i;
+      zmax = fmax(zmax, fabs(zi));
+      dmax = fmax(dmax, fabs(di));
+    }
   }
   zmax = dm_wave_max(zmax);
   dmax = dm_wave_max(dmax);
@@ -1184,7 +1204,9 @@ __global__ __launch_bounds__(256) void dc_gather_kernel(const dc_mat* __restrict
   }
 }
 
-// grid = (root tiles of 256, nodes); dynamic LDS: 2 * kmax doubles
+// grid = (root tiles of 256, nodes); dynamic LDS: 2 * kmax doubles (BIG: poles and weights are read
+// from global memory instead -- every lane of a wave reads the same element, one request per load)
+template <bool BIG>
 __global__ __launch_bounds__(256) void dc_secular_kernel(const dc_mat* __restrict__ ms, const dc_node* __restrict__ nodes,
                                                          const dc_nodeout* __restrict__ outs) {
   extern __shared__ __align__(16) unsigned char dc_smem[];
@@ -1193,14 +1215,22 @@ __global__ __launch_bounds__(256) void dc_secular_kernel(const dc_mat* __restric
   const dc_nodeout o = outs[blockIdx.y];
   const int k = o.k, lo = nd.lo;
   if ((int)(blockIdx.x * 256) >= k) return;
-  double* d = reinterpret_cast<double*>(dc_smem);
-  double* z2 = d + k;
-  for (int i = threadIdx.x; i < k; i += 256) {
-    d[i] = M.dk[lo + i];
-    const double z = M.zk[lo + i];
-    z2[i] = z * z;
+  const double* d = BIG ? M.dk + lo : reinterpret_cast<double*>(dc_smem);
+  const double* zsrc = BIG ? M.zk + lo : d + k;
+  auto Z2 = [&](int i) -> double {
+    const double z = zsrc[i];
+    return BIG ? z * z : z;
+  };
+  if (!BIG) {
+    double* d = reinterpret_cast<double*>(dc_smem);
+    double* z2 = d + k;
+    for (int i = threadIdx.x; i < k; i += 256) {
+      d[i] = M.dk[lo + i];
+      const double z = M.zk[lo + i];
+      z2[i] = z * z;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= k) return;
   const double rho = o.rho;
@@ -1208,8 +1238,8 @@ __global__ __launch_bounds__(256) void dc_secular_kernel(const dc_mat* __restric
   double* lamn = nd.flip ? M.lamA : M.lamB;
   if (k == 1) {
     M.org[lo] = 0;
-    M.mu[lo] = rho * z2[0];
-    lamn[lo] = d[0] + rho * z2[0];
+    M.mu[lo] = rho * Z2(0);
+    lamn[lo] = d[0] + rho * Z2(0);
     return;
   }
   const bool last = (j == k - 1);
@@ -1218,12 +1248,12 @@ __global__ __launch_bounds__(256) void dc_secular_kernel(const dc_mat* __restric
   if (!last) {
     const double mid = 0.5 * (d[j + 1] - d[j]);
     double f = 1.0;
-    for (int i = 0; i < k; ++i) f += rho * z2[i] / ((d[i] - d[j]) - mid);
+    for (int i = 0; i < k; ++i) f += rho * Z2(i) / ((d[i] - d[j]) - mid);
     if (f > 0.0) { og = j; lo_b = 0.0; hi_b = mid; } else { og = j + 1; lo_b = -mid; hi_b = 0.0; }
   } else {
     og = j;
     double sz = 0.0;
-    for (int i = 0; i < k; ++i) sz += z2[i];
+    for (int i = 0; i < k; ++i) sz += Z2(i);
     lo_b = 0.0;
     hi_b = rho * sz;
   }
@@ -1233,13 +1263,13 @@ __global__ __launch_bounds__(256) void dc_secular_kernel(const dc_mat* __restric
     double psi = 0.0, phi = 0.0, dpsi = 0.0, dphi = 0.0;
     for (int i = 0; i <= j; ++i) {
       const double t = 1.0 / ((d[i] - dorg) - mu);
-      const double term = rho * z2[i] * t;
+      const double term = rho * Z2(i) * t;
       psi += term;
       dpsi += term * t;
     }
     for (int i = j + 1; i < k; ++i) {
       const double t = 1.0 / ((d[i] - dorg) - mu);
-      const double term = rho * z2[i] * t;
+      const double term = rho * Z2(i) * t;
       phi += term;
       dphi += term * t;
     }
@@ -1261,7 +1291,7 @@ __global__ __launch_bounds__(256) void dc_secular_kernel(const dc_mat* __restric
       }
     } else {
       const double tq = (d[j] - dorg) - mu, tp = (d[j - 1] - dorg) - mu;
-      const double dphil = rho * z2[j] / (tq * tq);
+      const double dphil = rho * Z2(j) / (tq * tq);
       const double dpsil = dpsi + dphi - dphil;
       double c = fv - tp * dpsil - tq * dphil;
       const double a = (tp + tq) * fv - tp * tq * (dpsil + dphil);
@@ -1367,6 +1397,9 @@ static int dc_solve(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, 
   int* deflcol = dm_ws_alloc_t<int>(ctx, std::max<size_t>(totn, 1));
   int* org = dm_ws_alloc_t<int>(ctx, std::max<size_t>(totn, 1));
   double4* rots = dm_ws_alloc_t<double4>(ctx, std::max<size_t>(totn, 1));
+  double* gsc = dm_ws_alloc_t<double>(ctx, std::max<size_t>(4 * totn, 1));
+  int* gic = dm_ws_alloc_t<int>(ctx, std::max<size_t>(totn, 1));
+  if (!gsc || !gic) return DM_ENOMEM;
   if (!ZA || !ZB || !Zp || !Uw || !lamB || !dk || !zk || !defld || !muv || !zhat || !inv || !keepcol || !deflcol ||
       !org || !rots)
     return DM_ENOMEM;
@@ -1384,7 +1417,7 @@ static int dc_solve(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, 
     dmax = std::max(dmax, D);
     dm[p] = dc_mat{n, dd + offn[p], lamB + offn[p], ZA + off[p], ZB + off[p], Zp + off[p], dk + offn[p], zk + offn[p],
                    keepcol + offn[p], deflcol + offn[p], defld + offn[p], rots + offn[p], org + offn[p],
-                   muv + offn[p], zhat + offn[p], inv + offn[p], Uw + off[p]};
+                   muv + offn[p], zhat + offn[p], inv + offn[p], Uw + off[p], gsc + 4 * offn[p], gic + offn[p]};
   }
   dc_mat* d_dm = dm_ws_upload(ctx, dm);
   if (!d_dm) return DM_ENOMEM;
@@ -1472,9 +1505,9 @@ static int dc_solve(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, 
   // ---- merge level by level
   static bool attr2 = false;
   if (!attr2) {
-    DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dc_setup_kernel),
+    DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dc_setup_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 36 * DC_MAXNODE + 64));
-    DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dc_secular_kernel),
+    DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(dc_secular_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 16 * DC_MAXNODE + 64));
     attr2 = true;
   }
@@ -1495,8 +1528,13 @@ static int dc_solve(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, 
     dc_node* d_nodes = dm_ws_upload(ctx, nodes);
     dc_nodeout* d_out = dm_ws_alloc_t<dc_nodeout>(ctx, nn_nodes);
     if (!d_nodes || !d_out) return DM_ENOMEM;
-    hipLaunchKernelGGL(dc_setup_kernel, dim3(nn_nodes), dim3(256), (size_t)36 * maxnn + 64, ctx->stream, d_dm, d_nodes,
-                       d_out);
+    // levels with a node beyond the LDS capacity take the global-scratch variants (a handful of nodes)
+    const bool big = maxnn > DC_MAXNODE;
+    if (big)
+      hipLaunchKernelGGL(dc_setup_kernel<true>, dim3(nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
+    else
+      hipLaunchKernelGGL(dc_setup_kernel<false>, dim3(nn_nodes), dim3(256), (size_t)36 * maxnn + 64, ctx->stream, d_dm,
+                         d_nodes, d_out);
     hipLaunchKernelGGL(dc_permute_kernel, dim3(nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
     hipLaunchKernelGGL(dc_gather_kernel, dim3((maxnn + DCG - 1) / DCG, nn_nodes), dim3(256), 0, ctx->stream, d_dm,
                        d_nodes, d_out);
@@ -1507,8 +1545,11 @@ static int dc_solve(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, 
     for (auto& o : ho) kmax = std::max(kmax, o.k);
     if (kmax == 0) continue;
     const int kt = (kmax + 255) / 256;
-    hipLaunchKernelGGL(dc_secular_kernel, dim3(kt, nn_nodes), dim3(256), (size_t)16 * kmax + 64, ctx->stream, d_dm,
-                       d_nodes, d_out);
+    if (big)
+      hipLaunchKernelGGL(dc_secular_kernel<true>, dim3(kt, nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
+    else
+      hipLaunchKernelGGL(dc_secular_kernel<false>, dim3(kt, nn_nodes), dim3(256), (size_t)16 * kmax + 64, ctx->stream,
+                         d_dm, d_nodes, d_out);
     hipLaunchKernelGGL(dc_zhat_kernel, dim3(kt, nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
     hipLaunchKernelGGL(dc_unorm_kernel, dim3(kt, nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
     hipLaunchKernelGGL(dc_ubuild_kernel, dim3(kt, kmax, nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
@@ -1601,10 +1642,18 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
   double* dd = dm_ws_alloc_t<double>(ctx, std::max<size_t>(totn, 1));
   double* ee = dm_ws_alloc_t<double>(ctx, std::max<size_t>(totn, 1));
   cplx* tau = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn, 1));
+  // One chunk by default: T1 is a latency-bound chain of ~3 n small launches whose cost hardly
+  // depends on the batch size, so splitting the batch multiplies it (measured: 4 chunks = +40 %).
+  // DM_TRIDIAG_CHUNKS > 1 enables the side-stream pipeline for experiments.
+  int nch = 1;
+  if (const char* e = getenv("DM_TRIDIAG_CHUNKS")) nch = std::max(1, std::min(8, atoi(e)));
+  if (maxn < 256 || np < 2 * nch) nch = 1;
+  const bool use_dc = nch == 1 && maxn > DC_LEAF && !getenv("DM_EIG_QL");
+  // the recorded rotations (2 n^2 double2) and the QL eigenvector array only exist on the QL path
   size_t totsw = 0, totrot = 0;
   std::vector<size_t> swoff(np), rotoff(np);
   for (int p = 0; p < np; ++p) {
-    const size_t n = probs[p].n;
+    const size_t n = use_dc ? 0 : probs[p].n;
     swoff[p] = totsw; totsw += 4 * n + 8;
     rotoff[p] = totrot; totrot += 2 * n * n + 8;
   }
@@ -1615,7 +1664,7 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
   double2* rot = dm_ws_alloc_t<double2>(ctx, totrot);
   int* nsw = dm_ws_alloc_t<int>(ctx, np);
   int* stat = dm_ws_alloc_t<int>(ctx, np);
-  double* Zt = dm_ws_alloc_t<double>(ctx, std::max<size_t>(tot, 1));
+  double* Zt = dm_ws_alloc_t<double>(ctx, std::max<size_t>(use_dc ? 1 : tot, 1));
   // back-transformation in compact-WY blocks of NBB reflectors (merged from the TNB-wide panels)
   int NBB = 2 * TNB;
   if (const char* e = getenv("DM_WY_BLOCK")) {
@@ -1651,12 +1700,6 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
   std::vector<int> order(np);
   for (int p = 0; p < np; ++p) order[p] = p;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return probs[a].n > probs[b].n; });
-  // One chunk by default: T1 is a latency-bound chain of ~3 n small launches whose cost hardly
-  // depends on the batch size, so splitting the batch multiplies it (measured: 4 chunks = +40 %).
-  // DM_TRIDIAG_CHUNKS > 1 enables the side-stream pipeline for experiments.
-  int nch = 1;
-  if (const char* e = getenv("DM_TRIDIAG_CHUNKS")) nch = std::max(1, std::min(8, atoi(e)));
-  if (maxn < 256 || np < 2 * nch) nch = 1;
   std::vector<std::vector<int>> chunks(nch);
   {
     double total = 0.0;
@@ -2017,7 +2060,6 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
     return DM_OK;
   };
 
-  const bool use_dc = nch == 1 && maxn > DC_LEAF && maxn <= DC_MAXNODE && !getenv("DM_EIG_QL");
   if (use_dc) {
     DM_TRY(phase_T1(chunks[0]));
     DM_TRY(dc_solve(ctx, probs, dd, ee, offn, off, tot, totn, zfinal));

@@ -177,6 +177,34 @@ def test_herm_eig_tridiag(ctx, n):
         assert np.abs(D - np.diag(ev[b, :n])).max() <= 5e-13 * scale
 
 
+@pytest.mark.parametrize("kind", ["graded", "clustered"])
+def test_herm_eig_tridiag_beyond_lds(ctx, kind):
+    """n > 4096: the divide & conquer merge nodes no longer fit in LDS and take the global-scratch
+    setup / secular kernels (config 3 has ndof up to 32 832).  The spectrum is prescribed:
+    C = H diag(lam) H^H with H a product of three Householder reflectors (dense, exactly unitary)."""
+    n = 4500
+    rng = np.random.default_rng(4500)
+    if kind == "graded":
+        lam = 10.0 ** rng.uniform(-12, 0, n) * rng.choice([1.0, 1.0, -1.0], n)
+    else:
+        lam = rng.choice(np.linspace(0.5, 3.0, 40), n)  # heavy deflation
+    C = np.diag(lam).astype(np.complex128)
+    for _ in range(3):
+        u = crand(rng, n)
+        u /= np.linalg.norm(u)
+        C -= 2.0 * np.outer(u, u.conj() @ C)
+        C -= 2.0 * np.outer(C @ u, u.conj())
+    C = 0.5 * (C + C.conj().T)
+    ev, W = ctx.herm_eig(ctx.to_device(C), n, n, strideC=n * n, batch=1)
+    ev = ev.cpu().numpy()[0, :n]
+    W = W.cpu().numpy()[0]
+    scale = np.abs(lam).max()
+    assert np.abs(np.sort(ev) - np.sort(lam)).max() <= 2e-13 * scale
+    assert np.abs(W @ W.conj().T - np.eye(n)).max() < 2e-12
+    D = W @ C @ W.conj().T
+    assert np.abs(D - np.diag(ev)).max() <= 2e-12 * scale
+
+
 def test_herm_eig_mixed_sizes_via_eigh_gen(ctx):
     """Different n in one batch (the KL use: ndof varies with m)."""
     from driftscan_amd._lib import block_offsets

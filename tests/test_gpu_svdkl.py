@@ -155,3 +155,48 @@ def test_eigh_gen_rescue_and_zero(ctx, golden_dir):
     assert ac[0] == 0.0 and ac[2] == 0.0
     # the shift is 1e-15 ev_max - 2 ev_min + 1e-60 with ev_min ~ -1e-9: well determined
     assert np.isclose(ac[1], float(g["npd_ac"]), rtol=1e-5)
+
+
+def test_svd_chain_wide_dynamic_range(ctx):
+    """A polarised block whose spectrum runs over 15 decades with a rank-deficient polarised part, as a
+    config-3 beam block does (864 rows, several hundred of them below 1e-8 sigma_1): the rows that the first
+    Gram preconditioner cannot resolve go through its second and third level.  Checked against the oracle
+    (the restatement pinned on the reference) on the same input."""
+    from oracle import svdchain as osvd
+
+    rng = np.random.default_rng(77)
+    F, B, P, L = 2, 48, 4, 40
+    T = 2 * B
+    beam = np.zeros((F, T, P, L), dtype=np.complex128)
+    for f in range(F):
+        u = np.linalg.qr(rng.standard_normal((T, T)) + 1j * rng.standard_normal((T, T)))[0]
+        v = np.linalg.qr(rng.standard_normal((L, L)) + 1j * rng.standard_normal((L, L)))[0]
+        s = 10.0 ** np.linspace(0, -15, L)
+        beam[f, :, 0, :] = (u[:, :L] * s) @ v.conj().T
+        r = T // 4
+        a = rng.standard_normal((T, r)) + 1j * rng.standard_normal((T, r))
+        c = rng.standard_normal((r, 3 * L)) + 1j * rng.standard_normal((r, 3 * L))
+        beam[f, :, 1:, :] = 0.05 * (a @ c).reshape(T, 3, L) * 10.0 ** rng.uniform(-6, 0, (T, 1, 1))
+    npower = rng.uniform(0.5, 2.0, (F, B))
+    nw = np.concatenate([npower, npower], axis=1) ** -0.5
+    polsvcut, svcut = 1e-4, 1e-6
+    res = ctx.svd_chain(ctx.to_device(beam[None]), ctx.to_device(nw), polsvcut)
+    ref = osvd.svd_m(beam.reshape(F, 2, B, P, L), npower ** -0.5, polsvcut=polsvcut)
+    sv = res["singularvalues"].cpu().numpy()[0]
+    assert_spectrum(sv, ref["singularvalues"], 1e-10, "singular values")
+    svnum, _ = osvd.svd_num(sv, svcut)
+    svnum_ref, _ = osvd.svd_num(ref["singularvalues"], svcut)
+    assert (svnum == svnum_ref).all() and svnum.min() > 0
+    assert max(res["sweeps"]) <= 12, res["sweeps"]
+    bs = res["beam_svd"].cpu().numpy()[0]
+    ut = res["beam_ut"].cpu().numpy()[0]
+    ib = res["invbeam_svd"].cpu().numpy()[0]
+    for f in range(F):
+        n = svnum[f]
+        b0, b1 = ref["beam_svd"][f, :n].reshape(n, -1), bs[f, :n].reshape(n, -1)
+        assert relerr(b1.T.conj() @ b1, b0.T.conj() @ b0) < 1e-9
+        u1 = ut[f, :n] / nw[f][None, :]
+        assert np.abs(u1 @ u1.conj().T - np.eye(n)).max() < 1e-12
+        K = ib.shape[-1]
+        i1 = ib[f].reshape(-1, K)[:, :n]
+        assert np.abs(b1 @ i1 - np.eye(n)).max() < 1e-8  # kappa = 1 / svcut
