@@ -485,6 +485,39 @@ __global__ void jac_scatter_back_kernel(const jac_pdesc* __restrict__ pd, const 
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < w; c += gridDim.x * blockDim.x) s[c] = t[c];
 }
 
+// ---- block rotation between the rows above a level boundary (A) and the rows below it (B) ----
+struct jac_clean_desc {
+  cplx* Z; int ld; int row0; int ra; int rb; int ncols;
+  cplx* theta;          // rb x ra, row-major
+  const double* anorm;  // ra row norms of A over the Gram columns
+  cplx* tmp;            // (ra + rb) x ncols: P2 (ra rows) then P1 (rb rows)
+};
+// theta[j][i] = -c[j][i] / ||a_i||^2   (c = B A^H on entry)
+__global__ void jac_theta_kernel(const jac_clean_desc* __restrict__ ds) {
+  const jac_clean_desc d = ds[blockIdx.z];
+  const int j = blockIdx.y;
+  if (j >= d.rb) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.ra; i += gridDim.x * blockDim.x) {
+    const double nrm = d.anorm[i];
+    const double w = nrm > 0.0 ? -1.0 / (nrm * nrm) : 0.0;
+    cplx c = d.theta[(size_t)j * d.ra + i];
+    d.theta[(size_t)j * d.ra + i] = make_double2(c.x * w, c.y * w);
+  }
+}
+// tmp row r <- A_r - tmp_r / 2 (r < ra)   |   B_r + tmp_r / 2 (r >= ra)
+__global__ void jac_clean_mix_kernel(const jac_clean_desc* __restrict__ ds) {
+  const jac_clean_desc d = ds[blockIdx.z];
+  const int r = blockIdx.y;
+  if (r >= d.ra + d.rb) return;
+  const double h = r < d.ra ? -0.5 : 0.5;
+  const cplx* z = d.Z + (size_t)(d.row0 + r) * d.ld;
+  cplx* t = d.tmp + (size_t)r * d.ncols;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < d.ncols; c += gridDim.x * blockDim.x) {
+    const cplx a = z[c], b = t[c];
+    t[c] = make_double2(a.x + h * b.x, a.y + h * b.y);
+  }
+}
+
 // out = conj(in)^T for square n x n blocks, batched through descriptors
 struct jac_tdesc {
   const cplx* src; int lds; cplx* dst; int ldd; int n;
@@ -737,9 +770,69 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
     std::vector<int> sub0(np, 0), lvl_on(active);  // first row of the current level's sub-block, per problem
     std::vector<double> ev0(np, 0.0);              // largest Gram eigenvalue of level 0 (sigma_1^2)
     std::vector<double> hev;
-    int max_levels = 3;
-    if (const char* e = getenv("DM_JAC_PRECOND_LEVELS")) max_levels = std::max(0, std::min(4, atoi(e)));
+    int max_levels = 4;
+    if (const char* e = getenv("DM_JAC_PRECOND_LEVELS")) max_levels = std::max(0, std::min(6, atoi(e)));
+    const bool clean = !getenv("DM_JAC_NO_CLEAN");
     for (int level = 0; level < max_levels; ++level) {
+      if (level > 0 && clean) {
+        // The rows of this level still carry components along the rows above them (A) of absolute size
+        // ~eps sigma_1^2 / sigma_i — as large as the rows themselves.  Remove them BEFORE looking at the
+        // level's own Gram matrix, with the block rotation W = [[I - T^H T / 2, -T^H], [T, I - T T^H / 2]],
+        // T = -(B A^H) diag(||a_i||^-2): the rows of A are mutually orthogonal already, |T_ji| <= eps
+        // sigma_1^2 / sigma_i^2 <= 2e-7 by the choice of the level boundary, so W is unitary to ||T||^4.
+        std::vector<jac_clean_desc> cd;
+        std::vector<jac_pdesc> pa;
+        std::vector<dm_gemm_desc> gC, gP1, gP2, gA, gB;
+        int maxra = 0, maxrb = 0;
+        for (int p = 0; p < np; ++p) {
+          const dm_jac_problem& P = probs[p];
+          const int ra = sub0[p], rb = P.nrows - sub0[p];
+          if (!lvl_on[p] || ra < 1 || rb < 1) continue;
+          cplx* Arow = P.Z + (size_t)P.row0 * P.ld;
+          cplx* Brow = P.Z + (size_t)(P.row0 + ra) * P.ld;
+          cplx* th = Gm + goff[p];                         // rb x ra  (<= nrows^2 / 4)
+          cplx* t2 = d_tmp + toff[p];                      // P2: ra x ncols
+          cplx* t1 = t2 + (size_t)ra * P.ncols;            // P1: rb x ncols
+          double* an = d_key + (size_t)p * sigma_stride;
+          const int k = (int)cd.size();
+          cd.push_back(jac_clean_desc{P.Z, P.ld, P.row0, ra, rb, P.ncols, th, an + 0, t2});
+          jac_pdesc d = pd[p];
+          d.nrows = ra;
+          pa.push_back(d);
+          (void)k;
+          gC.push_back(dm_gemm_make(Brow + P.gc0, P.ld, 1, false, Arow + P.gc0, 1, P.ld, true, th, ra, rb, ra,
+                                    P.gc1 - P.gc0));
+          gP1.push_back(dm_gemm_make(th, ra, 1, false, Arow, P.ld, 1, false, t1, P.ncols, rb, P.ncols, ra));
+          gP2.push_back(dm_gemm_make(th, 1, ra, true, Brow, P.ld, 1, false, t2, P.ncols, ra, P.ncols, rb));
+          gA.push_back(dm_gemm_make(th, 1, ra, true, t1, P.ncols, 1, false, Arow, P.ld, ra, P.ncols, rb, -1.0, 1.0));
+          gB.push_back(dm_gemm_make(th, ra, 1, false, t2, P.ncols, 1, false, Brow, P.ld, rb, P.ncols, ra, 1.0, 1.0));
+          maxra = std::max(maxra, ra);
+          maxrb = std::max(maxrb, rb);
+        }
+        if (!cd.empty()) {
+          // row norms of A land at d_key[p * stride + i]: the descriptor list is compacted, so give the
+          // norm kernel its own output rows and point the descriptors at them
+          double* an = dm_ws_alloc_t<double>(ctx, cd.size() * (size_t)sigma_stride);
+          if (!an) return DM_ENOMEM;
+          for (size_t k = 0; k < cd.size(); ++k) cd[k].anorm = an + k * (size_t)sigma_stride;
+          jac_pdesc* d_pa = dm_ws_upload(ctx, pa);
+          jac_clean_desc* d_cd = dm_ws_upload(ctx, cd);
+          if (!d_pa || !d_cd) return DM_ENOMEM;
+          hipLaunchKernelGGL(jac_rownorm_kernel, dim3((maxra + 3) / 4, (unsigned)pa.size()), dim3(256), 0, ctx->stream, d_pa,
+                             an, sigma_stride, maxra);
+          DM_TRY(dm_gemm_grouped_launch(ctx, gC));
+          hipLaunchKernelGGL(jac_theta_kernel, dim3((maxra + 255) / 256, maxrb, (unsigned)cd.size()), dim3(256), 0,
+                             ctx->stream, d_cd);
+          DM_TRY(dm_gemm_grouped_launch(ctx, gP1));
+          DM_TRY(dm_gemm_grouped_launch(ctx, gP2));
+          const int gxm = std::max(1, std::min(8, (maxcols + 255) / 256));
+          hipLaunchKernelGGL(jac_clean_mix_kernel, dim3(gxm, maxra + maxrb, (unsigned)cd.size()), dim3(256), 0, ctx->stream,
+                             d_cd);
+          DM_TRY(dm_gemm_grouped_launch(ctx, gA));
+          DM_TRY(dm_gemm_grouped_launch(ctx, gB));
+          DM_HIP(ctx, hipGetLastError());
+        }
+      }
       std::vector<dm_gemm_desc> g;
       std::vector<dm_jac_herm_problem> hp;
       std::vector<int> who;
@@ -791,9 +884,9 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
                          d_pda, d_tmp, d_toffa);
       DM_HIP(ctx, hipGetLastError());
       if (level + 1 == max_levels) break;
-      // next level: the rows whose Gram eigenvalue fell below 1e-12 of this level's largest (sigma below
-      // 1e-6 of it: a margin of two decades above what this level resolves), unless they already sit
-      // at the rounding floor of the whole matrix
+      // next level: the rows whose Gram eigenvalue fell below 1e-9 of this level's largest (sigma below
+      // 3e-5 of it: a margin of three decades above what this level resolves, and the bound on the block
+      // rotation above), unless they already sit at the rounding floor of the whole matrix
       hev.resize(who.size() * (size_t)sigma_stride);
       DM_TRY(dm_download(ctx, hev.data(), evp, sizeof(double) * hev.size()));
       bool more = false;
@@ -805,10 +898,10 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
         lvl_on[p] = 0;
         if (!(ev[0] > 0.0)) continue;
         int i = 0;
-        while (i < ns && ev[i] >= 1e-12 * ev[0]) ++i;
+        while (i < ns && ev[i] >= 1e-9 * ev[0]) ++i;
         const double e4 = 4.0 * 2.220446049250313e-16;
         if (ns - i <= JP || i == 0) continue;  // up to one row pair the inner Jacobi solver sorts them out in LDS anyway
-        if (1e-12 * ev[0] <= e4 * e4 * ev0[p]) continue;  // what is left is rounding residue of the largest rows
+        if (1e-9 * ev[0] <= e4 * e4 * ev0[p]) continue;  // what is left is rounding residue of the largest rows
         sub0[p] += i;
         lvl_on[p] = 1;
         more = true;

@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""One GPU's share of BASELINE configs[2] (128-feed polarised cylinder, nfreq = 64, lmax = mmax = 512,
+513 m-blocks sharded over 8 GPUs): 64 m-blocks spread evenly over the m range, pushed through
+BT-gen -> SVD chain + pinv -> KL (covariance projections + generalised eigenproblem) in groups of
+`--group` contiguous blocks.  m-blocks are independent and there is no data-path collective, so the
+wall time of this share IS the wall time of the 8-GPU job (compute only; products stay in HBM, file
+output is not timed).
+
+    python scratch/config3_share.py --out gpurun_out/config3_share.json
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from scratch.config3_probe import CFG3, log  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ranks", type=int, default=8, help="GPUs of the full job")
+    ap.add_argument("--group", type=int, default=8, help="contiguous m-blocks per BT-gen / SVD / KL call")
+    ap.add_argument("--bt-gb", type=float, default=64.0)
+    ap.add_argument("--limit-groups", type=int, default=0, help="stop after this many groups (0 = the whole share)")
+    ap.add_argument("--out", default="gpurun_out/config3_share.json")
+    args = ap.parse_args()
+
+    import torch
+
+    from driftscan_amd import beamtransfer, btgen, cylinder, device, kltransform
+
+    tel = cylinder.PolarisedCylinderTelescope.from_config(dict(CFG3))
+    nm_total = tel.mmax + 1
+    share = (nm_total + args.ranks - 1) // args.ranks            # 65 blocks for the largest share
+    ngroups = (share + args.group - 1) // args.group
+    # group g covers m in [g * stride, g * stride + group): the share samples the whole m range evenly
+    stride = nm_total // ngroups
+    groups = [(g * stride, min(g * stride + args.group, nm_total) - 1) for g in range(ngroups)]
+    if args.limit_groups:
+        groups = groups[: args.limit_groups]
+    log("telescope: nfreq %d nbase %d lmax %d; %d m-blocks in total, share of one of %d GPUs: %d blocks in %d groups"
+        % (tel.nfreq, tel.nbase, tel.lmax, nm_total, args.ranks, sum(b - a + 1 for a, b in groups), len(groups)))
+    ctx = device.get_context(workspace_bytes=48 << 30)
+
+    def sync():
+        ctx.sync()
+        torch.cuda.synchronize()
+
+    res = dict(config=dict(CFG3), ranks=args.ranks, groups=[], totals={})
+    os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        bt = beamtransfer.BeamTransfer(tmp, telescope=tel)
+        kl = kltransform.KLTransform.from_config(dict(threshold=0.1), bt, subdir="kl")
+        t0 = time.perf_counter()
+        kl.signal(); kl.foreground()
+        bt._cl_device(kl.signal()); bt._cl_device(kl.foreground())
+        sync()
+        res["cl_tables_s"] = time.perf_counter() - t0   # host-side C_l(nu, nu') model tables, once per job
+        log("C_l tables: %.1f s" % res["cl_tables_s"])
+        ctx.prof_reset(True)
+        tall = time.perf_counter()
+        tb = ts = tk = 0.0
+        nblk = 0
+        for (m_lo, m_hi) in groups:
+            ms = list(range(m_lo, m_hi + 1))
+            sync()
+            t0 = time.perf_counter()
+            beam = btgen.beam_m_all(tel, ctx=ctx, max_bytes=int(args.bt_gb * (1 << 30)), m_range=(m_lo, m_hi))
+            sync()
+            t1 = time.perf_counter()
+            out = bt.svd_device(beam)
+            sv = out["singularvalues"].cpu().numpy()
+            sync()
+            t2 = time.perf_counter()
+            del beam
+            for i, mi in enumerate(ms):
+                bt._dev[mi] = dict(beam_svd=out["beam_svd"][i], beam_ut=out["beam_ut"][i], singularvalues=sv[i])
+            ndofs = [int(bt.ndof(mi)) for mi in ms]
+            prods = None
+            for batch in kl._batches(ms):
+                prods = kl._transform_batch(batch, to_host=False)
+            sync()
+            t3 = time.perf_counter()
+            nk = int(ctx.last_nkeep.sum()) if hasattr(ctx, "last_nkeep") else None
+            del out, prods
+            for mi in ms:
+                bt._dev.pop(mi, None)
+            torch.cuda.empty_cache()
+            rec = dict(m_lo=m_lo, m_hi=m_hi, btgen_s=t1 - t0, svd_s=t2 - t1, kl_s=t3 - t2, ndof=ndofs, kept_last_batch=nk)
+            res["groups"].append(rec)
+            tb += t1 - t0; ts += t2 - t1; tk += t3 - t2
+            nblk += len(ms)
+            log("m %3d..%3d: BT-gen %.2f s, SVD %.2f s, KL %.2f s, ndof %d..%d" % (m_lo, m_hi, t1 - t0, t2 - t1, t3 - t2,
+                                                                                 min(ndofs), max(ndofs)))
+            res["totals"] = dict(blocks=nblk, btgen_s=tb, svd_s=ts, kl_s=tk, wall_s=time.perf_counter() - tall)
+            json.dump(res, open(args.out, "w"), indent=1)
+        wall = time.perf_counter() - tall
+        pr = ctx.prof_report()
+        res["kernels_ms"] = {k: v["ms"] for k, v in pr.items()}
+        res["kernels_tflops"] = {k: (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else None) for k, v in pr.items()
+                                 if k not in ("trd_symv", "trd_wx")}
+        res["totals"] = dict(blocks=nblk, btgen_s=tb, svd_s=ts, kl_s=tk, wall_s=wall,
+                             m_blocks_per_s_per_gpu=nblk / wall,
+                             projected_job_s=wall * share / max(nblk, 1),
+                             projected_job_note="%d blocks per GPU on %d GPUs, compute only (products left in HBM)"
+                                                % (share, args.ranks))
+        res["hbm_peak_gb"] = torch.cuda.max_memory_allocated() / 2 ** 30
+        res["workspace_gb"] = ctx.lib.dm_ctx_workspace_bytes(ctx.h) / 2 ** 30
+        json.dump(res, open(args.out, "w"), indent=1)
+        log("share done: %d blocks in %.1f s (BT-gen %.1f, SVD %.1f, KL %.1f) -> %.2f m-blocks/s per GPU; "
+            "projected 8-GPU job: %.0f s" % (nblk, wall, tb, ts, tk, nblk / wall, res["totals"]["projected_job_s"]))
+
+
+if __name__ == "__main__":
+    main()
