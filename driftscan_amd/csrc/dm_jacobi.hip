@@ -900,7 +900,9 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
         int i = 0;
         while (i < ns && ev[i] >= 1e-9 * ev[0]) ++i;
         const double e4 = 4.0 * 2.220446049250313e-16;
-        if (ns - i <= JP || i == 0) continue;  // up to one row pair the inner Jacobi solver sorts them out in LDS anyway
+        // worth a level only when the rows below span several row blocks: a sweep costs ~(row blocks)^2, and up
+        // to one pair of blocks the inner Jacobi solver sorts them out in LDS anyway (config 2: T = 92 rows)
+        if (ns - i <= 2 * JP || i == 0) continue;
         if (1e-9 * ev[0] <= e4 * e4 * ev0[p]) continue;  // what is left is rounding residue of the largest rows
         sub0[p] += i;
         lvl_on[p] = 1;

@@ -1,10 +1,17 @@
 #!/usr/bin/env python3
 """One GPU's share of BASELINE configs[2] (128-feed polarised cylinder, nfreq = 64, lmax = mmax = 512,
-513 m-blocks sharded over 8 GPUs): 64 m-blocks spread evenly over the m range, pushed through
-BT-gen -> SVD chain + pinv -> KL (covariance projections + generalised eigenproblem) in groups of
-`--group` contiguous blocks.  m-blocks are independent and there is no data-path collective, so the
-wall time of this share IS the wall time of the 8-GPU job (compute only; products stay in HBM, file
-output is not timed).
+513 m-blocks sharded over 8 GPUs), measured the way the multi-rank pipeline splits the work
+(DESIGN.md section 6):
+
+  * BT-gen: a rank transforms a CONTIGUOUS range of 65 m (map synthesis and ring DFT are per (f, b)
+    column whatever the number of m kept, so few large calls are the cheap way): timed here as
+    `--bt-calls` calls of 65 / bt-calls blocks each, at the low-m end (the expensive end);
+  * SVD chain + pinv and KL (covariance projections + generalised eigenproblem): cost-balanced
+    assignment of m to ranks; timed here on 72 blocks spread evenly over the m range, in groups of
+    `--group` contiguous blocks (the inputs of those groups are generated untimed).
+
+m-blocks are independent and there is no data-path collective, so BT-gen + SVD + KL of this share IS the
+compute wall time of the 8-GPU job (products stay in HBM; file output is not timed).
 
     python scratch/config3_share.py --out gpurun_out/config3_share.json
 """
@@ -28,6 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ranks", type=int, default=8, help="GPUs of the full job")
     ap.add_argument("--group", type=int, default=8, help="contiguous m-blocks per BT-gen / SVD / KL call")
+    ap.add_argument("--bt-calls", type=int, default=3, help="BT-gen calls for the rank's contiguous range of m")
     ap.add_argument("--bt-gb", type=float, default=64.0)
     ap.add_argument("--limit-groups", type=int, default=0, help="stop after this many groups (0 = the whole share)")
     ap.add_argument("--out", default="gpurun_out/config3_share.json")
@@ -69,6 +77,23 @@ def main():
         tall = time.perf_counter()
         tb = ts = tk = 0.0
         nblk = 0
+        # ---- BT-gen of a rank's contiguous range (rank 0: the lowest m, the longest Legendre sums)
+        per_call = (share + args.bt_calls - 1) // args.bt_calls
+        res["btgen_calls"] = []
+        for c in range(args.bt_calls if not args.limit_groups else 1):
+            m_lo, m_hi = c * per_call, min((c + 1) * per_call, share) - 1
+            sync()
+            t0 = time.perf_counter()
+            beam = btgen.beam_m_all(tel, ctx=ctx, max_bytes=int(args.bt_gb * (1 << 30)), m_range=(m_lo, m_hi))
+            sync()
+            dt = time.perf_counter() - t0
+            tb += dt
+            res["btgen_calls"].append(dict(m_lo=m_lo, m_hi=m_hi, s=dt))
+            log("BT-gen m %d..%d (%d blocks, %.1f GB): %.2f s" % (m_lo, m_hi, m_hi - m_lo + 1,
+                                                                 beam.numel() * 16 / 2 ** 30, dt))
+            del beam
+            torch.cuda.empty_cache()
+        t_untimed = 0.0
         for (m_lo, m_hi) in groups:
             ms = list(range(m_lo, m_hi + 1))
             sync()
@@ -76,6 +101,7 @@ def main():
             beam = btgen.beam_m_all(tel, ctx=ctx, max_bytes=int(args.bt_gb * (1 << 30)), m_range=(m_lo, m_hi))
             sync()
             t1 = time.perf_counter()
+            t_untimed += t1 - t0
             out = bt.svd_device(beam)
             sv = out["singularvalues"].cpu().numpy()
             sync()
@@ -96,27 +122,28 @@ def main():
             torch.cuda.empty_cache()
             rec = dict(m_lo=m_lo, m_hi=m_hi, btgen_s=t1 - t0, svd_s=t2 - t1, kl_s=t3 - t2, ndof=ndofs, kept_last_batch=nk)
             res["groups"].append(rec)
-            tb += t1 - t0; ts += t2 - t1; tk += t3 - t2
+            ts += t2 - t1; tk += t3 - t2
             nblk += len(ms)
-            log("m %3d..%3d: BT-gen %.2f s, SVD %.2f s, KL %.2f s, ndof %d..%d" % (m_lo, m_hi, t1 - t0, t2 - t1, t3 - t2,
-                                                                                 min(ndofs), max(ndofs)))
-            res["totals"] = dict(blocks=nblk, btgen_s=tb, svd_s=ts, kl_s=tk, wall_s=time.perf_counter() - tall)
+            log("m %3d..%3d: (input generation %.2f s, not part of the share) SVD %.2f s, KL %.2f s, ndof %d..%d"
+                % (m_lo, m_hi, t1 - t0, t2 - t1, t3 - t2, min(ndofs), max(ndofs)))
+            res["totals"] = dict(blocks=nblk, btgen_s=tb, svd_s=ts, kl_s=tk)
             json.dump(res, open(args.out, "w"), indent=1)
-        wall = time.perf_counter() - tall
+        wall = tb + (ts + tk) * share / max(nblk, 1)   # BT-gen of 65 contiguous blocks + SVD/KL scaled from the sample to 65
         pr = ctx.prof_report()
         res["kernels_ms"] = {k: v["ms"] for k, v in pr.items()}
         res["kernels_tflops"] = {k: (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else None) for k, v in pr.items()
                                  if k not in ("trd_symv", "trd_wx")}
-        res["totals"] = dict(blocks=nblk, btgen_s=tb, svd_s=ts, kl_s=tk, wall_s=wall,
-                             m_blocks_per_s_per_gpu=nblk / wall,
-                             projected_job_s=wall * share / max(nblk, 1),
-                             projected_job_note="%d blocks per GPU on %d GPUs, compute only (products left in HBM)"
-                                                % (share, args.ranks))
+        res["totals"] = dict(svd_kl_blocks=nblk, btgen_blocks=share, btgen_s=tb, svd_s=ts, kl_s=tk,
+                             projected_job_s=wall, m_blocks_per_s_per_gpu=share / wall,
+                             m_blocks_per_s_8gpu=nm_total / wall,
+                             projected_job_note="%d blocks per GPU on %d GPUs, compute only (products left in HBM): BT-gen "
+                                                "of the rank's contiguous range + (SVD + KL of the %d-block sample) x %d / %d"
+                                                % (share, args.ranks, nblk, share, nblk))
         res["hbm_peak_gb"] = torch.cuda.max_memory_allocated() / 2 ** 30
         res["workspace_gb"] = ctx.lib.dm_ctx_workspace_bytes(ctx.h) / 2 ** 30
         json.dump(res, open(args.out, "w"), indent=1)
-        log("share done: %d blocks in %.1f s (BT-gen %.1f, SVD %.1f, KL %.1f) -> %.2f m-blocks/s per GPU; "
-            "projected 8-GPU job: %.0f s" % (nblk, wall, tb, ts, tk, nblk / wall, res["totals"]["projected_job_s"]))
+        log("share done: BT-gen of %d blocks %.1f s; SVD %.1f s + KL %.1f s on %d blocks -> projected 8-GPU job %.0f s "
+            "(%.2f m-blocks/s per GPU)" % (share, tb, ts, tk, nblk, wall, share / wall))
 
 
 if __name__ == "__main__":

@@ -165,7 +165,7 @@ def test_svd_chain_wide_dynamic_range(ctx):
     from oracle import svdchain as osvd
 
     rng = np.random.default_rng(77)
-    F, B, P, L = 2, 48, 4, 40
+    F, B, P, L = 2, 100, 4, 60
     T = 2 * B
     beam = np.zeros((F, T, P, L), dtype=np.complex128)
     for f in range(F):
@@ -187,7 +187,7 @@ def test_svd_chain_wide_dynamic_range(ctx):
     svnum, _ = osvd.svd_num(sv, svcut)
     svnum_ref, _ = osvd.svd_num(ref["singularvalues"], svcut)
     assert (svnum == svnum_ref).all() and svnum.min() > 0
-    assert max(res["sweeps"]) <= 12, res["sweeps"]
+    assert max(res["sweeps"]) <= 6, res["sweeps"]  # 12-20 without the deeper preconditioner levels
     bs = res["beam_svd"].cpu().numpy()[0]
     ut = res["beam_ut"].cpu().numpy()[0]
     ib = res["invbeam_svd"].cpu().numpy()[0]
