@@ -56,6 +56,7 @@ class BeamTransfer(config.Reader):
     # MI355X-side knobs (not in the reference)
     device_chunk_gb = config.Property(proptype=float, default=6.0)  # BT-gen working set per launch group
     svd_chunk_gb = config.Property(proptype=float, default=16.0)    # SVD working set per batch of m
+    beam_chunk_gb = config.Property(proptype=float, default=96.0)   # beam_m blocks resident per BT-gen call
 
     noise_weight = True
 
@@ -201,29 +202,36 @@ class BeamTransfer(config.Reader):
         st = time.time()
         finc, binc, pinc = tel.included_freq, tel.included_baseline, tel.included_pol
         nranks, r = parallel.size(), parallel.rank()
+        M = tel.mmax + 1
         if nranks == 1:
-            beam_all = btgen.beam_m_all(tel, ctx=ctx, max_bytes=int(self.device_chunk_gb * (1 << 30)))
-            self._beam_all = beam_all  # (mmax+1, F, 2, B, P, L), kept for the SVD stage
-            m_lo, mine = 0, list(range(tel.mmax + 1))
+            m_lo, m_hi = 0, M - 1
         else:
             # BT-gen costs about the same for every m: contiguous ranges, each rank transforms only its
             # own blocks (dm_bt_sht_range); the SVD / KL stages re-read the files under their own
             # cost-balanced assignment
-            M = tel.mmax + 1
             m_lo, m_hi = (M * r) // nranks, (M * (r + 1)) // nranks - 1
-            mine = list(range(m_lo, m_hi + 1))
-            self._beam_all = None
-            beam_all = (btgen.beam_m_all(tel, ctx=ctx, max_bytes=int(self.device_chunk_gb * (1 << 30)),
-                                         m_range=(m_lo, m_hi)) if mine else None)
-        for mi in mine:
-            if os.path.exists(self._mfile(mi)) and not regen:
-                continue
-            blk = beam_all[mi - m_lo].cpu().numpy()
-            with storage.File(self._mfile(mi), "w") as f:
-                data = blk[np.ix_(finc, np.arange(2), binc, pinc, np.arange(mi, tel.lmax + 1))]
-                f.create_dataset("beam_m", data=data)
-                f.attrs["m"] = mi
-                f.attrs["frequencies"] = tel.frequencies
+        # the blocks of one call stay in HBM until they are written: bound them (config 3: 1.8 GB per block,
+        # 934 GB for all m).  Every call synthesises all (f, b) maps again, so the ranges are as long as fit.
+        per_block = tel.nfreq * 2 * tel.nbase * tel.num_pol_sky * (tel.lmax + 1) * 16
+        nb_max = max(1, int(self.beam_chunk_gb * (1 << 30) // per_block))
+        ranges = [(a, min(a + nb_max, m_hi + 1) - 1) for a in range(m_lo, m_hi + 1, nb_max)]
+        self._beam_all = None
+        for (a, b) in ranges:
+            whole = nranks == 1 and len(ranges) == 1
+            beam_all = btgen.beam_m_all(tel, ctx=ctx, max_bytes=int(self.device_chunk_gb * (1 << 30)),
+                                        m_range=None if whole else (a, b))
+            if whole:
+                self._beam_all = beam_all  # (mmax+1, F, 2, B, P, L), kept for the SVD stage
+            for mi in range(a, b + 1):
+                if os.path.exists(self._mfile(mi)) and not regen:
+                    continue
+                blk = beam_all[mi - a].cpu().numpy()
+                with storage.File(self._mfile(mi), "w") as f:
+                    data = blk[np.ix_(finc, np.arange(2), binc, pinc, np.arange(mi, tel.lmax + 1))]
+                    f.create_dataset("beam_m", data=data)
+                    f.attrs["m"] = mi
+                    f.attrs["frequencies"] = tel.frequencies
+            del beam_all
         parallel.barrier()
         if parallel.rank0():
             open(marker, "a").close()

@@ -207,3 +207,28 @@ def test_product_manager_end_to_end(tmp_path):
     assert np.abs(ref).max() > 0
     assert relerr(fisher, ref) < 1e-8
     assert not bias.any()
+
+
+def test_generate_mfiles_in_m_ranges(tmp_path):
+    """beam_m generation with the blocks of one call bounded (`beam_chunk_gb`): several m sub-ranges, each
+    with its own map synthesis, give the files of the all-m call bit for bit (BASELINE configs[2] cannot hold
+    its 934 GB of beam_m blocks in one call)."""
+    from driftscan_amd import beamtransfer, cylinder, device, storage
+
+    device.reset_context()
+    tcfg = dict(num_freq=2, freq_start=400.0, freq_end=420.0, freq_mode="edge", num_cylinders=2, cylinder_width=2.0,
+                num_feeds=3, feed_spacing=0.4, tsys=1.0)
+    out = {}
+    for tag, gb in (("all", 96.0), ("ranges", None)):
+        tel = cylinder.PolarisedCylinderTelescope.from_config(dict(tcfg))
+        bt = beamtransfer.BeamTransfer(str(tmp_path / tag), telescope=tel)
+        if gb is None:
+            per_block = tel.nfreq * 2 * tel.nbase * tel.num_pol_sky * (tel.lmax + 1) * 16
+            bt.beam_chunk_gb = 5.5 * per_block / (1 << 30)  # five blocks per call
+        bt._generate_dirs()
+        bt._generate_mfiles(regen=True)
+        assert (bt._beam_all is not None) == (tag == "all")
+        out[tag] = [bt.beam_m(mi) for mi in range(tel.mmax + 1)]
+    assert len(out["all"]) > 11
+    for a, b in zip(out["all"], out["ranges"]):
+        assert np.array_equal(a, b)
