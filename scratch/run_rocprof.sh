@@ -1,11 +1,11 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/prof_r01i
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r01i -o bench -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/prof_r01i/bench_stdout.json 2> gpurun_out/prof_r01i/stderr.txt
-ls -R gpurun_out/prof_r01i | head -30
-f=$(find gpurun_out/prof_r01i -name "*kernel_stats.csv" | head -1)
+mkdir -p gpurun_out/prof_${TAG:-r01x}
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG:-r01x} -o bench -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/prof_${TAG:-r01x}/bench_stdout.json 2> gpurun_out/prof_${TAG:-r01x}/stderr.txt
+ls -R gpurun_out/prof_${TAG:-r01x} | head -30
+f=$(find gpurun_out/prof_${TAG:-r01x} -name "*kernel_stats.csv" | head -1)
 echo "STATS FILE $f"
 head -12 "$f" | cut -c1-150
 # keep only the small summaries (the raw trace is large)
-find gpurun_out/prof_r01i -name "*kernel_trace.csv" -size +20M -delete
+find gpurun_out/prof_${TAG:-r01x} -name "*kernel_trace.csv" -size +20M -delete
