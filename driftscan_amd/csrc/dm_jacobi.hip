@@ -27,6 +27,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 
 namespace {
@@ -653,7 +655,22 @@ void plan_rounds(const std::vector<int>& nrows, F make_item, round_plan& plan) {
 // one-sided driver
 // ===========================================================================
 int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double* sigma, int sigma_stride,
-                   int* sweeps_out) {
+                   int* sweeps_out, const dm_jac_rows_opts* opts) {
+  dm_jac_rows_opts O = opts ? *opts : dm_jac_rows_opts();
+  if (getenv("DM_JAC_MEASURE")) O.unconverged = false;   // debugging switches
+  if (getenv("DM_JAC_NO_DROP")) O.drop_below = 0.0;
+  const bool full_gram = getenv("DM_JAC_FULL_GRAM") != nullptr;
+  // DM_DEBUG: wall-clock of the phases of this call (synchronises at every mark)
+  const bool dbg_t = getenv("DM_DEBUG") != nullptr;
+  const bool dbg_sync = getenv("DM_DEBUG_NOSYNC") == nullptr;
+  auto dbg_now = [&]() { if (dbg_sync) (void)hipStreamSynchronize(ctx->stream); return std::chrono::steady_clock::now(); };
+  auto dbg_t0 = dbg_t ? dbg_now() : std::chrono::steady_clock::time_point();
+  auto dbg_mark = [&](const char* what) {
+    if (!dbg_t) return;
+    auto t1 = dbg_now();
+    fprintf(stderr, "[jacobi_rows]   %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - dbg_t0).count());
+    dbg_t0 = t1;
+  };
   const int np = (int)probs.size();
   if (sweeps_out) *sweeps_out = 0;
   if (np == 0) return DM_OK;
@@ -670,17 +687,21 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
   DM_ARG(ctx, maxrows <= sigma_stride);
 
   round_plan plan;
-  plan_rounds(nrows, [&](int p, int ba, int bb, int slot) {
-    const dm_jac_problem& P = probs[p];
-    jac_item it;
-    it.Z = P.Z; it.ld = P.ld;
-    it.ra = P.row0 + ba * JB; it.na = std::min(JB, P.nrows - ba * JB);
-    if (bb >= 0) { it.rb = P.row0 + bb * JB; it.nb = std::min(JB, P.nrows - bb * JB); }
-    else { it.rb = 0; it.nb = 0; }
-    it.c0 = 0; it.c1 = P.ncols; it.g0 = P.gc0; it.g1 = P.gc1;
-    it.prob = p; it.q = slot;
-    return it;
-  }, plan);
+  std::vector<int> nrows_eff(nrows);  // rows that take part in the sweeps (all of them unless drop_below cuts the tail)
+  auto build_plan = [&]() {
+    plan_rounds(nrows_eff, [&](int p, int ba, int bb, int slot) {
+      const dm_jac_problem& P = probs[p];
+      jac_item it;
+      it.Z = P.Z; it.ld = P.ld;
+      it.ra = P.row0 + ba * JB; it.na = std::min(JB, nrows_eff[p] - ba * JB);
+      if (bb >= 0) { it.rb = P.row0 + bb * JB; it.nb = std::min(JB, nrows_eff[p] - bb * JB); }
+      else { it.rb = 0; it.nb = 0; }
+      it.c0 = 0; it.c1 = P.ncols; it.g0 = P.gc0; it.g1 = P.gc1;
+      it.prob = p; it.q = slot;
+      return it;
+    }, plan);
+  };
+  build_plan();
 
   std::vector<jac_pdesc> pd(np);
   std::vector<size_t> toff(np);
@@ -722,14 +743,22 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
     hipLaunchKernelGGL(jac_floor_kernel, dim3(np), dim3(256), 0, ctx->stream, d_key, sigma_stride, d_nrows,
                        d_floor, e4 * e4);
   }
-  const double tol_outer = 1e-13, tol_inner = 1e-15;
-  const int nrounds = (int)plan.round_begin.size() - 1;
+  // Rows count as orthogonal at |cos| <= K u, K the length of the inner products and u the unit roundoff —
+  // the computed Gram entry of two exactly orthogonal rows is no smaller than that (LAPACK's zgesvj stops
+  // at the same level, TOL = CTOL * EPS with CTOL = M) — but never looser than 1e-13 (K <= 900).
+  int maxk = 0;
+  for (int p = 0; p < np; ++p) maxk = std::max(maxk, probs[p].gc1 - probs[p].gc0);
+  const double tol_outer = std::max(1e-13, maxk * 1.1102230246251565e-16), tol_inner = 1e-15;
+  int nrounds = (int)plan.round_begin.size() - 1;
   std::vector<unsigned long long> h_off(np);
   // Measuring pass (no rotations): problems whose rows are already orthogonal to tolerance — the
   // pseudo-inverse pass of an unpolarised telescope sees exactly the rows the previous pass
   // produced — skip the preconditioner and the sweeps.  (Re-diagonalising their Gram matrix would
   // even hurt: it is only accurate to eps sigma_1^2 and disturbs the small rows.)
-  {
+  if (O.unconverged) {
+    for (int p = 0; p < np; ++p) active[p] = nrows[p] > 1 ? 1 : 0;
+    DM_TRY(dm_upload(ctx, d_active, active.data(), sizeof(int) * np));
+  } else {
     DM_HIP(ctx, hipMemsetAsync(d_off, 0, sizeof(unsigned long long) * np, ctx->stream));
     for (int r = 0; r < nrounds; ++r) {
       const int nb = plan.round_begin[r], ni = plan.round_begin[r + 1] - nb;
@@ -748,6 +777,7 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
     }
     DM_TRY(dm_upload(ctx, d_active, active.data(), sizeof(int) * np));
   }
+  dbg_mark("setup + measuring pass");
   // Preconditioner: one Hermitian eigendecomposition of the full Gram matrix G = X X^H of every
   // (still active) problem (batched tridiagonal solver) followed by Z <- W Z.  On its own this would only be
   // accurate to eps ||X||^2 (the Gram squares the condition number), but it brings every pair of
@@ -841,19 +871,18 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
         const int ns = P.nrows - sub0[p];
         if (!lvl_on[p] || ns < 1) continue;
         const cplx* X = P.Z + (size_t)(P.row0 + sub0[p]) * P.ld + P.gc0;
-        g.push_back(dm_gemm_make(X, P.ld, 1, false, X, 1, P.ld, true, Gm + goff[p], ns, ns, ns, P.gc1 - P.gc0));
+        // the eigensolver reads the upper triangle only (LAPACK's uplo = 'U'): half of the Gram product
+        g.push_back(dm_gemm_make(X, P.ld, 1, false, X, 1, P.ld, true, Gm + goff[p], ns, ns, ns, P.gc1 - P.gc0, 1.0, 0.0,
+                                 nullptr, full_gram ? 0 : DM_GEMM_UPPER));
         hp.push_back(dm_jac_herm_problem{Gm + goff[p], ns, Wm + goff[p], ns, ns});
         who.push_back(p);
       }
       if (hp.empty()) break;
       DM_TRY(dm_gemm_grouped_launch(ctx, g));
-      {
-        std::vector<dm_mat> hm;
-        for (auto& h : hp) hm.push_back(dm_mat{h.C, h.ldc, h.n});
-        DM_TRY(dm_hermitize_batched(ctx, hm));
-      }
       // evals land at consecutive strides of the *compacted* problem list
+      dbg_mark("level: cleaning + Gram");
       DM_TRY(dm_herm_eig_tridiag(ctx, hp, evp, sigma_stride));
+      dbg_mark("level: eigensolver");
       std::vector<dm_jac_problem> sp;
       for (auto& h : hp) sp.push_back(dm_jac_problem{h.W, h.ldw, 0, h.n, h.n, 0, 0});
       DM_TRY(dm_sort_rows_by_key(ctx, sp, evp, sigma_stride, true));  // largest eigenvalue first
@@ -883,6 +912,7 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
       hipLaunchKernelGGL(jac_scatter_back_kernel, dim3(gx0, subrows, (unsigned)pda.size()), dim3(256), 0, ctx->stream,
                          d_pda, d_tmp, d_toffa);
       DM_HIP(ctx, hipGetLastError());
+      dbg_mark("level: sort + W Z");
       if (level + 1 == max_levels) break;
       // next level: the rows whose Gram eigenvalue fell below 1e-9 of this level's largest (sigma below
       // 3e-5 of it: a margin of three decades above what this level resolves, and the bound on the block
@@ -904,6 +934,7 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
         // to one pair of blocks the inner Jacobi solver sorts them out in LDS anyway (config 2: T = 92 rows)
         if (ns - i <= 2 * JP || i == 0) continue;
         if (1e-9 * ev[0] <= e4 * e4 * ev0[p]) continue;  // what is left is rounding residue of the largest rows
+        if (O.drop_below > 0.0 && ev[i] <= O.drop_below * O.drop_below * ev0[p] * 1e-2) continue;  // nobody wants them
         sub0[p] += i;
         lvl_on[p] = 1;
         more = true;
@@ -919,6 +950,32 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
     }
   }
 
+  dbg_mark("level: W Z + rest");
+  if (O.drop_below > 0.0) {
+    // rows below the caller's level of interest leave the tournament (they sit at the end: the levels are
+    // ordered by scale and sorted inside)
+    hipLaunchKernelGGL(jac_rownorm_kernel, dim3((maxrows + 3) / 4, np), dim3(256), 0, ctx->stream, d_pd, d_key,
+                       sigma_stride, maxrows);
+    std::vector<double> hk((size_t)np * sigma_stride);
+    DM_TRY(dm_download(ctx, hk.data(), d_key, sizeof(double) * hk.size()));
+    bool changed = false;
+    for (int p = 0; p < np; ++p) {
+      const double* kp = &hk[(size_t)p * sigma_stride];
+      double mx = 0.0;
+      for (int i = 0; i < nrows[p]; ++i) mx = std::max(mx, kp[i]);
+      int last = -1;
+      for (int i = 0; i < nrows[p]; ++i)
+        if (kp[i] >= O.drop_below * mx) last = i;
+      const int ne = std::max(std::min(nrows[p], 1), last + 1);
+      if (ne != nrows_eff[p]) { nrows_eff[p] = ne; changed = true; }
+    }
+    if (changed) {
+      build_plan();  // never more items per round than the plan the buffers were sized for
+      nrounds = (int)plan.round_begin.size() - 1;
+      d_items = dm_ws_upload(ctx, plan.items);
+      if (!d_items) return DM_ENOMEM;
+    }
+  }
   const int chunks = (maxcols + APPLY_CHUNK - 1) / APPLY_CHUNK;
   int sweep = 0;
   const int max_sweeps = 40;
@@ -955,7 +1012,9 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
       double mo;
       std::memcpy(&mo, &h_off[p], sizeof(double));
       dbg_max = std::max(dbg_max, mo);
-      active[p] = (active[p] && mo > tol_outer) ? 1 : 0;
+      // A sweep that met nothing above 1e-9 leaves nothing above ~n 1e-18 behind (the rotations of a sweep
+      // disturb each other only to second order): the problem is done without a sweep that merely confirms it.
+      active[p] = (active[p] && mo > std::max(tol_outer, 1e-9)) ? 1 : 0;
       any |= active[p] != 0;
     }
     if (getenv("DM_DEBUG")) {
@@ -970,6 +1029,7 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
   }
   if (sweeps_out) *sweeps_out = sweep;
 
+  dbg_mark("sweeps");
   // sort rows by descending norm over the Gram columns
   hipLaunchKernelGGL(jac_rownorm_kernel, dim3((maxrows + 3) / 4, np), dim3(256), 0, ctx->stream, d_pd, d_key,
                      sigma_stride, maxrows);
@@ -982,6 +1042,7 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
                      d_toff);
   DM_HIP(ctx, hipGetLastError());
   DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  dbg_mark("final sort");
   dm_ws_release(ctx, mark);
   return DM_OK;
 }

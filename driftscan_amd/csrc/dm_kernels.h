@@ -74,8 +74,17 @@ struct dm_jac_problem {
 // norms over the Gram columns, rows sorted by descending norm (rows physically
 // permuted).  `sigma` is a device array with `sigma_stride` doubles per problem.
 // Synchronises the stream (sweep control needs the convergence flags).
+// Options: `unconverged` — the caller knows the rows are not orthogonal yet, the measuring pass is skipped;
+// `drop_below` — rows whose norm ends up below drop_below * (largest row norm) after the preconditioner are
+// of no interest to the caller (SVD1 discards everything under 1e-10 sigma_0, beamtransfer.py:826): they are
+// kept out of the sweeps and of the deeper preconditioner levels (their norms are still reported; by Weyl's
+// inequality leaving them out moves the other singular values by at most their Frobenius norm).
+struct dm_jac_rows_opts {
+  bool unconverged = false;
+  double drop_below = 0.0;
+};
 int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double* sigma, int sigma_stride,
-                   int* sweeps_out = nullptr);
+                   int* sweeps_out = nullptr, const dm_jac_rows_opts* opts = nullptr);
 
 // Diagonalise Hermitian matrices (two-sided): C <- W C W^H (diagonal), with the
 // unitary W (rows) accumulated into `W` (nrows x nrows, row-major, ld = ldw),

@@ -137,7 +137,11 @@ extern "C" int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, c
     // ---- phase 1: SVD1, image with rtol 1e-10 (beamtransfer.py:826, :98)
     std::vector<dm_jac_problem> pr(nch);
     for (int c = 0; c < nch; ++c) pr[c] = dm_jac_problem{Z + (size_t)c * T * ldz, ldz, 0, T, ldz, 0, PL};
-    DM_TRY(dm_jacobi_rows(ctx, pr, sig, T, &sw));
+    // SVD1 keeps s > 1e-10 s_0 (beamtransfer.py:826): rows two decades further down are left out of the sweeps
+    dm_jac_rows_opts o1;
+    o1.unconverged = true;
+    o1.drop_below = 1e-12;
+    DM_TRY(dm_jacobi_rows(ctx, pr, sig, T, &sw, &o1));
     if (sweeps_host) sweeps_host[0] = sw;
     DM_TRY(dm_download(ctx, hs.data(), sig, sizeof(double) * hs.size()));
     for (int c = 0; c < nch; ++c) {
@@ -163,7 +167,9 @@ extern "C" int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, c
     }
     // ---- phase 2: SVD2, left null space of the polarised columns, `>=` cut (:844-848, :137)
     for (int c = 0; c < nch; ++c) pr[c] = dm_jac_problem{Z + (size_t)c * T * ldz, ldz, 0, r1[c], ldz, L, PL};
-    DM_TRY(dm_jacobi_rows(ctx, pr, sig, T, &sw));
+    dm_jac_rows_opts o2;
+    o2.unconverged = true;
+    DM_TRY(dm_jacobi_rows(ctx, pr, sig, T, &sw, &o2));
     if (sweeps_host) sweeps_host[1] = sw;
     DM_TRY(dm_download(ctx, hs.data(), sig, sizeof(double) * hs.size()));
     for (int c = 0; c < nch; ++c) {
@@ -186,7 +192,11 @@ extern "C" int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, c
       nrow3[c] = alive[c] ? std::max(0, r1[c] - cut2[c]) : 0;
       pr[c] = dm_jac_problem{Z + (size_t)c * T * ldz, ldz, row0[c], nrow3[c], ldz, 0, L};
     }
-    DM_TRY(dm_jacobi_rows(ctx, pr, sig, T, &sw));
+    // polarised: certainly not orthogonal yet.  Unpolarised: the measuring pass is kept, it retires the
+    // all-zero and trivially orthogonal blocks of the high m (a fifth of config 2) before the eigensolver.
+    dm_jac_rows_opts o3;
+    o3.unconverged = P > 1;
+    DM_TRY(dm_jacobi_rows(ctx, pr, sig, T, &sw, &o3));
     if (sweeps_host) sweeps_host[2] = sw;
     DM_TRY(dm_download(ctx, hs.data(), sig, sizeof(double) * hs.size()));
   }
@@ -233,7 +243,11 @@ extern "C" int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, c
       std::vector<dm_jac_problem> pr(nch);
       for (int c = 0; c < nch; ++c)
         pr[c] = dm_jac_problem{Z2 + (size_t)c * K * ld2, ld2, 0, nmodes[c], PL + nmodes[c], 0, PL};
-      DM_TRY(dm_jacobi_rows(ctx, pr, s4, K, &sw));
+      // unpolarised: these are exactly the rows SVD3 left orthogonal over the same columns (the measuring pass
+      // sees that and skips everything); polarised: orthogonal over the T columns only
+      dm_jac_rows_opts o4;
+      o4.unconverged = P > 1;
+      DM_TRY(dm_jacobi_rows(ctx, pr, s4, K, &sw, &o4));
       if (sweeps_host) sweeps_host[3] = sw;
       const double rtol = (double)std::max(PL, maxnm) * 2.220446049250313e-16;
       hipLaunchKernelGGL(svd_pinv_weights_kernel, dim3(nch), dim3(256), 0, ctx->stream, s4, d_nm, w4, K, rtol);
