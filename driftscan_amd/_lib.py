@@ -199,9 +199,12 @@ def _larr(a):
     return a, a.ctypes.data_as(ctypes.POINTER(c_i64))
 
 
-def _svd_chain(self, beam_m, noisew, polsvcut, skip_svd_inv=False):
+def _svd_chain(self, beam_m, noisew, polsvcut, skip_svd_inv=False, max_bytes=None):
     """beam_m: device (nblk, F, T, P, L) c128; noisew: device (F, T) f64.
-    Returns dict of device tensors + host nmodes (nblk, F) + sweeps[4]."""
+    Returns dict of device tensors + host nmodes (nblk, F) + sweeps[4].
+    The (m, frequency) chains are independent: when the working set of all of them (augmented matrices,
+    their row-mixing temporaries, Gram / eigenvector matrices and the eigensolver's workspace) exceeds
+    ``max_bytes`` (default: DRIFTMI_SVD_CHUNK_GB, 96) the frequencies go through the library in slices."""
     nblk, F, T, P, L = [int(x) for x in beam_m.shape]
     K = min(L, T)
     out = dict(
@@ -210,14 +213,37 @@ def _svd_chain(self, beam_m, noisew, polsvcut, skip_svd_inv=False):
         beam_ut=self.empty((nblk, F, K, T), np.complex128),
         singularvalues=self.empty((nblk, F, K), np.float64),
     )
-    nmodes = (c_int * max(nblk * F, 1))()
-    sweeps = (c_int * 4)()
-    rc = self.lib.dm_svd_chain(self.h, nblk, F, T, P, L, self.ptr(beam_m), self.ptr(noisew), float(polsvcut),
-                               self.ptr(out["beam_svd"]), self.ptr(out["invbeam_svd"]), self.ptr(out["beam_ut"]),
-                               self.ptr(out["singularvalues"]), nmodes, sweeps)
-    self.check(rc, "dm_svd_chain")
-    out["nmodes"] = np.array(nmodes[: nblk * F], dtype=np.int64).reshape(nblk, F)
-    out["sweeps"] = list(sweeps)
+    if max_bytes is None:
+        max_bytes = float(os.environ.get("DRIFTMI_SVD_CHUNK_GB", "96")) * (1 << 30)
+    per_chain = 16.0 * (2.0 * T * (P * L + T) + 16.0 * T * T)
+    fc = max(1, min(F, int(max_bytes // max(per_chain * max(nblk, 1), 1.0))))
+    nmodes_all = np.zeros((nblk, F), dtype=np.int64)
+    sweeps_all = [0, 0, 0, 0]
+    for f0 in range(0, F, fc):
+        f1 = min(F, f0 + fc)
+        whole = f0 == 0 and f1 == F
+        bm = beam_m if whole else beam_m[:, f0:f1].contiguous()
+        nw = noisew if whole else noisew[f0:f1].contiguous()
+        o = out if whole else dict(
+            beam_svd=self.empty((nblk, f1 - f0, K, P, L), np.complex128),
+            invbeam_svd=None if skip_svd_inv else self.empty((nblk, f1 - f0, P, L, K), np.complex128),
+            beam_ut=self.empty((nblk, f1 - f0, K, T), np.complex128),
+            singularvalues=self.empty((nblk, f1 - f0, K), np.float64))
+        nmodes = (c_int * max(nblk * (f1 - f0), 1))()
+        sweeps = (c_int * 4)()
+        rc = self.lib.dm_svd_chain(self.h, nblk, f1 - f0, T, P, L, self.ptr(bm), self.ptr(nw), float(polsvcut),
+                                   self.ptr(o["beam_svd"]), self.ptr(o["invbeam_svd"]), self.ptr(o["beam_ut"]),
+                                   self.ptr(o["singularvalues"]), nmodes, sweeps)
+        self.check(rc, "dm_svd_chain")
+        nmodes_all[:, f0:f1] = np.array(nmodes[: nblk * (f1 - f0)], dtype=np.int64).reshape(nblk, f1 - f0)
+        sweeps_all = [max(a, int(b)) for a, b in zip(sweeps_all, sweeps)]
+        if not whole:
+            for k in ("beam_svd", "invbeam_svd", "beam_ut", "singularvalues"):
+                if out[k] is not None:
+                    out[k][:, f0:f1].copy_(o[k])
+            del o, bm
+    out["nmodes"] = nmodes_all
+    out["sweeps"] = sweeps_all
     return out
 
 

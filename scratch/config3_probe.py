@@ -32,6 +32,11 @@ CFG3 = dict(num_freq=64, freq_start=400.0, freq_end=500.0, freq_mode="edge", num
             num_feeds=16, feed_spacing=0.4, tsys=1.0, force_lmax=512, force_mmax=512)
 
 
+# BASELINE configs[4]: CHIME-like stress case: 4 cylinders x 64 dual-pol feeds, 256 channels
+CFG5 = dict(num_freq=256, freq_start=400.0, freq_end=800.0, freq_mode="edge", num_cylinders=4, cylinder_width=14.5,
+            num_feeds=64, feed_spacing=0.3, tsys=1.0, force_lmax=1024, force_mmax=1024)
+
+
 def log(*a):
     print(time.strftime("%H:%M:%S"), *a, flush=True)
 
@@ -41,7 +46,13 @@ def main():
     ap.add_argument("--m", type=int, nargs="+", default=[100])
     ap.add_argument("--nm-bt", type=int, default=1, help="m-blocks per BT-gen call (timing of the m-dependent part)")
     ap.add_argument("--bt-gb", type=float, default=48.0, help="scratch budget of BT-gen (maps + ring DFT)")
-    ap.add_argument("--nfreq", type=int, default=64, help="reduce for a quick plumbing run")
+    ap.add_argument("--config", type=int, default=3, choices=[3, 5], help="BASELINE configs[2] (3) or configs[4] (5)")
+    ap.add_argument("--nfreq", type=int, default=0, help="reduce for a quick plumbing run (0 = the config's own)")
+    ap.add_argument("--workspace-gb", type=int, default=32)
+    ap.add_argument("--skip-pinv", action="store_true")
+    ap.add_argument("--kl-fresh-gb", type=int, default=0, help="before eigh_gen: drop every other device buffer and open a fresh "
+                    "context with a workspace of this many GB (configs[4]: n = 32 576 needs ~140 GB in one arena)")
+    ap.add_argument("--svd-once", action="store_true", help="time the first SVD call only (no separate allocator warm-up call)")
     ap.add_argument("--svd-batch", type=int, default=1, help="m-blocks [m0, m0 + n) pushed through the SVD chain in one call")
     ap.add_argument("--skip-kl", action="store_true")
     ap.add_argument("--checks", action="store_true", help="host-side property checks (downloads the products)")
@@ -52,11 +63,12 @@ def main():
 
     from driftscan_amd import beamtransfer, btgen, cylinder, device, kltransform
 
-    cfg = dict(CFG3)
-    cfg["num_freq"] = args.nfreq
+    cfg = dict(CFG3 if args.config == 3 else CFG5)
+    if args.nfreq:
+        cfg["num_freq"] = args.nfreq
     tel = cylinder.PolarisedCylinderTelescope.from_config(cfg)
     log("telescope: nfreq %d nbase %d ntel %d lmax %d mmax %d" % (tel.nfreq, tel.nbase, 2 * tel.nbase, tel.lmax, tel.mmax))
-    ctx = device.get_context(workspace_bytes=32 << 30)
+    ctx = device.get_context(workspace_bytes=args.workspace_gb << 30)
     res = dict(config=cfg, nbase=int(tel.nbase), lmax=int(tel.lmax), mmax=int(tel.mmax), blocks=[])
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
 
@@ -87,18 +99,20 @@ def main():
             # ---- SVD chain ---------------------------------------------------------------
             # first call: the workspace arena and torch's caching allocator grow to the size of this problem
             # (hipMalloc of tens of GB takes seconds); a pipeline pays that once per process, not per batch
-            sync()
-            t0 = time.perf_counter()
-            out = bt.svd_device(beam)
-            sync()
-            rec["svd_first_call_s"] = time.perf_counter() - t0
-            del out
             ctx.prof_reset(True)
             sync()
             t0 = time.perf_counter()
-            out = bt.svd_device(beam)
-            sv = out["singularvalues"].cpu().numpy()
+            out = bt.svd_device(beam, skip_svd_inv=args.skip_pinv)
             sync()
+            rec["svd_first_call_s"] = time.perf_counter() - t0
+            if not args.svd_once:
+                del out
+                ctx.prof_reset(True)
+                sync()
+                t0 = time.perf_counter()
+                out = bt.svd_device(beam, skip_svd_inv=args.skip_pinv)
+                sync()
+            sv = out["singularvalues"].cpu().numpy()
             rec["svd_s"] = time.perf_counter() - t0
             rec["svd_kernels_ms"] = {k: round(v["ms"], 1) for k, v in ctx.prof_report().items()}
             rec["svd_kernels_tflops"] = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in ctx.prof_report().items()
@@ -112,7 +126,7 @@ def main():
             log("m %d: SVD chain of %d block(s) %.2f s (first call, growing the arenas: %.2f s), ndof %d (modes per frequency %d..%d of %d)"
                 % (m0, rec["svd_blocks"], rec["svd_s"], rec["svd_first_call_s"], rec["ndof"], svnum.min(), svnum.max(),
                    sv.shape[-1]))
-            if args.checks:
+            if args.checks and not args.skip_pinv:
                 ut = out["beam_ut"][0].cpu().numpy()
                 bs = out["beam_svd"][0].cpu().numpy()
                 ib = out["invbeam_svd"][0].cpu().numpy()
@@ -157,6 +171,16 @@ def main():
                     n = int(ndofs[0])
                     Sh = S[: n * n].cpu().numpy().reshape(n, n)
                     Nh = N[: n * n].cpu().numpy().reshape(n, n)
+                if args.kl_fresh_gb:
+                    bt._dev.pop(m0, None)
+                    beamtransfer.BeamTransfer._clcache.clear()
+                    kl._cvsg = kl._cvfg = None
+                    torch.cuda.empty_cache()
+                    device.reset_context()
+                    ctx = device.get_context(workspace_bytes=args.kl_fresh_gb << 30)
+                    ctx.prof_reset(True)
+                    log("m %d: fresh context, workspace %d GB, torch holds %.1f GB" % (m0, args.kl_fresh_gb,
+                                                                                     torch.cuda.memory_allocated() / 2 ** 30))
                 t0 = time.perf_counter()
                 cut = ("upper", kl.threshold)
                 evals, evoff, evecs, ac, _ = ctx.eigh_gen(S, N, ndofs, off, cut=cut)
@@ -171,8 +195,12 @@ def main():
                     % (m0, rec["kl_eigh_s"], int(ndofs[0]), rec["kl_nkept"], rec["kl_add_const"]))
                 if args.checks and rec["kl_nkept"] > 0:
                     n, nk = int(ndofs[0]), rec["kl_nkept"]
-                    E = evecs[: n * n].view(n, n)[n - nk:].cpu().numpy()  # evals ascend: kept rows are the last nk
-                    lam = ev[n - nk:]
+                    pick = np.arange(n - nk, n)
+                    if nk > 256:  # a sample of the kept modes is enough at this size (the check is O(nk n^2) on the host)
+                        pick = np.unique(np.linspace(n - nk, n - 1, 256).astype(np.int64))
+                        nk = pick.size
+                    E = evecs[: n * n].view(n, n)[torch.as_tensor(pick, device=evecs.device)].cpu().numpy()  # evals ascend
+                    lam = ev[pick]
                     EN = E @ Nh @ E.conj().T
                     ES = E @ Sh @ E.conj().T
                     rec["check_ENE"] = float(np.abs(EN - np.eye(nk)).max())
