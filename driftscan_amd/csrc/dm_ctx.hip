@@ -1,5 +1,8 @@
 // dm_ctx.hip — context, workspace arena and host<->device staging for libdriftmi.
 #include "dm_common.h"
+
+#include <algorithm>
+#include <initializer_list>
 #include "dm_kernels.h"
 #include "../../include/driftmi.h"
 
@@ -9,37 +12,54 @@ constexpr size_t kPinned = 64u << 20;  // staging ring for descriptor uploads
 inline size_t align_up(size_t x) { return (x + kAlign - 1) & ~(kAlign - 1); }
 }  // namespace
 
-int dm_ws_reserve(dm_ctx* ctx, size_t bytes) {
-  bytes = align_up(bytes);
-  if (bytes <= ctx->ws_cap) return DM_OK;
+// Replace the arena by one of at least `bytes` (preferably `prefer`).  Live allocations of the old arena
+// stay valid: it is retired, not freed, until the outermost mark is released.
+static int ws_grow(dm_ctx* ctx, size_t prefer, size_t bytes) {
   // growing: kernels in flight may still use the old arena -> drain first
   DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->ws_used == 0 && ctx->ws) {
     (void)hipFree(ctx->ws);
     ctx->ws = nullptr;
-  } else if (ctx->ws) {
-    ctx->retired.push_back(ctx->ws);  // live allocations remain valid
+    ctx->ws_cap = 0;
   }
   void* p = nullptr;
-  hipError_t e = hipMalloc(&p, bytes);
+  hipError_t e = hipErrorOutOfMemory;
+  size_t got = 0;
+  // the preferred size doubles the arena (few growth steps); at hundreds of GB that may not exist while the
+  // old arena is still alive, so fall back to what is needed now
+  for (size_t want : {prefer, bytes + bytes / 8, bytes}) {
+    want = align_up(want);
+    if (want < bytes) continue;
+    e = hipMalloc(&p, want);
+    if (e == hipSuccess) { got = want; break; }
+    (void)hipGetLastError();
+    p = nullptr;
+  }
   if (e != hipSuccess) {
     ctx->err = std::string("hipMalloc workspace: ") + hipGetErrorString(e);
-    ctx->ws = nullptr;
-    ctx->ws_cap = 0;
-    return DM_ENOMEM;
+    return DM_ENOMEM;  // the old arena (if any) is untouched
   }
+  if (ctx->ws) ctx->retired.push_back(ctx->ws);  // live allocations remain valid
   ctx->ws = reinterpret_cast<char*>(p);
-  ctx->ws_cap = bytes;
+  ctx->ws_cap = got;
   ctx->ws_used = 0;
   return DM_OK;
+}
+
+int dm_ws_reserve(dm_ctx* ctx, size_t bytes) {
+  bytes = align_up(bytes);
+  if (bytes <= ctx->ws_cap) return DM_OK;
+  return ws_grow(ctx, bytes, bytes);
 }
 
 void* dm_ws_alloc(dm_ctx* ctx, size_t bytes) {
   bytes = align_up(bytes ? bytes : 1);
   if (ctx->ws_used + bytes > ctx->ws_cap) {
-    size_t want = ctx->ws_cap * 2 > ctx->ws_used + bytes ? ctx->ws_cap * 2 : (ctx->ws_used + bytes) * 2;
-    if (want < (256u << 20)) want = 256u << 20;
-    if (dm_ws_reserve(ctx, want) != DM_OK) return nullptr;
+    // the new arena starts empty (earlier allocations live on in the retired one): it has to hold this
+    // request, and preferably as much again as everything handed out so far
+    size_t prefer = std::max(ctx->ws_cap * 2, (ctx->ws_used + bytes) * 2);
+    if (prefer < (256u << 20)) prefer = 256u << 20;
+    if (ws_grow(ctx, prefer, bytes) != DM_OK) return nullptr;
   }
   void* p = ctx->ws + ctx->ws_used;
   ctx->ws_used += bytes;

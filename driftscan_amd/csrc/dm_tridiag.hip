@@ -1380,12 +1380,14 @@ __global__ void dc_tear_kernel(const dc_tear* __restrict__ ts, int nt) {
 // eigenvalues (unsorted) and zfinal[p] points at the eigenvector-major n x n eigenvector array.
 static int dc_solve(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, double* dd, double* ee,
                     const std::vector<size_t>& offn, const std::vector<size_t>& off, size_t tot, size_t totn,
-                    std::vector<double*>& zfinal) {
+                    std::vector<double*>& zfinal, double* scratch2 = nullptr) {
   const int np = (int)probs.size();
   double* ZA = dm_ws_alloc_t<double>(ctx, std::max<size_t>(tot, 1));
   double* ZB = dm_ws_alloc_t<double>(ctx, std::max<size_t>(tot, 1));
-  double* Zp = dm_ws_alloc_t<double>(ctx, std::max<size_t>(tot, 1));
-  double* Uw = dm_ws_alloc_t<double>(ctx, std::max<size_t>(tot, 1));
+  // gathered vectors and rank-one eigenvector blocks only live inside this function: the caller may lend
+  // 2 tot doubles it does not need yet (the T V^H buffer of the back-transformation)
+  double* Zp = scratch2 ? scratch2 : dm_ws_alloc_t<double>(ctx, std::max<size_t>(tot, 1));
+  double* Uw = scratch2 ? scratch2 + tot : dm_ws_alloc_t<double>(ctx, std::max<size_t>(tot, 1));
   double* lamB = dm_ws_alloc_t<double>(ctx, std::max<size_t>(totn, 1));
   double* dk = dm_ws_alloc_t<double>(ctx, std::max<size_t>(totn, 1));
   double* zk = dm_ws_alloc_t<double>(ctx, std::max<size_t>(totn, 1));
@@ -2062,7 +2064,9 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
 
   if (use_dc) {
     DM_TRY(phase_T1(chunks[0]));
-    DM_TRY(dc_solve(ctx, probs, dd, ee, offn, off, tot, totn, zfinal));
+    // Ut is first written by the back-transformation (unless the LDS-resident small path put Q there)
+    DM_TRY(dc_solve(ctx, probs, dd, ee, offn, off, tot, totn, zfinal,
+                    maxn > TSM ? reinterpret_cast<double*>(Ut) : nullptr));
     DM_TRY(phase_T34(0, false));
   } else if (nch == 1) {
     DM_TRY(phase_T1(chunks[0]));
