@@ -803,6 +803,8 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
     int max_levels = 4;
     if (const char* e = getenv("DM_JAC_PRECOND_LEVELS")) max_levels = std::max(0, std::min(6, atoi(e)));
     const bool clean = !getenv("DM_JAC_NO_CLEAN");
+    int level_min_rows = 2 * JP;
+    if (const char* e = getenv("DM_JAC_LEVEL_MIN_ROWS")) level_min_rows = std::max(1, atoi(e));
     for (int level = 0; level < max_levels; ++level) {
       if (level > 0 && clean) {
         // The rows of this level still carry components along the rows above them (A) of absolute size
@@ -932,7 +934,7 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
         const double e4 = 4.0 * 2.220446049250313e-16;
         // worth a level only when the rows below span several row blocks: a sweep costs ~(row blocks)^2, and up
         // to one pair of blocks the inner Jacobi solver sorts them out in LDS anyway (config 2: T = 92 rows)
-        if (ns - i <= 2 * JP || i == 0) continue;
+        if (ns - i <= level_min_rows || i == 0) continue;
         if (1e-9 * ev[0] <= e4 * e4 * ev0[p]) continue;  // what is left is rounding residue of the largest rows
         if (O.drop_below > 0.0 && ev[i] <= O.drop_below * O.drop_below * ev0[p] * 1e-2) continue;  // nobody wants them
         sub0[p] += i;
