@@ -11,6 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIBPATH = os.path.join(_HERE, "lib", "libdriftmi.so")
+if os.environ.get("DRIFTMI_LIB"):  # a differently built libdriftmi.so (kernel tuning experiments)
+    LIBPATH = os.environ["DRIFTMI_LIB"]
 
 c_int = ctypes.c_int
 c_i64 = ctypes.c_int64

@@ -68,9 +68,15 @@ struct trd_mat {
 //
 // HBM traffic per column: (n-k)^2/2 matrix elements + one pass over the panel (the zlatrd scheme
 // reads the full square and the panel twice).
-constexpr int SYR = 4;     // rows per wave in trd_symv
+#ifndef DM_SYR
+#define DM_SYR 4
+#endif
+#ifndef DM_SYC
+#define DM_SYC 2
+#endif
+constexpr int SYR = DM_SYR;     // rows per wave in trd_symv
 constexpr int SYG = 4 * SYR;  // rows per workgroup = rows behind one partial row of Pc
-constexpr int SYC = 2;        // 64-column chunks per loop iteration of trd_symv
+constexpr int SYC = DM_SYC;        // 64-column chunks per loop iteration of trd_symv
 constexpr int WXR = 64;    // rows per workgroup in trd_wx
 
 struct trd_refl { cplx tau, scal; double beta; };
