@@ -24,7 +24,10 @@ class DoubleKL(kltransform.KLTransform):
         # ---- stage 1: S vs F (use_thermal = False, doublekl.py:44-52)
         self.use_thermal = False
         S, N, ndofs, off = self.sn_covariance_device(ms)
-        ev1, evoff1, E1, ac1, _ = ctx.eigh_gen(S, N, ndofs, off)
+        # only the modes with S/F strictly above the threshold are used below (doublekl.py:56-60): the others
+        # are not back-transformed (their rows of E1 stay zero); all eigenvalues are returned either way
+        ev1, evoff1, E1, ac1, _ = ctx.eigh_gen(S, N, ndofs, off,
+                                               cut=("upper", float(np.nextafter(self.foreground_threshold, np.inf))))
         ev1_h = ev1.cpu().numpy()
         f_evals = [ev1_h[evoff1[i] : evoff1[i] + int(ndofs[i])].copy() for i in range(nb)]
         # modes with S/F above the threshold: eigenvalues ascend, so they are the trailing rows

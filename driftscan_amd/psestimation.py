@@ -137,6 +137,7 @@ class PSEstimation(config.Reader):
 
     def delbands(self):
         self.clarray = None
+        self.__dict__.pop("_cl_dev", None)
 
     # ---- per-m Fisher ----------------------------------------------------------------------------
     def fisher_bias_m(self, mi):
@@ -260,7 +261,12 @@ class PSExact(PSEstimation):
             Eh[eoff[i] : eoff[i] + nmodes[i] * ndofs[i]] = np.ascontiguousarray(E).ravel()
             Vh[voff[i] : voff[i] + nmodes[i]] = ev
         # (nbands, L, F, F) -> (nbands, F, F, L): the contraction index innermost, as dm_project_cov reads it
-        cl = ctx.to_device(np.ascontiguousarray(np.asarray(self.clarray, dtype=np.float64).transpose(0, 2, 3, 1)))
+        cache = self.__dict__.get("_cl_dev")
+        if cache is None or cache[0] is not self.clarray or cache[1].device.index != ctx.device:
+            cache = (self.clarray,
+                     ctx.to_device(np.ascontiguousarray(np.asarray(self.clarray, dtype=np.float64).transpose(0, 2, 3, 1))))
+            self.__dict__["_cl_dev"] = cache  # the band tables do not change between batches (151 MB at config 3)
+        cl = cache[1]
         F = ctx.fisher(bsvd, svnum, np.array(ms), cl, ctx.to_device(Eh), eoff, nmodes, ctx.to_device(Vh), voff)
         Fh = F.cpu().numpy()
         return [(Fh[i], np.zeros(nb, dtype=np.complex128)) if nmodes[i] > 0 else zero for i in range(len(ms))]

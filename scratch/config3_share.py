@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--bt-calls", type=int, default=3, help="BT-gen calls for the rank's contiguous range of m")
     ap.add_argument("--bt-gb", type=float, default=48.0)
     ap.add_argument("--workspace-gb", type=int, default=80)
+    ap.add_argument("--config4", action="store_true", help="BASELINE configs[3]: add the DoubleKL filter and the exact Fisher "
+                    "matrix (PSExact, analytic stand-in bands) of every sampled block")
     ap.add_argument("--limit-groups", type=int, default=0, help="stop after this many groups (0 = the whole share)")
     ap.add_argument("--out", default="gpurun_out/config3_share.json")
     args = ap.parse_args()
@@ -69,6 +71,18 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         bt = beamtransfer.BeamTransfer(tmp, telescope=tel)
         kl = kltransform.KLTransform.from_config(dict(threshold=0.1), bt, subdir="kl")
+        dk = ps = None
+        tdk = tps = 0.0
+        if args.config4:
+            from driftscan_amd import doublekl, psestimation
+
+            dk = doublekl.DoubleKL.from_config(dict(threshold=0.1, foreground_threshold=100.0), bt, subdir="dk")
+            dk._cvsg, dk._cvfg = None, None
+            ps = psestimation.PSExact.from_config(
+                dict(bandtype="polar", num_theta=3, threshold=0.1,
+                     k_bands=[dict(spacing="linear", start=0.0, stop=0.25, num=4)]), kl, subdir="ps")
+            ps.genbands()
+            log("config 4: DoubleKL (foreground_threshold 100) + PSExact with %d bands" % ps.nbands)
         t0 = time.perf_counter()
         kl.signal(); kl.foreground()
         bt._cl_device(kl.signal()); bt._cl_device(kl.foreground())
@@ -119,27 +133,61 @@ def main():
             sync()
             t3 = time.perf_counter()
             nk = int(ctx.last_nkeep.sum()) if hasattr(ctx, "last_nkeep") else None
+            out_keep = out if args.config4 else None
             del out, prods
             for mi in ms:
                 bt._dev.pop(mi, None)
+            t_dk = t_ps = 0.0
+            if args.config4:
+                # DoubleKL of the same blocks (two generalised eigenproblems + re-projections; modes go to the host)
+                for mi in ms:
+                    bt._dev[mi] = dict(beam_svd=out_keep["beam_svd"][mi - m_lo], beam_ut=out_keep["beam_ut"][mi - m_lo],
+                                       singularvalues=sv[mi - m_lo])
+                sync()
+                t4 = time.perf_counter()
+                for batch in dk._batches(ms):
+                    dk._transform_batch(batch)
+                sync()
+                t_dk = time.perf_counter() - t4
+                # exact Fisher matrix of the KL-filtered modes: the KL products are written as the pipeline does
+                # (untimed), PSExact reads the modes back and projects every band
+                for batch in kl._batches(ms):
+                    for mi, r in zip(batch, kl._transform_batch(batch)):
+                        kl._save(mi, *r)
+                sync()
+                t5 = time.perf_counter()
+                for batch in ps._batches(ms):
+                    ps.fisher_bias_batch(batch)
+                sync()
+                t_ps = time.perf_counter() - t5
+                for mi in ms:
+                    bt._dev.pop(mi, None)
+                    try:
+                        os.remove(kl._evfile % mi)
+                    except OSError:
+                        pass
+                del out_keep
             if warm:
                 warm = False
                 log("m %3d..%3d warm-up pass (allocators): SVD %.2f s, KL %.2f s" % (m_lo, m_hi, t2 - t1, t3 - t2))
                 continue
-            rec = dict(m_lo=m_lo, m_hi=m_hi, btgen_s=t1 - t0, svd_s=t2 - t1, kl_s=t3 - t2, ndof=ndofs, kept_last_batch=nk)
+            tdk += t_dk; tps += t_ps
+            rec = dict(m_lo=m_lo, m_hi=m_hi, btgen_s=t1 - t0, svd_s=t2 - t1, kl_s=t3 - t2, ndof=ndofs, kept_last_batch=nk,
+                       doublekl_s=t_dk, fisher_s=t_ps)
             res["groups"].append(rec)
             ts += t2 - t1; tk += t3 - t2
             nblk += len(ms)
-            log("m %3d..%3d: (input generation %.2f s, not part of the share) SVD %.2f s, KL %.2f s, ndof %d..%d"
-                % (m_lo, m_hi, t1 - t0, t2 - t1, t3 - t2, min(ndofs), max(ndofs)))
+            log("m %3d..%3d: (input generation %.2f s, not part of the share) SVD %.2f s, KL %.2f s%s, ndof %d..%d"
+                % (m_lo, m_hi, t1 - t0, t2 - t1, t3 - t2,
+                   (", DoubleKL %.2f s, Fisher %.2f s" % (t_dk, t_ps)) if args.config4 else "", min(ndofs), max(ndofs)))
             res["totals"] = dict(blocks=nblk, btgen_s=tb, svd_s=ts, kl_s=tk)
             json.dump(res, open(args.out, "w"), indent=1)
-        wall = tb + (ts + tk) * share / max(nblk, 1)   # BT-gen of 65 contiguous blocks + SVD/KL scaled from the sample to 65
+        wall = tb + (ts + tk + tdk + tps) * share / max(nblk, 1)   # BT-gen of 65 contiguous blocks + the rest scaled from the sample to 65
         pr = ctx.prof_report()
         res["kernels_ms"] = {k: v["ms"] for k, v in pr.items()}
         res["kernels_tflops"] = {k: (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else None) for k, v in pr.items()
                                  if k not in ("trd_symv", "trd_wx")}
-        res["totals"] = dict(svd_kl_blocks=nblk, btgen_blocks=share, btgen_s=tb, svd_s=ts, kl_s=tk,
+        res["totals"] = dict(svd_kl_blocks=nblk, btgen_blocks=share, btgen_s=tb, svd_s=ts, kl_s=tk, doublekl_s=tdk, fisher_s=tps,
                              projected_job_s=wall, m_blocks_per_s_per_gpu=share / wall,
                              m_blocks_per_s_8gpu=nm_total / wall,
                              projected_job_note="%d blocks per GPU on %d GPUs, compute only (products left in HBM): BT-gen "
@@ -148,8 +196,10 @@ def main():
         res["hbm_peak_gb"] = torch.cuda.max_memory_allocated() / 2 ** 30
         res["workspace_gb"] = ctx.lib.dm_ctx_workspace_bytes(ctx.h) / 2 ** 30
         json.dump(res, open(args.out, "w"), indent=1)
-        log("share done: BT-gen of %d blocks %.1f s; SVD %.1f s + KL %.1f s on %d blocks -> projected 8-GPU job %.0f s "
-            "(%.2f m-blocks/s per GPU)" % (share, tb, ts, tk, nblk, wall, share / wall))
+        log("share done: BT-gen of %d blocks %.1f s; SVD %.1f s + KL %.1f s%s on %d blocks -> projected 8-GPU job %.0f s "
+            "(%.2f m-blocks/s per GPU)" % (share, tb, ts, tk,
+                                           (" + DoubleKL %.1f s + Fisher %.1f s" % (tdk, tps)) if args.config4 else "",
+                                           nblk, wall, share / wall))
 
 
 if __name__ == "__main__":
