@@ -685,6 +685,10 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
     maxcols = std::max(maxcols, probs[p].ncols);
   }
   DM_ARG(ctx, maxrows <= sigma_stride);
+  if (maxrows == 0) {  // nothing to orthogonalise anywhere (e.g. every row of every block was cut by the caller)
+    dm_ws_release(ctx, mark);
+    return DM_OK;
+  }
 
   round_plan plan;
   std::vector<int> nrows_eff(nrows);  // rows that take part in the sweeps (all of them unless drop_below cuts the tail)

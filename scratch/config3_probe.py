@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--nfreq", type=int, default=0, help="reduce for a quick plumbing run (0 = the config's own)")
     ap.add_argument("--workspace-gb", type=int, default=32)
     ap.add_argument("--skip-pinv", action="store_true")
+    ap.add_argument("--lapack", action="store_true", help="with --checks: scipy.linalg.eigh(S, N) on the host for the same "
+                    "pencil — its eigenvalues and ITS residual E N E^H - I, the yardstick for ours")
     ap.add_argument("--kl-fresh-gb", type=int, default=0, help="before eigh_gen: drop every other device buffer and open a fresh "
                     "context with a workspace of this many GB (configs[4]: n = 32 576 needs ~140 GB in one arena)")
     ap.add_argument("--svd-once", action="store_true", help="time the first SVD call only (no separate allocator warm-up call)")
@@ -134,6 +136,8 @@ def main():
                 noisew = bt._noisew()
                 for fi in range(0, tel.nfreq, max(1, tel.nfreq // 4)):
                     n = int(svnum[fi])                      # modes above svcut (kappa <= 1/svcut)
+                    if n == 0:
+                        continue
                     u = ut[fi, :n] / noisew[fi][None, :]     # beam_ut = ut * noisew (beamtransfer.py:877)
                     worst_u = max(worst_u, float(np.abs(u @ u.conj().T - np.eye(n)).max()))
                     b2 = bs[fi, :n].reshape(n, -1)
@@ -146,7 +150,7 @@ def main():
             torch.cuda.empty_cache()
             json.dump(res | dict(blocks=res["blocks"] + [rec]), open(args.out, "w"), indent=1)
             # ---- KL ----------------------------------------------------------------------
-            if not args.skip_kl:
+            if not args.skip_kl and rec["ndof"] > 0:
                 ctx.prof_reset(True)
                 sync()
                 t0 = time.perf_counter()
@@ -208,6 +212,19 @@ def main():
                     rec["check_ESE_diag"] = float(np.abs(np.sort(np.diag(ES).real) - np.sort(lam)).max() / np.abs(lam).max())
                     log("m %d: |E N E^H - I| %.2e, offdiag(E S E^H)/max %.2e, diag vs lambda %.2e"
                         % (m0, rec["check_ENE"], rec["check_ESE_offdiag"], rec["check_ESE_diag"]))
+                    if args.lapack:
+                        import scipy.linalg as la
+
+                        t0 = time.perf_counter()
+                        lev, lV = la.eigh(Sh, Nh)
+                        rec["lapack_s"] = time.perf_counter() - t0
+                        lE = lV.T.conj()[pick]
+                        rec["lapack_ENE"] = float(np.abs(lE @ Nh @ lE.conj().T - np.eye(nk)).max())
+                        rec["evals_vs_lapack"] = float(np.abs(ev - lev).max() / np.abs(lev).max())
+                        rec["cond_N"] = float(np.linalg.cond(Nh))
+                        log("m %d: LAPACK zhegvd on the host (%.0f s): ITS |E N E^H - I| %.2e; eigenvalues ours vs LAPACK %.2e "
+                            "of lambda_max; cond(N) %.2e" % (m0, rec["lapack_s"], rec["lapack_ENE"], rec["evals_vs_lapack"],
+                                                             rec["cond_N"]))
                 del S, N, evecs
                 torch.cuda.empty_cache()
             rec["hbm_peak_gb"] = torch.cuda.max_memory_allocated() / 2 ** 30

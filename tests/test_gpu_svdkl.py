@@ -225,3 +225,30 @@ def test_svd_chain_frequency_slices(ctx, gold):
             gb = np.einsum("bfkpl,bfkpl->bfk", b.conj(), b).real
             assert np.abs(ga - gb).max() <= 1e-10 * ga.max()
         assert a.shape == b.shape
+
+
+@pytest.mark.parametrize("P", [1, 4])
+def test_svd_chain_degenerate_blocks(ctx, P):
+    """All-zero blocks and blocks with a single non-zero multipole (m = lmax of a polarised telescope: every
+    row is cut after SVD1 / SVD2): datasets stay blank as in the reference (beamtransfer.py:855-872)."""
+    from oracle import svdchain as osvd
+
+    rng = np.random.default_rng(3)
+    F, B, L = 2, 10, 12
+    T = 2 * B
+    beam = np.zeros((2, F, T, P, L), dtype=np.complex128)     # block 0: zeros; block 1: only l = L - 1
+    beam[1, :, :, :, L - 1] = rng.standard_normal((F, T, P)) + 1j * rng.standard_normal((F, T, P))
+    npower = rng.uniform(0.5, 2.0, (F, B))
+    nw = np.concatenate([npower, npower], axis=1) ** -0.5
+    for blocks in (beam[:1], beam):
+        res = ctx.svd_chain(ctx.to_device(blocks), ctx.to_device(nw), 1e-4)
+        sv = res["singularvalues"].cpu().numpy()
+        for b in range(blocks.shape[0]):
+            ref = osvd.svd_m(blocks[b].reshape(F, 2, B, P, L), npower ** -0.5, polsvcut=1e-4)
+            # `nmodes` counts s > 0.0 (rtol = 0, beamtransfer.py:863): for the rank-one block that is a count of
+            # rounding residues, in LAPACK as here; what is defined is the spectrum and the count above svcut
+            assert_spectrum(sv[b], ref["singularvalues"], 1e-10, "degenerate block %d" % b)
+            assert (osvd.svd_num(sv[b], 1e-6)[0] == osvd.svd_num(ref["singularvalues"], 1e-6)[0]).all()
+            if not blocks[b].any():
+                assert (res["nmodes"][b] == 0).all() and (ref["nmodes"] == 0).all()
+        assert np.abs(res["beam_svd"].cpu().numpy()[0]).max() == 0.0
