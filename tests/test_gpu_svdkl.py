@@ -252,3 +252,39 @@ def test_svd_chain_degenerate_blocks(ctx, P):
             if not blocks[b].any():
                 assert (res["nmodes"][b] == 0).all() and (ref["nmodes"] == 0).all()
         assert np.abs(res["beam_svd"].cpu().numpy()[0]).max() == 0.0
+
+
+def test_empty_kl_batches(ctx):
+    """Batches whose blocks all have ndof = 0 (the highest m of a polarised telescope keep no mode): every entry
+    point returns without launching anything (kltransform.py:322-331, the nside == 0 early-out)."""
+    from driftscan_amd._lib import block_offsets
+
+    ndofs = np.array([0, 0], dtype=np.int64)
+    off, tot = block_offsets(ndofs)
+    assert tot == 0
+    S = ctx.empty((1,), np.complex128)
+    N = ctx.empty((1,), np.complex128)
+    ctx.regularise(N, ndofs, off, 1e-14)
+    for cut in (None, ("upper", 0.1)):
+        evals, evoff, evecs, ac, _ = ctx.eigh_gen(S, N, ndofs, off, cut=cut)
+        assert list(evoff) == [0, 0, 0] and (ac == 0).all()
+    # mixed: an empty block between two real ones
+    rng = np.random.default_rng(0)
+    ns = [5, 0, 7]
+    off, tot = block_offsets(ns)
+    As, Bs = [], []
+    for n in ns:
+        X = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        Y = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        As.append(X @ X.conj().T)
+        Bs.append(Y @ Y.conj().T + n * np.eye(n))
+    A = np.concatenate([a.ravel() for a in As]) if tot else np.zeros(1, complex)
+    Bm = np.concatenate([b.ravel() for b in Bs])
+    evals, evoff, evecs, ac, _ = ctx.eigh_gen(ctx.to_device(A), ctx.to_device(Bm), ns, off)
+    import scipy.linalg as la
+
+    ev = evals.cpu().numpy()
+    for i, n in enumerate(ns):
+        if n:
+            ref = la.eigh(As[i], Bs[i], eigvals_only=True)
+            assert np.abs(ev[evoff[i]: evoff[i] + n] - ref).max() <= 1e-11 * ref.max()
