@@ -23,7 +23,8 @@ def get_context(workspace_bytes=None):
     if ctx is None:
         from ._lib import Context
 
-        dev = int(os.environ.get("LOCAL_RANK", "0"))
+        # one process per GPU: LOCAL_RANK picks it; DRIFTMI_DEVICE overrides (several ranks on one card in tests)
+        dev = int(os.environ.get("DRIFTMI_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         if workspace_bytes is None:
             workspace_bytes = _default_ws
         if workspace_bytes is None:

@@ -232,3 +232,87 @@ def test_generate_mfiles_in_m_ranges(tmp_path):
     assert len(out["all"]) > 11
     for a, b in zip(out["all"], out["ranges"]):
         assert np.array_equal(a, b)
+
+
+_RANK_SCRIPT = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
+from driftscan_amd import manager
+pm = manager.ProductManager.from_config(%(cfile)r)
+pm.generate()
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
+    """ProductManager.generate() with two ranks (gloo between the processes, both on this GPU, sharing the
+    output directory as MPI ranks of the reference do) against the single-process run: m-sharded BT-gen
+    (contiguous ranges), cost-balanced SVD / KL, gathered spectra, all-reduced Fisher matrix."""
+    import socket
+    import subprocess
+    import sys
+
+    import yaml
+
+    from driftscan_amd import device, manager, storage
+
+    def conf(outdir):
+        return dict(
+            config=dict(beamtransfers=True, kltransform=True, psfisher=True, output_directory=str(outdir), polsvcut=1e-4,
+                        truncate=False),
+            psfisher=[dict(type="Full", name="ps", klname="kl", threshold=0.0, bandtype="polar", num_theta=1,
+                           k_bands=[dict(spacing="linear", start=0.0, stop=0.006, num=4)])],
+            telescope=dict(type="PolarisedCylinder", num_freq=3, freq_start=400.0, freq_end=430.0, freq_mode="edge",
+                           num_cylinders=2, cylinder_width=2.0, num_feeds=3, feed_spacing=0.4, tsys=1.0),
+            kltransform=[dict(type="KLTransform", name="kl", use_foregrounds=True, threshold=0.0),
+                         dict(type="DoubleKL", name="dk", foreground_threshold=10.0)],
+        )
+
+    device.reset_context()
+    c1 = tmp_path / "one.yaml"
+    c1.write_text(yaml.dump(conf(tmp_path / "one")))
+    pm = manager.ProductManager.from_config(str(c1))
+    pm.generate()
+    device.reset_context()
+
+    c2 = tmp_path / "two.yaml"
+    c2.write_text(yaml.dump(conf(tmp_path / "two")))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT % dict(root=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), port=port,
+                                          cfile=str(c2)))
+    env = dict(os.environ, DRIFTMI_DEVICE="0", DRIFTMI_WORKSPACE_GB="2")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+    t, bt1 = pm.telescope, pm.beamtransfer
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+
+    def load(rel, name):
+        out = []
+        for root in (one, two):
+            with storage.File(root + "/" + rel, "r") as f:
+                out.append(np.array(f[name][:]))
+        return out
+
+    for mi in range(t.mmax + 1):
+        f1 = bt1._mfile(mi)
+        with storage.File(f1, "r") as fa, storage.File(f1.replace(one, two, 1), "r") as fb:
+            assert np.array_equal(fa["beam_m"][:], fb["beam_m"][:])
+    rel = os.path.relpath(bt1.directory, one)
+    a, b = load(rel + "/svdspectrum.hdf5", "singularvalues")
+    assert a.shape == b.shape and np.abs(a - b).max() <= 1e-12 * a.max()
+    for name in ("kl", "dk"):
+        evd = os.path.relpath(pm.kltransforms[name].evdir, one)
+        a, b = load(evd + "/evals.hdf5", "evals")
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-9 * np.abs(a).max()
+    psd = os.path.relpath(pm.psestimators["ps"].psdir, one)
+    a, b = load(psd + "/fisher.hdf5", "fisher")
+    assert np.abs(a).max() > 0 and np.abs(a - b).max() <= 1e-8 * np.abs(a).max()
