@@ -141,6 +141,13 @@ int dm_project_cov(dm_ctx* ctx, int nblk, int F, int K, int P, int L, const void
   int2* d_gat = dm_ws_upload(ctx, gat);
   if (!d_gat) return DM_ENOMEM;
   bool first_pair = zero_first != 0;
+  // When the output is overwritten and only diagonal pol pairs contribute (the usual sky models: C_l of
+  // (T,T), (Q,Q), (U,U)), every pair's contribution is Hermitian: block (f, f') is the conjugate transpose of
+  // (f', f).  Only the frequency blocks f' >= f are formed (half of the products) and mirrored afterwards.
+  bool herm = zero_first != 0 && !getenv("DM_COV_FULL");
+  for (int pi = 0; pi < npol && herm; ++pi)
+    for (int pj = 0; pj < npol; ++pj)
+      if (pi != pj && !(polmask_host && !polmask_host[pi * P + pj])) { herm = false; break; }
   for (int pi = 0; pi < npol; ++pi)
     for (int pj = 0; pj < npol; ++pj) {
       if (polmask_host && !polmask_host[pi * P + pj]) continue;
@@ -159,17 +166,34 @@ int dm_project_cov(dm_ctx* ctx, int nblk, int F, int K, int P, int L, const void
         for (int fi = 0; fi < F; ++fi) {
           const int ni = svnum_host[b * F + fi];
           if (ni == 0) continue;
+          const int c0 = herm ? bounds[b][fi] : 0;  // first column formed
           const cplx* Ai = beam + (((size_t)b * F + fi) * K) * PL + (size_t)pi * L + l0;
           const double* cl = cl_pfl_dev + (((size_t)pi * P + pj) * F + fi) * F * L;
-          dm_gemm_desc d = dm_gemm_make(Ai, PL, 1, false, Bb, 1, PL, true, ob + (size_t)bounds[b][fi] * ndof, ndof, ni,
-                                        ndof, L - l0, 1.0, beta, cl, DM_GEMM_B_GATHER);
-          d.bgather = d_gat + goff[(size_t)b * npol + pj];
+          dm_gemm_desc d = dm_gemm_make(Ai, PL, 1, false, Bb, 1, PL, true, ob + (size_t)bounds[b][fi] * ndof + c0, ndof, ni,
+                                        ndof - c0, L - l0, 1.0, beta, cl, DM_GEMM_B_GATHER);
+          d.bgather = d_gat + goff[(size_t)b * npol + pj] + c0;
           g.push_back(d);
         }
       }
       DM_TRY(dm_gemm_grouped_launch(ctx, g));
       first_pair = false;
     }
+  if (herm && !first_pair) {
+    // lower frequency blocks <- conjugate transposes of the upper ones (disjoint source and destination)
+    std::vector<dm_tdesc> tr;
+    for (int b = 0; b < nblk; ++b) {
+      const int ndof = bounds[b][F];
+      const int l0 = l0_host ? std::min(std::max(l0_host[b], 0), L) : 0;
+      if (ndof == 0 || L - l0 <= 0) continue;
+      cplx* ob = out + out_off_host[b];
+      for (int fi = 0; fi < F; ++fi) {
+        const int ni = svnum_host[b * F + fi], r0 = bounds[b][fi], c1 = bounds[b][fi + 1];
+        if (ni == 0 || c1 >= ndof) continue;
+        tr.push_back(dm_tdesc{ob + (size_t)r0 * ndof + c1, ndof, ob + (size_t)c1 * ndof + r0, ndof, ni, ndof - c1});
+      }
+    }
+    DM_TRY(dm_conj_transpose_batched(ctx, tr));
+  }
   if (first_pair)  // every pair masked: the contract is still out = 0
     for (int b = 0; b < nblk; ++b)
       if (bounds[b][F] > 0)

@@ -100,6 +100,13 @@ __global__ void copy_batched_kernel(const cdesc* __restrict__ ds) {
 
 int dm_conj_transpose_batched(dm_ctx* ctx, const std::vector<dm_tdesc>& v) {
   if (v.empty()) return DM_OK;
+  if (v.size() > 32768) {  // the descriptor index rides in gridDim.z
+    for (size_t i0 = 0; i0 < v.size(); i0 += 32768) {
+      std::vector<dm_tdesc> part(v.begin() + i0, v.begin() + std::min(v.size(), i0 + 32768));
+      DM_TRY(dm_conj_transpose_batched(ctx, part));
+    }
+    return DM_OK;
+  }
   std::vector<tdesc> h(v.size());
   int mr = 0, mc = 0;
   for (size_t i = 0; i < v.size(); ++i) {
