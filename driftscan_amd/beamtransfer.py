@@ -200,6 +200,10 @@ class BeamTransfer(config.Reader):
         tel = self.telescope
         ctx = get_context()
         st = time.time()
+        if self.truncate and parallel.rank0():
+            # beamtransfer.py:641-646 (caput.truncate.bit_truncate_max_complex + bitshuffle): not available here
+            logger.warning("truncate = True: bit truncation of the beam transfers is not implemented, the beam_m "
+                           "files are written at full precision (a superset of the information; larger files)")
         finc, binc, pinc = tel.included_freq, tel.included_baseline, tel.included_pol
         nranks, r = parallel.size(), parallel.rank()
         M = tel.mmax + 1
