@@ -226,16 +226,19 @@ class BeamTransfer(config.Reader):
                                         m_range=None if whole else (a, b))
             if whole:
                 self._beam_all = beam_all  # (mmax+1, F, 2, B, P, L), kept for the SVD stage
-            for mi in range(a, b + 1):
-                if os.path.exists(self._mfile(mi)) and not regen:
-                    continue
-                blk = beam_all[mi - a].cpu().numpy()
+            def write_m(mi, blk):
                 with storage.File(self._mfile(mi), "w") as f:
                     data = blk[np.ix_(finc, np.arange(2), binc, pinc, np.arange(mi, tel.lmax + 1))]
                     f.create_dataset("beam_m", data=data)
                     f.attrs["m"] = mi
                     f.attrs["frequencies"] = tel.frequencies
+
+            for mi in range(a, b + 1):
+                if os.path.exists(self._mfile(mi)) and not regen:
+                    continue
+                storage.submit(write_m, mi, beam_all[mi - a].cpu().numpy())
             del beam_all
+        storage.flush()
         parallel.barrier()
         if parallel.rank0():
             open(marker, "a").close()
@@ -271,18 +274,23 @@ class BeamTransfer(config.Reader):
             res = self.svd_device(blocks, skip_svd_inv=skip_svd_inv)
             host = {k: res[k].cpu().numpy() for k in ("beam_svd", "beam_ut", "singularvalues")}
             host["invbeam_svd"] = None if skip_svd_inv else res["invbeam_svd"].cpu().numpy()
-            for i, mi in enumerate(ms):
-                self._dev[mi] = dict(beam_svd=res["beam_svd"][i], beam_ut=res["beam_ut"][i],
-                                     singularvalues=host["singularvalues"][i])
+            def write_svd(mi, bsvd, ibsvd, but, sig):
                 with storage.File(self._svdfile(mi), "w") as fs:
-                    fs.create_dataset("beam_svd", data=host["beam_svd"][i])
-                    if not skip_svd_inv:
-                        fs.create_dataset("invbeam_svd", data=host["invbeam_svd"][i])
-                    fs.create_dataset("beam_ut", data=host["beam_ut"][i])
-                    fs.create_dataset("singularvalues", data=host["singularvalues"][i])
+                    fs.create_dataset("beam_svd", data=bsvd)
+                    if ibsvd is not None:
+                        fs.create_dataset("invbeam_svd", data=ibsvd)
+                    fs.create_dataset("beam_ut", data=but)
+                    fs.create_dataset("singularvalues", data=sig)
                     fs.attrs["baselines"] = tel.baselines
                     fs.attrs["m"] = mi
                     fs.attrs["frequencies"] = tel.frequencies
+
+            for i, mi in enumerate(ms):
+                self._dev[mi] = dict(beam_svd=res["beam_svd"][i], beam_ut=res["beam_ut"][i],
+                                     singularvalues=host["singularvalues"][i])
+                storage.submit(write_svd, mi, host["beam_svd"][i], None if skip_svd_inv else host["invbeam_svd"][i],
+                               host["beam_ut"][i], host["singularvalues"][i])
+        storage.flush()
         parallel.barrier()
         self._collect_svd_spectrum()
 
@@ -298,7 +306,8 @@ class BeamTransfer(config.Reader):
 
     def _collect_svd_spectrum(self):
         """svdspectrum.hdf5: (mmax+1, nfreq, svd_len) (beamtransfer.py:931-947)."""
-        mine = [(mi, self.beam_singularvalues(mi)) for mi in self._my_ms()]
+        mine = [(mi, self._dev[mi]["singularvalues"] if mi in self._dev else self.beam_singularvalues(mi))
+                for mi in self._my_ms()]
         allparts = parallel.gather_objects(mine)
         if parallel.rank0():
             spec = np.zeros((self.telescope.mmax + 1, self.nfreq, self.svd_len))

@@ -219,7 +219,8 @@ class KLTransform(config.Reader):
         todo = [mi for mi in self.beamtransfer._my_ms() if regen or not os.path.exists(self._evfile % mi)]
         for batch in self._batches(todo):
             for mi, res in zip(batch, self._transform_batch(batch)):
-                self._save(mi, *res)
+                storage.submit(self._save, mi, *res)   # written in the background while the next batch is computed
+        storage.flush()
         parallel.barrier()
         if parallel.rank0():
             logger.info("======== Ending KL calculation (time=%f) ========" % (time.time() - st))

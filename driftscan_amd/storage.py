@@ -5,7 +5,6 @@ same paths (``bt/beam_m/<m>/beam.hdf5`` ...), dataset names and attributes; with
 the mirror back-end the file at that path holds an npz archive instead of HDF5
 (h5py is not part of this image's primary Python).
 """
-import io
 import os
 
 import numpy as np
@@ -23,20 +22,23 @@ class _NpzDataset(object):
     def __init__(self, owner, name):
         self._o, self._n = owner, name
 
+    def _arr(self):
+        return self._o._load(self._n)
+
     @property
     def shape(self):
-        return self._o._data[self._n].shape
+        return self._arr().shape
 
     @property
     def dtype(self):
-        return self._o._data[self._n].dtype
+        return self._arr().dtype
 
     def __getitem__(self, idx):
-        out = self._o._data[self._n][idx]
+        out = self._arr()[idx]
         return np.array(out) if isinstance(out, np.ndarray) else out
 
     def __setitem__(self, idx, val):
-        self._o._data[self._n][idx] = val
+        self._arr()[idx] = val
         self._o._dirty = True
 
     def __len__(self):
@@ -49,14 +51,16 @@ class NpzFile(object):
     def __init__(self, path, mode="r"):
         self.path, self.mode = path, mode
         self._data, self.attrs, self._dirty = {}, {}, False
+        self._lazy = None   # open archive of a file being read: datasets are loaded when first touched
         if mode in ("r", "r+", "a") and os.path.exists(path):
-            with np.load(path, allow_pickle=False) as z:
-                for k in z.files:
-                    if k.startswith("__attr__"):
-                        v = z[k]
-                        self.attrs[k[8:]] = v.item() if v.shape == () else v
-                    else:
-                        self._data[k] = z[k]
+            z = np.load(path, allow_pickle=False)
+            for k in z.files:
+                if k.startswith("__attr__"):
+                    v = z[k]
+                    self.attrs[k[8:]] = v.item() if v.shape == () else v
+                else:
+                    self._data[k] = None
+            self._lazy = z
         elif mode == "r":
             raise IOError("no such file: %s" % path)
         if mode == "w":
@@ -64,12 +68,18 @@ class NpzFile(object):
 
     def create_dataset(self, name, shape=None, dtype=None, data=None, **kwargs):
         if data is not None:
-            arr = np.array(data, dtype=dtype) if dtype is not None else np.array(data)
+            # no copy for arrays handed over for writing (the products are hundreds of MB per file)
+            arr = np.asarray(data, dtype=dtype) if dtype is not None else np.asarray(data)
         else:
             arr = np.zeros(shape, dtype=dtype)
         self._data[name] = arr
         self._dirty = True
         return _NpzDataset(self, name)
+
+    def _load(self, name):
+        if self._data[name] is None:
+            self._data[name] = self._lazy[name]
+        return self._data[name]
 
     def __getitem__(self, name):
         if name not in self._data:
@@ -84,16 +94,17 @@ class NpzFile(object):
 
     def close(self):
         if self.mode != "r" and (self._dirty or self.attrs):
-            payload = dict(self._data)
+            payload = {k: self._load(k) for k in self._data}
             for k, v in self.attrs.items():
                 payload["__attr__" + k] = np.asarray(v)
-            buf = io.BytesIO()
-            np.savez(buf, **payload)
             tmp = self.path + ".tmp%d" % os.getpid()
             with open(tmp, "wb") as fh:
-                fh.write(buf.getvalue())
+                np.savez(fh, **payload)
             os.replace(tmp, self.path)  # write-temp-then-rename, like caput.misc.lock_file
             self._dirty = False
+        if self._lazy is not None:
+            self._lazy.close()
+            self._lazy = None
 
     def __enter__(self):
         return self
@@ -108,6 +119,36 @@ def File(path, mode="r", **kwargs):
     if HAVE_H5PY:
         return h5py.File(path, mode, **kwargs)
     return NpzFile(path, mode)
+
+
+# ---- background writers -------------------------------------------------------------------------
+# Product files are independent per m: they are written by a small thread pool while the GPU works on
+# the next batch (file output is 10x the compute time of BASELINE configs[1] when done inline).
+# DRIFTMI_IO_THREADS = 0 writes inline.
+_pool = None
+_pending = []
+
+
+def submit(fn, *args):
+    """Run ``fn(*args)`` (a closure that writes one file) on the writer pool."""
+    global _pool
+    nthreads = int(os.environ.get("DRIFTMI_IO_THREADS", "8"))
+    if nthreads <= 0:
+        fn(*args)
+        return
+    if _pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _pool = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="driftmi-io")
+    while len(_pending) >= 4 * nthreads:   # bound the host memory held by queued products
+        _pending.pop(0).result()
+    _pending.append(_pool.submit(fn, *args))
+
+
+def flush():
+    """Wait for every queued write (re-raises the first failure).  Called before anything reads the files."""
+    while _pending:
+        _pending.pop(0).result()
 
 
 def can_open(path):
