@@ -233,10 +233,11 @@ class BeamTransfer(config.Reader):
                     f.attrs["m"] = mi
                     f.attrs["frequencies"] = tel.frequencies
 
+            host_all = ctx.to_host(beam_all) if beam_all.numel() * 16 <= (8 << 30) else None
             for mi in range(a, b + 1):
                 if os.path.exists(self._mfile(mi)) and not regen:
                     continue
-                storage.submit(write_m, mi, beam_all[mi - a].cpu().numpy())
+                storage.submit(write_m, mi, host_all[mi - a] if host_all is not None else ctx.to_host(beam_all[mi - a]))
             del beam_all
         storage.flush()
         parallel.barrier()
@@ -272,8 +273,8 @@ class BeamTransfer(config.Reader):
             ms = todo[c0 : c0 + nb]
             blocks = self._device_beam_blocks(ms)
             res = self.svd_device(blocks, skip_svd_inv=skip_svd_inv)
-            host = {k: res[k].cpu().numpy() for k in ("beam_svd", "beam_ut", "singularvalues")}
-            host["invbeam_svd"] = None if skip_svd_inv else res["invbeam_svd"].cpu().numpy()
+            host = {k: ctx.to_host(res[k]) for k in ("beam_svd", "beam_ut", "singularvalues")}
+            host["invbeam_svd"] = None if skip_svd_inv else ctx.to_host(res["invbeam_svd"])
             def write_svd(mi, bsvd, ibsvd, but, sig):
                 with storage.File(self._svdfile(mi), "w") as fs:
                     fs.create_dataset("beam_svd", data=bsvd)

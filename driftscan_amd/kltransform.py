@@ -150,7 +150,7 @@ class KLTransform(config.Reader):
             if n == 0:
                 out.append((np.array([]), np.array([[]]), np.array([[]]), {"ac": 0.0}))
                 continue
-            E = evecs[off[i] : off[i] + n * n].cpu().numpy().reshape(n, n)
+            E = ctx.to_host(evecs[off[i] : off[i] + n * n]).reshape(n, n)
             inv = None
             if self.inverse:
                 inv = _inv_gen(E).T
