@@ -30,7 +30,7 @@ def main():
     cfile = out + "/params.yaml"
     os.makedirs(out, exist_ok=True)
     open(cfile, "w").write(yaml.dump(conf))
-    device.get_context(workspace_bytes=24 << 30)
+    device.get_context(workspace_bytes=int(os.environ["E2E_WS_GB"]) << 30 if os.environ.get("E2E_WS_GB") else None)
     res = {}
     for tag in ("first", "second"):   # the second pass re-uses the allocator state of the first (regen)
         pm = manager.ProductManager.from_config(cfile)
