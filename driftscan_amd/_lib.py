@@ -26,6 +26,7 @@ SIGNATURES = {
     "dm_ctx_destroy": (c_int, [c_vp]),
     "dm_ctx_sync": (c_int, [c_vp]),
     "dm_ctx_workspace_bytes": (c_sz, [c_vp]),
+    "dm_ctx_workspace_reset": (c_int, [c_vp, c_sz]),
     "dm_last_error": (ctypes.c_char_p, [c_vp]),
     "dm_version": (c_int, []),
     "dm_prof_reset": (c_int, [c_vp, c_int]),
@@ -143,6 +144,10 @@ class Context(object):
     def to_device(self, arr):
         t = self.torch.from_numpy(np.ascontiguousarray(arr))
         return t.to("cuda:%d" % self.device)
+
+    def workspace_reset(self, nbytes=0):
+        """Give the (idle) workspace arena back to the driver and optionally reserve ``nbytes`` afresh."""
+        self.check(self.lib.dm_ctx_workspace_reset(self.h, int(nbytes)), "dm_ctx_workspace_reset")
 
     def to_host(self, t):
         """Device tensor -> numpy through page-locked memory (torch's caching host allocator re-uses the

@@ -218,6 +218,19 @@ int dm_ctx_sync(dm_ctx* ctx) {
 
 size_t dm_ctx_workspace_bytes(dm_ctx* ctx) { return ctx ? ctx->ws_cap : 0; }
 
+int dm_ctx_workspace_reset(dm_ctx* ctx, size_t bytes) {
+  if (!ctx) return DM_EARG;
+  DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  DM_ARG(ctx, ctx->ws_used == 0);  // nothing may be live in the arena
+  for (void* p : ctx->retired) (void)hipFree(p);
+  ctx->retired.clear();
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  ctx->ws = nullptr;
+  ctx->ws_cap = 0;
+  ctx->ws_used = 0;
+  return bytes ? ws_grow(ctx, bytes, bytes) : DM_OK;
+}
+
 int dm_version(void) { return 100; }
 
 }  // extern "C"

@@ -138,6 +138,20 @@ class KLTransform(config.Reader):
         # and without `inverse` nothing else needs the discarded ones: they are not back-transformed
         # (their rows of the returned matrix are zero; `evals` is complete either way).
         cut = ("upper", self.threshold) if (self.subset and not self.inverse and self._cut_ok) else None
+        need = 8.5 * 16.0 * float((np.asarray(ndofs, dtype=np.float64) ** 2).sum())  # eigensolver workspace, one arena
+        if need > (64 << 30):
+            # a CHIME-sized block (ndof 32 576: ~140 GB): nothing else may stay on the card — the SVD products of
+            # the batch are re-read from their files when they are needed again, the C_l tables re-uploaded
+            import torch
+
+            from .beamtransfer import BeamTransfer
+
+            for mi in ms:
+                self.beamtransfer._dev.pop(mi, None)
+            BeamTransfer._clcache.clear()
+            ctx.sync()
+            torch.cuda.empty_cache()
+            ctx.workspace_reset(int(need))
         evals, evoff, evecs, ac, sweeps = ctx.eigh_gen(S, N, ndofs, off, cut=cut)
         if not to_host:
             return [(evals[evoff[i] : evoff[i] + int(ndofs[i])],

@@ -36,6 +36,11 @@ int dm_ctx_create(int device, size_t workspace_bytes, void* stream, dm_ctx** out
 int dm_ctx_destroy(dm_ctx* ctx);
 int dm_ctx_sync(dm_ctx* ctx);
 size_t dm_ctx_workspace_bytes(dm_ctx* ctx);
+/* Replace the (idle) workspace arena by one of exactly `bytes` (0: just give the memory back).  The arena
+ * only ever grows on its own; a stage that needs most of the card in one piece (dm_eigh_gen at n = 32 576:
+ * ~140 GB) calls this first so that the previous stage's arena is not in the way.  Synchronises.
+ * No reference counterpart (numpy allocates per call). */
+int dm_ctx_workspace_reset(dm_ctx* ctx, size_t bytes);
 const char* dm_last_error(dm_ctx* ctx);
 int dm_version(void);
 

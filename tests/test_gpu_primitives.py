@@ -228,3 +228,17 @@ def test_herm_eig_mixed_sizes_via_eigh_gen(ctx):
         assert np.abs(ev[evoff[i]: evoff[i] + n] - ref).max() <= 1e-11 * ref.max()
         Ei = E[off[i]: off[i] + n * n].reshape(n, n)
         assert np.abs(Ei @ Bs[i] @ Ei.conj().T - np.eye(n)).max() < 1e-10
+
+
+def test_workspace_reset(ctx):
+    """dm_ctx_workspace_reset: the idle arena is handed back / re-reserved; work afterwards is unaffected."""
+    rng = np.random.default_rng(11)
+    n = 40
+    C = crand(rng, 1, n, n)
+    C = C @ C.conj().transpose(0, 2, 1)
+    ref = np.linalg.eigvalsh(C[0])
+    for nbytes in (0, 300 << 20):
+        ctx.workspace_reset(nbytes)
+        assert ctx.lib.dm_ctx_workspace_bytes(ctx.h) >= nbytes
+        ev, _ = ctx.herm_eig(ctx.to_device(C), n, n, strideC=n * n, batch=1)
+        assert np.abs(np.sort(ev.cpu().numpy()[0, :n]) - ref).max() <= 1e-12 * ref.max()
