@@ -829,13 +829,10 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
           cplx* th = Gm + goff[p];                         // rb x ra  (<= nrows^2 / 4)
           cplx* t2 = d_tmp + toff[p];                      // P2: ra x ncols
           cplx* t1 = t2 + (size_t)ra * P.ncols;            // P1: rb x ncols
-          double* an = d_key + (size_t)p * sigma_stride;
-          const int k = (int)cd.size();
-          cd.push_back(jac_clean_desc{P.Z, P.ld, P.row0, ra, rb, P.ncols, th, an + 0, t2});
+          cd.push_back(jac_clean_desc{P.Z, P.ld, P.row0, ra, rb, P.ncols, th, nullptr, t2});  // anorm set below
           jac_pdesc d = pd[p];
           d.nrows = ra;
           pa.push_back(d);
-          (void)k;
           gC.push_back(dm_gemm_make(Brow + P.gc0, P.ld, 1, false, Arow + P.gc0, 1, P.ld, true, th, ra, rb, ra,
                                     P.gc1 - P.gc0));
           gP1.push_back(dm_gemm_make(th, ra, 1, false, Arow, P.ld, 1, false, t1, P.ncols, rb, P.ncols, ra));
@@ -846,8 +843,7 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
           maxrb = std::max(maxrb, rb);
         }
         if (!cd.empty()) {
-          // row norms of A land at d_key[p * stride + i]: the descriptor list is compacted, so give the
-          // norm kernel its own output rows and point the descriptors at them
+          // row norms of A: one output row per (compacted) descriptor
           double* an = dm_ws_alloc_t<double>(ctx, cd.size() * (size_t)sigma_stride);
           if (!an) return DM_ENOMEM;
           for (size_t k = 0; k < cd.size(); ++k) cd[k].anorm = an + k * (size_t)sigma_stride;
