@@ -35,7 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ranks", type=int, default=8, help="GPUs of the full job")
     ap.add_argument("--group", type=int, default=8, help="contiguous m-blocks per BT-gen / SVD / KL call")
-    ap.add_argument("--bt-calls", type=int, default=3, help="BT-gen calls for the rank's contiguous range of m")
+    ap.add_argument("--bt-calls", type=int, default=1, help="BT-gen calls for the rank's contiguous range of m")
     ap.add_argument("--bt-gb", type=float, default=48.0)
     ap.add_argument("--workspace-gb", type=int, default=80)
     ap.add_argument("--config4", action="store_true", help="BASELINE configs[3]: add the DoubleKL filter and the exact Fisher "
