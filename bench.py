@@ -240,6 +240,8 @@ def main():
                            "trd_wx": "trd_wx_kernel", "gemm_grouped_realB": "zgemm_grouped_kernel<true, false>",
                            "dgemm_grouped": "dgemm_grouped_kernel", "jac_inner": "jac_inner_kernel<false>",
                            "jac_gram": "jac_gram_kernel", "jac_apply": "jac_apply_kernel"}.get(dom)
+                    if key is not None and key not in rec:  # kernels compiled inside a namespace (dm_trd32::trd_symv_kernel)
+                        key = next((k for k in rec if k.endswith("::" + key)), key)
                     if key in rec:
                         traffic = rec[key]["fetch_bytes_per_launch"] + rec[key]["write_bytes_per_launch"]
                         traffic_src = os.path.relpath(tj[-1], ROOT)

@@ -1,7 +1,7 @@
 """Per-launch HBM traffic of the main kernels from the two PMC passes (FETCH_SIZE, WRITE_SIZE).
 Corrections as MI355X_MICROARCH.md prescribes: both counters are in KiB; on gfx950 FETCH_SIZE
 reports half of the bytes of wide (16 B/lane) coalesced reads -> doubled; WRITE_SIZE is exact."""
-import csv, glob, json, sys
+import csv, glob, json, re, sys
 from collections import defaultdict
 tag = sys.argv[1]
 def load(d, name):
@@ -9,7 +9,7 @@ def load(d, name):
     tot = defaultdict(float); calls = defaultdict(set)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != name: continue
-        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        k = re.sub(r"dm_trd\d+::", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")).split("(")[0]
         tot[k] += float(r["Counter_Value"]); calls[k].add(r["Dispatch_Id"])
     return tot, {k: len(v) for k, v in calls.items()}
 ft, fc = load("gpurun_out/pmc_fetch_" + tag, "FETCH_SIZE")

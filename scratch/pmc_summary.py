@@ -5,7 +5,7 @@ if not f: print("no counter file", glob.glob(sys.argv[1] + "/**/*", recursive=Tr
 agg = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(int)
 seen = set()
 for r in csv.DictReader(open(f[0])):
-    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:30]
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("dm_trd32::", "").replace("dm_trd64::", "").split("(")[0][:30]
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     key = (k, r["Dispatch_Id"])
     if key not in seen: seen.add(key); cnt[k] += 1

@@ -1,6 +1,6 @@
 import csv, sys
 rows=list(csv.DictReader(open(sys.argv[1])))
-ev=[(int(r['Start_Timestamp']),int(r['End_Timestamp']),r['Kernel_Name'].replace('(anonymous namespace)::','').replace('void ','').split('(')[0][:28], int(r['Grid_Size_X'])//int(r['Workgroup_Size_X'])) for r in rows]
+ev=[(int(r['Start_Timestamp']),int(r['End_Timestamp']),r['Kernel_Name'].replace('(anonymous namespace)::','').replace('void ','').replace('dm_trd32::','').replace('dm_trd64::','').split('(')[0][:28], int(r['Grid_Size_X'])//int(r['Workgroup_Size_X'])) for r in rows]
 ev.sort()
 idx=[i for i,e in enumerate(ev) if e[2].startswith('bt_') ]
 firsts=[idx[0]]+[idx[i] for i in range(1,len(idx)) if ev[idx[i]][0]-ev[idx[i-1]][1]>50e6]
