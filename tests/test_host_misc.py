@@ -124,3 +124,48 @@ def test_two_rank_gloo(tmp_path):
     load = [sum(12 - m for m in by_rank[r][0]) for r in (0, 1)]
     assert abs(load[0] - load[1]) <= 12                                     # balanced
     assert res["tot"] == [float(sum(range(11))), 2.0] and res["word"] == "hello"
+
+
+def test_storage_background_writers_and_lazy_reads(tmp_path, monkeypatch):
+    """Product files queued on the writer pool are complete after flush(); the npz mirror loads datasets only
+    when they are touched; a failing write surfaces in flush()."""
+    from driftscan_amd import storage
+
+    if storage.HAVE_H5PY:
+        pytest.skip("the npz mirror is not in use")
+    rng = np.random.default_rng(0)
+    data = {i: rng.standard_normal((50, 7)) + 1j * rng.standard_normal((50, 7)) for i in range(12)}
+
+    def write(i):
+        with storage.File(str(tmp_path / ("f%d.hdf5" % i)), "w") as f:
+            f.create_dataset("big", data=data[i])
+            f.create_dataset("small", data=np.arange(3) + i)
+            f.attrs["m"] = i
+
+    for threads in ("4", "0"):
+        monkeypatch.setenv("DRIFTMI_IO_THREADS", threads)
+        for i in data:
+            storage.submit(write, i)
+        storage.flush()
+        for i in data:
+            with storage.File(str(tmp_path / ("f%d.hdf5" % i)), "r") as f:
+                assert f.attrs["m"] == i
+                assert f._data["big"] is None            # not read yet
+                assert (f["small"][:] == np.arange(3) + i).all()
+                assert f._data["big"] is None            # still not
+                assert np.array_equal(f["big"][:], data[i])
+                assert f["big"].shape == (50, 7)
+    # read-modify-write keeps the untouched datasets
+    with storage.File(str(tmp_path / "f0.hdf5"), "r+") as f:
+        f["small"][0] = 99
+    with storage.File(str(tmp_path / "f0.hdf5"), "r") as f:
+        assert f["small"][0] == 99 and np.array_equal(f["big"][:], data[0])
+
+    def boom():
+        raise IOError("disk full")
+
+    monkeypatch.setenv("DRIFTMI_IO_THREADS", "2")
+    storage.submit(boom)
+    with pytest.raises(IOError):
+        storage.flush()
+    storage.flush()  # the queue is empty again
