@@ -19,6 +19,10 @@ import os
 import sys
 import time
 
+# one process per GPU: keep the host BLAS / OpenMP pools of the ranks from oversubscribing the node
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // int(os.environ["WORLD_SIZE"]))))
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
