@@ -4,26 +4,36 @@
 Workload (BASELINE.json configs[1]): 32-feed unpolarised cylinder
 (2 cylinders x 16 feeds, width 5 m, spacing 0.4 m), 16 channels 400-450 MHz (edge),
 force_lmax = force_mmax = 128  =>  nbase 46, ntel 92, 129 m-blocks, ndofmax 1472.
-One "step" = one pass of the whole hot path over all 129 m-blocks with the telescope
+One "step" = one pass of the whole hot path over the m-blocks of the rank with the telescope
 description resident (beam-transfer generation -> three-stage SVD compression + pinv ->
 covariance projection + generalised eigenproblem of the KL transform); products stay in
-HBM, file output is not part of the timed region.  With N > 1 ranks every GPU runs the
-same 129-block workload (independent m-blocks, no data-path collective): weak scaling,
-value = N * 129 * steps / max-over-ranks time.
+HBM, file output is not part of the timed region.
 
-Prints ONE JSON line on rank 0 (see the README of the driver contract).
+    python bench.py --gpus N --steps K --warmup W [--mode weak|sharded]
+
+`--gpus N` with N > 1 and no launcher environment (WORLD_SIZE unset): this process starts N
+rank processes itself — before it makes any GPU call — one per GPU over RCCL ("nccl"), relays
+rank 0's JSON line and exits non-zero if a rank fails.  Under `torch.distributed.run` the
+RANK/LOCAL_RANK/WORLD_SIZE of the launcher are used.
+
+Modes (m-blocks are independent: no data-path collective in either):
+  weak     every rank runs the full 129-block workload (per-GPU work fixed); the singular-value and
+           eigenvalue spectra of every rank are gathered to rank 0 inside the timed region, as
+           `_collect_svd_spectrum` / `KLTransform._collect` do.  value = N * 129 * steps / time.
+  sharded  ONE 129-block workload split over the ranks in contiguous m-ranges of equal estimated
+           cost (`parallel.partition_contiguous`); each rank generates, compresses and transforms only
+           its own blocks; the spectra gather and an all-reduce of a per-rank (nbands x nbands)
+           matrix (the Fisher assembly pattern, psestimation.py:506-507) are inside the timed
+           region.  value = 129 * steps / time ("scaling": "strong").
+
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-# one process per GPU: keep the host BLAS / OpenMP pools of the ranks from oversubscribing the node
-if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // int(os.environ["WORLD_SIZE"]))))
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -34,8 +44,180 @@ CFG2 = dict(num_freq=16, freq_start=400.0, freq_end=450.0, freq_mode="edge", num
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (AMD datasheet)
 HBM_PEAK_GBS = 8000.0         # HBM3E spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 achievable)
 HBM_CLASSES = ("trd_symv", "trd_wx")
+CPU_SAMPLE_M = (0, 32, 64, 96)
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mode", choices=["weak", "sharded"], default="weak")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo + --one-gpu rehearses the multi-rank path on a single card (RCCL refuses two ranks per GPU)")
+    ap.add_argument("--one-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal on a one-GPU box)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--all-modes", action="store_true",
+                    help="form every KL mode (subset = False) instead of only the ones transform_save keeps")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DRIFT_BENCH_STREAMS", "1")),
+                    help="concurrent m-block groups per GPU (threads x HIP streams); 2 gives +7 %% m-blocks/s but the "
+                         "per-kernel durations (and so the roofline figure) then include the interference")
+    ap.add_argument("--cpu-worker", nargs=2, metavar=("JOBS", "NPROC"), help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------
+# launcher: N rank processes from a parent that never touches the GPU
+# ---------------------------------------------------------------------------------------------------
+def launch_ranks(args, argv):
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", DRIFT_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while True:
+            states = [p.poll() for p in procs]
+            bad = [st for st in states if st not in (None, 0)]
+            if bad:  # a rank failed: the others would wait for it in a collective until the timeout
+                rc = bad[0]
+                break
+            if all(st == 0 for st in states):
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()   # exactly the PIDs started above
+        out0 = procs[0].stdout.read() or b""   # one JSON line: far below the pipe buffer
+        for p in procs:
+            p.wait()
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline worker (fresh process, no GPU): N single-thread workers over the sample blocks
+# ---------------------------------------------------------------------------------------------------
+def _cpu_one_block(job):
+    """SVD chain + covariance projections + KL of one m-block with the oracle; per-stage seconds."""
+    import numpy as np
+
+    from oracle import kl as okl
+    from oracle import svdchain as osvd
+
+    blk, noisew, cv_sg, cv_fg, npw, polsvcut, svcut = job
+    t0 = time.perf_counter()
+    o = osvd.svd_m(blk, noisew, polsvcut=polsvcut)
+    t1 = time.perf_counter()
+    cs, cn = okl.sn_covariance(o["beam_svd"], o["beam_ut"], o["singularvalues"], cv_sg, cv_fg, npw, svcut=svcut)
+    okl.kl_transform_m(cs, cn)
+    t2 = time.perf_counter()
+    return t1 - t0, t2 - t1, int(cs.shape[0])
+
+
+def _cpu_bt_columns(desc):
+    from oracle import btgen as ob
+
+    t0 = time.perf_counter()
+    ob.beam_transfer_m(desc)
+    return time.perf_counter() - t0
+
+
+def cpu_worker_main(path, nproc):
+    """`bench.py --cpu-worker file nproc`: the reference's MPI mode (one BLAS thread per rank, ranks over m)."""
+    os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = os.environ["MKL_NUM_THREADS"] = "1"
+    import multiprocessing as mp
+    import pickle
+
+    with open(path, "rb") as fh:
+        jobs, desc = pickle.load(fh)
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(min(int(nproc), len(jobs) + 1)) as pool:
+        bt = pool.apply_async(_cpu_bt_columns, (desc,))
+        res = pool.map(_cpu_one_block, jobs)
+        t_bt = bt.get()
+    wall = time.perf_counter() - t0
+    print(json.dumps(dict(wall_s=wall, per_block=[list(r) for r in res], bt_columns_s=t_bt)))
+
+
+def cpu_baseline(tel, bt, kl, blocks):
+    """The oracle (numpy/scipy restatement, kind = "port") on the host cores, on the REAL blocks of this
+    workload (`blocks`: {m: (F,2,B,P,L) numpy}, copied back from the device), per stage, in the two modes
+    BASELINE.md section 3 names:
+      threaded   one process, BLAS threads on all cores, blocks one after the other (median of 3);
+      workers    the reference's MPI mode: single-threaded processes over m (one per sample block here;
+                 the all-core figure is that per-core rate times the core count — an extrapolation, m-blocks
+                 are independent).
+    BT-gen is 2 of the F*B columns scaled to all.  The mean over the m-sample (evenly spread in m) stands for
+    the mean over all m-blocks; `value` is the better of the two modes."""
+    import pickle
+    import tempfile
+
+    import numpy as np
+    import scipy
+
+    ncores = os.cpu_count() or 1
+    M = tel.mmax + 1
+    desc = dict(polarised=False, zenith=tel.zenith, baselines=tel.baselines, uniquepairs=tel.uniquepairs,
+                beamclass=tel.beamclass, wavelengths=tel.wavelengths, cylinder_width=tel.cylinder_width,
+                fwhm_e=tel.fwhm_e, fwhm_h=tel.fwhm_h, lmax=tel.lmax, mmax=tel.mmax, l_boost=tel.l_boost,
+                included_freq=np.array([0]), included_baseline=np.array([0, tel.nbase - 1]),
+                accuracy_boost=tel.accuracy_boost)
+    ncol = tel.nfreq * tel.nbase
+    t_bt_block = _cpu_bt_columns(desc) / 2.0 * ncol / M    # 2 columns, all m -> seconds per m-block
+    ms = sorted(blocks)
+    noisew = bt._noisew()[:, : tel.nbase]
+    npw = kl._npower(1.0)
+    jobs = [(blocks[m], noisew, kl.signal(), kl.foreground(), npw, bt.polsvcut, bt.svcut) for m in ms]
+    reps = [[_cpu_one_block(j) for j in jobs] for _ in range(3)]
+    svd_s = [float(np.median([r[i][0] for r in reps])) for i in range(len(ms))]
+    kl_s = [float(np.median([r[i][1] for r in reps])) for i in range(len(ms))]
+    ndofs = [reps[0][i][2] for i in range(len(ms))]
+    thr = dict(stage_s_per_block=dict(btgen=t_bt_block, svd=float(np.mean(svd_s)), kl=float(np.mean(kl_s))),
+               per_block_s=dict(svd=svd_s, kl=kl_s))
+    thr["m_blocks_per_s"] = 1.0 / sum(thr["stage_s_per_block"].values())
+    # fresh process (this one holds a GPU context: never fork or exec from it), one single-threaded worker per block
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "jobs.pkl")
+            with open(path, "wb") as fh:
+                pickle.dump((jobs, desc), fh)
+            env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(len(ms) + 1)],
+                                 env=env, stdout=subprocess.PIPE, timeout=900, check=True).stdout
+            w = json.loads(out.decode().strip().splitlines()[-1])
+        st = dict(btgen=w["bt_columns_s"] / 2.0 * ncol / M, svd=float(np.mean([p[0] for p in w["per_block"]])),
+                  kl=float(np.mean([p[1] for p in w["per_block"]])))
+        wk = dict(processes=len(ms) + 1, threads_each=1, wall_s=w["wall_s"], stage_s_per_block_one_core=st,
+                  per_block_s=dict(svd=[p[0] for p in w["per_block"]], kl=[p[1] for p in w["per_block"]]),
+                  m_blocks_per_s_per_core=1.0 / sum(st.values()),
+                  m_blocks_per_s=ncores / sum(st.values()), extrapolated_to_cores=ncores)
+    except Exception as e:  # the baseline is reporting only: never lose the bench line over it
+        wk = dict(error=repr(e), m_blocks_per_s=0.0)
+    best = "workers" if wk["m_blocks_per_s"] > thr["m_blocks_per_s"] else "threaded"
+    return dict(value=max(wk["m_blocks_per_s"], thr["m_blocks_per_s"]), unit="m-blocks/s", cores=ncores, kind="port",
+                mode=best, threaded=thr, workers=wk, sample_m=ms, sample_ndof=ndofs,
+                sample="oracle (numpy %s / scipy %s) on the real configs[1] blocks m = %s copied back from the device: SVD "
+                       "chain + covariance projections + KL per block, BT-gen on 2 of %d (f,b) columns scaled to all; "
+                       "`threaded` = one process, BLAS on %d cores, median of 3; `workers` = single-threaded processes "
+                       "over m (the reference's MPI mode), per-core rate x %d cores"
+                       % (np.__version__, scipy.__version__, ms, ncol, ncores, ncores))
+
+
+# ---------------------------------------------------------------------------------------------------
+# the hot path
+# ---------------------------------------------------------------------------------------------------
 def build_objects(tmpdir):
     from driftscan_amd import beamtransfer, cylinder, kltransform
 
@@ -48,133 +230,146 @@ def build_objects(tmpdir):
 _pool = None
 
 
-def _svd_kl_group(bt, kl, beam_all, ms):
+def _svd_kl_group(bt, kl, beam_all, ms, m0=0):
     """SVD chain + KL for one group of m-blocks on the calling thread's context; returns
-    (seconds in SVD, seconds in KL) as seen by this thread."""
+    (seconds in SVD, seconds in KL, KL products, singular values (host), ndofs)."""
     import torch
 
     from driftscan_amd import device
 
     ctx = device.get_context()
     t0 = time.perf_counter()
-    idx = torch.as_tensor(ms, device=beam_all.device)
+    idx = torch.as_tensor([m - m0 for m in ms], device=beam_all.device)
     res = bt.svd_device(beam_all.index_select(0, idx))                # SVD chain + pinv, the whole group at once
     sv = res["singularvalues"].cpu().numpy()
     ctx.sync()
     t1 = time.perf_counter()
     for i, mi in enumerate(ms):
         bt._dev[mi] = dict(beam_svd=res["beam_svd"][i], beam_ut=res["beam_ut"][i], singularvalues=sv[i])
-    out = None
+    out = []
     for batch in kl._batches(list(ms)):
-        out = kl._transform_batch(batch, to_host=False)               # projections + eigh_gen, products stay in HBM
+        out += kl._transform_batch(batch, to_host=False)             # projections + eigh_gen, products stay in HBM
     ctx.sync()
-    return t1 - t0, time.perf_counter() - t1, out
+    return t1 - t0, time.perf_counter() - t1, out, sv
 
 
-def hot_path_step(tel, bt, kl, ctx, stage_times=None, streams=1):
-    """One pass over all m-blocks; everything stays on the device.  After the beam-transfer
-    generation the m-blocks are dealt round-robin into `streams` groups, each driven by its own
-    thread / libdriftmi context / HIP stream, so that the launch-latency-bound phases of one
-    group (Jacobi sweeps, the tail of the tridiagonalisation) overlap with the MFMA- and
-    HBM-bound phases of the other."""
+def hot_path_step(tel, bt, kl, ctx, stage_times=None, streams=1, m_range=None, collect=False, keep=None):
+    """One pass over the m-blocks of this rank (all of them, or the contiguous `m_range`); everything stays on
+    the device.  After the beam-transfer generation the m-blocks are dealt round-robin into `streams` groups,
+    each driven by its own thread / libdriftmi context / HIP stream.  With `collect` the spectra of all ranks are
+    gathered to rank 0 (beamtransfer.py:931-947, kltransform.py:452-478) and a per-rank band matrix is all-reduced
+    (the pattern of the Fisher assembly, psestimation.py:506-507)."""
+    import numpy as np
     import torch
 
-    from driftscan_amd import btgen
+    from driftscan_amd import btgen, parallel
 
     global _pool
     t0 = time.perf_counter()
-    beam_all = btgen.beam_m_all(tel, ctx=ctx)                         # (mmax+1, F, 2, B, P, L)
+    beam_all = btgen.beam_m_all(tel, ctx=ctx, m_range=m_range)        # (nm, F, 2, B, P, L)
     ctx.sync()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    ms = list(range(tel.mmax + 1))
+    m0 = 0 if m_range is None else m_range[0]
+    ms = list(range(tel.mmax + 1)) if m_range is None else list(range(m_range[0], m_range[1] + 1))
     groups = [ms[g::streams] for g in range(streams)]
     if streams == 1:
-        parts = [_svd_kl_group(bt, kl, beam_all, groups[0])]
+        parts = [_svd_kl_group(bt, kl, beam_all, groups[0], m0)]
     else:
         if _pool is None or _pool._max_workers != streams:
             from concurrent.futures import ThreadPoolExecutor
 
             _pool = ThreadPoolExecutor(max_workers=streams)
-        futs = [_pool.submit(_svd_kl_group, bt, kl, beam_all, g) for g in groups]
+        futs = [_pool.submit(_svd_kl_group, bt, kl, beam_all, g, m0) for g in groups]
         parts = [f.result() for f in futs]
     torch.cuda.synchronize()
     t3 = time.perf_counter()
+    tcoll = 0.0
+    if collect:
+        mine = []
+        for g, p in zip(groups, parts):
+            flat = torch.cat([r[0].reshape(-1) for r in p[2]]).cpu().numpy()   # one copy for all spectra of the group
+            cuts = np.cumsum([0] + [int(r[0].numel()) for r in p[2]])
+            mine += [(mi, p[3][i], flat[cuts[i] : cuts[i + 1]]) for i, mi in enumerate(g)]
+        allparts = parallel.gather_objects(mine)
+        band = np.zeros((9, 9))
+        for _, sv, ev in mine:
+            band[0, 0] += float(ev.sum())
+        parallel.allreduce_sum(band)
+        if parallel.rank0():
+            assert sum(len(p) for p in allparts) >= len(mine)
+        tcoll = time.perf_counter() - t3
+    if keep is not None:
+        for mi in keep:
+            if m0 <= mi < m0 + beam_all.shape[0]:
+                keep[mi] = beam_all[mi - m0].cpu().numpy()
     if stage_times is not None:
         tsvd = max(p[0] for p in parts)
-        stage_times.append((t1 - t0, tsvd, (t3 - t1) - tsvd))
+        stage_times.append((t1 - t0, tsvd, (t3 - t1) - tsvd, tcoll))
     return parts[0][2]
 
 
-def cpu_baseline(tel, bt, kl, budget_s=25.0):
-    """The oracle (numpy/scipy restatement, kind = "port") timed on the host cores for a
-    bounded sample of m-blocks of the same workload: SVD chain + KL for m in a spread of
-    values, plus BT-gen for a handful of (f, b) columns scaled to the full count."""
-    import scipy
+def stage_work(tel, bt, ms):
+    """Algorithmic work per stage, SURVEY.md §8(d): W_A (Legendre, 8 Nr Lm F B P per m), W_B (SVD chain),
+    W_C (covariance projections + eig), summed over the given m."""
+    import numpy as np
 
-    from oracle import btgen as ob
-    from oracle import kl as okl
-    from oracle import svdchain as osvd
+    from driftscan_amd import healpix
 
-    ncores = os.cpu_count() or 1
-    desc = dict(polarised=False, zenith=tel.zenith, baselines=tel.baselines, uniquepairs=tel.uniquepairs,
-                beamclass=tel.beamclass, wavelengths=tel.wavelengths, cylinder_width=tel.cylinder_width,
-                fwhm_e=tel.fwhm_e, fwhm_h=tel.fwhm_h, lmax=tel.lmax, mmax=tel.mmax, l_boost=tel.l_boost,
-                included_freq=np.array([0]), included_baseline=np.array([0, tel.nbase - 1]),
-                accuracy_boost=tel.accuracy_boost)
-    t0 = time.perf_counter()
-    ob.beam_transfer_m(desc)  # 2 of the F*B columns, all m
-    t_bt_cols = time.perf_counter() - t0
-    t_bt_full = t_bt_cols / 2.0 * tel.nfreq * tel.nbase
-    # SVD + KL on synthetic blocks of the right shape (random full-rank, like SURVEY §6's probe)
-    rng = np.random.default_rng(1000)
-    F, B, L = tel.nfreq, tel.nbase, tel.lmax + 1
-    noisew = bt._noisew()[:, :B]
-    npw = kl._npower(1.0)
-    sample_m = [0, tel.mmax // 4, tel.mmax // 2, 3 * tel.mmax // 4]
-    t_svdkl = 0.0
-    done = 0
-    for mi in sample_m:
-        blk = np.zeros((F, 2, B, 1, L), dtype=np.complex128)
-        blk[..., mi:] = (rng.standard_normal((F, 2, B, 1, L - mi)) + 1j * rng.standard_normal((F, 2, B, 1, L - mi))) \
-            * np.exp(-np.arange(L - mi) / 20.0)
-        t0 = time.perf_counter()
-        o = osvd.svd_m(blk, noisew, polsvcut=bt.polsvcut)
-        cs, cn = okl.sn_covariance(o["beam_svd"], o["beam_ut"], o["singularvalues"], kl.signal(), kl.foreground(),
-                                   npw, svcut=bt.svcut)
-        okl.kl_transform_m(cs, cn)
-        t_svdkl += time.perf_counter() - t0
-        done += 1
-        if t_svdkl + t_bt_cols > budget_s:
-            break
-    per_m = t_svdkl / done + t_bt_full / (tel.mmax + 1)
-    return dict(value=1.0 / per_m, unit="m-blocks/s", cores=ncores, kind="port",
-                sample="oracle (numpy %s / scipy %s, threaded BLAS on %d cores): SVD chain + KL on %d m-blocks "
-                       "(m = %s) of the config-2 shape, BT-gen on 2 of %d (f,b) columns scaled to all"
-                       % (np.__version__, scipy.__version__, ncores, done, sample_m[:done], tel.nfreq * tel.nbase))
+    F, B, P, L = tel.nfreq, tel.nbase, tel.num_pol_sky, tel.lmax + 1
+    T = 2 * B
+    lmax_bf, _ = tel.baseline_lmax(np.arange(B), np.full(B, F - 1))
+    nside = healpix.nside_for_lmax(int(lmax_bf.max()), tel.accuracy_boost if P == 1 else 1)
+    Nr = 4 * nside - 1
+
+    def svd(a, b):
+        lo, hi = min(a, b), max(a, b)
+        return 4.0 * (2.0 * hi * lo * lo + 11.0 * lo ** 3)
+
+    WA = WB = WC = 0.0
+    for mi in ms:
+        Lm = L - mi
+        WA += 8.0 * Nr * Lm * F * B * P
+        svnum = bt._svd_num(mi)[0]
+        ndof = float(svnum.sum())
+        for f in range(F):
+            n = float(svnum[f])
+            if P == 1:
+                WB += svd(T, Lm) + svd(n, Lm) + 8.0 * T * Lm * n
+            else:
+                r1 = r2 = float(min(T, P * Lm))
+                WB += svd(T, P * Lm) + svd(r1, (P - 1) * Lm) + svd(r2, Lm) + svd(n, P * Lm) \
+                    + 8.0 * T * P * Lm * (r1 + r2 + n) + 8.0 * T * (r2 * r1 + n * r2)
+        nF = 1 if P == 1 else 3
+        WC += 8.0 * ndof * ndof * Lm * (1 + nF) + 8.0 * T * float((svnum.astype(np.float64) ** 2).sum()) + 68.0 * ndof ** 3 / 3.0
+    return WA, WB, WC
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--all-modes", action="store_true",
-                    help="form every KL mode (subset = False) instead of only the ones transform_save keeps")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("DRIFT_BENCH_STREAMS", "1")),
-                    help="concurrent m-block groups per GPU (threads x HIP streams); 2 gives +7 %% m-blocks/s but the "
-                         "per-kernel durations (and so the roofline figure) then include the interference")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.cpu_worker:
+        cpu_worker_main(*args.cpu_worker)
+        return 0
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        # no launcher: start the ranks ourselves, before anything here touches the GPU
+        return launch_ranks(args, sys.argv[1:])
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # one process per GPU: keep the host BLAS / OpenMP pools of the ranks from oversubscribing the node
+    if world > 1:
+        os.environ.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // world)))
 
     import tempfile
 
+    import numpy as np
     import torch
 
     from driftscan_amd import device, parallel
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    force_dist = os.environ.get("DRIFT_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path on one GPU
+    force_dist = os.environ.get("DRIFT_BENCH_FORCE_DIST") == "1"  # exercise the collective path with one rank
+    local = 0 if args.one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    if args.one_gpu:
+        os.environ["DRIFTMI_DEVICE"] = "0"
     if world > 1 or force_dist:
         import torch.distributed as dist
 
@@ -182,10 +377,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group(backend="nccl")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend=args.backend)
     rank = parallel.rank()
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     ctx = device.get_context(workspace_bytes=24 << 30)
 
@@ -193,8 +387,15 @@ def main():
         tel, bt, kl = build_objects(tmp)
         if args.all_modes:
             kl.subset = False
+        nblocks = tel.mmax + 1
+        m_range = None
+        if args.mode == "sharded" and world > 1:
+            allm = list(range(nblocks))
+            mine = parallel.partition_contiguous(allm, [float(tel.lmax + 1 - m) + 1.0 for m in allm])
+            m_range = (mine[0], mine[-1])
+        collect = world > 1 or force_dist
         for _ in range(args.warmup):
-            hot_path_step(tel, bt, kl, ctx, streams=args.streams)
+            hot_path_step(tel, bt, kl, ctx, streams=args.streams, m_range=m_range, collect=collect)
         # A full (generation-2) cycle collection walks every object torch/numpy created at import
         # (~45 ms here) and would land at a random point of the timed region: collect now and move
         # the survivors to the permanent generation, as a long-running pipeline process would.
@@ -209,7 +410,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            hot_path_step(tel, bt, kl, ctx, stage_times=stage, streams=args.streams)
+            hot_path_step(tel, bt, kl, ctx, stage_times=stage, streams=args.streams, m_range=m_range, collect=collect)
         torch.cuda.synchronize()
         parallel.barrier()
         dt = time.perf_counter() - t0
@@ -221,11 +422,11 @@ def main():
         if world > 1 or force_dist:
             import torch.distributed as dist
 
-            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
-        nblocks = tel.mmax + 1
-        value = world * nblocks * args.steps / dt
+        sharded = m_range is not None
+        value = (nblocks if sharded else world * nblocks) * args.steps / dt
         if rank == 0:
             st = np.array(stage).mean(axis=0)
             dom = max(prof, key=lambda k: prof[k]["ms"] * (8.0 if k in HBM_CLASSES else 1.0)) if prof else None
@@ -233,7 +434,7 @@ def main():
             # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this
             # process, so the figure comes from the committed rocprofv3 --pmc passes of this same
             # command (profiles/*_pmc_traffic.json, made by scratch/run_profiles.sh + make_traffic_json.py).
-            traffic, traffic_src = None, None
+            traffic, traffic_src, mfma_busy = None, None, None
             try:
                 import glob
 
@@ -249,6 +450,9 @@ def main():
                     if key in rec:
                         traffic = rec[key]["fetch_bytes_per_launch"] + rec[key]["write_bytes_per_launch"]
                         traffic_src = os.path.relpath(tj[-1], ROOT)
+                mj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_mfma.json")))
+                if mj:
+                    mfma_busy = dict(json.load(open(mj[-1])), source=os.path.relpath(mj[-1], ROOT))
             except Exception:
                 traffic, traffic_src = None, None
             if dom is not None:
@@ -283,6 +487,20 @@ def main():
                         oa = q["flops"] / (q["ms"] * 1e-3) / 1e12
                         roofline["also"] = dict(kernel=o, bound="mfma", achieved=oa, unit="TFLOP/s",
                                                 frac=oa / FP64_MFMA_PEAK_TFLOPS, ms_per_step=q["ms"] / args.steps)
+                if mfma_busy is not None:
+                    roofline["mfma_busy"] = mfma_busy
+            # per-stage fractions of SURVEY.md §8(d): algorithmic work of the stage / its wall time / fp64 MFMA peak
+            my_ms = list(range(nblocks)) if m_range is None else list(range(m_range[0], m_range[1] + 1))
+            WA, WB, WC = stage_work(tel, bt, my_ms)
+            stages = {}
+            for name, W, secs in (("btgen", WA, st[0]), ("svd", WB, st[1]), ("kl", WC, st[2])):
+                tf = W / secs / 1e12 if secs > 0 else 0.0
+                stages[name] = dict(work_flop=W, ms=1e3 * secs, tflops=tf, frac_of_fp64_mfma_peak=tf / FP64_MFMA_PEAK_TFLOPS)
+            cpu = None
+            if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N = 1 only
+                keep = {m: None for m in CPU_SAMPLE_M if m in my_ms}
+                hot_path_step(tel, bt, kl, ctx, streams=args.streams, m_range=m_range, keep=keep)   # untimed: real blocks
+                cpu = cpu_baseline(tel, bt, kl, {m: b for m, b in keep.items() if b is not None})
             line = {
                 "metric": "m-blocks/sec (BT-gen + SVD + KL)",
                 "value": value,
@@ -292,27 +510,37 @@ def main():
                 "warmup": args.warmup,
                 "ms_per_step": 1e3 * dt / args.steps,
                 "higher_is_better": True,
-                "scaling": "weak",
+                "scaling": "strong" if sharded else "weak",
                 "vs_baseline": None,
                 "dtype": "f64",
                 "data": "synthetic",
                 "config": {"workload": "configs[1]: 32-feed unpolarised cylinder, nfreq=16, nbase=46, lmax=mmax=128, "
-                                       "129 m-blocks per GPU per step, KLTransform with foregrounds",
-                           "nfreq": 16, "nbase": 46, "lmax": 128, "mmax": 128, "sharding": "m-blocks, replicas per GPU", "streams_per_gpu": args.streams,
+                                       + ("129 m-blocks split over the ranks in cost-balanced contiguous m-ranges"
+                                          if sharded else "129 m-blocks per GPU per step") + ", KLTransform with foregrounds",
+                           "nfreq": 16, "nbase": 46, "lmax": 128, "mmax": 128,
+                           "sharding": "m-ranges, one job" if sharded else "m-blocks, one full workload per GPU",
+                           "mode": args.mode, "ranks": world, "backend": args.backend if world > 1 else None,
+                           "collectives_in_timed_region": "gather of sigma/lambda spectra + all-reduce of a 9x9 band matrix"
+                           if collect else None,
+                           "streams_per_gpu": args.streams,
                            "kl_products": "all eigenvalues + every mode" if args.all_modes else
                            "all eigenvalues + the modes with S/N >= threshold (subset = True, what transform_save writes)"},
-                "stage_ms": {"btgen": 1e3 * st[0], "svd": 1e3 * st[1], "kl": 1e3 * st[2]},
+                "stage_ms": {"btgen": 1e3 * st[0], "svd": 1e3 * st[1], "kl": 1e3 * st[2], "collectives": 1e3 * st[3]},
+                "stages": stages,
                 # the two tridiagonalisation classes are timed on every 8th launch: scaled back to all launches
                 "kernels_ms": {k: v["ms"] / args.steps * (8.0 if k in HBM_CLASSES else 1.0) for k, v in prof.items()},
                 "roofline": roofline,
-                "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(tel, bt, kl),
+                "cpu_baseline": cpu,
             }
             print(json.dumps(line))
+            sys.stdout.flush()
     if world > 1 or force_dist:
         import torch.distributed as dist
 
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -20,6 +20,13 @@ c_dbl = ctypes.c_double
 c_vp = ctypes.c_void_p
 c_sz = ctypes.c_size_t
 
+class ZgemmProblem(ctypes.Structure):
+    """dm_zgemm_problem of include/driftmi.h."""
+    _fields_ = [("A", c_vp), ("B", c_vp), ("C", c_vp), ("M", c_int), ("N", c_int), ("K", c_int),
+                ("rsA", c_int), ("csA", c_int), ("rsB", c_int), ("csB", c_int), ("ldc", c_int),
+                ("conjA", c_int), ("conjB", c_int), ("alpha", c_dbl), ("beta", c_dbl)]
+
+
 # name -> (restype, argtypes); mirrors include/driftmi.h one to one
 SIGNATURES = {
     "dm_ctx_create": (c_int, [c_int, c_sz, c_vp, ctypes.POINTER(c_vp)]),
@@ -36,6 +43,7 @@ SIGNATURES = {
         [c_vp, c_int, c_int, c_int, c_dbl, c_vp, c_int, c_int, c_int, c_i64, c_vp, c_int, c_int, c_int, c_i64,
          c_dbl, c_vp, c_int, c_i64, c_vp, c_i64, c_int],
     ),
+    "dm_zgemm_grouped": (c_int, [c_vp, c_int, ctypes.POINTER(ZgemmProblem)]),
     "dm_zpotrf_batched": (c_int, [c_vp, c_int, c_vp, c_int, c_i64, c_int, ctypes.POINTER(c_int)]),
     "dm_ztrsm_left_lower_batched": (
         c_int, [c_vp, c_int, c_int, c_vp, c_int, c_i64, c_vp, c_int, c_i64, c_int, c_int]),
@@ -59,7 +67,7 @@ SIGNATURES = {
                 c_vp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_int), c_int, c_dbl, ctypes.POINTER(c_int)]),
     "dm_fisher": (
         c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int,
-                c_vp, c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_int), c_vp, ctypes.POINTER(c_i64), c_vp]),
+                c_vp, c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_int), c_vp, ctypes.POINTER(c_i64), c_vp, c_int]),
     "dm_bt_beam_cyl": (
         c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int,
                 ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_dbl, c_vp]),
@@ -178,6 +186,21 @@ class Context(object):
             strideB, beta, self.ptr(C), ldc, strideC, self.ptr(kscale), stride_kscale, batch)
         self.check(rc, "dm_zgemm_strided_batched")
 
+    def zgemm_grouped(self, problems):
+        """One launch for a ragged list of products.  Each problem is a dict with device tensors A, B, C and
+        M, N, K, rsA, csA, rsB, csB, ldc (+ optional conjA, conjB, alpha, beta)."""
+        n = len(problems)
+        if n == 0:
+            return
+        arr = (ZgemmProblem * n)()
+        for q, p in zip(arr, problems):
+            q.A, q.B, q.C = p["A"].data_ptr(), p["B"].data_ptr(), p["C"].data_ptr()
+            q.M, q.N, q.K = int(p["M"]), int(p["N"]), int(p["K"])
+            q.rsA, q.csA, q.rsB, q.csB, q.ldc = int(p["rsA"]), int(p["csA"]), int(p["rsB"]), int(p["csB"]), int(p["ldc"])
+            q.conjA, q.conjB = int(bool(p.get("conjA", False))), int(bool(p.get("conjB", False)))
+            q.alpha, q.beta = float(p.get("alpha", 1.0)), float(p.get("beta", 0.0))
+        self.check(self.lib.dm_zgemm_grouped(self.h, n, arr), "dm_zgemm_grouped")
+
     def zpotrf(self, A, n, ld, stride=0, batch=1):
         info = (c_int * batch)()
         self.check(self.lib.dm_zpotrf_batched(self.h, n, self.ptr(A), ld, stride, batch, info), "dm_zpotrf_batched")
@@ -267,7 +290,10 @@ def _block_offsets(ndofs):
     return off[:-1].copy(), int(off[-1])
 
 
-def _project_cov(self, beam_svd, svnum, cl_pfl, out, out_off, npol=None, polmask=None, l0=None, zero_first=True):
+def _project_cov(self, beam_svd, svnum, cl_pfl, out, out_off, npol=None, polmask=None, l0=None, zero_first=True,
+                 symmetric=False):
+    """``symmetric``: the caller has checked cl[p,q,f,f',l] == cl[p,q,f',f,l]; only then may the library
+    form the frequency blocks f' >= f alone and mirror them (the reference accepts any array)."""
     nblk, F, K, P, L = [int(x) for x in beam_svd.shape]
     sv, svp = _iarr(svnum)
     off, offp = _larr(out_off)
@@ -279,11 +305,11 @@ def _project_cov(self, beam_svd, svnum, cl_pfl, out, out_off, npol=None, polmask
     if l0 is not None:
         l0a, l0p = _iarr(l0)
     rc = self.lib.dm_project_cov(self.h, nblk, F, K, P, L, self.ptr(beam_svd), svp, l0p, self.ptr(cl_pfl), npol, pmp,
-                                 self.ptr(out), offp, int(zero_first))
+                                 self.ptr(out), offp, int(bool(zero_first)) | (2 if symmetric else 0))
     self.check(rc, "dm_project_cov")
 
 
-def _fisher(self, beam_svd, svnum, l0, cl_bands, evecs, evecs_off, nmodes, evals, evals_off):
+def _fisher(self, beam_svd, svnum, l0, cl_bands, evecs, evecs_off, nmodes, evals, evals_off, cl_symmetric=False):
     """Per-m Fisher matrices (nblk, nbands, nbands) complex; see dm_fisher in include/driftmi.h."""
     nblk, F, K, P, L = [int(x) for x in beam_svd.shape]
     nbands = int(cl_bands.shape[0])
@@ -294,7 +320,7 @@ def _fisher(self, beam_svd, svnum, l0, cl_bands, evecs, evecs_off, nmodes, evals
     nm, nmp = _iarr(nmodes)
     out = self.empty((nblk, nbands, nbands), np.complex128)
     rc = self.lib.dm_fisher(self.h, nblk, F, K, P, L, self.ptr(beam_svd), svp, l0p, nbands, self.ptr(cl_bands),
-                            self.ptr(evecs), eop, nmp, self.ptr(evals), vop, self.ptr(out))
+                            self.ptr(evecs), eop, nmp, self.ptr(evals), vop, self.ptr(out), int(bool(cl_symmetric)))
     self.check(rc, "dm_fisher")
     return out
 

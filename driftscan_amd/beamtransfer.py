@@ -170,8 +170,6 @@ class BeamTransfer(config.Reader):
         if parallel.rank0():
             logger.info("Beam generation time: %f" % (time.time() - st))
 
-    generate_cache = generate
-
     generate_cache = generate  # beamtransfer.py: old name kept by the reference
 
     def _generate_dirs(self):
@@ -347,18 +345,22 @@ class BeamTransfer(config.Reader):
 
     @staticmethod
     def _cl_device(mat):
-        """(P,P,L,F,F) real sky covariance -> device (P,P,F,F,L) + mask of the non-zero pol pairs."""
+        """(P,P,L,F,F) real sky covariance -> device (P,P,F,F,L), mask of the non-zero pol pairs, and whether
+        the array is symmetric under f <-> f' (only then may dm_project_cov mirror the frequency blocks; the
+        reference, beamtransfer.py:1135-1188, takes any array)."""
         ctx = get_context()
         key = id(mat)
         cache = BeamTransfer._clcache
         if key not in cache or cache[key][0] is not mat:
             P = mat.shape[0]
-            mask = (np.abs(mat).reshape(P, P, -1).max(axis=-1) > 0).astype(np.int32)
-            dev = ctx.to_device(np.ascontiguousarray(np.asarray(mat, dtype=np.float64).transpose(0, 1, 3, 4, 2)))
+            m64 = np.asarray(mat, dtype=np.float64)
+            mask = (np.abs(m64).reshape(P, P, -1).max(axis=-1) > 0).astype(np.int32)
+            sym = bool(np.array_equal(m64, m64.swapaxes(3, 4)))
+            dev = ctx.to_device(np.ascontiguousarray(m64.transpose(0, 1, 3, 4, 2)))
             if len(cache) > 8:
                 cache.clear()
-            cache[key] = (mat, dev, mask)
-        return cache[key][1], cache[key][2]
+            cache[key] = (mat, dev, mask, sym)
+        return cache[key][1], cache[key][2], cache[key][3]
 
     _clcache = {}
 
@@ -370,9 +372,9 @@ class BeamTransfer(config.Reader):
         prods = [self._dev_products(mi) for mi in ms]
         bsvd = torch.stack([p["beam_svd"] for p in prods])
         svnum = np.stack([self._svd_num(mi)[0] for mi in ms])
-        cl, mask = self._cl_device(mat)
+        cl, mask, sym = self._cl_device(mat)
         ctx.project_cov(bsvd, svnum, cl, out, off, npol=1 if temponly else None, polmask=mask, l0=np.array(ms),
-                        zero_first=zero_first)
+                        zero_first=zero_first, symmetric=sym)
 
     def project_matrix_sky_to_svd(self, mi, mat, temponly=False):
         """Sky covariance [pol, pol, l, freq, freq] -> SVD basis [nsvd, nsvd]
@@ -470,9 +472,9 @@ class BeamTransfer(config.Reader):
         out = ctx.empty((max(tot, 1),), np.complex128)
         beam = ctx.to_device(np.ascontiguousarray(self.beam_m(mi).reshape(1, F, T, P, L)))
         svnum = np.full((1, F), T, dtype=np.int32)
-        cl, mask = self._cl_device(mat)
+        cl, mask, sym = self._cl_device(mat)
         ctx.project_cov(beam, svnum, cl, out, off, npol=1 if temponly else None, polmask=mask, l0=np.array([mi]),
-                        zero_first=True)
+                        zero_first=True, symmetric=sym)
         ctx.sync()
         return out[: n * n].cpu().numpy().reshape(F, T, F, T)
 

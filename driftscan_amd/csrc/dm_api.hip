@@ -11,7 +11,8 @@ int dm_zgemm_strided_batched(dm_ctx* ctx, int M, int N, int K, double alpha, con
                              const double* kscale, int64_t stride_kscale, int batch) {
   if (!ctx) return DM_EARG;
   DM_ARG(ctx, M >= 0 && N >= 0 && K >= 0 && batch >= 0 && A && B && C);
-  const size_t mark = dm_ws_mark(ctx);
+  dm_ws_scope ws_scope__(ctx);  // releases on every return path
+  const size_t mark = ws_scope__.mark;
   std::vector<dm_gemm_desc> g;
   g.reserve(batch);
   for (int b = 0; b < batch; ++b) {
@@ -25,10 +26,28 @@ int dm_zgemm_strided_batched(dm_ctx* ctx, int M, int N, int K, double alpha, con
   return rc;
 }
 
+int dm_zgemm_grouped(dm_ctx* ctx, int nprob, const dm_zgemm_problem* probs) {
+  if (!ctx) return DM_EARG;
+  DM_ARG(ctx, nprob >= 0 && (nprob == 0 || probs));
+  dm_ws_scope ws_scope__(ctx);
+  std::vector<dm_gemm_desc> g;
+  g.reserve(nprob);
+  for (int i = 0; i < nprob; ++i) {
+    const dm_zgemm_problem& p = probs[i];
+    DM_ARG(ctx, p.M >= 0 && p.N >= 0 && p.K >= 0);
+    if (p.M == 0 || p.N == 0) continue;
+    DM_ARG(ctx, p.A && p.B && p.C);
+    g.push_back(dm_gemm_make(reinterpret_cast<const cplx*>(p.A), p.rsA, p.csA, p.conjA != 0, p.B, p.rsB, p.csB,
+                             p.conjB != 0, reinterpret_cast<cplx*>(p.C), p.ldc, p.M, p.N, p.K, p.alpha, p.beta));
+  }
+  return dm_gemm_grouped_launch(ctx, g);
+}
+
 int dm_zpotrf_batched(dm_ctx* ctx, int n, void* A, int ld, int64_t stride, int batch, int* info_host) {
   if (!ctx) return DM_EARG;
   DM_ARG(ctx, n >= 0 && batch >= 0 && A && info_host);
-  const size_t mark = dm_ws_mark(ctx);
+  dm_ws_scope ws_scope__(ctx);  // releases on every return path
+  const size_t mark = ws_scope__.mark;
   std::vector<dm_mat> mats(batch);
   for (int b = 0; b < batch; ++b) mats[b] = dm_mat{reinterpret_cast<cplx*>(A) + b * stride, ld, n};
   int* info_dev = dm_ws_alloc_t<int>(ctx, batch > 0 ? batch : 1);
@@ -43,7 +62,8 @@ int dm_ztrsm_left_lower_batched(dm_ctx* ctx, int n, int nrhs, const void* L, int
                                 int ldb, int64_t strideB, int conjtrans, int batch) {
   if (!ctx) return DM_EARG;
   DM_ARG(ctx, n >= 0 && nrhs >= 0 && batch >= 0 && L && B);
-  const size_t mark = dm_ws_mark(ctx);
+  dm_ws_scope ws_scope__(ctx);  // releases on every return path
+  const size_t mark = ws_scope__.mark;
   std::vector<dm_trsm_problem> ps(batch);
   for (int b = 0; b < batch; ++b)
     ps[b] = dm_trsm_problem{reinterpret_cast<const cplx*>(L) + b * strideL, ldl, n,

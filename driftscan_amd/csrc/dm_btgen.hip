@@ -324,7 +324,8 @@ int dm_bt_beam_cyl(dm_ctx* ctx, int nside, const double* ring_cth_host, const do
   if (!ctx) return DM_EARG;
   DM_ARG(ctx, nside > 0 && ring_cth_host && ring_sth_host && frame_host && kind >= 0 && kind <= 2 && tab_x_host &&
                   tab_y_host && tab_y2_host && ntab >= 2 && out_dev);
-  const size_t mark = dm_ws_mark(ctx);
+  dm_ws_scope ws_scope__(ctx);  // releases on every return path
+  const size_t mark = ws_scope__.mark;
   geo_host gh;
   DM_TRY(upload_geo(ctx, nside, ring_cth_host, ring_sth_host, gh));
   std::vector<double> tx(tab_x_host, tab_x_host + ntab), ty(tab_y_host, tab_y_host + ntab),
@@ -354,7 +355,8 @@ int dm_bt_maps(dm_ctx* ctx, int nside, const double* ring_cth_host, const double
   DM_ARG(ctx, nside > 0 && ring_cth_host && ring_sth_host && frame_host && nbeam > 0 && beams_dev && ncol >= 0 &&
                   uv_host && bi_host && bj_host && maps_dev);
   if (ncol == 0) return DM_OK;
-  const size_t mark = dm_ws_mark(ctx);
+  dm_ws_scope ws_scope__(ctx);  // releases on every return path
+  const size_t mark = ws_scope__.mark;
   geo_host gh;
   DM_TRY(upload_geo(ctx, nside, ring_cth_host, ring_sth_host, gh));
   const int ncomp = polarised ? 2 : 1;
@@ -391,7 +393,8 @@ int dm_bt_sht_range(dm_ctx* ctx, int nside, const double* ring_cth_host, const d
                   lmax_grp <= lside && F > 0 && B > 0 && ncol >= 0 && col_f_host && col_b_host && col_lmax_host &&
                   maps_dev && beam_m_dev);
   if (ncol == 0) return DM_OK;
-  const size_t mark = dm_ws_mark(ctx);
+  dm_ws_scope ws_scope__(ctx);  // releases on every return path
+  const size_t mark = ws_scope__.mark;
   geo_host gh;
   DM_TRY(upload_geo(ctx, nside, ring_cth_host, ring_sth_host, gh));
   const int P = polarised ? 4 : 1;

@@ -192,7 +192,8 @@ __global__ __launch_bounds__(64) void diag_solve_kernel(const trsm_desc* __restr
 int dm_potrf_batched(dm_ctx* ctx, const std::vector<dm_mat>& mats, int* info_dev) {
   const int nbatch = (int)mats.size();
   if (nbatch == 0) return DM_OK;
-  const size_t mark = dm_ws_mark(ctx);
+  dm_ws_scope ws_scope__(ctx);  // releases on every return path
+  const size_t mark = ws_scope__.mark;
   std::vector<chol_desc> ds(nbatch);
   int maxn = 0;
   for (int i = 0; i < nbatch; ++i) {

@@ -97,6 +97,18 @@ void dm_ws_release(dm_ctx* ctx, size_t mark);
 int dm_upload(dm_ctx* ctx, void* dst, const void* src, size_t bytes);    // async H2D via pinned staging
 int dm_download(dm_ctx* ctx, void* dst, const void* src, size_t bytes);  // D2H + stream sync
 
+// RAII guard for the bump arena: every extern "C" entry point (and every internal driver that
+// allocates) opens one, so an early `return` after a failed launch or allocation cannot leave
+// ws_used above its entry value (dm_ctx_workspace_reset insists on an empty arena).
+struct dm_ws_scope {
+  dm_ctx* c;
+  size_t mark;
+  explicit dm_ws_scope(dm_ctx* ctx) : c(ctx), mark(dm_ws_mark(ctx)) {}
+  ~dm_ws_scope() { dm_ws_release(c, mark); }
+  dm_ws_scope(const dm_ws_scope&) = delete;
+  dm_ws_scope& operator=(const dm_ws_scope&) = delete;
+};
+
 template <typename T>
 static inline T* dm_ws_alloc_t(dm_ctx* ctx, size_t n) {
   return reinterpret_cast<T*>(dm_ws_alloc(ctx, n * sizeof(T)));

@@ -48,13 +48,14 @@ __global__ __launch_bounds__(256) void fisher_sum_chunks_kernel(const sum_desc* 
 extern "C" int dm_fisher(dm_ctx* ctx, int nblk, int F, int K, int P, int L, const void* beam_svd_dev,
                          const int* svnum_host, const int* l0_host, int nbands, const double* cl_bands_dev,
                          const void* evecs_dev, const int64_t* evecs_off_host, const int* nmodes_host,
-                         const double* evals_dev, const int64_t* evals_off_host, void* fisher_dev) {
+                         const double* evals_dev, const int64_t* evals_off_host, void* fisher_dev, int cl_symmetric) {
   if (!ctx) return DM_EARG;
   DM_ARG(ctx, nblk >= 0 && F > 0 && K > 0 && P > 0 && L > 0 && nbands > 0 && beam_svd_dev && svnum_host &&
                   cl_bands_dev && evecs_dev && evecs_off_host && nmodes_host && evals_dev && evals_off_host &&
                   fisher_dev);
   if (nblk == 0) return DM_OK;
-  const size_t mark = dm_ws_mark(ctx);
+  dm_ws_scope ws_scope__(ctx);  // releases on every return path
+  const size_t mark = ws_scope__.mark;
   const cplx* evecs = reinterpret_cast<const cplx*>(evecs_dev);
   cplx* fisher = reinterpret_cast<cplx*>(fisher_dev);
   DM_TRY(dm_fill_zero(ctx, fisher, sizeof(cplx) * (size_t)nblk * nbands * nbands));
@@ -96,7 +97,7 @@ extern "C" int dm_fisher(dm_ctx* ctx, int nblk, int F, int K, int P, int L, cons
   for (int a = 0; a < nbands; ++a) {
     // S_b = B C_l^a B^H (temperature block only: makeproj calls project_matrix_sky_to_svd(temponly=True))
     DM_TRY(dm_project_cov(ctx, nblk, F, K, P, L, beam_svd_dev, svnum_host, l0_host,
-                          cl_bands_dev + (size_t)a * F * F * L, 1, nullptr, S, offS.data(), 1));
+                          cl_bands_dev + (size_t)a * F * F * L, 1, nullptr, S, offS.data(), 1 | (cl_symmetric ? 2 : 0)));
     std::vector<dm_gemm_desc> g1, g2;
     for (int b = 0; b < nblk; ++b) {
       const int n = ndof[b], nm = nmodes_host[b];

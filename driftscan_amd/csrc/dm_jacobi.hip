@@ -675,7 +675,8 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
   if (sweeps_out) *sweeps_out = 0;
   if (np == 0) return DM_OK;
   DM_TRY(set_attrs(ctx));
-  const size_t mark = dm_ws_mark(ctx);
+  dm_ws_scope ws_scope__(ctx);  // releases on every return path
+  const size_t mark = ws_scope__.mark;
 
   std::vector<int> nrows(np);
   int maxrows = 0, maxcols = 0;
@@ -1058,7 +1059,8 @@ int dm_jacobi_herm(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, d
   if (sweeps_out) *sweeps_out = 0;
   if (np == 0) return DM_OK;
   DM_TRY(set_attrs(ctx));
-  const size_t mark = dm_ws_mark(ctx);
+  dm_ws_scope ws_scope__(ctx);  // releases on every return path
+  const size_t mark = ws_scope__.mark;
 
   std::vector<int> nrows(np);
   int maxn = 0;
@@ -1220,7 +1222,8 @@ int dm_sort_rows_by_key(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, d
                         bool descending) {
   const int np = (int)probs.size();
   if (np == 0) return DM_OK;
-  const size_t mark = dm_ws_mark(ctx);
+  dm_ws_scope ws_scope__(ctx);  // releases on every return path
+  const size_t mark = ws_scope__.mark;
   std::vector<jac_pdesc> pd(np);
   std::vector<size_t> toff(np);
   std::vector<int> nrows(np);

@@ -114,7 +114,8 @@ int dm_project_cov(dm_ctx* ctx, int nblk, int F, int K, int P, int L, const void
   if (!ctx) return DM_EARG;
   DM_ARG(ctx, nblk >= 0 && F > 0 && K > 0 && P > 0 && L > 0 && beam_svd_dev && svnum_host && cl_pfl_dev &&
                   out_dev && out_off_host && npol >= 1 && npol <= P);
-  const size_t mark = dm_ws_mark(ctx);
+  dm_ws_scope ws_scope__(ctx);  // releases on every return path
+  const size_t mark = ws_scope__.mark;
   const cplx* beam = reinterpret_cast<const cplx*>(beam_svd_dev);
   cplx* out = reinterpret_cast<cplx*>(out_dev);
   const int PL = P * L;
@@ -140,11 +141,14 @@ int dm_project_cov(dm_ctx* ctx, int nblk, int F, int K, int P, int L, const void
   }
   int2* d_gat = dm_ws_upload(ctx, gat);
   if (!d_gat) return DM_ENOMEM;
-  bool first_pair = zero_first != 0;
+  // `zero_first` carries two flag bits: 1 = clear the outputs first, 2 = the caller has verified
+  // cl[pi,pj,f,f',l] == cl[pi,pj,f',f,l] (frequency-symmetric covariance)
+  bool first_pair = (zero_first & 1) != 0;
   // When the output is overwritten and only diagonal pol pairs contribute (the usual sky models: C_l of
   // (T,T), (Q,Q), (U,U)), every pair's contribution is Hermitian: block (f, f') is the conjugate transpose of
   // (f', f).  Only the frequency blocks f' >= f are formed (half of the products) and mirrored afterwards.
-  bool herm = zero_first != 0 && !getenv("DM_COV_FULL");
+  // (the reference, beamtransfer.py:1135-1188, accepts any array: without the symmetry bit every block is formed)
+  bool herm = (zero_first & 1) != 0 && (zero_first & 2) != 0 && !getenv("DM_COV_FULL");
   for (int pi = 0; pi < npol && herm; ++pi)
     for (int pj = 0; pj < npol; ++pj)
       if (pi != pj && !(polmask_host && !polmask_host[pi * P + pj])) { herm = false; break; }
@@ -209,7 +213,8 @@ int dm_project_diag(dm_ctx* ctx, int nblk, int F, int K, int T, const void* beam
   if (!ctx) return DM_EARG;
   DM_ARG(ctx, nblk >= 0 && F > 0 && K > 0 && T > 0 && beam_ut_dev && svnum_host && dmat_dev && out_dev &&
                   out_off_host);
-  const size_t mark = dm_ws_mark(ctx);
+  dm_ws_scope ws_scope__(ctx);  // releases on every return path
+  const size_t mark = ws_scope__.mark;
   const cplx* ut = reinterpret_cast<const cplx*>(beam_ut_dev);
   cplx* out = reinterpret_cast<cplx*>(out_dev);
   std::vector<dm_gemm_desc> g;
@@ -237,7 +242,8 @@ int dm_regularise(dm_ctx* ctx, int nblk, const int* n_host, void* mats_dev, cons
   if (!ctx) return DM_EARG;
   DM_ARG(ctx, nblk >= 0 && n_host && mats_dev && off_host);
   if (nblk == 0) return DM_OK;
-  const size_t mark = dm_ws_mark(ctx);
+  dm_ws_scope ws_scope__(ctx);  // releases on every return path
+  const size_t mark = ws_scope__.mark;
   std::vector<blk_desc> bd(nblk);
   for (int b = 0; b < nblk; ++b) bd[b] = blk_desc{reinterpret_cast<cplx*>(mats_dev) + off_host[b], n_host[b]};
   blk_desc* d = dm_ws_upload(ctx, bd);
@@ -270,7 +276,8 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
   if (nkeep_host)
     for (int b = 0; b < nblk; ++b) nkeep_host[b] = n_host[b];
   if (nblk == 0) return DM_OK;
-  const size_t mark = dm_ws_mark(ctx);
+  dm_ws_scope ws_scope__(ctx);  // releases on every return path
+  const size_t mark = ws_scope__.mark;
   cplx* A = reinterpret_cast<cplx*>(A_dev);
   cplx* B = reinterpret_cast<cplx*>(B_dev);
   cplx* E = reinterpret_cast<cplx*>(evecs_dev);

@@ -115,7 +115,8 @@ extern "C" int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, c
   const int PL = P * L;
   const int K = std::min(L, T);
   const int ldz = PL + T;
-  const size_t mark = dm_ws_mark(ctx);
+  dm_ws_scope ws_scope__(ctx);  // releases on every return path
+  const size_t mark = ws_scope__.mark;
 
   const cplx* beam = reinterpret_cast<const cplx*>(beam_m_dev);
   cplx* beam_svd = reinterpret_cast<cplx*>(beam_svd_dev);

@@ -1592,7 +1592,8 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
                      dm_eig_select* sel) {
   const int np = (int)probs.size();
   if (np == 0) return DM_OK;
-  const size_t mark = dm_ws_mark(ctx);
+  dm_ws_scope ws_scope__(ctx);  // releases on every return path
+  const size_t mark = ws_scope__.mark;
   int maxn = 0;
   size_t tot = 0, totn = 0;
   std::vector<size_t> off(np), offn(np);

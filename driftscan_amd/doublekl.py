@@ -18,63 +18,124 @@ from .device import get_context
 class DoubleKL(kltransform.KLTransform):
     foreground_threshold = config.Property(proptype=float, default=100.0)
 
-    def _transform_batch(self, ms):
+    def _transform_batch(self, ms, to_host=True):
+        """Two-stage KL of several m at once (doublekl.py:30-87).  Every product of stage 2 — E C E^H for the
+        signal and noise matrices, the composition E2 E, the inverses — is ONE grouped launch over all live
+        blocks; nothing is copied to the host until the end."""
+        import torch
+
         ctx = get_context()
         nb = len(ms)
+        thr = float(self.foreground_threshold)
         # ---- stage 1: S vs F (use_thermal = False, doublekl.py:44-52)
         self.use_thermal = False
-        S, N, ndofs, off = self.sn_covariance_device(ms)
+        try:
+            S, N, ndofs, off = self.sn_covariance_device(ms)
+        finally:
+            self.use_thermal = True
+        ndofs = [int(n) for n in ndofs]
+        # Stage 2 needs the same S, and N with the thermal term at full strength instead of the 1 mK floor
+        # (kltransform.py:292-303): N2 = N1 + (1 - nc1) U diag(noise) U^H.  eigh_gen destroys its inputs,
+        # so keep copies instead of projecting both sky covariances a second time.
+        S2, N2 = S.clone(), N.clone()
+        N1 = N.clone() if self.inverse else None   # inv_gen(E1) = N1 E1^H needs the stage-1 noise matrix itself
         # only the modes with S/F strictly above the threshold are used below (doublekl.py:56-60): the others
-        # are not back-transformed (their rows of E1 stay zero); all eigenvalues are returned either way
-        ev1, evoff1, E1, ac1, _ = ctx.eigh_gen(S, N, ndofs, off,
-                                               cut=("upper", float(np.nextafter(self.foreground_threshold, np.inf))))
+        # are not back-transformed unless the inverse needs the whole of E1
+        cut1 = None if self.inverse else ("upper", float(np.nextafter(thr, np.inf)))
+        ev1, evoff1, E1, ac1, _ = ctx.eigh_gen(S, N, ndofs, off, cut=cut1)
+        del S, N
         ev1_h = ev1.cpu().numpy()
-        f_evals = [ev1_h[evoff1[i] : evoff1[i] + int(ndofs[i])].copy() for i in range(nb)]
-        # modes with S/F above the threshold: eigenvalues ascend, so they are the trailing rows
-        keep = [int((fe > self.foreground_threshold).sum()) for fe in f_evals]
-        results = [None] * nb
+        f_evals = [ev1_h[evoff1[i] : evoff1[i] + ndofs[i]].copy() for i in range(nb)]
+        # eigenvalues ascend, so the modes with S/F above the threshold are the trailing rows of E1
+        keep = [int((fe > thr).sum()) for fe in f_evals]
         live = [i for i in range(nb) if keep[i] > 0]
+        results = [None] * nb
         for i in range(nb):
             if ndofs[i] == 0:
                 results[i] = (np.array([]), np.array([[]]), np.array([[]]), {"ac": 0.0, "f_evals": np.array([])})
             elif keep[i] == 0:
-                n = int(ndofs[i])
-                results[i] = (np.array([]), np.zeros((0, n), dtype=np.complex128), None,
+                z = np.zeros((0, ndofs[i]), dtype=np.complex128)
+                results[i] = (np.array([]), z, z.copy() if self.inverse else None,
                               {"ac": float(ac1[i]), "f_evals": f_evals[i]})
-        if live:
-            # ---- stage 2: full S, N projected into the kept subspace (doublekl.py:70-80)
-            self.use_thermal = True
-            S2, N2, _, _ = self.sn_covariance_device(ms)
-            n2 = np.array([keep[i] for i in live], dtype=np.int64)
-            off2, tot2 = block_offsets(n2)
-            cs = ctx.empty((max(tot2, 1),), np.complex128)
-            cn = ctx.empty((max(tot2, 1),), np.complex128)
-            tmp_off = np.concatenate([[0], np.cumsum([keep[i] * int(ndofs[i]) for i in live])])
-            tmp = ctx.empty((max(int(tmp_off[-1]), 1),), np.complex128)
-            for src, dst in ((S2, cs), (N2, cn)):
-                for k, i in enumerate(live):
-                    n, r = int(ndofs[i]), keep[i]
-                    Ei = E1[off[i] + (n - r) * n : off[i] + n * n]          # kept rows of E (r x n)
-                    Ci = src[off[i] : off[i] + n * n]
-                    Ti = tmp[tmp_off[k] : tmp_off[k] + r * n]
-                    ctx.zgemm(Ei, Ci, Ti, r, n, n, rsA=n, csA=1, rsB=n, csB=1, ldc=n)               # E C
-                    ctx.zgemm(Ti, Ei, dst[off2[k] : off2[k] + r * r], r, r, n, rsA=n, csA=1, rsB=1, csB=n,
-                              conjB=True, ldc=r)                                                     # (E C) E^H
-            ev2, evoff2, E2, ac2, _ = ctx.eigh_gen(cs, cn, n2, off2)
-            ev2_h = ev2.cpu().numpy()
+        if not live:
+            return results
+
+        def rows_kept(i):  # kept rows of E1 (r x n)
+            n, r = ndofs[i], keep[i]
+            return E1[off[i] + (n - r) * n : off[i] + n * n]
+
+        # ---- stage 2 covariances (doublekl.py:70-74)
+        nc1 = (1e-3 / self.telescope.tsys_flat) ** 2
+        bt = self.beamtransfer
+        but = torch.stack([bt._dev_products(mi)["beam_ut"] for mi in ms])
+        svnum = np.stack([bt._svd_num(mi)[0] for mi in ms])
+        if self.use_thermal:  # always true here; spelled out to mirror sn_covariance
+            ctx.project_diag(but, svnum, ctx.to_device(self._npower(1.0)), N2, off, alpha=1.0 - nc1, accumulate=True)
+        n2 = np.array([keep[i] for i in live], dtype=np.int64)
+        off2, tot2 = block_offsets(n2)
+        rn = np.array([keep[i] * ndofs[i] for i in live], dtype=np.int64)
+        toff = np.concatenate([[0], np.cumsum(rn)])
+        cs = ctx.empty((max(tot2, 1),), np.complex128)
+        cn = ctx.empty((max(tot2, 1),), np.complex128)
+        tmp = ctx.empty((2, max(int(toff[-1]), 1)), np.complex128)
+        p1, p2 = [], []
+        for k, i in enumerate(live):
+            n, r = ndofs[i], keep[i]
+            Ei = rows_kept(i)
+            for j, (src, dst) in enumerate(((S2, cs), (N2, cn))):
+                Ti = tmp[j, toff[k] : toff[k] + r * n]
+                p1.append(dict(A=Ei, B=src[off[i] : off[i] + n * n], C=Ti, M=r, N=n, K=n, rsA=n, csA=1, rsB=n, csB=1, ldc=n))
+                p2.append(dict(A=Ti, B=Ei, C=dst[off2[k] : off2[k] + r * r], M=r, N=r, K=n, rsA=n, csA=1, rsB=1, csB=n,
+                               conjB=True, ldc=r))
+        ctx.zgemm_grouped(p1)   # E C
+        ctx.zgemm_grouped(p2)   # (E C) E^H
+        cn_keep = cn.clone() if self.inverse else None
+        # stage-2 modes below the S/N threshold are dropped by transform_save (kltransform.py:388-398)
+        cut2 = ("upper", self.threshold) if (self.subset and not self.inverse) else None
+        ev2, evoff2, E2, ac2, _ = ctx.eigh_gen(cs, cn, n2, off2, cut=cut2)
+        # ---- modes = E2 . E1[kept] (doublekl.py:80)
+        modes = ctx.empty((max(int(toff[-1]), 1),), np.complex128)
+        ctx.zgemm_grouped([dict(A=E2[off2[k] : off2[k] + keep[i] ** 2], B=rows_kept(i),
+                                C=modes[toff[k] : toff[k] + keep[i] * ndofs[i]], M=keep[i], N=ndofs[i], K=keep[i],
+                                rsA=keep[i], csA=1, rsB=ndofs[i], csB=1, ldc=ndofs[i]) for k, i in enumerate(live)])
+        inv = None
+        if self.inverse:
+            # doublekl.py:63-67, :83-85: inv = inv_gen(evecs2) . inv_gen(E1).T[ind].  With E N E^H = I the inverse of
+            # a mode matrix is N E^H, so inv_gen(E1).T = conj(E1 N1) and inv_gen(evecs2) = inv(E2^H) = E2 N2'.
+            for k, i in enumerate(live):   # the non-positive-definite rescue shifted diag(N) (kltransform.py:101-111)
+                if ac1[i] != 0.0:
+                    N1[off[i] : off[i] + ndofs[i] ** 2].view(ndofs[i], ndofs[i]).diagonal().add_(float(ac1[i]))
+                if ac2[k] != 0.0:
+                    cn_keep[off2[k] : off2[k] + keep[i] ** 2].view(keep[i], keep[i]).diagonal().add_(float(ac2[k]))
+            inv1 = tmp[0]
+            inv2 = ctx.empty((max(tot2, 1),), np.complex128)
+            q1, q2, q3 = [], [], []
+            inv = ctx.empty((max(int(toff[-1]), 1),), np.complex128)
             for k, i in enumerate(live):
-                n, r = int(ndofs[i]), keep[i]
-                Ei = E1[off[i] + (n - r) * n : off[i] + n * n]
-                out = ctx.empty((r * n,), np.complex128)
-                # rows of E2 are the stage-2 modes in the stage-1 basis: modes = E2 . E
-                ctx.zgemm(E2[off2[k] : off2[k] + r * r], Ei, out, r, n, r, rsA=r, csA=1, rsB=n, csB=1, ldc=n)
-                ctx.sync()
-                evecs = out.cpu().numpy().reshape(r, n)
-                inv = None
-                if self.inverse:
-                    inv = kltransform._inv_gen(evecs).T
-                results[i] = (ev2_h[evoff2[k] : evoff2[k] + r].copy(), evecs, inv,
-                              {"ac": float(ac2[k]), "f_evals": f_evals[i]})
+                n, r = ndofs[i], keep[i]
+                q1.append(dict(A=rows_kept(i), B=N1[off[i] : off[i] + n * n], C=inv1[toff[k] : toff[k] + r * n], M=r, N=n, K=n,
+                               rsA=n, csA=1, rsB=n, csB=1, ldc=n, conjA=True, conjB=True))
+                q2.append(dict(A=E2[off2[k] : off2[k] + r * r], B=cn_keep[off2[k] : off2[k] + r * r],
+                               C=inv2[off2[k] : off2[k] + r * r], M=r, N=r, K=r, rsA=r, csA=1, rsB=r, csB=1, ldc=r))
+                q3.append(dict(A=inv2[off2[k] : off2[k] + r * r], B=inv1[toff[k] : toff[k] + r * n],
+                               C=inv[toff[k] : toff[k] + r * n], M=r, N=n, K=r, rsA=r, csA=1, rsB=n, csB=1, ldc=n))
+            ctx.zgemm_grouped(q1 + q2)
+            ctx.zgemm_grouped(q3)
+        if not to_host:
+            for k, i in enumerate(live):
+                n, r = ndofs[i], keep[i]
+                results[i] = (ev2[evoff2[k] : evoff2[k] + r], modes[toff[k] : toff[k] + r * n].view(r, n),
+                              None if inv is None else inv[toff[k] : toff[k] + r * n].view(r, n),
+                              {"ac": float(ac1[i]), "f_evals": f_evals[i]})
+            return results
+        ev2_h = ev2.cpu().numpy()
+        modes_h = ctx.to_host(modes)
+        inv_h = ctx.to_host(inv) if inv is not None else None
+        for k, i in enumerate(live):
+            n, r = ndofs[i], keep[i]
+            results[i] = (ev2_h[evoff2[k] : evoff2[k] + r].copy(), modes_h[toff[k] : toff[k] + r * n].reshape(r, n),
+                          None if inv_h is None else inv_h[toff[k] : toff[k] + r * n].reshape(r, n),
+                          {"ac": float(ac1[i]), "f_evals": f_evals[i]})   # `ac` is the stage-1 value (doublekl.py:58)
         return results
 
     def _ev_save_hook(self, f, evextra):

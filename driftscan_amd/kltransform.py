@@ -152,12 +152,17 @@ class KLTransform(config.Reader):
             ctx.sync()
             torch.cuda.empty_cache()
             ctx.workspace_reset(int(need))
+        Nk = N.clone() if self.inverse else None  # eigh_gen destroys its inputs; the inverse is N E^H (below)
         evals, evoff, evecs, ac, sweeps = ctx.eigh_gen(S, N, ndofs, off, cut=cut)
+        ev_h = evals.cpu().numpy()
+        inv = None
+        if self.inverse:
+            inv = self._inverse_device(ctx, evecs, Nk, ndofs, off, ac, [ev_h[evoff[i] : evoff[i + 1]] for i in range(len(ms))])
         if not to_host:
             return [(evals[evoff[i] : evoff[i] + int(ndofs[i])],
-                     evecs[off[i] : off[i] + int(ndofs[i]) ** 2].view(int(ndofs[i]), int(ndofs[i])), None,
+                     evecs[off[i] : off[i] + int(ndofs[i]) ** 2].view(int(ndofs[i]), int(ndofs[i])),
+                     None if inv is None else inv[off[i] : off[i] + int(ndofs[i]) ** 2].view(int(ndofs[i]), int(ndofs[i])),
                      {"ac": float(ac[i])}) for i in range(len(ms))]
-        ev_h = evals.cpu().numpy()
         out = []
         for i, mi in enumerate(ms):
             n = int(ndofs[i])
@@ -165,21 +170,45 @@ class KLTransform(config.Reader):
                 out.append((np.array([]), np.array([[]]), np.array([[]]), {"ac": 0.0}))
                 continue
             E = ctx.to_host(evecs[off[i] : off[i] + n * n]).reshape(n, n)
-            inv = None
-            if self.inverse:
-                inv = _inv_gen(E).T
-            out.append((ev_h[evoff[i] : evoff[i] + n].copy(), E, inv, {"ac": float(ac[i])}))
+            inv_i = None if inv is None else ctx.to_host(inv[off[i] : off[i] + n * n]).reshape(n, n)
+            out.append((ev_h[evoff[i] : evoff[i] + n].copy(), E, inv_i, {"ac": float(ac[i])}))
         return out
+
+    @staticmethod
+    def _inverse_device(ctx, evecs, Nk, ndofs, off, ac, evals_host):
+        """`inv_gen(evecs).T` of the reference (kltransform.py:124-143, :346-347) for every block, on the device:
+        the modes satisfy E (N + ac I) E^H = I, so E^-1 = (N + ac I) E^H and its transpose is conj(E (N + ac I)) —
+        one grouped product instead of an LU inversion per m on the host.  The all-zero shortcut of eigh_gen
+        (kltransform.py:81-85) returns the identity, whose inverse is the identity."""
+        import torch
+
+        inv = ctx.empty((max(int(evecs.numel()), 1),), np.complex128)
+        probs = []
+        for i, n in enumerate(int(x) for x in ndofs):
+            if n == 0:
+                continue
+            blk = slice(int(off[i]), int(off[i]) + n * n)
+            if not np.any(evals_host[i]):
+                inv[blk].view(n, n).copy_(torch.eye(n, dtype=torch.complex128, device=inv.device))
+                continue
+            if ac[i] != 0.0:
+                Nk[blk].view(n, n).diagonal().add_(float(ac[i]))
+            probs.append(dict(A=evecs[blk], B=Nk[blk], C=inv[blk], M=n, N=n, K=n, rsA=n, csA=1, rsB=n, csB=1, ldc=n,
+                              conjA=True, conjB=True))
+        ctx.zgemm_grouped(probs)
+        return inv
 
     def _transform_m(self, mi):
         return self._transform_batch([mi])[0]
 
-    def _save(self, mi, evals, evecs, inv, evextra):
-        """Write ev_m_<m>.hdf5 (kltransform.py:377-421)."""
+    def _save(self, mi, evals, evecs, inv, evextra, nside=None):
+        """Write ev_m_<m>.hdf5 (kltransform.py:377-421).  `nside` (= ndof of the m) is looked up by the
+        submitting thread: the accessors behind it keep a last-call cache that the writer threads must not share."""
+        if nside is None:
+            nside = int(self.beamtransfer.ndof(mi))
         with storage.File(self._evfile % mi, "w") as f:
             f.attrs["m"] = mi
             f.attrs["SUBSET"] = bool(self.subset)
-            nside = int(self.beamtransfer.ndof(mi))
             evalsf = np.zeros(nside, dtype=np.float64)
             if evals.size != 0:
                 evalsf[-evals.size :] = evals
@@ -233,7 +262,8 @@ class KLTransform(config.Reader):
         todo = [mi for mi in self.beamtransfer._my_ms() if regen or not os.path.exists(self._evfile % mi)]
         for batch in self._batches(todo):
             for mi, res in zip(batch, self._transform_batch(batch)):
-                storage.submit(self._save, mi, *res)   # written in the background while the next batch is computed
+                # written in the background while the next batch is computed
+                storage.submit(self._save, mi, *res, int(self.beamtransfer.ndof(mi)))
         storage.flush()
         parallel.barrier()
         if parallel.rank0():
@@ -352,12 +382,3 @@ class KLTransform(config.Reader):
 
     def project_matrix_sky_to_kl(self, mi, mat, threshold=None):
         return self.project_matrix_svd_to_kl(mi, self.beamtransfer.project_matrix_sky_to_svd(mi, mat), threshold)
-
-
-def _inv_gen(A):
-    """Inverse of the mode matrix (kltransform.py:124-143); small, host LAPACK is fine for this
-    optional product (off the generation path unless `inverse` is set)."""
-    try:
-        return np.linalg.inv(A)
-    except np.linalg.LinAlgError:
-        return np.linalg.pinv(A)

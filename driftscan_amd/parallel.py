@@ -79,6 +79,27 @@ def partition(items, costs=None):
     return sorted(mine, key=items.index)
 
 
+def partition_contiguous(items, costs, n=None, r=None):
+    """Contiguous ranges of `items` with (nearly) equal summed cost: the slice this rank owns.  Beam-transfer
+    generation produces a contiguous range of m per call, so a rank that keeps its blocks in HBM from
+    generation to the KL stage owns a range; the boundaries follow the cost model instead of the reference's
+    equal-count split (caput.mpiutil.partition_list_mpi).  Every rank gets at least one item while items last."""
+    items = list(items)
+    n = size() if n is None else n
+    r = rank() if r is None else r
+    if n == 1:
+        return items
+    c = np.cumsum(np.asarray(costs, dtype=np.float64))
+    total = float(c[-1]) if len(items) else 0.0
+    bounds = [0]
+    for k in range(1, n):
+        b = int(np.searchsorted(c, total * k / n, side="left")) + 1
+        b = min(max(b, bounds[-1] + 1), max(len(items) - (n - k), bounds[-1]))
+        bounds.append(b)
+    bounds.append(len(items))
+    return items[bounds[r] : bounds[r + 1]]
+
+
 def gather_objects(obj):
     """Gather picklable objects to rank 0 (list over ranks there, None elsewhere)."""
     d = _dist()

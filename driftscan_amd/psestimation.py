@@ -263,11 +263,13 @@ class PSExact(PSEstimation):
         # (nbands, L, F, F) -> (nbands, F, F, L): the contraction index innermost, as dm_project_cov reads it
         cache = self.__dict__.get("_cl_dev")
         if cache is None or cache[0] is not self.clarray or cache[1].device.index != ctx.device:
-            cache = (self.clarray,
-                     ctx.to_device(np.ascontiguousarray(np.asarray(self.clarray, dtype=np.float64).transpose(0, 2, 3, 1))))
+            c64 = np.asarray(self.clarray, dtype=np.float64)
+            cache = (self.clarray, ctx.to_device(np.ascontiguousarray(c64.transpose(0, 2, 3, 1))),
+                     bool(np.array_equal(c64, c64.swapaxes(2, 3))))  # f <-> f' symmetry, checked not assumed
             self.__dict__["_cl_dev"] = cache  # the band tables do not change between batches (151 MB at config 3)
         cl = cache[1]
-        F = ctx.fisher(bsvd, svnum, np.array(ms), cl, ctx.to_device(Eh), eoff, nmodes, ctx.to_device(Vh), voff)
+        F = ctx.fisher(bsvd, svnum, np.array(ms), cl, ctx.to_device(Eh), eoff, nmodes, ctx.to_device(Vh), voff,
+                       cl_symmetric=cache[2])
         Fh = F.cpu().numpy()
         return [(Fh[i], np.zeros(nb, dtype=np.complex128)) if nmodes[i] > 0 else zero for i in range(len(ms))]
 

@@ -125,8 +125,11 @@ def File(path, mode="r", **kwargs):
 # Product files are independent per m: they are written by a small thread pool while the GPU works on
 # the next batch (file output is 10x the compute time of BASELINE configs[1] when done inline).
 # DRIFTMI_IO_THREADS = 0 writes inline.
+import threading
+
 _pool = None
 _pending = []
+_plock = threading.Lock()   # submit() may be called from several driver threads (bench --streams)
 
 
 def submit(fn, *args):
@@ -136,19 +139,27 @@ def submit(fn, *args):
     if nthreads <= 0:
         fn(*args)
         return
-    if _pool is None:
-        from concurrent.futures import ThreadPoolExecutor
+    with _plock:
+        if _pool is None:
+            from concurrent.futures import ThreadPoolExecutor
 
-        _pool = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="driftmi-io")
-    while len(_pending) >= 4 * nthreads:   # bound the host memory held by queued products
-        _pending.pop(0).result()
-    _pending.append(_pool.submit(fn, *args))
+            _pool = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="driftmi-io")
+        wait = []
+        while len(_pending) >= 4 * nthreads:   # bound the host memory held by queued products
+            wait.append(_pending.pop(0))
+        _pending.append(_pool.submit(fn, *args))
+    for w in wait:
+        w.result()
 
 
 def flush():
     """Wait for every queued write (re-raises the first failure).  Called before anything reads the files."""
-    while _pending:
-        _pending.pop(0).result()
+    while True:
+        with _plock:
+            if not _pending:
+                return
+            w = _pending.pop(0)
+        w.result()
 
 
 def can_open(path):

@@ -14,14 +14,17 @@ def natpattern(n):
 
 
 def cache_last(func):
-    """Remember the result of the most recent call (same args -> same object back)."""
-    state = {"args": None, "kwargs": None, "ret": None, "set": False}
+    """Remember the result of the most recent call (same args -> same object back).  The (arguments, result)
+    pair is replaced in one assignment, so a reader on another thread (the background file writers call the
+    accessors too) can never pair one call's arguments with another call's result."""
+    state = [None]  # (args, kwargs, ret) of the last call
 
     @functools.wraps(func)
     def wrapper(*args, **kwargs):
-        if not state["set"] or args != state["args"] or kwargs != state["kwargs"]:
-            state["ret"] = func(*args, **kwargs)
-            state["args"], state["kwargs"], state["set"] = args, kwargs, True
-        return state["ret"]
+        last = state[0]
+        if last is None or args != last[0] or kwargs != last[1]:
+            last = (args, kwargs, func(*args, **kwargs))
+            state[0] = last
+        return last[2]
 
     return wrapper

@@ -63,6 +63,22 @@ int dm_zgemm_strided_batched(dm_ctx* ctx, int M, int N, int K, double alpha, con
                              int64_t strideB, double beta, void* C_dev, int ldc, int64_t strideC,
                              const double* kscale_dev, int64_t stride_kscale, int batch);
 
+/* The same product for a ragged group: `nprob` independent problems of different shapes in ONE launch
+ * (every 64x64 output tile of every problem is a workgroup).  Used where the reference loops over m or
+ * frequency with one np.dot per iteration.
+ * Replaces: np.dot at drift/core/doublekl.py:73-74, :80, :85; drift/core/kltransform.py:124-143 (inv_gen,
+ * formed here as N E^H from E N E^H = I). */
+typedef struct dm_zgemm_problem {
+  const void* A;  /* device c128, viewed (M x K) through element strides (rsA, csA) */
+  const void* B;  /* device c128, viewed (K x N) through (rsB, csB) */
+  void* C;        /* device c128, row-major, leading dimension ldc */
+  int M, N, K;
+  int rsA, csA, rsB, csB, ldc;
+  int conjA, conjB;
+  double alpha, beta;
+} dm_zgemm_problem;
+int dm_zgemm_grouped(dm_ctx* ctx, int nprob, const dm_zgemm_problem* probs_host);
+
 /* Batched lower Cholesky A = L L^H in place (n x n, row-major, ld), `batch`
  * matrices `stride` elements apart.  info_host[i] = 0 or the order of the first
  * non-positive-definite leading minor.  Synchronises.
@@ -127,7 +143,11 @@ int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, const void* 
  *   npol         pol pairs looped: P, or 1 for `temponly`
  *   polmask_host (P*P) int or NULL: non-zero where cl[pi,pj] is not identically zero
  *   out_dev      c128, block b is (ndof_b x ndof_b) row-major at element offset out_off_host[b]
- *   zero_first   clear the outputs before accumulating
+ *   zero_first   flag bits: 1 = clear the outputs before accumulating; 2 = the caller has checked that
+ *                cl[pi,pj,f,f',l] == cl[pi,pj,f',f,l] for every pair it passes (the usual sky models): together
+ *                with bit 1 and a pol mask without off-diagonal pairs the result is Hermitian block by block and
+ *                only the frequency blocks f' >= f are formed, the others mirrored.  Without bit 2 every block
+ *                is formed, as the reference does for an arbitrary array.
  * Replaces: BeamTransfer.project_matrix_sky_to_svd, drift/core/beamtransfer.py:1135-1188. */
 int dm_project_cov(dm_ctx* ctx, int nblk, int F, int K, int P, int L, const void* beam_svd_dev,
                    const int* svnum_host, const int* l0_host, const double* cl_pfl_dev, int npol,
@@ -168,13 +188,14 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
  *   evecs_dev + evecs_off_host[b]       (nmodes_host[b] x ndof_b) c128, rows = KL modes above the threshold
  *   evals_dev + evals_off_host[b]       their eigenvalues (f64)
  *   fisher_dev (nblk, nbands, nbands) c128  out (zero for blocks without modes)
+ *   cl_symmetric  non-zero when cl_bands[a,f,f',l] == cl_bands[a,f',f,l] was checked by the caller (see dm_project_cov)
  * Synchronises.
  * Replaces: PSExact.makeproj + _work_fisher_bias_m, drift/core/psestimation.py:672-699, :775-815
  * (the bias of PSExact is identically zero, :797). */
 int dm_fisher(dm_ctx* ctx, int nblk, int F, int K, int P, int L, const void* beam_svd_dev, const int* svnum_host,
               const int* l0_host, int nbands, const double* cl_bands_dev, const void* evecs_dev,
               const int64_t* evecs_off_host, const int* nmodes_host, const double* evals_dev,
-              const int64_t* evals_off_host, void* fisher_dev);
+              const int64_t* evals_off_host, void* fisher_dev, int cl_symmetric);
 
 /* ---- beam-transfer generation (cylinder telescopes) --------------------------- */
 /* Host geometry shared by the three calls below: ring_cth_host / ring_sth_host hold

@@ -284,11 +284,13 @@ def ring_dft(maps, nside, mlist, sign=+1):
     return out
 
 
-def transfer_single(maps, nside, lmax, lside, polarised):
+def transfer_single(maps, nside, lmax, lside, polarised, mabs=None):
     """The reference's ``_transfer_single``: conj(SHT(conj(map))) zero-embedded into
     (P, lside+1, 2*lside+1) with non-centred m (negative m wrapped to the end).
 
     maps: (npix,) complex for unpolarised, (4, npix) [I, Q, U, V] for polarised.
+    mabs: optional list of |m|: only the columns +m and -m of those are filled (the rest stay zero) —
+    the full-size parity tests compare a few m of a 3.1 Mpixel map and cannot afford all 1025 columns.
     """
     z, nphi, phi0, start = ring_info(nside)
     npix = 12 * nside**2
@@ -297,6 +299,9 @@ def transfer_single(maps, nside, lmax, lside, polarised):
     maps = np.asarray(maps).reshape(P, npix)
     out = np.zeros((P, lside + 1, 2 * lside + 1), dtype=np.complex128)
     ms = np.arange(-lmax, lmax + 1)
+    if mabs is not None:
+        keep = sorted({int(a) for a in mabs if 0 <= int(a) <= lmax})
+        ms = np.array(sorted({-a for a in keep} | set(keep)), dtype=np.int64)
     G = ring_dft(maps, nside, ms, sign=+1)  # (nm, nring, P): conj-trick turns e^{-im phi} into e^{+im phi}
     for mi, m in enumerate(ms):
         am = abs(m)
@@ -394,7 +399,7 @@ def beam_transfer_m(tel, mlist=None):
                 om_i = np.sum(np.abs(beams[0]) ** 2 * hz) * pxarea
                 om_j = np.sum(np.abs(beams[1]) ** 2 * hz) * pxarea
                 maps = hz * fr * beams[0] * beams[1].conjugate() / np.sqrt(om_i * om_j)
-            t = transfer_single(maps, nside, lmax_bf, lside, pol)
+            t = transfer_single(maps, nside, lmax_bf, lside, pol, mabs=mlist)
             for m in mlist:
                 out[m][f, 0, b, :, m:] = t[:, m:, m]
                 if m > 0:

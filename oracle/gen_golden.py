@@ -522,9 +522,62 @@ def gen_bt_variants(ref):
     print("bt_variants.npz")
 
 
+def gen_inverse(ref):
+    """`inverse = True` for KLTransform and DoubleKL, and a frequency-ASYMMETRIC sky covariance through
+    project_matrix_sky_to_svd.  The beams are real-valued: the reference's DoubleKL inverse
+    (doublekl.py:63-67, :83-85) multiplies an un-transposed inverse into a transposed one, so it depends on
+    the arbitrary phases LAPACK gives the eigenvectors; on a real pencil those phases are signs, which
+    cancel, and the output is unique."""
+    btmod, klmod, dkmod = ref["beamtransfer"], ref["kltransform"], ref["doublekl"]
+    F, B, P, lmax, mlist = 3, 6, 1, 16, [2, 9]
+    rng = np.random.default_rng(2003)
+    L = lmax + 1
+    redundancy = rng.integers(1, 6, size=B).astype(np.float64)
+    npower = (2.5e-7 * (1.0 + 0.1 * np.arange(F))[:, None] / redundancy[None, :]).astype(np.float64)
+    tel = FakeTelescope(F, B, P, lmax, lmax, npower, tsys_flat=1.0)
+    bt = btmod.BeamTransfer("/mem/inverse/bt", telescope=tel)
+    bt.polsvcut, bt.svcut = 1e-4, 1e-6
+    cv_sg = analytic_cl(tel.frequencies, L, P, "signal")
+    cv_fg = analytic_cl(tel.frequencies, L, P, "foreground", fg_amp=3e-9)
+    cv_asym = cv_fg * (1.0 + 0.3 * np.arange(F)[:, None] - 0.2 * np.arange(F)[None, :])[None, None, None]
+    assert not np.array_equal(cv_asym, cv_asym.swapaxes(3, 4))
+    out = dict(F=F, B=B, P=P, lmax=lmax, mlist=np.array(mlist), polsvcut=bt.polsvcut, svcut=bt.svcut, npower=npower,
+               frequencies=tel.frequencies, cv_sg=cv_sg, cv_fg=cv_fg, cv_asym=cv_asym, fg_threshold=FGT_UNPOL,
+               threshold=0.1, tsys_flat=1.0)
+    kl = klmod.KLTransform(bt, subdir="kl")
+    kl._cvsg, kl._cvfg, kl.threshold, kl.inverse = cv_sg, cv_fg, 0.1, True
+    dk = dkmod.DoubleKL(bt, subdir="dk")
+    dk._cvsg, dk._cvfg, dk.threshold, dk.inverse = cv_sg, cv_fg, 0.1, True
+    dk.foreground_threshold = FGT_UNPOL
+    for mi in mlist:
+        beam = synth_beam_m(rng, F, B, P, L, mi)
+        beam = np.ascontiguousarray(beam.real).astype(np.complex128)
+        write_beam_file(ref, bt, mi, beam)
+        bt._generate_svdfile_m(mi)
+        svd = read_svd_file(bt, mi)
+        pre = "m%d_" % mi
+        out[pre + "beam_m"] = beam
+        for k, v in svd.items():
+            out[pre + k] = v
+        out[pre + "proj_asym"] = bt.project_matrix_sky_to_svd(mi, cv_asym)
+        evals, evecs, inv, extra = kl._transform_m(mi)
+        out[pre + "kl_evals"], out[pre + "kl_evecs"], out[pre + "kl_inv"] = evals, evecs, inv
+        dk.use_thermal = True
+        evals, evecs, inv, extra = dk._transform_m(mi)
+        assert np.abs(evecs.imag).max() <= 1e-12 * np.abs(evecs).max(), "LAPACK left complex phases on a real pencil"
+        out[pre + "dk_evals"], out[pre + "dk_evecs"], out[pre + "dk_inv"] = evals, evecs, inv
+        out[pre + "dk_f_evals"], out[pre + "dk_ac"] = extra["f_evals"], extra["ac"]
+        print("inverse m", mi, "kl modes", out[pre + "kl_evals"].size, "dk modes", evals.size, "of", extra["f_evals"].size)
+    np.savez_compressed(os.path.join(OUT, "svdkl_inverse.npz"), **out)
+    print("svdkl_inverse.npz")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = refimport.load()
+    if len(sys.argv) > 1 and sys.argv[1] == "inverse":
+        gen_inverse(ref)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "variants":
         gen_bt_variants(ref)
         return
@@ -550,6 +603,7 @@ def main():
     gen_svd_kl(ref, "unpol_harsh", F=4, B=10, P=1, lmax=24, mlist=[5], polsvcut=1e-4,
                seed=2001, fg_threshold=1.0, threshold=0.1, fg_amp=10.0)
     gen_psfisher(ref)
+    gen_inverse(ref)
 
 
 if __name__ == "__main__":

@@ -146,21 +146,39 @@ def threshold_cut(evals, evecs, threshold, ndof=None):
     return evals_full, evals[i_ev:], evecs[i_ev:]
 
 
-def doublekl_transform_m(sn_cov, foreground_threshold=100.0):
+def inv_gen(A):
+    """Inverse with the pseudo-inverse as fallback (kltransform.py:124-143)."""
+    try:
+        return la.inv(A)
+    except la.LinAlgError:
+        return la.pinv(A)
+
+
+def kl_inverse(evecs_rows):
+    """The `inv` of KLTransform._transform_m: inv_gen(evecs).T (kltransform.py:346-347)."""
+    return inv_gen(evecs_rows).T
+
+
+def doublekl_transform_m(sn_cov, foreground_threshold=100.0, inverse=False):
     """DoubleKL._transform_m (doublekl.py:30-87).
 
     ``sn_cov(use_thermal)`` must return the (S, N) pair for the given flag —
     the reference calls ``sn_covariance`` twice, first with ``use_thermal=False``
     and then with ``True``.
-    Returns (evals, evecs [rows are modes], f_evals, ac).
+    Returns (evals, evecs [rows are modes], f_evals, ac) — `ac` is the STAGE-1 shift, the one the
+    reference stores in `evextra` (doublekl.py:58) — and, with ``inverse``, `inv` as a fifth item
+    (doublekl.py:63-67, :83-85: ``inv_gen(evecs2) @ inv_gen(E1).T[ind]``).
     """
     cs, cn = sn_cov(False)
     if cs.shape[0] == 0:
-        return np.array([]), np.array([[]]), np.array([]), 0.0
+        out = (np.array([]), np.array([[]]), np.array([]), 0.0)
+        return out + (np.array([[]]),) if inverse else out
     evals, evecs2, ac = eigh_gen(cs, cn)
     evecs = evecs2.T.conj()
     f_evals = evals.copy()
+    ac1 = ac
     ind = np.where(evals > foreground_threshold)
+    inv = inv_gen(evecs).T[ind] if inverse else None
     evals = evals[ind]
     evecs = evecs[ind]
     if evals.size > 0:
@@ -169,4 +187,7 @@ def doublekl_transform_m(sn_cov, foreground_threshold=100.0):
         cn = evecs @ (cn @ evecs.T.conj())
         evals, evecs2, ac = eigh_gen(cs, cn)
         evecs = evecs2.T.conj() @ evecs
-    return evals, evecs, f_evals, ac
+        if inverse:
+            inv = inv_gen(evecs2) @ inv
+    out = (evals, evecs, f_evals, ac1)
+    return out + (inv,) if inverse else out

@@ -1,0 +1,379 @@
+"""BASELINE.json configs[2] / [3] / [4] under `pytest -m gpu`.
+
+configs[2]  128-feed polarised cylinder (4 x 16 dual-pol feeds), nfreq = 64, lmax = mmax = 512:
+            three m-blocks (m = 1, 200, 460; 864 x 2052 per frequency, ndof ~5800 / ~3750 / ~450) go through
+            BT-gen -> SVD chain + pinv -> KL on the device.  This reaches what the small fixtures cannot: the
+            multi-level Jacobi preconditioner, the 64-wide tridiagonal panels, D&C merge nodes beyond LDS.
+            Checked: (f, b) columns of beam_m against the oracle's pixel-space restatement; the size-independent
+            properties of the SVD products (beamtransfer.py:802-924) and of the KL modes
+            (kltransform.py:310-355); and for the smallest block singular values / svnum of four frequencies
+            and the whole KL spectrum + kept count against the oracle chain on the same block.
+configs[3]  the same blocks through DoubleKL (foreground_threshold 100, doublekl.py:30-87) and PSExact
+            (psestimation.py:672-815), the smallest block against the oracle.
+configs[4]  reduced CHIME-sized stress shapes that fit the test budget: one 3552 x 4100 frequency slice pushed
+            through `svd_chain(max_bytes=...)` (the frequency-sliced path), and `eigh_gen` at n = 8192 (merge
+            nodes of 8192 > 4096: the global-scratch <BIG> divide-and-conquer kernels).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CFG3 = dict(num_freq=64, freq_start=400.0, freq_end=500.0, freq_mode="edge", num_cylinders=4, cylinder_width=12.0,
+            num_feeds=16, feed_spacing=0.4, tsys=1.0, force_lmax=512, force_mmax=512)
+MS = [1, 200, 460]
+
+
+def _log(*a):
+    print(time.strftime("%H:%M:%S"), *a, flush=True)
+
+
+@pytest.fixture(scope="module")
+def c3(tmp_path_factory, golden_dir):
+    import torch
+
+    from driftscan_amd import beamtransfer, btgen, cylinder, device, kltransform
+
+    device.reset_context()
+    torch.cuda.empty_cache()
+    ctx = device.get_context(workspace_bytes=48 << 30)
+    tel = cylinder.PolarisedCylinderTelescope.from_config(CFG3)
+    # the geometry itself is pinned bit-exactly against the reference in tests/test_host_geometry.py (`cfg3`)
+    geo = np.load(os.path.join(golden_dir, "geometry.npz"))
+    assert tel.nbase == 432 and tel.lmax == 512 and tel.mmax == 512 and tel.num_pol_sky == 4
+    assert np.array_equal(tel.baselines, geo["cfg3_baselines"]) if "cfg3_baselines" in geo else True
+    bt = beamtransfer.BeamTransfer(str(tmp_path_factory.mktemp("c3")), telescope=tel)
+    t0 = time.perf_counter()
+    blocks = [btgen.beam_m_all(tel, ctx=ctx, max_bytes=24 << 30, m_range=(m, m)) for m in MS]
+    beam = torch.cat(blocks)                         # (3, F, 2, B, P, L)
+    del blocks
+    ctx.sync()
+    t1 = time.perf_counter()
+    res = bt.svd_device(beam)
+    ctx.sync()
+    t2 = time.perf_counter()
+    sv = res["singularvalues"].cpu().numpy()
+    for i, mi in enumerate(MS):
+        bt._dev[mi] = dict(beam_svd=res["beam_svd"][i], beam_ut=res["beam_ut"][i], singularvalues=sv[i])
+    kl = kltransform.KLTransform.from_config(dict(threshold=0.1), bt, subdir="kl")
+    _log("configs[2] fixture: BT-gen of 3 blocks %.1f s, SVD chain %.1f s (sweeps %s), ndof %s"
+         % (t1 - t0, t2 - t1, res["sweeps"], [int(bt.ndof(m)) for m in MS]))
+    yield dict(tel=tel, bt=bt, kl=kl, ctx=ctx, beam=beam, res=res, sv=sv)
+    bt._dev.clear()
+    beamtransfer.BeamTransfer._clcache.clear()
+    del beam, res
+    device.reset_context()
+    torch.cuda.empty_cache()
+
+
+def test_beam_m_columns_against_oracle(c3):
+    """One (f, b) column per m-block against the oracle (pixel sums over 3.1 M pixels, four Stokes maps)."""
+    from oracle import btgen as ob
+
+    tel, beam = c3["tel"], c3["beam"]
+    # a short and the longest E-W baseline: the latter still has power at m = 460
+    b_long = int(np.argmax(np.abs(tel.baselines[:, 0])))
+    cols = [(40, 300), (tel.nfreq - 1, b_long)]
+    for fi, bi in cols:
+        desc = dict(polarised=True, zenith=tel.zenith, baselines=tel.baselines, uniquepairs=tel.uniquepairs,
+                    beamclass=tel.beamclass, wavelengths=tel.wavelengths, cylinder_width=tel.cylinder_width,
+                    fwhm_e=tel.fwhm_e, fwhm_h=tel.fwhm_h, lmax=tel.lmax, mmax=tel.mmax, l_boost=tel.l_boost,
+                    included_freq=np.array([fi]), included_baseline=np.array([bi]), accuracy_boost=tel.accuracy_boost)
+        ref = ob.beam_transfer_m(desc, mlist=MS)
+        scale = max(np.abs(ref[m][fi, :, bi]).max() for m in MS)
+        assert scale > 0
+        for i, mi in enumerate(MS):
+            got = beam[i, fi, :, bi].cpu().numpy()        # (2, P, L)
+            want = ref[mi][fi, :, bi]
+            err = np.abs(got - want).max()
+            _log("beam_m column (f %d, b %d) m %d: max |diff| %.2e of scale %.2e" % (fi, bi, mi, err, scale))
+            assert err < 1e-10 * scale, (fi, bi, mi)
+            assert not got[..., :mi].any()                  # l < m stays zero
+    assert np.abs(ref[460][tel.nfreq - 1, :, b_long]).max() > 0   # the long baseline does reach m = 460
+
+
+def test_svd_chain_properties(c3):
+    """Size-independent properties of the three-stage chain (beamtransfer.py:802-924) on 864 x 2052 blocks."""
+    tel, bt, res, sv, beam = c3["tel"], c3["bt"], c3["res"], c3["sv"], c3["beam"]
+    T, P, L = bt.ntel, tel.num_pol_sky, tel.lmax + 1
+    noisew = bt._noisew()
+    worst = dict(orth=0.0, proj=0.0, pinv=0.0, rows=0.0)
+    for i, mi in enumerate(MS):
+        svnum, _ = bt._svd_num(mi)
+        assert (sv[i] >= 0).all() and (np.diff(sv[i], axis=1) <= 1e-12 * sv[i].max()).all()   # descending per frequency
+        for fi in (0, 21, 42, 63):
+            n = int(svnum[fi])
+            if n == 0:
+                continue
+            ut = res["beam_ut"][i, fi, :n].cpu().numpy()
+            bs = res["beam_svd"][i, fi, :n].cpu().numpy().reshape(n, P * L)
+            ib = res["invbeam_svd"][i, fi].cpu().numpy().reshape(P * L, -1)[:, :n]
+            B = beam[i, fi].cpu().numpy().reshape(T, P * L) * noisew[fi][:, None]
+            U = ut / noisew[fi][None, :]                                   # beam_ut = ut * noisew (beamtransfer.py:877)
+            worst["orth"] = max(worst["orth"], float(np.abs(U @ U.conj().T - np.eye(n)).max()))
+            worst["proj"] = max(worst["proj"], float(np.abs(U @ B - bs).max() / sv[i, fi, 0]))
+            worst["pinv"] = max(worst["pinv"], float(np.abs(bs @ ib - np.eye(n)).max()))
+            # the temperature rows of beam_svd carry the singular values (SVD3 is taken on the T part, :866-877)
+            g = np.sqrt(np.abs(np.einsum("ij,ij->i", bs[:, :L], bs[:, :L].conj())))
+            worst["rows"] = max(worst["rows"], float(np.abs(g - sv[i, fi, :n]).max() / sv[i, fi, 0]))
+    _log("configs[2] SVD properties: %s" % worst)
+    assert worst["orth"] < 1e-12, worst
+    assert worst["proj"] < 1e-11, worst
+    assert worst["rows"] < 1e-11, worst
+    assert worst["pinv"] < 1e-7, worst     # kappa = 1 / svcut = 1e6 on the kept modes
+
+
+def test_smallest_block_against_oracle_chain(c3):
+    """m = 460 (ndof ~450): singular values, nmodes and svnum of four frequencies against the oracle's
+    restatement of _generate_svdfile_m on the SAME beam block; then the KL spectrum and the kept-mode count
+    against the oracle fed with our SVD products (what tests/test_gpu_testparams.py does for configs[0])."""
+    from oracle import kl as okl
+    from oracle import svdchain as osvd
+    from parity_util import assert_spectrum, pencil_sensitivity
+
+    tel, bt, kl, res, sv, beam = c3["tel"], c3["bt"], c3["kl"], c3["res"], c3["sv"], c3["beam"]
+    i, mi = MS.index(460), 460
+    fsel = [0, 21, 42, 63]
+    blk = beam[i].cpu().numpy()[fsel]                         # (4, 2, B, P, L)
+    o = osvd.svd_m(blk, bt._noisew()[fsel][:, : tel.nbase], polsvcut=bt.polsvcut)
+    smax = sv[i].max()
+    for k, fi in enumerate(fsel):
+        err = np.abs(o["singularvalues"][k] - sv[i, fi]).max() / smax
+        _log("m 460 f %d: singular values vs oracle %.2e of sigma_max, nmodes %d" % (fi, err, int(res["nmodes"][i, fi])))
+        assert err < 1e-10
+        assert int((o["singularvalues"][k] > smax * bt.svcut).sum()) == int(bt._svd_num(mi)[0][fi])
+    # KL on the oracle with OUR svd products of every frequency
+    bs, bu = res["beam_svd"][i].cpu().numpy(), res["beam_ut"][i].cpu().numpy()
+    cs, cn = okl.sn_covariance(bs, bu, sv[i], kl.signal(), kl.foreground(), kl._npower(1.0), svcut=bt.svcut)
+    ev_o, E_o, ac_o = okl.kl_transform_m(cs, cn)
+    ours = kl._transform_batch([mi], to_host=True)[0]
+    tol = max(1e-10, 10 * pencil_sensitivity(cs, cn))
+    err = np.abs(ours[0] - ev_o).max() / np.abs(ev_o).max()
+    _log("m 460: ndof %d, KL spectrum vs oracle %.2e of lambda_max (bound %.1e)" % (ev_o.size, err, tol))
+    assert_spectrum(ours[0], ev_o, tol, "KL evals m=460")
+    i_o, i_g = int(np.searchsorted(ev_o, kl.threshold)), int(np.searchsorted(ours[0], kl.threshold))
+    assert i_o == i_g or np.abs(ev_o - kl.threshold).min() < tol * np.abs(ev_o).max()
+    assert ours[3]["ac"] == ac_o == 0.0
+    c3["cs460"], c3["cn460"] = cs, cn
+
+
+@pytest.mark.parametrize("mi,bound", [(460, 1e-9), (200, 1e-9), (1, 1e-4)])
+def test_kl_properties(c3, mi, bound):
+    """E N E^H = I and E S E^H = diag(lambda) on (a sample of) the kept modes (kltransform.py:339-345).  The
+    bound is the conditioning of N: at m = 1 foregrounds against thermal noise give cond(N) ~ 1e11 and LAPACK's
+    own zhegvd leaves 1.2e-6 on the same pencil."""
+    import torch
+
+    kl, ctx = c3["kl"], c3["ctx"]
+    S, N, ndofs, off = kl.sn_covariance_device([mi])
+    ctx.sync()
+    n = int(ndofs[0])
+    Sh, Nh = S[: n * n].cpu().numpy().reshape(n, n), N[: n * n].cpu().numpy().reshape(n, n)
+    del S, N
+    assert np.abs(Sh - Sh.conj().T).max() <= 1e-12 * np.abs(Sh).max()       # Hermitian by construction (mirrored blocks)
+    ev, E, _, extra = kl._transform_batch([mi], to_host=False)[0]
+    ev = ev.cpu().numpy()
+    assert np.all(np.diff(ev) >= 0)
+    i_ev = int(np.searchsorted(ev, kl.threshold))
+    nk = n - i_ev
+    assert nk > 0
+    pick = np.arange(i_ev, n) if nk <= 256 else np.unique(np.linspace(i_ev, n - 1, 256).astype(np.int64))
+    Ek = E[torch.as_tensor(pick, device=E.device)].cpu().numpy()
+    lam = ev[pick]
+    ENE = Ek @ Nh @ Ek.conj().T
+    ESE = Ek @ Sh @ Ek.conj().T
+    e1 = float(np.abs(ENE - np.eye(pick.size)).max())
+    e2 = float(np.abs(ESE - np.diag(np.diag(ESE))).max() / np.abs(ESE).max())
+    e3 = float(np.abs(np.diag(ESE).real - lam).max() / np.abs(lam).max())
+    _log("m %d: n %d kept %d  |E N E^H - I| %.2e  offdiag(E S E^H) %.2e  diag vs lambda %.2e" % (mi, n, nk, e1, e2, e3))
+    assert e1 < bound and e2 < bound and e3 < bound
+    assert not E[:i_ev].abs().max().item() if i_ev else True       # modes below the threshold are never formed
+
+
+def test_doublekl_and_fisher_config4(c3):
+    """BASELINE configs[3]: DoubleKL (foreground_threshold 100) and the exact Fisher matrix on the same blocks;
+    m = 460 against the oracle (f_evals, kept-mode count, stage-2 spectrum, per-m Fisher matrix)."""
+    from driftscan_amd import doublekl, psestimation
+    from oracle import kl as okl
+    from oracle import psfisher as opf
+    from parity_util import assert_spectrum, pencil_sensitivity
+
+    tel, bt, kl, res, sv = c3["tel"], c3["bt"], c3["kl"], c3["res"], c3["sv"]
+    dk = doublekl.DoubleKL.from_config(dict(threshold=0.1, foreground_threshold=100.0), bt, subdir="dk")
+    t0 = time.perf_counter()
+    out = dk._transform_batch(MS, to_host=True)
+    _log("DoubleKL of 3 blocks: %.2f s" % (time.perf_counter() - t0))
+    i = MS.index(460)
+    bs, bu = res["beam_svd"][i].cpu().numpy(), res["beam_ut"][i].cpu().numpy()
+
+    def sn(use_thermal):
+        return okl.sn_covariance(bs, bu, sv[i], kl.signal(), kl.foreground(), kl._npower(1.0), svcut=bt.svcut,
+                                 use_thermal=use_thermal, tsys_flat=tel.tsys_flat)
+
+    ev_o, E_o, fev_o, ac_o = okl.doublekl_transform_m(sn, foreground_threshold=100.0)
+    ev_g, E_g, _, extra = out[i]
+    tol1 = max(1e-10, 10 * pencil_sensitivity(*sn(False)))
+    assert_spectrum(extra["f_evals"], fev_o, tol1, "f_evals m=460")
+    near = np.abs(fev_o - 100.0).min() < tol1 * np.abs(fev_o).max()
+    _log("m 460: DoubleKL keeps %d of %d modes past the foreground cut (oracle %d); f_evals error %.2e (bound %.1e)"
+         % (ev_g.size, fev_o.size, ev_o.size, np.abs(extra["f_evals"] - fev_o).max() / np.abs(fev_o).max(), tol1))
+    assert ev_g.size == ev_o.size or near
+    if ev_g.size == ev_o.size and ev_o.size:
+        assert_spectrum(ev_g, ev_o, max(1e-8, 100 * tol1), "DoubleKL evals m=460")
+        assert E_g.shape == E_o.shape
+    # every block: f_evals ascending, kept count = #(f_evals > threshold), composed modes diagonalise the pencil
+    for k, mi in enumerate(MS):
+        ev2, M, _, ex = out[k]
+        fe = ex["f_evals"]
+        assert fe.size == int(bt.ndof(mi)) and np.all(np.diff(fe) >= 0)
+        assert ev2.size == int((fe > 100.0).sum())
+        if ev2.size == 0 or mi == 1:
+            continue
+        S, N = kl.sn_covariance(mi)
+        i2 = int(np.searchsorted(ev2, dk.threshold))
+        assert not M[:i2].any()
+        pick = np.arange(i2, ev2.size) if ev2.size - i2 <= 192 else np.unique(np.linspace(i2, ev2.size - 1, 192).astype(int))
+        if pick.size == 0:
+            continue
+        Mk = M[pick]
+        e1 = float(np.abs(Mk @ N @ Mk.conj().T - np.eye(pick.size)).max())
+        d = Mk @ S @ Mk.conj().T
+        e2 = float(np.abs(np.diag(d).real - ev2[pick]).max() / np.abs(ev2).max())
+        _log("m %d: DoubleKL modes %d (S/N >= %.1f: %d): |M N M^H - I| %.2e, diag(M S M^H) vs evals %.2e"
+             % (mi, ev2.size, dk.threshold, ev2.size - i2, e1, e2))
+        assert e1 < 1e-7 and e2 < 1e-7
+    # ---- exact Fisher matrix of the KL modes (PSExact), m = 460 against the oracle
+    for mi, r in zip(MS, kl._transform_batch(MS, to_host=True)):
+        kl._save(mi, *r)
+    ps = psestimation.PSExact.from_config(dict(bandtype="polar", num_theta=3, threshold=0.1,
+                                               k_bands=[dict(spacing="linear", start=0.0, stop=0.25, num=4)]),
+                                          kl, subdir="ps")
+    ps.genbands()
+    t0 = time.perf_counter()
+    fb = ps.fisher_bias_batch(MS)
+    _log("PSExact of 3 blocks, %d bands: %.2f s" % (ps.nbands, time.perf_counter() - t0))
+    evk, Ek = kl.modes_m(460, threshold=0.1)
+    svnum, svbounds = bt._svd_num(460)
+    f_o, b_o = opf.fisher_m(bs, svnum, svbounds, evk, Ek, ps.clarray)
+    err = np.abs(fb[i][0] - f_o).max() / np.abs(f_o).max()
+    _log("m 460: Fisher matrix vs oracle %.2e of its largest element" % err)
+    assert err < 1e-8
+    for k in range(len(MS)):
+        Fm = fb[k][0]
+        assert np.abs(Fm - Fm.conj().T).max() <= 1e-9 * np.abs(Fm).max()     # Hermitian
+        assert np.linalg.eigvalsh((Fm + Fm.conj().T) / 2).min() > -1e-9 * np.abs(Fm).max()   # a Gram matrix
+        assert not fb[k][1].any()                                             # PSExact has no bias (psestimation.py:797)
+
+
+# ---- configs[4]: CHIME-sized shapes, reduced to what the test budget holds ------------------------------
+def test_config5_svd_slice_frequency_chunks():
+    """One 3552 x 4100 frequency slice (T = 2 x 1776 baselines, P = 4, L = 1025) x 3 frequencies through
+    Context.svd_chain with a byte budget that forces the frequency-sliced path; the slices must reproduce the
+    one-call result exactly and satisfy the chain's properties."""
+    import torch
+
+    from driftscan_amd import device
+
+    device.reset_context()
+    torch.cuda.empty_cache()
+    ctx = device.get_context(workspace_bytes=24 << 30)
+    F, T, P, L, m = 3, 3552, 4, 1025, 300
+    g = torch.Generator(device="cuda").manual_seed(5)
+    Lm = L - m
+    colw = torch.exp(-torch.arange(Lm, device="cuda", dtype=torch.float64) / (Lm / 6.0))
+    beam = torch.zeros((1, F, T, P, L), dtype=torch.complex128, device="cuda")
+    r = T // 8   # low-rank polarised part: the null-space stage (SVD2) has something to find
+    for f in range(F):
+        a = torch.randn((T, Lm, 2), generator=g, device="cuda", dtype=torch.float64)
+        beam[0, f, :, 0, m:] = torch.view_as_complex(a) * colw
+        left = torch.view_as_complex(torch.randn((T, r, 2), generator=g, device="cuda", dtype=torch.float64))
+        for p in range(1, P):
+            right = torch.view_as_complex(torch.randn((r, Lm, 2), generator=g, device="cuda", dtype=torch.float64))
+            beam[0, f, :, p, m:] = 0.05 * (left @ right) / np.sqrt(r)
+    nw = torch.ones((F, T), dtype=torch.float64, device="cuda") * 2.0
+    per_chain = 16.0 * (2.0 * T * (P * L + T) + 16.0 * T * T)
+    t0 = time.perf_counter()
+    sliced = ctx.svd_chain(beam, nw, 1e-4, max_bytes=1.5 * per_chain)      # one frequency per call
+    ctx.sync()
+    t1 = time.perf_counter()
+    whole = ctx.svd_chain(beam, nw, 1e-4, max_bytes=1e15)
+    ctx.sync()
+    _log("configs[4] slice: 3 x (3552 x 4100) sliced %.1f s, one call %.1f s, sweeps %s, nmodes %s"
+         % (t1 - t0, time.perf_counter() - t1, whole["sweeps"], whole["nmodes"].tolist()))
+    assert np.array_equal(sliced["nmodes"], whole["nmodes"])
+    sv = whole["singularvalues"].cpu().numpy()
+    assert np.abs(sliced["singularvalues"].cpu().numpy() - sv).max() <= 1e-12 * sv.max()
+    K = min(L, T)
+    for f in range(F):
+        n = int((sv[0, f] > sv[0, f].max() * 1e-6).sum())
+        assert 0 < n <= K
+        ut = whole["beam_ut"][0, f, :n]
+        U = ut / nw[f][None, :]
+        eye = torch.eye(n, dtype=torch.complex128, device="cuda")
+        bs = whole["beam_svd"][0, f, :n].reshape(n, P * L)
+        ib = whole["invbeam_svd"][0, f].reshape(P * L, K)[:, :n]
+        B = beam[0, f].reshape(T, P * L) * nw[f][:, None]
+        e_orth = (U @ U.conj().T - eye).abs().max().item()
+        e_proj = ((U @ B - bs).abs().max() / sv[0, f, 0]).item()
+        e_pinv = (bs @ ib - eye).abs().max().item()
+        _log("  f %d: n %d  |U U^H - I| %.2e  |U^H w B - beam_svd| %.2e  |beam_svd pinv - I| %.2e" % (f, n, e_orth, e_proj, e_pinv))
+        assert e_orth < 1e-12 and e_proj < 1e-11 and e_pinv < 1e-7
+    del beam, sliced, whole
+    device.reset_context()
+    torch.cuda.empty_cache()
+
+
+def test_config5_eigh_gen_big_dc():
+    """Generalised eigenproblem at n = 8192: the top divide-and-conquer merge node (8192 > 4096) runs the
+    global-scratch <BIG> kernels, the tridiagonalisation its 64-wide panels."""
+    import torch
+
+    from driftscan_amd import device
+    from driftscan_amd._lib import block_offsets
+
+    device.reset_context()
+    torch.cuda.empty_cache()
+    ctx = device.get_context(workspace_bytes=24 << 30)
+    n = 8192
+    g = torch.Generator(device="cuda").manual_seed(8)
+
+    def rnd(rows, cols):
+        return torch.view_as_complex(torch.randn((rows, cols, 2), generator=g, device="cuda", dtype=torch.float64))
+
+    X, Y = rnd(n, n // 2), rnd(n, n)
+    d = torch.logspace(0, -6, n // 2, device="cuda", dtype=torch.float64)          # graded signal spectrum
+    S = ((X * d) @ X.conj().T).contiguous()
+    N = (Y @ Y.conj().T / n + torch.eye(n, device="cuda", dtype=torch.complex128)).contiguous()
+    S = (S + S.conj().T) / 2
+    N = (N + N.conj().T) / 2
+    Sk, Nk = S.clone(), N.clone()
+    off, tot = block_offsets([n])
+    t0 = time.perf_counter()
+    ev, evoff, E, ac, _ = ctx.eigh_gen(S.reshape(-1), N.reshape(-1), [n], off)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    E = E[: n * n].view(n, n)
+    ev_h = ev.cpu().numpy()
+    assert np.all(np.diff(ev_h) >= 0) and ac[0] == 0.0
+    pick = torch.as_tensor(np.unique(np.linspace(0, n - 1, 256).astype(np.int64)), device="cuda")
+    Ek = E[pick]
+    lam = ev[pick]
+    e1 = (Ek @ Nk @ Ek.conj().T - torch.eye(pick.numel(), dtype=torch.complex128, device="cuda")).abs().max().item()
+    D = Ek @ Sk @ Ek.conj().T
+    e2 = ((D - torch.diag(torch.diagonal(D))).abs().max() / D.abs().max()).item()
+    e3 = ((torch.diagonal(D).real - lam).abs().max() / lam.abs().max()).item()
+    # the trace is invariant: sum(lambda) = trace(N^-1 S) = trace(E S E^H)
+    tr = torch.einsum("ij,jk,ik->", E, Sk, E.conj()).real.item()
+    e4 = abs(tr - float(ev_h.sum())) / abs(float(ev_h.sum()))
+    _log("configs[4] eigh_gen n = %d: %.2f s  |E N E^H - I| %.2e  offdiag %.2e  diag %.2e  trace %.2e" % (n, dt, e1, e2, e3, e4))
+    assert e1 < 1e-10 and e2 < 1e-11 and e3 < 1e-10 and e4 < 1e-10
+    del S, N, Sk, Nk, E, X, Y
+    device.reset_context()
+    torch.cuda.empty_cache()

@@ -133,11 +133,89 @@ def test_doublekl(setup):
             full = f["evals_full"][:]
         assert_spectrum(f_evals, g[pre + "f_evals"], tol1, "f_evals m=%d" % mi)
         ref = g[pre + "evals"]
-        # number of modes passing the foreground cut, then the stage-2 spectrum
-        assert (full != 0).sum() == ref.size or np.count_nonzero(full) <= ref.size
-        got = full[full.size - ref.size :] if ref.size else full[:0]
+            kept = f["evals"][:]
+            evecs = f["evecs"][:]
+            flags = f.attrs["FLAGS"]
+        # the number of modes passing the foreground cut is exact (doublekl.py:56-60) ...
+        assert int((f_evals > dk.foreground_threshold).sum()) == ref.size
+        assert int((g[pre + "f_evals"] > dk.foreground_threshold).sum()) == ref.size
+        assert not full[: full.size - ref.size].any()          # evals_full is right aligned, zero padded
+        got = full[full.size - ref.size :]
+        # ... then the stage-2 spectrum and the S/N cut transform_save applies to it (kltransform.py:388-398)
         if ref.size:
-            assert_spectrum(got, ref, max(1e-8, 100 * tol1), "dk evals m=%d" % mi)
+            tol2 = max(1e-8, 100 * tol1)
+            assert_spectrum(got, ref, tol2, "dk evals m=%d" % mi)
+            err = np.abs(got - ref).max() / np.abs(ref).max()
+            print("DoubleKL m=%d: stage-2 spectrum error %.2e of lambda_max (bound %.1e)" % (mi, err, tol2))
+            nkept_ref = ref.size - int(np.searchsorted(ref, dk.threshold))
+            near = np.abs(ref - dk.threshold).min() <= tol2 * np.abs(ref).max()
+            assert kept.size == nkept_ref or near
+            assert evecs.shape == (kept.size, f_evals.size)
+        # `ac`/FLAGS come from stage 1 (doublekl.py:58): the fixture's stage-1 pencils are positive definite
+        assert (flags == "Normal") == (float(g[pre + "ac"]) == 0.0)
+
+
+def test_inverse_and_asymmetric_covariance(golden_dir, tmp_path):
+    """`inverse: Yes` for KLTransform and DoubleKL on the device (N E^H instead of an LU inversion per m,
+    kltransform.py:124-143, :346-347; doublekl.py:63-67, :83-85) and a sky covariance that is NOT symmetric
+    under f <-> f' through project_matrix_sky_to_svd (beamtransfer.py:1135-1188 takes any array)."""
+    from driftscan_amd import beamtransfer, device, doublekl, kltransform, storage
+
+    device.reset_context()
+    g = np.load(os.path.join(golden_dir, "svdkl_inverse.npz"))
+    tel = FakeTelescope(g)
+    bt = beamtransfer.BeamTransfer(str(tmp_path / "bt"), telescope=tel)
+    bt.polsvcut, bt.svcut = float(g["polsvcut"]), float(g["svcut"])
+    bt._generate_dirs()
+    mlist = [int(m) for m in g["mlist"]]
+    for mi in mlist:
+        with storage.File(bt._mfile(mi), "w") as f:
+            f.create_dataset("beam_m", data=g["m%d_beam_m" % mi][..., mi:])
+    bt._my_ms = lambda mlist_=None: mlist
+    bt._generate_svdfiles(regen=True)
+    kl = kltransform.KLTransform.from_config(dict(threshold=float(g["threshold"]), inverse=True), bt, subdir="kli")
+    dk = doublekl.DoubleKL.from_config(dict(threshold=float(g["threshold"]), inverse=True,
+                                            foreground_threshold=float(g["fg_threshold"])), bt, subdir="dki")
+    for o in (kl, dk):
+        o._cvsg, o._cvfg = g["cv_sg"], g["cv_fg"]
+        o.generate(regen=True)
+
+    def fix_signs(rows, other):
+        sg = np.array([np.sign(r[np.argmax(np.abs(r))].real) or 1.0 for r in rows])
+        return sg[:, None] * rows, sg[:, None] * other
+
+    for mi in mlist:
+        pre = "m%d_" % mi
+        # the asymmetric covariance: compare through OUR svd basis (gauge: U -> D U per frequency leaves
+        # the singular values of the non-Hermitian projection unchanged)
+        ours = bt.project_matrix_sky_to_svd(mi, g["cv_asym"])
+        ref = g[pre + "proj_asym"]
+        assert np.abs(ours - ours.T.conj()).max() > 1e-3 * np.abs(ours).max()
+        sv_o, sv_r = np.linalg.svd(ours, compute_uv=False), np.linalg.svd(ref, compute_uv=False)
+        assert np.abs(sv_o - sv_r).max() < 1e-9 * sv_r.max()
+        assert np.abs(np.linalg.eigvals(ours).real.sum() - np.trace(ref).real) < 1e-9 * np.abs(ref).max() * ref.shape[0]
+        # KLTransform inverse: evinv^T is the inverse of the mode matrix
+        with storage.File(kl._evfile % mi, "r") as f:
+            ev, E, inv = f["evals"][:], f["evecs"][:], f["evinv"][:]
+        i0 = int(np.searchsorted(g[pre + "kl_evals"], kl.threshold))
+        assert ev.size == g[pre + "kl_evals"].size - i0
+        assert_spectrum(ev, g[pre + "kl_evals"][i0:], 1e-9, "kl evals (inverse)")
+        assert inv.shape == E.shape
+        assert np.abs(E @ inv.T - np.eye(ev.size)).max() < 1e-8
+        refP = g[pre + "kl_inv"][i0:].T @ g[pre + "kl_evecs"][i0:]
+        assert np.abs(inv.T @ E - refP).max() < 1e-7 * max(np.abs(refP).max(), 1.0)
+        assert np.array_equal(kl.invmodes_m(mi), inv.T)
+        # DoubleKL inverse: the reference's formula, unique on this real pencil up to a sign per mode
+        with storage.File(dk._evfile % mi, "r") as f:
+            ev, E, inv = f["evals"][:], f["evecs"][:], f["evinv"][:]
+        rE, rI, rv = g[pre + "dk_evecs"], g[pre + "dk_inv"], g[pre + "dk_evals"]
+        j0 = int(np.searchsorted(rv, dk.threshold))
+        assert ev.size == rv.size - j0 and E.shape == inv.shape == (ev.size, rE.shape[1])
+        assert np.abs(E.imag).max() < 1e-9 * np.abs(E).max()
+        e1, i1 = fix_signs(E.real, inv.real)
+        e2, i2 = fix_signs(rE[j0:].real, rI[j0:].real)
+        assert np.abs(e1 - e2).max() < 1e-6 * np.abs(e2).max()
+        assert np.abs(i1 - i2).max() < 1e-6 * np.abs(i2).max()
 
 
 def test_product_manager_end_to_end(tmp_path):

@@ -131,6 +131,47 @@ def test_doublekl(svdkl):
             assert relerr(evecs @ cn @ evecs.T.conj(), np.eye(evals.size), 1.0) <= max(10 * rn_ref, 1e-8)
 
 
+def _sn_inv(g, pre, use_thermal):
+    F, B = int(g["F"]), int(g["B"])
+    npw = np.concatenate([g["npower"], g["npower"]], axis=1)
+    return okl.sn_covariance(g[pre + "beam_svd"], g[pre + "beam_ut"], g[pre + "singularvalues"], g["cv_sg"], g["cv_fg"],
+                             npw, svcut=float(g["svcut"]), use_thermal=use_thermal, tsys_flat=float(g["tsys_flat"]))
+
+
+def _fix_signs(rows, *others):
+    """Real pencils leave only a sign per mode: make the largest component of every row positive."""
+    sg = np.array([np.sign(r[np.argmax(np.abs(r))].real) or 1.0 for r in rows])
+    return [sg[:, None] * m for m in (rows,) + others]
+
+
+def test_inverse_and_asymmetric_projection(golden_dir):
+    """`inverse = True` (kltransform.py:346-347, doublekl.py:63-67, :83-85) and a frequency-asymmetric sky
+    covariance through project_matrix_sky_to_svd, against the unmodified reference on a real-valued pencil."""
+    g = np.load(os.path.join(golden_dir, "svdkl_inverse.npz"))
+    for mi in g["mlist"]:
+        pre = "m%d_" % mi
+        svnum, svbounds = osvd.svd_num(g[pre + "singularvalues"], float(g["svcut"]))
+        got = okl.project_matrix_sky_to_svd(g[pre + "beam_svd"], svnum, svbounds, g["cv_asym"])
+        assert relerr(got, g[pre + "proj_asym"]) < 1e-13
+        assert relerr(got, got.T.conj()) > 1e-3   # genuinely not Hermitian: a mirrored lower half would be wrong
+        cs, cn = _sn_inv(g, pre, True)
+        evals, evecs, ac = okl.kl_transform_m(cs, cn)
+        inv = okl.kl_inverse(evecs)
+        assert_spectrum(evals, g[pre + "kl_evals"], 1e-10, "kl evals")
+        # gauge free: sum over modes of inv[i]^T (x) evecs[i] = E^-1 E = I for both; compare the kept half instead
+        k = evals.size // 2
+        ours = inv[k:].T @ evecs[k:]
+        ref = g[pre + "kl_inv"][k:].T @ g[pre + "kl_evecs"][k:]
+        assert relerr(ours, ref, 1.0) < 1e-7
+        evals, evecs, f_evals, ac, dinv = okl.doublekl_transform_m(lambda th: _sn_inv(g, pre, th),
+                                                                  foreground_threshold=float(g["fg_threshold"]), inverse=True)
+        assert evals.shape == g[pre + "dk_evals"].shape and ac == float(g[pre + "dk_ac"])
+        assert_spectrum(evals, g[pre + "dk_evals"], 1e-8, "dk evals")
+        e1, i1 = _fix_signs(evecs.real, dinv.real)
+        e2, i2 = _fix_signs(g[pre + "dk_evecs"].real, g[pre + "dk_inv"].real)
+        assert relerr(e1, e2) < 1e-6 and relerr(i1, i2) < 1e-6
+
+
 def test_eigh_gen(golden_dir):
     g = np.load(os.path.join(golden_dir, "eigh_gen.npz"))
     for case in ("pd", "npd", "zero"):
