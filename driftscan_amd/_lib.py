@@ -80,6 +80,7 @@ SIGNATURES = {
     "dm_bt_sht_range": (
         c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_int, c_int, c_int, c_int, c_int,
                 c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_vp, c_vp]),
+    "dm_bit_truncate_max_complex": (c_int, [c_vp, c_vp, c_i64, c_int, c_i64, c_dbl, c_dbl]),
 }
 
 _lib = None
@@ -200,6 +201,14 @@ class Context(object):
             q.conjA, q.conjB = int(bool(p.get("conjA", False))), int(bool(p.get("conjB", False)))
             q.alpha, q.beta = float(p.get("alpha", 1.0)), float(p.get("beta", 0.0))
         self.check(self.lib.dm_zgemm_grouped(self.h, n, arr), "dm_zgemm_grouped")
+
+    def bit_truncate_max_complex(self, t, prec, prec_max_row):
+        """In place on a contiguous complex device tensor whose LAST axis is the row (drift/core/beamtransfer.py:641-646)."""
+        ncols = int(t.shape[-1])
+        nrows = int(t.numel() // max(ncols, 1))
+        assert t.is_contiguous()
+        self.check(self.lib.dm_bit_truncate_max_complex(self.h, self.ptr(t), nrows, ncols, ncols, float(prec),
+                                                        float(prec_max_row)), "dm_bit_truncate_max_complex")
 
     def zpotrf(self, A, n, ld, stride=0, batch=1):
         info = (c_int * batch)()

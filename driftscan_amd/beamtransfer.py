@@ -48,7 +48,9 @@ class BeamTransfer(config.Reader):
     mem_chunk = config.Property(proptype=float, default=3.0)
     svcut = config.Property(proptype=float, default=1e-6)
     polsvcut = config.Property(proptype=float, default=1e-4)
-    # bit truncation / bitshuffle are not available in this image: default off
+    # The reference's default is "bitshuffle importable" (beamtransfer.py:192); it is not in this image.  When set,
+    # the blocks are truncated on the device (dm_bit_truncate_max_complex) before they are written; the files are
+    # lzf-compressed either way (readable by plain h5py without the bitshuffle plugin).
     truncate = config.Property(proptype=config.truthy, default=False)
     truncate_rel = config.Property(proptype=float, default=1e-7)
     truncate_maxl = config.Property(proptype=float, default=1e-8)
@@ -198,10 +200,6 @@ class BeamTransfer(config.Reader):
         tel = self.telescope
         ctx = get_context()
         st = time.time()
-        if self.truncate and parallel.rank0():
-            # beamtransfer.py:641-646 (caput.truncate.bit_truncate_max_complex + bitshuffle): not available here
-            logger.warning("truncate = True: bit truncation of the beam transfers is not implemented, the beam_m "
-                           "files are written at full precision (a superset of the information; larger files)")
         finc, binc, pinc = tel.included_freq, tel.included_baseline, tel.included_pol
         nranks, r = parallel.size(), parallel.rank()
         M = tel.mmax + 1
@@ -222,12 +220,19 @@ class BeamTransfer(config.Reader):
             whole = nranks == 1 and len(ranges) == 1
             beam_all = btgen.beam_m_all(tel, ctx=ctx, max_bytes=int(self.device_chunk_gb * (1 << 30)),
                                         m_range=None if whole else (a, b))
+            if self.truncate:
+                # beamtransfer.py:641-646: rows of the m-ordered array (runs over l) truncated to
+                # max(truncate_rel |z|, truncate_maxl max_l |z|); in place, so the SVD stage sees what the files hold
+                ctx.bit_truncate_max_complex(beam_all, self.truncate_rel, self.truncate_maxl)
             if whole:
                 self._beam_all = beam_all  # (mmax+1, F, 2, B, P, L), kept for the SVD stage
+
             def write_m(mi, blk):
                 with storage.File(self._mfile(mi), "w") as f:
                     data = blk[np.ix_(finc, np.arange(2), binc, pinc, np.arange(mi, tel.lmax + 1))]
-                    f.create_dataset("beam_m", data=data)
+                    # chunk shape and compression of beamtransfer.py:548-571
+                    f.create_dataset("beam_m", data=data, **storage.compression_kwargs(
+                        (1, 2, min(10, len(binc)), len(pinc), tel.lmax + 1 - mi)))
                     f.attrs["m"] = mi
                     f.attrs["frequencies"] = tel.frequencies
 
@@ -274,11 +279,12 @@ class BeamTransfer(config.Reader):
             host = {k: ctx.to_host(res[k]) for k in ("beam_svd", "beam_ut", "singularvalues")}
             host["invbeam_svd"] = None if skip_svd_inv else ctx.to_host(res["invbeam_svd"])
             def write_svd(mi, bsvd, ibsvd, but, sig):
-                with storage.File(self._svdfile(mi), "w") as fs:
-                    fs.create_dataset("beam_svd", data=bsvd)
+                with storage.File(self._svdfile(mi), "w") as fs:   # chunk shapes of beamtransfer.py:741-798
+                    k10 = min(10, K)
+                    fs.create_dataset("beam_svd", data=bsvd, **storage.compression_kwargs((1, k10, P, L)))
                     if ibsvd is not None:
-                        fs.create_dataset("invbeam_svd", data=ibsvd)
-                    fs.create_dataset("beam_ut", data=but)
+                        fs.create_dataset("invbeam_svd", data=ibsvd, **storage.compression_kwargs((1, P, L, k10)))
+                    fs.create_dataset("beam_ut", data=but, **storage.compression_kwargs((1, k10, T)))
                     fs.create_dataset("singularvalues", data=sig)
                     fs.attrs["baselines"] = tel.baselines
                     fs.attrs["m"] = mi

@@ -1,0 +1,680 @@
+/* dm_h5io.c — libdriftio: HDF5 product files for the per-m hot path (see include/driftio.h).
+ *
+ * Plain C on the HDF5 1.10 C API.  What is specific to this library:
+ *   - its own LZF codec (the byte format of liblzf 3.x, which h5py's filter 32000 wraps), registered as an
+ *     HDF5 filter so that H5Dread decodes files written by h5py and h5py decodes ours;
+ *   - chunked writes go through H5Dwrite_chunk: the caller's thread gathers and compresses each chunk with
+ *     no lock held, and only the hand-over of the finished bytes to HDF5 is serialised.  The product files
+ *     of one m are independent, so the writer pool of driftscan_amd/storage.py compresses as many datasets
+ *     at once as it has threads although libhdf5 itself is single-threaded.
+ */
+#include "../../include/driftio.h"
+
+#include <hdf5.h>
+#include <pthread.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define DIO_LZF_FILTER 32000
+#define DIO_LZF_VERSION 0x0105 /* liblzf 3.5, as h5py writes into cd_values[1] */
+#define DIO_LZF_REVISION 4     /* h5py's H5PY_FILTER_LZF_VERSION */
+
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static pthread_once_t g_once = PTHREAD_ONCE_INIT;
+static __thread char g_err[512];
+
+#define LOCK() pthread_mutex_lock(&g_lock)
+#define UNLOCK() pthread_mutex_unlock(&g_lock)
+
+static int fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return -1;
+}
+
+const char* dio_last_error(void) { return g_err; }
+int dio_version(void) { return 100; }
+
+/* ------------------------------------------------------------------------------------------------
+ * LZF: control byte c < 32: c + 1 literal bytes follow; else a back reference of length (c >> 5) + 2
+ * (a length field of 7 is extended by the next byte) at distance ((c & 31) << 8 | next byte) + 1.
+ * ------------------------------------------------------------------------------------------------ */
+#define HLOG 16
+#define MAX_LIT 32
+#define MAX_OFF 8192
+#define MAX_REF 264
+
+size_t dio_lzf_compress(const void* in_, size_t n, void* out_, size_t out_len) {
+  const unsigned char* in = (const unsigned char*)in_;
+  unsigned char* out = (unsigned char*)out_;
+  if (n == 0 || out_len == 0) return 0;
+  uint32_t* htab = (uint32_t*)calloc((size_t)1 << HLOG, sizeof(uint32_t)); /* position + 1, 0 = empty */
+  if (!htab) return 0;
+  size_t ip = 0, op = 0, lit = 0; /* lit: literals pending since out[op - lit - 1] (their control byte) */
+  size_t ctrl = op++;              /* control byte of the open literal run */
+  if (op > out_len) { free(htab); return 0; }
+#define EMIT(b)                                   \
+  do {                                            \
+    if (op >= out_len) { free(htab); return 0; } \
+    out[op++] = (unsigned char)(b);               \
+  } while (0)
+  while (ip + 2 < n) {
+    const uint32_t v = ((uint32_t)in[ip] << 16) | ((uint32_t)in[ip + 1] << 8) | in[ip + 2];
+    const uint32_t h = ((v * 2654435761u) >> (32 - HLOG)) & ((1u << HLOG) - 1);
+    const size_t cand1 = htab[h];
+    htab[h] = (uint32_t)(ip + 1);
+    size_t ref = cand1 - 1;
+    if (cand1 != 0 && ip - ref <= MAX_OFF && in[ref] == in[ip] && in[ref + 1] == in[ip + 1] && in[ref + 2] == in[ip + 2]) {
+      size_t maxlen = n - ip;
+      if (maxlen > MAX_REF) maxlen = MAX_REF;
+      size_t len = 3;
+      while (len < maxlen && in[ref + len] == in[ip + len]) ++len;
+      /* close the literal run */
+      if (lit) out[ctrl] = (unsigned char)(lit - 1);
+      else --op; /* no literals: take the reserved control byte back */
+      const size_t off = ip - ref - 1, l = len - 2;
+      if (l < 7) {
+        EMIT((l << 5) | (off >> 8));
+      } else {
+        EMIT((7u << 5) | (off >> 8));
+        EMIT(l - 7);
+      }
+      EMIT(off & 0xff);
+      /* index the last positions covered by the match so that later data can refer to them */
+      if (len > 3 && ip + len + 2 < n) {
+        const size_t q = ip + len - 2;
+        const uint32_t w = ((uint32_t)in[q] << 16) | ((uint32_t)in[q + 1] << 8) | in[q + 2];
+        htab[((w * 2654435761u) >> (32 - HLOG)) & ((1u << HLOG) - 1)] = (uint32_t)(q + 1);
+      }
+      ip += len;
+      lit = 0;
+      ctrl = op;
+      EMIT(0);
+    } else {
+      EMIT(in[ip]);
+      ++ip;
+      if (++lit == MAX_LIT) {
+        out[ctrl] = MAX_LIT - 1;
+        lit = 0;
+        ctrl = op;
+        EMIT(0);
+      }
+    }
+  }
+  while (ip < n) {
+    EMIT(in[ip]);
+    ++ip;
+    if (++lit == MAX_LIT && ip < n) {
+      out[ctrl] = MAX_LIT - 1;
+      lit = 0;
+      ctrl = op;
+      EMIT(0);
+    }
+  }
+  if (lit) out[ctrl] = (unsigned char)(lit - 1);
+  else --op;
+#undef EMIT
+  free(htab);
+  return op;
+}
+
+size_t dio_lzf_decompress(const void* in_, size_t n, void* out_, size_t out_len) {
+  const unsigned char* ip = (const unsigned char*)in_;
+  const unsigned char* const iend = ip + n;
+  unsigned char* out = (unsigned char*)out_;
+  size_t op = 0;
+  while (ip < iend) {
+    unsigned c = *ip++;
+    if (c < 32) {
+      ++c;
+      if (op + c > out_len || ip + c > iend) return 0;
+      memcpy(out + op, ip, c);
+      op += c;
+      ip += c;
+    } else {
+      size_t len = c >> 5;
+      if (len == 7) {
+        if (ip >= iend) return 0;
+        len += *ip++;
+      }
+      if (ip >= iend) return 0;
+      const size_t dist = (((size_t)(c & 31)) << 8 | *ip++) + 1;
+      len += 2;
+      if (dist > op || op + len > out_len) return 0;
+      const unsigned char* src = out + op - dist;
+      for (size_t i = 0; i < len; ++i) out[op + i] = src[i]; /* may overlap: byte by byte */
+      op += len;
+    }
+  }
+  return op;
+}
+
+/* ---- the HDF5 filter around it (same contract as h5py's lzf_filter.c) --------------------------- */
+static size_t lzf_h5_filter(unsigned flags, size_t cd_nelmts, const unsigned cd_values[], size_t nbytes, size_t* buf_size,
+                            void** buf) {
+  if (!(flags & H5Z_FLAG_REVERSE)) { /* compress; "does not shrink" = failure of an optional filter */
+    void* out = malloc(nbytes ? nbytes : 1);
+    if (!out) return 0;
+    const size_t got = dio_lzf_compress(*buf, nbytes, out, nbytes > 0 ? nbytes - 1 : 0);
+    if (got == 0) { free(out); return 0; }
+    free(*buf);
+    *buf = out;
+    *buf_size = nbytes;
+    return got;
+  }
+  size_t cap = (cd_nelmts >= 3 && cd_values[2] != 0) ? cd_values[2] : *buf_size;
+  for (int attempt = 0; attempt < 32; ++attempt) {
+    void* out = malloc(cap ? cap : 1);
+    if (!out) return 0;
+    const size_t got = dio_lzf_decompress(*buf, nbytes, out, cap);
+    if (got != 0) {
+      free(*buf);
+      *buf = out;
+      *buf_size = cap;
+      return got;
+    }
+    free(out);
+    cap = cap ? cap * 2 : 4096;
+  }
+  return 0;
+}
+
+static herr_t lzf_h5_set_local(hid_t dcpl, hid_t type, hid_t space) {
+  unsigned flags;
+  size_t nelem = 8;
+  unsigned values[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  hsize_t chunk[32];
+  (void)space;
+  if (H5Pget_filter_by_id2(dcpl, DIO_LZF_FILTER, &flags, &nelem, values, 0, NULL, NULL) < 0) return -1;
+  if (nelem < 3) nelem = 3;
+  if (values[0] == 0) values[0] = DIO_LZF_REVISION;
+  if (values[1] == 0) values[1] = DIO_LZF_VERSION;
+  const int nd = H5Pget_chunk(dcpl, 32, chunk);
+  if (nd < 0) return -1;
+  size_t bytes = H5Tget_size(type);
+  if (bytes == 0) return -1;
+  for (int i = 0; i < nd; ++i) bytes *= (size_t)chunk[i];
+  values[2] = (unsigned)bytes;
+  return H5Pmodify_filter(dcpl, DIO_LZF_FILTER, flags, nelem, values) < 0 ? -1 : 0;
+}
+
+static const H5Z_class2_t g_lzf_class = {H5Z_CLASS_T_VERS, (H5Z_filter_t)DIO_LZF_FILTER, 1, 1, "lzf", NULL,
+                                         (H5Z_set_local_func_t)lzf_h5_set_local, (H5Z_func_t)lzf_h5_filter};
+
+static void init_once(void) {
+  H5open();
+  H5Eset_auto2(H5E_DEFAULT, NULL, NULL); /* errors are reported through return codes + dio_last_error */
+  if (H5Zfilter_avail(DIO_LZF_FILTER) <= 0) H5Zregister(&g_lzf_class);
+}
+
+int dio_hdf5_version(void) {
+  unsigned a = 0, b = 0, c = 0;
+  pthread_once(&g_once, init_once);
+  H5get_libversion(&a, &b, &c);
+  return (int)(a * 10000 + b * 100 + c);
+}
+
+/* ---- types --------------------------------------------------------------------------------------- */
+static size_t dtype_size(int dtype) {
+  switch (dtype) {
+    case DIO_F64: return 8;
+    case DIO_C128: return 16;
+    case DIO_I64: return 8;
+    case DIO_I32: return 4;
+    case DIO_BOOL: return 1;
+    case DIO_F32: return 4;
+    default: return 0;
+  }
+}
+
+/* a new type id (caller closes) */
+static hid_t make_type(int dtype) {
+  switch (dtype) {
+    case DIO_F64: return H5Tcopy(H5T_IEEE_F64LE);
+    case DIO_F32: return H5Tcopy(H5T_IEEE_F32LE);
+    case DIO_I64: return H5Tcopy(H5T_STD_I64LE);
+    case DIO_I32: return H5Tcopy(H5T_STD_I32LE);
+    case DIO_C128: {
+      hid_t t = H5Tcreate(H5T_COMPOUND, 16);
+      if (t < 0) return t;
+      H5Tinsert(t, "r", 0, H5T_IEEE_F64LE);
+      H5Tinsert(t, "i", 8, H5T_IEEE_F64LE);
+      return t;
+    }
+    case DIO_BOOL: {
+      hid_t t = H5Tenum_create(H5T_STD_I8LE);
+      if (t < 0) return t;
+      signed char v = 0;
+      H5Tenum_insert(t, "FALSE", &v);
+      v = 1;
+      H5Tenum_insert(t, "TRUE", &v);
+      return t;
+    }
+    case DIO_STR: {
+      hid_t t = H5Tcopy(H5T_C_S1);
+      if (t < 0) return t;
+      H5Tset_size(t, H5T_VARIABLE);
+      H5Tset_cset(t, H5T_CSET_UTF8);
+      return t;
+    }
+    default: return -1;
+  }
+}
+
+static int classify(hid_t t) {
+  const H5T_class_t c = H5Tget_class(t);
+  const size_t sz = H5Tget_size(t);
+  if (c == H5T_FLOAT) return sz == 8 ? DIO_F64 : (sz == 4 ? DIO_F32 : DIO_OTHER);
+  if (c == H5T_INTEGER) return sz == 8 ? DIO_I64 : (sz == 4 ? DIO_I32 : (sz == 1 ? DIO_BOOL : DIO_OTHER));
+  if (c == H5T_ENUM) return sz == 1 ? DIO_BOOL : DIO_OTHER;
+  if (c == H5T_STRING) return DIO_STR;
+  if (c == H5T_COMPOUND && H5Tget_nmembers(t) == 2 && sz == 16) {
+    char* a = H5Tget_member_name(t, 0);
+    char* b = H5Tget_member_name(t, 1);
+    const int ok = a && b && strcmp(a, "r") == 0 && strcmp(b, "i") == 0;
+    if (a) H5free_memory(a);
+    if (b) H5free_memory(b);
+    return ok ? DIO_C128 : DIO_OTHER;
+  }
+  return DIO_OTHER;
+}
+
+/* ---- files ----------------------------------------------------------------------------------------- */
+int dio_open(const char* path, const char* mode, int64_t* file_out) {
+  pthread_once(&g_once, init_once);
+  if (!path || !mode || !file_out) return fail("dio_open: bad argument");
+  hid_t f = -1;
+  LOCK();
+  if (strcmp(mode, "w") == 0) {
+    f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+  } else if (strcmp(mode, "r") == 0) {
+    f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
+  } else if (strcmp(mode, "r+") == 0) {
+    f = H5Fopen(path, H5F_ACC_RDWR, H5P_DEFAULT);
+  }
+  UNLOCK();
+  if (f < 0) return fail("dio_open: cannot open '%s' with mode '%s'", path, mode);
+  *file_out = (int64_t)f;
+  return 0;
+}
+
+int dio_close(int64_t file) {
+  LOCK();
+  const herr_t rc = H5Fclose((hid_t)file);
+  UNLOCK();
+  return rc < 0 ? fail("dio_close failed") : 0;
+}
+
+int dio_exists(int64_t file, const char* name) {
+  LOCK();
+  const htri_t r = H5Lexists((hid_t)file, name, H5P_DEFAULT);
+  UNLOCK();
+  return r < 0 ? fail("dio_exists failed") : (r > 0);
+}
+
+/* ---- datasets --------------------------------------------------------------------------------------- */
+int dio_write_dataset(int64_t file, const char* name, int dtype, int ndim, const uint64_t* shape, const uint64_t* chunks,
+                      int compression, const void* data) {
+  if (!name || ndim < 0 || ndim > DIO_MAX_DIMS || (ndim > 0 && !shape)) return fail("dio_write_dataset: bad argument");
+  const size_t esz = dtype_size(dtype);
+  if (esz == 0) return fail("dio_write_dataset: unsupported element type %d", dtype);
+  if (!chunks && compression != DIO_COMP_NONE) return fail("dio_write_dataset: compression needs chunks");
+  hsize_t dims[DIO_MAX_DIMS], cdims[DIO_MAX_DIMS];
+  size_t total = 1, chunk_elems = 1;
+  for (int i = 0; i < ndim; ++i) {
+    dims[i] = shape[i];
+    total *= (size_t)shape[i];
+  }
+  int chunked = chunks != NULL && total > 0 && ndim > 0;
+  if (chunked) {
+    for (int i = 0; i < ndim; ++i) {
+      cdims[i] = chunks[i] < 1 ? 1 : (chunks[i] > shape[i] ? shape[i] : chunks[i]);
+      chunk_elems *= (size_t)cdims[i];
+    }
+    if (chunk_elems * esz > 0xffffffffu) return fail("dio_write_dataset: chunk larger than 4 GiB");
+  }
+  if (total > 0 && !data) return fail("dio_write_dataset: no data");
+  hid_t ftype = -1, space = -1, dcpl = -1, dset = -1;
+  int rc = 0;
+  LOCK();
+  ftype = make_type(dtype);
+  space = ndim == 0 ? H5Screate(H5S_SCALAR) : H5Screate_simple(ndim, dims, NULL);
+  dcpl = H5Pcreate(H5P_DATASET_CREATE);
+  if (ftype < 0 || space < 0 || dcpl < 0) rc = fail("dio_write_dataset: HDF5 object creation failed");
+  if (rc == 0 && chunked) {
+    if (H5Pset_chunk(dcpl, ndim, cdims) < 0) rc = fail("H5Pset_chunk failed");
+    if (rc == 0 && compression == DIO_COMP_LZF) {
+      const unsigned cd[3] = {DIO_LZF_REVISION, DIO_LZF_VERSION, (unsigned)(chunk_elems * esz)};
+      if (H5Pset_filter(dcpl, DIO_LZF_FILTER, H5Z_FLAG_OPTIONAL, 3, cd) < 0) rc = fail("H5Pset_filter(lzf) failed");
+    }
+  }
+  if (rc == 0) {
+    dset = H5Dcreate2((hid_t)file, name, ftype, space, H5P_DEFAULT, dcpl, H5P_DEFAULT);
+    if (dset < 0) rc = fail("H5Dcreate2('%s') failed", name);
+  }
+  if (rc == 0 && total > 0 && !chunked) {
+    if (H5Dwrite(dset, ftype, H5S_ALL, H5S_ALL, H5P_DEFAULT, data) < 0) rc = fail("H5Dwrite('%s') failed", name);
+  }
+  UNLOCK();
+  if (rc == 0 && total > 0 && chunked) {
+    /* chunk by chunk: gather (zero padded at the edges) and compress without the lock, hand over with it */
+    const size_t cbytes = chunk_elems * esz;
+    unsigned char* cbuf = (unsigned char*)malloc(cbytes);
+    unsigned char* zbuf = compression == DIO_COMP_LZF ? (unsigned char*)malloc(cbytes) : NULL;
+    if (!cbuf || (compression == DIO_COMP_LZF && !zbuf)) rc = fail("dio_write_dataset: out of memory");
+    hsize_t nchunk[DIO_MAX_DIMS], cidx[DIO_MAX_DIMS], off[DIO_MAX_DIMS];
+    size_t stride[DIO_MAX_DIMS]; /* element strides of the source array */
+    size_t nch = 1;
+    for (int i = ndim - 1, s = 1; i >= 0; --i) {
+      stride[i] = (size_t)s;
+      s *= (int)1;
+      stride[i] = i == ndim - 1 ? 1 : stride[i + 1] * (size_t)dims[i + 1];
+    }
+    for (int i = 0; i < ndim; ++i) {
+      nchunk[i] = (dims[i] + cdims[i] - 1) / cdims[i];
+      nch *= (size_t)nchunk[i];
+      cidx[i] = 0;
+    }
+    const unsigned char* src = (const unsigned char*)data;
+    for (size_t c = 0; c < nch && rc == 0; ++c) {
+      size_t ext[DIO_MAX_DIMS];
+      int full = 1;
+      for (int i = 0; i < ndim; ++i) {
+        off[i] = cidx[i] * cdims[i];
+        ext[i] = (size_t)((off[i] + cdims[i] <= dims[i]) ? cdims[i] : dims[i] - off[i]);
+        if (ext[i] != cdims[i]) full = 0;
+      }
+      if (!full) memset(cbuf, 0, cbytes);
+      /* copy runs along the last axis */
+      size_t idx[DIO_MAX_DIMS] = {0};
+      const size_t run = ext[ndim - 1] * esz;
+      for (;;) {
+        size_t so = 0, dof = 0, cs = 1;
+        for (int i = ndim - 1; i >= 0; --i) {
+          so += ((size_t)off[i] + idx[i]) * stride[i];
+          dof += idx[i] * cs;
+          cs *= (size_t)cdims[i];
+        }
+        memcpy(cbuf + dof * esz, src + so * esz, run);
+        int d = ndim - 2;
+        while (d >= 0) {
+          if (++idx[d] < ext[d]) break;
+          idx[d] = 0;
+          --d;
+        }
+        if (d < 0) break;
+      }
+      const void* wbuf = cbuf;
+      size_t wbytes = cbytes;
+      uint32_t mask = 0;
+      if (compression == DIO_COMP_LZF) {
+        /* dense full-precision doubles do not compress: probe the head of the chunk before paying for all of it */
+        const size_t probe = cbytes < 8192 ? cbytes : 8192;
+        size_t got = dio_lzf_compress(cbuf, probe, zbuf, probe - probe / 16 - 1);
+        if (got > 0 && probe < cbytes) got = dio_lzf_compress(cbuf, cbytes, zbuf, cbytes - 1);
+        if (got > 0) {
+          wbuf = zbuf;
+          wbytes = got;
+        } else {
+          mask = 1; /* filter 0 of the pipeline was skipped for this chunk */
+        }
+      }
+      LOCK();
+      if (H5Dwrite_chunk(dset, H5P_DEFAULT, mask, off, wbytes, wbuf) < 0) rc = fail("H5Dwrite_chunk('%s') failed", name);
+      UNLOCK();
+      for (int d = ndim - 1; d >= 0; --d) {
+        if (++cidx[d] < nchunk[d]) break;
+        cidx[d] = 0;
+      }
+    }
+    free(cbuf);
+    free(zbuf);
+  }
+  LOCK();
+  if (dset >= 0) H5Dclose(dset);
+  if (dcpl >= 0) H5Pclose(dcpl);
+  if (space >= 0) H5Sclose(space);
+  if (ftype >= 0) H5Tclose(ftype);
+  UNLOCK();
+  return rc;
+}
+
+int dio_dataset_info(int64_t file, const char* name, int* dtype, int* ndim, uint64_t* shape, uint64_t* chunks,
+                     int* compression) {
+  int rc = 0;
+  LOCK();
+  hid_t dset = H5Dopen2((hid_t)file, name, H5P_DEFAULT);
+  if (dset < 0) {
+    UNLOCK();
+    return fail("no dataset '%s'", name);
+  }
+  hid_t t = H5Dget_type(dset), s = H5Dget_space(dset), p = H5Dget_create_plist(dset);
+  hsize_t dims[H5S_MAX_RANK];
+  const int nd = H5Sget_simple_extent_ndims(s);
+  if (nd < 0 || nd > DIO_MAX_DIMS) rc = fail("dataset '%s': unsupported rank %d", name, nd);
+  if (rc == 0) {
+    H5Sget_simple_extent_dims(s, dims, NULL);
+    if (dtype) *dtype = classify(t);
+    if (ndim) *ndim = nd;
+    for (int i = 0; i < nd; ++i) {
+      if (shape) shape[i] = dims[i];
+      if (chunks) chunks[i] = 0;
+    }
+    if (chunks && H5Pget_layout(p) == H5D_CHUNKED) {
+      hsize_t cd[H5S_MAX_RANK];
+      H5Pget_chunk(p, nd, cd);
+      for (int i = 0; i < nd; ++i) chunks[i] = cd[i];
+    }
+    if (compression) {
+      const int nf = H5Pget_nfilters(p);
+      *compression = DIO_COMP_NONE;
+      if (nf > 0) {
+        unsigned fl;
+        size_t ne = 0;
+        const H5Z_filter_t id = H5Pget_filter2(p, 0, &fl, &ne, NULL, 0, NULL, NULL);
+        *compression = (nf == 1 && id == DIO_LZF_FILTER) ? DIO_COMP_LZF : -1;
+      }
+    }
+  }
+  H5Pclose(p);
+  H5Sclose(s);
+  H5Tclose(t);
+  H5Dclose(dset);
+  UNLOCK();
+  return rc;
+}
+
+int dio_read_dataset(int64_t file, const char* name, int dtype, const uint64_t* start, const uint64_t* count, void* out) {
+  int rc = 0;
+  LOCK();
+  hid_t dset = H5Dopen2((hid_t)file, name, H5P_DEFAULT);
+  if (dset < 0) {
+    UNLOCK();
+    return fail("no dataset '%s'", name);
+  }
+  hid_t mt = make_type(dtype), fs = H5Dget_space(dset), ms = H5S_ALL;
+  if (mt < 0) rc = fail("dio_read_dataset: unsupported element type %d", dtype);
+  const int nd = H5Sget_simple_extent_ndims(fs);
+  if (rc == 0 && start && count && nd > 0) {
+    hsize_t st[H5S_MAX_RANK], ct[H5S_MAX_RANK];
+    size_t total = 1;
+    for (int i = 0; i < nd; ++i) {
+      st[i] = start[i];
+      ct[i] = count[i];
+      total *= (size_t)count[i];
+    }
+    if (total == 0) goto done;
+    if (H5Sselect_hyperslab(fs, H5S_SELECT_SET, st, NULL, ct, NULL) < 0) rc = fail("hyperslab selection failed");
+    ms = H5Screate_simple(nd, ct, NULL);
+  } else if (rc == 0) {
+    if (H5Sget_simple_extent_npoints(fs) == 0) goto done;
+  }
+  if (rc == 0 && H5Dread(dset, mt, ms, ms == H5S_ALL ? H5S_ALL : fs, H5P_DEFAULT, out) < 0)
+    rc = fail("H5Dread('%s') failed (unknown filter or type conversion)", name);
+done:
+  if (ms != H5S_ALL && ms >= 0) H5Sclose(ms);
+  if (mt >= 0) H5Tclose(mt);
+  H5Sclose(fs);
+  H5Dclose(dset);
+  UNLOCK();
+  return rc;
+}
+
+struct namebuf {
+  char* buf;
+  int64_t cap, used;
+};
+
+static void nb_add(struct namebuf* nb, const char* s) {
+  const int64_t n = (int64_t)strlen(s);
+  if (nb->buf && nb->used + n + 1 <= nb->cap) {
+    memcpy(nb->buf + nb->used, s, (size_t)n);
+    nb->buf[nb->used + n] = '\n';
+  }
+  nb->used += n + 1;
+}
+
+static herr_t link_cb(hid_t g, const char* name, const H5L_info_t* info, void* data) {
+  (void)g;
+  (void)info;
+  nb_add((struct namebuf*)data, name);
+  return 0;
+}
+
+static herr_t attr_cb(hid_t loc, const char* name, const H5A_info_t* info, void* data) {
+  (void)loc;
+  (void)info;
+  nb_add((struct namebuf*)data, name);
+  return 0;
+}
+
+int64_t dio_list(int64_t file, char* buf, int64_t buflen) {
+  struct namebuf nb = {buf, buflen, 0};
+  LOCK();
+  const herr_t rc = H5Literate((hid_t)file, H5_INDEX_NAME, H5_ITER_INC, NULL, link_cb, &nb);
+  UNLOCK();
+  return rc < 0 ? fail("H5Literate failed") : nb.used;
+}
+
+int64_t dio_list_attrs(int64_t file, char* buf, int64_t buflen) {
+  struct namebuf nb = {buf, buflen, 0};
+  LOCK();
+  const herr_t rc = H5Aiterate2((hid_t)file, H5_INDEX_NAME, H5_ITER_INC, NULL, attr_cb, &nb);
+  UNLOCK();
+  return rc < 0 ? fail("H5Aiterate2 failed") : nb.used;
+}
+
+/* ---- attributes ------------------------------------------------------------------------------------- */
+int dio_write_attr(int64_t file, const char* name, int dtype, int ndim, const uint64_t* shape, const void* data) {
+  if (!name || !data || ndim < 0 || ndim > DIO_MAX_DIMS) return fail("dio_write_attr: bad argument");
+  hsize_t dims[DIO_MAX_DIMS];
+  for (int i = 0; i < ndim; ++i) dims[i] = shape[i];
+  int rc = 0;
+  LOCK();
+  hid_t t = make_type(dtype);
+  hid_t s = ndim == 0 ? H5Screate(H5S_SCALAR) : H5Screate_simple(ndim, dims, NULL);
+  if (t < 0 || s < 0) rc = fail("dio_write_attr: unsupported type %d", dtype);
+  if (rc == 0) {
+    if (H5Aexists((hid_t)file, name) > 0) H5Adelete((hid_t)file, name);
+    hid_t a = H5Acreate2((hid_t)file, name, t, s, H5P_DEFAULT, H5P_DEFAULT);
+    if (a < 0) {
+      rc = fail("H5Acreate2('%s') failed", name);
+    } else {
+      const char* sp = (const char*)data;
+      const void* src = dtype == DIO_STR ? (const void*)&sp : data;
+      if (H5Awrite(a, t, src) < 0) rc = fail("H5Awrite('%s') failed", name);
+      H5Aclose(a);
+    }
+  }
+  if (s >= 0) H5Sclose(s);
+  if (t >= 0) H5Tclose(t);
+  UNLOCK();
+  return rc;
+}
+
+int dio_attr_info(int64_t file, const char* name, int* dtype, int* ndim, uint64_t* shape, int64_t* strlen_out) {
+  int rc = 0;
+  LOCK();
+  hid_t a = H5Aopen((hid_t)file, name, H5P_DEFAULT);
+  if (a < 0) {
+    UNLOCK();
+    return fail("no attribute '%s'", name);
+  }
+  hid_t t = H5Aget_type(a), s = H5Aget_space(a);
+  const int cls = classify(t);
+  const int nd = H5Sget_simple_extent_ndims(s);
+  hsize_t dims[H5S_MAX_RANK];
+  if (nd < 0 || nd > DIO_MAX_DIMS) rc = fail("attribute '%s': unsupported rank", name);
+  if (rc == 0) {
+    if (nd > 0) H5Sget_simple_extent_dims(s, dims, NULL);
+    if (dtype) *dtype = cls;
+    if (ndim) *ndim = nd;
+    for (int i = 0; i < nd && shape; ++i) shape[i] = dims[i];
+    if (strlen_out) {
+      *strlen_out = 0;
+      if (cls == DIO_STR && nd == 0) {
+        if (H5Tis_variable_str(t) > 0) {
+          char* p = NULL;
+          hid_t mt = make_type(DIO_STR);
+          if (H5Aread(a, mt, &p) >= 0 && p) {
+            *strlen_out = (int64_t)strlen(p);
+            H5free_memory(p);
+          }
+          H5Tclose(mt);
+        } else {
+          *strlen_out = (int64_t)H5Tget_size(t);
+        }
+      }
+    }
+  }
+  H5Sclose(s);
+  H5Tclose(t);
+  H5Aclose(a);
+  UNLOCK();
+  return rc;
+}
+
+int dio_read_attr(int64_t file, const char* name, int dtype, void* out, int64_t outlen) {
+  int rc = 0;
+  LOCK();
+  hid_t a = H5Aopen((hid_t)file, name, H5P_DEFAULT);
+  if (a < 0) {
+    UNLOCK();
+    return fail("no attribute '%s'", name);
+  }
+  if (dtype == DIO_STR) {
+    hid_t t = H5Aget_type(a);
+    if (H5Tis_variable_str(t) > 0) {
+      char* p = NULL;
+      hid_t mt = make_type(DIO_STR);
+      if (H5Aread(a, mt, &p) < 0 || !p) {
+        rc = fail("H5Aread('%s') failed", name);
+      } else {
+        snprintf((char*)out, (size_t)outlen, "%s", p);
+        H5free_memory(p);
+      }
+      H5Tclose(mt);
+    } else {
+      const size_t sz = H5Tget_size(t);
+      char* tmp = (char*)calloc(sz + 1, 1);
+      hid_t mt = H5Tcopy(H5T_C_S1);
+      H5Tset_size(mt, sz);
+      if (!tmp || H5Aread(a, mt, tmp) < 0) rc = fail("H5Aread('%s') failed", name);
+      else snprintf((char*)out, (size_t)outlen, "%s", tmp);
+      H5Tclose(mt);
+      free(tmp);
+    }
+    H5Tclose(t);
+  } else {
+    hid_t mt = make_type(dtype);
+    if (mt < 0 || H5Aread(a, mt, out) < 0) rc = fail("H5Aread('%s') failed", name);
+    if (mt >= 0) H5Tclose(mt);
+  }
+  H5Aclose(a);
+  UNLOCK();
+  return rc;
+}

@@ -1,11 +1,25 @@
-"""Product files: real HDF5 through h5py when it is importable, otherwise a
-directory-free single-file ``.npz`` mirror with the same group/dataset/attribute
-names.  The reference's on-disk layout is preserved by name: the
-same paths (``bt/beam_m/<m>/beam.hdf5`` ...), dataset names and attributes; with
-the mirror back-end the file at that path holds an npz archive instead of HDF5
-(h5py is not part of this image's primary Python).
+"""Product files.
+
+Three back-ends behind one small h5py-like interface (``File``, ``create_dataset``, ``f[name][idx]``,
+``f.attrs``), picked in this order:
+
+  h5py       when it is importable (not in this image's primary Python);
+  libdriftio the in-tree C library (``include/driftio.h``, ``csrc/dm_h5io.c``) on the HDF5 C API: REAL
+             HDF5 files with the reference's dataset names, chunk shapes, the compound ``{r, i}`` complex
+             type h5py uses and LZF compression (filter 32000, its own codec), readable by plain h5py —
+             and lzf files written by the reference are readable here.  Chunks are compressed by the calling
+             thread outside the library's HDF5 lock, so the writer pool below scales with its threads;
+  npz        a single-file ``.npz`` mirror with the same names, when no HDF5 library can be loaded.
+
+Every back-end writes to ``<path>.tmp<pid>`` and renames on close (the reference guards its svd files
+the same way, ``caput.misc.lock_file``, drift/core/beamtransfer.py:738): a killed run never leaves a
+truncated file under the final name, so "skip if the file exists" resumes are safe.
+``DRIFTMI_STORAGE = hdf5 | npz`` forces a back-end.  Readers look at the file's magic bytes, not at the
+configured back-end.
 """
+import ctypes
 import os
+import threading
 
 import numpy as np
 
@@ -17,8 +31,88 @@ except Exception:  # pragma: no cover
     h5py = None
     HAVE_H5PY = False
 
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_DIO_PATH = os.path.join(_HERE, "lib", "libdriftio.so")
+_dio = None
+_dio_tried = False
 
-class _NpzDataset(object):
+F64, C128, I64, I32, BOOL, STR, F32, OTHER = 0, 1, 2, 3, 4, 5, 6, 99
+COMP_NONE, COMP_LZF = 0, 1
+_NP2DIO = {np.dtype(np.float64): F64, np.dtype(np.complex128): C128, np.dtype(np.int64): I64,
+           np.dtype(np.int32): I32, np.dtype(np.bool_): BOOL, np.dtype(np.float32): F32}
+_DIO2NP = {v: k for k, v in _NP2DIO.items()}
+
+DIO_SIGNATURES = {
+    "dio_last_error": (ctypes.c_char_p, []),
+    "dio_version": (ctypes.c_int, []),
+    "dio_hdf5_version": (ctypes.c_int, []),
+    "dio_open": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
+    "dio_close": (ctypes.c_int, [ctypes.c_int64]),
+    "dio_write_dataset": (ctypes.c_int, [ctypes.c_int64, ctypes.c_char_p, ctypes.c_int, ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.c_int,
+                                         ctypes.c_void_p]),
+    "dio_dataset_info": (ctypes.c_int, [ctypes.c_int64, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int),
+                                        ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64),
+                                        ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int)]),
+    "dio_read_dataset": (ctypes.c_int, [ctypes.c_int64, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64),
+                                        ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p]),
+    "dio_exists": (ctypes.c_int, [ctypes.c_int64, ctypes.c_char_p]),
+    "dio_list": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_char_p, ctypes.c_int64]),
+    "dio_write_attr": (ctypes.c_int, [ctypes.c_int64, ctypes.c_char_p, ctypes.c_int, ctypes.c_int,
+                                      ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p]),
+    "dio_attr_info": (ctypes.c_int, [ctypes.c_int64, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int),
+                                     ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64),
+                                     ctypes.POINTER(ctypes.c_int64)]),
+    "dio_read_attr": (ctypes.c_int, [ctypes.c_int64, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]),
+    "dio_list_attrs": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_char_p, ctypes.c_int64]),
+    "dio_lzf_compress": (ctypes.c_size_t, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]),
+    "dio_lzf_decompress": (ctypes.c_size_t, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]),
+}
+
+
+def load_driftio():
+    """libdriftio.so with its prototypes declared, or None when it (or the HDF5 library it links) is absent."""
+    global _dio, _dio_tried
+    if _dio_tried:
+        return _dio
+    _dio_tried = True
+    try:
+        lib = ctypes.CDLL(_DIO_PATH)
+        for name, (res, args) in DIO_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        lib.dio_hdf5_version()
+        _dio = lib
+    except (OSError, AttributeError):
+        _dio = None
+    return _dio
+
+
+def backend():
+    forced = os.environ.get("DRIFTMI_STORAGE", "").lower()
+    if forced == "npz":
+        return "npz"
+    if forced == "hdf5":
+        if HAVE_H5PY:
+            return "h5py"
+        if load_driftio() is None:
+            raise IOError("DRIFTMI_STORAGE=hdf5 but neither h5py nor libdriftio (HDF5 C library) can be loaded")
+        return "driftio"
+    if HAVE_H5PY:
+        return "h5py"
+    return "driftio" if load_driftio() is not None else "npz"
+
+
+def _is_hdf5(path):
+    try:
+        with open(path, "rb") as fh:
+            return fh.read(8) == b"\x89HDF\r\n\x1a\n"
+    except IOError:
+        return False
+
+
+# ---- in-memory dataset shared by the write-at-close back-ends -----------------------------------
+class _MemDataset(object):
     def __init__(self, owner, name):
         self._o, self._n = owner, name
 
@@ -27,13 +121,24 @@ class _NpzDataset(object):
 
     @property
     def shape(self):
-        return self._arr().shape
+        return self._o._shape(self._n)
 
     @property
     def dtype(self):
-        return self._arr().dtype
+        return self._o._dtype(self._n)
+
+    @property
+    def chunks(self):
+        return self._o._layout(self._n)[0]
+
+    @property
+    def compression(self):
+        return self._o._layout(self._n)[1]
 
     def __getitem__(self, idx):
+        part = self._o._read_part(self._n, idx)
+        if part is not None:
+            return part
         out = self._arr()[idx]
         return np.array(out) if isinstance(out, np.ndarray) else out
 
@@ -45,46 +150,81 @@ class _NpzDataset(object):
         return self.shape[0]
 
 
-class NpzFile(object):
-    """Minimal h5py.File look-alike persisted as one ``.npz`` archive at ``path``."""
+class _BaseFile(object):
+    """Write-at-close file: datasets live as numpy arrays until ``close`` writes them to a temporary file that is
+    then renamed.  Subclasses provide ``_open_existing``, ``_read``, ``_write_all``."""
 
     def __init__(self, path, mode="r"):
         self.path, self.mode = path, mode
-        self._data, self.attrs, self._dirty = {}, {}, False
-        self._lazy = None   # open archive of a file being read: datasets are loaded when first touched
+        self._data, self._opts, self.attrs, self._dirty = {}, {}, {}, False
+        self._h = None
         if mode in ("r", "r+", "a") and os.path.exists(path):
-            z = np.load(path, allow_pickle=False)
-            for k in z.files:
-                if k.startswith("__attr__"):
-                    v = z[k]
-                    self.attrs[k[8:]] = v.item() if v.shape == () else v
-                else:
-                    self._data[k] = None
-            self._lazy = z
-        elif mode == "r":
+            self._open_existing()
+        elif mode in ("r", "r+"):
             raise IOError("no such file: %s" % path)
         if mode == "w":
             self._dirty = True
 
-    def create_dataset(self, name, shape=None, dtype=None, data=None, **kwargs):
+    # -- subclass hooks
+    def _open_existing(self):
+        raise NotImplementedError
+
+    def _read(self, name):
+        raise NotImplementedError
+
+    def _write_all(self, tmp):
+        raise NotImplementedError
+
+    def _close_handle(self):
+        pass
+
+    def _info(self, name):
+        return None
+
+    def _read_part(self, name, idx):
+        return None
+
+    # -- h5py-like surface
+    def create_dataset(self, name, shape=None, dtype=None, data=None, chunks=None, compression=None, **kwargs):
         if data is not None:
             # no copy for arrays handed over for writing (the products are hundreds of MB per file)
             arr = np.asarray(data, dtype=dtype) if dtype is not None else np.asarray(data)
         else:
             arr = np.zeros(shape, dtype=dtype)
         self._data[name] = arr
+        self._opts[name] = (tuple(int(c) for c in chunks) if chunks is not None else None, compression)
         self._dirty = True
-        return _NpzDataset(self, name)
+        return _MemDataset(self, name)
 
     def _load(self, name):
         if self._data[name] is None:
-            self._data[name] = self._lazy[name]
+            self._data[name] = self._read(name)
         return self._data[name]
+
+    def _shape(self, name):
+        if self._data[name] is None:
+            info = self._info(name)
+            if info is not None:
+                return info[1]
+        return self._load(name).shape
+
+    def _dtype(self, name):
+        if self._data[name] is None:
+            info = self._info(name)
+            if info is not None:
+                return info[0]
+        return self._load(name).dtype
+
+    def _layout(self, name):
+        if name in self._opts:
+            return self._opts[name]
+        info = self._info(name)
+        return (info[2], info[3]) if info is not None else (None, None)
 
     def __getitem__(self, name):
         if name not in self._data:
             raise KeyError(name)
-        return _NpzDataset(self, name)
+        return _MemDataset(self, name)
 
     def __contains__(self, name):
         return name in self._data
@@ -93,18 +233,22 @@ class NpzFile(object):
         return self._data.keys()
 
     def close(self):
-        if self.mode != "r" and (self._dirty or self.attrs):
-            payload = {k: self._load(k) for k in self._data}
-            for k, v in self.attrs.items():
-                payload["__attr__" + k] = np.asarray(v)
-            tmp = self.path + ".tmp%d" % os.getpid()
-            with open(tmp, "wb") as fh:
-                np.savez(fh, **payload)
-            os.replace(tmp, self.path)  # write-temp-then-rename, like caput.misc.lock_file
+        if self.mode != "r" and (self._dirty or (self.attrs and self.mode == "w")):
+            for k in self._data:   # read-modify-write: everything must be in memory before the old file goes away
+                self._load(k)
+                if k not in self._opts:
+                    chunks, comp = self._layout(k)   # keep the chunk shape / compression the dataset had
+                    self._opts[k] = (chunks, comp if comp in (None, "lzf") else None)
+            self._close_handle()
+            tmp = self.path + ".tmp%d_%d" % (os.getpid(), threading.get_ident())
+            try:
+                self._write_all(tmp)
+                os.replace(tmp, self.path)  # write-temp-then-rename, like caput.misc.lock_file
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
             self._dirty = False
-        if self._lazy is not None:
-            self._lazy.close()
-            self._lazy = None
+        self._close_handle()
 
     def __enter__(self):
         return self
@@ -114,19 +258,247 @@ class NpzFile(object):
         return False
 
 
+class NpzFile(_BaseFile):
+    """Minimal h5py.File look-alike persisted as one ``.npz`` archive at ``path``."""
+
+    def _open_existing(self):
+        z = np.load(self.path, allow_pickle=False)
+        for k in z.files:
+            if k.startswith("__attr__"):
+                v = z[k]
+                self.attrs[k[8:]] = v.item() if v.shape == () else v
+            else:
+                self._data[k] = None
+        self._h = z   # datasets are loaded when first touched
+
+    def _read(self, name):
+        return self._h[name]
+
+    def _write_all(self, tmp):
+        payload = {k: self._data[k] for k in self._data}
+        for k, v in self.attrs.items():
+            payload["__attr__" + k] = np.asarray(v)
+        with open(tmp, "wb") as fh:
+            np.savez(fh, **payload)
+
+    def _close_handle(self):
+        if self._h is not None:
+            self._h.close()
+            self._h = None
+
+
+def _u64(seq):
+    return (ctypes.c_uint64 * max(len(seq), 1))(*[int(x) for x in seq])
+
+
+class DriftioFile(_BaseFile):
+    """HDF5 through libdriftio (include/driftio.h)."""
+
+    def __init__(self, path, mode="r"):
+        self._lib = load_driftio()
+        if self._lib is None:
+            raise IOError("libdriftio is not available")
+        self._infos = {}
+        _BaseFile.__init__(self, path, mode)
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise IOError("%s: %s" % (what, (self._lib.dio_last_error() or b"").decode()))
+        return rc
+
+    @staticmethod
+    def _names(fn, h):
+        n = fn(h, None, 0)
+        if n <= 0:
+            return []
+        buf = ctypes.create_string_buffer(int(n) + 1)
+        fn(h, buf, n)
+        return [s for s in buf.raw[: int(n)].decode().split("\n") if s]
+
+    def _open_existing(self):
+        h = ctypes.c_int64(0)
+        self._check(self._lib.dio_open(self.path.encode(), b"r", ctypes.byref(h)), "open %s" % self.path)
+        self._h = h
+        for name in self._names(self._lib.dio_list, h):
+            self._data[name] = None
+        for name in self._names(self._lib.dio_list_attrs, h):
+            self.attrs[name] = self._read_attr(name)
+
+    def _read_attr(self, name):
+        dt, nd, sl = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int64(0)
+        shape = (ctypes.c_uint64 * 8)()
+        self._check(self._lib.dio_attr_info(self._h, name.encode(), ctypes.byref(dt), ctypes.byref(nd), shape,
+                                            ctypes.byref(sl)), "attribute %s" % name)
+        if dt.value == STR:
+            buf = ctypes.create_string_buffer(int(sl.value) + 1)
+            self._check(self._lib.dio_read_attr(self._h, name.encode(), STR, buf, int(sl.value) + 1), "attribute %s" % name)
+            return buf.value.decode()
+        if dt.value not in _DIO2NP:
+            return None
+        out = np.zeros(tuple(int(shape[i]) for i in range(nd.value)), dtype=_DIO2NP[dt.value])
+        self._check(self._lib.dio_read_attr(self._h, name.encode(), dt.value, out.ctypes.data_as(ctypes.c_void_p), out.nbytes),
+                    "attribute %s" % name)
+        return out[()] if out.shape == () else out
+
+    def _info(self, name):
+        if name not in self._infos:
+            if self._h is None:
+                return None
+            dt, nd, comp = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+            shape, chunks = (ctypes.c_uint64 * 8)(), (ctypes.c_uint64 * 8)()
+            self._check(self._lib.dio_dataset_info(self._h, name.encode(), ctypes.byref(dt), ctypes.byref(nd), shape, chunks,
+                                                   ctypes.byref(comp)), "dataset %s" % name)
+            shp = tuple(int(shape[i]) for i in range(nd.value))
+            chk = tuple(int(chunks[i]) for i in range(nd.value))
+            self._infos[name] = (_DIO2NP.get(dt.value, np.dtype(np.float64)), shp, chk if any(chk) else None,
+                                 {COMP_NONE: None, COMP_LZF: "lzf"}.get(comp.value, "unknown"), dt.value)
+        return self._infos[name]
+
+    def _read(self, name, start=None, count=None):
+        info = self._info(name)
+        if info[4] not in _DIO2NP:
+            raise IOError("dataset %s has an element type this reader does not handle" % name)
+        shape = info[1] if count is None else tuple(count)
+        out = np.empty(shape, dtype=info[0])
+        if out.size:
+            st = _u64(start) if start is not None else None
+            ct = _u64(count) if count is not None else None
+            self._check(self._lib.dio_read_dataset(self._h, name.encode(), info[4], st, ct,
+                                                   out.ctypes.data_as(ctypes.c_void_p)), "read %s" % name)
+        return out
+
+    def _read_part(self, name, idx):
+        """Index the leading axis with an int or a slice straight from the file (one frequency of a block:
+        `beam_m(mi, fi)` of the reference reads `fh[dset][fi]`) instead of loading the whole dataset."""
+        if self._data.get(name) is not None or self._h is None:
+            return None
+        info = self._info(name)
+        shp = info[1]
+        if not shp:
+            return None
+        first, rest = (idx[0], idx[1:]) if isinstance(idx, tuple) and idx else (idx, ())
+        if isinstance(first, (int, np.integer)):
+            i = int(first) + (shp[0] if first < 0 else 0)
+            if not 0 <= i < shp[0]:
+                raise IndexError(first)
+            part = self._read(name, (i,) + (0,) * (len(shp) - 1), (1,) + shp[1:])[0]
+        elif isinstance(first, slice) and first.step in (None, 1) and first != slice(None):
+            a, b, _ = first.indices(shp[0])
+            part = self._read(name, (a,) + (0,) * (len(shp) - 1), (max(b - a, 0),) + shp[1:])
+        else:
+            return None
+        return part[rest] if rest else part
+
+    def _write_all(self, tmp):
+        h = ctypes.c_int64(0)
+        self._check(self._lib.dio_open(tmp.encode(), b"w", ctypes.byref(h)), "create %s" % tmp)
+        try:
+            for name, arr in self._data.items():
+                arr = np.asarray(arr)
+                if arr.dtype not in _NP2DIO:
+                    arr = arr.astype(np.complex128 if arr.dtype.kind == "c" else (np.int64 if arr.dtype.kind in "iu" else np.float64))
+                arr = np.ascontiguousarray(arr).reshape(arr.shape)   # ascontiguousarray turns 0-d into 1-d
+                chunks, comp = self._opts.get(name, (None, None))
+                if comp not in (None, "lzf"):
+                    raise IOError("compression %r is not available (libdriftio writes lzf)" % (comp,))
+                if comp == "lzf" and chunks is None:
+                    chunks = arr.shape   # h5py would guess a chunk shape; one chunk keeps small datasets simple
+                if arr.ndim == 0 or arr.size == 0:
+                    chunks, comp = None, None
+                self._check(self._lib.dio_write_dataset(h, name.encode(), _NP2DIO[arr.dtype], arr.ndim, _u64(arr.shape),
+                                                        _u64(chunks) if chunks is not None else None,
+                                                        COMP_LZF if comp == "lzf" else COMP_NONE,
+                                                        arr.ctypes.data_as(ctypes.c_void_p)), "write %s" % name)
+            for k, v in self.attrs.items():
+                self._write_attr(h, k, v)
+        finally:
+            self._lib.dio_close(h)
+
+    def _write_attr(self, h, name, v):
+        if isinstance(v, bytes):
+            v = v.decode()
+        if isinstance(v, str):
+            self._check(self._lib.dio_write_attr(h, name.encode(), STR, 0, None, ctypes.c_char_p(v.encode())), "attr %s" % name)
+            return
+        a = np.asarray(v)
+        if a.dtype.kind in "US":
+            self._write_attr(h, name, str(a.item()) if a.shape == () else ",".join(str(x) for x in a.ravel()))
+            return
+        if a.dtype not in _NP2DIO:
+            a = a.astype(np.complex128 if a.dtype.kind == "c" else (np.int64 if a.dtype.kind in "iu" else np.float64))
+        a = np.ascontiguousarray(a).reshape(a.shape)
+        self._check(self._lib.dio_write_attr(h, name.encode(), _NP2DIO[a.dtype], a.ndim, _u64(a.shape) if a.ndim else None,
+                                             a.ctypes.data_as(ctypes.c_void_p)), "attr %s" % name)
+
+    def _close_handle(self):
+        if self._h is not None:
+            self._lib.dio_close(self._h)
+            self._h = None
+
+
+class _H5pyTmp(object):
+    """h5py.File opened for writing on a temporary name, renamed into place on close."""
+
+    def __init__(self, path, **kwargs):
+        self._path = path
+        self._tmp = path + ".tmp%d_%d" % (os.getpid(), threading.get_ident())
+        self._f = h5py.File(self._tmp, "w", **kwargs)
+
+    def __getattr__(self, name):
+        return getattr(self._f, name)
+
+    def __getitem__(self, name):
+        return self._f[name]
+
+    def __contains__(self, name):
+        return name in self._f
+
+    def close(self):
+        self._f.close()
+        os.replace(self._tmp, self._path)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is None:
+            self.close()
+        else:
+            self._f.close()
+            if os.path.exists(self._tmp):
+                os.remove(self._tmp)
+        return False
+
+
 def File(path, mode="r", **kwargs):
-    """Open a product file with the best available back-end."""
-    if HAVE_H5PY:
-        return h5py.File(path, mode, **kwargs)
+    """Open a product file.  Existing files are opened by what they ARE (HDF5 or npz); new files are written
+    with the configured back-end."""
+    if mode in ("r", "r+", "a") and os.path.exists(path):
+        if _is_hdf5(path):
+            if HAVE_H5PY:
+                return h5py.File(path, mode, **kwargs)
+            if load_driftio() is None:
+                raise IOError("%s is an HDF5 file and no HDF5 library is available" % path)
+            return DriftioFile(path, mode)
+        return NpzFile(path, mode)
+    be = backend()
+    if be == "h5py":
+        return _H5pyTmp(path, **kwargs) if mode == "w" else h5py.File(path, mode, **kwargs)
+    if be == "driftio":
+        return DriftioFile(path, mode)
     return NpzFile(path, mode)
+
+
+def compression_kwargs(chunks):
+    """create_dataset keywords for a chunked, lzf-compressed product dataset (drift/core/beamtransfer.py:548-555,
+    :741-792).  The npz mirror ignores them."""
+    return dict(chunks=tuple(int(c) for c in chunks), compression="lzf")
 
 
 # ---- background writers -------------------------------------------------------------------------
 # Product files are independent per m: they are written by a small thread pool while the GPU works on
 # the next batch (file output is 10x the compute time of BASELINE configs[1] when done inline).
 # DRIFTMI_IO_THREADS = 0 writes inline.
-import threading
-
 _pool = None
 _pending = []
 _plock = threading.Lock()   # submit() may be called from several driver threads (bench --streams)

@@ -241,6 +241,17 @@ int dm_bt_sht_range(dm_ctx* ctx, int nside, const double* ring_cth_host, const d
                     int lside, int m_lo, int m_hi, int lmax_grp, int F, int B, int ncol, const int* col_f_host,
                     const int* col_b_host, const int* col_lmax_host, const void* maps_dev, void* beam_m_dev);
 
+/* ---- bit truncation of beam-transfer blocks before they are written ------------------------------- */
+/* In place on `nrows` rows of `ncols` complex128 values (`ld` elements between rows): every real and
+ * imaginary part is rounded to the coarsest multiple of a power of two that keeps its error below
+ *   err = max(prec * |z|, prec_max_row * max_j |z_row,j|),
+ * ties to even — trailing mantissa bits become zero and the byte planes compress.  Rows are the runs
+ * over l of the m-ordered blocks (the reference truncates `m_array.reshape(-1, nl)`).
+ * Replaces: caput.truncate.bit_truncate_max_complex at drift/core/beamtransfer.py:641-646 (caput is not
+ * vendored with the reference; restated from its documented contract, see oracle/truncate.py). */
+int dm_bit_truncate_max_complex(dm_ctx* ctx, void* data_dev, int64_t nrows, int ncols, int64_t ld, double prec,
+                                double prec_max_row);
+
 #ifdef __cplusplus
 }
 #endif

@@ -183,7 +183,16 @@ def test_kl_properties(c3, mi, bound):
     assert np.all(np.diff(ev) >= 0)
     i_ev = int(np.searchsorted(ev, kl.threshold))
     nk = n - i_ev
-    assert nk > 0
+    assert not E[:i_ev].abs().max().item() if i_ev else True       # modes below the threshold are never formed
+    if nk == 0:
+        # no mode of this block reaches S/N 0.1 (m = 460): check the full set, as `subset = False` forms it
+        kl.subset = False
+        try:
+            ev2, E, _, extra = kl._transform_batch([mi], to_host=False)[0]
+        finally:
+            kl.subset = True
+        assert np.abs(ev2.cpu().numpy() - ev).max() <= 1e-12 * np.abs(ev).max()
+        i_ev, nk = 0, n
     pick = np.arange(i_ev, n) if nk <= 256 else np.unique(np.linspace(i_ev, n - 1, 256).astype(np.int64))
     Ek = E[torch.as_tensor(pick, device=E.device)].cpu().numpy()
     lam = ev[pick]
@@ -194,7 +203,6 @@ def test_kl_properties(c3, mi, bound):
     e3 = float(np.abs(np.diag(ESE).real - lam).max() / np.abs(lam).max())
     _log("m %d: n %d kept %d  |E N E^H - I| %.2e  offdiag(E S E^H) %.2e  diag vs lambda %.2e" % (mi, n, nk, e1, e2, e3))
     assert e1 < bound and e2 < bound and e3 < bound
-    assert not E[:i_ev].abs().max().item() if i_ev else True       # modes below the threshold are never formed
 
 
 def test_doublekl_and_fisher_config4(c3):
@@ -259,12 +267,24 @@ def test_doublekl_and_fisher_config4(c3):
     t0 = time.perf_counter()
     fb = ps.fisher_bias_batch(MS)
     _log("PSExact of 3 blocks, %d bands: %.2f s" % (ps.nbands, time.perf_counter() - t0))
-    evk, Ek = kl.modes_m(460, threshold=0.1)
+    # no mode of m = 460 reaches S/N 0.1: its Fisher matrix is zero there; against the oracle it is taken with
+    # every mode of non-negative eigenvalue (threshold 0) through a second KLTransform / PSExact pair
+    assert kl.modes_m(460, threshold=0.1)[0] is None and not fb[i][0].any()
+    from driftscan_amd import kltransform
+
+    kl0 = kltransform.KLTransform.from_config(dict(threshold=0.0), bt, subdir="kl0")
+    kl0._save(460, *kl0._transform_batch([460], to_host=True)[0])
+    ps0 = psestimation.PSExact.from_config(dict(bandtype="polar", num_theta=3, threshold=0.0,
+                                                k_bands=[dict(spacing="linear", start=0.0, stop=0.25, num=4)]),
+                                           kl0, subdir="ps0")
+    ps0.genbands()
+    f_g = ps0.fisher_bias_batch([460])[0][0]
+    evk, Ek = kl0.modes_m(460, threshold=0.0)
     svnum, svbounds = bt._svd_num(460)
-    f_o, b_o = opf.fisher_m(bs, svnum, svbounds, evk, Ek, ps.clarray)
-    err = np.abs(fb[i][0] - f_o).max() / np.abs(f_o).max()
-    _log("m 460: Fisher matrix vs oracle %.2e of its largest element" % err)
-    assert err < 1e-8
+    f_o, b_o = opf.fisher_m(bs, svnum, svbounds, evk, Ek, ps0.clarray)
+    err = np.abs(f_g - f_o).max() / np.abs(f_o).max()
+    _log("m 460: Fisher matrix (%d modes) vs oracle %.2e of its largest element" % (evk.size, err))
+    assert evk.size > 0 and err < 1e-8
     for k in range(len(MS)):
         Fm = fb[k][0]
         assert np.abs(Fm - Fm.conj().T).max() <= 1e-9 * np.abs(Fm).max()     # Hermitian

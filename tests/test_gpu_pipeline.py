@@ -131,11 +131,11 @@ def test_doublekl(setup):
         with storage.File(dk._evfile % mi, "r") as f:
             f_evals = f["f_evals"][:]
             full = f["evals_full"][:]
-        assert_spectrum(f_evals, g[pre + "f_evals"], tol1, "f_evals m=%d" % mi)
-        ref = g[pre + "evals"]
             kept = f["evals"][:]
             evecs = f["evecs"][:]
             flags = f.attrs["FLAGS"]
+        assert_spectrum(f_evals, g[pre + "f_evals"], tol1, "f_evals m=%d" % mi)
+        ref = g[pre + "evals"]
         # the number of modes passing the foreground cut is exact (doublekl.py:56-60) ...
         assert int((f_evals > dk.foreground_threshold).sum()) == ref.size
         assert int((g[pre + "f_evals"] > dk.foreground_threshold).sum()) == ref.size

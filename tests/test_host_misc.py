@@ -169,3 +169,20 @@ def test_storage_background_writers_and_lazy_reads(tmp_path, monkeypatch):
     with pytest.raises(IOError):
         storage.flush()
     storage.flush()  # the queue is empty again
+
+
+def test_partition_contiguous_balances_cost():
+    """Contiguous m-ranges of equal estimated cost (bench.py --mode sharded, BeamTransfer generation ranges)."""
+    from driftscan_amd import parallel
+
+    items = list(range(129))
+    costs = [130.0 - m for m in items]
+    for n in (1, 2, 3, 8):
+        parts = [parallel.partition_contiguous(items, costs, n=n, r=r) for r in range(n)]
+        assert sum(parts, []) == items                      # a partition, in order
+        assert all(p == list(range(p[0], p[-1] + 1)) for p in parts)
+        loads = [sum(costs[i] for i in p) for p in parts]
+        assert max(loads) <= 1.15 * sum(costs) / n
+    # more ranks than items: everybody gets at most one, nothing is lost
+    parts = [parallel.partition_contiguous([7, 8, 9], [1, 1, 1], n=5, r=r) for r in range(5)]
+    assert sorted(sum(parts, [])) == [7, 8, 9] and max(len(p) for p in parts) == 1
