@@ -47,7 +47,8 @@ def bit_truncate_f64(x, err):
     base = man - r
     up = (r > half) | ((r == half) & (((base >> (k + np.uint64(1))) & np.uint64(1)) == 1))
     base = np.where(up, base + q, base)
-    out = np.ldexp(base.astype(np.float64), e.astype(np.int64))
+    with np.errstate(over="ignore", invalid="ignore"):
+        out = np.ldexp(base.astype(np.float64), e.astype(np.int64))
     out = np.where(bits >> np.uint64(63) == 1, -out, out)
     return np.where(active, out, x)
 
@@ -62,4 +63,7 @@ def bit_truncate_max_complex(val, prec, prec_max_row):
         row_max = np.fmax(np.fmax.reduce(abs2, axis=-1, keepdims=True), 0.0) if val.shape[-1] else 0.0
         floor_err = prec_max_row * np.sqrt(row_max)
         err = np.fmax(prec * np.sqrt(abs2), floor_err)
-    return bit_truncate_f64(re, err) + 1j * bit_truncate_f64(im, err)
+    out = np.empty(val.shape, dtype=np.complex128)   # not re + 1j * im: that turns (inf, nan) into (nan, nan)
+    out.real = bit_truncate_f64(re, err)
+    out.imag = bit_truncate_f64(im, err)
+    return out
