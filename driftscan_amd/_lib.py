@@ -80,6 +80,10 @@ SIGNATURES = {
     "dm_bt_sht_range": (
         c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_int, c_int, c_int, c_int, c_int,
                 c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_vp, c_vp]),
+    "dm_bt_sht_opts": (
+        c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_int, c_int, c_int, c_int, c_int,
+                c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_vp, c_vp, c_int,
+                ctypes.POINTER(c_dbl)]),
     "dm_bit_truncate_max_complex": (c_int, [c_vp, c_vp, c_i64, c_int, c_i64, c_dbl, c_dbl]),
 }
 
@@ -419,13 +423,24 @@ def _bt_maps(self, nside, cth, sth, frame, polarised, beams, uv, bi, bj, maps):
 
 
 def _bt_sht(self, nside, cth, sth, polarised, lside, mmax, lmax_grp, F, B, col_f, col_b, col_lmax, maps, beam_m,
-            m_range=None):
-    """m_range = (m_lo, m_hi): only those m-blocks are produced and `beam_m` has m_hi - m_lo + 1 of them."""
+            m_range=None, niter=0, ring_w=None):
+    """m_range = (m_lo, m_hi): only those m-blocks are produced and `beam_m` has m_hi - m_lo + 1 of them.
+    niter / ring_w: healpy.map2alm's `iter` and ring weights (see dm_bt_sht_opts)."""
     c, cp = _darr(cth)
     s_, sp = _darr(sth)
     f_, fp = _iarr(col_f)
     b_, bp = _iarr(col_b)
     l_, lp = _iarr(col_lmax)
+    if niter or ring_w is not None:
+        m_lo, m_hi = (0, int(mmax)) if m_range is None else (int(m_range[0]), int(m_range[1]))
+        w, wp = (None, None) if ring_w is None else _darr(ring_w)
+        if w is not None and w.size != 4 * int(nside) - 1:
+            raise ValueError("ring weights: need one per ring (4 nside - 1 = %d), got %d" % (4 * int(nside) - 1, w.size))
+        rc = self.lib.dm_bt_sht_opts(self.h, int(nside), cp, sp, int(bool(polarised)), int(lside), m_lo, m_hi,
+                                     int(lmax_grp), int(F), int(B), len(f_), fp, bp, lp, self.ptr(maps), self.ptr(beam_m),
+                                     int(niter), wp)
+        self.check(rc, "dm_bt_sht_opts")
+        return
     if m_range is None:
         rc = self.lib.dm_bt_sht(self.h, int(nside), cp, sp, int(bool(polarised)), int(lside), int(mmax), int(lmax_grp),
                                 int(F), int(B), len(f_), fp, bp, lp, self.ptr(maps), self.ptr(beam_m))

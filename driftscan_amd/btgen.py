@@ -52,6 +52,12 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
     pairs = tel.uniquepairs
     cls = np.asarray(tel.beamclass)
     wl = tel.wavelengths
+    # healpy.map2alm knobs the reference reaches through cora (telescope.py:1179-1191, :1288-1312); the
+    # defaults (no refinement, equal weights) are the restatement the oracle is built on
+    niter = int(getattr(tel, "sht_iter", 0) or 0)
+    ringw = getattr(tel, "sht_ring_weights", None)   # None, or {nside: (4 nside - 1) factors}
+    if niter and m_range is not None and (m_range[0] != 0 or m_range[1] < int(lmax_bf.max())):
+        raise ValueError("sht_iter > 0 needs every m of a column in one call (the residual map is synthesised from all of them)")
 
     for nside in np.unique(nsides):
         sel = np.nonzero(nsides == nside)[0]
@@ -62,7 +68,7 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
         lgrp = int(lmax_bf[sel].max())
         mtop = min(mmax, lgrp)
         nmr = (2 * mtop + 1) if m_range is None else 2 * max(min(m_range[1], mtop) - m_range[0] + 1, 1)
-        per_col = P * 16 * (npix + nmr * nring)
+        per_col = P * 16 * ((2 if niter else 1) * npix + nmr * nring)   # + the residual maps of the refinement
         fixed = nmr * npix * 16
         ncol_max = max(1, int((max_bytes - fixed) // per_col)) if max_bytes > fixed else 1
         # keep all baselines of a frequency together and in order: dm_bt_sht merges such runs
@@ -89,7 +95,8 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
             maps = ctx.empty((cols.size, P, npix), np.complex128)
             ctx.bt_maps(int(nside), cth, sth, frame, pol, beams, uv, bi, bj, maps)
             ctx.bt_sht(int(nside), cth, sth, pol, lside, mmax, int(lmax_bf[cols].max()), F, B, row_f[cols],
-                       row_b[cols], lmax_bf[cols], maps, beam_m, m_range=m_range)
+                       row_b[cols], lmax_bf[cols], maps, beam_m, m_range=m_range, niter=niter,
+                       ring_w=None if ringw is None else ringw.get(int(nside)))
             del maps, beams
     return beam_m
 

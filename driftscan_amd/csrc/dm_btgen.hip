@@ -385,13 +385,20 @@ int dm_bt_maps(dm_ctx* ctx, int nside, const double* ring_cth_host, const double
 //   lmax_grp: largest per-column lmax in the group (<= lside) — tables are built up to it
 //   m_lo .. m_hi: only these m-blocks are produced; beam_m_dev is then (m_hi - m_lo + 1, F, 2, B, P, L)
 //   (a rank that owns a range of m synthesises the maps but transforms and stores its own m only)
-int dm_bt_sht_range(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised,
-                    int lside, int m_lo, int m_hi, int lmax_grp, int F, int B, int ncol, const int* col_f_host,
-                    const int* col_b_host, const int* col_lmax_host, const void* maps_dev, void* beam_m_dev) {
+//   niter > 0: healpy-style Jacobi refinement of the quadrature (map2alm's `iter`): after the first analysis the
+//   map is re-synthesised from the coefficients, the residual map analysed and added, niter times.  It needs every
+//   (l, m) of a column, i.e. m_lo = 0 and m_hi >= lmax_grp, and a scratch copy of the maps.
+//   ring_w_host (nring) or NULL: per-ring quadrature weights multiplying the equal-area weight 4 pi / npix
+//   (healpy's `use_weights` ring weights are 1 + w_ring; the tables themselves are data files of healpy).
+int dm_bt_sht_opts(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised,
+                   int lside, int m_lo, int m_hi, int lmax_grp, int F, int B, int ncol, const int* col_f_host,
+                   const int* col_b_host, const int* col_lmax_host, const void* maps_dev, void* beam_m_dev, int niter,
+                   const double* ring_w_host) {
   if (!ctx) return DM_EARG;
   DM_ARG(ctx, nside > 0 && ring_cth_host && ring_sth_host && lside >= 0 && m_lo >= 0 && m_hi >= m_lo && lmax_grp >= 0 &&
                   lmax_grp <= lside && F > 0 && B > 0 && ncol >= 0 && col_f_host && col_b_host && col_lmax_host &&
-                  maps_dev && beam_m_dev);
+                  maps_dev && beam_m_dev && niter >= 0);
+  DM_ARG(ctx, niter == 0 || (m_lo == 0 && m_hi >= lmax_grp));  // the residual needs every m of a column
   if (ncol == 0) return DM_OK;
   dm_ws_scope ws_scope__(ctx);  // releases on every return path
   const size_t mark = ws_scope__.mark;
@@ -416,17 +423,17 @@ int dm_bt_sht_range(dm_ctx* ctx, int nside, const double* ring_cth_host, const d
   if (!d_toff || !tw || !G) return DM_ENOMEM;
   hipLaunchKernelGGL(bt_twiddle_kernel, dim3(8, nring), dim3(256), 0, ctx->stream, gh.g, m_lo, std::max(cnt, 1), d_toff,
                      tw);
-  if (cnt > 0) {
-    const cplx* maps = reinterpret_cast<const cplx*>(maps_dev);
+  auto ring_dft = [&](const cplx* maps) -> int {
     std::vector<dm_gemm_desc> g;
     g.reserve(nring);
     for (int r = 0; r < nring; ++r) {
-      // C[mm][colp] (ld = nring*ncp, origin at ring r) = tw_r[mm][j] * maps[colp][start_r + j]
+      // C[mm][colp] (ld = nring*ncp, origin at ring r) = w_r * tw_r[mm][j] * maps[colp][start_r + j]
       g.push_back(dm_gemm_make(tw + toff[r], gh.nphi[r], 1, false, maps + gh.start[r], 1, npix, false,
-                               G + (size_t)r * ncp, nring * ncp, nm, ncp, gh.nphi[r]));
+                               G + (size_t)r * ncp, nring * ncp, nm, ncp, gh.nphi[r], ring_w_host ? ring_w_host[r] : 1.0));
     }
-    DM_TRY(dm_gemm_grouped_launch(ctx, g));
-  }
+    return dm_gemm_grouped_launch(ctx, g);
+  };
+  if (cnt > 0) DM_TRY(ring_dft(reinterpret_cast<const cplx*>(maps_dev)));
 
   // ---- Legendre tables up to lmax_grp
   std::vector<size_t> loff(std::max(cnt, 1), 0);  // loff[m - m_lo]
@@ -469,6 +476,7 @@ int dm_bt_sht_range(dm_ctx* ctx, int nside, const double* ring_cth_host, const d
   }
   // Terms whose outputs accumulate (E and B each take two products) go in separate launches
   // so that no two tiles of one launch touch the same C entries.
+  auto legendre_analysis = [&](bool accumulate) -> int {
   for (int pass = 0; pass < (polarised ? 2 : 1); ++pass) {
     std::vector<dm_gemm_desc> g;
     for (int m = m_lo; m <= mtop; ++m) {
@@ -486,13 +494,14 @@ int dm_bt_sht_range(dm_ctx* ctx, int nside, const double* ring_cth_host, const d
             d.alpha_im = aim;
             g.push_back(d);
           };
+          const double b0 = accumulate ? 1.0 : 0.0;
           if (!polarised) {
-            add(0, lam, 0, 1.0, 0.0, 0.0);
+            add(0, lam, 0, 1.0, 0.0, b0);
           } else if (pass == 0) {
-            add(0, lam, 0, 1.0, 0.0, 0.0);  // T = lam . G^I
-            add(3, lam, 3, 1.0, 0.0, 0.0);  // V = lam . G^V
-            add(1, Wt, 1, 1.0, 0.0, 0.0);   // E  = W . G^Q ...
-            add(2, Wt, 2, 1.0, 0.0, 0.0);   // B  = W . G^U ...
+            add(0, lam, 0, 1.0, 0.0, b0);  // T = lam . G^I
+            add(3, lam, 3, 1.0, 0.0, b0);  // V = lam . G^V
+            add(1, Wt, 1, 1.0, 0.0, b0);   // E  = W . G^Q ...
+            add(2, Wt, 2, 1.0, 0.0, b0);   // B  = W . G^U ...
           } else {
             add(2, Xt, 1, 0.0, -1.0, 1.0);  // E -= i X . G^U
             add(1, Xt, 2, 0.0, 1.0, 1.0);   // B += i X . G^Q
@@ -506,9 +515,78 @@ int dm_bt_sht_range(dm_ctx* ctx, int nside, const double* ring_cth_host, const d
   hipLaunchKernelGGL(bt_mask_kernel, dim3((2 * P * L + 255) / 256, ncol, nmblk), dim3(256), 0, ctx->stream, bm, F, B,
                      P, L, m_hi, ncol, d_cf, d_cb, d_cl);
   DM_HIP(ctx, hipGetLastError());
+  return DM_OK;
+  };
+  DM_TRY(legendre_analysis(false));
+
+  // ---- Jacobi refinement (healpy map2alm `iter`): coefficients += analysis(map - synthesis(coefficients)).
+  // With c_lm = sum_pix w f Y_lm (the reference's conj(SHT(conj f))) the synthesis is f = sum_lm c_lm conj(Y_lm):
+  //   H[+m][col][ring] = sum_l lambda_lm(ring) b0_lm,   H[-m] = sum_l lambda_lm conj(b1_lm)   (the fold undone)
+  //   f[col][ring, j]  = sum_mm conj(tw[mm][j]) H[mm][col][ring]
+  // and for the spin-2 pair the Hermitian 2x2 block [[W, -iX], [iX, W]] of the analysis applied once more.
+  // The tables carry the quadrature weight w = 4 pi / npix: the synthesis divides it out again.
+  if (niter > 0 && cnt > 0) {
+    const double iw = (double)npix / (4.0 * kPi);
+    cplx* res = dm_ws_alloc_t<cplx>(ctx, (size_t)ncp * npix);
+    if (!res) return DM_ENOMEM;
+    cplx* H = G;  // same size: (nm, ncp, nring) here against (nm, nring, ncp) there
+    for (int it = 0; it < niter; ++it) {
+      DM_HIP(ctx, hipMemcpyAsync(res, maps_dev, sizeof(cplx) * (size_t)ncp * npix, hipMemcpyDeviceToDevice, ctx->stream));
+      for (int pass = 0; pass < (polarised ? 2 : 1); ++pass) {
+        std::vector<dm_gemm_desc> g;
+        for (int m = m_lo; m <= mtop; ++m) {
+          const int Lm = lmax_grp + 1 - m;
+          for (int s = 0; s < 2; ++s) {
+            const int mm = (s == 0) ? (m - m_lo) : (cnt + m - m_lo);
+            cplx* Hm = H + (size_t)mm * ncp * nring;
+            for (const run& rn : runs) {
+              const cplx* in = bm + ((((size_t)(m - m_lo) * F + rn.f) * 2 + s) * B + rn.b0) * P * L + m;
+              // C[col][ring] (row stride P * nring: the P maps of a column are adjacent rows) = A[col][l] * tab[l][ring]
+              auto add = [&](int pin, const double* tab, int pout, double are, double aim, double beta) {
+                dm_gemm_desc d = dm_gemm_make(in + (size_t)pin * L, P * L, 1, s == 1, tab + loff[m - m_lo], nring, 1, false,
+                                              Hm + ((size_t)rn.c0 * P + pout) * nring, P * nring, rn.n, nring, Lm,
+                                              are * iw, beta, nullptr, DM_GEMM_B_REAL);
+                d.alpha_im = (s == 1 ? -aim : aim) * iw;  // H[-m] = conj(M b1) = conj(M) conj(b1)
+                g.push_back(d);
+              };
+              if (!polarised) {
+                add(0, lam, 0, 1.0, 0.0, 0.0);
+              } else if (pass == 0) {
+                add(0, lam, 0, 1.0, 0.0, 0.0);
+                add(3, lam, 3, 1.0, 0.0, 0.0);
+                add(1, Wt, 1, 1.0, 0.0, 0.0);   // Q  = W . E ...
+                add(2, Wt, 2, 1.0, 0.0, 0.0);   // U  = W . B ...
+              } else {
+                add(2, Xt, 1, 0.0, -1.0, 1.0);  // Q -= i X . B
+                add(1, Xt, 2, 0.0, 1.0, 1.0);   // U += i X . E
+              }
+            }
+          }
+        }
+        DM_TRY(dm_gemm_grouped_launch(ctx, g));
+      }
+      {
+        std::vector<dm_gemm_desc> g;
+        g.reserve(nring);
+        for (int r = 0; r < nring; ++r)  // res[colp][start_r + j] -= sum_mm H[mm][colp][r] conj(tw_r[mm][j])
+          g.push_back(dm_gemm_make(H + r, nring, ncp * nring, false, tw + toff[r], gh.nphi[r], 1, true, res + gh.start[r],
+                                   npix, ncp, gh.nphi[r], nm, -1.0, 1.0));
+        DM_TRY(dm_gemm_grouped_launch(ctx, g));
+      }
+      DM_TRY(ring_dft(res));
+      DM_TRY(legendre_analysis(true));
+    }
+  }
   DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   dm_ws_release(ctx, mark);
   return DM_OK;
+}
+
+int dm_bt_sht_range(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised,
+                    int lside, int m_lo, int m_hi, int lmax_grp, int F, int B, int ncol, const int* col_f_host,
+                    const int* col_b_host, const int* col_lmax_host, const void* maps_dev, void* beam_m_dev) {
+  return dm_bt_sht_opts(ctx, nside, ring_cth_host, ring_sth_host, polarised, lside, m_lo, m_hi, lmax_grp, F, B, ncol,
+                        col_f_host, col_b_host, col_lmax_host, maps_dev, beam_m_dev, 0, nullptr);
 }
 
 // all m-blocks 0 .. mmax

@@ -48,6 +48,11 @@ class TransitTelescope(config.Reader):
 
     accuracy_boost = config.Property(proptype=float, default=1.0)
     l_boost = config.Property(proptype=float, default=1.0)
+    # MI355X-side knobs for the spherical-harmonic transform behind transfer_matrices (telescope.py:1179-1191,
+    # :1288-1312 reach healpy.map2alm through cora, whose `iter` / ring-weight settings cannot be read here):
+    # Jacobi refinements of the quadrature, and optional per-ring weight factors {nside: array(4 nside - 1)}
+    sht_iter = config.Property(proptype=int, default=0)
+    sht_ring_weights = None
     force_lmax = config.Property(proptype=int, default=None)
     force_mmax = config.Property(proptype=int, default=None)
 

@@ -241,6 +241,19 @@ int dm_bt_sht_range(dm_ctx* ctx, int nside, const double* ring_cth_host, const d
                     int lside, int m_lo, int m_hi, int lmax_grp, int F, int B, int ncol, const int* col_f_host,
                     const int* col_b_host, const int* col_lmax_host, const void* maps_dev, void* beam_m_dev);
 
+/* dm_bt_sht_opts: dm_bt_sht_range with the two knobs of healpy.map2alm that cora's sphtrans_* may set
+ * (neither healpy nor cora is available here, so which values the reference ends up with is not verifiable;
+ * the defaults of every other entry point are niter = 0 and equal weights):
+ *   niter        Jacobi refinements: coefficients += analysis(map - synthesis(coefficients)), niter times
+ *                (healpy's `iter`, default 3 there).  Needs m_lo = 0 and m_hi >= lmax_grp.
+ *   ring_w_host  (4 nside - 1) factors on the equal-area quadrature weight of each ring, or NULL
+ *                (healpy's `use_weights` multiplies by 1 + w_ring from its data files).
+ * Replaces: the same call sites as dm_bt_sht (drift/core/telescope.py:1179-1191, :1288-1312). */
+int dm_bt_sht_opts(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised,
+                   int lside, int m_lo, int m_hi, int lmax_grp, int F, int B, int ncol, const int* col_f_host,
+                   const int* col_b_host, const int* col_lmax_host, const void* maps_dev, void* beam_m_dev, int niter,
+                   const double* ring_w_host);
+
 /* ---- bit truncation of beam-transfer blocks before they are written ------------------------------- */
 /* In place on `nrows` rows of `ncols` complex128 values (`ld` elements between rows): every real and
  * imaginary part is rounded to the coarsest multiple of a power of two that keeps its error below

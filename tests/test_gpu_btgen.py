@@ -120,3 +120,42 @@ def test_sht_m_range_matches_full():
                 part = btgen.beam_m_all(tel, ctx=ctx, m_range=(lo, hi - 1)).cpu().numpy()
                 assert part.shape[0] == hi - lo
                 assert np.array_equal(part, full[lo:hi]), (cls.__name__, lo, hi)
+
+
+@pytest.mark.parametrize("pol", [False, True])
+@pytest.mark.parametrize("niter", [0, 3])
+def test_beam_m_sht_iterations_and_ring_weights(ctx, pol, niter):
+    """healpy.map2alm's `iter` (Jacobi refinement through a synthesis + residual analysis on the device) and
+    per-ring weight factors: GPU == oracle.  These are the two settings of the reference's SHT (through cora)
+    that cannot be read in this image; the default (0, equal weights) is unchanged."""
+    from driftscan_amd import btgen
+    from oracle import btgen as ob
+
+    t = _tel(pol)
+    base = btgen.beam_m_all(t, ctx=ctx).cpu().numpy()
+    rng = np.random.default_rng(5)
+    weights = {}
+    lmax_bf, _ = t.baseline_lmax(np.repeat(np.arange(t.nbase), t.nfreq), np.tile(np.arange(t.nfreq), t.nbase))
+    for ns in set(int(x) for x in btgen._nside_of(t, lmax_bf)):
+        weights[ns] = 1.0 + 1e-3 * rng.standard_normal(4 * ns - 1)
+    for rw in (None, weights):
+        if niter == 0 and rw is None:
+            continue
+        t.sht_iter, t.sht_ring_weights = niter, rw
+        bm = btgen.beam_m_all(t, ctx=ctx).cpu().numpy()
+        desc = _oracle_desc(t)
+        desc["sht_iter"], desc["sht_ring_weights"] = niter, rw
+        ref = ob.beam_transfer_m(desc)
+        scale = max(np.abs(ref[m]).max() for m in ref)
+        worst = max(np.abs(bm[m] - ref[m]).max() for m in range(t.mmax + 1)) / scale
+        moved = max(np.abs(bm[m] - base[m]).max() for m in range(t.mmax + 1)) / scale
+        print("pol %s iter %d ring weights %s: GPU vs oracle %.2e, moved from the default by %.2e" % (pol, niter, rw is not None, worst, moved))
+        assert worst < 1e-10, worst
+        assert moved > 1e-8          # the options do something
+    t.sht_iter, t.sht_ring_weights = 0, None
+    with pytest.raises(ValueError):
+        t.sht_iter = 2
+        try:
+            btgen.beam_m_all(t, ctx=ctx, m_range=(1, 2))
+        finally:
+            t.sht_iter = 0

@@ -288,7 +288,7 @@ def test_doublekl_and_fisher_config4(c3):
     for k in range(len(MS)):
         Fm = fb[k][0]
         assert np.abs(Fm - Fm.conj().T).max() <= 1e-9 * np.abs(Fm).max()     # Hermitian
-        assert np.linalg.eigvalsh((Fm + Fm.conj().T) / 2).min() > -1e-9 * np.abs(Fm).max()   # a Gram matrix
+        assert np.linalg.eigvalsh((Fm + Fm.conj().T) / 2).min() >= -1e-9 * np.abs(Fm).max()   # a Gram matrix
         assert not fb[k][1].any()                                             # PSExact has no bias (psestimation.py:797)
 
 
