@@ -56,8 +56,6 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
     # defaults (no refinement, equal weights) are the restatement the oracle is built on
     niter = int(getattr(tel, "sht_iter", 0) or 0)
     ringw = getattr(tel, "sht_ring_weights", None)   # None, or {nside: (4 nside - 1) factors}
-    if niter and m_range is not None and (m_range[0] != 0 or m_range[1] < int(lmax_bf.max())):
-        raise ValueError("sht_iter > 0 needs every m of a column in one call (the residual map is synthesised from all of them)")
 
     for nside in np.unique(nsides):
         sel = np.nonzero(nsides == nside)[0]
@@ -68,7 +66,9 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
         lgrp = int(lmax_bf[sel].max())
         mtop = min(mmax, lgrp)
         nmr = (2 * mtop + 1) if m_range is None else 2 * max(min(m_range[1], mtop) - m_range[0] + 1, 1)
-        per_col = P * 16 * ((2 if niter else 1) * npix + nmr * nring)   # + the residual maps of the refinement
+        if niter:   # residual maps, all m of the group's columns in G and in the private coefficient buffer
+            nmr = 2 * (lgrp + 1)
+        per_col = P * 16 * ((2 if niter else 1) * npix + nmr * nring + (2 * (lgrp + 1) * (lside + 1) if niter else 0))
         fixed = nmr * npix * 16
         ncol_max = max(1, int((max_bytes - fixed) // per_col)) if max_bytes > fixed else 1
         # keep all baselines of a frequency together and in order: dm_bt_sht merges such runs

@@ -265,6 +265,21 @@ __global__ void bt_mask_kernel(cplx* __restrict__ beam_m, int F, int B, int P, i
   beam_m[((((size_t)m * F + f) * 2 + s) * B + b) * P * L + (size_t)p * L + l] = make_double2(0.0, 0.0);
 }
 
+// rows of the private coefficient buffer of the refinement path -> the caller's beam_m blocks
+// src (msrc, 1, 2, ncol, P, L), dst (m_hi - m_lo + 1, F, 2, B, P, L); blocks beyond msrc - 1 are zero
+__global__ void bt_scatter_kernel(const cplx* __restrict__ src, int msrc, cplx* __restrict__ dst, int m_lo, int F, int B, int P,
+                                  int L, int ncol, const int* __restrict__ colf, const int* __restrict__ colb) {
+  const int col = blockIdx.y;
+  const int mo = blockIdx.z;  // output block index, m = m_lo + mo
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over (s, p, l)
+  if (idx >= 2 * P * L) return;
+  const int s = idx / (P * L), pl = idx % (P * L);
+  const int m = m_lo + mo;
+  cplx v = make_double2(0.0, 0.0);
+  if (m < msrc) v = src[(((size_t)m * 2 + s) * ncol + col) * P * L + pl];
+  dst[((((size_t)mo * F + colf[col]) * 2 + s) * B + colb[col]) * P * L + pl] = v;
+}
+
 struct geo_host {
   ring_geo g;
   std::vector<double> cth, sth, phi0;
@@ -387,13 +402,13 @@ int dm_bt_maps(dm_ctx* ctx, int nside, const double* ring_cth_host, const double
 //   (a rank that owns a range of m synthesises the maps but transforms and stores its own m only)
 //   niter > 0: healpy-style Jacobi refinement of the quadrature (map2alm's `iter`): after the first analysis the
 //   map is re-synthesised from the coefficients, the residual map analysed and added, niter times.  It needs every
-//   (l, m) of a column, i.e. m_lo = 0 and m_hi >= lmax_grp, and a scratch copy of the maps.
+//   (l, m) of a column, i.e. m_lo = 0 and m_hi >= lmax_grp (dm_bt_sht_opts arranges that), and a scratch copy of the maps.
 //   ring_w_host (nring) or NULL: per-ring quadrature weights multiplying the equal-area weight 4 pi / npix
 //   (healpy's `use_weights` ring weights are 1 + w_ring; the tables themselves are data files of healpy).
-int dm_bt_sht_opts(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised,
-                   int lside, int m_lo, int m_hi, int lmax_grp, int F, int B, int ncol, const int* col_f_host,
-                   const int* col_b_host, const int* col_lmax_host, const void* maps_dev, void* beam_m_dev, int niter,
-                   const double* ring_w_host) {
+static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised,
+                       int lside, int m_lo, int m_hi, int lmax_grp, int F, int B, int ncol, const int* col_f_host,
+                       const int* col_b_host, const int* col_lmax_host, const void* maps_dev, void* beam_m_dev, int niter,
+                       const double* ring_w_host) {
   if (!ctx) return DM_EARG;
   DM_ARG(ctx, nside > 0 && ring_cth_host && ring_sth_host && lside >= 0 && m_lo >= 0 && m_hi >= m_lo && lmax_grp >= 0 &&
                   lmax_grp <= lside && F > 0 && B > 0 && ncol >= 0 && col_f_host && col_b_host && col_lmax_host &&
@@ -579,6 +594,40 @@ int dm_bt_sht_opts(dm_ctx* ctx, int nside, const double* ring_cth_host, const do
   }
   DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   dm_ws_release(ctx, mark);
+  return DM_OK;
+}
+
+int dm_bt_sht_opts(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised,
+                   int lside, int m_lo, int m_hi, int lmax_grp, int F, int B, int ncol, const int* col_f_host,
+                   const int* col_b_host, const int* col_lmax_host, const void* maps_dev, void* beam_m_dev, int niter,
+                   const double* ring_w_host) {
+  if (!ctx) return DM_EARG;
+  if (niter <= 0)
+    return bt_sht_impl(ctx, nside, ring_cth_host, ring_sth_host, polarised, lside, m_lo, m_hi, lmax_grp, F, B, ncol,
+                       col_f_host, col_b_host, col_lmax_host, maps_dev, beam_m_dev, 0, ring_w_host);
+  // The refinement synthesises the map from EVERY (l, m) of a column, whatever range of m the caller keeps (and the
+  // telescope's mmax may lie below a column's lmax): it runs on a private coefficient buffer holding m = 0 .. lmax_grp
+  // of this group's columns, laid out like beam_m with F = 1, B = ncol; the requested blocks are copied out at the end.
+  DM_ARG(ctx, nside > 0 && lside >= 0 && m_lo >= 0 && m_hi >= m_lo && lmax_grp >= 0 && lmax_grp <= lside && F > 0 && B > 0 &&
+                  ncol >= 0 && col_f_host && col_b_host && col_lmax_host && maps_dev && beam_m_dev);
+  if (ncol == 0) return DM_OK;
+  dm_ws_scope ws_scope__(ctx);
+  const int P = polarised ? 4 : 1, L = lside + 1, msrc = lmax_grp + 1;
+  for (int c = 0; c < ncol; ++c) DM_ARG(ctx, col_f_host[c] >= 0 && col_f_host[c] < F && col_b_host[c] >= 0 && col_b_host[c] < B);
+  cplx* cf = dm_ws_alloc_t<cplx>(ctx, (size_t)msrc * 2 * ncol * P * L);
+  if (!cf) return DM_ENOMEM;
+  std::vector<int> zf(ncol, 0), ib(ncol);
+  for (int c = 0; c < ncol; ++c) ib[c] = c;
+  DM_TRY(bt_sht_impl(ctx, nside, ring_cth_host, ring_sth_host, polarised, lside, 0, lmax_grp, lmax_grp, 1, ncol, ncol,
+                     zf.data(), ib.data(), col_lmax_host, maps_dev, cf, niter, ring_w_host));
+  std::vector<int> cfv(col_f_host, col_f_host + ncol), cbv(col_b_host, col_b_host + ncol);
+  int* d_cf = dm_ws_upload(ctx, cfv);
+  int* d_cb = dm_ws_upload(ctx, cbv);
+  if (!d_cf || !d_cb) return DM_ENOMEM;
+  hipLaunchKernelGGL(bt_scatter_kernel, dim3((2 * P * L + 255) / 256, ncol, m_hi - m_lo + 1), dim3(256), 0, ctx->stream, cf, msrc,
+                     reinterpret_cast<cplx*>(beam_m_dev), m_lo, F, B, P, L, ncol, d_cf, d_cb);
+  DM_HIP(ctx, hipGetLastError());
+  DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return DM_OK;
 }
 

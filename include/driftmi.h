@@ -245,7 +245,8 @@ int dm_bt_sht_range(dm_ctx* ctx, int nside, const double* ring_cth_host, const d
  * (neither healpy nor cora is available here, so which values the reference ends up with is not verifiable;
  * the defaults of every other entry point are niter = 0 and equal weights):
  *   niter        Jacobi refinements: coefficients += analysis(map - synthesis(coefficients)), niter times
- *                (healpy's `iter`, default 3 there).  Needs m_lo = 0 and m_hi >= lmax_grp.
+ *                (healpy's `iter`, default 3 there).  The synthesis uses every (l, m) of a column, whatever m-range
+ *                is requested: with niter > 0 the call transforms all m <= lmax_grp into a private buffer first.
  *   ring_w_host  (4 nside - 1) factors on the equal-area quadrature weight of each ring, or NULL
  *                (healpy's `use_weights` multiplies by 1 + w_ring from its data files).
  * Replaces: the same call sites as dm_bt_sht (drift/core/telescope.py:1179-1191, :1288-1312). */
