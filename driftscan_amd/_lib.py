@@ -84,6 +84,10 @@ SIGNATURES = {
         c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_int, c_int, c_int, c_int, c_int,
                 c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_vp, c_vp, c_int,
                 ctypes.POINTER(c_dbl)]),
+    "dm_bt_columns": (
+        c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_int, c_vp, c_int,
+                ctypes.POINTER(c_dbl), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int,
+                ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_vp, ctypes.POINTER(c_dbl)]),
     "dm_bit_truncate_max_complex": (c_int, [c_vp, c_vp, c_i64, c_int, c_i64, c_dbl, c_dbl]),
 }
 
@@ -451,6 +455,27 @@ def _bt_sht(self, nside, cth, sth, polarised, lside, mmax, lmax_grp, F, B, col_f
     self.check(rc, "dm_bt_sht")
 
 
+def _bt_columns(self, nside, cth, sth, frame, polarised, beams, uv, bi, bj, lside, mmax, lmax_grp, F, B, col_f, col_b,
+                col_lmax, beam_m, m_range=None, ring_w=None):
+    """Beams -> beam_m rows of the given columns without materialising the Stokes maps (dm_bt_columns)."""
+    c, cp = _darr(cth)
+    s_, sp = _darr(sth)
+    fr, frp = _darr(frame)
+    u, up = _darr(uv)
+    i_, ip = _iarr(bi)
+    j_, jp = _iarr(bj)
+    f_, fp = _iarr(col_f)
+    b_, bp = _iarr(col_b)
+    l_, lp = _iarr(col_lmax)
+    m_lo, m_hi = (0, int(mmax)) if m_range is None else (int(m_range[0]), int(m_range[1]))
+    w, wp = (None, None) if ring_w is None else _darr(ring_w)
+    rc = self.lib.dm_bt_columns(self.h, int(nside), cp, sp, frp, int(bool(polarised)), int(beams.shape[0]), self.ptr(beams),
+                                len(i_), up, ip, jp, int(lside), m_lo, m_hi, int(lmax_grp), int(F), int(B), fp, bp, lp,
+                                self.ptr(beam_m), wp)
+    self.check(rc, "dm_bt_columns")
+
+
+Context.bt_columns = _bt_columns
 Context.bt_beam_cyl = _bt_beam_cyl
 Context.bt_maps = _bt_maps
 Context.bt_sht = _bt_sht

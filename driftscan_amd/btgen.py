@@ -6,6 +6,8 @@ drift/core/telescope.py:1179-1184, :1288), evaluates the beams, synthesises the
 visibility response maps and transforms them straight into the m-ordered
 ``beam_m`` blocks (``dm_bt_beam_cyl`` / ``dm_bt_maps`` / ``dm_bt_sht``).
 """
+import os
+
 import numpy as np
 
 from . import healpix
@@ -66,10 +68,14 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
         lgrp = int(lmax_bf[sel].max())
         mtop = min(mmax, lgrp)
         nmr = (2 * mtop + 1) if m_range is None else 2 * max(min(m_range[1], mtop) - m_range[0] + 1, 1)
+        # default: the fused path (dm_bt_columns) — the Stokes maps are never written; with the SHT refinement the
+        # maps are needed (residual), and DRIFTMI_BT_MAPS=1 forces the two-call path for comparisons
+        fused = not niter and os.environ.get("DRIFTMI_BT_MAPS") != "1"
         if niter:   # residual maps, all m of the group's columns in G and in the private coefficient buffer
             nmr = 2 * (lgrp + 1)
-        per_col = P * 16 * ((2 if niter else 1) * npix + nmr * nring + (2 * (lgrp + 1) * (lside + 1) if niter else 0))
-        fixed = nmr * npix * 16
+        per_col = P * 16 * ((0 if fused else (2 if niter else 1)) * npix + nmr * nring
+                            + (2 * (lgrp + 1) * (lside + 1) if niter else 0))
+        fixed = 0 if fused else nmr * npix * 16
         ncol_max = max(1, int((max_bytes - fixed) // per_col)) if max_bytes > fixed else 1
         # keep all baselines of a frequency together and in order: dm_bt_sht merges such runs
         order = sel[np.lexsort((row_b[sel], row_f[sel]))]
@@ -92,6 +98,12 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
                 kind, tab, fwhm_ns = tel.beam_spec(bc, f)
                 ctx.bt_beam_cyl(int(nside), cth, sth, frame, kind, tab, fwhm_ns, beams[idx])
             uv = tel.baselines[b_list[cols]] / wl[f_list[cols]][:, None]
+            if fused:
+                ctx.bt_columns(int(nside), cth, sth, frame, pol, beams, uv, bi, bj, lside, mmax, int(lmax_bf[cols].max()), F, B,
+                               row_f[cols], row_b[cols], lmax_bf[cols], beam_m, m_range=m_range,
+                               ring_w=None if ringw is None else ringw.get(int(nside)))
+                del beams
+                continue
             maps = ctx.empty((cols.size, P, npix), np.complex128)
             ctx.bt_maps(int(nside), cth, sth, frame, pol, beams, uv, bi, bj, maps)
             ctx.bt_sht(int(nside), cth, sth, pol, lside, mmax, int(lmax_bf[cols].max()), F, B, row_f[cols],

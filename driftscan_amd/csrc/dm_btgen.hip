@@ -172,6 +172,147 @@ __global__ void bt_maps_kernel(ring_geo g, frame3 fr, int polarised, int ncol, c
   }
 }
 
+
+// ---- fused map synthesis + ring DFT (no Stokes maps in HBM) ---------------------------------------------
+// G[mm][ring][col * P + p] = w_ring * sum_j exp(i m_mm phi_j) * map_p(col, ring, j) with the map value
+// h * fringe * (b_i x b_j) / sqrt(O_i O_j) formed in registers right before it is used.  The sum over the pixels
+// of a ring is the K dimension of v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 products per instruction, the
+// one fp64 MFMA shape that issues at the datasheet rate on gfx950):
+//   lane l = 16 k + 4 g + t supplies   A_g[i = t][k] = twiddle of m-value t at pixel k of the current quad (same for all g)
+//                                      B_g[k][j = t] = map value of pixel k, column 16 cg + 4 g + t
+//   and receives                       D_g[i][j] in lane 16 i + 4 g + j = partial G of m-value i, column 16 cg + (l & 15).
+// A wave owns one ring and NCG groups of 16 columns; per pixel quad the geometry (n.x, n.y, horizon) and the NMG x 4
+// twiddles are computed once and shared by all its column groups, per (quad, group) a lane does one sincos (the
+// fringe of ITS pixel and column), loads the two beams and issues NMG * P * 4 MFMAs.  m-values beyond 4 NMG take
+// further passes (blockIdx.z), which repeat the synthesis: with P * NMG * 4 >= 16 MFMAs behind every sincos the
+// matrix pipe, not the VALU, bounds the kernel.
+// Algorithmic bytes per (pixel, column): 2 beams x ncomp x 8 B from L1/L2 (beams are shared by all baselines of a
+// frequency), 16 P nm / npix-th of the G row written — compute-bound, see DESIGN.md section 4.5.
+struct fdft_col { double u, v, pre; int bi, bj; };   // pre = 1 / sqrt(Omega_i Omega_j); bi < 0: padding
+template <int P, int NMG, int NCG>
+__global__ __launch_bounds__(256) void bt_fused_dft_kernel(ring_geo g, frame3 fr, const double* __restrict__ beams, size_t bstride,
+                                                           const fdft_col* __restrict__ cols, int ncol16, int m_lo, int cnt,
+                                                           const double* __restrict__ ring_w, cplx* __restrict__ G, int ncp,
+                                                           int ring0) {
+  constexpr int NCOMP = P == 4 ? 2 : 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = ring0 + blockIdx.y;
+  const int cg0 = (blockIdx.x * 4 + wave) * NCG;          // first column group of this wave
+  if (cg0 >= ncol16) return;                              // (wave-uniform; no workgroup barrier follows)
+  const int mg0 = blockIdx.z * NMG;                       // first group of four m-values of this pass
+  const int nm = 2 * cnt;
+  const int k = lane >> 4, t = lane & 3;
+  const int nphi = g.nphi[r];
+  const double phi0 = g.phi0[r], st = g.sth[r], ct = g.cth[r];
+  const int pix0 = g.start[r];
+  // m-values of this lane's twiddle rows: rows [0, cnt) are +m, rows [cnt, 2 cnt) are -m
+  int mval[NMG];
+  bool mok[NMG];
+#pragma unroll
+  for (int a = 0; a < NMG; ++a) {
+    const int mm = (mg0 + a) * 4 + t;
+    mok[a] = mm < nm;
+    mval[a] = mm < cnt ? m_lo + mm : -(m_lo + mm - cnt);
+  }
+  // per-column constants of this wave's groups live in LDS (read once per (quad, group); in registers they would cost
+  // 8 VGPRs per group and the kernel one of its two waves per SIMD)
+  __shared__ fdft_col s_cd[4][NCG * 16];
+  for (int c = lane; c < NCG * 16; c += 64) {
+    const int cg = cg0 + (c >> 4);
+    s_cd[wave][c] = cg < ncol16 ? cols[(size_t)cg * 16 + (c & 15)] : fdft_col{0.0, 0.0, 0.0, -1, -1};
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave reads back only what it wrote itself
+  __builtin_amdgcn_wave_barrier();
+  double acc_re[NCG][NMG][P], acc_im[NCG][NMG][P];
+#pragma unroll
+  for (int c = 0; c < NCG; ++c)
+#pragma unroll
+    for (int a = 0; a < NMG; ++a)
+#pragma unroll
+      for (int p = 0; p < P; ++p) acc_re[c][a][p] = acc_im[c][a][p] = 0.0;
+
+  for (int q = 0; q < nphi; q += 4) {
+    const int j = q + k;
+    const bool pv = j < nphi;
+    const int jj = pv ? j : nphi - 1;
+    double sp, cp;
+    sincos(phi0 + 2.0 * kPi * (double)jj / (double)nphi, &sp, &cp);
+    const double n0 = st * cp, n1 = st * sp, n2 = ct;
+    const double hz = (pv && (n0 * fr.z[0] + n1 * fr.z[1] + n2 * fr.z[2]) > 0.0) ? 1.0 : 0.0;
+    if (__ballot(hz != 0.0) == 0ull) continue;  // the whole quad lies below the horizon: every map value is zero
+    const double nx = n0 * fr.x[0] + n1 * fr.x[1] + n2 * fr.x[2];
+    const double ny = n0 * fr.y[0] + n1 * fr.y[1] + n2 * fr.y[2];
+    double tw_re[NMG], tw_im[NMG];
+#pragma unroll
+    for (int a = 0; a < NMG; ++a) {
+      // reduce the argument exactly: m * j mod nphi keeps the phase in [0, 2 pi) (as bt_twiddle_kernel)
+      const long long mj = ((long long)mval[a] * jj) % nphi;
+      double s, c;
+      sincos((double)mval[a] * phi0 + 2.0 * kPi * (double)mj / (double)nphi, &s, &c);
+      tw_re[a] = mok[a] ? c : 0.0;
+      tw_im[a] = mok[a] ? s : 0.0;
+    }
+    const size_t pix = (size_t)pix0 + jj;
+#pragma unroll
+    for (int c = 0; c < NCG; ++c) {
+      double m_re[P], m_im[P];
+      const fdft_col cdc = s_cd[wave][c * 16 + (lane & 15)];
+      if (cdc.bi >= 0 && hz != 0.0) {
+        double sf, cf;
+        sincos(2.0 * kPi * (cdc.u * nx + cdc.v * ny), &sf, &cf);
+        const double tre = cdc.pre * cf, tim = cdc.pre * sf;
+        const double* a = beams + (size_t)cdc.bi * bstride + NCOMP * pix;
+        const double* b = beams + (size_t)cdc.bj * bstride + NCOMP * pix;
+        if constexpr (P == 1) {
+          const double bb = dm_ldg(a) * dm_ldg(b);
+          m_re[0] = tre * bb;
+          m_im[0] = tim * bb;
+        } else {
+          const double a0 = dm_ldg(a), a1 = dm_ldg(a, 1), b0 = dm_ldg(b), b1 = dm_ldg(b, 1);
+          const double sI = a0 * b0 + a1 * b1, sQ = a0 * b0 - a1 * b1, sU = a0 * b1 + a1 * b0, sV = a0 * b1 - a1 * b0;
+          m_re[0] = tre * sI; m_im[0] = tim * sI;
+          m_re[1] = tre * sQ; m_im[1] = tim * sQ;
+          m_re[2] = tre * sU; m_im[2] = tim * sU;
+          m_re[3] = -tim * sV; m_im[3] = tre * sV;  // 1j * fringe * sV
+        }
+      } else {
+#pragma unroll
+        for (int p = 0; p < P; ++p) m_re[p] = m_im[p] = 0.0;
+      }
+#pragma unroll
+      for (int a = 0; a < NMG; ++a)
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          acc_re[c][a][p] = dm_mfma4(tw_re[a], m_re[p], acc_re[c][a][p]);
+          acc_im[c][a][p] = dm_mfma4(tw_re[a], m_im[p], acc_im[c][a][p]);
+        }
+#pragma unroll
+      for (int a = 0; a < NMG; ++a)
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          acc_re[c][a][p] = dm_mfma4(-tw_im[a], m_im[p], acc_re[c][a][p]);
+          acc_im[c][a][p] = dm_mfma4(tw_im[a], m_re[p], acc_im[c][a][p]);
+        }
+    }
+  }
+  // lane 16 i + (lane & 15) holds m-row i of the group: G[mm][ring][col * P + p]
+  const double w = ring_w ? ring_w[r] : 1.0;
+  const int i = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < NCG; ++c) {
+    const int col = (cg0 + c) * 16 + (lane & 15);
+    if (cg0 + c >= ncol16 || col * P >= ncp) continue;
+#pragma unroll
+    for (int a = 0; a < NMG; ++a) {
+      const int mm = (mg0 + a) * 4 + i;
+      if (mm >= nm) continue;
+      cplx* out = G + ((size_t)mm * g.nring + r) * ncp + (size_t)col * P;
+#pragma unroll
+      for (int p = 0; p < P; ++p) dm_stg(out, p, make_double2(w * acc_re[c][a][p], w * acc_im[c][a][p]));
+    }
+  }
+}
+
 // tw[pix][mm] laid out per ring as (2*mmax+1) x nphi row-major: tw[off_r + mm*nphi + j] = exp(i (mm - mmax) phi_j)
 __global__ void bt_twiddle_kernel(ring_geo g, int m_lo, int cnt, const size_t* __restrict__ toff, cplx* __restrict__ tw) {
   // rows [0, cnt): m = +m_lo .. +(m_lo + cnt - 1);  rows [cnt, 2 cnt): the same with a minus sign
@@ -405,14 +546,25 @@ int dm_bt_maps(dm_ctx* ctx, int nside, const double* ring_cth_host, const double
 //   (l, m) of a column, i.e. m_lo = 0 and m_hi >= lmax_grp (dm_bt_sht_opts arranges that), and a scratch copy of the maps.
 //   ring_w_host (nring) or NULL: per-ring quadrature weights multiplying the equal-area weight 4 pi / npix
 //   (healpy's `use_weights` ring weights are 1 + w_ring; the tables themselves are data files of healpy).
+// optional inputs of the fused path: with `syn` given (and maps_dev == NULL) the ring DFT synthesises the map values itself
+struct bt_synth_in {
+  const double* frame_host;
+  int nbeam;
+  const double* beams_dev;
+  const double* uv_host;
+  const int* bi_host;
+  const int* bj_host;
+};
+
 static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised,
                        int lside, int m_lo, int m_hi, int lmax_grp, int F, int B, int ncol, const int* col_f_host,
                        const int* col_b_host, const int* col_lmax_host, const void* maps_dev, void* beam_m_dev, int niter,
-                       const double* ring_w_host) {
+                       const double* ring_w_host, const bt_synth_in* syn = nullptr) {
   if (!ctx) return DM_EARG;
+  DM_ARG(ctx, maps_dev || (syn && niter == 0));
   DM_ARG(ctx, nside > 0 && ring_cth_host && ring_sth_host && lside >= 0 && m_lo >= 0 && m_hi >= m_lo && lmax_grp >= 0 &&
                   lmax_grp <= lside && F > 0 && B > 0 && ncol >= 0 && col_f_host && col_b_host && col_lmax_host &&
-                  maps_dev && beam_m_dev && niter >= 0);
+                  beam_m_dev && niter >= 0);
   DM_ARG(ctx, niter == 0 || (m_lo == 0 && m_hi >= lmax_grp));  // the residual needs every m of a column
   if (ncol == 0) return DM_OK;
   dm_ws_scope ws_scope__(ctx);  // releases on every return path
@@ -429,15 +581,60 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
   const int nmblk = m_hi - m_lo + 1;
 
   // ---- twiddles and ring DFT: G[mm][ring][colp]
+  const bool fused = maps_dev == nullptr;
   std::vector<size_t> toff(nring);
   size_t ttot = 0;
   for (int r = 0; r < nring; ++r) { toff[r] = ttot; ttot += (size_t)nm * gh.nphi[r]; }
   size_t* d_toff = dm_ws_upload(ctx, toff);
-  cplx* tw = dm_ws_alloc_t<cplx>(ctx, ttot);
+  cplx* tw = fused ? nullptr : dm_ws_alloc_t<cplx>(ctx, ttot);
   cplx* G = dm_ws_alloc_t<cplx>(ctx, (size_t)nm * nring * ncp);
-  if (!d_toff || !tw || !G) return DM_ENOMEM;
-  hipLaunchKernelGGL(bt_twiddle_kernel, dim3(8, nring), dim3(256), 0, ctx->stream, gh.g, m_lo, std::max(cnt, 1), d_toff,
-                     tw);
+  if (!d_toff || (!fused && !tw) || !G) return DM_ENOMEM;
+  if (!fused)
+    hipLaunchKernelGGL(bt_twiddle_kernel, dim3(8, nring), dim3(256), 0, ctx->stream, gh.g, m_lo, std::max(cnt, 1), d_toff,
+                       tw);
+  if (fused && cnt > 0) {
+    // beam solid angles, per-column constants, then synthesis + DFT in one kernel (no Stokes maps in HBM)
+    const int ncomp = polarised ? 2 : 1;
+    const size_t bstride = (size_t)npix * ncomp;
+    frame3 fr = make_frame(syn->frame_host, syn->frame_host + 3, syn->frame_host + 6);
+    double* omega = dm_ws_alloc_t<double>(ctx, syn->nbeam);
+    if (!omega) return DM_ENOMEM;
+    hipLaunchKernelGGL(bt_omega_kernel, dim3(syn->nbeam), dim3(256), 0, ctx->stream, gh.g, fr, syn->beams_dev, ncomp, bstride,
+                       omega);
+    std::vector<double> om(syn->nbeam);
+    DM_TRY(dm_download(ctx, om.data(), omega, sizeof(double) * syn->nbeam));
+    const int ncol16 = (ncol + 15) / 16;
+    std::vector<fdft_col> fc((size_t)ncol16 * 16, fdft_col{0.0, 0.0, 0.0, -1, -1});
+    for (int c = 0; c < ncol; ++c) {
+      const int bi = syn->bi_host[c], bj = syn->bj_host[c];
+      DM_ARG(ctx, bi >= 0 && bi < syn->nbeam && bj >= 0 && bj < syn->nbeam);
+      fc[c] = fdft_col{syn->uv_host[2 * c], syn->uv_host[2 * c + 1], 1.0 / std::sqrt(om[bi] * om[bj]), bi, bj};
+    }
+    fdft_col* d_fc = dm_ws_upload(ctx, fc);
+    double* d_rw = nullptr;
+    if (ring_w_host) {
+      std::vector<double> rw(ring_w_host, ring_w_host + nring);
+      d_rw = dm_ws_upload(ctx, rw);
+      if (!d_rw) return DM_ENOMEM;
+    }
+    if (!d_fc) return DM_ENOMEM;
+    const int nmg = (nm + 3) / 4;  // groups of four m-values
+    auto launch = [&](auto kern, int NMG, int NCG) {
+      const dim3 grid((unsigned)((ncol16 + 4 * NCG - 1) / (4 * NCG)), (unsigned)nring, (unsigned)((nmg + NMG - 1) / NMG));
+      hipLaunchKernelGGL(kern, grid, dim3(256), 0, ctx->stream, gh.g, fr, syn->beams_dev, bstride, d_fc, ncol16, m_lo, cnt, d_rw, G,
+                         ncp, 0);
+    };
+    // 32 complex accumulators per lane (64 AGPRs) keep two waves per SIMD: the sincos of one wave runs under
+    // the MFMAs of the other
+    if (polarised) {
+      if (nmg <= 1) launch(bt_fused_dft_kernel<4, 1, 4>, 1, 4);
+      else launch(bt_fused_dft_kernel<4, 2, 2>, 2, 2);
+    } else {
+      if (nmg <= 1) launch(bt_fused_dft_kernel<1, 1, 8>, 1, 8);
+      else launch(bt_fused_dft_kernel<1, 4, 4>, 4, 4);
+    }
+    DM_HIP(ctx, hipGetLastError());
+  }
   auto ring_dft = [&](const cplx* maps) -> int {
     std::vector<dm_gemm_desc> g;
     g.reserve(nring);
@@ -448,7 +645,7 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
     }
     return dm_gemm_grouped_launch(ctx, g);
   };
-  if (cnt > 0) DM_TRY(ring_dft(reinterpret_cast<const cplx*>(maps_dev)));
+  if (cnt > 0 && !fused) DM_TRY(ring_dft(reinterpret_cast<const cplx*>(maps_dev)));
 
   // ---- Legendre tables up to lmax_grp
   std::vector<size_t> loff(std::max(cnt, 1), 0);  // loff[m - m_lo]
@@ -629,6 +826,18 @@ int dm_bt_sht_opts(dm_ctx* ctx, int nside, const double* ring_cth_host, const do
   DM_HIP(ctx, hipGetLastError());
   DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return DM_OK;
+}
+
+// Beams -> beam_m blocks in one call: the Stokes maps are never written to memory (dm_bt_maps + dm_bt_sht_range fused).
+int dm_bt_columns(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, const double* frame_host,
+                  int polarised, int nbeam, const double* beams_dev, int ncol, const double* uv_host, const int* bi_host,
+                  const int* bj_host, int lside, int m_lo, int m_hi, int lmax_grp, int F, int B, const int* col_f_host,
+                  const int* col_b_host, const int* col_lmax_host, void* beam_m_dev, const double* ring_w_host) {
+  if (!ctx) return DM_EARG;
+  DM_ARG(ctx, frame_host && nbeam > 0 && beams_dev && uv_host && bi_host && bj_host);
+  bt_synth_in syn{frame_host, nbeam, beams_dev, uv_host, bi_host, bj_host};
+  return bt_sht_impl(ctx, nside, ring_cth_host, ring_sth_host, polarised, lside, m_lo, m_hi, lmax_grp, F, B, ncol, col_f_host,
+                     col_b_host, col_lmax_host, nullptr, beam_m_dev, 0, ring_w_host, &syn);
 }
 
 int dm_bt_sht_range(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised,

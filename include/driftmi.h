@@ -255,6 +255,16 @@ int dm_bt_sht_opts(dm_ctx* ctx, int nside, const double* ring_cth_host, const do
                    const int* col_b_host, const int* col_lmax_host, const void* maps_dev, void* beam_m_dev, int niter,
                    const double* ring_w_host);
 
+/* dm_bt_columns: dm_bt_maps + dm_bt_sht_range in one call — the visibility response of every pixel is formed in
+ * registers inside the ring transform (v_mfma_f64_4x4x4 over the pixels of a ring) and the (ncol, P, npix) Stokes
+ * maps are never written to memory; pixels below the horizon are skipped.  Arguments as for those two calls.
+ * Replaces: _beam_map_single + _transfer_single + the +/-m fold (drift/core/telescope.py:1156-1193, :1268-1316;
+ * drift/util/_fast_tools.pyx:18-164; drift/core/beamtransfer.py:620-624). */
+int dm_bt_columns(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, const double* frame_host,
+                  int polarised, int nbeam, const double* beams_dev, int ncol, const double* uv_host, const int* bi_host,
+                  const int* bj_host, int lside, int m_lo, int m_hi, int lmax_grp, int F, int B, const int* col_f_host,
+                  const int* col_b_host, const int* col_lmax_host, void* beam_m_dev, const double* ring_w_host);
+
 /* ---- bit truncation of beam-transfer blocks before they are written ------------------------------- */
 /* In place on `nrows` rows of `ncols` complex128 values (`ld` elements between rows): every real and
  * imaginary part is rounded to the coarsest multiple of a power of two that keeps its error below
