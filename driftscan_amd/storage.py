@@ -35,6 +35,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _DIO_PATH = os.path.join(_HERE, "lib", "libdriftio.so")
 _dio = None
 _dio_tried = False
+_dio_lock = threading.Lock()   # the first caller may be any of the writer threads
 
 F64, C128, I64, I32, BOOL, STR, F32, OTHER = 0, 1, 2, 3, 4, 5, 6, 99
 COMP_NONE, COMP_LZF = 0, 1
@@ -73,19 +74,20 @@ DIO_SIGNATURES = {
 def load_driftio():
     """libdriftio.so with its prototypes declared, or None when it (or the HDF5 library it links) is absent."""
     global _dio, _dio_tried
-    if _dio_tried:
+    with _dio_lock:
+        if _dio_tried:
+            return _dio
+        try:
+            lib = ctypes.CDLL(_DIO_PATH)
+            for name, (res, args) in DIO_SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype, fn.argtypes = res, args
+            lib.dio_hdf5_version()
+            _dio = lib
+        except (OSError, AttributeError):
+            _dio = None
+        _dio_tried = True
         return _dio
-    _dio_tried = True
-    try:
-        lib = ctypes.CDLL(_DIO_PATH)
-        for name, (res, args) in DIO_SIGNATURES.items():
-            fn = getattr(lib, name)
-            fn.restype, fn.argtypes = res, args
-        lib.dio_hdf5_version()
-        _dio = lib
-    except (OSError, AttributeError):
-        _dio = None
-    return _dio
 
 
 def backend():
