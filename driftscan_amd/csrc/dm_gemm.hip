@@ -239,6 +239,184 @@ __global__ __launch_bounds__(256, 3) void zgemm_grouped_kernel(const dm_gemm_des
       }
 }
 
+
+// ---- register-only variant on v_mfma_f64_4x4x4_4b_f64 ------------------------------------------------------
+// The 16x16x4 form issues at 62 % of the datasheet rate on gfx950, the 4x4x4 form (four independent 4x4x4
+// products per instruction) at the full rate; it needs four times the operand values per flop, which an LDS-staged
+// loop pays in barriers and ds_read latency.  Here there is no LDS and no barrier at all: every lane loads the one
+// A element and the one B element the instruction wants from it straight from L1 / L2 (the panels of a 64x64 tile
+// are shared by the four waves of the workgroup through the vector L1), prefetched one K-step of 4 ahead.
+//   lane l = 16 k + 4 g + t:  A operand = A[row 4 g + t][k],  B operand = B[k][col 4 g' + t]
+//   rotation s (s = 0..3) pairs row block g with column block g' = (g + s) & 3, so four instructions cover a
+//   16x16 tile; D of rotation s lands in lane 16 i + 4 g + j = C[4 g + i][4 ((g + s) & 3) + j].
+// The rotated B operands are the rotation-0 registers moved by DPP row_ror inside each 16-lane row (same k).
+template <int CTRL>
+__device__ __forceinline__ double dm_dpp_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <bool B_REAL, bool B_GATHER>
+__global__ __launch_bounds__(256, 2) void zgemm4_grouped_kernel(const dm_gemm_desc* __restrict__ descs,
+                                                                const dm_gemm_tile* __restrict__ tiles, int ntiles) {
+  const int bid = dm_xcd_remap(blockIdx.x, ntiles);
+  const dm_gemm_tile tl = tiles[bid];
+  const dm_gemm_desc d = descs[tl.desc];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int k = lane >> 4, g = (lane >> 2) & 3, t = lane & 3;
+  const int mrow = tl.tm * BM + wm * 32, ncol = tl.tn * BN + wn * 32;
+  const cplx* __restrict__ A = reinterpret_cast<const cplx*>(d.A);
+  const cplx* __restrict__ Bc = reinterpret_cast<const cplx*>(d.B);
+  const double* __restrict__ Br = reinterpret_cast<const double*>(d.B);
+  const double sa = (d.flags & DM_GEMM_CONJ_A) ? -1.0 : 1.0, sb = (d.flags & DM_GEMM_CONJ_B) ? -1.0 : 1.0;
+  // this lane's rows / columns of the two 16-wide sub-tiles (clamped; masked by zeroing the operand)
+  size_t aoff[2], boff[2], ksoff[2];
+  bool aok[2], bok[2], tile_i[2], tile_j[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = mrow + i * 16 + 4 * g + t;
+    aok[i] = r < d.M;
+    tile_i[i] = mrow + i * 16 < d.M;
+    aoff[i] = (size_t)min(r, d.M - 1) * d.rsA;
+    const int c = ncol + i * 16 + 4 * g + t;
+    bok[i] = c < d.N;
+    tile_j[i] = ncol + i * 16 < d.N;
+    const int cc = min(c, d.N - 1);
+    ksoff[i] = 0;
+    if (B_GATHER) {
+      const int2 gg = d.bgather[cc];
+      boff[i] = (size_t)gg.x;
+      ksoff[i] = (size_t)gg.y;
+    } else {
+      boff[i] = (size_t)cc * d.csB;
+    }
+  }
+  double acc_re[2][2][4], acc_im[2][2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc_re[i][j][s] = acc_im[i][j][s] = 0.0;
+
+  struct frag { cplx a[2], b[2]; };
+  // tiles that lie inside the matrix with nothing to scale take the lean loader: no masks, no multiplies
+  const bool plain = !d.kscale && !B_GATHER && mrow + 32 <= d.M && ncol + 32 <= d.N;
+  auto load = [&](int k0) {
+    frag f;
+    const int kk = k0 + k;
+    const bool kv = kk < d.K;
+    const int kc = min(kk, d.K - 1);
+    if (plain && k0 + 4 <= d.K) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const cplx v = dm_ldg(A, aoff[i] + (size_t)kc * d.csA);
+        f.a[i] = make_double2(v.x, v.y * sa);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (B_REAL) {
+          f.b[j] = make_double2(dm_ldg(Br, (size_t)kc * d.rsB + boff[j]), 0.0);
+        } else {
+          const cplx v = dm_ldg(Bc, boff[j] + (size_t)kc * d.rsB);
+          f.b[j] = make_double2(v.x, v.y * sb);
+        }
+      }
+      return f;
+    }
+    const double ks = (d.kscale && !B_GATHER) ? dm_ldg(d.kscale, kc) : 1.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      cplx v = dm_ldg(A, aoff[i] + (size_t)kc * d.csA);
+      const double m = (kv && aok[i]) ? ks : 0.0;
+      f.a[i] = make_double2(v.x * m, v.y * m * sa);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      cplx v;
+      if (B_REAL) {
+        v = make_double2(dm_ldg(Br, (size_t)kc * d.rsB + boff[j]), 0.0);
+      } else {
+        v = dm_ldg(Bc, boff[j] + (size_t)kc * d.rsB);
+      }
+      double m = (kv && bok[j]) ? 1.0 : 0.0;
+      if (B_GATHER) m *= dm_ldg(d.kscale, ksoff[j] + kc);
+      f.b[j] = make_double2(v.x * m, v.y * m * sb);
+    }
+    return f;
+  };
+  auto compute = [&](const frag& f) {
+    double bre[2][4], bim[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bre[j][0] = f.b[j].x;
+      bim[j][0] = f.b[j].y;
+      // rotation s needs the operand of the lane 4 s further along its 16-lane row: row_ror:n hands lane i the
+      // value of lane (i - n) mod 16, so "4 s further" is a rotation by 16 - 4 s (checked against the LDS kernel)
+      bre[j][1] = dm_dpp_f64<0x12C>(f.b[j].x); bim[j][1] = dm_dpp_f64<0x12C>(f.b[j].y);
+      bre[j][2] = dm_dpp_f64<0x128>(f.b[j].x); bim[j][2] = dm_dpp_f64<0x128>(f.b[j].y);
+      bre[j][3] = dm_dpp_f64<0x124>(f.b[j].x); bim[j][3] = dm_dpp_f64<0x124>(f.b[j].y);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (!(tile_i[i] && tile_j[j])) continue;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc_re[i][j][s] = dm_mfma4(f.a[i].x, bre[j][s], acc_re[i][j][s]);
+          acc_im[i][j][s] = dm_mfma4(f.a[i].x, bim[j][s], acc_im[i][j][s]);
+        }
+        if (!B_REAL) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            acc_re[i][j][s] = dm_mfma4(-f.a[i].y, bim[j][s], acc_re[i][j][s]);
+            acc_im[i][j][s] = dm_mfma4(f.a[i].y, bre[j][s], acc_im[i][j][s]);
+          }
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc_im[i][j][s] = dm_mfma4(f.a[i].y, bre[j][s], acc_im[i][j][s]);
+        }
+      }
+  };
+  const int nk = (d.K + 3) / 4;
+  if (nk > 0) {
+    frag cur = load(0);
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      const frag nxt = load((kt + 1) * 4);   // in flight under the MFMAs of this step
+      compute(cur);
+      cur = nxt;
+    }
+    compute(cur);
+  }
+  // epilogue: lane 16 i' + 4 g + j' of rotation s holds C[4 g + i'][4 ((g + s) & 3) + j']
+  cplx* __restrict__ C = reinterpret_cast<cplx*>(d.C);
+  const int ip = lane >> 4, jp = lane & 3;
+  const bool rmw = d.beta != 0.0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int gm = mrow + i * 16 + 4 * g + ip;
+        const int gn = ncol + j * 16 + 4 * ((g + s) & 3) + jp;
+        if (gm >= d.M || gn >= d.N) continue;
+        const double are = acc_re[i][j][s], aim = acc_im[i][j][s];
+        cplx v = make_double2(d.alpha * are - d.alpha_im * aim, d.alpha * aim + d.alpha_im * are);
+        if (rmw) {
+          const cplx o = dm_ldg(C, (size_t)gm * d.ldc + gn);
+          v.x += d.beta * o.x;
+          v.y += d.beta * o.y;
+        }
+        dm_stg(C, (size_t)gm * d.ldc + gn, v);
+      }
+}
+
 // ---- all-real variant: C[M x N] (double) = alpha * A * B + beta * C, same tiling, one MFMA per
 // (tile, k-step).  Used by the divide & conquer eigenvector updates (real orthogonal matrices).
 __global__ __launch_bounds__(256) void dgemm_grouped_kernel(const dm_gemm_desc* __restrict__ descs,
@@ -377,6 +555,9 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
   auto by_k = [&](const dm_gemm_tile& a, const dm_gemm_tile& b) { return descs[a.desc].K > descs[b.desc].K; };
   for (auto* tl : {&tiles, &tiles_real, &tiles_dd, &tiles_gat})
     if (!std::is_sorted(tl->begin(), tl->end(), by_k)) std::stable_sort(tl->begin(), tl->end(), by_k);
+  // DM_GEMM4 = 1 / 0 selects the register-only 4x4x4 kernel / the LDS-staged 16x16x4 kernel (default below)
+  static const int use4_env = getenv("DM_GEMM4") ? atoi(getenv("DM_GEMM4")) : -1;
+  const bool use4 = use4_env >= 0 ? use4_env != 0 : true;
   size_t mark = dm_ws_mark(ctx);
   // descriptors and all tile lists travel in ONE host-to-device copy: on the chains of short
   // dependent products (triangular solves, Cholesky) the API calls per launch are what the GPU waits for
@@ -411,8 +592,12 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
     }
     {
       dm_prof_scope ps(ctx, DM_PROF_GEMM, fl_c);
-      hipLaunchKernelGGL((zgemm_grouped_kernel<false, false>), dim3((unsigned)tiles.size()), dim3(256), 0, ctx->stream, dd,
-                         dt, (int)tiles.size());
+      if (use4)
+        hipLaunchKernelGGL((zgemm4_grouped_kernel<false, false>), dim3((unsigned)tiles.size()), dim3(256), 0, ctx->stream, dd,
+                           dt, (int)tiles.size());
+      else
+        hipLaunchKernelGGL((zgemm_grouped_kernel<false, false>), dim3((unsigned)tiles.size()), dim3(256), 0, ctx->stream, dd,
+                           dt, (int)tiles.size());
     }
     if (log) {
       (void)hipEventRecord(e1, ctx->stream);
@@ -437,14 +622,22 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
   if (!tiles_gat.empty()) {
     dm_gemm_tile* dt = dt_g;
     dm_prof_scope ps(ctx, DM_PROF_GEMM, fl_g);
-    hipLaunchKernelGGL((zgemm_grouped_kernel<false, true>), dim3((unsigned)tiles_gat.size()), dim3(256), 0, ctx->stream,
-                       dd, dt, (int)tiles_gat.size());
+    if (use4)
+      hipLaunchKernelGGL((zgemm4_grouped_kernel<false, true>), dim3((unsigned)tiles_gat.size()), dim3(256), 0, ctx->stream,
+                         dd, dt, (int)tiles_gat.size());
+    else
+      hipLaunchKernelGGL((zgemm_grouped_kernel<false, true>), dim3((unsigned)tiles_gat.size()), dim3(256), 0, ctx->stream,
+                         dd, dt, (int)tiles_gat.size());
   }
   if (!tiles_real.empty()) {
     dm_gemm_tile* dt = dt_r;
     dm_prof_scope ps(ctx, DM_PROF_GEMM_REAL, fl_r);
-    hipLaunchKernelGGL((zgemm_grouped_kernel<true, false>), dim3((unsigned)tiles_real.size()), dim3(256), 0, ctx->stream,
-                       dd, dt, (int)tiles_real.size());
+    if (use4)
+      hipLaunchKernelGGL((zgemm4_grouped_kernel<true, false>), dim3((unsigned)tiles_real.size()), dim3(256), 0, ctx->stream,
+                         dd, dt, (int)tiles_real.size());
+    else
+      hipLaunchKernelGGL((zgemm_grouped_kernel<true, false>), dim3((unsigned)tiles_real.size()), dim3(256), 0, ctx->stream,
+                         dd, dt, (int)tiles_real.size());
   }
   if (!tiles_dd.empty()) {
     dm_gemm_tile* dt = dt_d;
