@@ -43,7 +43,7 @@ int dio_version(void) { return 100; }
  * LZF: control byte c < 32: c + 1 literal bytes follow; else a back reference of length (c >> 5) + 2
  * (a length field of 7 is extended by the next byte) at distance ((c & 31) << 8 | next byte) + 1.
  * ------------------------------------------------------------------------------------------------ */
-#define HLOG 16
+#define HLOG 14
 #define MAX_LIT 32
 #define MAX_OFF 8192
 #define MAX_REF 264
@@ -51,22 +51,32 @@ int dio_version(void) { return 100; }
 size_t dio_lzf_compress(const void* in_, size_t n, void* out_, size_t out_len) {
   const unsigned char* in = (const unsigned char*)in_;
   unsigned char* out = (unsigned char*)out_;
-  if (n == 0 || out_len == 0) return 0;
-  uint32_t* htab = (uint32_t*)calloc((size_t)1 << HLOG, sizeof(uint32_t)); /* position + 1, 0 = empty */
-  if (!htab) return 0;
+  if (n == 0 || out_len == 0 || n >= 0x7fffffffu) return 0;
+  /* The hash table is per thread and never cleared between calls (chunks are a few KB to a few MB, thousands per
+   * file: clearing would cost more than compressing): an entry holds base + position + 1 and is valid only while it
+   * exceeds the base of the current call. */
+  static __thread uint32_t htab[(size_t)1 << HLOG];
+  static __thread uint32_t hbase = 0;
+  if (hbase > 0xffffffffu - (uint32_t)n - 2u) {
+    memset(htab, 0, sizeof(htab));
+    hbase = 0;
+  }
+  const uint32_t base = hbase;
+  hbase += (uint32_t)n + 1u;
   size_t ip = 0, op = 0, lit = 0; /* lit: literals pending since out[op - lit - 1] (their control byte) */
   size_t ctrl = op++;              /* control byte of the open literal run */
-  if (op > out_len) { free(htab); return 0; }
-#define EMIT(b)                                   \
-  do {                                            \
-    if (op >= out_len) { free(htab); return 0; } \
-    out[op++] = (unsigned char)(b);               \
+  if (op > out_len) return 0;
+#define EMIT(b)                     \
+  do {                              \
+    if (op >= out_len) return 0;    \
+    out[op++] = (unsigned char)(b); \
   } while (0)
   while (ip + 2 < n) {
     const uint32_t v = ((uint32_t)in[ip] << 16) | ((uint32_t)in[ip + 1] << 8) | in[ip + 2];
     const uint32_t h = ((v * 2654435761u) >> (32 - HLOG)) & ((1u << HLOG) - 1);
-    const size_t cand1 = htab[h];
-    htab[h] = (uint32_t)(ip + 1);
+    const uint32_t cand = htab[h];
+    htab[h] = base + (uint32_t)ip + 1u;
+    const size_t cand1 = cand > base ? (size_t)(cand - base) : 0;
     size_t ref = cand1 - 1;
     if (cand1 != 0 && ip - ref <= MAX_OFF && in[ref] == in[ip] && in[ref + 1] == in[ip + 1] && in[ref + 2] == in[ip + 2]) {
       size_t maxlen = n - ip;
@@ -88,7 +98,7 @@ size_t dio_lzf_compress(const void* in_, size_t n, void* out_, size_t out_len) {
       if (len > 3 && ip + len + 2 < n) {
         const size_t q = ip + len - 2;
         const uint32_t w = ((uint32_t)in[q] << 16) | ((uint32_t)in[q + 1] << 8) | in[q + 2];
-        htab[((w * 2654435761u) >> (32 - HLOG)) & ((1u << HLOG) - 1)] = (uint32_t)(q + 1);
+        htab[((w * 2654435761u) >> (32 - HLOG)) & ((1u << HLOG) - 1)] = base + (uint32_t)q + 1u;
       }
       ip += len;
       lit = 0;
@@ -118,7 +128,6 @@ size_t dio_lzf_compress(const void* in_, size_t n, void* out_, size_t out_len) {
   if (lit) out[ctrl] = (unsigned char)(lit - 1);
   else --op;
 #undef EMIT
-  free(htab);
   return op;
 }
 
@@ -302,6 +311,32 @@ int dio_open(const char* path, const char* mode, int64_t* file_out) {
   return 0;
 }
 
+/* Create a file whose final size is roughly known: small files (the per-m products of small telescopes: thousands
+ * of chunks of a few KB) are assembled in memory by HDF5's core driver and reach the disk in ONE write at close —
+ * with the default driver every H5Dwrite_chunk is a system call of its own.  Large files keep the default driver. */
+int dio_create(const char* path, uint64_t expected_bytes, int64_t* file_out) {
+  pthread_once(&g_once, init_once);
+  if (!path || !file_out) return fail("dio_create: bad argument");
+  hid_t f = -1;
+  LOCK();
+  hid_t fapl = H5Pcreate(H5P_FILE_ACCESS);
+  /* 1.10 file format: fixed-size chunked datasets get the "fixed array" chunk index instead of the version-1
+   * B-tree, whose insertions dominate files made of thousands of small chunks (any HDF5 >= 1.10 reads it,
+   * i.e. every h5py >= 2.8 wheel) */
+  if (fapl >= 0 && !getenv("DRIFTIO_LIBVER_EARLIEST")) H5Pset_libver_bounds(fapl, H5F_LIBVER_V110, H5F_LIBVER_V110);
+  if (fapl >= 0 && expected_bytes > 0 && expected_bytes <= ((uint64_t)256 << 20)) {
+    size_t inc = (size_t)(expected_bytes / 4);
+    if (inc < ((size_t)1 << 20)) inc = (size_t)1 << 20;
+    H5Pset_fapl_core(fapl, inc, 1);
+  }
+  f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, fapl >= 0 ? fapl : H5P_DEFAULT);
+  if (fapl >= 0) H5Pclose(fapl);
+  UNLOCK();
+  if (f < 0) return fail("dio_create: cannot create '%s'", path);
+  *file_out = (int64_t)f;
+  return 0;
+}
+
 int dio_close(int64_t file) {
   LOCK();
   const herr_t rc = H5Fclose((hid_t)file);
@@ -413,7 +448,7 @@ int dio_write_dataset(int64_t file, const char* name, int dtype, int ndim, const
       uint32_t mask = 0;
       if (compression == DIO_COMP_LZF) {
         /* dense full-precision doubles do not compress: probe the head of the chunk before paying for all of it */
-        const size_t probe = cbytes < 8192 ? cbytes : 8192;
+        const size_t probe = cbytes < 2048 ? cbytes : 2048;
         size_t got = dio_lzf_compress(cbuf, probe, zbuf, probe - probe / 16 - 1);
         if (got > 0 && probe < cbytes) got = dio_lzf_compress(cbuf, cbytes, zbuf, cbytes - 1);
         if (got > 0) {

@@ -48,6 +48,7 @@ DIO_SIGNATURES = {
     "dio_version": (ctypes.c_int, []),
     "dio_hdf5_version": (ctypes.c_int, []),
     "dio_open": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
+    "dio_create": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_int64)]),
     "dio_close": (ctypes.c_int, [ctypes.c_int64]),
     "dio_write_dataset": (ctypes.c_int, [ctypes.c_int64, ctypes.c_char_p, ctypes.c_int, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.c_int,
@@ -393,7 +394,8 @@ class DriftioFile(_BaseFile):
 
     def _write_all(self, tmp):
         h = ctypes.c_int64(0)
-        self._check(self._lib.dio_open(tmp.encode(), b"w", ctypes.byref(h)), "create %s" % tmp)
+        expected = sum(int(np.asarray(a).nbytes) for a in self._data.values()) + 65536
+        self._check(self._lib.dio_create(tmp.encode(), expected, ctypes.byref(h)), "create %s" % tmp)
         try:
             for name, arr in self._data.items():
                 arr = np.asarray(arr)

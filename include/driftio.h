@@ -50,6 +50,8 @@ int dio_hdf5_version(void);
 
 /* mode: "w" (create / truncate), "r", "r+" */
 int dio_open(const char* path, const char* mode, int64_t* file_out);
+/* "w" with a size hint: files up to 256 MB are assembled in memory (HDF5 core driver) and written once at close */
+int dio_create(const char* path, uint64_t expected_bytes, int64_t* file_out);
 int dio_close(int64_t file);
 
 /* Create dataset `name` (shape[ndim]) and write `data` (C order, contiguous, host).
