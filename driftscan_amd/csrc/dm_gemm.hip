@@ -268,7 +268,12 @@ __global__ __launch_bounds__(256, 2) void zgemm4_grouped_kernel(const dm_gemm_de
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int k = lane >> 4, g = (lane >> 2) & 3, t = lane & 3;
-  const int mrow = tl.tm * BM + wm * 32, ncol = tl.tn * BN + wn * 32;
+  // square tile: 2 x 2 waves of 32 x 32; flat tile (tm < 0, unit -tm - 1): 32 rows x 128 columns, one wave per 32
+  // columns — ragged row counts (the per-frequency blocks of 70-92 modes) then waste at most 15 rows instead of 63
+  const bool flat = tl.tm < 0;
+  const int mrow = flat ? (-tl.tm - 1) * 32 : tl.tm * BM + wm * 32;
+  const int ncol = flat ? tl.tn * 128 + wave * 32 : tl.tn * BN + wn * 32;
+  if (mrow >= d.M || ncol >= d.N) return;  // no LDS, no barrier: a wave without outputs just leaves
   const cplx* __restrict__ A = reinterpret_cast<const cplx*>(d.A);
   const cplx* __restrict__ Bc = reinterpret_cast<const cplx*>(d.B);
   const double* __restrict__ Br = reinterpret_cast<const double*>(d.B);
@@ -528,6 +533,10 @@ __global__ __launch_bounds__(256) void dgemm_grouped_kernel(const dm_gemm_desc* 
 // Host side: flatten descriptors into tiles, upload, launch.
 int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) {
   if (descs.empty()) return DM_OK;
+  // DM_GEMM4 = 1 / 0 selects the register-only 4x4x4 kernel (default) / the LDS-staged 16x16x4 kernel
+  static const int use4_env = getenv("DM_GEMM4") ? atoi(getenv("DM_GEMM4")) : -1;
+  static const bool noflat = getenv("DM_GEMM4_NOFLAT") != nullptr;
+  const bool use4 = use4_env >= 0 ? use4_env != 0 : true;
   std::vector<dm_gemm_tile> tiles;
   std::vector<dm_gemm_tile> tiles_real;
   std::vector<dm_gemm_tile> tiles_dd;
@@ -538,6 +547,19 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
     const dm_gemm_desc& d = descs[i];
     if (d.M <= 0 || d.N <= 0) continue;
     int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
+    // flat 32 x 128 tiles of the register-only kernel where the 32-row granularity saves work (M = 70..96, 130..160, ...)
+    if (use4 && !noflat && !(d.flags & (DM_GEMM_ALL_REAL | DM_GEMM_LOWER | DM_GEMM_UPPER)) && ((d.M + 31) / 32) * 32 < tm * BM) {
+      const int um = (d.M + 31) / 32, un = (d.N + 127) / 128;
+      for (int a = 0; a < um; ++a)
+        for (int b = 0; b < un; ++b) {
+          dm_gemm_tile t{(int)i, -a - 1, b};
+          const double rows = std::min(32, d.M - a * 32), cols = std::min(128, d.N - b * 128);
+          if (d.flags & DM_GEMM_B_REAL) { tiles_real.push_back(t); fl_r += 4.0 * rows * cols * d.K; }
+          else if (d.flags & DM_GEMM_B_GATHER) { tiles_gat.push_back(t); fl_g += 8.0 * rows * cols * d.K; }
+          else { tiles.push_back(t); fl_c += 8.0 * rows * cols * d.K; }
+        }
+      continue;
+    }
     for (int a = 0; a < tm; ++a)
       for (int b = 0; b < tn; ++b) {
         if ((d.flags & DM_GEMM_LOWER) && b > a) continue;
@@ -555,9 +577,6 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
   auto by_k = [&](const dm_gemm_tile& a, const dm_gemm_tile& b) { return descs[a.desc].K > descs[b.desc].K; };
   for (auto* tl : {&tiles, &tiles_real, &tiles_dd, &tiles_gat})
     if (!std::is_sorted(tl->begin(), tl->end(), by_k)) std::stable_sort(tl->begin(), tl->end(), by_k);
-  // DM_GEMM4 = 1 / 0 selects the register-only 4x4x4 kernel / the LDS-staged 16x16x4 kernel (default below)
-  static const int use4_env = getenv("DM_GEMM4") ? atoi(getenv("DM_GEMM4")) : -1;
-  const bool use4 = use4_env >= 0 ? use4_env != 0 : true;
   size_t mark = dm_ws_mark(ctx);
   // descriptors and all tile lists travel in ONE host-to-device copy: on the chains of short
   // dependent products (triangular solves, Cholesky) the API calls per launch are what the GPU waits for
