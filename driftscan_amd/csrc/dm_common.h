@@ -174,6 +174,25 @@ __device__ __forceinline__ double dm_mfma4(double a, double b, double c) {
   return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
+// DPP move of a double inside each 16-lane row (two v_mov_b32 with a dpp modifier, no LDS crossbar).
+// row_ror:n (CTRL = 0x120 + n) hands lane i the value of lane (i - n) mod 16 of its row.  The 4x4x4 MFMA pairs
+// row block g with column block (g + s) & 3 in its rotation s: the operand of the lane 4 s further along the row,
+// i.e. a rotation by 16 - 4 s: dm_rot4<1> = row_ror:12, <2> = row_ror:8, <3> = row_ror:4.
+template <int CTRL>
+__device__ __forceinline__ double dm_dpp_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int S>
+__device__ __forceinline__ double dm_rot4(double v) {
+  if constexpr (S == 0) return v;
+  else if constexpr (S == 1) return dm_dpp_f64<0x12C>(v);
+  else if constexpr (S == 2) return dm_dpp_f64<0x128>(v);
+  else return dm_dpp_f64<0x124>(v);
+}
+
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
   return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }

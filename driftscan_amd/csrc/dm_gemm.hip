@@ -250,14 +250,6 @@ __global__ __launch_bounds__(256, 3) void zgemm_grouped_kernel(const dm_gemm_des
 //   rotation s (s = 0..3) pairs row block g with column block g' = (g + s) & 3, so four instructions cover a
 //   16x16 tile; D of rotation s lands in lane 16 i + 4 g + j = C[4 g + i][4 ((g + s) & 3) + j].
 // The rotated B operands are the rotation-0 registers moved by DPP row_ror inside each 16-lane row (same k).
-template <int CTRL>
-__device__ __forceinline__ double dm_dpp_f64(double v) {
-  const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
 template <bool B_REAL, bool B_GATHER>
 __global__ __launch_bounds__(256, 2) void zgemm4_grouped_kernel(const dm_gemm_desc* __restrict__ descs,
                                                                 const dm_gemm_tile* __restrict__ tiles, int ntiles) {
@@ -547,8 +539,9 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
     const dm_gemm_desc& d = descs[i];
     if (d.M <= 0 || d.N <= 0) continue;
     int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
-    // flat 32 x 128 tiles of the register-only kernel where the 32-row granularity saves work (M = 70..96, 130..160, ...)
-    if (use4 && !noflat && !(d.flags & (DM_GEMM_ALL_REAL | DM_GEMM_LOWER | DM_GEMM_UPPER)) && ((d.M + 31) / 32) * 32 < tm * BM) {
+    // flat 32 x 128 tiles of the register-only kernel where the 32-row granularity saves work and the problem is small
+    if (use4 && !noflat && !(d.flags & (DM_GEMM_ALL_REAL | DM_GEMM_LOWER | DM_GEMM_UPPER)) && ((d.M + 31) / 32) * 32 < tm * BM &&
+        (d.M <= 32 || d.N <= 256)) {  // measured: 32-row panels 36 -> 50 TFLOP/s, 92 x 92 x 129 26 -> 33.5; wide ragged ones lose 5 %
       const int um = (d.M + 31) / 32, un = (d.N + 127) / 128;
       for (int a = 0; a < um; ++a)
         for (int b = 0; b < un; ++b) {

@@ -50,7 +50,7 @@ int dio_hdf5_version(void);
 
 /* mode: "w" (create / truncate), "r", "r+" */
 int dio_open(const char* path, const char* mode, int64_t* file_out);
-/* "w" with a size hint: files up to 256 MB are assembled in memory (HDF5 core driver) and written once at close */
+/* "w" with a size hint (reserved: the default file driver is used whatever the size) */
 int dio_create(const char* path, uint64_t expected_bytes, int64_t* file_out);
 int dio_close(int64_t file);
 
