@@ -74,13 +74,12 @@ __global__ __launch_bounds__(256) void jac_gram_kernel(const jac_item* __restric
     atomicAdd(flopctr, 8ull * nr * nr * (unsigned long long)(it.g1 - it.g0));
   }
 
-  // v_mfma_f64_4x4x4 (the fp64 MFMA shape that issues at the datasheet rate): rotation s of tile j accumulates
-  // G[16 wave + 4 g + i][16 j + 4 ((g + s) & 3) + jj] in lane 16 i + 4 g + jj
-  double gre[4][4], gim[4][4];
+  dm_f64x4 gre[4], gim[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int r2 = 0; r2 < 4; ++r2) gre[j][r2] = gim[j][r2] = 0.0;
+  for (int j = 0; j < 4; ++j) {
+    gre[j] = dm_f64x4{0, 0, 0, 0};
+    gim[j] = dm_f64x4{0, 0, 0, 0};
+  }
 
   // staging map: 64 rows x 16 cols, k fastest (each row segment = 256 contiguous bytes)
   int srow[4], scol[4], grow[4];
@@ -119,33 +118,22 @@ __global__ __launch_bounds__(256) void jac_gram_kernel(const jac_item* __restric
         int rb = (j * 16 + fi) * XP + kk * 4 + fk;
         double x_re = Xre[rb], x_im = Xim[rb];
         // G[i][j] += a_i * conj(x_j)
-        const double xr[4] = {x_re, dm_rot4<1>(x_re), dm_rot4<2>(x_re), dm_rot4<3>(x_re)};
-        const double xi[4] = {x_im, dm_rot4<1>(x_im), dm_rot4<2>(x_im), dm_rot4<3>(x_im)};
-#pragma unroll
-        for (int r2 = 0; r2 < 4; ++r2) {
-          gre[j][r2] = dm_mfma4(a_re, xr[r2], gre[j][r2]);
-          gim[j][r2] = dm_mfma4(a_im, xr[r2], gim[j][r2]);
-        }
-#pragma unroll
-        for (int r2 = 0; r2 < 4; ++r2) {
-          gre[j][r2] = dm_mfma4(a_im, xi[r2], gre[j][r2]);
-          gim[j][r2] = dm_mfma4(a_ren, xi[r2], gim[j][r2]);
-        }
+        gre[j] = dm_mfma(a_re, x_re, gre[j]);
+        gre[j] = dm_mfma(a_im, x_im, gre[j]);
+        gim[j] = dm_mfma(a_im, x_re, gim[j]);
+        gim[j] = dm_mfma(a_ren, x_im, gim[j]);
       }
     }
   }
   cplx* G = Gbuf + (size_t)it.q * JP * JP;
-  {
-    const int gi = lane >> 4, gg = (lane >> 2) & 3, gj = lane & 3;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r2 = 0; r2 < 4; ++r2) {
-        const int row = wave * 16 + 4 * gg + gi;
-        const int col = j * 16 + 4 * ((gg + r2) & 3) + gj;
-        G[row * JP + col] = make_double2(gre[j][r2], gim[j][r2]);
-      }
-  }
+    for (int rr = 0; rr < 4; ++rr) {
+      int row = wave * 16 + (lane >> 4) + 4 * rr;
+      int col = j * 16 + (lane & 15);
+      G[row * JP + col] = make_double2(gre[j][rr], gim[j][rr]);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -391,43 +379,22 @@ __global__ __launch_bounds__(256) void jac_apply_kernel(const jac_item* __restri
       bre[ks] = v.x;
       bim[ks] = v.y;
     }
-    // 4x4x4 MFMAs: the strip in registers is the rotation-0 B operand as it stands (lane = 16 k + column), the other
-    // rotations are DPP moves; rotation s of row tile mt accumulates out[16 mt + 4 g + i][c + 4 ((g + s) & 3) + j]
-    double ore[4][4], oim[4][4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt) {
+      dm_f64x4 ore = {0, 0, 0, 0}, oim = {0, 0, 0, 0};
 #pragma unroll
-      for (int r2 = 0; r2 < 4; ++r2) ore[mt][r2] = oim[mt][r2] = 0.0;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const double br[4] = {bre[ks], dm_rot4<1>(bre[ks]), dm_rot4<2>(bre[ks]), dm_rot4<3>(bre[ks])};
-      const double bi[4] = {bim[ks], dm_rot4<1>(bim[ks]), dm_rot4<2>(bim[ks]), dm_rot4<3>(bim[ks])};
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const int ra = (ks * 4 + fk) * QP + mt * 16 + fj;
-        const double a_re = Are[ra], a_im = Aim[ra], a_imn = -a_im;
-#pragma unroll
-        for (int r2 = 0; r2 < 4; ++r2) {
-          ore[mt][r2] = dm_mfma4(a_re, br[r2], ore[mt][r2]);
-          oim[mt][r2] = dm_mfma4(a_re, bi[r2], oim[mt][r2]);
-        }
-#pragma unroll
-        for (int r2 = 0; r2 < 4; ++r2) {
-          ore[mt][r2] = dm_mfma4(a_imn, bi[r2], ore[mt][r2]);
-          oim[mt][r2] = dm_mfma4(a_im, br[r2], oim[mt][r2]);
-        }
+      for (int ks = 0; ks < 16; ++ks) {
+        int ra = (ks * 4 + fk) * QP + mt * 16 + fj;
+        double a_re = Are[ra], a_im = Aim[ra];
+        ore = dm_mfma(a_re, bre[ks], ore);
+        ore = dm_mfma(-a_im, bim[ks], ore);
+        oim = dm_mfma(a_re, bim[ks], oim);
+        oim = dm_mfma(a_im, bre[ks], oim);
       }
-    }
-    {
-      const int oi = lane >> 4, og = (lane >> 2) & 3, oj = lane & 3;
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const int grow = item_row(it, mt * 16 + 4 * og + oi);
-#pragma unroll
-        for (int r2 = 0; r2 < 4; ++r2) {
-          const int ocol = c + 4 * ((og + r2) & 3) + oj;
-          if (ocol < cend && grow >= 0) it.Z[(size_t)grow * it.ld + ocol] = make_double2(ore[mt][r2], oim[mt][r2]);
-        }
+      for (int rr = 0; rr < 4; ++rr) {
+        int grow = item_row(it, mt * 16 + (lane >> 4) + 4 * rr);
+        if (cok && grow >= 0) it.Z[(size_t)grow * it.ld + col] = make_double2(ore[rr], oim[rr]);
       }
     }
   }
