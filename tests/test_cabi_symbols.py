@@ -28,6 +28,22 @@ def test_header_symbols_exported():
     assert lib.dm_version() >= 100
 
 
+def test_driftcomm_header_symbols_exported():
+    """include/driftcomm.h <-> libdriftcomm.so <-> driftscan_amd/comm.py (no collective is called without a GPU)."""
+    from driftscan_amd import comm
+
+    txt = open(os.path.join(ROOT, "include", "driftcomm.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = sorted(set(re.findall(r"\b(dm_[a-z0-9_]+)\s*\(", txt)))
+    if not os.path.exists(comm.LIBPATH):
+        pytest.skip("libdriftcomm.so not built (no RCCL headers)")
+    lib = comm.load()
+    assert len(names) >= 8 and sorted(comm.SIGNATURES) == names
+    for n in names:
+        assert hasattr(lib, n)
+    assert lib.dm_comm_size(None) == -1 and lib.dm_comm_rank(None) == -1
+
+
 def test_no_cpu_fallback():
     import torch
 

@@ -242,3 +242,22 @@ def test_workspace_reset(ctx):
         assert ctx.lib.dm_ctx_workspace_bytes(ctx.h) >= nbytes
         ev, _ = ctx.herm_eig(ctx.to_device(C), n, n, strideC=n * n, batch=1)
         assert np.abs(np.sort(ev.cpu().numpy()[0, :n]) - ref).max() <= 1e-12 * ref.max()
+
+
+def test_driftcomm_single_rank(ctx):
+    """The RCCL wrappers of include/driftcomm.h with one rank (all a one-GPU box can run): id, init, all-reduce and
+    gather of doubles are the identity, rank / size are reported, sync returns."""
+    import torch
+
+    from driftscan_amd import comm
+
+    c = comm.Communicator(1, 0, comm.unique_id(), device=0)
+    assert c.rank == 0 and c.size == 1
+    x = torch.arange(1000, dtype=torch.float64, device="cuda") * 0.5
+    ref = x.clone()
+    c.allreduce(x)
+    out = torch.zeros(1000, dtype=torch.float64, device="cuda")
+    c.gather(x, out, root=0)
+    c.sync()
+    assert torch.equal(x, ref) and torch.equal(out, ref)
+    c.close()
