@@ -65,6 +65,15 @@ SIGNATURES = {
     "dm_eigh_gen": (
         c_int, [c_vp, c_int, ctypes.POINTER(c_int), c_vp, c_vp, ctypes.POINTER(c_i64), c_vp, ctypes.POINTER(c_i64),
                 c_vp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_int), c_int, c_dbl, ctypes.POINTER(c_int)]),
+    "dm_kl_m": (
+        c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_vp,
+                ctypes.POINTER(c_int), c_int, c_vp, ctypes.POINTER(c_int), c_int, c_vp, c_dbl, c_dbl, c_int, c_dbl, c_vp,
+                ctypes.POINTER(c_i64), c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_dbl), ctypes.POINTER(c_int)]),
+    "dm_doublekl_m": (
+        c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_vp,
+                ctypes.POINTER(c_int), c_int, c_vp, ctypes.POINTER(c_int), c_int, c_vp, c_dbl, c_dbl, c_dbl, c_int, c_dbl, c_vp,
+                c_vp, ctypes.POINTER(c_i64), c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                ctypes.POINTER(c_dbl)]),
     "dm_fisher": (
         c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int,
                 c_vp, c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_int), c_vp, ctypes.POINTER(c_i64), c_vp, c_int]),
@@ -389,6 +398,69 @@ def _eigh_gen(self, A, B, ndofs, off, cut=None):
     return evals, evoff, evecs, np.array(ac[: len(n)], dtype=np.float64), sw.value
 
 
+def _kl_m(self, beam_svd, beam_ut, svnum, l0, cl_sg, sg_mask, sg_sym, cl_fg, fg_mask, fg_sym, npower, noise_scale, regulariser,
+          cut=None):
+    """dm_kl_m: covariances + generalised eigenproblem of a batch of m-blocks in one library call.  Returns
+    (evals flat, evoff, evecs flat, off, add_const, nkeep)."""
+    nblk, F, K, P, L = [int(x) for x in beam_svd.shape]
+    T = int(beam_ut.shape[-1])
+    sv, svp = _iarr(svnum)
+    ndofs = np.asarray(svnum).reshape(nblk, F).sum(axis=1).astype(np.int64)
+    off, tot = _block_offsets(ndofs)
+    evoff = np.concatenate([[0], np.cumsum(ndofs)])
+    o, op = _larr(off)
+    eo, eop = _larr(evoff[:-1])
+    l0a, l0p = (None, None) if l0 is None else _iarr(l0)
+    sm, smp = (None, None) if sg_mask is None else _iarr(sg_mask)
+    fm, fmp = (None, None) if fg_mask is None else _iarr(fg_mask)
+    evals = self.empty((max(int(evoff[-1]), 1),), np.float64)
+    evecs = self.empty((max(tot, 1),), np.complex128)
+    ac = (c_dbl * max(nblk, 1))()
+    nk = (c_int * max(nblk, 1))()
+    mode, thr = (0, 0.0) if cut is None else ({"upper": 1, "lower": 2}[cut[0]], float(cut[1]))
+    rc = self.lib.dm_kl_m(self.h, nblk, F, K, P, L, T, self.ptr(beam_svd), self.ptr(beam_ut), svp, l0p, self.ptr(cl_sg), smp,
+                          int(bool(sg_sym)), self.ptr(cl_fg), fmp, int(bool(fg_sym)), self.ptr(npower), float(noise_scale),
+                          float(regulariser), mode, thr, self.ptr(evals), eop, self.ptr(evecs), op, ac, nk)
+    self.check(rc, "dm_kl_m")
+    if rc > 0:
+        raise DriftMIError("dm_kl_m: numerical failure (info=%d)" % rc)
+    return evals, evoff, evecs, off, np.array(ac[:nblk]), np.array(nk[:nblk], dtype=np.int64)
+
+
+def _doublekl_m(self, beam_svd, beam_ut, svnum, l0, cl_sg, sg_mask, sg_sym, cl_fg, fg_mask, fg_sym, npower, floor_scale,
+                regulariser, foreground_threshold, cut=None):
+    """dm_doublekl_m.  Returns (f_evals flat, evals flat, evoff, modes flat, off, nmodes, nkeep, add_const)."""
+    nblk, F, K, P, L = [int(x) for x in beam_svd.shape]
+    T = int(beam_ut.shape[-1])
+    sv, svp = _iarr(svnum)
+    ndofs = np.asarray(svnum).reshape(nblk, F).sum(axis=1).astype(np.int64)
+    off, tot = _block_offsets(ndofs)
+    evoff = np.concatenate([[0], np.cumsum(ndofs)])
+    o, op = _larr(off)
+    eo, eop = _larr(evoff[:-1])
+    l0a, l0p = (None, None) if l0 is None else _iarr(l0)
+    sm, smp = (None, None) if sg_mask is None else _iarr(sg_mask)
+    fm, fmp = (None, None) if fg_mask is None else _iarr(fg_mask)
+    f_evals = self.empty((max(int(evoff[-1]), 1),), np.float64)
+    evals = self.zeros((max(int(evoff[-1]), 1),), np.float64)
+    modes = self.zeros((max(tot, 1),), np.complex128)
+    ac = (c_dbl * max(nblk, 1))()
+    nm = (c_int * max(nblk, 1))()
+    nk = (c_int * max(nblk, 1))()
+    mode, thr = (0, 0.0) if cut is None else ({"upper": 1, "lower": 2}[cut[0]], float(cut[1]))
+    rc = self.lib.dm_doublekl_m(self.h, nblk, F, K, P, L, T, self.ptr(beam_svd), self.ptr(beam_ut), svp, l0p, self.ptr(cl_sg), smp,
+                                int(bool(sg_sym)), self.ptr(cl_fg), fmp, int(bool(fg_sym)), self.ptr(npower), float(floor_scale),
+                                float(regulariser), float(foreground_threshold), mode, thr, self.ptr(f_evals), self.ptr(evals),
+                                eop, self.ptr(modes), op, nm, nk, ac)
+    self.check(rc, "dm_doublekl_m")
+    if rc > 0:
+        raise DriftMIError("dm_doublekl_m: numerical failure (info=%d)" % rc)
+    return (f_evals, evals, evoff, modes, off, np.array(nm[:nblk], dtype=np.int64), np.array(nk[:nblk], dtype=np.int64),
+            np.array(ac[:nblk]))
+
+
+Context.kl_m = _kl_m
+Context.doublekl_m = _doublekl_m
 Context.svd_chain = _svd_chain
 Context.project_cov = _project_cov
 Context.project_diag = _project_diag

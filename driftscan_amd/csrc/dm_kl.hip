@@ -485,4 +485,171 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
   return DM_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// One-call drivers: KLTransform._transform_m and DoubleKL._transform_m for a batch of m-blocks
+// (drift/core/kltransform.py:258-355, drift/core/doublekl.py:30-87).  They compose the entry points above; the
+// Python classes call those one by one (they also serve `inverse`, the files, the projections), a host without the
+// Python layer calls these.
+// ---------------------------------------------------------------------------------------------------------------
+static int kl_covariances(dm_ctx* ctx, int nblk, int F, int K, int P, int L, int T, const void* beam_svd_dev,
+                          const void* beam_ut_dev, const int* svnum_host, const int* l0_host, const double* cl_sg_dev,
+                          const int* sg_mask_host, int sg_symmetric, const double* cl_fg_dev, const int* fg_mask_host,
+                          int fg_symmetric, const double* npower_dev, double noise_scale, double regulariser,
+                          const std::vector<int>& ndof, const std::vector<int64_t>& off, cplx* S, cplx* N) {
+  // S = B C_sg B^H (kltransform.py:281); N = B C_fg B^H or 0 (:283-286); diag(N) += reg * max(N) (:289-290);
+  // N += noise_scale * U diag(noisepower) U^H (:292-303)
+  DM_TRY(dm_project_cov(ctx, nblk, F, K, P, L, beam_svd_dev, svnum_host, l0_host, cl_sg_dev, P, sg_mask_host, S, off.data(),
+                        1 | (sg_symmetric ? 2 : 0)));
+  if (cl_fg_dev) {
+    DM_TRY(dm_project_cov(ctx, nblk, F, K, P, L, beam_svd_dev, svnum_host, l0_host, cl_fg_dev, P, fg_mask_host, N, off.data(),
+                          1 | (fg_symmetric ? 2 : 0)));
+  } else {
+    for (int b = 0; b < nblk; ++b) DM_TRY(dm_fill_zero(ctx, N + off[b], sizeof(cplx) * (size_t)ndof[b] * ndof[b]));
+  }
+  DM_TRY(dm_regularise(ctx, nblk, ndof.data(), N, off.data(), regulariser));
+  DM_TRY(dm_project_diag(ctx, nblk, F, K, T, beam_ut_dev, svnum_host, npower_dev, noise_scale, N, off.data(), 1));
+  return DM_OK;
+}
+
+int dm_kl_m(dm_ctx* ctx, int nblk, int F, int K, int P, int L, int T, const void* beam_svd_dev, const void* beam_ut_dev,
+            const int* svnum_host, const int* l0_host, const double* cl_sg_dev, const int* sg_mask_host, int sg_symmetric,
+            const double* cl_fg_dev, const int* fg_mask_host, int fg_symmetric, const double* npower_dev, double noise_scale,
+            double regulariser, int cut_mode, double cut_value, double* evals_dev, const int64_t* evoff_host, void* evecs_dev,
+            const int64_t* off_host, double* add_const_host, int* nkeep_host) {
+  if (!ctx) return DM_EARG;
+  DM_ARG(ctx, nblk >= 0 && F > 0 && K > 0 && P > 0 && L > 0 && T > 0 && beam_svd_dev && beam_ut_dev && svnum_host && cl_sg_dev &&
+                  npower_dev && evals_dev && evoff_host && evecs_dev && off_host && add_const_host);
+  if (nblk == 0) return DM_OK;
+  dm_ws_scope ws_scope__(ctx);
+  std::vector<int> ndof(nblk, 0);
+  std::vector<int64_t> off(nblk);
+  size_t tot = 0;
+  for (int b = 0; b < nblk; ++b) {
+    for (int f = 0; f < F; ++f) ndof[b] += svnum_host[b * F + f];
+    off[b] = (int64_t)tot;
+    tot += (size_t)ndof[b] * ndof[b];
+  }
+  cplx* S = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(tot, 1));
+  cplx* N = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(tot, 1));
+  if (!S || !N) return DM_ENOMEM;
+  DM_TRY(kl_covariances(ctx, nblk, F, K, P, L, T, beam_svd_dev, beam_ut_dev, svnum_host, l0_host, cl_sg_dev, sg_mask_host,
+                        sg_symmetric, cl_fg_dev, fg_mask_host, fg_symmetric, npower_dev, noise_scale, regulariser, ndof, off, S, N));
+  // the caller's block offsets may differ from the dense local ones: solve in place, then copy the modes out
+  int sweeps = 0;
+  cplx* E = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(tot, 1));
+  if (!E) return DM_ENOMEM;
+  const int rc = dm_eigh_gen(ctx, nblk, ndof.data(), S, N, off.data(), evals_dev, evoff_host, E, add_const_host, &sweeps, cut_mode,
+                             cut_value, nkeep_host);
+  if (rc != DM_OK) return rc;
+  std::vector<dm_cdesc> cp;
+  for (int b = 0; b < nblk; ++b)
+    if (ndof[b] > 0)
+      cp.push_back(dm_cdesc{E + off[b], reinterpret_cast<cplx*>(evecs_dev) + off_host[b], sizeof(cplx) * (size_t)ndof[b] * ndof[b]});
+  DM_TRY(dm_copy_batched(ctx, cp));
+  DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return DM_OK;
+}
+
+int dm_doublekl_m(dm_ctx* ctx, int nblk, int F, int K, int P, int L, int T, const void* beam_svd_dev, const void* beam_ut_dev,
+                  const int* svnum_host, const int* l0_host, const double* cl_sg_dev, const int* sg_mask_host, int sg_symmetric,
+                  const double* cl_fg_dev, const int* fg_mask_host, int fg_symmetric, const double* npower_dev,
+                  double floor_scale, double regulariser, double foreground_threshold, int cut_mode, double cut_value,
+                  double* f_evals_dev, double* evals_dev, const int64_t* evoff_host, void* modes_dev, const int64_t* off_host,
+                  int* nmodes_host, int* nkeep_host, double* add_const_host) {
+  if (!ctx) return DM_EARG;
+  DM_ARG(ctx, nblk >= 0 && F > 0 && K > 0 && P > 0 && L > 0 && T > 0 && beam_svd_dev && beam_ut_dev && svnum_host && cl_sg_dev &&
+                  npower_dev && f_evals_dev && evals_dev && evoff_host && modes_dev && off_host && nmodes_host && add_const_host);
+  if (nblk == 0) return DM_OK;
+  dm_ws_scope ws_scope__(ctx);
+  std::vector<int> ndof(nblk, 0);
+  std::vector<int64_t> off(nblk);
+  size_t tot = 0;
+  for (int b = 0; b < nblk; ++b) {
+    for (int f = 0; f < F; ++f) ndof[b] += svnum_host[b * F + f];
+    off[b] = (int64_t)tot;
+    tot += (size_t)ndof[b] * ndof[b];
+  }
+  cplx* S = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(tot, 1));
+  cplx* N = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(tot, 1));
+  cplx* S2 = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(tot, 1));
+  cplx* N2 = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(tot, 1));
+  cplx* E1 = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(tot, 1));
+  if (!S || !N || !S2 || !N2 || !E1) return DM_ENOMEM;
+  // ---- stage 1: signal against foregrounds, thermal noise down at the 1 mK floor (doublekl.py:44-52)
+  DM_TRY(kl_covariances(ctx, nblk, F, K, P, L, T, beam_svd_dev, beam_ut_dev, svnum_host, l0_host, cl_sg_dev, sg_mask_host,
+                        sg_symmetric, cl_fg_dev, fg_mask_host, fg_symmetric, npower_dev, floor_scale, regulariser, ndof, off, S, N));
+  // stage 2 wants the same S and N with the thermal term at full strength: eigh_gen destroys its inputs, keep copies
+  DM_HIP(ctx, hipMemcpyAsync(S2, S, sizeof(cplx) * tot, hipMemcpyDeviceToDevice, ctx->stream));
+  DM_HIP(ctx, hipMemcpyAsync(N2, N, sizeof(cplx) * tot, hipMemcpyDeviceToDevice, ctx->stream));
+  DM_TRY(dm_project_diag(ctx, nblk, F, K, T, beam_ut_dev, svnum_host, npower_dev, 1.0 - floor_scale, N2, off.data(), 1));
+  std::vector<int> keep(nblk, 0);
+  int sweeps = 0;
+  // modes with S/F strictly above the threshold (doublekl.py:56-60): eigenvalues ascend, so they are the trailing rows
+  int rc = dm_eigh_gen(ctx, nblk, ndof.data(), S, N, off.data(), f_evals_dev, evoff_host, E1, add_const_host, &sweeps, 1,
+                       std::nextafter(foreground_threshold, INFINITY), keep.data());
+  if (rc != DM_OK) return rc;
+  // ---- stage 2 in the kept subspace (doublekl.py:70-80)
+  std::vector<int> n2(nblk);
+  std::vector<int64_t> off2(nblk), toff(nblk);
+  size_t tot2 = 0, ttot = 0;
+  for (int b = 0; b < nblk; ++b) {
+    n2[b] = keep[b];
+    off2[b] = (int64_t)tot2;
+    tot2 += (size_t)n2[b] * n2[b];
+    toff[b] = (int64_t)ttot;
+    ttot += (size_t)n2[b] * ndof[b];
+  }
+  cplx* cs = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(tot2, 1));
+  cplx* cn = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(tot2, 1));
+  cplx* E2 = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(tot2, 1));
+  cplx* tmp = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(2 * ttot, 1));
+  double* ev2 = dm_ws_alloc_t<double>(ctx, std::max<size_t>((size_t)nblk * std::max(K * F, 1), 1));
+  if (!cs || !cn || !E2 || !tmp || !ev2) return DM_ENOMEM;
+  {
+    std::vector<dm_gemm_desc> g1, g2;
+    for (int b = 0; b < nblk; ++b) {
+      const int n = ndof[b], r = n2[b];
+      if (r <= 0) continue;
+      const cplx* Ek = E1 + off[b] + (size_t)(n - r) * n;   // kept rows of E1 (r x n)
+      for (int j = 0; j < 2; ++j) {
+        cplx* Tj = tmp + (size_t)j * ttot + toff[b];
+        g1.push_back(dm_gemm_make(Ek, n, 1, false, (j ? N2 : S2) + off[b], n, 1, false, Tj, n, r, n, n));        // E C
+        g2.push_back(dm_gemm_make(Tj, n, 1, false, Ek, 1, n, true, (j ? cn : cs) + off2[b], r, r, r, n));          // (E C) E^H
+      }
+    }
+    DM_TRY(dm_gemm_grouped_launch(ctx, g1));
+    DM_TRY(dm_gemm_grouped_launch(ctx, g2));
+  }
+  std::vector<int64_t> evoff2(nblk);
+  {
+    int64_t o = 0;
+    for (int b = 0; b < nblk; ++b) { evoff2[b] = o; o += n2[b]; }
+  }
+  std::vector<double> ac2(nblk, 0.0);
+  std::vector<int> nk2(nblk, 0);
+  rc = dm_eigh_gen(ctx, nblk, n2.data(), cs, cn, off2.data(), ev2, evoff2.data(), E2, ac2.data(), &sweeps, cut_mode, cut_value,
+                   nk2.data());
+  if (rc != DM_OK) return rc;
+  // ---- modes = E2 . E1[kept] (doublekl.py:80), stage-2 eigenvalues to the caller's layout
+  {
+    std::vector<dm_gemm_desc> g;
+    std::vector<dm_cdesc> cp;
+    for (int b = 0; b < nblk; ++b) {
+      const int n = ndof[b], r = n2[b];
+      nmodes_host[b] = r;
+      if (nkeep_host) nkeep_host[b] = nk2[b];
+      if (r <= 0) continue;
+      const cplx* Ek = E1 + off[b] + (size_t)(n - r) * n;
+      g.push_back(dm_gemm_make(E2 + off2[b], r, 1, false, Ek, n, 1, false, reinterpret_cast<cplx*>(modes_dev) + off_host[b], n, r,
+                               n, r));
+      cp.push_back(dm_cdesc{ev2 + evoff2[b], evals_dev + evoff_host[b], sizeof(double) * (size_t)r});
+    }
+    DM_TRY(dm_gemm_grouped_launch(ctx, g));
+    DM_TRY(dm_copy_batched(ctx, cp));
+  }
+  DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return DM_OK;
+}
+
 }  // extern "C"

@@ -181,6 +181,35 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
                 double* evals_dev, const int64_t* evoff_host, void* evecs_dev, double* add_const_host,
                 int* sweeps_host, int cut_mode, double cut_value, int* nkeep_host);
 
+/* KLTransform._transform_m for nblk m-blocks in one call: S = B C_sg B^H, N = B C_fg B^H (cl_fg_dev NULL: zero) +
+ * regulariser * max(N) on the diagonal + noise_scale * U diag(npower) U^H, then dm_eigh_gen with the given cut.
+ *   beam_svd_dev (nblk, F, K, P, L), beam_ut_dev (nblk, F, K, T), svnum_host (nblk * F), l0_host (nblk) or NULL
+ *   cl_*_dev (P, P, F, F, L) f64 with masks / symmetry flags as for dm_project_cov; npower_dev (F, T) f64
+ *   noise_scale  1 with `use_thermal`, (1e-3 / Tsys)^2 without (kltransform.py:292-296)
+ *   outputs as dm_eigh_gen (block b of the modes at evecs_dev + off_host[b], (ndof_b x ndof_b), rows = modes)
+ * Synchronises.  Replaces: drift/core/kltransform.py:258-355 (sn_covariance + _transform_m). */
+int dm_kl_m(dm_ctx* ctx, int nblk, int F, int K, int P, int L, int T, const void* beam_svd_dev, const void* beam_ut_dev,
+            const int* svnum_host, const int* l0_host, const double* cl_sg_dev, const int* sg_mask_host, int sg_symmetric,
+            const double* cl_fg_dev, const int* fg_mask_host, int fg_symmetric, const double* npower_dev, double noise_scale,
+            double regulariser, int cut_mode, double cut_value, double* evals_dev, const int64_t* evoff_host, void* evecs_dev,
+            const int64_t* off_host, double* add_const_host, int* nkeep_host);
+
+/* DoubleKL._transform_m for nblk m-blocks in one call: stage 1 diagonalises S against N with the thermal term at
+ * floor_scale = (1e-3 / Tsys)^2 and keeps the modes with eigenvalue > foreground_threshold; stage 2 diagonalises the full
+ * S, N (thermal term at 1) inside that subspace; the composed modes E2 . E1[kept] are returned.
+ *   f_evals_dev  ndof_b stage-1 eigenvalues at evoff_host[b]
+ *   evals_dev    the nmodes_host[b] stage-2 eigenvalues at evoff_host[b]
+ *   modes_dev    (nmodes_b x ndof_b) at off_host[b]; with cut_mode 1 the rows below the cut are zero and
+ *                nkeep_host[b] (may be NULL) counts the rows formed
+ *   add_const_host  the stage-1 rescue shift, the one the reference stores (doublekl.py:58)
+ * Synchronises.  Replaces: drift/core/doublekl.py:30-87 (without `inverse`). */
+int dm_doublekl_m(dm_ctx* ctx, int nblk, int F, int K, int P, int L, int T, const void* beam_svd_dev, const void* beam_ut_dev,
+                  const int* svnum_host, const int* l0_host, const double* cl_sg_dev, const int* sg_mask_host, int sg_symmetric,
+                  const double* cl_fg_dev, const int* fg_mask_host, int fg_symmetric, const double* npower_dev,
+                  double floor_scale, double regulariser, double foreground_threshold, int cut_mode, double cut_value,
+                  double* f_evals_dev, double* evals_dev, const int64_t* evoff_host, void* modes_dev, const int64_t* off_host,
+                  int* nmodes_host, int* nkeep_host, double* add_const_host);
+
 /* Exact per-m Fisher matrices of the band powers for nblk m-blocks:
  *   C_a = E (B C_l^a B^H) E^H,  F[a][b] = sum_ij C_a[i][j] C_b[j][i] / ((lam_i + 1)(lam_j + 1)).
  *   beam_svd_dev, svnum_host, l0_host   as for dm_project_cov

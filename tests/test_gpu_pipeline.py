@@ -155,6 +155,53 @@ def test_doublekl(setup):
         assert (flags == "Normal") == (float(g[pre + "ac"]) == 0.0)
 
 
+def test_one_call_c_drivers_match_the_classes(setup):
+    """dm_kl_m / dm_doublekl_m (the one-call drivers of include/driftmi.h for hosts without the Python layer) against
+    KLTransform / DoubleKL, which compose the same entry points one by one."""
+    import torch
+
+    from driftscan_amd import device
+    from driftscan_amd.beamtransfer import BeamTransfer
+
+    g, bt, mlist = setup
+    kls = _kl_objects(g, bt)
+    ctx = device.get_context()
+    prods = [bt._dev_products(mi) for mi in mlist]
+    bsvd = torch.stack([p["beam_svd"] for p in prods])
+    but = torch.stack([p["beam_ut"] for p in prods])
+    svnum = np.stack([bt._svd_num(mi)[0] for mi in mlist])
+    kl, dk = kls["kl"], kls["dk"]
+    cl_sg, m_sg, s_sg = BeamTransfer._cl_device(kl.signal())
+    cl_fg, m_fg, s_fg = BeamTransfer._cl_device(kl.foreground())
+    npw = ctx.to_device(kl._npower(1.0))
+    # ---- KLTransform
+    ref = kl._transform_batch(mlist, to_host=True)
+    ev, evoff, E, off, ac, nk = ctx.kl_m(bsvd, but, svnum, np.array(mlist), cl_sg, m_sg, s_sg, cl_fg, m_fg, s_fg, npw, 1.0,
+                                         kl._foreground_regulariser, cut=("upper", kl.threshold))
+    evh, Eh = ev.cpu().numpy(), E.cpu().numpy()
+    for i, mi in enumerate(mlist):
+        n = int(svnum[i].sum())
+        assert np.abs(evh[evoff[i] : evoff[i] + n] - ref[i][0]).max() <= 1e-12 * np.abs(ref[i][0]).max()
+        assert np.abs(Eh[off[i] : off[i] + n * n].reshape(n, n) - ref[i][1]).max() <= 1e-9 * np.abs(ref[i][1]).max()
+        assert int(nk[i]) == n - int(np.searchsorted(ref[i][0], kl.threshold)) and ac[i] == ref[i][3]["ac"]
+    # ---- DoubleKL
+    refd = dk._transform_batch(mlist, to_host=True)
+    nc1 = (1e-3 / bt.telescope.tsys_flat) ** 2
+    fev, ev2, evoff, M, off, nm, nk2, ac1 = ctx.doublekl_m(bsvd, but, svnum, np.array(mlist), cl_sg, m_sg, s_sg, cl_fg, m_fg, s_fg,
+                                                          npw, nc1, dk._foreground_regulariser, dk.foreground_threshold,
+                                                          cut=("upper", dk.threshold))
+    fevh, ev2h, Mh = fev.cpu().numpy(), ev2.cpu().numpy(), M.cpu().numpy()
+    for i, mi in enumerate(mlist):
+        n = int(svnum[i].sum())
+        e_ref, m_ref, _, ex = refd[i]
+        assert int(nm[i]) == e_ref.size and ac1[i] == ex["ac"]
+        assert np.abs(fevh[evoff[i] : evoff[i] + n] - ex["f_evals"]).max() <= 1e-12 * np.abs(ex["f_evals"]).max()
+        if e_ref.size:
+            r = e_ref.size
+            assert np.abs(ev2h[evoff[i] : evoff[i] + r] - e_ref).max() <= 1e-11 * np.abs(e_ref).max()
+            assert np.abs(Mh[off[i] : off[i] + r * n].reshape(r, n) - m_ref).max() <= 1e-8 * np.abs(m_ref).max()
+
+
 def test_inverse_and_asymmetric_covariance(golden_dir, tmp_path):
     """`inverse: Yes` for KLTransform and DoubleKL on the device (N E^H instead of an LU inversion per m,
     kltransform.py:124-143, :346-347; doublekl.py:63-67, :83-85) and a sky covariance that is NOT symmetric
