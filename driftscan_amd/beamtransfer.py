@@ -578,6 +578,54 @@ class BeamTransferFullSVD(BeamTransfer):
         return res
 
 
+class BeamTransferTempSVD(BeamTransfer):
+    """The old temperature-only compression (beamtransfer.py:1458-1593): ONE economy SVD of the noise-weighted
+    temperature block per (m, frequency); its left vectors project every polarisation (`beam_svd = U^H w B`), no
+    polarisation null space is removed.  On the device: one-sided block-Jacobi on `[w B | I_T]` with the Gram columns
+    restricted to the temperature block — the accumulated row mixing is U^H, the polarised columns and the identity
+    ride along as passengers — then the pseudo-inverse of the full `beam_svd` as in `invbeam_m` (a second pass on
+    `[beam_svd | I]` and one grouped ZGEMM with the 1/sigma^2 weights; scipy's pinv cut rtol = max(M, N) eps)."""
+
+    def svd_device(self, beam_blocks, skip_svd_inv=False):
+        import torch
+
+        ctx = get_context()
+        nblk, F = int(beam_blocks.shape[0]), int(beam_blocks.shape[1])
+        T, P, L, K = self.ntel, self.telescope.num_pol_sky, self.telescope.lmax + 1, self.svd_len
+        S = P * L
+        nw = ctx.to_device(self._noisew())                                  # (F, T)
+        Z = torch.zeros((nblk, F, T, S + T), dtype=torch.complex128, device=beam_blocks.device)
+        Z[..., :S] = beam_blocks.reshape(nblk, F, T, S) * nw[None, :, :, None]
+        Z[..., S:] = torch.eye(T, dtype=torch.complex128, device=Z.device)
+        sigma, sweeps = ctx.jacobi_rows(Z, T, S + T, 0, L, S + T, stride=T * (S + T), batch=nblk * F)   # Gram over pol 0
+        sg = sigma.reshape(nblk, F, T)[..., :K]
+        beam_svd = Z[:, :, :K, :S].contiguous()                             # U^H (w B): rows sorted by descending sigma
+        beam_ut = (Z[:, :, :K, S:] * nw[None, :, None, :]).contiguous()     # U^H diag(w)  (beamtransfer.py:1562)
+        out = dict(beam_svd=beam_svd.reshape(nblk, F, K, P, L), beam_ut=beam_ut, singularvalues=sg.contiguous(),
+                   invbeam_svd=None, sweeps=[0, 0, sweeps, 0])
+        ctx.sync()
+        out["nmodes"] = (sg > 0).sum(dim=-1).cpu().numpy()
+        if not skip_svd_inv:
+            # pinv of the (K x S) projected beam: rows orthogonalised over ALL sky columns, pinv = (S V^H)^H S^-2 W
+            Y = torch.zeros((nblk, F, K, S + K), dtype=torch.complex128, device=Z.device)
+            Y[..., :S] = beam_svd
+            Y[..., S:] = torch.eye(K, dtype=torch.complex128, device=Z.device)
+            s2, sw2 = ctx.jacobi_rows(Y, K, S + K, 0, S, S + K, stride=K * (S + K), batch=nblk * F)
+            ctx.sync()
+            s2h = s2.reshape(nblk * F, K).cpu().numpy()
+            smax = s2h.max(axis=1, keepdims=True)
+            cut = max(K, S) * np.finfo(np.float64).eps * smax
+            wts = np.where((s2h > cut) & (s2h > 0.0), 1.0 / np.where(s2h > 0.0, s2h, 1.0) ** 2, 0.0)
+            dW = ctx.to_device(np.ascontiguousarray(wts))
+            ib = ctx.empty((nblk * F, S, K), np.complex128)
+            Yf = Y.reshape(nblk * F, K, S + K)
+            ctx.zgemm(Yf, Yf[:, :, S:], ib, S, K, K, rsA=1, csA=S + K, rsB=S + K, csB=1, ldc=K, conjA=True, kscale=dW,
+                      batch=nblk * F, strideA=K * (S + K), strideB=K * (S + K), strideC=S * K, stride_kscale=K)
+            out["invbeam_svd"] = ib.reshape(nblk, F, P, L, K)
+            out["sweeps"][3] = sw2
+        return out
+
+
 class BeamTransferNoSVD(BeamTransfer):
     """No SVD compression: the "SVD basis" is the telescope basis itself, ndof = nfreq * ntel
     (beamtransfer.py:1736-1968).  The batched device paths of the KL transform see the

@@ -518,6 +518,24 @@ def gen_bt_variants(ref):
         svd = read_svd_file(bt, mi)
         for k, v in svd.items():
             out["fullsvd_m%d_%s" % (mi, k)] = v
+    # ---- TempSVD, polarised: one SVD of the temperature part per frequency, every polarisation carried along
+    F, B, P, lmax, seed = 2, 4, 4, 8, 4103
+    rng = np.random.default_rng(seed)
+    L = lmax + 1
+    redundancy = rng.integers(1, 6, size=B).astype(np.float64)
+    npower = (2.5e-7 * (1.0 + 0.1 * np.arange(F))[:, None] / redundancy[None, :]).astype(np.float64)
+    tel = FakeTelescope(F, B, P, lmax, lmax, npower, tsys_flat=1.0)
+    bt = btmod.BeamTransferTempSVD("/mem/tempsvd/bt", telescope=tel)
+    out.update(tempsvd_dims=np.array([F, B, P, lmax]), tempsvd_npower=npower)
+    for mi in range(lmax + 1):
+        beam = synth_beam_m(rng, F, B, P, L, mi, polrank=None, polscale=0.3)
+        write_beam_file(ref, bt, mi, beam)
+        out["tempsvd_m%d_beam_m" % mi] = beam
+    bt._generate_svdfiles()
+    for mi in range(lmax + 1):
+        svd = read_svd_file(bt, mi)
+        for k, v in svd.items():
+            out["tempsvd_m%d_%s" % (mi, k)] = v
     np.savez_compressed(os.path.join(OUT, "bt_variants.npz"), **out)
     print("bt_variants.npz")
 

@@ -1,5 +1,5 @@
-"""GPU parity of BeamTransferNoSVD and BeamTransferFullSVD against outputs of
-the unmodified reference classes (tests/golden/bt_variants.npz)."""
+"""GPU parity of BeamTransferNoSVD, BeamTransferFullSVD and BeamTransferTempSVD against
+outputs of the unmodified reference classes (tests/golden/bt_variants.npz)."""
 import os
 
 import numpy as np
@@ -84,3 +84,40 @@ def test_fullsvd_products(golden_dir, tmp_path):
             assert relerr(U.conj().T @ U, Ur.conj().T @ Ur) < 1e-9
             ib = bt.invbeam_svd(mi)[fi].reshape(-1, bs.shape[1])[:, :n]
             assert np.abs(X @ ib - np.eye(n)).max() < 1e-7
+
+
+def test_tempsvd_products(golden_dir, tmp_path):
+    """BeamTransferTempSVD (beamtransfer.py:1458-1593): SVD of the temperature block only, all polarisations projected."""
+    from driftscan_amd import beamtransfer
+
+    g = np.load(os.path.join(golden_dir, "bt_variants.npz"))
+    F, B, P, lmax = (int(x) for x in g["tempsvd_dims"])
+    ms = list(range(lmax + 1))
+    tel, bt = _make(beamtransfer.BeamTransferTempSVD, g, "tempsvd", tmp_path, ms)
+    assert bt.svd_len == min(lmax + 1, 2 * B)
+    bt._my_ms = lambda mlist_=None: ms
+    bt._generate_svdfiles(regen=True)
+    L = lmax + 1
+    for mi in ms:
+        pre = "tempsvd_m%d_" % mi
+        sv, ref_sv = bt.beam_singularvalues(mi), g[pre + "singularvalues"]
+        assert sv.shape == ref_sv.shape
+        assert np.abs(sv - ref_sv).max() < 1e-10 * max(ref_sv.max(), 1e-300)
+        bs, ref_bs = bt.beam_svd(mi), g[pre + "beam_svd"]
+        but, ref_but = bt.beam_ut(mi), g[pre + "beam_ut"]
+        ib = bt.invbeam_svd(mi)
+        assert bs.shape == ref_bs.shape and but.shape == ref_but.shape and ib.shape == g[pre + "invbeam_svd"].shape
+        for fi in range(F):
+            n = int((ref_sv[fi] > 1e-10 * ref_sv[fi].max()).sum()) if ref_sv[fi].max() > 0 else 0
+            if n == 0:
+                continue
+            X, Xr = bs[fi, :n].reshape(n, -1), ref_bs[fi, :n].reshape(n, -1)
+            assert relerr(X.conj().T @ X, Xr.conj().T @ Xr) < 1e-9           # gauge-free: rows up to phases
+            U, Ur = but[fi, :n], ref_but[fi, :n]
+            assert relerr(U.conj().T @ U, Ur.conj().T @ Ur) < 1e-9
+            # the temperature block carries the singular values
+            assert np.abs(np.linalg.norm(bs[fi, :n, 0, :], axis=1) - ref_sv[fi, :n]).max() < 1e-10 * ref_sv[fi].max()
+            # pseudo-inverse of the whole projected beam: the same operator as the reference's la.pinv
+            Pi, Pr = ib[fi].reshape(-1, bs.shape[1]) @ bs[fi].reshape(bs.shape[1], -1), \
+                g[pre + "invbeam_svd"][fi].reshape(-1, bs.shape[1]) @ ref_bs[fi].reshape(bs.shape[1], -1)
+            assert relerr(Pi, Pr) < 1e-7
