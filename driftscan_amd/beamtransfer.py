@@ -587,29 +587,31 @@ class BeamTransferTempSVD(BeamTransfer):
     `[beam_svd | I]` and one grouped ZGEMM with the 1/sigma^2 weights; scipy's pinv cut rtol = max(M, N) eps)."""
 
     def svd_device(self, beam_blocks, skip_svd_inv=False):
-        import torch
-
         ctx = get_context()
         nblk, F = int(beam_blocks.shape[0]), int(beam_blocks.shape[1])
         T, P, L, K = self.ntel, self.telescope.num_pol_sky, self.telescope.lmax + 1, self.svd_len
         S = P * L
-        nw = ctx.to_device(self._noisew())                                  # (F, T)
-        Z = torch.zeros((nblk, F, T, S + T), dtype=torch.complex128, device=beam_blocks.device)
-        Z[..., :S] = beam_blocks.reshape(nblk, F, T, S) * nw[None, :, :, None]
-        Z[..., S:] = torch.eye(T, dtype=torch.complex128, device=Z.device)
+        # the augmented matrices are assembled on the host (this variant is off the hot path; torch only moves memory)
+        nwh = self._noisew()                                                # (F, T)
+        Zh = np.zeros((nblk, F, T, S + T), dtype=np.complex128)
+        Zh[..., :S] = beam_blocks.cpu().numpy().reshape(nblk, F, T, S) * nwh[None, :, :, None]
+        Zh[..., S:] = np.eye(T)
+        Z = ctx.to_device(Zh)
         sigma, sweeps = ctx.jacobi_rows(Z, T, S + T, 0, L, S + T, stride=T * (S + T), batch=nblk * F)   # Gram over pol 0
-        sg = sigma.reshape(nblk, F, T)[..., :K]
-        beam_svd = Z[:, :, :K, :S].contiguous()                             # U^H (w B): rows sorted by descending sigma
-        beam_ut = (Z[:, :, :K, S:] * nw[None, :, None, :]).contiguous()     # U^H diag(w)  (beamtransfer.py:1562)
-        out = dict(beam_svd=beam_svd.reshape(nblk, F, K, P, L), beam_ut=beam_ut, singularvalues=sg.contiguous(),
-                   invbeam_svd=None, sweeps=[0, 0, sweeps, 0])
         ctx.sync()
-        out["nmodes"] = (sg > 0).sum(dim=-1).cpu().numpy()
+        Zh = Z.cpu().numpy()
+        sgh = sigma.cpu().numpy().reshape(nblk, F, T)[..., :K]
+        bsvd_h = np.ascontiguousarray(Zh[:, :, :K, :S])                     # U^H (w B): rows sorted by descending sigma
+        but_h = np.ascontiguousarray(Zh[:, :, :K, S:] * nwh[None, :, None, :])   # U^H diag(w)  (beamtransfer.py:1562)
+        out = dict(beam_svd=ctx.to_device(bsvd_h).reshape(nblk, F, K, P, L), beam_ut=ctx.to_device(but_h),
+                   singularvalues=ctx.to_device(np.ascontiguousarray(sgh)), invbeam_svd=None, sweeps=[0, 0, sweeps, 0])
+        out["nmodes"] = (sgh > 0).sum(axis=-1)
         if not skip_svd_inv:
             # pinv of the (K x S) projected beam: rows orthogonalised over ALL sky columns, pinv = (S V^H)^H S^-2 W
-            Y = torch.zeros((nblk, F, K, S + K), dtype=torch.complex128, device=Z.device)
-            Y[..., :S] = beam_svd
-            Y[..., S:] = torch.eye(K, dtype=torch.complex128, device=Z.device)
+            Yh = np.zeros((nblk, F, K, S + K), dtype=np.complex128)
+            Yh[..., :S] = bsvd_h
+            Yh[..., S:] = np.eye(K)
+            Y = ctx.to_device(Yh)
             s2, sw2 = ctx.jacobi_rows(Y, K, S + K, 0, S, S + K, stride=K * (S + K), batch=nblk * F)
             ctx.sync()
             s2h = s2.reshape(nblk * F, K).cpu().numpy()
