@@ -83,6 +83,7 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
             cols = order[c0 : c0 + ncol_max]
             # distinct (frequency, beam class) beams of this chunk
             keys = {}
+            feed_of = {}
             bi = np.empty(cols.size, dtype=np.int32)
             bj = np.empty(cols.size, dtype=np.int32)
             for k, c in enumerate(cols):
@@ -91,11 +92,18 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
                     key = (int(f_list[c]), int(cls[feed]))
                     if key not in keys:
                         keys[key] = len(keys)
+                        feed_of[key] = int(feed)
                     which[k] = keys[key]
             ncomp = 2 if pol else 1
             beams = ctx.empty((len(keys), npix * ncomp), np.float64)
             for (f, bc), idx in keys.items():
-                kind, tab, fwhm_ns = tel.beam_spec(bc, f)
+                spec = tel.beam_spec(bc, f)
+                if spec is None:
+                    # the reference's plug-in interface: beam(feed, freq) evaluated by the telescope class on the
+                    # host (telescope.py:954-973 keys the maps by beam class as here), uploaded once
+                    beams[idx].copy_(ctx.to_device(tel._beam_host(feed_of[(f, bc)], f, int(nside)).reshape(-1)))
+                    continue
+                kind, tab, fwhm_ns = spec
                 ctx.bt_beam_cyl(int(nside), cth, sth, frame, kind, tab, fwhm_ns, beams[idx])
             uv = tel.baselines[b_list[cols]] / wl[f_list[cols]][:, None]
             if fused:

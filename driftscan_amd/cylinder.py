@@ -91,11 +91,13 @@ class CylinderTelescope(telescope.TransitTelescope):
     def v_width(self):
         return 0.0
 
-    def _pair_mask(self):
-        d, mask = super(CylinderTelescope, self)._pair_mask()
+    def _unique_baselines(self):
+        base_map, base_mask = super(CylinderTelescope, self)._unique_baselines()
         if not self.in_cylinder:
-            mask = mask & (d[..., 0] != 0.0)  # drop pairs on the same cylinder (cylinder.py:72-109)
-        return d, mask
+            d, _ = self._separations()
+            base_mask = base_mask & (d[..., 0] != 0.0)  # drop pairs on the same cylinder (cylinder.py:72-109)
+            base_map = telescope._label_keys(base_map, base_mask)
+        return base_map, base_mask
 
     @property
     def cylinder_spacing(self):
@@ -125,11 +127,35 @@ class CylinderTelescope(telescope.TransitTelescope):
         width E-W and the H-plane width N-S; Y swaps them (cylbeam.py:150-212)."""
         raise NotImplementedError
 
+    def _pattern_host(self, kind, fwhm_ew, fwhm_ns, freq_index):
+        """The cylinder field pattern on the pixels of ``self._nside`` as a host array — (npix,) for kind 0,
+        (npix, 2) otherwise — evaluated by the device kernel (``dm_bt_beam_cyl``) and copied back: what the
+        reference's ``beam`` / ``beamx`` / ``beamy`` return (cylinder.py:171-218), times the horizon mask.
+        For the subclasses that modify the cylinder beam on the host (restricted / perturbed cylinders)."""
+        from . import btgen, healpix
+        from .device import get_context
+
+        if self._nside is None:
+            raise RuntimeError("call _init_trans(nside) first")
+        ctx = get_context()
+        nside = int(self._nside)
+        cth, sth = healpix.ring_trig(nside)
+        ncomp = 1 if kind == 0 else 2
+        out = ctx.empty((healpix.npix(nside) * ncomp,), np.float64)
+        width = self.cylinder_width / self.wavelengths[freq_index]
+        ctx.bt_beam_cyl(nside, cth, sth, btgen.telescope_frame(self.zenith), kind, fraunhofer_table(fwhm_ew, width),
+                        fwhm_ns, out)
+        h = out.cpu().numpy()
+        return h if kind == 0 else h.reshape(-1, 2)
+
 
 class UnpolarisedCylinderTelescope(CylinderTelescope, telescope.SimpleUnpolarisedTelescope):
     def beam_spec(self, beamclass, freq_index):
         width = self.cylinder_width / self.wavelengths[freq_index]
         return 0, fraunhofer_table(self.fwhm_h, width), self.fwhm_h  # cylinder.py:171-194
+
+    def beam(self, feed, freq):
+        return self._pattern_host(0, self.fwhm_h, self.fwhm_h, freq)
 
 
 class PolarisedCylinderTelescope(CylinderTelescope, telescope.SimplePolarisedTelescope):
@@ -138,3 +164,9 @@ class PolarisedCylinderTelescope(CylinderTelescope, telescope.SimplePolarisedTel
         if beamclass % 2 == 0:  # X feed: beam_x(width, fwhm_e, fwhm_h)
             return 1, fraunhofer_table(self.fwhm_e, width), self.fwhm_h
         return 2, fraunhofer_table(self.fwhm_h, width), self.fwhm_e  # Y feed: widths swapped
+
+    def beamx(self, feed, freq):
+        return self._pattern_host(1, self.fwhm_e, self.fwhm_h, freq)
+
+    def beamy(self, feed, freq):
+        return self._pattern_host(2, self.fwhm_h, self.fwhm_e, freq)

@@ -30,6 +30,18 @@ def npix(nside):
     return 12 * nside * nside
 
 
+def ang_positions(nside):
+    """(npix, 2) pixel centres (theta, phi) in RING order (cora.util.hputil.ang_positions = healpy.pix2ang):
+    the sky positions a telescope class's host-side ``beam(feed, freq)`` is evaluated on."""
+    nphi, phi0, start = ring_layout(nside)
+    theta = np.arccos(ring_z(nside))
+    out = np.empty((npix(nside), 2))
+    out[:, 0] = np.repeat(theta, nphi)
+    j = np.arange(npix(nside)) - np.repeat(start, nphi)
+    out[:, 1] = np.repeat(phi0, nphi) + 2.0 * np.pi * j / np.repeat(nphi, nphi)
+    return out
+
+
 # ---- sky maps <-> spherical harmonics for the consumers of the operators (timestream simulation, map-making) ----
 # cora.util.hputil.sphtrans_sky / sphtrans_inv_sky (drift/pipeline/timestream.py:262, :295, :451, :717) are not
 # available; these restate them on the equal-weight HEALPix quadrature of the rest of the package.  The forward

@@ -29,6 +29,39 @@ def max_lm(baselines, wavelengths, uwidth, vwidth=0.0):
     return lmax, mmax
 
 
+def sph_to_cart(sph):
+    """Unit vectors of (theta, phi) positions (cora.util.coord.sph_to_cart on two-column input)."""
+    sph = np.asarray(sph, dtype=np.float64)
+    st = np.sin(sph[..., 0])
+    return np.stack([st * np.cos(sph[..., 1]), st * np.sin(sph[..., 1]), np.cos(sph[..., 0])], axis=-1)
+
+
+def sph_dot(a, b):
+    """Cosine of the angle between (theta, phi) positions (cora.util.coord.sph_dot)."""
+    return np.sum(sph_to_cart(a) * sph_to_cart(b), axis=-1)
+
+
+def _label_keys(keys, mask):
+    """Integer labels 0.. of the distinct values of `keys` among the entries selected by `mask` (in sorted
+    order of the values: complex keys sort on the real part first), -1 elsewhere (telescope.py:66-79)."""
+    keys = np.asarray(keys)
+    out = np.full(keys.shape, -1, dtype=np.int64)
+    sel = np.nonzero(np.ones(keys.shape, dtype=bool) if mask is None else mask)
+    if sel[0].size:
+        out[sel] = np.asarray(np.unique(keys[sel], return_inverse=True)[1]).reshape(-1)
+    return out
+
+
+def _representatives(labels, mask, ngrp):
+    """(i, j) of the first pair in row-major order carrying each label among `mask` (telescope.py:82-96)."""
+    flat = np.nonzero(mask.ravel())[0]
+    _, first = np.unique(labels.ravel()[flat], return_index=True)
+    if first.size != ngrp:
+        raise ValueError("a baseline group has no member with the stored orientation")
+    rep = flat[first]
+    return rep // labels.shape[1], rep % labels.shape[1]
+
+
 class TransitTelescope(config.Reader):
     """Base class; subclasses provide ``feedpositions``, ``beamclass``, ``u_width``,
     ``v_width`` and the beam description consumed by ``btgen``."""
@@ -131,79 +164,83 @@ class TransitTelescope(config.Reader):
     def num_pol_sky(self):
         return self._npol_sky_
 
-    def _pair_mask(self):
-        """Which ordered feed pairs take part (telescope.py:556-594)."""
+    def _separations(self):
+        """(d, blen): separation vectors and lengths of every ordered feed pair."""
         pos = self.feedpositions
         d = pos[:, None, :] - pos[None, :, :]
-        blen = np.sqrt(np.sum(d**2, axis=-1))
+        return d, np.sqrt(np.sum(d**2, axis=-1))
+
+    # The three hooks below are the reference's plug-in points for telescope classes
+    # (telescope.py:556-626): integer label maps over the (nfeed, nfeed) pair grid plus masks.
+    def _unique_baselines(self):
+        """(label map of equal separations, mask of the pairs taking part)."""
+        d, blen = self._separations()
+        key = np.around(d[..., 0] + 1.0j * d[..., 1], self._bl_tol)
         mask = (blen >= self.minlength) & (blen <= self.maxlength)
         if not self.auto_correlations:
             mask &= blen > 0.0
-            mask &= ~np.eye(self.nfeed, dtype=bool)
-        return d, mask
+        return _label_keys(key, mask), mask
+
+    def _unique_beams(self):
+        """(label map of equal (class_i, class_j), mask: everything but the diagonal unless auto_correlations)."""
+        cls = np.asarray(self.beamclass)
+        lab = _label_keys(cls[:, None] + 1.0j * cls[None, :], None)
+        mask = np.ones((self.nfeed, self.nfeed), dtype=bool) if self.auto_correlations else ~np.eye(self.nfeed, dtype=bool)
+        return lab, mask
+
+    def _get_unique(self):
+        """(feedmap, feedmask, feedconj) before orientation and ordering: pairs with the same separation and
+        the same beam classes are one baseline, a pair and its transpose share the label and one of the two
+        is marked as the conjugate."""
+        base, bmask = self._unique_baselines()
+        beam, cmask = self._unique_beams()
+        mask = bmask & cmask
+        comb = _label_keys(base + 1.0j * beam, mask)
+        conj = comb > comb.T
+        comb = _label_keys(np.minimum(comb, comb.T), mask)
+        return comb, mask, conj
 
     def calculate_feedpairs(self):
         """Group feed pairs into unique baselines (telescope.py:507-675).
 
-        Two ordered pairs are the same baseline when their separations agree to
-        ``_bl_tol`` decimals and their (class_i, class_j) agree; a pair and its
-        transpose are conjugates.  The stored orientation points East (or due North),
-        baselines are ordered lexicographically in (u, v, class_j, class_i), the
-        representative pair of a baseline is its first member in row-major (i, j)
-        order and the redundancy counts the members with the stored orientation.
+        ``_get_unique`` labels the pairs; the stored orientation of a baseline is then made to point East (or
+        due North), baselines are ordered lexicographically in (u, v, class_j, class_i) of their representative
+        pair — the first member with the stored orientation in row-major (i, j) order — and the redundancy
+        counts the members with the stored orientation.
         """
         pos = self.feedpositions
         cls = np.asarray(self.beamclass)
-        nf = self.nfeed
-        d, mask = self._pair_mask()
-        dr = np.around(d, self._bl_tol) + 0.0  # +0.0 folds -0.0 into 0.0
-        ii, jj = np.nonzero(mask)
-        dx, dy = dr[ii, jj, 0], dr[ii, jj, 1]
-        ci, cj = cls[ii], cls[jj]
-        east = (dx > 0.0) | ((dx == 0.0) & (dy > 0.0))
-        zero = (dx == 0.0) & (dy == 0.0)
-        canonical = east | (zero & (ci <= cj))
-        # key of the stored orientation for every participating pair
-        kx = np.where(canonical, dx, -dx) + 0.0
-        ky = np.where(canonical, dy, -dy) + 0.0
-        ka = np.where(canonical, ci, cj)
-        kb = np.where(canonical, cj, ci)
-        keys = np.stack([kx, ky, ka.astype(np.float64), kb.astype(np.float64)], axis=1)
-        uniq, inv = np.unique(keys, axis=0, return_inverse=True)
-        inv = np.asarray(inv).reshape(-1)
-        ngrp = uniq.shape[0]
-        # representative = first canonical member in row-major order
-        flat = ii * nf + jj
-        rep = np.full(ngrp, -1, dtype=np.int64)
-        count = np.zeros(ngrp, dtype=np.int64)
-        order = np.argsort(flat, kind="stable")
-        for idx in order:
-            if canonical[idx]:
-                g = inv[idx]
-                count[g] += 1
-                if rep[g] < 0:
-                    rep[g] = flat[idx]
-        ri, rj = rep // nf, rep % nf
-        # sort on the unrounded separation of the representative, then (class_j, class_i)
-        bx = pos[ri, 0] - pos[rj, 0]
-        by = pos[ri, 1] - pos[rj, 1]
+        feedmap, mask, conj = self._get_unique()
+        feedmap = np.array(feedmap, dtype=np.int64)
+        mask = np.asarray(mask, dtype=bool)
+        conj = np.asarray(conj, dtype=bool)
+        ngrp = int(feedmap[mask].max()) + 1 if mask.any() else 0
+
+        # orientation: flip the groups whose representative points West (or due South)
+        ri, rj = _representatives(feedmap, mask & ~conj, ngrp)
+        sep = pos[ri] - pos[rj]
+        west = (sep[:, 0] < 0.0) | ((sep[:, 0] == 0.0) & (sep[:, 1] < 0.0))
+        flip = np.zeros(feedmap.shape, dtype=bool)
+        flip[mask] = west[feedmap[mask]]
+        conj = conj ^ flip
+
+        # order on the unrounded separation of the (new) representative, then (class_j, class_i)
+        ri, rj = _representatives(feedmap, mask & ~conj, ngrp)
         sort_arr = np.zeros(ngrp, dtype=np.dtype("f8,f8,i4,i4"))
-        sort_arr["f0"], sort_arr["f1"], sort_arr["f2"], sort_arr["f3"] = bx, by, cls[rj], cls[ri]
+        sort_arr["f0"], sort_arr["f1"] = pos[ri, 0] - pos[rj, 0], pos[ri, 1] - pos[rj, 1]
+        sort_arr["f2"], sort_arr["f3"] = cls[rj], cls[ri]
         perm = np.argsort(sort_arr)
         newlabel = np.empty(ngrp, dtype=np.int64)
         newlabel[perm] = np.arange(ngrp)
+        feedmap[mask] = newlabel[feedmap[mask]]
 
-        feedmap = -np.ones((nf, nf), dtype=np.int64)
-        feedmap[ii, jj] = newlabel[inv]
-        feedconj = np.zeros((nf, nf), dtype=bool)
-        feedconj[ii, jj] = ~canonical
-        uniquepairs = np.stack([ri[perm], rj[perm]], axis=1)
+        uniquepairs = np.stack([ri[perm], rj[perm]], axis=1).reshape(-1, 2)
         self._pairs = dict(
             feedmap=feedmap,
             feedmask=mask,
-            feedconj=feedconj,
+            feedconj=conj,
             uniquepairs=uniquepairs,
-            redundancy=count[perm],
+            redundancy=np.bincount(feedmap[mask & ~conj], minlength=ngrp),
             baselines=pos[uniquepairs[:, 0]] - pos[uniquepairs[:, 1]],
         )
 
@@ -275,6 +312,49 @@ class TransitTelescope(config.Reader):
         noisepower = self.tsys(f_indices) ** 2 / (2 * np.pi * delnu * ndays)
         return noisepower / self.redundancy[bl_indices]
 
+    # ---- beams --------------------------------------------------------------------
+    # A telescope class describes its primary beams in one of two ways:
+    #   * ``beam_spec(beamclass, freq)`` -> (kind, spline table, fwhm_ns): evaluated per pixel ON THE DEVICE
+    #     (``dm_bt_beam_cyl``; the cylinder classes), or
+    #   * the reference's plug-in interface (telescope.py:943-952, :1136, :1399-1447): ``beam(feed, freq)``
+    #     (``beamx`` / ``beamy`` for polarised classes) returning the field pattern on ``self._angpos`` as a host
+    #     array — [npix] amplitudes, or [npix, 2] (theta, phi) components.  ``btgen`` uploads one such map per
+    #     (frequency, beam class) and the device does the rest.
+    _nside = None
+    _angpos = None
+    _horizon = None
+
+    def beam_spec(self, beamclass, freq_index):
+        return None
+
+    def _init_trans(self, nside):
+        """Pixel centres and horizon mask of a HEALPix resolution (telescope.py:943-952)."""
+        from . import healpix
+
+        self._nside = int(nside)
+        self._angpos = healpix.ang_positions(self._nside)
+        # drift/core/visibility.py:27-46: signbit(-n . zenith), the hemisphere above the horizon
+        self._horizon = np.signbit(-sph_dot(self._angpos, self.zenith))
+
+    def beam(self, feed, freq):
+        raise NotImplementedError("%s defines neither beam_spec() nor beam()" % type(self).__name__)
+
+    def _beam_host(self, feed, freq_index, nside):
+        """float64 field pattern of `feed` at a frequency on the pixels of `nside`, zero below the horizon:
+        (npix,) for an unpolarised telescope, (npix, 2) for a polarised one."""
+        if self._nside != int(nside) or self._angpos is None:
+            self._init_trans(nside)
+        b = np.asarray(self.beam(feed, freq_index))
+        if np.iscomplexobj(b):
+            if np.any(b.imag != 0.0):
+                raise NotImplementedError("complex field patterns (the device beams are real)")
+            b = b.real
+        want = (self._angpos.shape[0],) if self.num_pol_sky == 1 else (self._angpos.shape[0], 2)
+        if b.shape != want:
+            raise ValueError("beam(%d, %d) returned shape %r, expected %r" % (feed, freq_index, b.shape, want))
+        hz = self._horizon.astype(np.float64)
+        return np.ascontiguousarray(b.astype(np.float64) * (hz if b.ndim == 1 else hz[:, None]))
+
     # ---- transfer matrices ------------------------------------------------------
     def transfer_matrices(self, bl_indices, f_indices, global_lmax=True):
         """(nfb, P, lside+1, 2*lside+1) a_lm of the requested (baseline, frequency) pairs,
@@ -333,3 +413,13 @@ class SimplePolarisedTelescope(PolarisedTelescope):
     @property
     def feedpositions(self):
         return np.concatenate((self._single_feedpositions, self._single_feedpositions))
+
+    def beam(self, feed, freq):
+        """Field pattern of a feed: ``beamx`` for the X feeds, ``beamy`` for the Y feeds (telescope.py:1399-1403)."""
+        return self.beamx(feed, freq) if self.polarisation[feed] == "X" else self.beamy(feed, freq)
+
+    def beamx(self, feed, freq):
+        raise NotImplementedError
+
+    def beamy(self, feed, freq):
+        raise NotImplementedError

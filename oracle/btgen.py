@@ -427,6 +427,7 @@ def beam_transfer_m(tel, mlist=None):
       polarised (bool), zenith (2,), baselines (B,2), uniquepairs (B,2), beamclass (nfeed,),
       wavelengths (F,), cylinder_width, fwhm_e, fwhm_h, lmax, mmax, l_boost,
       included_freq, included_baseline, accuracy_boost
+      and optionally u_width, v_width, beam_fn(feed, freq_index, angpos) for non-cylinder telescope classes
 
     Returns {m: (F, 2, B, P, L) complex128} with the reference's ``beam_m`` layout
     (zero for l < m and for skipped frequencies / baselines).
@@ -442,7 +443,8 @@ def beam_transfer_m(tel, mlist=None):
     geo = {}
     for f in tel["included_freq"]:
         for b in tel["included_baseline"]:
-            lm, _ = max_lm(tel["baselines"][b : b + 1], tel["wavelengths"][f], tel["cylinder_width"], 0.0)
+            lm, _ = max_lm(tel["baselines"][b : b + 1], tel["wavelengths"][f], tel.get("u_width", tel.get("cylinder_width")),
+                           tel.get("v_width", 0.0))
             lmax_bf = int(np.ceil(tel.get("l_boost", 1.0) * lm[0]))
             nside = nside_for_lmax(lmax_bf, tel.get("accuracy_boost", 1) if not pol else 1)
             if nside not in geo:
@@ -453,6 +455,10 @@ def beam_transfer_m(tel, mlist=None):
             beams = []
             for feed in (fi, fj):
                 key = (nside, f, int(tel["beamclass"][feed]))
+                if key not in cache and "beam_fn" in tel:
+                    # any other telescope class: beam_fn(feed, freq index, angpos) is the class's beam() restated
+                    # by the caller (telescope.py:954-973 caches by beam class like this)
+                    cache[key] = np.asarray(tel["beam_fn"](int(feed), int(f), ap))
                 if key not in cache:
                     width = tel["cylinder_width"] / tel["wavelengths"][f]
                     if not pol:

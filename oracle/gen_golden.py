@@ -351,6 +351,74 @@ def gen_pixel_kernels(ref):
     print("pixel_kernels.npz")
 
 
+def _telescope_cases(ref):
+    """(name, constructor) of the reference's other telescope classes (drift/telescope/*.py, examples/disharray)."""
+    import importlib
+
+    T = {n: importlib.import_module("drift.telescope." + n) for n in ["gmrt", "restrictedcylinder", "exotic_cylinder"]}
+    exdir = os.path.join(refimport.REFROOT, "examples", "disharray")
+    if exdir not in sys.path:
+        sys.path.insert(0, exdir)
+    import simplearray
+
+    band = dict(num_freq=3, freq_start=400.0, freq_end=450.0, freq_mode="edge", tsys=1.0)
+    cyl = dict(band, num_cylinders=2, num_feeds=4, cylinder_width=5.0, feed_spacing=0.5)
+    return [
+        ("gmrt", lambda: T["gmrt"].GmrtUnpolarised(pointing=5.0), dict(pointing=5.0)),
+        ("restricted_box", lambda c: T["restrictedcylinder"].RestrictedCylinder.from_config(c), dict(cyl, beam_height=40.0)),
+        ("restricted_pol_gauss", lambda c: T["restrictedcylinder"].RestrictedPolarisedCylinder.from_config(c),
+         dict(cyl, beam_type="gaussian", beam_height=25.0)),
+        ("restricted_extra", lambda c: T["restrictedcylinder"].RestrictedExtra.from_config(c),
+         dict(cyl, extra_feeds=[-1.3, -2.9])),
+        ("random", lambda c: T["exotic_cylinder"].RandomCylinder.from_config(c), dict(cyl)),
+        ("gradient", lambda c: T["exotic_cylinder"].GradientCylinder.from_config(c), dict(cyl, max_spacing=6.0)),
+        ("extra", lambda c: T["exotic_cylinder"].CylinderExtra.from_config(c), dict(cyl, extra_feeds=[-1.3])),
+        ("perturbed", lambda c: T["exotic_cylinder"].CylinderPerturbed.from_config(c), dict(cyl, num_feeds=3)),
+        ("dish_pol", lambda c: simplearray.DishArray.from_config(c), dict(freq_mode="edge", tsys=1.0)),   # the example's band (100-150 MHz, 5 channels) and 4 x 4 grid are class attributes
+    ]
+
+
+def gen_telescopes(ref):
+    """Geometry, host beams and visibility-response maps (before the spherical-harmonic transform, which is
+    unpinned) of the reference's non-cylinder / modified-cylinder telescope classes.  ``_init_trans`` needs
+    healpy's pix2ang through cora: the pixel centres are supplied by the oracle's restatement instead."""
+    from oracle import btgen as obt
+
+    vis = ref["visibility"]
+    out = {}
+    nside = 16
+    ap = obt.ang_positions(nside)
+    names = []
+    for name, make, cfg in _telescope_cases(ref):
+        t = make() if name == "gmrt" else make(cfg)
+        names.append(name)
+        out[name + "_cfg_keys"] = np.array(sorted(cfg.keys()))
+        out[name + "_cfg_vals"] = np.array([repr(cfg[k]) for k in sorted(cfg.keys())])
+        for attr in ("feedpositions", "beamclass", "uniquepairs", "baselines", "redundancy", "feedmap", "feedmask",
+                     "feedconj", "frequencies", "zenith"):
+            out[name + "_" + attr] = np.asarray(getattr(t, attr))
+        out[name + "_lmax"], out[name + "_mmax"] = t.lmax, t.mmax
+        out[name + "_npol"] = t.num_pol_sky
+        bl = np.arange(t.nbase)
+        out[name + "_noisepower"] = np.array([np.asarray(t.noisepower(bl, fi)).reshape(-1) for fi in range(t.nfreq)])
+        t._nside, t._angpos = nside, ap
+        t._horizon = vis.horizon(ap, t.zenith)
+        classes = np.unique(t.beamclass)
+        feeds = np.array([int(np.nonzero(t.beamclass == c)[0][0]) for c in classes])
+        out[name + "_beam_feeds"] = feeds
+        out[name + "_beams"] = np.array([t.beam(int(fd), 1) for fd in feeds])
+        rng = np.random.default_rng(11)
+        bsel = np.sort(rng.choice(t.nbase, size=min(6, t.nbase), replace=False))
+        out[name + "_map_bl"] = bsel
+        out[name + "_maps"] = np.array([t._beam_map_single(int(b), 1) for b in bsel])
+        print(name, type(t).__name__, "nfeed", t.nfeed, "nbase", t.nbase, "lmax", t.lmax, "npol", t.num_pol_sky,
+              "maps", out[name + "_maps"].shape)
+    out["names"] = np.array(names)
+    out["nside"] = nside
+    np.savez_compressed(os.path.join(OUT, "telescopes.npz"), **out)
+    print("telescopes.npz")
+
+
 FGT_UNPOL, FGT_POL, THR_POL = 1.0, 1e-2, 1e-3
 
 
@@ -596,6 +664,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "inverse":
         gen_inverse(ref)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "telescopes":
+        gen_telescopes(ref)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "variants":
         gen_bt_variants(ref)
         return
@@ -622,6 +693,7 @@ def main():
                seed=2001, fg_threshold=1.0, threshold=0.1, fg_amp=10.0)
     gen_psfisher(ref)
     gen_inverse(ref)
+    gen_telescopes(ref)
 
 
 if __name__ == "__main__":
