@@ -50,8 +50,8 @@ CPU_SAMPLE_M = (0, 32, 64, 96)
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--mode", choices=["weak", "sharded"], default="weak")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo + --one-gpu rehearses the multi-rank path on a single card (RCCL refuses two ranks per GPU)")

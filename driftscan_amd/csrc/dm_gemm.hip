@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, 3) void zgemm_grouped_kernel(const dm_gemm_des
 //   rotation s (s = 0..3) pairs row block g with column block g' = (g + s) & 3, so four instructions cover a
 //   16x16 tile; D of rotation s lands in lane 16 i + 4 g + j = C[4 g + i][4 ((g + s) & 3) + j].
 // The rotated B operands are the rotation-0 registers moved by DPP row_ror inside each 16-lane row (same k).
-template <bool B_REAL, bool B_GATHER>
+template <bool B_REAL, bool B_GATHER, int PD>
 __global__ __launch_bounds__(256, 2) void zgemm4_grouped_kernel(const dm_gemm_desc* __restrict__ descs,
                                                                 const dm_gemm_tile* __restrict__ tiles, int ntiles) {
   const int bid = dm_xcd_remap(blockIdx.x, ntiles);
@@ -300,63 +300,51 @@ __global__ __launch_bounds__(256, 2) void zgemm4_grouped_kernel(const dm_gemm_de
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc_re[i][j][s] = acc_im[i][j][s] = 0.0;
 
-  struct frag { cplx a[2], b[2]; };
-  // tiles that lie inside the matrix with nothing to scale take the lean loader: no masks, no multiplies
+  // Operands travel as RAW loads: no arithmetic touches a fragment before its compute step, so the loads of step
+  // t + 1 stay in flight under the 64 MFMAs of step t (an `s_waitcnt` lands wherever the first use is — conjugation
+  // signs, masks and scale factors are therefore applied at compute time).
+  struct raw { cplx a[2], b[2]; double ks, kb[2]; };
+  // tiles that lie inside the matrix with nothing to scale take the lean steps: no masks, no scale loads
   const bool plain = !d.kscale && !B_GATHER && mrow + 32 <= d.M && ncol + 32 <= d.N;
-  auto load = [&](int k0) {
-    frag f;
-    const int kk = k0 + k;
-    const bool kv = kk < d.K;
-    const int kc = min(kk, d.K - 1);
-    if (plain && k0 + 4 <= d.K) {
+  auto load_lean = [&](int k0) {
+    raw f;
+    const size_t kk = (size_t)(k0 + k);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const cplx v = dm_ldg(A, aoff[i] + (size_t)kc * d.csA);
-        f.a[i] = make_double2(v.x, v.y * sa);
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (B_REAL) {
-          f.b[j] = make_double2(dm_ldg(Br, (size_t)kc * d.rsB + boff[j]), 0.0);
-        } else {
-          const cplx v = dm_ldg(Bc, boff[j] + (size_t)kc * d.rsB);
-          f.b[j] = make_double2(v.x, v.y * sb);
-        }
-      }
-      return f;
-    }
-    const double ks = (d.kscale && !B_GATHER) ? dm_ldg(d.kscale, kc) : 1.0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      cplx v = dm_ldg(A, aoff[i] + (size_t)kc * d.csA);
-      const double m = (kv && aok[i]) ? ks : 0.0;
-      f.a[i] = make_double2(v.x * m, v.y * m * sa);
-    }
+    for (int i = 0; i < 2; ++i) f.a[i] = dm_ldg(A, aoff[i] + kk * d.csA);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      cplx v;
-      if (B_REAL) {
-        v = make_double2(dm_ldg(Br, (size_t)kc * d.rsB + boff[j]), 0.0);
-      } else {
-        v = dm_ldg(Bc, boff[j] + (size_t)kc * d.rsB);
-      }
-      double m = (kv && bok[j]) ? 1.0 : 0.0;
-      if (B_GATHER) m *= dm_ldg(d.kscale, ksoff[j] + kc);
-      f.b[j] = make_double2(v.x * m, v.y * m * sb);
+      if (B_REAL) f.b[j] = make_double2(dm_ldg(Br, kk * d.rsB + boff[j]), 0.0);
+      else f.b[j] = dm_ldg(Bc, boff[j] + kk * d.rsB);
     }
+    f.ks = 1.0;
+    f.kb[0] = f.kb[1] = 1.0;
     return f;
   };
-  auto compute = [&](const frag& f) {
+  auto load_gen = [&](int k0) {
+    raw f;
+    const size_t kc = (size_t)min(k0 + k, d.K - 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) f.a[i] = dm_ldg(A, aoff[i] + kc * d.csA);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (B_REAL) f.b[j] = make_double2(dm_ldg(Br, kc * d.rsB + boff[j]), 0.0);
+      else f.b[j] = dm_ldg(Bc, boff[j] + kc * d.rsB);
+      f.kb[j] = B_GATHER ? dm_ldg(d.kscale, ksoff[j] + kc) : 1.0;
+    }
+    f.ks = (d.kscale && !B_GATHER) ? dm_ldg(d.kscale, kc) : 1.0;
+    return f;
+  };
+  auto mfmas = [&](const cplx (&fa)[2], const cplx (&fb)[2]) {
     double bre[2][4], bim[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      bre[j][0] = f.b[j].x;
-      bim[j][0] = f.b[j].y;
+      bre[j][0] = fb[j].x;
+      bim[j][0] = fb[j].y;
       // rotation s needs the operand of the lane 4 s further along its 16-lane row: row_ror:n hands lane i the
       // value of lane (i - n) mod 16, so "4 s further" is a rotation by 16 - 4 s (checked against the LDS kernel)
-      bre[j][1] = dm_dpp_f64<0x12C>(f.b[j].x); bim[j][1] = dm_dpp_f64<0x12C>(f.b[j].y);
-      bre[j][2] = dm_dpp_f64<0x128>(f.b[j].x); bim[j][2] = dm_dpp_f64<0x128>(f.b[j].y);
-      bre[j][3] = dm_dpp_f64<0x124>(f.b[j].x); bim[j][3] = dm_dpp_f64<0x124>(f.b[j].y);
+      bre[j][1] = dm_dpp_f64<0x12C>(fb[j].x); bim[j][1] = dm_dpp_f64<0x12C>(fb[j].y);
+      bre[j][2] = dm_dpp_f64<0x128>(fb[j].x); bim[j][2] = dm_dpp_f64<0x128>(fb[j].y);
+      bre[j][3] = dm_dpp_f64<0x124>(fb[j].x); bim[j][3] = dm_dpp_f64<0x124>(fb[j].y);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -365,30 +353,92 @@ __global__ __launch_bounds__(256, 2) void zgemm4_grouped_kernel(const dm_gemm_de
         if (!(tile_i[i] && tile_j[j])) continue;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          acc_re[i][j][s] = dm_mfma4(f.a[i].x, bre[j][s], acc_re[i][j][s]);
-          acc_im[i][j][s] = dm_mfma4(f.a[i].x, bim[j][s], acc_im[i][j][s]);
+          acc_re[i][j][s] = dm_mfma4(fa[i].x, bre[j][s], acc_re[i][j][s]);
+          acc_im[i][j][s] = dm_mfma4(fa[i].x, bim[j][s], acc_im[i][j][s]);
         }
         if (!B_REAL) {
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            acc_re[i][j][s] = dm_mfma4(-f.a[i].y, bim[j][s], acc_re[i][j][s]);
-            acc_im[i][j][s] = dm_mfma4(f.a[i].y, bre[j][s], acc_im[i][j][s]);
+            acc_re[i][j][s] = dm_mfma4(-fa[i].y, bim[j][s], acc_re[i][j][s]);
+            acc_im[i][j][s] = dm_mfma4(fa[i].y, bre[j][s], acc_im[i][j][s]);
           }
         } else {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc_im[i][j][s] = dm_mfma4(f.a[i].y, bre[j][s], acc_im[i][j][s]);
+          for (int s = 0; s < 4; ++s) acc_im[i][j][s] = dm_mfma4(fa[i].y, bre[j][s], acc_im[i][j][s]);
         }
       }
   };
-  const int nk = (d.K + 3) / 4;
-  if (nk > 0) {
-    frag cur = load(0);
-    for (int kt = 0; kt + 1 < nk; ++kt) {
-      const frag nxt = load((kt + 1) * 4);   // in flight under the MFMAs of this step
-      compute(cur);
-      cur = nxt;
+  auto compute_lean = [&](const raw& f) {
+    cplx fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[i] = make_double2(f.a[i].x, f.a[i].y * sa);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = make_double2(f.b[j].x, f.b[j].y * sb);
+    mfmas(fa, fb);
+  };
+  auto compute_gen = [&](const raw& f, int k0) {
+    const bool kv = k0 + k < d.K;
+    cplx fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool on = kv && aok[i];
+      fa[i] = on ? make_double2(f.a[i].x * f.ks, f.a[i].y * f.ks * sa) : make_double2(0.0, 0.0);
     }
-    compute(cur);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool on = kv && bok[j];
+      fb[j] = on ? make_double2(f.b[j].x * f.kb[j], f.b[j].y * f.kb[j] * sb) : make_double2(0.0, 0.0);
+    }
+    mfmas(fa, fb);
+  };
+  if (plain) {
+    const int nfull = d.K / 4;
+    if (PD == 1) {
+      // one step ahead: 144 VGPRs, three waves per SIMD — the better trade for short K and ragged tiles
+      if (nfull > 0) {
+        raw cur = load_lean(0);
+        for (int kt = 0; kt + 1 < nfull; ++kt) {
+          const raw nxt = load_lean((kt + 1) * 4);  // in flight under the MFMAs of this step
+          compute_lean(cur);
+          cur = nxt;
+        }
+        compute_lean(cur);
+      }
+    } else if (nfull == 1) {
+      compute_lean(load_lean(0));
+    } else if (nfull > 1) {
+      // two steps of operands in flight, three buffers rotating through an unrolled-by-three loop (no copies):
+      // 184 VGPRs, two waves per SIMD — +3-4 % on K >= 512, -5-8 % on K = 64..128
+      raw b0 = load_lean(0), b1 = load_lean(4), b2;
+      int t = 0;
+      for (; t + 5 <= nfull; t += 3) {
+        b2 = load_lean((t + 2) * 4);
+        compute_lean(b0);
+        b0 = load_lean((t + 3) * 4);
+        compute_lean(b1);
+        b1 = load_lean((t + 4) * 4);
+        compute_lean(b2);
+      }
+      const int rem = nfull - t;  // 2, 3 or 4 steps left; b0, b1 hold the first two
+      if (rem >= 3) b2 = load_lean((t + 2) * 4);
+      compute_lean(b0);
+      if (rem >= 4) b0 = load_lean((t + 3) * 4);
+      compute_lean(b1);
+      if (rem >= 3) compute_lean(b2);
+      if (rem >= 4) compute_lean(b0);
+    }
+    if (nfull * 4 < d.K) compute_gen(load_gen(nfull * 4), nfull * 4);
+  } else {
+    const int nk = (d.K + 3) / 4;
+    if (nk > 0) {
+      raw cur = load_gen(0);
+      for (int kt = 0; kt + 1 < nk; ++kt) {
+        const raw nxt = load_gen((kt + 1) * 4);
+        compute_gen(cur, kt * 4);
+        cur = nxt;
+      }
+      compute_gen(cur, (nk - 1) * 4);
+    }
   }
   // epilogue: lane 16 i' + 4 g + j' of rotation s holds C[4 g + i'][4 ((g + s) & 3) + j']
   cplx* __restrict__ C = reinterpret_cast<cplx*>(d.C);
@@ -595,6 +645,12 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
   dm_gemm_tile* const dt_g = dtiles + n0 + n1 + n2;
   if (!tiles.empty()) {
     dm_gemm_tile* dt = dt_c;
+    // deep operand prefetch (two waves per SIMD) pays on long inner dimensions only
+    static const int deep_env = getenv("DM_GEMM4_DEEP") ? atoi(getenv("DM_GEMM4_DEEP")) : -1;
+    int kmin_c = 1 << 30;
+    for (const auto& d : descs)
+      if (d.M > 0 && d.N > 0 && !(d.flags & (DM_GEMM_ALL_REAL | DM_GEMM_B_REAL | DM_GEMM_B_GATHER))) kmin_c = std::min(kmin_c, d.K);
+    const bool deep = deep_env >= 0 ? deep_env != 0 : kmin_c >= 512;
     static const bool log = getenv("DM_GEMM_LOG") != nullptr;  // debugging aid: per-launch shape and rate
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (log) {
@@ -605,8 +661,12 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
     {
       dm_prof_scope ps(ctx, DM_PROF_GEMM, fl_c);
       if (use4)
-        hipLaunchKernelGGL((zgemm4_grouped_kernel<false, false>), dim3((unsigned)tiles.size()), dim3(256), 0, ctx->stream, dd,
-                           dt, (int)tiles.size());
+        if (deep)
+          hipLaunchKernelGGL((zgemm4_grouped_kernel<false, false, 2>), dim3((unsigned)tiles.size()), dim3(256), 0, ctx->stream,
+                             dd, dt, (int)tiles.size());
+        else
+          hipLaunchKernelGGL((zgemm4_grouped_kernel<false, false, 1>), dim3((unsigned)tiles.size()), dim3(256), 0, ctx->stream,
+                             dd, dt, (int)tiles.size());
       else
         hipLaunchKernelGGL((zgemm_grouped_kernel<false, false>), dim3((unsigned)tiles.size()), dim3(256), 0, ctx->stream, dd,
                            dt, (int)tiles.size());
@@ -635,7 +695,7 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
     dm_gemm_tile* dt = dt_g;
     dm_prof_scope ps(ctx, DM_PROF_GEMM, fl_g);
     if (use4)
-      hipLaunchKernelGGL((zgemm4_grouped_kernel<false, true>), dim3((unsigned)tiles_gat.size()), dim3(256), 0, ctx->stream,
+      hipLaunchKernelGGL((zgemm4_grouped_kernel<false, true, 1>), dim3((unsigned)tiles_gat.size()), dim3(256), 0, ctx->stream,
                          dd, dt, (int)tiles_gat.size());
     else
       hipLaunchKernelGGL((zgemm_grouped_kernel<false, true>), dim3((unsigned)tiles_gat.size()), dim3(256), 0, ctx->stream,
@@ -645,7 +705,7 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
     dm_gemm_tile* dt = dt_r;
     dm_prof_scope ps(ctx, DM_PROF_GEMM_REAL, fl_r);
     if (use4)
-      hipLaunchKernelGGL((zgemm4_grouped_kernel<true, false>), dim3((unsigned)tiles_real.size()), dim3(256), 0, ctx->stream,
+      hipLaunchKernelGGL((zgemm4_grouped_kernel<true, false, 1>), dim3((unsigned)tiles_real.size()), dim3(256), 0, ctx->stream,
                          dd, dt, (int)tiles_real.size());
     else
       hipLaunchKernelGGL((zgemm_grouped_kernel<true, false>), dim3((unsigned)tiles_real.size()), dim3(256), 0, ctx->stream,

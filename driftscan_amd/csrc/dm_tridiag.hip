@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 // The panel width is a compile-time constant of the kernels (LDS arrays, T-factor layout): the body is
@@ -47,6 +48,11 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
   int maxn = 0;
   for (const auto& p : probs) maxn = std::max(maxn, p.n);
   int width = maxn <= 2048 ? 32 : 64;
+  if (getenv("DM_TRD_SIZES")) {  // debugging aid: the batch composition
+    fprintf(stderr, "[dm_herm_eig_tridiag] %zu problems, n =", probs.size());
+    for (const auto& p : probs) fprintf(stderr, " %d", p.n);
+    fprintf(stderr, "\n");
+  }
   if (const char* e = getenv("DM_TRD_PANEL")) width = atoi(e) == 64 ? 64 : 32;
   return width == 32 ? dm_trd32::herm_eig_tridiag(ctx, probs, evals, evals_stride, sel)
                      : dm_trd64::herm_eig_tridiag(ctx, probs, evals, evals_stride, sel);

@@ -25,3 +25,8 @@ run(1024, 1024, 64, 128)
 run(1024, 1024, 64, 128, "NC")
 run(92, 92, 129, 4096, "NC")
 run(32, 1024, 512, 128)
+run(4096, 4096, 128, 4)
+run(128, 4096, 4096, 4)
+run(4096, 1024, 128, 8)
+run(92, 4989, 413, 64, "NC")
+run(128, 4989, 413, 64, "NC")
