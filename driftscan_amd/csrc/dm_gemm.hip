@@ -351,20 +351,23 @@ __global__ __launch_bounds__(256, 2) void zgemm4_grouped_kernel(const dm_gemm_de
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if (!(tile_i[i] && tile_j[j])) continue;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          acc_re[i][j][s] = dm_mfma4(fa[i].x, bre[j][s], acc_re[i][j][s]);
-          acc_im[i][j][s] = dm_mfma4(fa[i].x, bim[j][s], acc_im[i][j][s]);
-        }
         if (!B_REAL) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            acc_re[i][j][s] = dm_mfma4(fa[i].x, bre[j][s], acc_re[i][j][s]);
+            acc_im[i][j][s] = dm_mfma4(fa[i].x, bim[j][s], acc_im[i][j][s]);
+          }
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             acc_re[i][j][s] = dm_mfma4(-fa[i].y, bim[j][s], acc_re[i][j][s]);
             acc_im[i][j][s] = dm_mfma4(fa[i].y, bre[j][s], acc_im[i][j][s]);
           }
-        } else {
+        } else {  // real B: two products per output block, not four
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc_im[i][j][s] = dm_mfma4(fa[i].y, bre[j][s], acc_im[i][j][s]);
+          for (int s = 0; s < 4; ++s) {
+            acc_re[i][j][s] = dm_mfma4(fa[i].x, bre[j][s], acc_re[i][j][s]);
+            acc_im[i][j][s] = dm_mfma4(fa[i].y, bre[j][s], acc_im[i][j][s]);
+          }
         }
       }
   };

@@ -51,7 +51,11 @@ struct trd_mat {
 #define DM_SYC 2
 #endif
 constexpr int SYR = DM_SYR;     // rows per wave in trd_symv
-constexpr int SYG = 4 * SYR;  // rows per workgroup = rows behind one partial row of Pc
+#ifndef DM_SYW
+#define DM_SYW 4
+#endif
+constexpr int SYW = DM_SYW;     // waves per workgroup in trd_symv
+constexpr int SYG = SYW * SYR;  // rows per workgroup = rows behind one partial row of Pc
 constexpr int SYC = DM_SYC;        // 64-column chunks per loop iteration of trd_symv
 constexpr int WXR = 64;    // rows per workgroup in trd_wx
 
@@ -96,7 +100,7 @@ __device__ __forceinline__ cplx trd_v_at(const trd_mat& M, const trd_refl& R, in
   return c == k + 1 ? make_double2(1.0, 0.0) : t;
 }
 
-__global__ __launch_bounds__(256) void trd_symv_kernel(const trd_mat* __restrict__ ms, int k, int j) {
+__global__ __launch_bounds__(64 * SYW) void trd_symv_kernel(const trd_mat* __restrict__ ms, int k, int j) {
   const trd_mat M = ms[blockIdx.y];
   const int n = M.n;
   if (k >= n - 1) return;
@@ -105,13 +109,13 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const trd_mat* __restrict
   // the panel dot products take SLV vectors per wave: v is formed once per element and reused
   constexpr int SLV = 4;
   const int nslot = (2 * j + SLV - 1) / SLV;
-  const int nslotblk = (nslot + 3) / 4;
+  const int nslotblk = (nslot + SYW - 1) / SYW;
   if ((int)blockIdx.x >= nslotblk && k + 1 + SYG * ((int)blockIdx.x - nslotblk) >= n) return;  // no rows left
-  if ((int)blockIdx.x < nslotblk && (int)blockIdx.x * 4 + wave >= nslot) return;
+  if ((int)blockIdx.x < nslotblk && (int)blockIdx.x * SYW + wave >= nslot) return;
   if ((int)blockIdx.x < nslotblk) {
     const trd_refl R = trd_reflector(M, k);
     // a[q] = W_q^H v, b[q] = V_q^H v (needed by trd_wx); vector index q < j: W_q, else V_{q-j}
-    const int q0 = (blockIdx.x * 4 + wave) * SLV;
+    const int q0 = (blockIdx.x * SYW + wave) * SLV;
     const cplx* xs[SLV];
 #pragma unroll
     for (int u = 0; u < SLV; ++u) {
@@ -143,8 +147,8 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const trd_mat* __restrict
   const int g = blockIdx.x - nslotblk;
   const int R0 = k + 1 + SYG * g;
   if (R0 >= n) return;
-  __shared__ cplx colbuf[2][SYC][4][64];
-  __shared__ double sbuf[4];
+  __shared__ cplx colbuf[2][SYC][SYW][64];
+  __shared__ double sbuf[SYW];
   const int rstart = R0 + SYR * wave;
   const int dl = SYR * wave;  // lane of this wave's first diagonal element in chunk 0
   const cplx* __restrict__ A = M.A;
@@ -208,9 +212,12 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const trd_mat* __restrict
     }
     colbuf[0][0][wave][lane] = col;
     __syncthreads();
-    if (wave == 0 && valid)
-      dm_stg(pc, c,
-             cadd(cadd(colbuf[0][0][0][lane], colbuf[0][0][1][lane]), cadd(colbuf[0][0][2][lane], colbuf[0][0][3][lane])));
+    if (wave == 0 && valid) {
+      cplx tsum = colbuf[0][0][0][lane];
+#pragma unroll
+      for (int w = 1; w < SYW; ++w) tsum = cadd(tsum, colbuf[0][0][w][lane]);
+      dm_stg(pc, c, tsum);
+    }
     t = 1;
   }
   // main loop: SYC chunks (64 SYC columns) per iteration -> SYC * SYR row loads in flight per lane;
@@ -249,9 +256,12 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const trd_mat* __restrict
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < SYC; ++u)
-      if (wave == ((t * SYC + u) & 3) && vld[u])
-        dm_stg(pc, c0 + 64 * u + lane,
-               cadd(cadd(colbuf[pb][u][0][lane], colbuf[pb][u][1][lane]), cadd(colbuf[pb][u][2][lane], colbuf[pb][u][3][lane])));
+      if (wave == ((t * SYC + u) & (SYW - 1)) && vld[u]) {
+        cplx tsum = colbuf[pb][u][0][lane];
+#pragma unroll
+        for (int w = 1; w < SYW; ++w) tsum = cadd(tsum, colbuf[pb][u][w][lane]);
+        dm_stg(pc, c0 + 64 * u + lane, tsum);
+      }
   }
   // Transposing butterfly: the 2 SYR per-lane partial sums are folded so that lane L ends up with
   // the wave total of entry L / PER (2 SYR + log2(PER) shuffles instead of 2 SYR full reductions).
@@ -281,7 +291,12 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const trd_mat* __restrict
   s = dm_wave_sum(s);
   if (lane == 0) sbuf[wave] = s;
   __syncthreads();
-  if (threadIdx.x == 0) M.Sp[g] = (sbuf[0] + sbuf[1]) + (sbuf[2] + sbuf[3]);
+  if (threadIdx.x == 0) {
+    double tsum = 0.0;
+#pragma unroll
+    for (int w = 0; w < SYW; ++w) tsum += sbuf[w];
+    M.Sp[g] = tsum;
+  }
 }
 
 __global__ __launch_bounds__(256) void trd_wx_kernel(const trd_mat* __restrict__ ms, int k, int j, int do_w, int do_x) {
@@ -1746,7 +1761,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
         const int j = k - k0;
         if (k < cmax - 1) {
           const int ng = (cmax - k - 1 + SYG - 1) / SYG;
-          const int nslotblk = ((2 * j + 3) / 4 + 3) / 4;  // 4 vectors per wave, 4 waves per workgroup
+          const int nslotblk = ((2 * j + 3) / 4 + SYW - 1) / SYW;  // 4 vectors per wave, SYW waves per workgroup
           // algorithmic HBM bytes of this column: half of every trailing matrix (symv), one pass over
           // the panel rows of V and W (wx)
           // Timed with events on every DM_PROF_TRD_STRIDE-th column only (event records on a chain of
@@ -1761,7 +1776,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
             }
           hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
           if (timed) { e0 = dm_prof_event(ctx); (void)hipEventRecord(e0, ctx->stream); }
-          hipLaunchKernelGGL(trd_symv_kernel, dim3(nslotblk + ng, nc), dim3(256), 0, ctx->stream, d_tm, k, j);
+          hipLaunchKernelGGL(trd_symv_kernel, dim3(nslotblk + ng, nc), dim3(64 * SYW), 0, ctx->stream, d_tm, k, j);
           hipEvent_t e1b = nullptr;  // a record owns both of its events: end of symv and start of wx are two events
           if (timed) {
             e1 = dm_prof_event(ctx);
