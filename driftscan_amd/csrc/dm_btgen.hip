@@ -231,53 +231,83 @@ __global__ __launch_bounds__(256) void bt_fused_dft_kernel(ring_geo g, frame3 fr
 #pragma unroll
       for (int p = 0; p < P; ++p) acc_re[c][a][p] = acc_im[c][a][p] = 0.0;
 
-  for (int q = 0; q < nphi; q += 4) {
+  // The pixel direction (cos phi_j, sin phi_j) and the twiddles exp(i m phi_j) advance by four pixels per step:
+  // one complex rotation each, re-seeded exactly every FDFT_RS steps (a rotation costs 6 flops against the ~60 of a
+  // sincos plus a 64-bit modulo; the drift over 15 rotations stays below 1e-14, the exact seed bounds it).
+  constexpr int FDFT_RS = 16;
+  double rotp_c, rotp_s;
+  sincos(2.0 * kPi * 4.0 / (double)nphi, &rotp_s, &rotp_c);
+  double rot_re[NMG], rot_im[NMG];
+#pragma unroll
+  for (int a = 0; a < NMG; ++a) {
+    const long long m4 = (4ll * mval[a]) % nphi;
+    sincos(2.0 * kPi * (double)m4 / (double)nphi, &rot_im[a], &rot_re[a]);
+  }
+  double sp = 0.0, cp = 1.0;
+  double tw_re[NMG], tw_im[NMG];
+#pragma unroll
+  for (int a = 0; a < NMG; ++a) tw_re[a] = tw_im[a] = 0.0;
+  int step = 0;
+  for (int q = 0; q < nphi; q += 4, ++step) {
     const int j = q + k;
     const bool pv = j < nphi;
     const int jj = pv ? j : nphi - 1;
-    double sp, cp;
-    sincos(phi0 + 2.0 * kPi * (double)jj / (double)nphi, &sp, &cp);
+    if ((step & (FDFT_RS - 1)) == 0) {
+      sincos(phi0 + 2.0 * kPi * (double)j / (double)nphi, &sp, &cp);
+#pragma unroll
+      for (int a = 0; a < NMG; ++a) {
+        // reduce the argument exactly: m * j mod nphi keeps the phase in [0, 2 pi) (as bt_twiddle_kernel)
+        const long long mj = ((long long)mval[a] * j) % nphi;
+        double s, c;
+        sincos((double)mval[a] * phi0 + 2.0 * kPi * (double)mj / (double)nphi, &s, &c);
+        tw_re[a] = mok[a] ? c : 0.0;
+        tw_im[a] = mok[a] ? s : 0.0;
+      }
+    } else {
+      // explicit rounding order: every instantiation (and therefore every partition of m over ranks) forms the
+      // same bits for a given (m, pixel)
+      const double c2 = __fma_rn(cp, rotp_c, -__dmul_rn(sp, rotp_s));
+      sp = __fma_rn(cp, rotp_s, __dmul_rn(sp, rotp_c));
+      cp = c2;
+#pragma unroll
+      for (int a = 0; a < NMG; ++a) {
+        const double r2 = __fma_rn(tw_re[a], rot_re[a], -__dmul_rn(tw_im[a], rot_im[a]));
+        tw_im[a] = __fma_rn(tw_re[a], rot_im[a], __dmul_rn(tw_im[a], rot_re[a]));
+        tw_re[a] = r2;
+      }
+    }
     const double n0 = st * cp, n1 = st * sp, n2 = ct;
     const double hz = (pv && (n0 * fr.z[0] + n1 * fr.z[1] + n2 * fr.z[2]) > 0.0) ? 1.0 : 0.0;
     if (__ballot(hz != 0.0) == 0ull) continue;  // the whole quad lies below the horizon: every map value is zero
     const double nx = n0 * fr.x[0] + n1 * fr.x[1] + n2 * fr.x[2];
     const double ny = n0 * fr.y[0] + n1 * fr.y[1] + n2 * fr.y[2];
-    double tw_re[NMG], tw_im[NMG];
-#pragma unroll
-    for (int a = 0; a < NMG; ++a) {
-      // reduce the argument exactly: m * j mod nphi keeps the phase in [0, 2 pi) (as bt_twiddle_kernel)
-      const long long mj = ((long long)mval[a] * jj) % nphi;
-      double s, c;
-      sincos((double)mval[a] * phi0 + 2.0 * kPi * (double)mj / (double)nphi, &s, &c);
-      tw_re[a] = mok[a] ? c : 0.0;
-      tw_im[a] = mok[a] ? s : 0.0;
-    }
     const size_t pix = (size_t)pix0 + jj;
 #pragma unroll
     for (int c = 0; c < NCG; ++c) {
       double m_re[P], m_im[P];
       const fdft_col cdc = s_cd[wave][c * 16 + (lane & 15)];
-      if (cdc.bi >= 0 && hz != 0.0) {
-        double sf, cf;
-        sincos(2.0 * kPi * (cdc.u * nx + cdc.v * ny), &sf, &cf);
-        const double tre = cdc.pre * cf, tim = cdc.pre * sf;
-        const double* a = beams + (size_t)cdc.bi * bstride + NCOMP * pix;
-        const double* b = beams + (size_t)cdc.bj * bstride + NCOMP * pix;
-        if constexpr (P == 1) {
-          const double bb = dm_ldg(a) * dm_ldg(b);
-          m_re[0] = tre * bb;
-          m_im[0] = tim * bb;
-        } else {
-          const double a0 = dm_ldg(a), a1 = dm_ldg(a, 1), b0 = dm_ldg(b), b1 = dm_ldg(b, 1);
-          const double sI = a0 * b0 + a1 * b1, sQ = a0 * b0 - a1 * b1, sU = a0 * b1 + a1 * b0, sV = a0 * b1 - a1 * b0;
-          m_re[0] = tre * sI; m_im[0] = tim * sI;
-          m_re[1] = tre * sQ; m_im[1] = tim * sQ;
-          m_re[2] = tre * sU; m_im[2] = tim * sU;
-          m_re[3] = -tim * sV; m_im[3] = tre * sV;  // 1j * fringe * sV
-        }
+      // branch-free: padding columns and pixels below the horizon read beam 0 and are zeroed through `pre`, so the
+      // loads and the sincos of all NCG groups of a quad can be in flight together
+      const bool on = cdc.bi >= 0 && hz != 0.0;
+      const double* a = beams + (size_t)max(cdc.bi, 0) * bstride + NCOMP * pix;
+      const double* b = beams + (size_t)max(cdc.bj, 0) * bstride + NCOMP * pix;
+      // the fringe phase in turns: sincospi reduces 2 t exactly (no large-argument path, no branches), which is
+      // also closer to the true phase than sin(fl(2 pi t)) once |u| reaches hundreds of wavelengths
+      double sf, cf;
+      sincospi(2.0 * (cdc.u * nx + cdc.v * ny), &sf, &cf);
+      const double pre = on ? cdc.pre : 0.0;
+      const double tre = pre * cf, tim = pre * sf;
+      if constexpr (P == 1) {
+        const double bb = dm_ldg(a) * dm_ldg(b);
+        m_re[0] = tre * bb;
+        m_im[0] = tim * bb;
       } else {
-#pragma unroll
-        for (int p = 0; p < P; ++p) m_re[p] = m_im[p] = 0.0;
+        const double a0 = dm_ldg(a), a1 = dm_ldg(a, 1), b0 = dm_ldg(b), b1 = dm_ldg(b, 1);
+        const double sI = a0 * b0 + a1 * b1, sQ = a0 * b0 - a1 * b1, sU = a0 * b1 + a1 * b0, sV = a0 * b1 - a1 * b0;
+        m_re[0] = tre * sI; m_im[0] = tim * sI;
+        m_re[1] = tre * sQ; m_im[1] = tim * sQ;
+        m_re[2] = tre * sU; m_im[2] = tim * sU;
+        m_re[3] = -tim * sV; m_im[3] = tre * sV;  // 1j * fringe * sV
       }
 #pragma unroll
       for (int a = 0; a < NMG; ++a)
@@ -626,6 +656,8 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
     };
     // 32 complex accumulators per lane (64 AGPRs) keep two waves per SIMD: the sincos of one wave runs under
     // the MFMAs of the other
+    // measured: twice / four times the m-values per pass (<4,4,1>, <4,8,1>, <1,8,2>, <1,16,1>) halve the repeated
+    // synthesis but cost a wave per SIMD — no faster on configs[1] or configs[2]
     if (polarised) {
       if (nmg <= 1) launch(bt_fused_dft_kernel<4, 1, 4>, 1, 4);
       else launch(bt_fused_dft_kernel<4, 2, 2>, 2, 2);
