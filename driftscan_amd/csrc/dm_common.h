@@ -31,6 +31,7 @@ struct dm_ctx {
   char* hpin = nullptr;
   size_t hpin_cap = 0;
   size_t hpin_used = 0;  // ring offset (per context: contexts may be driven from different threads)
+  char* hpin_dl = nullptr;  // page-locked landing buffer of dm_download (allocated on first use)
   std::string err;
   // optional per-kernel-class timing (HIP events on ctx->stream) and flop accounting
   bool prof_on = false;

@@ -99,10 +99,28 @@ int dm_upload(dm_ctx* ctx, void* dst, const void* src, size_t bytes) {
   return DM_OK;
 }
 
+// Device -> host through a page-locked landing buffer: the callers hand in pageable memory (std::vector), for which
+// the runtime stages small copies itself at several hundred microseconds apiece — and every one of these calls sits
+// on the critical path (ranks, eigenvalues, status words the host decides on).
 int dm_download(dm_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return DM_OK;
-  DM_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  constexpr size_t kLand = 8u << 20;
+  if (!ctx->hpin_dl) {
+    void* hp = nullptr;
+    if (hipHostMalloc(&hp, kLand, hipHostMallocDefault) == hipSuccess) ctx->hpin_dl = reinterpret_cast<char*>(hp);
+    else (void)hipGetLastError();
+  }
+  if (!ctx->hpin_dl) {
+    DM_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DM_OK;
+  }
+  for (size_t off = 0; off < bytes; off += kLand) {
+    const size_t n = std::min(kLand, bytes - off);
+    DM_HIP(ctx, hipMemcpyAsync(ctx->hpin_dl, static_cast<const char*>(src) + off, n, hipMemcpyDeviceToHost, ctx->stream));
+    DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(static_cast<char*>(dst) + off, ctx->hpin_dl, n);
+  }
   return DM_OK;
 }
 
@@ -200,6 +218,7 @@ int dm_ctx_destroy(dm_ctx* ctx) {
   for (void* p : ctx->retired) (void)hipFree(p);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->hpin) (void)hipHostFree(ctx->hpin);
+  if (ctx->hpin_dl) (void)hipHostFree(ctx->hpin_dl);
   if (ctx->prof_dev) (void)hipFree(ctx->prof_dev);
   for (auto& r : ctx->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
