@@ -255,13 +255,25 @@ class BeamTransfer(config.Reader):
                        for fi in range(tel.nfreq)])
         return np.concatenate([nw, nw], axis=1)
 
+    def _noisew_device(self):
+        """The noise weights on the device, uploaded once per context: a pageable host-to-device copy waits for the
+        stream to drain, which would serialise every batch behind the previous one's kernels."""
+        ctx = get_context()
+        key = id(ctx)
+        cache = self.__dict__.setdefault("_noisew_dev", {})
+        if key not in cache:
+            if len(cache) > 8:
+                cache.clear()
+            cache[key] = ctx.to_device(self._noisew())
+        return cache[key]
+
     def svd_device(self, beam_blocks, skip_svd_inv=False):
         """Run the SVD chain on a device tensor (nblk, F, 2, B, P, L); returns the dict of
         device products (see Context.svd_chain)."""
         ctx = get_context()
         nblk, F = int(beam_blocks.shape[0]), int(beam_blocks.shape[1])
         T, P, L = self.ntel, self.telescope.num_pol_sky, self.telescope.lmax + 1
-        nw = ctx.to_device(self._noisew())
+        nw = self._noisew_device()
         return ctx.svd_chain(beam_blocks.reshape(nblk, F, T, P, L), nw, self.polsvcut, skip_svd_inv=skip_svd_inv)
 
     def _generate_svdfiles(self, regen=False, skip_svd_inv=False):
@@ -569,7 +581,7 @@ class BeamTransferFullSVD(BeamTransfer):
         ctx = get_context()
         nblk, F = int(beam_blocks.shape[0]), int(beam_blocks.shape[1])
         T, P, L = self.ntel, self.telescope.num_pol_sky, self.telescope.lmax + 1
-        nw = ctx.to_device(self._noisew())
+        nw = self._noisew_device()
         res = ctx.svd_chain(beam_blocks.reshape(nblk, F, T, 1, P * L), nw, self.polsvcut, skip_svd_inv=skip_svd_inv)
         K = int(res["beam_svd"].shape[2])
         res["beam_svd"] = res["beam_svd"].reshape(nblk, F, K, P, L)

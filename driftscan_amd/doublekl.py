@@ -70,7 +70,7 @@ class DoubleKL(kltransform.KLTransform):
         but = torch.stack([bt._dev_products(mi)["beam_ut"] for mi in ms])
         svnum = np.stack([bt._svd_num(mi)[0] for mi in ms])
         if self.use_thermal:  # always true here; spelled out to mirror sn_covariance
-            ctx.project_diag(but, svnum, ctx.to_device(self._npower(1.0)), N2, off, alpha=1.0 - nc1, accumulate=True)
+            ctx.project_diag(but, svnum, self._npower_device(1.0), N2, off, alpha=1.0 - nc1, accumulate=True)
         n2 = np.array([keep[i] for i in live], dtype=np.int64)
         off2, tot2 = block_offsets(n2)
         rn = np.array([keep[i] * ndofs[i] for i in live], dtype=np.int64)

@@ -94,6 +94,17 @@ class KLTransform(config.Reader):
         return nc * np.asarray(tel.noisepower(bl[np.newaxis, :], np.arange(tel.nfreq)[:, np.newaxis])).reshape(
             tel.nfreq, self.beamtransfer.ntel)
 
+    def _npower_device(self, nc):
+        """_npower(nc) on the device, uploaded once per (context, nc) — see BeamTransfer._noisew_device."""
+        ctx = get_context()
+        key = (id(ctx), float(nc))
+        cache = self.__dict__.setdefault("_npower_dev", {})
+        if key not in cache:
+            if len(cache) > 8:
+                cache.clear()
+            cache[key] = ctx.to_device(self._npower(nc))
+        return cache[key]
+
     def sn_covariance_device(self, ms):
         """Signal and noise covariances of several m at once, left on the device.
         Returns (S, N, ndofs, off): flat complex buffers with block b at off[b]."""
@@ -118,7 +129,7 @@ class KLTransform(config.Reader):
 
         but = torch.stack([bt._dev_products(mi)["beam_ut"] for mi in ms])
         svnum = np.stack([bt._svd_num(mi)[0] for mi in ms])
-        ctx.project_diag(but, svnum, ctx.to_device(self._npower(nc)), N, off, alpha=1.0, accumulate=True)
+        ctx.project_diag(but, svnum, self._npower_device(nc), N, off, alpha=1.0, accumulate=True)
         return S, N, ndofs, off
 
     def sn_covariance(self, mi):
