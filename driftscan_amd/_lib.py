@@ -83,6 +83,9 @@ SIGNATURES = {
     "dm_bt_maps": (
         c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_int, c_vp,
                 c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_vp]),
+    "dm_bt_maps_c": (
+        c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_int, c_vp,
+                c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_vp]),
     "dm_bt_sht": (
         c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_int, c_int, c_int, c_int, c_int,
                 c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_vp, c_vp]),
@@ -493,8 +496,10 @@ def _bt_maps(self, nside, cth, sth, frame, polarised, beams, uv, bi, bj, maps):
     u, up = _darr(uv)
     i_, ip = _iarr(bi)
     j_, jp = _iarr(bj)
-    rc = self.lib.dm_bt_maps(self.h, int(nside), cp, sp, frp, int(bool(polarised)), int(beams.shape[0]),
-                             self.ptr(beams), len(i_), up, ip, jp, self.ptr(maps))
+    # complex128 beams take the complex-pattern kernels (second beam conjugated, |b|^2 solid angles)
+    fn = self.lib.dm_bt_maps_c if beams.is_complex() else self.lib.dm_bt_maps
+    rc = fn(self.h, int(nside), cp, sp, frp, int(bool(polarised)), int(beams.shape[0]),
+            self.ptr(beams), len(i_), up, ip, jp, self.ptr(maps))
     self.check(rc, "dm_bt_maps")
 
 

@@ -70,7 +70,9 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
         nmr = (2 * mtop + 1) if m_range is None else 2 * max(min(m_range[1], mtop) - m_range[0] + 1, 1)
         # default: the fused path (dm_bt_columns) — the Stokes maps are never written; with the SHT refinement the
         # maps are needed (residual), and DRIFTMI_BT_MAPS=1 forces the two-call path for comparisons
-        fused = not niter and os.environ.get("DRIFTMI_BT_MAPS") != "1"
+        # (a telescope class with complex field patterns declares `complex_beams = True`: those go through the
+        # two-call path with the complex-pattern map kernel)
+        fused = not niter and os.environ.get("DRIFTMI_BT_MAPS") != "1" and not getattr(tel, "complex_beams", False)
         if niter:   # residual maps, all m of the group's columns in G and in the private coefficient buffer
             nmr = 2 * (lgrp + 1)
         per_col = P * 16 * ((0 if fused else (2 if niter else 1)) * npix + nmr * nring
@@ -95,16 +97,27 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
                         feed_of[key] = int(feed)
                     which[k] = keys[key]
             ncomp = 2 if pol else 1
-            beams = ctx.empty((len(keys), npix * ncomp), np.float64)
-            for (f, bc), idx in keys.items():
-                spec = tel.beam_spec(bc, f)
-                if spec is None:
-                    # the reference's plug-in interface: beam(feed, freq) evaluated by the telescope class on the
-                    # host (telescope.py:954-973 keys the maps by beam class as here), uploaded once
-                    beams[idx].copy_(ctx.to_device(tel._beam_host(feed_of[(f, bc)], f, int(nside)).reshape(-1)))
+            # the reference's plug-in interface: beam(feed, freq) evaluated by the telescope class on the host
+            # (telescope.py:954-973 keys the maps by beam class as here), uploaded once
+            specs = {key: tel.beam_spec(key[1], key[0]) for key in keys}
+            hostb = {key: tel._beam_host(feed_of[key], key[0], int(nside)) for key in keys if specs[key] is None}
+            cbeams = any(np.iscomplexobj(b) for b in hostb.values())   # complex patterns: _construct_pol_complex
+            beams = ctx.empty((len(keys), npix * ncomp), np.complex128 if cbeams else np.float64)
+            for key, idx in keys.items():
+                if specs[key] is None:
+                    beams[idx].copy_(ctx.to_device(hostb[key].reshape(-1)))
                     continue
-                kind, tab, fwhm_ns = spec
-                ctx.bt_beam_cyl(int(nside), cth, sth, frame, kind, tab, fwhm_ns, beams[idx])
+                kind, tab, fwhm_ns = specs[key]
+                if cbeams:   # a device-evaluated (real) pattern next to complex ones
+                    tmp = ctx.empty((npix * ncomp,), np.float64)
+                    ctx.bt_beam_cyl(int(nside), cth, sth, frame, kind, tab, fwhm_ns, tmp)
+                    beams[idx].copy_(tmp)
+                else:
+                    ctx.bt_beam_cyl(int(nside), cth, sth, frame, kind, tab, fwhm_ns, beams[idx])
+            del hostb
+            if cbeams and fused:
+                raise ValueError("%s.beam() returned a complex field pattern: set `complex_beams = True` on the class "
+                                 "(the memory plan of the fused path has no room for the Stokes maps)" % type(tel).__name__)
             uv = tel.baselines[b_list[cols]] / wl[f_list[cols]][:, None]
             if fused:
                 ctx.bt_columns(int(nside), cth, sth, frame, pol, beams, uv, bi, bj, lside, mmax, int(lmax_bf[cols].max()), F, B,

@@ -173,6 +173,63 @@ __global__ void bt_maps_kernel(ring_geo g, frame3 fr, int polarised, int ncol, c
 }
 
 
+// ---- complex field patterns (_fast_tools.pyx:167-242, telescope.py:1156-1176): beams are (npix * ncomp) complex128,
+// the second beam enters conjugated, the solid angles are sums of |b|^2 ------------------------------------
+__global__ void bt_omega_c_kernel(ring_geo g, const cplx* __restrict__ beams, int ncomp, size_t bstride,
+                                  double* __restrict__ omega) {
+  __shared__ double red[4];
+  const cplx* b = beams + (size_t)blockIdx.x * bstride;
+  double s = 0.0;
+  for (int pix = threadIdx.x; pix < g.npix; pix += blockDim.x) {
+    double v = 0.0;
+    for (int c = 0; c < ncomp; ++c) v += cabs2(b[(size_t)pix * ncomp + c]);  // beams already carry the horizon
+    s += v;
+  }
+  s = dm_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) omega[blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) * 4.0 * kPi / (double)g.npix;
+}
+
+__global__ void bt_maps_c_kernel(ring_geo g, frame3 fr, int polarised, int ncol, const double* __restrict__ uv,
+                                 const int* __restrict__ bi, const int* __restrict__ bj,
+                                 const cplx* __restrict__ beams, size_t bstride, const double* __restrict__ omega,
+                                 cplx* __restrict__ maps) {
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  const int col = blockIdx.y;
+  if (pix >= g.npix) return;
+  const int r = ring_of_pixel(g, pix);
+  const int j = pix - g.start[r];
+  const double phi = g.phi0[r] + 2.0 * kPi * (double)j / (double)g.nphi[r];
+  double sp, cp;
+  sincos(phi, &sp, &cp);
+  const double st = g.sth[r], ct = g.cth[r];
+  const double n0 = st * cp, n1 = st * sp, n2 = ct;
+  const double hz = (n0 * fr.z[0] + n1 * fr.z[1] + n2 * fr.z[2]) > 0.0 ? 1.0 : 0.0;
+  const double u = uv[2 * col], v = uv[2 * col + 1];
+  const double du = n0 * (u * fr.x[0] + v * fr.y[0]) + n1 * (u * fr.x[1] + v * fr.y[1]) + n2 * (u * fr.x[2] + v * fr.y[2]);
+  double sf, cf;
+  sincos(2.0 * kPi * du, &sf, &cf);
+  const int ib = bi[col], jb = bj[col];
+  const double pre = hz / sqrt(omega[ib] * omega[jb]);
+  const cplx tc = make_double2(pre * cf, pre * sf);
+  if (!polarised) {
+    const cplx bb = cmulc(beams[(size_t)ib * bstride + pix], beams[(size_t)jb * bstride + pix]);  // b_i conj(b_j)
+    maps[(size_t)col * g.npix + pix] = cmul(tc, bb);
+  } else {
+    const cplx* a = beams + (size_t)ib * bstride + 2 * (size_t)pix;
+    const cplx* b = beams + (size_t)jb * bstride + 2 * (size_t)pix;
+    const cplx a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+    const cplx p00 = cmulc(a0, b0), p11 = cmulc(a1, b1), p01 = cmulc(a0, b1), p10 = cmulc(a1, b0);
+    cplx* m = maps + (size_t)col * 4 * g.npix + pix;
+    m[0] = cmul(tc, cadd(p00, p11));
+    m[(size_t)g.npix] = cmul(tc, csub(p00, p11));
+    m[2 * (size_t)g.npix] = cmul(tc, cadd(p01, p10));
+    const cplx sv = cmul(tc, csub(p01, p10));
+    m[3 * (size_t)g.npix] = make_double2(-sv.y, sv.x);  // 1j * tc * (...)
+  }
+}
+
 // ---- fused map synthesis + ring DFT (no Stokes maps in HBM) ---------------------------------------------
 // G[mm][ring][col * P + p] = w_ring * sum_j exp(i m_mm phi_j) * map_p(col, ring, j) with the map value
 // h * fringe * (b_i x b_j) / sqrt(O_i O_j) formed in registers right before it is used.  The sum over the pixels
@@ -562,6 +619,36 @@ int dm_bt_maps(dm_ctx* ctx, int nside, const double* ring_cth_host, const double
                      polarised, ncol, duv, dbi, dbj, beams_dev, bstride, omega, reinterpret_cast<cplx*>(maps_dev));
   DM_HIP(ctx, hipGetLastError());
   dm_ws_release(ctx, mark);
+  return DM_OK;
+}
+
+// dm_bt_maps for COMPLEX field patterns: beams_dev holds nbeam maps of npix * ncomp complex128 (zero below the horizon).
+int dm_bt_maps_c(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host,
+                 const double* frame_host, int polarised, int nbeam, const void* beams_dev, int ncol,
+                 const double* uv_host, const int* bi_host, const int* bj_host, void* maps_dev) {
+  if (!ctx) return DM_EARG;
+  DM_ARG(ctx, nside > 0 && ring_cth_host && ring_sth_host && frame_host && nbeam > 0 && beams_dev && ncol >= 0 &&
+                  uv_host && bi_host && bj_host && maps_dev);
+  if (ncol == 0) return DM_OK;
+  dm_ws_scope ws_scope__(ctx);  // releases on every return path
+  geo_host gh;
+  DM_TRY(upload_geo(ctx, nside, ring_cth_host, ring_sth_host, gh));
+  const int ncomp = polarised ? 2 : 1;
+  const size_t bstride = (size_t)gh.g.npix * ncomp;
+  frame3 fr = make_frame(frame_host, frame_host + 3, frame_host + 6);
+  double* omega = dm_ws_alloc_t<double>(ctx, nbeam);
+  std::vector<double> uv(uv_host, uv_host + 2 * (size_t)ncol);
+  std::vector<int> bi(bi_host, bi_host + ncol), bj(bj_host, bj_host + ncol);
+  for (int c = 0; c < ncol; ++c) DM_ARG(ctx, bi[c] >= 0 && bi[c] < nbeam && bj[c] >= 0 && bj[c] < nbeam);
+  double* duv = dm_ws_upload(ctx, uv);
+  int* dbi = dm_ws_upload(ctx, bi);
+  int* dbj = dm_ws_upload(ctx, bj);
+  if (!omega || !duv || !dbi || !dbj) return DM_ENOMEM;
+  const cplx* bc = reinterpret_cast<const cplx*>(beams_dev);
+  hipLaunchKernelGGL(bt_omega_c_kernel, dim3(nbeam), dim3(256), 0, ctx->stream, gh.g, bc, ncomp, bstride, omega);
+  hipLaunchKernelGGL(bt_maps_c_kernel, dim3((gh.g.npix + 255) / 256, ncol), dim3(256), 0, ctx->stream, gh.g, fr,
+                     polarised, ncol, duv, dbi, dbj, bc, bstride, omega, reinterpret_cast<cplx*>(maps_dev));
+  DM_HIP(ctx, hipGetLastError());
   return DM_OK;
 }
 

@@ -323,6 +323,7 @@ class TransitTelescope(config.Reader):
     _nside = None
     _angpos = None
     _horizon = None
+    complex_beams = False   # True: beam() may return complex patterns (two-call BT-gen path, dm_bt_maps_c)
 
     def beam_spec(self, beamclass, freq_index):
         return None
@@ -340,20 +341,21 @@ class TransitTelescope(config.Reader):
         raise NotImplementedError("%s defines neither beam_spec() nor beam()" % type(self).__name__)
 
     def _beam_host(self, feed, freq_index, nside):
-        """float64 field pattern of `feed` at a frequency on the pixels of `nside`, zero below the horizon:
-        (npix,) for an unpolarised telescope, (npix, 2) for a polarised one."""
+        """Field pattern of `feed` at a frequency on the pixels of `nside`, zero below the horizon: (npix,) for an
+        unpolarised telescope, (npix, 2) for a polarised one; float64, or complex128 if the class returns a pattern
+        with a non-zero imaginary part."""
         if self._nside != int(nside) or self._angpos is None:
             self._init_trans(nside)
         b = np.asarray(self.beam(feed, freq_index))
-        if np.iscomplexobj(b):
-            if np.any(b.imag != 0.0):
-                raise NotImplementedError("complex field patterns (the device beams are real)")
+        if np.iscomplexobj(b) and not np.any(b.imag != 0.0):
             b = b.real
         want = (self._angpos.shape[0],) if self.num_pol_sky == 1 else (self._angpos.shape[0], 2)
         if b.shape != want:
             raise ValueError("beam(%d, %d) returned shape %r, expected %r" % (feed, freq_index, b.shape, want))
         hz = self._horizon.astype(np.float64)
-        return np.ascontiguousarray(b.astype(np.float64) * (hz if b.ndim == 1 else hz[:, None]))
+        # a genuinely complex pattern stays complex128: btgen then takes the complex-pattern kernels (dm_bt_maps_c)
+        dt = np.complex128 if np.iscomplexobj(b) else np.float64
+        return np.ascontiguousarray(b.astype(dt) * (hz if b.ndim == 1 else hz[:, None]))
 
     # ---- transfer matrices ------------------------------------------------------
     def transfer_matrices(self, bl_indices, f_indices, global_lmax=True):

@@ -251,6 +251,14 @@ int dm_bt_maps(dm_ctx* ctx, int nside, const double* ring_cth_host, const double
                const double* frame_host, int polarised, int nbeam, const double* beams_dev, int ncol,
                const double* uv_host, const int* bi_host, const int* bj_host, void* maps_dev);
 
+/* dm_bt_maps_c: dm_bt_maps for COMPLEX field patterns — beams_dev holds nbeam maps of npix * ncomp complex128 (zero
+ * below the horizon); the second beam of a pair enters conjugated and the solid angles are sums of |b|^2.
+ * Replaces drift/util/_fast_tools.pyx:167-242 (_construct_pol_complex, reached from telescope.py:1278-1279) and the
+ * complex case of UnpolarisedTelescope._beam_map_single (telescope.py:1156-1176). */
+int dm_bt_maps_c(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host,
+                 const double* frame_host, int polarised, int nbeam, const void* beams_dev, int ncol,
+                 const double* uv_host, const int* bi_host, const int* bj_host, void* maps_dev);
+
 /* dm_bt_sht: spherical-harmonic transform of the maps straight into the m-ordered
  * blocks beam_m_dev (mmax+1, F, 2, B, P, lside+1) c128 (the reference's beam_m layout
  * with l padded from 0): rows (f, :, b) of the given columns are overwritten, zero for

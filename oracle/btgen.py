@@ -136,6 +136,22 @@ def construct_pol_real(beami, beamj, fr, hz):
     return out
 
 
+def construct_pol_complex(beami, beamj, fr, hz):
+    """Four Stokes response maps for complex field patterns: the second beam enters conjugated, the solid angles are
+    sums of |b|^2 (_fast_tools.pyx:167-242)."""
+    n = beami.shape[0]
+    om_i = np.sum(hz * (np.abs(beami[:, 0]) ** 2 + np.abs(beami[:, 1]) ** 2)) * 4.0 * np.pi / n
+    om_j = np.sum(hz * (np.abs(beamj[:, 0]) ** 2 + np.abs(beamj[:, 1]) ** 2)) * 4.0 * np.pi / n
+    tc = fr * hz / np.sqrt(om_i * om_j)
+    cj = beamj.conj()
+    out = np.empty((4, n), dtype=np.complex128)
+    out[0] = tc * (beami[:, 0] * cj[:, 0] + beami[:, 1] * cj[:, 1])
+    out[1] = tc * (beami[:, 0] * cj[:, 0] - beami[:, 1] * cj[:, 1])
+    out[2] = tc * (beami[:, 0] * cj[:, 1] + beami[:, 1] * cj[:, 0])
+    out[3] = 1j * tc * (beami[:, 0] * cj[:, 1] - beami[:, 1] * cj[:, 0])
+    return out
+
+
 # ----------------------------------------------------------------------------
 # cylinder beam model (cylbeam.py)
 # ----------------------------------------------------------------------------
@@ -470,7 +486,9 @@ def beam_transfer_m(tel, mlist=None):
                 beams.append(cache[key])
             uv = tel["baselines"][b] / tel["wavelengths"][f]
             fr = fringe(ap, tel["zenith"], uv)
-            if pol:
+            if pol and (np.iscomplexobj(beams[0]) or np.iscomplexobj(beams[1])):   # telescope.py:1278-1281
+                maps = construct_pol_complex(beams[0].astype(np.complex128), beams[1].astype(np.complex128), fr, hz)
+            elif pol:
                 maps = construct_pol_real(beams[0], beams[1], fr, hz)
             else:
                 pxarea = 4 * np.pi / ap.shape[0]

@@ -162,3 +162,79 @@ def test_focalplane_beam_m(ctx):
         r = bm[m, 0, 0, 1, 0, m:] / bm[m, 0, 0, 0, 0, m:]
     big = np.abs(bm[m, 0, 0, 0, 0, m:]) > 1e-3 * np.abs(bm[m, 0, 0, 0, 0, m:]).max()
     assert np.abs(np.abs(r[big]) - 1).max() < 2e-2
+
+
+def test_complex_patterns_pixel_kernel(ctx):
+    """dm_bt_maps_c against the oracle's construct_pol_complex (pinned on the reference's compiled Cython in
+    tests/test_oracle_btgen.py) and the complex unpolarised product b_i conj(b_j)."""
+    from driftscan_amd import btgen, healpix
+    from oracle import btgen as ob
+
+    nside = 16
+    npix = healpix.npix(nside)
+    zen = np.array([np.pi / 2 - np.radians(45.0), 0.0])
+    cth, sth = healpix.ring_trig(nside)
+    frame = btgen.telescope_frame(zen)
+    ap = ob.ang_positions(nside)
+    hz = ob.horizon(ap, zen).astype(np.float64)
+    rng = np.random.default_rng(3)
+    width, fe, fh = 5.0 / 0.7, 2.0 * np.pi / 3.0 * 0.7, 2.0 * np.pi / 3.0
+    bx = ob.beam_x(ap, zen, width, fe, fh) * np.exp(0.3j + 0.2j * np.cos(ap[:, 1]))[:, None]
+    by = ob.beam_y(ap, zen, width, fe, fh) * np.exp(-0.7j + 0.4j * np.sin(ap[:, 0]))[:, None]
+    hb = np.stack([bx * hz[:, None], by * hz[:, None]])                      # (2, npix, 2)
+    beams = ctx.to_device(hb.reshape(2, -1))
+    uv = np.array([[3.1, -2.2], [0.0, 1.7], [-4.0, 0.3]])
+    bi, bj = np.array([0, 1, 1]), np.array([1, 1, 0])
+    maps = ctx.empty((3, 4, npix), np.complex128)
+    ctx.bt_maps(nside, cth, sth, frame, True, beams, uv, bi, bj, maps)
+    ctx.sync()
+    hm = maps.cpu().numpy()
+    for k in range(3):
+        ref = ob.construct_pol_complex(hb[bi[k]], hb[bj[k]], ob.fringe(ap, zen, uv[k]), hz)
+        assert np.abs(hm[k] - ref).max() <= 1e-11 * np.abs(ref).max()
+    # unpolarised: telescope.py:1156-1176 with complex beams
+    ub = ob.beam_amp(ap, zen, width, fh, fh) * hz
+    ub2 = np.stack([ub * np.exp(0.5j * ap[:, 1]), ub * np.exp(-0.2j * ap[:, 0])])
+    m1 = ctx.empty((1, 1, npix), np.complex128)
+    ctx.bt_maps(nside, cth, sth, frame, False, ctx.to_device(ub2), uv[:1], np.array([0]), np.array([1]), m1)
+    ctx.sync()
+    px = 4 * np.pi / npix
+    om = [np.sum(np.abs(b) ** 2 * hz) * px for b in ub2]
+    ref = hz * ob.fringe(ap, zen, uv[0]) * ub2[0] * ub2[1].conj() / np.sqrt(om[0] * om[1])
+    assert np.abs(m1.cpu().numpy()[0, 0] - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("pol", [False, True])
+def test_complex_beam_telescope_vs_oracle(ctx, pol):
+    """A dish array whose apertures carry a phase gradient (complex field patterns): beam() -> complex host maps ->
+    dm_bt_maps_c -> dm_bt_sht, against the oracle fed with the same patterns."""
+    from driftscan_amd import btgen, disharray
+
+    base = disharray.PolarisedDishArray if pol else disharray.UnpolarisedDishArray
+
+    class PhasedDishes(base):
+        complex_beams = True
+
+        def _amplitude(self, freq):
+            amp = base._amplitude(self, freq)
+            return amp * np.exp(0.8j * np.sin(self._angpos[:, 0]) * np.cos(self._angpos[:, 1]))
+
+    cfg = dict(gridu=2, gridv=2, dish_width=2.0, num_freq=2, freq_lower=None, freq_upper=None, freq_start=400.0,
+               freq_end=440.0, freq_mode="edge", tsys=1.0)
+    t = PhasedDishes.from_config(cfg)
+
+    def beam_fn(feed, f, ap):
+        amp = disharray.beam_circular(ap, t.zenith, t.dish_width / t.wavelengths[f])
+        amp = amp * np.exp(0.8j * np.sin(ap[:, 0]) * np.cos(ap[:, 1]))
+        if not pol:
+            return amp
+        return amp[:, None] * (np.array([0.0, 1.0]) if t.polarisation[feed] == "X" else np.array([1.0, 0.0]))
+
+    _check_beam_m(t, ctx, _oracle_desc(t, beam_fn), mlist=[0, 1, 7, t.mmax])
+
+    # without the declaration the fused memory plan refuses complex patterns instead of dropping the imaginary part
+    class Undeclared(PhasedDishes):
+        complex_beams = False
+
+    with pytest.raises(ValueError, match="complex_beams"):
+        btgen.beam_m_all(Undeclared.from_config(cfg), ctx=ctx)

@@ -24,6 +24,12 @@ def test_pixel_kernels_vs_reference(pk):
     for key, bi, bj in (("pol_real_xy", "beam_x", "beam_y"), ("pol_real_xx", "beam_x", "beam_x")):
         out = ob.construct_pol_real(pk[bi], pk[bj], pk["fringe"], hz)
         assert np.abs(out - pk[key]).max() <= 1e-13 * np.abs(pk[key]).max()
+    # complex field patterns: the reference's compiled _construct_pol_complex on phase-rotated beams
+    outc = ob.construct_pol_complex(pk["beam_xc"], pk["beam_yc"], pk["fringe"], hz)
+    assert np.abs(outc - pk["pol_complex_xy"]).max() <= 1e-13 * np.abs(pk["pol_complex_xy"]).max()
+    # and it reduces to the real kernel on real patterns
+    outr = ob.construct_pol_complex(pk["beam_x"].astype(complex), pk["beam_y"].astype(complex), pk["fringe"], hz)
+    assert np.abs(outr - pk["pol_real_xy"]).max() <= 1e-13 * np.abs(pk["pol_real_xy"]).max()
 
 
 def test_cylinder_beams_vs_reference(pk):
