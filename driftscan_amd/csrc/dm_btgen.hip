@@ -288,12 +288,10 @@ __global__ __launch_bounds__(256) void bt_fused_dft_kernel(ring_geo g, frame3 fr
 #pragma unroll
       for (int p = 0; p < P; ++p) acc_re[c][a][p] = acc_im[c][a][p] = 0.0;
 
-  // The pixel direction (cos phi_j, sin phi_j) and the twiddles exp(i m phi_j) advance by four pixels per step:
-  // one complex rotation each, re-seeded exactly every FDFT_RS steps (a rotation costs 6 flops against the ~60 of a
-  // sincos plus a 64-bit modulo; the drift over 15 rotations stays below 1e-14, the exact seed bounds it).
+  // The twiddles exp(i m phi_j) advance by four pixels per step: one complex rotation each, re-seeded exactly every
+  // FDFT_RS steps (a rotation costs 6 flops against the ~60 of a sincos plus a 64-bit modulo; the drift over 15
+  // rotations stays below 1e-14, the exact seed bounds it).
   constexpr int FDFT_RS = 16;
-  double rotp_c, rotp_s;
-  sincos(2.0 * kPi * 4.0 / (double)nphi, &rotp_s, &rotp_c);
   double rot_re[NMG], rot_im[NMG];
 #pragma unroll
   for (int a = 0; a < NMG; ++a) {
@@ -309,8 +307,10 @@ __global__ __launch_bounds__(256) void bt_fused_dft_kernel(ring_geo g, frame3 fr
     const int j = q + k;
     const bool pv = j < nphi;
     const int jj = pv ? j : nphi - 1;
+    // the pixel direction is taken exactly for every quad: it enters the map values, which have to come out with
+    // the same bits from every kernel that synthesises them (bt_fused_dft2_kernel visits the quads in another order)
+    sincos(phi0 + 2.0 * kPi * (double)j / (double)nphi, &sp, &cp);
     if ((step & (FDFT_RS - 1)) == 0) {
-      sincos(phi0 + 2.0 * kPi * (double)j / (double)nphi, &sp, &cp);
 #pragma unroll
       for (int a = 0; a < NMG; ++a) {
         // reduce the argument exactly: m * j mod nphi keeps the phase in [0, 2 pi) (as bt_twiddle_kernel)
@@ -323,9 +323,6 @@ __global__ __launch_bounds__(256) void bt_fused_dft_kernel(ring_geo g, frame3 fr
     } else {
       // explicit rounding order: every instantiation (and therefore every partition of m over ranks) forms the
       // same bits for a given (m, pixel)
-      const double c2 = __fma_rn(cp, rotp_c, -__dmul_rn(sp, rotp_s));
-      sp = __fma_rn(cp, rotp_s, __dmul_rn(sp, rotp_c));
-      cp = c2;
 #pragma unroll
       for (int a = 0; a < NMG; ++a) {
         const double r2 = __fma_rn(tw_re[a], rot_re[a], -__dmul_rn(tw_im[a], rot_im[a]));
@@ -383,6 +380,179 @@ __global__ __launch_bounds__(256) void bt_fused_dft_kernel(ring_geo g, frame3 fr
     }
   }
   // lane 16 i + (lane & 15) holds m-row i of the group: G[mm][ring][col * P + p]
+  const double w = ring_w ? ring_w[r] : 1.0;
+  const int i = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < NCG; ++c) {
+    const int col = (cg0 + c) * 16 + (lane & 15);
+    if (cg0 + c >= ncol16 || col * P >= ncp) continue;
+#pragma unroll
+    for (int a = 0; a < NMG; ++a) {
+      const int mm = (mg0 + a) * 4 + i;
+      if (mm >= nm) continue;
+      cplx* out = G + ((size_t)mm * g.nring + r) * ncp + (size_t)col * P;
+#pragma unroll
+      for (int p = 0; p < P; ++p) dm_stg(out, p, make_double2(w * acc_re[c][a][p], w * acc_im[c][a][p]));
+    }
+  }
+}
+
+// ---- the same transform with the synthesis SHARED by the four waves of a workgroup ---------------------------
+// bt_fused_dft_kernel repeats the map synthesis (a sincospi, two beam loads and the Stokes products per pixel and
+// column) for every pass over m: 17 times for a rank's 130 m-values at configs[2], and its MFMA pipe sits idle
+// behind that VALU work.  Here the four waves of a workgroup own the SAME ring and the same NCG column groups but
+// different m-values (4 NMG each, 16 NMG per pass): per chunk of four pixel quads every wave synthesises ONE quad
+// (for all NCG groups) into LDS, and after a barrier every wave runs its own twiddles over all four quads.  The
+// synthesis per MFMA drops fourfold, the passes over m fourfold: the kernel is bound by the matrix pipe.
+// LDS: two buffers x 4 quads x NCG groups x P x (re, im) x 64 lanes x 8 B (32 KB for <4, *, 1> and <1, *, 4>); one
+// barrier per chunk (the buffers alternate: a wave can only reach the second write of a buffer through the barrier
+// that every reader of its previous content has passed).
+template <int P, int NMG, int NCG>
+__global__ __launch_bounds__(256) void bt_fused_dft2_kernel(ring_geo g, frame3 fr, const double* __restrict__ beams, size_t bstride,
+                                                            const fdft_col* __restrict__ cols, int ncol16, int m_lo, int cnt,
+                                                            const double* __restrict__ ring_w, cplx* __restrict__ G, int ncp) {
+  constexpr int NCOMP = P == 4 ? 2 : 1;
+  constexpr int QC = 4;  // quads per chunk = waves per workgroup
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = blockIdx.y;
+  const int cg0 = blockIdx.x * NCG;
+  if (cg0 >= ncol16) return;  // uniform over the workgroup
+  const int nm = 2 * cnt;
+  const int mg0 = (blockIdx.z * 4 + wave) * NMG;  // first group of four m-values of this wave
+  const bool has_m = mg0 * 4 < nm;                // (a wave without m-values still synthesises its quads)
+  const int k = lane >> 4, t = lane & 3;
+  const int nphi = g.nphi[r];
+  const double phi0 = g.phi0[r], st = g.sth[r], ct = g.cth[r];
+  const int pix0 = g.start[r];
+  int mval[NMG];
+  bool mok[NMG];
+#pragma unroll
+  for (int a = 0; a < NMG; ++a) {
+    const int mm = (mg0 + a) * 4 + t;
+    mok[a] = mm < nm;
+    mval[a] = mm < cnt ? m_lo + mm : -(m_lo + mm - cnt);
+  }
+  __shared__ fdft_col s_cd[NCG * 16];
+  __shared__ double s_map[2][QC][NCG][P][2][64];
+  __shared__ int s_on[2][QC];
+  for (int c = threadIdx.x; c < NCG * 16; c += 256) {
+    const int cg = cg0 + (c >> 4);
+    s_cd[c] = cg < ncol16 ? cols[(size_t)cg * 16 + (c & 15)] : fdft_col{0.0, 0.0, 0.0, -1, -1};
+  }
+  __syncthreads();
+  double acc_re[NCG][NMG][P], acc_im[NCG][NMG][P];
+#pragma unroll
+  for (int c = 0; c < NCG; ++c)
+#pragma unroll
+    for (int a = 0; a < NMG; ++a)
+#pragma unroll
+      for (int p = 0; p < P; ++p) acc_re[c][a][p] = acc_im[c][a][p] = 0.0;
+
+  // twiddle state: advances by 4 pixels per quad; exact re-seed every 16 quads (as bt_fused_dft_kernel)
+  constexpr int TW_RS = 16;
+  double rot_re[NMG], rot_im[NMG], tw_re[NMG], tw_im[NMG];
+#pragma unroll
+  for (int a = 0; a < NMG; ++a) {
+    const long long m4 = (4ll * mval[a]) % nphi;
+    sincos(2.0 * kPi * (double)m4 / (double)nphi, &rot_im[a], &rot_re[a]);
+    tw_re[a] = tw_im[a] = 0.0;
+  }
+  const int nchunk = (nphi + 4 * QC - 1) / (4 * QC);
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int buf = ch & 1;
+    // ---- synthesis of quad `wave` of this chunk, all NCG groups
+    {
+      const int j = 16 * ch + 4 * wave + k;
+      const bool pv = j < nphi;
+      const int jj = pv ? j : nphi - 1;
+      double sp, cp;
+      sincos(phi0 + 2.0 * kPi * (double)j / (double)nphi, &sp, &cp);  // exact, as in bt_fused_dft_kernel: same map bits
+      const double n0 = st * cp, n1 = st * sp, n2 = ct;
+      const double hz = (pv && (n0 * fr.z[0] + n1 * fr.z[1] + n2 * fr.z[2]) > 0.0) ? 1.0 : 0.0;
+      const bool any = __ballot(hz != 0.0) != 0ull;
+      if (lane == 0) s_on[buf][wave] = any ? 1 : 0;
+      if (any) {  // (wave-uniform) a quad wholly below the horizon is skipped by every reader
+        const double nx = n0 * fr.x[0] + n1 * fr.x[1] + n2 * fr.x[2];
+        const double ny = n0 * fr.y[0] + n1 * fr.y[1] + n2 * fr.y[2];
+        const size_t pix = (size_t)pix0 + jj;
+#pragma unroll
+        for (int c = 0; c < NCG; ++c) {
+          const fdft_col cdc = s_cd[c * 16 + (lane & 15)];
+          const bool on = cdc.bi >= 0 && hz != 0.0;
+          const double* a = beams + (size_t)max(cdc.bi, 0) * bstride + NCOMP * pix;
+          const double* b = beams + (size_t)max(cdc.bj, 0) * bstride + NCOMP * pix;
+          double sf, cf;
+          sincospi(2.0 * (cdc.u * nx + cdc.v * ny), &sf, &cf);
+          const double pre = on ? cdc.pre : 0.0;
+          const double tre = pre * cf, tim = pre * sf;
+          if constexpr (P == 1) {
+            const double bb = dm_ldg(a) * dm_ldg(b);
+            s_map[buf][wave][c][0][0][lane] = tre * bb;
+            s_map[buf][wave][c][0][1][lane] = tim * bb;
+          } else {
+            const double a0 = dm_ldg(a), a1 = dm_ldg(a, 1), b0 = dm_ldg(b), b1 = dm_ldg(b, 1);
+            const double sI = a0 * b0 + a1 * b1, sQ = a0 * b0 - a1 * b1, sU = a0 * b1 + a1 * b0, sV = a0 * b1 - a1 * b0;
+            s_map[buf][wave][c][0][0][lane] = tre * sI; s_map[buf][wave][c][0][1][lane] = tim * sI;
+            s_map[buf][wave][c][1][0][lane] = tre * sQ; s_map[buf][wave][c][1][1][lane] = tim * sQ;
+            s_map[buf][wave][c][2][0][lane] = tre * sU; s_map[buf][wave][c][2][1][lane] = tim * sU;
+            s_map[buf][wave][c][3][0][lane] = -tim * sV; s_map[buf][wave][c][3][1][lane] = tre * sV;  // 1j * fringe * sV
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (!has_m) continue;  // (wave-uniform; the barrier above is still reached every chunk)
+    // ---- this wave's m-values over the four quads of the chunk
+#pragma unroll
+    for (int qi = 0; qi < QC; ++qi) {
+      const int quad = ch * QC + qi;
+      const int j = 4 * quad + k;
+      if (4 * quad >= nphi) break;
+      if ((quad & (TW_RS - 1)) == 0) {
+#pragma unroll
+        for (int a = 0; a < NMG; ++a) {
+          const long long mj = ((long long)mval[a] * j) % nphi;
+          double s_, c_;
+          sincos((double)mval[a] * phi0 + 2.0 * kPi * (double)mj / (double)nphi, &s_, &c_);
+          tw_re[a] = mok[a] ? c_ : 0.0;
+          tw_im[a] = mok[a] ? s_ : 0.0;
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < NMG; ++a) {
+          const double r2 = __fma_rn(tw_re[a], rot_re[a], -__dmul_rn(tw_im[a], rot_im[a]));
+          tw_im[a] = __fma_rn(tw_re[a], rot_im[a], __dmul_rn(tw_im[a], rot_re[a]));
+          tw_re[a] = r2;
+        }
+      }
+      if (!s_on[buf][qi]) continue;
+#pragma unroll
+      for (int c = 0; c < NCG; ++c) {
+        double m_re[P], m_im[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          m_re[p] = s_map[buf][qi][c][p][0][lane];
+          m_im[p] = s_map[buf][qi][c][p][1][lane];
+        }
+#pragma unroll
+        for (int a = 0; a < NMG; ++a)
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            acc_re[c][a][p] = dm_mfma4(tw_re[a], m_re[p], acc_re[c][a][p]);
+            acc_im[c][a][p] = dm_mfma4(tw_re[a], m_im[p], acc_im[c][a][p]);
+          }
+#pragma unroll
+        for (int a = 0; a < NMG; ++a)
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            acc_re[c][a][p] = dm_mfma4(-tw_im[a], m_im[p], acc_re[c][a][p]);
+            acc_im[c][a][p] = dm_mfma4(tw_im[a], m_re[p], acc_im[c][a][p]);
+          }
+      }
+    }
+  }
+  if (!has_m) return;
   const double w = ring_w ? ring_w[r] : 1.0;
   const int i = lane >> 4;
 #pragma unroll
@@ -745,11 +915,22 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
     // the MFMAs of the other
     // measured: twice / four times the m-values per pass (<4,4,1>, <4,8,1>, <1,8,2>, <1,16,1>) halve the repeated
     // synthesis but cost a wave per SIMD — no faster on configs[1] or configs[2]
+    // shared-synthesis kernel: the four waves of a workgroup take different m-values (16 NMG per pass)
+    auto launch2 = [&](auto kern, int NMG, int NCG) {
+      const dim3 grid((unsigned)((ncol16 + NCG - 1) / NCG), (unsigned)nring, (unsigned)((nmg + 4 * NMG - 1) / (4 * NMG)));
+      hipLaunchKernelGGL(kern, grid, dim3(256), 0, ctx->stream, gh.g, fr, syn->beams_dev, bstride, d_fc, ncol16, m_lo, cnt, d_rw, G,
+                         ncp);
+    };
+    static const int shared_env = getenv("DM_FDFT_SHARED") ? atoi(getenv("DM_FDFT_SHARED")) : 1;
     if (polarised) {
       if (nmg <= 1) launch(bt_fused_dft_kernel<4, 1, 4>, 1, 4);
+      else if (shared_env == 2 && nmg > 8) launch2(bt_fused_dft2_kernel<4, 4, 1>, 4, 1);
+      else if (shared_env >= 1 && nmg > 2) launch2(bt_fused_dft2_kernel<4, 2, 1>, 2, 1);
       else launch(bt_fused_dft_kernel<4, 2, 2>, 2, 2);
     } else {
       if (nmg <= 1) launch(bt_fused_dft_kernel<1, 1, 8>, 1, 8);
+      else if (shared_env == 2 && nmg > 8) launch2(bt_fused_dft2_kernel<1, 4, 4>, 4, 4);
+      else if (shared_env >= 1 && nmg > 4) launch2(bt_fused_dft2_kernel<1, 2, 4>, 2, 4);
       else launch(bt_fused_dft_kernel<1, 4, 4>, 4, 4);
     }
     DM_HIP(ctx, hipGetLastError());
