@@ -52,6 +52,8 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--prime-passes", type=int, default=10,
+                    help="untimed passes of the hot path before the warm-up steps (settles a fresh box; 0 to skip)")
     ap.add_argument("--mode", choices=["weak", "sharded"], default="weak")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo + --one-gpu rehearses the multi-rank path on a single card (RCCL refuses two ranks per GPU)")
@@ -394,6 +396,15 @@ def main():
             mine = parallel.partition_contiguous(allm, [float(tel.lmax + 1 - m) + 1.0 for m in allm])
             m_range = (mine[0], mine[-1])
         collect = world > 1 or force_dist
+        # Device priming, before the W warm-up steps: a fresh box runs its first ~1.5 s of GPU work about 4 % slower
+        # (clocks and page mappings settle; measured: first process of a box 719 m-blocks/s at W = 2, 756 at W = 12,
+        # every later process 753 at W = 2).  The same hot path, untimed, for PRIME_S seconds of wall time; every rank
+        # runs the same number of passes so that the collectives inside them match.
+        t_prime = time.perf_counter()
+        for _ in range(args.prime_passes):
+            hot_path_step(tel, bt, kl, ctx, streams=args.streams, m_range=m_range, collect=collect)
+        torch.cuda.synchronize()
+        t_prime = time.perf_counter() - t_prime
         for _ in range(args.warmup):
             hot_path_step(tel, bt, kl, ctx, streams=args.streams, m_range=m_range, collect=collect)
         # A full (generation-2) cycle collection walks every object torch/numpy created at import
@@ -508,6 +519,8 @@ def main():
                 "n_gpus": world,
                 "steps": args.steps,
                 "warmup": args.warmup,
+                "priming": {"passes": args.prime_passes, "seconds": t_prime, "note": "untimed passes of the same hot path "
+                            "before the warm-up steps: the first ~1.5 s of GPU work on a fresh box run ~4 % slow"},
                 "ms_per_step": 1e3 * dt / args.steps,
                 "higher_is_better": True,
                 "scaling": "strong" if sharded else "weak",
