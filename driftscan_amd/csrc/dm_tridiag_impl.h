@@ -599,6 +599,8 @@ struct ql_mat {
   int max_sweeps; long long max_rot;
   int* nsweeps;       // out
   int* status;        // out: 0 ok, 1 no convergence, 2 storage exhausted
+  double* Zt = nullptr;  // APPLY instantiation: eigenvectors out, Zt[col * ldz + row]
+  int ldz = 0;
 };
 
 __device__ __forceinline__ void dev_lartg(double f, double g, double& c, double& s, double& r) {
@@ -650,23 +652,34 @@ __device__ void dev_laev2(double a, double b, double c, double& rt1, double& rt2
   if (sgn1 == sgn2) { const double tn = cs1; cs1 = -sn1; sn1 = tn; }
 }
 
-template <bool USE_LDS>
+// APPLY (the leaves of the divide & conquer, n <= 64): the rotations are not recorded but applied at once to Z = I
+// held in LDS — lane r owns row r of Z, all lanes run the (uniform) scalar recurrences, and a rotation costs two LDS
+// reads and writes per lane off the critical path of the next lartg.  This replaces the record / zt_identity /
+// rot_apply sequence, whose rot_apply ran one thread per ROW of a 23..32-row leaf.
+template <bool USE_LDS, bool APPLY = false>
 __global__ __launch_bounds__(64) void ql_kernel(const ql_mat* __restrict__ qs) {
   extern __shared__ __align__(16) unsigned char ql_smem[];
   const ql_mat Q = qs[blockIdx.x];
   const int n = Q.n;
   double* d = Q.d;
   double* e = Q.e;
+  double* Zs = nullptr;
+  const int lane = threadIdx.x;
   if (USE_LDS) {
     // the serial chain below touches d and e at every rotation: keep them in LDS
     double* ld = reinterpret_cast<double*>(ql_smem);
     double* le = ld + n;
     for (int i = threadIdx.x; i < n; i += 64) { ld[i] = Q.d[i]; le[i] = (i + 1 < n) ? Q.e[i] : 0.0; }
+    if (APPLY) {
+      Zs = le + n;  // column-major: Zs[c * n + r]
+      if (lane < n)
+        for (int c = 0; c < n; ++c) Zs[c * n + lane] = (c == lane) ? 1.0 : 0.0;
+    }
     __syncthreads();
     d = ld;
     e = le;
   }
-  if (threadIdx.x != 0) return;
+  if (!APPLY && threadIdx.x != 0) return;
   int ns = 0;
   long long nr = 0;
   int status = 0;
@@ -674,11 +687,20 @@ __global__ __launch_bounds__(64) void ql_kernel(const ql_mat* __restrict__ qs) {
   const double eps2 = eps * eps;
   const double safmin = 2.2250738585072014e-308;
   auto record = [&](int dir, int lo, int cnt) -> bool {
+    if (APPLY) { ++ns; return true; }
     if (ns >= Q.max_sweeps || nr + cnt > Q.max_rot) { status = 2; return false; }
     Q.sw_dir[ns] = dir; Q.sw_lo[ns] = lo; Q.sw_cnt[ns] = cnt; Q.sw_off[ns] = nr;
     ++ns;
     nr += cnt;
     return true;
+  };
+  // plane rotation of the columns (j, j + 1) of Z:  t = z[j+1];  z[j+1] = c t - s z[j];  z[j] = s t + c z[j]
+  auto rotate = [&](int j, double c, double s) {
+    if (lane < n) {
+      const double zj = Zs[j * n + lane], zj1 = Zs[(j + 1) * n + lane];
+      Zs[(j + 1) * n + lane] = c * zj1 - s * zj;
+      Zs[j * n + lane] = s * zj1 + c * zj;
+    }
   };
   if (n > 1) {
     // global scaling to unit max-norm (dsteqr scales each block; one scaling suffices within fp64 range)
@@ -719,7 +741,8 @@ __global__ __launch_bounds__(64) void ql_kernel(const ql_mat* __restrict__ qs) {
             double rt1, rt2, c, s;
             dev_laev2(d[l], e[l], d[l + 1], rt1, rt2, c, s);
             if (!record(0, l, 1)) break;
-            Q.rot[nr - 1] = make_double2(c, s);
+            if (APPLY) rotate(l, c, s);
+            else Q.rot[nr - 1] = make_double2(c, s);
             d[l] = rt1; d[l + 1] = rt2; e[l] = 0.0;
             l += 2;
             continue;
@@ -732,7 +755,7 @@ __global__ __launch_bounds__(64) void ql_kernel(const ql_mat* __restrict__ qs) {
           double s = 1.0, c = 1.0;
           p = 0.0;
           if (!record(0, l, mq - l)) break;
-          double2* rot = Q.rot + (nr - (mq - l));
+          double2* rot = APPLY ? nullptr : Q.rot + (nr - (mq - l));
           double dup = d[mq];            // d[i+1], carried in a register
           double ei = e[mq - 1], di = d[mq - 1];
           for (int i = mq - 1; i >= l; --i) {
@@ -746,7 +769,8 @@ __global__ __launch_bounds__(64) void ql_kernel(const ql_mat* __restrict__ qs) {
             p = s * r;
             d[i + 1] = g + p;
             g = c * r - b;
-            rot[i - l] = make_double2(c, -s);
+            if (APPLY) rotate(i, c, -s);
+            else rot[i - l] = make_double2(c, -s);
             dup = di;
             ei = en;
             di = dn;
@@ -769,7 +793,8 @@ __global__ __launch_bounds__(64) void ql_kernel(const ql_mat* __restrict__ qs) {
             double rt1, rt2, c, s;
             dev_laev2(d[l - 1], e[l - 1], d[l], rt1, rt2, c, s);
             if (!record(1, l - 1, 1)) break;
-            Q.rot[nr - 1] = make_double2(c, s);
+            if (APPLY) rotate(l - 1, c, s);
+            else Q.rot[nr - 1] = make_double2(c, s);
             d[l - 1] = rt1; d[l] = rt2; e[l - 1] = 0.0;
             l -= 2;
             continue;
@@ -782,7 +807,7 @@ __global__ __launch_bounds__(64) void ql_kernel(const ql_mat* __restrict__ qs) {
           double s = 1.0, c = 1.0;
           p = 0.0;
           if (!record(1, mq, l - mq)) break;
-          double2* rot = Q.rot + (nr - (l - mq));
+          double2* rot = APPLY ? nullptr : Q.rot + (nr - (l - mq));
           double dlo = d[mq];            // d[i], carried in a register
           double ei = e[mq], di1 = d[mq + 1];
           for (int i = mq; i <= l - 1; ++i) {
@@ -795,7 +820,8 @@ __global__ __launch_bounds__(64) void ql_kernel(const ql_mat* __restrict__ qs) {
             p = s * r;
             d[i] = g + p;
             g = c * r - b;
-            rot[i - mq] = make_double2(c, s);
+            if (APPLY) rotate(i, c, s);
+            else rot[i - mq] = make_double2(c, s);
             dlo = di1;
             ei = en;
             di1 = dn;
@@ -805,10 +831,18 @@ __global__ __launch_bounds__(64) void ql_kernel(const ql_mat* __restrict__ qs) {
         }
       }
     }
-    for (int i = 0; i < n; ++i) Q.d[i] = d[i] * (anorm > 0.0 ? anorm : 1.0);
+    if (lane == 0)
+      for (int i = 0; i < n; ++i) Q.d[i] = d[i] * (anorm > 0.0 ? anorm : 1.0);
   }
-  *Q.nsweeps = ns;
-  *Q.status = status;
+  if (APPLY && lane < n) {
+    if (n == 1) Q.Zt[0] = 1.0;
+    else
+      for (int c = 0; c < n; ++c) Q.Zt[(size_t)c * Q.ldz + lane] = Zs[c * n + lane];
+  }
+  if (lane == 0) {
+    *Q.nsweeps = ns;
+    *Q.status = status;
+  }
 }
 
 // ---- T3: apply the recorded rotations to the rows of Z (stored column-major: Zt[col*n + row]) ----
@@ -1455,7 +1489,7 @@ static int dc_solve(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, 
         const int lo = bound(p, D, i), hi = bound(p, D, i + 1), nl = hi - lo;
         leafmat.push_back(p);
         qm.push_back(ql_mat{dd + offn[p] + lo, ee + offn[p] + lo, nl, sw_dir + so, sw_lo + so, sw_cnt + so, sw_off + so,
-                            rot + ro, 4 * nl + 8, 2LL * nl * nl + 8, nullptr, nullptr});
+                            rot + ro, 4 * nl + 8, 2LL * nl * nl + 8, nullptr, nullptr, ZA + off[p] + (size_t)lo * n + lo, n});
         rm.push_back(rot_mat{ZA + off[p] + (size_t)lo * n + lo, nl, n, sw_dir + so, sw_lo + so, sw_cnt + so,
                              sw_off + so, rot + ro, nullptr});
         so += 4 * (size_t)nl + 8;
@@ -1486,10 +1520,17 @@ static int dc_solve(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, 
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
         attr = true;
       }
-      hipLaunchKernelGGL(ql_kernel<true>, dim3(nleaf), dim3(64), (size_t)maxleaf * 16, ctx->stream, d_qm);
-      hipLaunchKernelGGL(zt_identity_kernel, dim3((maxleaf + 255) / 256, maxleaf, nleaf), dim3(256), 0, ctx->stream,
-                         d_rm);
-      hipLaunchKernelGGL(rot_apply_kernel, dim3((maxleaf + 255) / 256, nleaf), dim3(256), 0, ctx->stream, d_rm);
+      static const bool leaf_apply = !getenv("DM_QL_LEAF_RECORD");
+      if (leaf_apply && maxleaf <= 64) {
+        // rotations applied in LDS as they are generated (d, e and the n x n Z of a leaf: 16 n + 8 n^2 bytes)
+        hipLaunchKernelGGL((ql_kernel<true, true>), dim3(nleaf), dim3(64), (size_t)maxleaf * 16 + (size_t)maxleaf * maxleaf * 8,
+                           ctx->stream, d_qm);
+      } else {
+        hipLaunchKernelGGL(ql_kernel<true>, dim3(nleaf), dim3(64), (size_t)maxleaf * 16, ctx->stream, d_qm);
+        hipLaunchKernelGGL(zt_identity_kernel, dim3((maxleaf + 255) / 256, maxleaf, nleaf), dim3(256), 0, ctx->stream,
+                           d_rm);
+        hipLaunchKernelGGL(rot_apply_kernel, dim3((maxleaf + 255) / 256, nleaf), dim3(256), 0, ctx->stream, d_rm);
+      }
       DM_HIP(ctx, hipGetLastError());
       std::vector<int> hs(nleaf);
       DM_TRY(dm_download(ctx, hs.data(), stat, sizeof(int) * nleaf));
