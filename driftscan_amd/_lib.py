@@ -37,6 +37,7 @@ SIGNATURES = {
     "dm_last_error": (ctypes.c_char_p, [c_vp]),
     "dm_version": (c_int, []),
     "dm_prof_reset": (c_int, [c_vp, c_int]),
+    "dm_prof_trd_stride": (c_int, []),
     "dm_prof_report": (c_int, [c_vp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(ctypes.c_longlong)]),
     "dm_zgemm_strided_batched": (
         c_int,

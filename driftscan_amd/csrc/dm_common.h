@@ -35,13 +35,20 @@ struct dm_ctx {
   std::string err;
   // optional per-kernel-class timing (HIP events on ctx->stream) and flop accounting
   bool prof_on = false;
-  struct prof_rec { int cls; hipEvent_t a, b; double flops; };
+  struct prof_rec { int cls; hipEvent_t a, b; double flops; double weight = 1.0; };
+  unsigned prof_seq[16] = {0};  // per class: launches seen (small launches are timed one in DM_PROF_SMALL_STRIDE)
   std::vector<prof_rec> prof;
   std::vector<hipEvent_t> ev_pool;
   unsigned long long* prof_dev = nullptr;  // device flop counters, one per class
 };
 
-constexpr int DM_PROF_TRD_STRIDE = 8;  // every 8th column of the tridiagonalisation is timed
+// Event records are not free on a chain of thousands of short launches (each is a marker packet that breaks the
+// back-to-back dispatch: ~1200 of them cost 4-9 ms of a 170 ms step), so the live measurement SAMPLES: every
+// DM_PROF_TRD_STRIDE-th column of the tridiagonalisation, every launch of at least DM_PROF_BIG work units, and
+// one in DM_PROF_SMALL_STRIDE of the smaller launches of a class (weighted accordingly in dm_prof_report).
+constexpr int DM_PROF_TRD_STRIDE = 32;
+constexpr int DM_PROF_SMALL_STRIDE = 4;
+constexpr double DM_PROF_BIG = 2.0e9;
 // classes 0-5 carry algorithmic FLOPs, 6-7 (the HBM-bound tridiagonalisation kernels) algorithmic BYTES
 enum { DM_PROF_GEMM = 0, DM_PROF_GEMM_REAL = 1, DM_PROF_JAC_GRAM = 2, DM_PROF_JAC_INNER = 3, DM_PROF_JAC_APPLY = 4,
        DM_PROF_DGEMM = 5, DM_PROF_TRD_SYMV = 6, DM_PROF_TRD_WX = 7, DM_PROF_NCLASS = 8 };
@@ -49,15 +56,22 @@ enum { DM_PROF_GEMM = 0, DM_PROF_GEMM_REAL = 1, DM_PROF_JAC_GRAM = 2, DM_PROF_JA
 hipEvent_t dm_prof_event(dm_ctx* ctx);
 // bracket one launch: DM_PROF(ctx, cls, flops) { launch; }
 struct dm_prof_scope {
-  dm_ctx* c; int cls; double flops; hipEvent_t a = nullptr;
+  dm_ctx* c; int cls; double flops; hipEvent_t a = nullptr; double weight = 1.0;
   dm_prof_scope(dm_ctx* ctx, int cls_, double fl) : c(ctx), cls(cls_), flops(fl) {
-    if (c->prof_on) { a = dm_prof_event(c); (void)hipEventRecord(a, c->stream); }
+    if (!c->prof_on) return;
+    const bool gemm_class = cls == DM_PROF_GEMM || cls == DM_PROF_GEMM_REAL || cls == DM_PROF_DGEMM;
+    if (gemm_class && fl < DM_PROF_BIG) {  // (the Jacobi classes are a few dozen launches per step: all timed)
+      if (c->prof_seq[cls & 15]++ % DM_PROF_SMALL_STRIDE != 0) return;
+      weight = DM_PROF_SMALL_STRIDE;
+    }
+    a = dm_prof_event(c);
+    (void)hipEventRecord(a, c->stream);
   }
   ~dm_prof_scope() {
     if (c->prof_on && a) {
       hipEvent_t b = dm_prof_event(c);
       (void)hipEventRecord(b, c->stream);
-      c->prof.push_back(dm_ctx::prof_rec{cls, a, b, flops});
+      c->prof.push_back(dm_ctx::prof_rec{cls, a, b, flops, weight});
     }
   }
 };

@@ -142,6 +142,7 @@ int dm_prof_reset(dm_ctx* ctx, int enable) {
   DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (auto& r : ctx->prof) { ctx->ev_pool.push_back(r.a); ctx->ev_pool.push_back(r.b); }
   ctx->prof.clear();
+  for (auto& q : ctx->prof_seq) q = 0;
   if (!ctx->prof_dev) DM_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->prof_dev), sizeof(unsigned long long) * DM_PROF_NCLASS));
   DM_HIP(ctx, hipMemset(ctx->prof_dev, 0, sizeof(unsigned long long) * DM_PROF_NCLASS));
   ctx->prof_on = enable != 0;
@@ -150,15 +151,17 @@ int dm_prof_reset(dm_ctx* ctx, int enable) {
 
 // ms[c], flops[c], launches[c] for c < DM_PROF_NCLASS (= 8): summed event time, algorithmic
 // flops and launch count of each kernel class since dm_prof_reset.
+int dm_prof_trd_stride(void) { return DM_PROF_TRD_STRIDE; }
+
 int dm_prof_report(dm_ctx* ctx, double* ms, double* flops, long long* launches) {
   if (!ctx || !ms || !flops || !launches) return DM_EARG;
   DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int c = 0; c < DM_PROF_NCLASS; ++c) { ms[c] = 0.0; flops[c] = 0.0; launches[c] = 0; }
   for (auto& r : ctx->prof) {
     float t = 0.f;
-    if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ms[r.cls] += t;
-    flops[r.cls] += r.flops;
-    launches[r.cls] += 1;
+    if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ms[r.cls] += r.weight * t;
+    flops[r.cls] += r.weight * r.flops;
+    launches[r.cls] += (long long)r.weight;
   }
   if (ctx->prof_dev) {
     unsigned long long h[DM_PROF_NCLASS];

@@ -1808,7 +1808,8 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
           // Timed with events on every DM_PROF_TRD_STRIDE-th column only (event records on a chain of
           // ~2400 short launches are not free: all of them cost 7 % of the step); columns are sampled
           // uniformly, so the ratio bytes / time of the sample estimates the average of the kernel.
-          const bool timed = ctx->prof_on && (k % DM_PROF_TRD_STRIDE) == 0;
+          // (the sampled position walks through the panel: every column index j of a panel is drawn equally often)
+          const bool timed = ctx->prof_on && (k % DM_PROF_TRD_STRIDE) == ((k / DM_PROF_TRD_STRIDE) * 13) % DM_PROF_TRD_STRIDE;
           double by_symv = 0.0, by_wx = 0.0;
           if (timed)
             for (int p : ch) {
