@@ -12,4 +12,4 @@ with tempfile.TemporaryDirectory() as tmp:
     bench.hot_path_step(tel, bt, kl, ctx)
     torch.cuda.synchronize()
     pr.disable()
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
