@@ -81,6 +81,10 @@ SIGNATURES = {
     "dm_bt_beam_cyl": (
         c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int,
                 ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_dbl, c_vp]),
+    "dm_bt_beams_cyl": (
+        c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int,
+                ctypes.POINTER(c_int), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl),
+                ctypes.POINTER(c_int), ctypes.POINTER(c_dbl), c_vp, ctypes.c_size_t]),
     "dm_bt_maps": (
         c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_int, c_vp,
                 c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_vp]),
@@ -490,6 +494,33 @@ def _bt_beam_cyl(self, nside, cth, sth, frame, kind, tab, fwhm_ns, out):
     self.check(rc, "dm_bt_beam_cyl")
 
 
+def _bt_beams_cyl(self, nside, cth, sth, frame, specs, out, rows):
+    """Evaluate the cylinder patterns `specs` = [(kind, (x, y, y2), fwhm_ns), ...] into the rows `rows` of the 2-D
+    float64 device tensor `out` — consecutive rows go up in one dm_bt_beams_cyl call each."""
+    if not specs:
+        return
+    c, cp = _darr(cth)
+    s_, sp = _darr(sth)
+    fr, frp = _darr(frame)
+    stride = int(out.stride(0))
+    i = 0
+    while i < len(specs):
+        j = i + 1
+        while j < len(specs) and rows[j] == rows[j - 1] + 1:
+            j += 1
+        kinds, kp = _iarr([sp_[0] for sp_ in specs[i:j]])
+        fw, fwp = _darr([sp_[2] for sp_ in specs[i:j]])
+        offs = np.concatenate([[0], np.cumsum([len(sp_[1][0]) for sp_ in specs[i:j]])])
+        of, ofp = _iarr(offs)
+        tx, txp = _darr(np.concatenate([sp_[1][0] for sp_ in specs[i:j]]))
+        ty, typ = _darr(np.concatenate([sp_[1][1] for sp_ in specs[i:j]]))
+        t2, t2p = _darr(np.concatenate([sp_[1][2] for sp_ in specs[i:j]]))
+        rc = self.lib.dm_bt_beams_cyl(self.h, int(nside), cp, sp, frp, j - i, kp, txp, typ, t2p, ofp, fwp,
+                                      self.ptr(out[rows[i]]), stride)
+        self.check(rc, "dm_bt_beams_cyl")
+        i = j
+
+
 def _bt_maps(self, nside, cth, sth, frame, polarised, beams, uv, bi, bj, maps):
     c, cp = _darr(cth)
     s_, sp = _darr(sth)
@@ -555,6 +586,7 @@ def _bt_columns(self, nside, cth, sth, frame, polarised, beams, uv, bi, bj, lsid
 
 Context.bt_columns = _bt_columns
 Context.bt_beam_cyl = _bt_beam_cyl
+Context.bt_beams_cyl = _bt_beams_cyl
 Context.bt_maps = _bt_maps
 Context.bt_sht = _bt_sht
 

@@ -103,6 +103,7 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
             hostb = {key: tel._beam_host(feed_of[key], key[0], int(nside)) for key in keys if specs[key] is None}
             cbeams = any(np.iscomplexobj(b) for b in hostb.values())   # complex patterns: _construct_pol_complex
             beams = ctx.empty((len(keys), npix * ncomp), np.complex128 if cbeams else np.float64)
+            dev_specs, dev_rows = [], []
             for key, idx in keys.items():
                 if specs[key] is None:
                     beams[idx].copy_(ctx.to_device(hostb[key].reshape(-1)))
@@ -113,7 +114,10 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
                     ctx.bt_beam_cyl(int(nside), cth, sth, frame, kind, tab, fwhm_ns, tmp)
                     beams[idx].copy_(tmp)
                 else:
-                    ctx.bt_beam_cyl(int(nside), cth, sth, frame, kind, tab, fwhm_ns, beams[idx])
+                    dev_specs.append(specs[key])
+                    dev_rows.append(idx)
+            # all device-evaluated patterns of the chunk in one call (geometry and tables staged once)
+            ctx.bt_beams_cyl(int(nside), cth, sth, frame, dev_specs, beams, dev_rows)
             del hostb
             if cbeams and fused:
                 raise ValueError("%s.beam() returned a complex field pattern: set `complex_beams = True` on the class "

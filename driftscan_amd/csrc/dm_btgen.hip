@@ -24,6 +24,7 @@
 // The SHT itself is restated from the published HEALPix algorithm (equal weights,
 // no iterations): see oracle/btgen.py for the pinning status of that boundary.
 #include "dm_common.h"
+#include <cstring>
 #include "dm_kernels.h"
 #include "../../include/driftmi.h"
 
@@ -706,12 +707,21 @@ int upload_geo(dm_ctx* ctx, int nside, const double* cth, const double* sth, geo
   }
   gh.g.nring = nring;
   gh.g.npix = acc;
-  gh.g.cth = dm_ws_upload(ctx, gh.cth);
-  gh.g.sth = dm_ws_upload(ctx, gh.sth);
-  gh.g.phi0 = dm_ws_upload(ctx, gh.phi0);
-  gh.g.nphi = dm_ws_upload(ctx, gh.nphi);
-  gh.g.start = dm_ws_upload(ctx, gh.start);
-  if (!gh.g.cth || !gh.g.sth || !gh.g.phi0 || !gh.g.nphi || !gh.g.start) return DM_ENOMEM;
+  // one staged copy for the five arrays (every descriptor upload is a copy kernel of its own in the stream)
+  std::vector<double> blob(4 * (size_t)nring);
+  std::memcpy(blob.data(), gh.cth.data(), sizeof(double) * nring);
+  std::memcpy(blob.data() + nring, gh.sth.data(), sizeof(double) * nring);
+  std::memcpy(blob.data() + 2 * (size_t)nring, gh.phi0.data(), sizeof(double) * nring);
+  int* ib = reinterpret_cast<int*>(blob.data() + 3 * (size_t)nring);
+  std::memcpy(ib, gh.nphi.data(), sizeof(int) * nring);
+  std::memcpy(ib + nring, gh.start.data(), sizeof(int) * nring);
+  double* d = dm_ws_upload(ctx, blob);
+  if (!d) return DM_ENOMEM;
+  gh.g.cth = d;
+  gh.g.sth = d + nring;
+  gh.g.phi0 = d + 2 * (size_t)nring;
+  gh.g.nphi = reinterpret_cast<const int*>(d + 3 * (size_t)nring);
+  gh.g.start = gh.g.nphi + nring;
   return DM_OK;
 }
 
@@ -754,6 +764,43 @@ int dm_bt_beam_cyl(dm_ctx* ctx, int nside, const double* ring_cth_host, const do
                      dy2, ntab, alpha, out_dev);
   DM_HIP(ctx, hipGetLastError());
   dm_ws_release(ctx, mark);
+  return DM_OK;
+}
+
+// nbeam cylinder patterns in one call: geometry and spline tables go up in two staged copies instead of eight per beam.
+//   kind_host, fwhm_ns_host (nbeam); tab_off_host (nbeam + 1): beam b uses knots [tab_off[b], tab_off[b + 1]) of the
+//   concatenated tab_x / tab_y / tab_y2 arrays; out_dev row b starts at out_dev + b * out_stride (doubles)
+int dm_bt_beams_cyl(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host,
+                    const double* frame_host, int nbeam, const int* kind_host, const double* tab_x_host,
+                    const double* tab_y_host, const double* tab_y2_host, const int* tab_off_host,
+                    const double* fwhm_ns_host, double* out_dev, size_t out_stride) {
+  if (!ctx) return DM_EARG;
+  DM_ARG(ctx, nside > 0 && ring_cth_host && ring_sth_host && frame_host && nbeam >= 0 && kind_host && tab_x_host &&
+                  tab_y_host && tab_y2_host && tab_off_host && fwhm_ns_host && out_dev);
+  if (nbeam == 0) return DM_OK;
+  dm_ws_scope ws_scope__(ctx);  // releases on every return path
+  geo_host gh;
+  DM_TRY(upload_geo(ctx, nside, ring_cth_host, ring_sth_host, gh));
+  const int ntot = tab_off_host[nbeam];
+  for (int b = 0; b < nbeam; ++b) {
+    DM_ARG(ctx, kind_host[b] >= 0 && kind_host[b] <= 2 && tab_off_host[b + 1] - tab_off_host[b] >= 2);
+    DM_ARG(ctx, out_stride >= (size_t)gh.g.npix * (kind_host[b] == 0 ? 1 : 2));
+  }
+  std::vector<double> tabs(3 * (size_t)ntot);
+  std::memcpy(tabs.data(), tab_x_host, sizeof(double) * ntot);
+  std::memcpy(tabs.data() + ntot, tab_y_host, sizeof(double) * ntot);
+  std::memcpy(tabs.data() + 2 * (size_t)ntot, tab_y2_host, sizeof(double) * ntot);
+  double* dt = dm_ws_upload(ctx, tabs);
+  if (!dt) return DM_ENOMEM;
+  frame3 fr = make_frame(frame_host, frame_host + 3, frame_host + 6);
+  for (int b = 0; b < nbeam; ++b) {
+    const int o = tab_off_host[b], nt = tab_off_host[b + 1] - o;
+    const double th = tan(fwhm_ns_host[b] / 2.0);
+    const double alpha = log(2.0) / (2.0 * th * th);
+    hipLaunchKernelGGL(bt_beam_kernel, dim3((gh.g.npix + 255) / 256), dim3(256), 0, ctx->stream, gh.g, fr, kind_host[b],
+                       dt + o, dt + ntot + o, dt + 2 * (size_t)ntot + o, nt, alpha, out_dev + (size_t)b * out_stride);
+  }
+  DM_HIP(ctx, hipGetLastError());
   return DM_OK;
 }
 

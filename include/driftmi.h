@@ -247,6 +247,14 @@ int dm_bt_beam_cyl(dm_ctx* ctx, int nside, const double* ring_cth_host, const do
                    const double* frame_host, int kind, const double* tab_x_host, const double* tab_y_host,
                    const double* tab_y2_host, int ntab, double fwhm_ns, double* out_dev);
 
+/* dm_bt_beams_cyl: nbeam patterns of dm_bt_beam_cyl in one call (one upload of the ring geometry and one of all spline
+ * tables instead of eight staged copies per beam).  tab_off_host (nbeam + 1) delimits the knots of each beam in the
+ * concatenated tab_x / tab_y / tab_y2 arrays; row b of the output starts at out_dev + b * out_stride (doubles). */
+int dm_bt_beams_cyl(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host,
+                    const double* frame_host, int nbeam, const int* kind_host, const double* tab_x_host,
+                    const double* tab_y_host, const double* tab_y2_host, const int* tab_off_host,
+                    const double* fwhm_ns_host, double* out_dev, size_t out_stride);
+
 /* dm_bt_maps: complex visibility response maps for ncol (frequency, baseline) columns:
  * h * fringe * (b_i x b_j) / sqrt(Omega_i Omega_j) -> (ncol, P, npix) c128 with P = 4
  * (I, Q, U, V) if polarised else 1.  beams_dev: nbeam maps from dm_bt_beam_cyl;

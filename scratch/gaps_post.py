@@ -60,3 +60,20 @@ t0 = seg[0][0]
 for nm, s, cnt, busy, idle in runs:
     if busy > 3e5 or idle > 1e5:
         print("%8.2f  %-40s x%-5d busy %7.2f  idle %6.2f" % ((s - t0) / 1e6, nm[:40], cnt, busy / 1e6, idle / 1e6))
+
+print("\n---- what follows the descriptor uploads (__amd_rocclr_copyBuffer) in the step")
+import collections
+h = collections.Counter()
+i = 0
+while i < len(seg):
+    if "copyBuffer" in seg[i][2]:
+        j = i
+        while j < len(seg) and ("copyBuffer" in seg[j][2] or "fillBuffer" in seg[j][2]):
+            j += 1
+        nxt = short(seg[j][2]) if j < len(seg) else "END"
+        h[nxt] += sum(1 for q in range(i, j) if "copyBuffer" in seg[q][2])
+        i = j
+    else:
+        i += 1
+for k, v in h.most_common(25):
+    print("%5d  %s" % (v, k))
