@@ -440,8 +440,8 @@ def main():
         value = (nblocks if sharded else world * nblocks) * args.steps / dt
         if rank == 0:
             st = np.array(stage).mean(axis=0)
-            trd_stride = float(ctx.lib.dm_prof_trd_stride())  # the column loop is sampled (every stride-th column)
-            dom = max(prof, key=lambda k: prof[k]["ms"] * (trd_stride if k in HBM_CLASSES else 1.0)) if prof else None
+            trd_stride = int(ctx.lib.dm_prof_trd_stride())  # the column loop is sampled; the library scales the figures
+            dom = max(prof, key=lambda k: prof[k]["ms"]) if prof else None
             roofline = None
             # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this
             # process, so the figure comes from the committed rocprofv3 --pmc passes of this same
@@ -477,8 +477,9 @@ def main():
                                     traffic_source=traffic_src, launches=p["launches"],
                                     avg_launch_us=1e3 * p["ms"] / max(p["launches"], 1),
                                     bytes_per_launch=p["flops"] / max(p["launches"], 1),
-                                    sampling="every %dth launch of the column loop is timed (uniform in k); "
-                                             "`launches` counts the timed ones" % int(trd_stride))
+                                    sampling="every %dth launch of the column loop is bracketed by events (position "
+                                             "walking through the panels); time, bytes and `launches` are the samples "
+                                             "scaled by %d" % (trd_stride, trd_stride))
                 else:
                     ach = p["flops"] / secs / 1e12 if secs > 0 else 0.0
                     roofline = dict(bound="mfma", kernel=dom, achieved=ach, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
@@ -489,12 +490,12 @@ def main():
                 # the runner-up class of the other kind, for context (MFMA vs HBM side of the step)
                 others = [k for k in prof if (k in HBM_CLASSES) != (dom in HBM_CLASSES)]
                 if others:
-                    o = max(others, key=lambda k: prof[k]["ms"] * (trd_stride if k in HBM_CLASSES else 1.0))
+                    o = max(others, key=lambda k: prof[k]["ms"])
                     q = prof[o]
                     if o in HBM_CLASSES:
                         oa = q["flops"] / (q["ms"] * 1e-3) / 1e9
                         roofline["also"] = dict(kernel=o, bound="hbm", achieved=oa, unit="GB/s", frac=oa / HBM_PEAK_GBS,
-                                                ms_per_step=trd_stride * q["ms"] / args.steps)
+                                                ms_per_step=q["ms"] / args.steps)
                     else:
                         oa = q["flops"] / (q["ms"] * 1e-3) / 1e12
                         roofline["also"] = dict(kernel=o, bound="mfma", achieved=oa, unit="TFLOP/s",
@@ -542,8 +543,7 @@ def main():
                 "stage_ms": {"btgen": 1e3 * st[0], "svd": 1e3 * st[1], "kl": 1e3 * st[2], "collectives": 1e3 * st[3]},
                 "stages": stages,
                 # the two tridiagonalisation classes are timed on every 8th launch: scaled back to all launches
-                "kernels_ms": {k: v["ms"] / args.steps * (float(ctx.lib.dm_prof_trd_stride()) if k in HBM_CLASSES else 1.0)
-                               for k, v in prof.items()},
+                "kernels_ms": {k: v["ms"] / args.steps for k, v in prof.items()},
                 "roofline": roofline,
                 "cpu_baseline": cpu,
             }

@@ -1831,8 +1831,9 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
           if (timed) {
             e2 = dm_prof_event(ctx);
             (void)hipEventRecord(e2, ctx->stream);
-            ctx->prof.push_back(dm_ctx::prof_rec{DM_PROF_TRD_SYMV, e0, e1, by_symv});
-            ctx->prof.push_back(dm_ctx::prof_rec{DM_PROF_TRD_WX, e1b, e2, by_wx});
+            // weight = stride: dm_prof_report returns estimates of the totals over ALL columns
+            ctx->prof.push_back(dm_ctx::prof_rec{DM_PROF_TRD_SYMV, e0, e1, by_symv, (double)DM_PROF_TRD_STRIDE});
+            ctx->prof.push_back(dm_ctx::prof_rec{DM_PROF_TRD_WX, e1b, e2, by_wx, (double)DM_PROF_TRD_STRIDE});
           }
         }
       }

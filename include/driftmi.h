@@ -45,9 +45,9 @@ const char* dm_last_error(dm_ctx* ctx);
 int dm_version(void);
 
 /* dm_prof_trd_stride: the live measurement samples — every dm_prof_trd_stride()-th column of the tridiagonalisation
- * is bracketed by events (its two classes report the sampled launches only: scale their time by the stride for a
- * per-step total), every launch of >= 2e9 work units of the other classes, and one in four of the smaller ones
- * (weighted by four in dm_prof_report).  Event records cost a marker packet each. */
+ * is bracketed by events, every launch of >= 2e9 work units of the other classes, and one in four of the smaller
+ * ones; dm_prof_report weights the samples (by the stride / by four), so its figures estimate the totals over all
+ * launches and `launches` the number of launches.  Event records cost a marker packet each. */
 int dm_prof_trd_stride(void);
 
 /* Per-kernel-class instrumentation for bench.py: when enabled every launch of the
