@@ -1850,13 +1850,12 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
                                    1.0, nullptr, DM_GEMM_UPPER));
         }
         DM_TRY(dm_gemm_grouped_launch(ctx, g));
-        // next panel starts from clean V, W
-        if ((int)ch.size() == np) {
-          DM_TRY(dm_fill_zero(ctx, PP, sizeof(cplx) * totn * 3 * TNB));
-        } else {
-          for (int p : ch)
-            DM_TRY(dm_fill_zero(ctx, PP + offn[p] * 3 * TNB, sizeof(cplx) * (size_t)probs[p].n * 3 * TNB));
-        }
+        // The panel buffers are NOT cleared between panels: every entry a kernel reads has been written inside the
+        // current panel — trd_symv / trd_wx read the vectors q < j at rows > k only (v_q and w_q are written for all
+        // rows > k0 + q), the her2k above reads rows >= k1 of all TNB vectors of a FULL panel (a matrix that ends
+        // inside the panel has n - k1 <= 0 and takes no part).  (170 MB of memset per panel at configs[1].)
+        static const bool clear_panels = getenv("DM_TRD_CLEAR_PANELS") != nullptr;
+        if (clear_panels) DM_TRY(dm_fill_zero(ctx, PP, sizeof(cplx) * totn * 3 * TNB));
       }
     }
     DM_HIP(ctx, hipGetLastError());
