@@ -1,0 +1,647 @@
+// dm_sbr_impl.h — two-stage tridiagonalisation (dense -> band on MFMA, band -> tridiagonal by bulge chasing)
+// and the back-transformation of the second stage.  Included by dm_tridiag_impl.h inside the namespace of
+// the 32-wide instantiation (the bandwidth is the panel width TNB = 32).  No include guard on purpose.
+//
+// Replaces the zhetrd inside scipy.linalg.eigh (drift/core/kltransform.py:89, :107) by the LAPACK 3.7
+// two-stage scheme (zhetrd_he2hb + zhetrd_hb2st):
+//
+//   S1  dense -> band, bandwidth SB = 32.  Per panel of 32 columns: Householder QR of the block below the
+//       band (sb_qr_* kernels, or the one-workgroup-per-matrix kernel for small matrices), T factor, then the
+//       two-sided update  A22 <- Q^H A22 Q  as level-3 products through the grouped ZGEMM:
+//         Y = A22 (V T),  W = Y - V (T^H V^H Y) / 2,  A22 -= V W^H + W V^H      (16 n^3 / 3 flop, MFMA-bound)
+//       The trailing matrix is read 3 times per 32 columns instead of once per column: 5-10 x fewer HBM
+//       bytes than the one-stage reduction (8 n^3 / 3 bytes), which is HBM-bound at 0.5 of the roofline.
+//   S2  band -> real tridiagonal: sweep s annihilates column s below the sub-diagonal and chases the bulge
+//       down the band with reflectors of length <= 32 (sb_chase_kernel).  One WAVE runs one sweep; a 32 x 32
+//       block lives in the registers of the wave as 4 x 4 sub-blocks per lane (row and column reductions are
+//       three butterfly steps each); sweep s + 1 follows sweep s two blocks behind, synchronised through
+//       progress words (LDS within a workgroup, agent-scope flags across workgroups for one large matrix).
+//   B2  X = Q2 Z: the n^2 / 64 short reflectors are applied by sb_q2_apply_kernel to column slabs of X that
+//       stay in registers while a group of sweeps passes over them (VALU fp64 — as fast as the fp64 MFMA on
+//       this part — with no T factors and no padding flops); slabs are independent, no inter-workgroup sync.
+//   B1  X = Q1 (Q2 Z): the compact-WY path of the one-stage solver with the T factors of S1.
+
+constexpr int SB = TNB;       // bandwidth = reflector length of the chase
+constexpr int SLD = 2 * SB;   // band storage: column c holds A[c .. c + 2 SB - 1][c] (band + bulge)
+constexpr int SQR = 256;      // indices per workgroup in the launched panel-QR kernels
+constexpr int SBG = 32;       // sweeps per group in the second-stage back-transformation
+constexpr int SBW = SBG + SB; // window rows of a diamond block (SBG + SB - 1, padded)
+
+struct sb_mat {
+  cplx* A; int lda; int n;
+  cplx* Vt;     // n x n: row k = reflector of column k (first stage): zero below index k + SB, 1 at k + SB
+  cplx* Vp;     // SB x n panel of V, then W, then V again (her2k layout, see trd_mat)
+  cplx* Wp;
+  cplx* Vp2;
+  cplx* Pw;     // SB x n: working copy of the panel columns, row q = column k0 + q of the Hermitian matrix
+  cplx* tau;    // n
+  cplx* Yp;     // (n / SQR + 1) x SB: partial dot products v_q^H P[:, c]
+  double* Np;   // 2 x (n / SQR + 1): partial norms (double-buffered over q)
+  int npstride; // n / SQR + 1
+};
+
+// ---- S1: launched panel QR (any size; two launches per column, all matrices in lock-step) ----------------------
+
+// copy the panel columns into the work array (math orientation) and clear the panel rows above the panel
+__global__ __launch_bounds__(256) void sb_panel_load_kernel(const sb_mat* __restrict__ ms, int k0, int a0) {
+  const sb_mat M = ms[blockIdx.y];
+  const int n = M.n;
+  if (n - k0 - SB < 2) return;
+  const int i = a0 + blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int i0 = k0 + SB;
+  const cplx z = make_double2(0.0, 0.0);
+  if (i >= i0) {
+#pragma unroll 4
+    for (int q = 0; q < SB; ++q) dm_stg(M.Pw, (size_t)q * n + i, cconj(dm_ldg(M.A, (size_t)(k0 + q) * M.lda + i)));
+  } else {
+    for (int q = 0; q < SB; ++q) {
+      dm_stg(M.Vp, (size_t)q * n + i, z);
+      dm_stg(M.Vp2, (size_t)q * n + i, z);
+      dm_stg(M.Wp, (size_t)q * n + i, z);
+    }
+  }
+}
+
+__device__ __forceinline__ double sb_block_sum(double v, double* red) {
+  v = dm_wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// K_a(q): finish reflector q - 1 (apply it to the columns c >= q, write v, R and tau), partial norms of column q
+__global__ __launch_bounds__(256) void sb_qr_update_kernel(const sb_mat* __restrict__ ms, int k0, int q) {
+  const sb_mat M = ms[blockIdx.y];
+  const int n = M.n;
+  const int m = n - k0 - SB;
+  if (m < 2) return;
+  const int nch = (m + SQR - 1) / SQR;
+  if ((int)blockIdx.x >= nch) return;
+  const int nrf = min(SB, m - 1);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int i = k0 + SB + blockIdx.x * SQR + tid;
+  const bool valid = i < n;
+  __shared__ cplx ys[SB];
+  __shared__ double red[4];
+  if (q >= 1) {
+    const int r = q - 1;
+    const int lead = k0 + SB + r;
+    if (r < nrf) {
+      double np = 0.0;
+      const double* Npr = M.Np + (size_t)(r & 1) * M.npstride;
+      for (int t = lane; t < nch; t += 64) np += dm_ldg(Npr, t);
+      const cplx alpha = dm_ldg(M.Pw, (size_t)r * n + lead);
+      const trd_refl R = trd_reflector_from(np, alpha);
+      if (tid < SB) {
+        cplx acc = make_double2(0.0, 0.0);
+        if (tid >= q)
+          for (int t = 0; t < nch; ++t) acc = cadd(acc, dm_ldg(M.Yp, (size_t)t * SB + tid));
+        ys[tid] = acc;
+      }
+      __syncthreads();
+      if (valid) {
+        const cplx x = dm_ldg(M.Pw, (size_t)r * n + i);
+        cplx v = cmul(x, R.scal);
+        if (i == lead) v = make_double2(1.0, 0.0);
+        if (i < lead) v = make_double2(0.0, 0.0);
+        if (i >= lead) {
+          const cplx tv = cmul(cconj(R.tau), v);  // H^H a = a - conj(tau) v (v^H a)
+          for (int c = q; c < SB; ++c) {
+            const cplx a = dm_ldg(M.Pw, (size_t)c * n + i);
+            dm_stg(M.Pw, (size_t)c * n + i, csub(a, cmul(tv, ys[c])));
+          }
+        }
+        dm_stg(M.Vp, (size_t)r * n + i, v);
+        dm_stg(M.Vp2, (size_t)r * n + i, v);
+        dm_stg(M.Vt, (size_t)(k0 + r) * n + i, v);
+        if (i <= lead) dm_stg(M.A, (size_t)(k0 + r) * M.lda + i, i < lead ? cconj(x) : make_double2(R.beta, 0.0));
+      }
+      if (blockIdx.x == 0 && tid == 0) M.tau[k0 + r] = R.tau;
+    } else {
+      if (valid) {
+        const cplx z = make_double2(0.0, 0.0);
+        dm_stg(M.Vp, (size_t)r * n + i, z);
+        dm_stg(M.Vp2, (size_t)r * n + i, z);
+        dm_stg(M.Vt, (size_t)(k0 + r) * n + i, z);
+        dm_stg(M.A, (size_t)(k0 + r) * M.lda + i, cconj(dm_ldg(M.Pw, (size_t)r * n + i)));
+      }
+      if (blockIdx.x == 0 && tid == 0) M.tau[k0 + r] = make_double2(0.0, 0.0);
+    }
+  }
+  if (q < nrf) {
+    double s = 0.0;
+    if (valid && i > k0 + SB + q) s = cabs2(dm_ldg(M.Pw, (size_t)q * n + i));
+    s = sb_block_sum(s, red);
+    if (tid == 0) M.Np[(size_t)(q & 1) * M.npstride + blockIdx.x] = s;
+  }
+}
+
+// K_b(q): partial dot products v_q^H P[:, c], c > q, of this workgroup's rows
+__global__ __launch_bounds__(256) void sb_qr_dots_kernel(const sb_mat* __restrict__ ms, int k0, int q) {
+  const sb_mat M = ms[blockIdx.y];
+  const int n = M.n;
+  const int m = n - k0 - SB;
+  if (m < 2) return;
+  const int nch = (m + SQR - 1) / SQR;
+  if ((int)blockIdx.x >= nch) return;
+  const int nrf = min(SB, m - 1);
+  if (q >= nrf) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = k0 + SB + blockIdx.x * SQR + tid;
+  const int lead = k0 + SB + q;
+  double np = 0.0;
+  const double* Npr = M.Np + (size_t)(q & 1) * M.npstride;
+  for (int t = lane; t < nch; t += 64) np += dm_ldg(Npr, t);
+  const cplx alpha = dm_ldg(M.Pw, (size_t)q * n + lead);
+  const trd_refl R = trd_reflector_from(np, alpha);
+  cplx v = make_double2(0.0, 0.0);
+  if (i < n && i >= lead) {
+    v = cmul(dm_ldg(M.Pw, (size_t)q * n + i), R.scal);
+    if (i == lead) v = make_double2(1.0, 0.0);
+  }
+  __shared__ cplx part[4][SB];
+  for (int c = q + 1; c < SB; ++c) {
+    cplx t = make_double2(0.0, 0.0);
+    if (i < n && i >= lead) {
+      const cplx a = dm_ldg(M.Pw, (size_t)c * n + i);
+      t = make_double2(v.x * a.x + v.y * a.y, v.x * a.y - v.y * a.x);  // conj(v) * a
+    }
+    t.x = dm_wave_sum(t.x);
+    t.y = dm_wave_sum(t.y);
+    if (lane == 0) part[wave][c] = t;
+  }
+  __syncthreads();
+  if (tid > q && tid < SB) {
+    const cplx s = cadd(cadd(part[0][tid], part[1][tid]), cadd(part[2][tid], part[3][tid]));
+    M.Yp[(size_t)blockIdx.x * SB + tid] = s;
+  }
+}
+
+// make the 64-aligned diagonal tiles complete (lower part <- conj of the upper part): the products
+// Y = A22 X of the first stage read whole diagonal tiles, the her2k updates keep them complete
+struct sb_dmat { cplx* A; int lda; int n; };
+__global__ __launch_bounds__(256) void sb_diag_tiles_kernel(const sb_dmat* __restrict__ ms) {
+  const sb_dmat M = ms[blockIdx.y];
+  const int t0 = blockIdx.x * 64;
+  if (t0 >= M.n) return;
+  for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+    const int r = t0 + idx / 64, c = t0 + idx % 64;
+    if (r < M.n && c < r) dm_stg(M.A, (size_t)r * M.lda + c, cconj(dm_ldg(M.A, (size_t)c * M.lda + r)));
+  }
+}
+
+// band extraction: AB[c][i] = A_math[c + i][c] = conj(C[c][c + i]), i <= SB; the bulge rows start at zero
+struct sb_bmat { const cplx* A; int lda; int n; cplx* AB; };
+__global__ __launch_bounds__(256) void sb_band_extract_kernel(const sb_bmat* __restrict__ ms) {
+  const sb_bmat M = ms[blockIdx.y];
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)M.n * SLD) return;
+  const int c = (int)(idx / SLD), i = (int)(idx % SLD);
+  cplx v = make_double2(0.0, 0.0);
+  if (i <= SB && c + i < M.n) {
+    v = cconj(dm_ldg(M.A, (size_t)c * M.lda + c + i));
+    if (i == 0) v.y = 0.0;
+  }
+  dm_stg(M.AB, idx, v);
+}
+
+// ---- S2: bulge chasing ---------------------------------------------------------------------------------------------
+//
+// Sweep s, task 0:   x = A[s+1 : s+1+SB, s]  ->  H_0 (zlarfg);  A[s+1, s] = beta = e[s];  D_0 <- H_0^H D_0 H_0
+//          task j>0: E_j = A[R_j, R_{j-1}]   (R_j = s + 1 + j SB + [0, SB))
+//                    E_j <- E_j H_{j-1};  H_j from the first column of E_j;  E_j <- H_j^H E_j;  D_j <- H_j^H D_j H_j
+// Task j of sweep s may start once sweep s - 1 has finished its task j + 1 (the two share one row / column).
+//
+// Reflector (s, j) is stored where the back-transformation wants it: group G = s / SBG, member i = s % SBG of the
+// diamond block (G, j) — a SBG x SBW array whose row i holds the vector at columns [i, i + SB) and zeros elsewhere
+// (the window of block (G, j) starts at row G SBG + 1 + j SB of X).
+struct sb_chase_mat {
+  cplx* AB; int n;
+  cplx* Vd;        // diamond blocks: ((G * jb + j) * SBG + i) * SBW
+  cplx* tau2;      // (G * jb + j) * SBG + i
+  double* d; double* e;
+  int jb;          // blocks per sweep group: (n - 2) / SB + 1
+  unsigned* prog;  // multi-workgroup mode: one progress word per sweep (zero-initialised)
+  int* next;       // multi-workgroup mode: sweep counter (zero-initialised)
+};
+
+constexpr unsigned SB_DONE = 0xffffu;
+
+__device__ __forceinline__ double sb_xor(double v, int m) { return __shfl_xor(v, m, 64); }
+// sum over the lanes that share the block ROW (bits 0..2 of the lane differ)
+__device__ __forceinline__ cplx sb_sum_bc(cplx v) {
+  v.x += sb_xor(v.x, 1); v.y += sb_xor(v.y, 1);
+  v.x += sb_xor(v.x, 2); v.y += sb_xor(v.y, 2);
+  v.x += sb_xor(v.x, 4); v.y += sb_xor(v.y, 4);
+  return v;
+}
+// sum over the lanes that share the block COLUMN (bits 3..5 differ)
+__device__ __forceinline__ cplx sb_sum_br(cplx v) {
+  v.x += sb_xor(v.x, 8); v.y += sb_xor(v.y, 8);
+  v.x += sb_xor(v.x, 16); v.y += sb_xor(v.y, 16);
+  v.x += sb_xor(v.x, 32); v.y += sb_xor(v.y, 32);
+  return v;
+}
+__device__ __forceinline__ cplx sb_from_lane(cplx v, int src) {
+  return make_double2(__shfl(v.x, src, 64), __shfl(v.y, src, 64));
+}
+
+// Householder scalars from alpha and the squared norm of the rest (zlarfg), every lane the same
+__device__ __forceinline__ trd_refl sb_reflector(double xnorm2, cplx alpha) {
+  trd_refl R;
+  if (xnorm2 == 0.0 && alpha.y == 0.0) {
+    R.tau = make_double2(0.0, 0.0);
+    R.beta = alpha.x;
+    R.scal = make_double2(0.0, 0.0);
+  } else {
+    R.beta = -copysign(sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xnorm2), alpha.x);
+    R.tau = make_double2((R.beta - alpha.x) / R.beta, -alpha.y / R.beta);
+    const double dr = alpha.x - R.beta, di = alpha.y;
+    const double den = dr * dr + di * di;
+    R.scal = make_double2(dr / den, -di / den);
+  }
+  return R;
+}
+
+// MULTI = false: one workgroup per matrix, progress words in LDS (workgroup-scope ordering);
+// MULTI = true: several workgroups share one matrix, progress words and the sweep counter in global memory
+// with agent-scope release / acquire around the band accesses.
+template <bool MULTI, int NW>
+__global__ __launch_bounds__(64 * NW) void sb_chase_kernel(const sb_chase_mat* __restrict__ ms, int wg_per_mat) {
+  const sb_chase_mat M = ms[MULTI ? blockIdx.x / wg_per_mat : blockIdx.x];
+  const int n = M.n;
+  const int lane = threadIdx.x & 63;
+  const int br = lane >> 3, bc = lane & 7;
+  __shared__ unsigned lprog[64];
+  __shared__ int lnext;
+  if (!MULTI) {
+    if (threadIdx.x < 64) lprog[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) lnext = 0;
+    __syncthreads();
+  }
+  if (n == 1) {
+    if (threadIdx.x == 0 && (!MULTI || blockIdx.x % wg_per_mat == 0)) M.d[0] = dm_ldg(M.AB, 0).x;
+    return;
+  }
+  cplx* AB = M.AB;
+  for (;;) {
+    int s = 0;
+    if (lane == 0) s = MULTI ? atomicAdd(M.next, 1) : atomicAdd(&lnext, 1);
+    s = __builtin_amdgcn_readfirstlane(s);
+    if (s >= n - 1) break;
+    const int G = s / SBG, gi = s % SBG;
+    unsigned seen = (s == 0) ? SB_DONE : 0u;  // tasks of sweep s - 1 known to be finished
+    cplx vrow[4], vcol[4];  // the current reflector by block rows / block columns of this lane
+    cplx tau = make_double2(0.0, 0.0);
+    for (int j = 0;; ++j) {
+      const int r0 = s + 1 + j * SB;  // first row of R_j
+      if (r0 >= n) break;
+      const int nr = min(SB, n - r0);
+      // ---- wait for sweep s - 1 to have finished task j + 1
+      if (seen < (unsigned)(j + 2)) {
+        for (;;) {
+          unsigned v;
+          if (MULTI) {
+            v = __hip_atomic_load(M.prog + (s - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            const unsigned w = __hip_atomic_load(&lprog[(s - 1) & 63], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned tag = w >> 16;
+            v = tag == (unsigned)s ? (w & 0xffffu) : (tag > (unsigned)s ? SB_DONE : 0u);  // tag = sweep + 1
+          }
+          if (v >= (unsigned)(j + 2)) { seen = v; break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        if (MULTI) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+      bool reflect = true;
+      double beta = 0.0;
+      if (j == 0) {
+        // ---- task 0: reflector from column s
+        if (lane == 0) M.d[s] = dm_ldg(AB, (size_t)s * SLD).x;
+        cplx x[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int rr = 4 * br + a;
+          x[a] = (rr < nr) ? dm_ldg(AB, (size_t)s * SLD + 1 + rr) : make_double2(0.0, 0.0);
+        }
+        double sq = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          if (4 * br + a > 0) sq += cabs2(x[a]);
+        cplx t = sb_sum_br(make_double2(sq, 0.0));
+        const double xn2 = __shfl(t.x, 0, 64);
+        const cplx alpha = sb_from_lane(x[0], 0);
+        const trd_refl R = sb_reflector(xn2, alpha);
+        tau = R.tau;
+        beta = R.beta;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int rr = 4 * br + a;
+          cplx v = cmul(x[a], R.scal);
+          if (rr == 0) v = make_double2(1.0, 0.0);
+          if (rr >= nr) v = make_double2(0.0, 0.0);
+          vrow[a] = v;
+        }
+        if (bc == 0) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const int rr = 4 * br + a;
+            if (rr < nr) dm_stg(AB, (size_t)s * SLD + 1 + rr, rr == 0 ? make_double2(beta, 0.0) : make_double2(0.0, 0.0));
+          }
+        }
+        if (lane == 0) M.e[s] = beta;
+      } else {
+        // ---- E <- E H_{j-1}, new reflector from its first column, E <- H_j^H E
+        const int c0 = r0 - SB;
+        cplx e[4][4];
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+          const int c = c0 + 4 * bc + bb;
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const int r = r0 + 4 * br + a;
+            e[a][bb] = (r < n) ? dm_ldg(AB, (size_t)c * SLD + (r - c)) : make_double2(0.0, 0.0);
+          }
+        }
+        cplx w[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) acc = cadd(acc, cmul(e[a][bb], vcol[bb]));
+          w[a] = cmul(tau, sb_sum_bc(acc));
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) e[a][bb] = csub(e[a][bb], cmulc(w[a], vcol[bb]));
+        reflect = nr >= 2;
+        cplx tauj = make_double2(0.0, 0.0);
+        cplx vnew[4];
+        if (reflect) {
+          double sq = 0.0;
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+            if (4 * br + a > 0 && 4 * br + a < nr) sq += cabs2(e[a][0]);
+          if (bc != 0) sq = 0.0;
+          cplx t = sb_sum_br(make_double2(sq, 0.0));
+          const double xn2 = __shfl(t.x, 0, 64);
+          const cplx alpha = sb_from_lane(e[0][0], 0);
+          const trd_refl R = sb_reflector(xn2, alpha);
+          tauj = R.tau;
+          beta = R.beta;
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const int rr = 4 * br + a;
+            cplx x = sb_from_lane(e[a][0], lane & ~7);  // first column lives in the lanes bc == 0
+            cplx v = cmul(x, R.scal);
+            if (rr == 0) v = make_double2(1.0, 0.0);
+            if (rr >= nr) v = make_double2(0.0, 0.0);
+            vnew[a] = v;
+          }
+          cplx y[4];
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) {
+            cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc = cadd(acc, make_double2(vnew[a].x * e[a][bb].x + vnew[a].y * e[a][bb].y,
+                                                                      vnew[a].x * e[a][bb].y - vnew[a].y * e[a][bb].x));
+            y[bb] = cmul(cconj(tauj), sb_sum_br(acc));
+          }
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) e[a][bb] = csub(e[a][bb], cmul(vnew[a], y[bb]));
+          if (bc == 0) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) e[a][0] = (4 * br + a == 0) ? make_double2(beta, 0.0) : make_double2(0.0, 0.0);
+          }
+        }
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+          const int c = c0 + 4 * bc + bb;
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const int r = r0 + 4 * br + a;
+            if (r < n) dm_stg(AB, (size_t)c * SLD + (r - c), e[a][bb]);
+          }
+        }
+        tau = tauj;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) vrow[a] = reflect ? vnew[a] : make_double2(0.0, 0.0);
+      }
+      if (reflect) {
+        // ---- store the reflector (lanes bc == 0 hold it by rows)
+        const size_t blk = (size_t)G * M.jb + j;
+        if (bc == 0) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const int rr = 4 * br + a;
+            if (rr < nr) dm_stg(M.Vd, (blk * SBG + gi) * SBW + gi + rr, vrow[a]);
+          }
+        }
+        if (lane == 0) M.tau2[blk * SBG + gi] = tau;
+        // the same vector by block columns: lane (br, bc) takes the rows of lane (bc, 0)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) vcol[a] = sb_from_lane(vrow[a], bc * 8);
+        // ---- D <- H^H D H on the Hermitian diagonal block (zhetd2's x, w recurrences)
+        cplx d[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int r = r0 + 4 * br + a;
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) {
+            const int c = r0 + 4 * bc + bb;
+            cplx v = make_double2(0.0, 0.0);
+            if (r < n && c < n) {
+              if (r >= c) v = dm_ldg(AB, (size_t)c * SLD + (r - c));
+              else v = cconj(dm_ldg(AB, (size_t)r * SLD + (c - r)));
+              if (r == c) v.y = 0.0;
+            }
+            d[a][bb] = v;
+          }
+        }
+        cplx x[4];
+        cplx xv = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) acc = cadd(acc, cmul(d[a][bb], vcol[bb]));
+          x[a] = cmul(tau, sb_sum_bc(acc));
+          // x^H v, rows of this lane (the same in all lanes of the block row)
+          xv = cadd(xv, make_double2(x[a].x * vrow[a].x + x[a].y * vrow[a].y, x[a].x * vrow[a].y - x[a].y * vrow[a].x));
+        }
+        xv = sb_sum_br(xv);
+        const cplx al = cmul(make_double2(-0.5 * tau.x, -0.5 * tau.y), xv);
+        cplx wv[4], wc[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) wv[a] = cadd(x[a], cmul(al, vrow[a]));
+#pragma unroll
+        for (int a = 0; a < 4; ++a) wc[a] = sb_from_lane(wv[a], bc * 8);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb)
+            d[a][bb] = csub(csub(d[a][bb], cmulc(vrow[a], wc[bb])), cmulc(wv[a], vcol[bb]));
+        if (br >= bc) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const int r = r0 + 4 * br + a;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+              const int c = r0 + 4 * bc + bb;
+              if (r < n && c <= r) {
+                cplx v = d[a][bb];
+                if (r == c) v.y = 0.0;
+                dm_stg(AB, (size_t)c * SLD + (r - c), v);
+              }
+            }
+          }
+        }
+      }
+      // ---- publish: task j of sweep s is finished
+      if (MULTI) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(M.prog + s, (unsigned)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0)
+          __hip_atomic_store(&lprog[s & 63], ((unsigned)(s + 1) << 16) | (unsigned)(j + 1), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      if (!reflect) break;
+    }
+    // ---- sweep finished
+    if (s == n - 2 && lane == 0) M.d[n - 1] = dm_ldg(AB, (size_t)(n - 1) * SLD).x;
+    if (MULTI) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(M.prog + s, SB_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0)
+        __hip_atomic_store(&lprog[s & 63], ((unsigned)(s + 1) << 16) | SB_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+}
+
+// ---- B2: X <- Q2 X, column slabs in registers ------------------------------------------------------------------------
+//
+// A wave owns 16 columns of X; four lanes share a column and take the window rows w = 4 u + part (any 32 consecutive
+// rows hold exactly eight — at most nine counting both ends — rows of each part).  Groups of SBG sweeps are applied last
+// to first; inside a group the diamond blocks j = 0, 1, ... in turn (block (G, j) touches the rows [G SBG + 1 + j SB,
+// + SBG + SB - 1) of X), inside a block the sweeps last to first.  The window slides down by SB rows per block: the rows
+// that leave are final for this group and are written back, SB new rows are loaded.  The reflectors of a block (SBG x SBW
+// values, zero outside each vector) are staged in LDS by the workgroup, whose waves all work on the same matrix.
+struct sb_q2_mat {
+  const cplx* Vd; const cplx* tau2; int jb;
+  cplx* X; int ldx; int n; int ncol;   // X is n x ncol (row-major, leading dimension ldx)
+  int slab0;                           // first slab (of 16 columns) id of this matrix in the launch
+};
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void sb_q2_apply_kernel(const sb_q2_mat* __restrict__ ms, const int2* __restrict__ wgs) {
+  // wgs[blockIdx.x] = (matrix, first slab of this workgroup)
+  const int2 wg = wgs[blockIdx.x];
+  const sb_q2_mat M = ms[wg.x];
+  const int n = M.n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = (wg.y + wave) * 16 + (lane & 15);
+  const int part = lane >> 4;
+  const bool cvalid = col < M.ncol;
+  extern __shared__ __align__(16) unsigned char sb_q2_smem[];
+  cplx (*sv)[SBG * SBW] = reinterpret_cast<cplx (*)[SBG * SBW]>(sb_q2_smem);
+  cplx (*st)[SBG] = reinterpret_cast<cplx (*)[SBG]>(sb_q2_smem + sizeof(cplx) * 2 * SBG * SBW);
+  constexpr int NU = SBW / 4;  // window rows per lane
+  const int nsweep = n - 1;
+  if (nsweep <= 0) return;
+  const int ngroup = (nsweep + SBG - 1) / SBG;
+  for (int G = ngroup - 1; G >= 0; --G) {
+    const int s0 = G * SBG;
+    const int row0 = s0 + 1;                       // window start of block 0
+    const int nb = (n - 1 - row0) / SB + 1;        // blocks with at least one row: row0 + j SB <= n - 1
+    cplx xw[NU];
+    // stage block 0 and load the first window
+    __syncthreads();
+    {
+      const cplx* src = M.Vd + ((size_t)G * M.jb) * SBG * SBW;
+      for (int idx = tid; idx < SBG * SBW; idx += 64 * NW) sv[0][idx] = dm_ldg(src, idx);
+      if (tid < SBG) st[0][tid] = dm_ldg(M.tau2, ((size_t)G * M.jb) * SBG + tid);
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int r = row0 + 4 * u + part;
+      xw[u] = (cvalid && r < n) ? dm_ldg(M.X, (size_t)r * M.ldx + col) : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    for (int j = 0; j < nb; ++j) {
+      const int buf = j & 1;
+      // prefetch the next block of reflectors into the other buffer
+      if (j + 1 < nb) {
+        const cplx* src = M.Vd + ((size_t)G * M.jb + j + 1) * SBG * SBW;
+        for (int idx = tid; idx < SBG * SBW; idx += 64 * NW) sv[buf ^ 1][idx] = dm_ldg(src, idx);
+        if (tid < SBG) st[buf ^ 1][tid] = dm_ldg(M.tau2, ((size_t)G * M.jb + j + 1) * SBG + tid);
+      }
+      const int nsw = min(SBG, nsweep - s0);
+#pragma unroll
+      for (int iq = SBG / 4 - 1; iq >= 0; --iq) {
+#pragma unroll
+        for (int ir = 3; ir >= 0; --ir) {
+          const int i = 4 * iq + ir;
+          if (i < nsw) {
+            const cplx tq = st[buf][i];
+            const cplx* vv = &sv[buf][i * SBW + part];
+            // rows w = 4 u + part, u = iq .. iq + 8 cover [i, i + SB) (zeros outside the vector)
+            cplx acc = make_double2(0.0, 0.0);
+            cplx v[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+              v[t] = (iq + t < NU) ? vv[4 * (iq + t)] : make_double2(0.0, 0.0);
+              if (iq + t < NU) {
+                const cplx xx = xw[iq + t];
+                acc.x += v[t].x * xx.x + v[t].y * xx.y;  // conj(v) * x
+                acc.y += v[t].x * xx.y - v[t].y * xx.x;
+              }
+            }
+            acc.x += sb_xor(acc.x, 16); acc.y += sb_xor(acc.y, 16);
+            acc.x += sb_xor(acc.x, 32); acc.y += sb_xor(acc.y, 32);
+            const cplx f = cmul(tq, acc);  // H x = x - tau v (v^H x)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+              if (iq + t < NU) xw[iq + t] = csub(xw[iq + t], cmul(v[t], f));
+          }
+        }
+      }
+      // slide: the first SB rows of the window are final for this group
+      const int wr0 = row0 + j * SB;
+#pragma unroll
+      for (int u = 0; u < SB / 4; ++u) {
+        const int r = wr0 + 4 * u + part;
+        if (cvalid && r < n) dm_stg(M.X, (size_t)r * M.ldx + col, xw[u]);
+      }
+      if (j + 1 < nb) {
+#pragma unroll
+        for (int u = 0; u + SB / 4 < NU; ++u) xw[u] = xw[u + SB / 4];
+#pragma unroll
+        for (int u = NU - SB / 4; u < NU; ++u) {
+          const int r = wr0 + SB + 4 * u + part;
+          xw[u] = (cvalid && r < n) ? dm_ldg(M.X, (size_t)r * M.ldx + col) : make_double2(0.0, 0.0);
+        }
+      } else {
+        // last block: the rest of the window is final too
+#pragma unroll
+        for (int u = SB / 4; u < NU; ++u) {
+          const int r = wr0 + 4 * u + part;
+          if (cvalid && r < n) dm_stg(M.X, (size_t)r * M.ldx + col, xw[u]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}

@@ -1404,6 +1404,10 @@ __global__ void dc_tear_kernel(const dc_tear* __restrict__ ts, int nt) {
   t.d[t.b] -= ab;
 }
 
+#if DM_TNB == 32
+#include "dm_sbr_impl.h"
+#endif
+
 }  // namespace
 
 
@@ -1755,6 +1759,222 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
   }
   if (nch > 1 && !g_side.s) DM_HIP(ctx, hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking));
 
+  // ---- two-stage reduction (dm_sbr_impl.h): dense -> band (MFMA) -> tridiagonal (bulge chasing)
+#if DM_TNB == 32
+  bool two_stage = false;
+  {
+    // DM_TRD_TWOSTAGE = 1 / 0 forces / forbids it; by default batches whose largest matrix has at least
+    // DM_TRD_TWOSTAGE_MIN rows take it (below that the one-stage chain of small launches is as fast)
+    int mode = -1;
+    if (const char* e = getenv("DM_TRD_TWOSTAGE")) mode = atoi(e);
+    int minn = 100000000;
+    if (const char* e = getenv("DM_TRD_TWOSTAGE_MIN")) minn = atoi(e);
+    two_stage = use_dc && maxn > TSM && maxn > SB + 2 && (mode == 1 || (mode != 0 && maxn >= minn));
+  }
+#else
+  const bool two_stage = false;
+#endif
+  const int shift = two_stage ? TNB : 1;  // reflector k has its leading 1 at row k + shift
+  auto nrefl_of = [&](int n) { return two_stage ? std::max(0, n - TNB - 1) : std::max(0, n - 1); };
+#if DM_TNB == 32
+  cplx *sbPw = nullptr, *sbXt = nullptr, *sbYp = nullptr, *sbAB = nullptr, *sbVd = nullptr, *sbTau2 = nullptr, *sbM1 = nullptr,
+       *sbS = nullptr;
+  double* sbNp = nullptr;
+  unsigned* sbProg = nullptr;
+  int* sbNext = nullptr;
+  std::vector<size_t> offyp(np), offvd(np), offt2(np);
+  std::vector<int> sb_jb(np, 0);
+  size_t totyp = 0, totvd = 0, tott2 = 0;
+  if (two_stage) {
+    for (int p = 0; p < np; ++p) {
+      const size_t n = probs[p].n;
+      offyp[p] = totyp; totyp += n / SQR + 1;
+      const size_t ng = n > 1 ? (n - 1 + SBG - 1) / SBG : 0;
+      sb_jb[p] = n > 1 ? (int)((n - 2) / SB + 1) : 0;
+      offvd[p] = totvd; totvd += ng * sb_jb[p] * SBG * SBW;
+      offt2[p] = tott2; tott2 += ng * sb_jb[p] * SBG;
+    }
+    sbPw = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * SB, 1));
+    sbXt = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * SB, 1));
+    sbYp = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totyp * SB, 1));
+    sbNp = dm_ws_alloc_t<double>(ctx, std::max<size_t>(totyp * 2, 1));
+    sbAB = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * SLD, 1));
+    sbVd = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totvd, 1));
+    sbTau2 = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(tott2, 1));
+    sbM1 = dm_ws_alloc_t<cplx>(ctx, (size_t)np * SB * SB);
+    sbS = dm_ws_alloc_t<cplx>(ctx, (size_t)np * SB * SB);
+    sbProg = dm_ws_alloc_t<unsigned>(ctx, std::max<size_t>(totn, 1));
+    sbNext = dm_ws_alloc_t<int>(ctx, np);
+    if (!sbPw || !sbXt || !sbYp || !sbNp || !sbAB || !sbVd || !sbTau2 || !sbM1 || !sbS || !sbProg || !sbNext) return DM_ENOMEM;
+  }
+
+  auto phase_T1_two = [&](const std::vector<int>& ch) -> int {
+    if (ch.empty()) return DM_OK;
+    const int nc = (int)ch.size();
+    int cmax = 0;
+    std::vector<sb_mat> sm(nc);
+    std::vector<sb_dmat> dmv(nc);
+    std::vector<sb_bmat> bm(nc);
+    std::vector<sb_chase_mat> cm(nc);
+    for (int i = 0; i < nc; ++i) {
+      const int p = ch[i];
+      const size_t n = probs[p].n;
+      cmax = std::max(cmax, probs[p].n);
+      cplx* pp = PP + offn[p] * 3 * TNB;
+      sm[i] = sb_mat{probs[p].C, probs[p].ldc, probs[p].n, Vt + off[p], pp, pp + n * TNB, pp + 2 * n * TNB,
+                     sbPw + offn[p] * SB, tau + offn[p], sbYp + offyp[p] * SB, sbNp + offyp[p] * 2, (int)(n / SQR + 1)};
+      dmv[i] = sb_dmat{probs[p].C, probs[p].ldc, probs[p].n};
+      bm[i] = sb_bmat{probs[p].C, probs[p].ldc, probs[p].n, sbAB + offn[p] * SLD};
+      cm[i] = sb_chase_mat{sbAB + offn[p] * SLD, probs[p].n, sbVd + offvd[p], sbTau2 + offt2[p], dd + offn[p], ee + offn[p],
+                           sb_jb[p], sbProg + offn[p], sbNext + p};
+    }
+    sb_mat* d_sm = dm_ws_upload(ctx, sm);
+    sb_dmat* d_dm = dm_ws_upload(ctx, dmv);
+    sb_bmat* d_bm = dm_ws_upload(ctx, bm);
+    sb_chase_mat* d_cmat = dm_ws_upload(ctx, cm);
+    if (!d_sm || !d_dm || !d_bm || !d_cmat) return DM_ENOMEM;
+    DM_TRY(dm_fill_zero(ctx, Tbig, sizeof(cplx) * tottb));
+    DM_TRY(dm_fill_zero(ctx, sbVd, sizeof(cplx) * totvd));
+    DM_TRY(dm_fill_zero(ctx, sbTau2, sizeof(cplx) * tott2));
+    hipLaunchKernelGGL(sb_diag_tiles_kernel, dim3((cmax + 63) / 64, nc), dim3(256), 0, ctx->stream, d_dm);
+    // ---- S1: dense -> band, one panel of SB columns at a time, all matrices in lock-step
+    for (int k0 = 0; cmax - k0 - SB >= 2; k0 += SB) {
+      const int i0 = k0 + SB;        // first row of the trailing matrix
+      const int a0 = i0 & ~63;       // its 64-aligned tile origin (the panel vectors are zero on [a0, i0))
+      hipLaunchKernelGGL(sb_panel_load_kernel, dim3((cmax - a0 + 255) / 256, nc), dim3(256), 0, ctx->stream, d_sm, k0, a0);
+      const int nchmax = (cmax - i0 + SQR - 1) / SQR;
+      for (int q = 0; q <= SB; ++q) {
+        hipLaunchKernelGGL(sb_qr_update_kernel, dim3(nchmax, nc), dim3(256), 0, ctx->stream, d_sm, k0, q);
+        if (q < SB) hipLaunchKernelGGL(sb_qr_dots_kernel, dim3(nchmax, nc), dim3(256), 0, ctx->stream, d_sm, k0, q);
+      }
+      // T factor of the panel (zlarft from the Gram matrix), straight into the slot the back-transformation reads
+      std::vector<dm_gemm_desc> gg, gx, gy1, gy2, gm, gs, gw, gh;
+      std::vector<tf_mat> tf;
+      for (int p : ch) {
+        const int n = probs[p].n;
+        const int m = n - i0;
+        if (m < 2) continue;
+        const int kb = std::min(SB, m - 1);
+        const int lda = probs[p].ldc;
+        cplx* C = probs[p].C;
+        cplx* pp = PP + offn[p] * 3 * TNB;
+        cplx* Vp = pp;
+        cplx* Wp = pp + (size_t)n * TNB;
+        cplx* Xt = sbXt + offn[p] * SB;
+        const cplx* Vb = Vt + off[p] + (size_t)k0 * n + i0;
+        cplx* G = Gs + offg[p] + (size_t)(k0 / TNB) * TNB * TNB;
+        cplx* T = Tbig + offtb[p] + (size_t)(k0 / NBB) * NBB * NBB + (size_t)(k0 % NBB) * NBB + (k0 % NBB);
+        gg.push_back(dm_gemm_make(Vb, n, 1, true, Vb, 1, n, false, G, TNB, kb, kb, m));
+        tf.push_back(tf_mat{G, tau + offn[p] + k0, T, kb, NBB});
+        // Xt = T^T Vp  (SB x m)
+        gx.push_back(dm_gemm_make(T, 1, NBB, false, Vp + i0, n, 1, false, Xt + i0, n, SB, m, SB));
+        // Yt = Xt A22 by 64-column blocks: stored part (rows >= block start, whole diagonal tile) + mirrored part
+        for (int cb = a0; cb < n; cb += 64) {
+          const int c_lo = std::max(cb, i0), c_hi = std::min(cb + 64, n);
+          if (c_hi <= c_lo) continue;
+          gy1.push_back(dm_gemm_make(Xt + c_lo, n, 1, false, C + (size_t)c_lo * lda + c_lo, 1, lda, false, Wp + c_lo, n, SB,
+                                     c_hi - c_lo, n - c_lo));
+          if (c_lo > i0)
+            gy2.push_back(dm_gemm_make(Xt + i0, n, 1, false, C + (size_t)i0 * lda + c_lo, lda, 1, true, Wp + c_lo, n, SB,
+                                       c_hi - c_lo, c_lo - i0, 1.0, 1.0));
+        }
+        cplx* M1 = sbM1 + (size_t)p * SB * SB;
+        cplx* S = sbS + (size_t)p * SB * SB;
+        // M1 = V^H Y, S = T^H M1, W = Y - V S / 2  (row-stored: Wp += -1/2 S^T Vp)
+        gm.push_back(dm_gemm_make(Vp + i0, n, 1, true, Wp + i0, 1, n, false, M1, SB, SB, SB, m));
+        gs.push_back(dm_gemm_make(T, 1, NBB, true, M1, SB, 1, false, S, SB, SB, SB, SB));
+        gw.push_back(dm_gemm_make(S, 1, SB, false, Vp + i0, n, 1, false, Wp + i0, n, SB, m, SB, -0.5, 1.0));
+        // A22 -= V W^H + W V^H on the tiles on or above the diagonal (64-aligned origin a0)
+        gh.push_back(dm_gemm_make(pp + a0, 1, n, false, pp + (size_t)n * TNB + a0, n, 1, true, C + (size_t)a0 * lda + a0, lda,
+                                  n - a0, n - a0, 2 * TNB, -1.0, 1.0, nullptr, DM_GEMM_UPPER));
+      }
+      if (gg.empty()) continue;
+      DM_TRY(dm_gemm_grouped_launch(ctx, gg));
+      {
+        tf_mat* d_tf = dm_ws_upload(ctx, tf);
+        if (!d_tf) return DM_ENOMEM;
+        static bool attr = false;
+        const size_t lds = sizeof(cplx) * TNB * (TNB + 1);
+        if (!attr) {
+          DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(larft_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          attr = true;
+        }
+        hipLaunchKernelGGL(larft_kernel, dim3((unsigned)tf.size()), dim3(64), lds, ctx->stream, d_tf);
+      }
+      DM_TRY(dm_gemm_grouped_launch(ctx, gx));
+      DM_TRY(dm_gemm_grouped_launch(ctx, gy1));
+      DM_TRY(dm_gemm_grouped_launch(ctx, gy2));
+      DM_TRY(dm_gemm_grouped_launch(ctx, gm));
+      DM_TRY(dm_gemm_grouped_launch(ctx, gs));
+      DM_TRY(dm_gemm_grouped_launch(ctx, gw));
+      DM_TRY(dm_gemm_grouped_launch(ctx, gh));
+    }
+    // ---- S2: band -> tridiagonal
+    const char* dump = getenv("DM_SB_DUMP");  // debugging aid: the band and the tridiagonal of every matrix to files
+    auto dump_arr = [&](const char* suffix, const void* src, size_t bytes) -> int {
+      std::vector<char> h(bytes);
+      DM_TRY(dm_download(ctx, h.data(), src, bytes));
+      const std::string fn = std::string(dump) + suffix;
+      if (FILE* f = fopen(fn.c_str(), "wb")) { fwrite(h.data(), 1, bytes, f); fclose(f); }
+      return DM_OK;
+    };
+    {
+      size_t maxel = (size_t)cmax * SLD;
+      hipLaunchKernelGGL(sb_band_extract_kernel, dim3((unsigned)((maxel + 255) / 256), nc), dim3(256), 0, ctx->stream, d_bm);
+      if (dump) DM_TRY(dump_arr(".band", sbAB, sizeof(cplx) * totn * SLD));
+      constexpr int NW = 8;
+      int wgpm = std::min((cmax + 2 * SB * NW - 1) / (2 * SB * NW), std::max(1, 512 / nc));
+      if (const char* e = getenv("DM_SB_WGPM")) wgpm = std::max(1, atoi(e));
+      if (wgpm <= 1) {
+        hipLaunchKernelGGL((sb_chase_kernel<false, NW>), dim3(nc), dim3(64 * NW), 0, ctx->stream, d_cmat, 1);
+      } else {
+        DM_TRY(dm_fill_zero(ctx, sbProg, sizeof(unsigned) * totn));
+        DM_TRY(dm_fill_zero(ctx, sbNext, sizeof(int) * np));
+        hipLaunchKernelGGL((sb_chase_kernel<true, NW>), dim3(nc * wgpm), dim3(64 * NW), 0, ctx->stream, d_cmat, wgpm);
+      }
+      if (dump) {
+        DM_TRY(dump_arr(".d", dd, sizeof(double) * totn));
+        DM_TRY(dump_arr(".e", ee, sizeof(double) * totn));
+      }
+    }
+    DM_HIP(ctx, hipGetLastError());
+    return DM_OK;
+  };
+
+  // X <- Q2 X (X = probs[p].C, n x ncolv[p]): workgroups of NW column slabs, large matrices first
+  auto apply_q2 = [&](const std::vector<int>& ch, const std::vector<int>& ncolv) -> int {
+    constexpr int NW = 8;
+    std::vector<sb_q2_mat> qm;
+    std::vector<int2> wgs;
+    std::vector<int> order(ch);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return probs[a].n > probs[b].n; });
+    for (int p : order) {
+      if (probs[p].n < 2 || ncolv[p] <= 0) continue;
+      const int mi = (int)qm.size();
+      qm.push_back(sb_q2_mat{sbVd + offvd[p], sbTau2 + offt2[p], sb_jb[p], probs[p].C, probs[p].ldc, probs[p].n, ncolv[p], 0});
+      const int nslab = (ncolv[p] + 15) / 16;
+      for (int s0 = 0; s0 < nslab; s0 += NW) wgs.push_back(make_int2(mi, s0));
+    }
+    if (wgs.empty()) return DM_OK;
+    sb_q2_mat* d_qm = dm_ws_upload(ctx, qm);
+    int2* d_wgs = dm_ws_upload(ctx, wgs);
+    if (!d_qm || !d_wgs) return DM_ENOMEM;
+    const size_t lds = sizeof(cplx) * (2 * SBG * SBW + 2 * SBG);
+    static bool attr = false;
+    if (!attr) {
+      DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sb_q2_apply_kernel<NW>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr = true;
+    }
+    hipLaunchKernelGGL((sb_q2_apply_kernel<NW>), dim3((unsigned)wgs.size()), dim3(64 * NW), lds, ctx->stream, d_qm, d_wgs);
+    DM_HIP(ctx, hipGetLastError());
+    return DM_OK;
+  };
+#else
+  auto apply_q2 = [&](const std::vector<int>&, const std::vector<int>&) -> int { return DM_OK; };
+#endif
+
   bool small_path = false;  // set by phase_T1 when the chunk went through trd_small (explicit Q in Ut)
   auto phase_T1 = [&](const std::vector<int>& ch) -> int {
     if (ch.empty()) return DM_OK;
@@ -1995,12 +2215,14 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
     }
     const int tb = (cmax + 31) / 32;
     hipLaunchKernelGGL(zt_to_x_kernel, dim3(tb, tb, nc), dim3(256), 0, ctx->stream, d_cm);
+    // two-stage reduction: X <- Q2 X first (the reflectors of the bulge chase), then the blocks of the first stage
+    if (two_stage) DM_TRY(apply_q2(ch, ncolv));
     // ---- T factors of all blocks up front (they depend on V only), batched over blocks and matrices:
     //   level 0: T of every TNB-wide panel from its Gram matrix (zlarft)
     //   merge:   [T_l, -T_l (V_l^H V_r) T_r; 0, T_r] for neighbouring blocks until NBB is reached
     //   U^H = T V^H per block, so that applying a block is two products: W = U^H X, X -= V W
-    DM_TRY(dm_fill_zero(ctx, Tbig, sizeof(cplx) * tottb));
-    {
+    if (!two_stage) DM_TRY(dm_fill_zero(ctx, Tbig, sizeof(cplx) * tottb));
+    if (!two_stage) {  // (the first stage of the two-stage reduction has left the T factors of its panels in Tbig)
       std::vector<dm_gemm_desc> g;
       std::vector<tf_mat> tf;
       for (int p : ch) {
@@ -2033,10 +2255,11 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       std::vector<dm_gemm_desc> ga, gb, gc;
       for (int p : ch) {
         const int n = probs[p].n;
-        for (int k0 = 0; k0 + sz < n - 1; k0 += 2 * sz) {  // left block [k0, k0+sz), right block [k0+sz, ...)
+        const int nrefl = nrefl_of(n);
+        for (int k0 = 0; k0 + sz < nrefl; k0 += 2 * sz) {  // left block [k0, k0+sz), right block [k0+sz, ...)
           const int kr0 = k0 + sz;
-          const int kl = sz, kr = std::min(kr0 + sz, n - 1) - kr0;
-          const int r0 = kr0 + 1, nr = n - r0;             // rows where the right block is non-zero
+          const int kl = sz, kr = std::min(kr0 + sz, nrefl) - kr0;
+          const int r0 = kr0 + shift, nr = n - r0;         // rows where the right block is non-zero
           const cplx* Vl = Vt + off[p] + (size_t)k0 * n + r0;
           const cplx* Vr = Vt + off[p] + (size_t)kr0 * n + r0;
           cplx* G = Gs + offg[p] + (size_t)(k0 / (2 * sz)) * sz * sz;
@@ -2059,9 +2282,10 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       std::vector<dm_gemm_desc> g;
       for (int p : ch) {
         const int n = probs[p].n;
-        for (int k0 = 0; k0 < n - 1; k0 += NBB) {
-          const int kb = std::min(k0 + NBB, n - 1) - k0;
-          const int r0 = k0 + 1, nr = n - r0;
+        const int nrefl = nrefl_of(n);
+        for (int k0 = 0; k0 < nrefl; k0 += NBB) {
+          const int kb = std::min(k0 + NBB, nrefl) - k0;
+          const int r0 = k0 + shift, nr = n - r0;
           const cplx* T = Tbig + offtb[p] + (size_t)(k0 / NBB) * NBB * NBB;
           g.push_back(dm_gemm_make(T, NBB, 1, false, Vt + off[p] + (size_t)k0 * n + r0, n, 1, true,
                                    Ut + off[p] + (size_t)k0 * n + r0, n, kb, nr, kb));
@@ -2070,16 +2294,16 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       DM_TRY(dm_gemm_grouped_launch(ctx, g));
     }
     // ---- apply the blocks, last to first
-    const int nblk = (std::max(cmax - 1, 0) + NBB - 1) / NBB;
+    const int nblk = (nrefl_of(cmax) + NBB - 1) / NBB;
     for (int b = nblk - 1; b >= 0; --b) {
       const int k0 = b * NBB;
       std::vector<dm_gemm_desc> g2, g4;
       for (int p : ch) {
         const int n = probs[p].n;
-        const int kb = std::min(k0 + NBB, n - 1) - k0;
+        const int kb = std::min(k0 + NBB, nrefl_of(n)) - k0;
         if (kb <= 0) continue;
-        // reflectors k >= k0 vanish on rows <= k0: only rows r0.. of X take part
-        const int r0 = k0 + 1, nr = n - r0;
+        // reflectors k >= k0 vanish on rows < k0 + shift: only rows r0.. of X take part
+        const int r0 = k0 + shift, nr = n - r0;
         cplx* Xr = probs[p].C + (size_t)r0 * probs[p].ldc;
         cplx* w1 = W1 + offn[p] * NBB;
         const int nx = ncolv[p];  // columns of X = eigenvectors being back-transformed
@@ -2103,6 +2327,10 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
   };
 
   if (use_dc) {
+#if DM_TNB == 32
+    if (two_stage) DM_TRY(phase_T1_two(chunks[0]));
+    else
+#endif
     DM_TRY(phase_T1(chunks[0]));
     // Ut is first written by the back-transformation (unless the LDS-resident small path put Q there)
     DM_TRY(dc_solve(ctx, probs, dd, ee, offn, off, tot, totn, zfinal,
