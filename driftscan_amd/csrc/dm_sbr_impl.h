@@ -224,21 +224,29 @@ struct sb_chase_mat {
   cplx* tau2;      // (G * jb + j) * SBG + i
   double* d; double* e;
   int jb;          // blocks per sweep group: (n - 2) / SB + 1
-  unsigned* prog;  // multi-workgroup mode: one progress word per sweep (zero-initialised)
-  int* next;       // multi-workgroup mode: sweep counter (zero-initialised)
+  unsigned* prog;  // one progress word per sweep (zero-initialised): tasks finished, SB_DONE at the end
+  int* next;       // sweep counter (zero-initialised)
+  int* owner;      // XCD that works on this matrix (-1 initially)
 };
+// Work queues, one per XCD: entries are matrix ids (a large matrix has several entries = several workgroups).
+// All workgroups that work on one matrix sit on ONE XCD — its L2 is their coherence point: band data are written
+// with plain stores (write-through to L2) and read with sc1 loads (served by L2, never by a stale L1 line), so a
+// hand-off between CUs costs an L2 round trip and no cache maintenance.  Nothing is assumed about placement: a
+// workgroup reads its XCC_ID, takes entries from the queue of its XCD first and then from the others, and the
+// first workgroup to touch a matrix claims it for its XCD (entries of a matrix claimed by another XCD are skipped).
+struct sb_chase_ctl { int* qhead; const int* qent; int* err; unsigned long long* dbg; int qoff[9]; };
 
 constexpr unsigned SB_DONE = 0xffffu;
 
 __device__ __forceinline__ double sb_xor(double v, int m) { return __shfl_xor(v, m, 64); }
-// sum over the lanes that share the block ROW (bits 0..2 of the lane differ)
+// sum over the lanes that share the row set (bits 0..2 of the lane differ)
 __device__ __forceinline__ cplx sb_sum_bc(cplx v) {
   v.x += sb_xor(v.x, 1); v.y += sb_xor(v.y, 1);
   v.x += sb_xor(v.x, 2); v.y += sb_xor(v.y, 2);
   v.x += sb_xor(v.x, 4); v.y += sb_xor(v.y, 4);
   return v;
 }
-// sum over the lanes that share the block COLUMN (bits 3..5 differ)
+// sum over the lanes that share the column set (bits 3..5 differ)
 __device__ __forceinline__ cplx sb_sum_br(cplx v) {
   v.x += sb_xor(v.x, 8); v.y += sb_xor(v.y, 8);
   v.x += sb_xor(v.x, 16); v.y += sb_xor(v.y, 16);
@@ -266,267 +274,292 @@ __device__ __forceinline__ trd_refl sb_reflector(double xnorm2, cplx alpha) {
   return R;
 }
 
-// MULTI = false: one workgroup per matrix, progress words in LDS (workgroup-scope ordering);
-// MULTI = true: several workgroups share one matrix, progress words and the sweep counter in global memory
-// with agent-scope release / acquire around the band accesses.
-template <bool MULTI, int NW>
-__global__ __launch_bounds__(64 * NW) void sb_chase_kernel(const sb_chase_mat* __restrict__ ms, int wg_per_mat) {
-  const sb_chase_mat M = ms[MULTI ? blockIdx.x / wg_per_mat : blockIdx.x];
+typedef unsigned int sb_u4 __attribute__((ext_vector_type(4)));
+// sc1 loads: served by the XCD's L2, bypassing the vector L1 of this CU (element index in units of cplx / dwords)
+__device__ __forceinline__ cplx sb_ld(__amdgpu_buffer_rsrc_t rs, unsigned idx) {
+  const sb_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, idx * 16u, 0, 16);
+  cplx w;
+  __builtin_memcpy(&w, &v, 16);
+  return w;
+}
+__device__ __forceinline__ unsigned sb_ld_u32(__amdgpu_buffer_rsrc_t rs, unsigned idx) {
+  return __builtin_amdgcn_raw_buffer_load_b32(rs, idx * 4u, 0, 16);
+}
+
+// One sweep of the chase by one wave.  A 32 x 32 block lives in the wave as 4 x 4 values per lane with INTERLEAVED
+// ownership: lane (br, bc) = (lane >> 3, lane & 7) holds the rows br + 8 a and the columns bc + 8 b — eight lanes
+// with consecutive br read 128 contiguous bytes of a band column, so every load instruction moves whole lines.
+__device__ __forceinline__ void sb_chase_sweep(const sb_chase_mat& M, __amdgpu_buffer_rsrc_t rsAB, int* err, int s, int lane) {
   const int n = M.n;
-  const int lane = threadIdx.x & 63;
   const int br = lane >> 3, bc = lane & 7;
-  __shared__ unsigned lprog[64];
-  __shared__ int lnext;
-  if (!MULTI) {
-    if (threadIdx.x < 64) lprog[threadIdx.x] = 0u;
-    if (threadIdx.x == 0) lnext = 0;
-    __syncthreads();
-  }
-  if (n == 1) {
-    if (threadIdx.x == 0 && (!MULTI || blockIdx.x % wg_per_mat == 0)) M.d[0] = dm_ldg(M.AB, 0).x;
-    return;
-  }
   cplx* AB = M.AB;
-  for (;;) {
-    int s = 0;
-    if (lane == 0) s = MULTI ? atomicAdd(M.next, 1) : atomicAdd(&lnext, 1);
-    s = __builtin_amdgcn_readfirstlane(s);
-    if (s >= n - 1) break;
-    const int G = s / SBG, gi = s % SBG;
-    unsigned seen = (s == 0) ? SB_DONE : 0u;  // tasks of sweep s - 1 known to be finished
-    cplx vrow[4], vcol[4];  // the current reflector by block rows / block columns of this lane
-    cplx tau = make_double2(0.0, 0.0);
-    for (int j = 0;; ++j) {
-      const int r0 = s + 1 + j * SB;  // first row of R_j
-      if (r0 >= n) break;
-      const int nr = min(SB, n - r0);
-      // ---- wait for sweep s - 1 to have finished task j + 1
-      if (seen < (unsigned)(j + 2)) {
-        for (;;) {
-          unsigned v;
-          if (MULTI) {
-            v = __hip_atomic_load(M.prog + (s - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } else {
-            const unsigned w = __hip_atomic_load(&lprog[(s - 1) & 63], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const unsigned tag = w >> 16;
-            v = tag == (unsigned)s ? (w & 0xffffu) : (tag > (unsigned)s ? SB_DONE : 0u);  // tag = sweep + 1
-          }
-          if (v >= (unsigned)(j + 2)) { seen = v; break; }
-          __builtin_amdgcn_s_sleep(2);
+  const int G = s / SBG, gi = s % SBG;
+  unsigned seen = (s == 0) ? SB_DONE : 0u;  // tasks of sweep s - 1 known to be finished
+  cplx vrow[4], vcol[4];  // the current reflector by the rows / the columns of this lane
+  cplx tau = make_double2(0.0, 0.0);
+  for (int j = 0;; ++j) {
+    const int r0 = s + 1 + j * SB;  // first row of R_j
+    if (r0 >= n) break;
+    const int nr = min(SB, n - r0);
+    // ---- wait for sweep s - 1 to have finished task j + 1
+    if (seen < (unsigned)(j + 2)) {
+      // (an atomic load: a plain one would be hoisted out of the loop; agent scope = sc1 = served by L2)
+      int spins = 0;
+      bool bail = false;
+      for (;;) {
+        const unsigned v = __hip_atomic_load(M.prog + (s - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v >= (unsigned)(j + 2)) { seen = v; break; }
+        __builtin_amdgcn_s_sleep(1);
+        // never in a correct run: every wave leaves instead of hanging the GPU (the host reports the failure)
+        ++spins;
+        if (spins > (1 << 20)) {
+          if (lane == 0) atomicCAS(err, 0, 1 + s + (j << 12) + ((int)(v & 0xff) << 20));  // first failure wins
+          bail = true;
         }
-        if (MULTI) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) bail = true;
+        if (bail) {
+          if (lane == 0) __hip_atomic_store(M.prog + s, 0x40000000u | ((unsigned)j << 8) | (v & 0xffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return;
+        }
       }
-      bool reflect = true;
-      double beta = 0.0;
-      if (j == 0) {
-        // ---- task 0: reflector from column s
-        if (lane == 0) M.d[s] = dm_ldg(AB, (size_t)s * SLD).x;
-        cplx x[4];
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // keeps the band loads below behind the poll
+    }
+    // the Hermitian diagonal block D_j (its loads overlap the work on E_j)
+    cplx d[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int r = r0 + br + 8 * a;
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const int c = r0 + bc + 8 * bb;
+        d[a][bb] = (r >= c) ? sb_ld(rsAB, (unsigned)c * SLD + (unsigned)(r - c)) : sb_ld(rsAB, (unsigned)r * SLD + (unsigned)(c - r));
+      }
+    }
+    bool reflect = true;
+    double beta = 0.0;
+    if (j == 0) {
+      // ---- task 0: reflector from column s
+      cplx x[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) x[a] = sb_ld(rsAB, (unsigned)s * SLD + 1u + (unsigned)(br + 8 * a));
+      if (lane == 0) M.d[s] = sb_ld(rsAB, (unsigned)s * SLD).x;
+      double sq = 0.0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        if (br + 8 * a > 0) sq += cabs2(x[a]);
+      cplx t = sb_sum_br(make_double2(sq, 0.0));
+      const double xn2 = __shfl(t.x, 0, 64);
+      const cplx alpha = sb_from_lane(x[0], 0);
+      const trd_refl R = sb_reflector(xn2, alpha);
+      tau = R.tau;
+      beta = R.beta;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int rr = br + 8 * a;
+        cplx v = cmul(x[a], R.scal);
+        if (rr == 0) v = make_double2(1.0, 0.0);
+        if (rr >= nr) v = make_double2(0.0, 0.0);
+        vrow[a] = v;
+      }
+      if (bc == 0) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-          const int rr = 4 * br + a;
-          x[a] = (rr < nr) ? dm_ldg(AB, (size_t)s * SLD + 1 + rr) : make_double2(0.0, 0.0);
+          const int rr = br + 8 * a;
+          if (rr < nr) dm_stg(AB, (size_t)s * SLD + 1 + rr, rr == 0 ? make_double2(beta, 0.0) : make_double2(0.0, 0.0));
         }
+      }
+      if (lane == 0) M.e[s] = beta;
+    } else {
+      // ---- E <- E H_{j-1}, new reflector from its first column, E <- H_j^H E
+      const int c0 = r0 - SB;
+      cplx e[4][4];
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const int c = c0 + bc + 8 * bb;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int r = r0 + br + 8 * a;
+          e[a][bb] = sb_ld(rsAB, (unsigned)c * SLD + (unsigned)(r - c));
+        }
+      }
+      cplx w[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) acc = cadd(acc, cmul(e[a][bb], vcol[bb]));
+        w[a] = cmul(tau, sb_sum_bc(acc));
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) e[a][bb] = csub(e[a][bb], cmulc(w[a], vcol[bb]));
+      reflect = nr >= 2;
+      cplx tauj = make_double2(0.0, 0.0);
+      cplx vnew[4];
+      if (reflect) {
         double sq = 0.0;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
-          if (4 * br + a > 0) sq += cabs2(x[a]);
+          if (br + 8 * a > 0 && br + 8 * a < nr) sq += cabs2(e[a][0]);
+        if (bc != 0) sq = 0.0;
         cplx t = sb_sum_br(make_double2(sq, 0.0));
         const double xn2 = __shfl(t.x, 0, 64);
-        const cplx alpha = sb_from_lane(x[0], 0);
+        const cplx alpha = sb_from_lane(e[0][0], 0);
         const trd_refl R = sb_reflector(xn2, alpha);
-        tau = R.tau;
+        tauj = R.tau;
         beta = R.beta;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-          const int rr = 4 * br + a;
-          cplx v = cmul(x[a], R.scal);
+          const int rr = br + 8 * a;
+          cplx x = sb_from_lane(e[a][0], lane & ~7);  // column 0 of the block lives in the lanes bc == 0
+          cplx v = cmul(x, R.scal);
           if (rr == 0) v = make_double2(1.0, 0.0);
           if (rr >= nr) v = make_double2(0.0, 0.0);
-          vrow[a] = v;
+          vnew[a] = v;
         }
-        if (bc == 0) {
-#pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            const int rr = 4 * br + a;
-            if (rr < nr) dm_stg(AB, (size_t)s * SLD + 1 + rr, rr == 0 ? make_double2(beta, 0.0) : make_double2(0.0, 0.0));
-          }
-        }
-        if (lane == 0) M.e[s] = beta;
-      } else {
-        // ---- E <- E H_{j-1}, new reflector from its first column, E <- H_j^H E
-        const int c0 = r0 - SB;
-        cplx e[4][4];
+        cplx y[4];
 #pragma unroll
         for (int bb = 0; bb < 4; ++bb) {
-          const int c = c0 + 4 * bc + bb;
-#pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            const int r = r0 + 4 * br + a;
-            e[a][bb] = (r < n) ? dm_ldg(AB, (size_t)c * SLD + (r - c)) : make_double2(0.0, 0.0);
-          }
-        }
-        cplx w[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
           cplx acc = make_double2(0.0, 0.0);
 #pragma unroll
-          for (int bb = 0; bb < 4; ++bb) acc = cadd(acc, cmul(e[a][bb], vcol[bb]));
-          w[a] = cmul(tau, sb_sum_bc(acc));
+          for (int a = 0; a < 4; ++a) acc = cadd(acc, make_double2(vnew[a].x * e[a][bb].x + vnew[a].y * e[a][bb].y,
+                                                                    vnew[a].x * e[a][bb].y - vnew[a].y * e[a][bb].x));
+          y[bb] = cmul(cconj(tauj), sb_sum_br(acc));
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-          for (int bb = 0; bb < 4; ++bb) e[a][bb] = csub(e[a][bb], cmulc(w[a], vcol[bb]));
-        reflect = nr >= 2;
-        cplx tauj = make_double2(0.0, 0.0);
-        cplx vnew[4];
-        if (reflect) {
-          double sq = 0.0;
-#pragma unroll
-          for (int a = 0; a < 4; ++a)
-            if (4 * br + a > 0 && 4 * br + a < nr) sq += cabs2(e[a][0]);
-          if (bc != 0) sq = 0.0;
-          cplx t = sb_sum_br(make_double2(sq, 0.0));
-          const double xn2 = __shfl(t.x, 0, 64);
-          const cplx alpha = sb_from_lane(e[0][0], 0);
-          const trd_refl R = sb_reflector(xn2, alpha);
-          tauj = R.tau;
-          beta = R.beta;
-#pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            const int rr = 4 * br + a;
-            cplx x = sb_from_lane(e[a][0], lane & ~7);  // first column lives in the lanes bc == 0
-            cplx v = cmul(x, R.scal);
-            if (rr == 0) v = make_double2(1.0, 0.0);
-            if (rr >= nr) v = make_double2(0.0, 0.0);
-            vnew[a] = v;
-          }
-          cplx y[4];
-#pragma unroll
-          for (int bb = 0; bb < 4; ++bb) {
-            cplx acc = make_double2(0.0, 0.0);
-#pragma unroll
-            for (int a = 0; a < 4; ++a) acc = cadd(acc, make_double2(vnew[a].x * e[a][bb].x + vnew[a].y * e[a][bb].y,
-                                                                      vnew[a].x * e[a][bb].y - vnew[a].y * e[a][bb].x));
-            y[bb] = cmul(cconj(tauj), sb_sum_br(acc));
-          }
-#pragma unroll
-          for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb) e[a][bb] = csub(e[a][bb], cmul(vnew[a], y[bb]));
-          if (bc == 0) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) e[a][0] = (4 * br + a == 0) ? make_double2(beta, 0.0) : make_double2(0.0, 0.0);
-          }
-        }
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-          const int c = c0 + 4 * bc + bb;
-#pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            const int r = r0 + 4 * br + a;
-            if (r < n) dm_stg(AB, (size_t)c * SLD + (r - c), e[a][bb]);
-          }
-        }
-        tau = tauj;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) vrow[a] = reflect ? vnew[a] : make_double2(0.0, 0.0);
-      }
-      if (reflect) {
-        // ---- store the reflector (lanes bc == 0 hold it by rows)
-        const size_t blk = (size_t)G * M.jb + j;
+          for (int bb = 0; bb < 4; ++bb) e[a][bb] = csub(e[a][bb], cmul(vnew[a], y[bb]));
         if (bc == 0) {
 #pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            const int rr = 4 * br + a;
-            if (rr < nr) dm_stg(M.Vd, (blk * SBG + gi) * SBW + gi + rr, vrow[a]);
-          }
-        }
-        if (lane == 0) M.tau2[blk * SBG + gi] = tau;
-        // the same vector by block columns: lane (br, bc) takes the rows of lane (bc, 0)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) vcol[a] = sb_from_lane(vrow[a], bc * 8);
-        // ---- D <- H^H D H on the Hermitian diagonal block (zhetd2's x, w recurrences)
-        cplx d[4][4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          const int r = r0 + 4 * br + a;
-#pragma unroll
-          for (int bb = 0; bb < 4; ++bb) {
-            const int c = r0 + 4 * bc + bb;
-            cplx v = make_double2(0.0, 0.0);
-            if (r < n && c < n) {
-              if (r >= c) v = dm_ldg(AB, (size_t)c * SLD + (r - c));
-              else v = cconj(dm_ldg(AB, (size_t)r * SLD + (c - r)));
-              if (r == c) v.y = 0.0;
-            }
-            d[a][bb] = v;
-          }
-        }
-        cplx x[4];
-        cplx xv = make_double2(0.0, 0.0);
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          cplx acc = make_double2(0.0, 0.0);
-#pragma unroll
-          for (int bb = 0; bb < 4; ++bb) acc = cadd(acc, cmul(d[a][bb], vcol[bb]));
-          x[a] = cmul(tau, sb_sum_bc(acc));
-          // x^H v, rows of this lane (the same in all lanes of the block row)
-          xv = cadd(xv, make_double2(x[a].x * vrow[a].x + x[a].y * vrow[a].y, x[a].x * vrow[a].y - x[a].y * vrow[a].x));
-        }
-        xv = sb_sum_br(xv);
-        const cplx al = cmul(make_double2(-0.5 * tau.x, -0.5 * tau.y), xv);
-        cplx wv[4], wc[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) wv[a] = cadd(x[a], cmul(al, vrow[a]));
-#pragma unroll
-        for (int a = 0; a < 4; ++a) wc[a] = sb_from_lane(wv[a], bc * 8);
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int bb = 0; bb < 4; ++bb)
-            d[a][bb] = csub(csub(d[a][bb], cmulc(vrow[a], wc[bb])), cmulc(wv[a], vcol[bb]));
-        if (br >= bc) {
-#pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            const int r = r0 + 4 * br + a;
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-              const int c = r0 + 4 * bc + bb;
-              if (r < n && c <= r) {
-                cplx v = d[a][bb];
-                if (r == c) v.y = 0.0;
-                dm_stg(AB, (size_t)c * SLD + (r - c), v);
-              }
-            }
-          }
+          for (int a = 0; a < 4; ++a) e[a][0] = (br + 8 * a == 0) ? make_double2(beta, 0.0) : make_double2(0.0, 0.0);
         }
       }
-      // ---- publish: task j of sweep s is finished
-      if (MULTI) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(M.prog + s, (unsigned)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0)
-          __hip_atomic_store(&lprog[s & 63], ((unsigned)(s + 1) << 16) | (unsigned)(j + 1), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const int c = c0 + bc + 8 * bb;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int r = r0 + br + 8 * a;
+          if (r < n) dm_stg(AB, (size_t)c * SLD + (r - c), e[a][bb]);
+        }
       }
-      if (!reflect) break;
+      tau = tauj;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) vrow[a] = reflect ? vnew[a] : make_double2(0.0, 0.0);
     }
-    // ---- sweep finished
-    if (s == n - 2 && lane == 0) M.d[n - 1] = dm_ldg(AB, (size_t)(n - 1) * SLD).x;
-    if (MULTI) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_store(M.prog + s, SB_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0)
-        __hip_atomic_store(&lprog[s & 63], ((unsigned)(s + 1) << 16) | SB_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (reflect) {
+      // ---- store the reflector (lanes bc == 0 hold it by rows)
+      const size_t blk = (size_t)G * M.jb + j;
+      if (bc == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int rr = br + 8 * a;
+          if (rr < nr) dm_stg(M.Vd, (blk * SBG + gi) * SBW + gi + rr, vrow[a]);
+        }
+      }
+      if (lane == 0) M.tau2[blk * SBG + gi] = tau;
+      // the same vector by columns: lane (br, bc) wants v[bc + 8 b] = vrow[b] of the lanes br' = bc
+#pragma unroll
+      for (int a = 0; a < 4; ++a) vcol[a] = sb_from_lane(vrow[a], bc * 8);
+      // ---- D <- H^H D H on the Hermitian diagonal block (zhetd2's x, w recurrences)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int r = br + 8 * a;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+          const int c = bc + 8 * bb;
+          if (r < c) d[a][bb] = cconj(d[a][bb]);
+          if (r == c) d[a][bb].y = 0.0;
+        }
+      }
+      cplx x[4];
+      cplx xv = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) acc = cadd(acc, cmul(d[a][bb], vcol[bb]));
+        x[a] = cmul(tau, sb_sum_bc(acc));
+        // x^H v over the rows of this lane (the same in all lanes that share the rows)
+        xv = cadd(xv, make_double2(x[a].x * vrow[a].x + x[a].y * vrow[a].y, x[a].x * vrow[a].y - x[a].y * vrow[a].x));
+      }
+      xv = sb_sum_br(xv);
+      const cplx al = cmul(make_double2(-0.5 * tau.x, -0.5 * tau.y), xv);
+      cplx wv[4], wc[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) wv[a] = cadd(x[a], cmul(al, vrow[a]));
+#pragma unroll
+      for (int a = 0; a < 4; ++a) wc[a] = sb_from_lane(wv[a], bc * 8);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int r = r0 + br + 8 * a;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+          const int c = r0 + bc + 8 * bb;
+          if (r < n && c <= r) {
+            cplx v = csub(csub(d[a][bb], cmulc(vrow[a], wc[bb])), cmulc(wv[a], vcol[bb]));
+            if (r == c) v.y = 0.0;
+            dm_stg(AB, (size_t)c * SLD + (r - c), v);
+          }
+        }
+      }
+    }
+    // ---- publish: task j of sweep s is finished (the stores have reached L2)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(M.prog + s, (unsigned)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!reflect) break;
+  }
+  // ---- sweep finished
+  if (s == n - 2 && lane == 0) M.d[n - 1] = sb_ld(rsAB, (unsigned)(n - 1) * SLD).x;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_store(M.prog + s, SB_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void sb_chase_kernel(const sb_chase_mat* __restrict__ ms, const sb_chase_ctl ctl) {
+  const int lane = threadIdx.x & 63;
+  const int xcd = __builtin_amdgcn_s_getreg(6164) & 7;  // hwreg(HW_REG_XCC_ID, 0, 4)
+  __shared__ int s_mat;
+  for (int qq = 0; qq < 8; ++qq) {
+    const int q = (xcd + qq) & 7;
+    const int qlen = ctl.qoff[q + 1] - ctl.qoff[q];
+    for (;;) {
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int m = -1;
+        const int ent = atomicAdd(ctl.qhead + q, 1);
+        if (ent < qlen) {
+          m = ctl.qent[ctl.qoff[q] + ent];
+          const int old = atomicCAS(ms[m].owner, -1, xcd);
+          if (old != -1 && old != xcd) m = -2;  // claimed by another XCD
+        }
+        s_mat = m;
+      }
+      __syncthreads();
+      const int m = s_mat;
+      if (m == -1) break;
+      if (m == -2) continue;
+      const sb_chase_mat M = ms[m];
+      if (M.n == 1) {
+        if (threadIdx.x == 0) M.d[0] = dm_ldg(M.AB, 0).x;
+        continue;
+      }
+      const __amdgpu_buffer_rsrc_t rsAB =
+          __builtin_amdgcn_make_buffer_rsrc((void*)M.AB, 0, (int)min((size_t)M.n * SLD * sizeof(cplx), (size_t)0x7fffffff), 0x00020000);
+      for (;;) {
+        int s = 0;
+        if (lane == 0) s = atomicAdd(M.next, 1);
+        s = __builtin_amdgcn_readfirstlane(s);
+        if (s >= M.n - 1) break;
+        if (__hip_atomic_load(ctl.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        const unsigned long long t0 = wall_clock64();
+        sb_chase_sweep(M, rsAB, ctl.err, s, lane);
+        if (ctl.dbg && lane == 0) { ctl.dbg[2 * s] = t0; ctl.dbg[2 * s + 1] = wall_clock64(); }
+      }
     }
   }
 }

@@ -1804,7 +1804,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
     sbM1 = dm_ws_alloc_t<cplx>(ctx, (size_t)np * SB * SB);
     sbS = dm_ws_alloc_t<cplx>(ctx, (size_t)np * SB * SB);
     sbProg = dm_ws_alloc_t<unsigned>(ctx, std::max<size_t>(totn, 1));
-    sbNext = dm_ws_alloc_t<int>(ctx, np);
+    sbNext = dm_ws_alloc_t<int>(ctx, 2 * (size_t)np + 9);  // sweep counters, owners, queue heads, error flag
     if (!sbPw || !sbXt || !sbYp || !sbNp || !sbAB || !sbVd || !sbTau2 || !sbM1 || !sbS || !sbProg || !sbNext) return DM_ENOMEM;
   }
 
@@ -1826,7 +1826,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       dmv[i] = sb_dmat{probs[p].C, probs[p].ldc, probs[p].n};
       bm[i] = sb_bmat{probs[p].C, probs[p].ldc, probs[p].n, sbAB + offn[p] * SLD};
       cm[i] = sb_chase_mat{sbAB + offn[p] * SLD, probs[p].n, sbVd + offvd[p], sbTau2 + offt2[p], dd + offn[p], ee + offn[p],
-                           sb_jb[p], sbProg + offn[p], sbNext + p};
+                           sb_jb[p], sbProg + offn[p], sbNext + p, sbNext + np + p};
     }
     sb_mat* d_sm = dm_ws_upload(ctx, sm);
     sb_dmat* d_dm = dm_ws_upload(ctx, dmv);
@@ -1923,15 +1923,62 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       size_t maxel = (size_t)cmax * SLD;
       hipLaunchKernelGGL(sb_band_extract_kernel, dim3((unsigned)((maxel + 255) / 256), nc), dim3(256), 0, ctx->stream, d_bm);
       if (dump) DM_TRY(dump_arr(".band", sbAB, sizeof(cplx) * totn * SLD));
+      // One persistent launch: per-XCD queues of matrix ids; a matrix gets as many entries (= workgroups) as its
+      // pipeline of sweeps can keep busy (sweep s + 1 trails sweep s by two blocks: n / (2 SB) sweeps in flight).
       constexpr int NW = 8;
-      int wgpm = std::min((cmax + 2 * SB * NW - 1) / (2 * SB * NW), std::max(1, 512 / nc));
-      if (const char* e = getenv("DM_SB_WGPM")) wgpm = std::max(1, atoi(e));
-      if (wgpm <= 1) {
-        hipLaunchKernelGGL((sb_chase_kernel<false, NW>), dim3(nc), dim3(64 * NW), 0, ctx->stream, d_cmat, 1);
-      } else {
-        DM_TRY(dm_fill_zero(ctx, sbProg, sizeof(unsigned) * totn));
-        DM_TRY(dm_fill_zero(ctx, sbNext, sizeof(int) * np));
-        hipLaunchKernelGGL((sb_chase_kernel<true, NW>), dim3(nc * wgpm), dim3(64 * NW), 0, ctx->stream, d_cmat, wgpm);
+      std::vector<int> order(nc);
+      for (int i = 0; i < nc; ++i) order[i] = i;
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cm[a].n > cm[b].n; });
+      int wgmax = 32;
+      if (const char* e = getenv("DM_SB_WGPM")) wgmax = std::max(1, atoi(e));
+      std::vector<std::vector<int>> qs(8);
+      double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i : order) {
+        const int n = cm[i].n;
+        if (n < 1) continue;
+        int k = std::max(1, std::min(wgmax, (n + 2 * SB * NW - 1) / (2 * SB * NW)));
+        int q = 0;
+        for (int t = 1; t < 8; ++t)
+          if (load[t] < load[q]) q = t;
+        load[q] += (double)n * n;
+        for (int t = 0; t < k; ++t) qs[q].push_back(i);
+      }
+      sb_chase_ctl ctl;
+      std::vector<int> qent;
+      for (int q = 0; q < 8; ++q) {
+        ctl.qoff[q] = (int)qent.size();
+        qent.insert(qent.end(), qs[q].begin(), qs[q].end());
+      }
+      ctl.qoff[8] = (int)qent.size();
+      int* d_qent = dm_ws_upload(ctx, qent);
+      if (!d_qent) return DM_ENOMEM;
+      ctl.qent = d_qent;
+      ctl.qhead = sbNext + 2 * (size_t)np;
+      DM_TRY(dm_fill_zero(ctx, sbProg, sizeof(unsigned) * totn));
+      DM_TRY(dm_fill_zero(ctx, sbNext, sizeof(int) * np));
+      DM_HIP(ctx, hipMemsetAsync(sbNext + np, 0xff, sizeof(int) * np, ctx->stream));
+      DM_TRY(dm_fill_zero(ctx, sbNext + 2 * (size_t)np, sizeof(int) * 9));
+      ctl.err = sbNext + 2 * (size_t)np + 8;
+      ctl.dbg = nullptr;
+      if (dump) {
+        ctl.dbg = dm_ws_alloc_t<unsigned long long>(ctx, 2 * (size_t)cmax + 2);
+        if (!ctl.dbg) return DM_ENOMEM;
+        DM_TRY(dm_fill_zero(ctx, ctl.dbg, sizeof(unsigned long long) * (2 * (size_t)cmax + 2)));
+      }
+      const int nwg = std::min(256, (int)qent.size());
+      hipLaunchKernelGGL((sb_chase_kernel<NW>), dim3(nwg), dim3(64 * NW), 0, ctx->stream, d_cmat, ctl);
+      {
+        int herr = 0;  // (the eigenvalue selection synchronises right after this stage anyway)
+        DM_TRY(dm_download(ctx, &herr, sbNext + 2 * (size_t)np + 8, sizeof(int)));
+        if (herr) {
+          if (dump) {
+            DM_TRY(dump_arr(".dbg", ctl.dbg, sizeof(unsigned long long) * (2 * (size_t)cmax + 2)));
+            DM_TRY(dump_arr(".prog", sbProg, sizeof(unsigned) * totn));
+            DM_TRY(dump_arr(".next", sbNext, sizeof(int) * (2 * (size_t)np + 9)));
+          }
+          ctx->err = "bulge chase: a sweep waited for its predecessor for too long";
+          return 2000;
+        }
       }
       if (dump) {
         DM_TRY(dump_arr(".d", dd, sizeof(double) * totn));
@@ -1957,6 +2004,11 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       for (int s0 = 0; s0 < nslab; s0 += NW) wgs.push_back(make_int2(mi, s0));
     }
     if (wgs.empty()) return DM_OK;
+    if (getenv("DM_TRD_SIZES")) {
+      fprintf(stderr, "[apply_q2] n:ncol");
+      for (const auto& q : qm) fprintf(stderr, " %d:%d", q.n, q.ncol);
+      fprintf(stderr, " -> %zu workgroups\n", wgs.size());
+    }
     sb_q2_mat* d_qm = dm_ws_upload(ctx, qm);
     int2* d_wgs = dm_ws_upload(ctx, wgs);
     if (!d_qm || !d_wgs) return DM_ENOMEM;
