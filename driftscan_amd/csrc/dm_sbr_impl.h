@@ -238,19 +238,39 @@ struct sb_chase_ctl { int* qhead; const int* qent; int* err; unsigned long long*
 
 constexpr unsigned SB_DONE = 0xffffu;
 
-__device__ __forceinline__ double sb_xor(double v, int m) { return __shfl_xor(v, m, 64); }
+// Butterfly sums without the LDS crossbar: DPP moves inside a 16-lane row (quad_perm for xor 1 and 2, row_half_mirror
+// once the quads are uniform, row_ror:8 for xor 8) and the gfx950 lane swaps across rows: v_permlane16_swap(x, x) leaves
+// {row0, row0, row2, row2} and {row1, row1, row3, row3}, v_permlane32_swap(x, x) the two halves, each in every lane.
+__device__ __forceinline__ double sb_swap16_sum(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)(b & 0xffffffffll), hi = (unsigned)(b >> 32);
+  const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __longlong_as_double(((long long)rh[0] << 32) | rl[0]) + __longlong_as_double(((long long)rh[1] << 32) | rl[1]);
+}
+__device__ __forceinline__ double sb_swap32_sum(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)(b & 0xffffffffll), hi = (unsigned)(b >> 32);
+  const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __longlong_as_double(((long long)rh[0] << 32) | rl[0]) + __longlong_as_double(((long long)rh[1] << 32) | rl[1]);
+}
+__device__ __forceinline__ double sb_quad_sum(double v) {  // sum over the four lanes of a quad
+  v += dm_dpp_f64<0xB1>(v);  // quad_perm [1, 0, 3, 2]
+  v += dm_dpp_f64<0x4E>(v);  // quad_perm [2, 3, 0, 1]
+  return v;
+}
 // sum over the lanes that share the row set (bits 0..2 of the lane differ)
 __device__ __forceinline__ cplx sb_sum_bc(cplx v) {
-  v.x += sb_xor(v.x, 1); v.y += sb_xor(v.y, 1);
-  v.x += sb_xor(v.x, 2); v.y += sb_xor(v.y, 2);
-  v.x += sb_xor(v.x, 4); v.y += sb_xor(v.y, 4);
+  v.x = sb_quad_sum(v.x); v.y = sb_quad_sum(v.y);
+  v.x += dm_dpp_f64<0x141>(v.x); v.y += dm_dpp_f64<0x141>(v.y);  // row_half_mirror: the other quad of the 8 lanes
   return v;
 }
 // sum over the lanes that share the column set (bits 3..5 differ)
 __device__ __forceinline__ cplx sb_sum_br(cplx v) {
-  v.x += sb_xor(v.x, 8); v.y += sb_xor(v.y, 8);
-  v.x += sb_xor(v.x, 16); v.y += sb_xor(v.y, 16);
-  v.x += sb_xor(v.x, 32); v.y += sb_xor(v.y, 32);
+  v.x += dm_dpp_f64<0x128>(v.x); v.y += dm_dpp_f64<0x128>(v.y);  // row_ror:8
+  v.x = sb_swap16_sum(v.x); v.y = sb_swap16_sum(v.y);
+  v.x = sb_swap32_sum(v.x); v.y = sb_swap32_sum(v.y);
   return v;
 }
 __device__ __forceinline__ cplx sb_from_lane(cplx v, int src) {
@@ -323,17 +343,6 @@ __device__ __forceinline__ void sb_chase_sweep(const sb_chase_mat& M, __amdgpu_b
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // keeps the band loads below behind the poll
-    }
-    // the Hermitian diagonal block D_j (its loads overlap the work on E_j)
-    cplx d[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int r = r0 + br + 8 * a;
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb) {
-        const int c = r0 + bc + 8 * bb;
-        d[a][bb] = (r >= c) ? sb_ld(rsAB, (unsigned)c * SLD + (unsigned)(r - c)) : sb_ld(rsAB, (unsigned)r * SLD + (unsigned)(c - r));
-      }
     }
     bool reflect = true;
     double beta = 0.0;
@@ -450,6 +459,18 @@ __device__ __forceinline__ void sb_chase_sweep(const sb_chase_mat& M, __amdgpu_b
       for (int a = 0; a < 4; ++a) vrow[a] = reflect ? vnew[a] : make_double2(0.0, 0.0);
     }
     if (reflect) {
+      // the Hermitian diagonal block D_j (loaded once E_j is on its way out: both blocks at once do not fit the registers
+      // of two waves per SIMD)
+      cplx d[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int r = r0 + br + 8 * a;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+          const int c = r0 + bc + 8 * bb;
+          d[a][bb] = (r >= c) ? sb_ld(rsAB, (unsigned)c * SLD + (unsigned)(r - c)) : sb_ld(rsAB, (unsigned)r * SLD + (unsigned)(c - r));
+        }
+      }
       // ---- store the reflector (lanes bc == 0 hold it by rows)
       const size_t blk = (size_t)G * M.jb + j;
       if (bc == 0) {
@@ -566,7 +587,7 @@ __global__ __launch_bounds__(64 * NW) void sb_chase_kernel(const sb_chase_mat* _
 
 // ---- B2: X <- Q2 X, column slabs in registers ------------------------------------------------------------------------
 //
-// A wave owns 16 columns of X; four lanes share a column and take the window rows w = 4 u + part (any 32 consecutive
+// A wave owns 16 columns of X; the four lanes of a quad share a column and take the window rows w = 4 u + part (any 32 consecutive
 // rows hold exactly eight — at most nine counting both ends — rows of each part).  Groups of SBG sweeps are applied last
 // to first; inside a group the diamond blocks j = 0, 1, ... in turn (block (G, j) touches the rows [G SBG + 1 + j SB,
 // + SBG + SB - 1) of X), inside a block the sweeps last to first.  The window slides down by SB rows per block: the rows
@@ -585,8 +606,8 @@ __global__ __launch_bounds__(64 * NW) void sb_q2_apply_kernel(const sb_q2_mat* _
   const sb_q2_mat M = ms[wg.x];
   const int n = M.n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = (wg.y + wave) * 16 + (lane & 15);
-  const int part = lane >> 4;
+  const int col = (wg.y + wave) * 16 + (lane >> 2);
+  const int part = lane & 3;
   const bool cvalid = col < M.ncol;
   extern __shared__ __align__(16) unsigned char sb_q2_smem[];
   cplx (*sv)[SBG * SBW] = reinterpret_cast<cplx (*)[SBG * SBW]>(sb_q2_smem);
@@ -642,8 +663,8 @@ __global__ __launch_bounds__(64 * NW) void sb_q2_apply_kernel(const sb_q2_mat* _
                 acc.y += v[t].x * xx.y - v[t].y * xx.x;
               }
             }
-            acc.x += sb_xor(acc.x, 16); acc.y += sb_xor(acc.y, 16);
-            acc.x += sb_xor(acc.x, 32); acc.y += sb_xor(acc.y, 32);
+            acc.x = sb_quad_sum(acc.x);
+            acc.y = sb_quad_sum(acc.y);
             const cplx f = cmul(tq, acc);  // H x = x - tau v (v^H x)
 #pragma unroll
             for (int t = 0; t < 9; ++t)

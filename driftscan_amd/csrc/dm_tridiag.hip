@@ -53,6 +53,9 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
     for (const auto& p : probs) fprintf(stderr, " %d", p.n);
     fprintf(stderr, "\n");
   }
+  // the two-stage reduction (dm_sbr_impl.h) lives in the 32-wide instantiation: its bandwidth is the panel width
+  if (const char* e = getenv("DM_TRD_TWOSTAGE"))
+    if (atoi(e) == 1) width = 32;
   if (const char* e = getenv("DM_TRD_PANEL")) width = atoi(e) == 64 ? 64 : 32;
   return width == 32 ? dm_trd32::herm_eig_tridiag(ctx, probs, evals, evals_stride, sel)
                      : dm_trd64::herm_eig_tridiag(ctx, probs, evals, evals_stride, sel);

@@ -1965,7 +1965,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
         if (!ctl.dbg) return DM_ENOMEM;
         DM_TRY(dm_fill_zero(ctx, ctl.dbg, sizeof(unsigned long long) * (2 * (size_t)cmax + 2)));
       }
-      const int nwg = std::min(256, (int)qent.size());
+      const int nwg = 256;  // one per CU: a matrix is served by the workgroups of ONE XCD, whichever claims it first
       hipLaunchKernelGGL((sb_chase_kernel<NW>), dim3(nwg), dim3(64 * NW), 0, ctx->stream, d_cmat, ctl);
       {
         int herr = 0;  // (the eigenvalue selection synchronises right after this stage anyway)
@@ -1981,6 +1981,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
         }
       }
       if (dump) {
+        DM_TRY(dump_arr(".dbg", ctl.dbg, sizeof(unsigned long long) * (2 * (size_t)cmax + 2)));
         DM_TRY(dump_arr(".d", dd, sizeof(double) * totn));
         DM_TRY(dump_arr(".e", ee, sizeof(double) * totn));
       }
@@ -1991,7 +1992,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
 
   // X <- Q2 X (X = probs[p].C, n x ncolv[p]): workgroups of NW column slabs, large matrices first
   auto apply_q2 = [&](const std::vector<int>& ch, const std::vector<int>& ncolv) -> int {
-    constexpr int NW = 8;
+    constexpr int NW = 4;
     std::vector<sb_q2_mat> qm;
     std::vector<int2> wgs;
     std::vector<int> order(ch);
