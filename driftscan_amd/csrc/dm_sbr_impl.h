@@ -180,6 +180,297 @@ __global__ __launch_bounds__(256) void sb_qr_dots_kernel(const sb_mat* __restric
   }
 }
 
+// Butterfly sums without the LDS crossbar: DPP moves inside a 16-lane row (quad_perm for xor 1 and 2, row_half_mirror
+// once the quads are uniform, row_ror:8 for xor 8) and the gfx950 lane swaps across rows: v_permlane16_swap(x, x) leaves
+// {row0, row0, row2, row2} and {row1, row1, row3, row3}, v_permlane32_swap(x, x) the two halves, each in every lane.
+__device__ __forceinline__ double sb_swap16_sum(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)(b & 0xffffffffll), hi = (unsigned)(b >> 32);
+  const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __longlong_as_double(((long long)rh[0] << 32) | rl[0]) + __longlong_as_double(((long long)rh[1] << 32) | rl[1]);
+}
+__device__ __forceinline__ double sb_swap32_sum(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)(b & 0xffffffffll), hi = (unsigned)(b >> 32);
+  const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __longlong_as_double(((long long)rh[0] << 32) | rl[0]) + __longlong_as_double(((long long)rh[1] << 32) | rl[1]);
+}
+__device__ __forceinline__ double sb_quad_sum(double v) {  // sum over the four lanes of a quad
+  v += dm_dpp_f64<0xB1>(v);  // quad_perm [1, 0, 3, 2]
+  v += dm_dpp_f64<0x4E>(v);  // quad_perm [2, 3, 0, 1]
+  return v;
+}
+// sum over the lanes that share the row set (bits 0..2 of the lane differ)
+__device__ __forceinline__ cplx sb_sum_bc(cplx v) {
+  v.x = sb_quad_sum(v.x); v.y = sb_quad_sum(v.y);
+  v.x += dm_dpp_f64<0x141>(v.x); v.y += dm_dpp_f64<0x141>(v.y);  // row_half_mirror: the other quad of the 8 lanes
+  return v;
+}
+// sum over the lanes that share the column set (bits 3..5 differ)
+__device__ __forceinline__ cplx sb_sum_br(cplx v) {
+  v.x += dm_dpp_f64<0x128>(v.x); v.y += dm_dpp_f64<0x128>(v.y);  // row_ror:8
+  v.x = sb_swap16_sum(v.x); v.y = sb_swap16_sum(v.y);
+  v.x = sb_swap32_sum(v.x); v.y = sb_swap32_sum(v.y);
+  return v;
+}
+__device__ __forceinline__ cplx sb_from_lane(cplx v, int src) {
+  return make_double2(__shfl(v.x, src, 64), __shfl(v.y, src, 64));
+}
+
+// Householder scalars from alpha and the squared norm of the rest (zlarfg), every lane the same
+__device__ __forceinline__ trd_refl sb_reflector(double xnorm2, cplx alpha) {
+  trd_refl R;
+  if (xnorm2 == 0.0 && alpha.y == 0.0) {
+    R.tau = make_double2(0.0, 0.0);
+    R.beta = alpha.x;
+    R.scal = make_double2(0.0, 0.0);
+  } else {
+    R.beta = -copysign(sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xnorm2), alpha.x);
+    R.tau = make_double2((R.beta - alpha.x) / R.beta, -alpha.y / R.beta);
+    const double dr = alpha.x - R.beta, di = alpha.y;
+    const double den = dr * dr + di * di;
+    R.scal = make_double2(dr / den, -di / den);
+  }
+  return R;
+}
+
+// ---- S1: fused panel QR, one workgroup per matrix (panels of at most SFR * SFT rows) ---------------------------------
+//
+// The 32 columns are factorised as four sub-panels of 8 that live in the registers of the workgroup (thread t holds
+// the rows i0 + t + 512 r): the reflectors of the earlier sub-panels are applied to the sub-panel first (one workgroup
+// reduction each), then 8 right-looking column steps.  A column step costs two workgroup reductions (norm + alpha, then
+// the dot products with the remaining columns of the sub-panel) and no memory traffic; one launch replaces the 65
+// launches per panel of the launched kernels above.
+constexpr int SFT = 512;  // threads
+constexpr int SFR = 3;    // rows per thread
+constexpr int SFH = 8;    // columns per sub-panel
+
+// Transposing butterfly: 32 doubles per lane -> lane L ends with the wave total of value (L >> 1).  Each stage pairs
+// two values and halves their number: the gfx950 lane swaps exchange the halves (rows) of TWO registers at once, the
+// stages inside a 16-lane row send one value of the pair and keep the other (DPP moves, no LDS crossbar).  ~140
+// instructions for 32 values against ~800 for 32 separate all-reduces.
+__device__ __forceinline__ void sb_swap32_pair(double& a, double b) {  // lower half: a summed, upper half: b summed
+  const long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
+  const auto rl = __builtin_amdgcn_permlane32_swap((unsigned)(ba & 0xffffffffll), (unsigned)(bb & 0xffffffffll), false, false);
+  const auto rh = __builtin_amdgcn_permlane32_swap((unsigned)(ba >> 32), (unsigned)(bb >> 32), false, false);
+  a = __longlong_as_double(((long long)rh[0] << 32) | rl[0]) + __longlong_as_double(((long long)rh[1] << 32) | rl[1]);
+}
+__device__ __forceinline__ void sb_swap16_pair(double& a, double b) {  // even rows: a summed, odd rows: b summed
+  const long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
+  const auto rl = __builtin_amdgcn_permlane16_swap((unsigned)(ba & 0xffffffffll), (unsigned)(bb & 0xffffffffll), false, false);
+  const auto rh = __builtin_amdgcn_permlane16_swap((unsigned)(ba >> 32), (unsigned)(bb >> 32), false, false);
+  a = __longlong_as_double(((long long)rh[0] << 32) | rl[0]) + __longlong_as_double(((long long)rh[1] << 32) | rl[1]);
+}
+__device__ __forceinline__ double sb_wave_reduce32(double (&v)[32]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) sb_swap32_pair(v[k], v[k + 16]);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sb_swap16_pair(v[k], v[k + 8]);
+  const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double send = b3 ? v[k] : v[k + 4], keep = b3 ? v[k + 4] : v[k];
+    v[k] = keep + dm_dpp_f64<0x128>(send);  // row_ror:8
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const double send = b2 ? v[k] : v[k + 2], keep = b2 ? v[k + 2] : v[k];
+    const double up = dm_dpp_f64<0x114>(send), dn = dm_dpp_f64<0x104>(send);  // row_shr:4 (from lane - 4), row_shl:4 (from lane + 4)
+    v[k] = keep + (b2 ? up : dn);
+  }
+  {
+    const double send = b1 ? v[0] : v[1], keep = b1 ? v[1] : v[0];
+    v[0] = keep + dm_dpp_f64<0x4E>(send);  // quad_perm [2, 3, 0, 1]
+  }
+  return v[0] + dm_dpp_f64<0xB1>(v[0]);    // quad_perm [1, 0, 3, 2]
+}
+
+// sums of K <= 32 doubles over the workgroup (8 waves): the butterfly inside each wave, then through LDS
+template <int K>
+__device__ __forceinline__ void sb_wg_reduce(double (&v)[K], double* red /* [2][8 * 32 + 32] */, int& phase) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* r = red + (size_t)phase * (8 * 32 + 32);
+  if constexpr (K <= 4) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      double t = sb_quad_sum(v[k]);
+      t += dm_dpp_f64<0x141>(t);
+      t += dm_dpp_f64<0x128>(t);
+      t = sb_swap16_sum(t);
+      t = sb_swap32_sum(t);
+      if (lane == 0) r[wave * 32 + k] = t;
+    }
+  } else {
+    double w[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) w[k] = k < K ? v[k] : 0.0;
+    const double t = sb_wave_reduce32(w);
+    if (!(lane & 1) && (lane >> 1) < K) r[wave * 32 + (lane >> 1)] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    double t = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < 8; ++wv) t += r[wv * 32 + threadIdx.x];
+    r[8 * 32 + threadIdx.x] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = r[8 * 32 + k];
+  phase ^= 1;  // the next reduction uses the other buffer
+}
+
+// Right-looking Householder QR of the SFH columns [cb, cb + SFH) of the panel held in a[][] (nrf = reflectors of the
+// panel).  The column being factorised is always a[.][0]: the array is shifted by one column after every step, so the
+// loop body is the same code for every column (columns past the end are zero and cost nothing but their flops).
+__device__ __forceinline__ void sb_fused_half(const sb_mat& M, cplx (&a)[SFR][SFH], int k0, int cb, int nrf, double* red, int& phase) {
+  const int n = M.n;
+  const int tid = threadIdx.x;
+  const int i0 = k0 + SB;
+#pragma unroll 1
+  for (int q = 0; q < SFH; ++q) {
+    const int qq = cb + q;          // column of the panel
+    const int lead = i0 + qq;
+    const bool has = qq < nrf;
+    trd_refl R;
+    R.tau = make_double2(0.0, 0.0); R.scal = make_double2(0.0, 0.0); R.beta = 0.0;
+    cplx v[SFR];
+    if (has) {
+      double t3[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < SFR; ++r) {
+        const int i = i0 + tid + SFT * r;
+        if (i < n && i > lead) t3[0] += cabs2(a[r][0]);
+        if (i == lead) { t3[1] = a[r][0].x; t3[2] = a[r][0].y; }
+      }
+      sb_wg_reduce<3>(t3, red, phase);
+      R = sb_reflector(t3[0], make_double2(t3[1], t3[2]));
+    }
+#pragma unroll
+    for (int r = 0; r < SFR; ++r) {
+      const int i = i0 + tid + SFT * r;
+      cplx x = cmul(a[r][0], R.scal);
+      if (i == lead) x = make_double2(1.0, 0.0);
+      if (i < lead || i >= n || !has) x = make_double2(0.0, 0.0);
+      v[r] = x;
+    }
+    if (has && q + 1 < SFH) {
+      double y[2 * (SFH - 1)];
+#pragma unroll
+      for (int c = 1; c < SFH; ++c) {
+        cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int r = 0; r < SFR; ++r) {
+          acc.x += v[r].x * a[r][c].x + v[r].y * a[r][c].y;  // conj(v) * a
+          acc.y += v[r].x * a[r][c].y - v[r].y * a[r][c].x;
+        }
+        y[2 * (c - 1)] = acc.x;
+        y[2 * (c - 1) + 1] = acc.y;
+      }
+      sb_wg_reduce<2 * (SFH - 1)>(y, red, phase);
+      const cplx ct = cconj(R.tau);
+#pragma unroll
+      for (int c = 1; c < SFH; ++c) {
+        const cplx f = cmul(ct, make_double2(y[2 * (c - 1)], y[2 * (c - 1) + 1]));
+#pragma unroll
+        for (int r = 0; r < SFR; ++r) a[r][c] = csub(a[r][c], cmul(v[r], f));
+      }
+    }
+    // outputs: v into the panel buffers and Vt, the column of R into the band part of A, tau
+#pragma unroll
+    for (int r = 0; r < SFR; ++r) {
+      const int i = i0 + tid + SFT * r;
+      if (i < n) {
+        dm_stg(M.Vp, (size_t)qq * n + i, v[r]);
+        dm_stg(M.Vp2, (size_t)qq * n + i, v[r]);
+        dm_stg(M.Vt, (size_t)(k0 + qq) * n + i, v[r]);
+        if (has) {
+          if (i <= lead) dm_stg(M.A, (size_t)(k0 + qq) * M.lda + i, i < lead ? cconj(a[r][0]) : make_double2(R.beta, 0.0));
+        } else {
+          dm_stg(M.A, (size_t)(k0 + qq) * M.lda + i, cconj(a[r][0]));
+        }
+      }
+    }
+    if (tid == 0) M.tau[k0 + qq] = R.tau;
+    // next column to the front
+#pragma unroll
+    for (int r = 0; r < SFR; ++r) {
+#pragma unroll
+      for (int c = 0; c + 1 < SFH; ++c) a[r][c] = a[r][c + 1];
+      a[r][SFH - 1] = make_double2(0.0, 0.0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(SFT) void sb_panel_fused_kernel(const sb_mat* __restrict__ ms, int k0, int a0) {
+  const sb_mat M = ms[blockIdx.x];
+  const int n = M.n;
+  const int m = n - k0 - SB;
+  if (m < 2) return;
+  const int nrf = min(SB, m - 1);
+  const int tid = threadIdx.x;
+  const int i0 = k0 + SB;
+  __shared__ double red[2 * (8 * 32 + 32)];
+  int phase = 0;
+  // the panel rows above the trailing matrix inside its first 64-aligned tile are zero in V and W
+  for (int i = a0 + tid; i < i0; i += SFT) {
+    const cplx z = make_double2(0.0, 0.0);
+    for (int q = 0; q < SB; ++q) {
+      dm_stg(M.Vp, (size_t)q * n + i, z);
+      dm_stg(M.Vp2, (size_t)q * n + i, z);
+      dm_stg(M.Wp, (size_t)q * n + i, z);
+    }
+  }
+  cplx a[SFR][SFH];
+#pragma unroll 1
+  for (int cb = 0; cb < SB; cb += SFH) {
+    // ---- sub-panel [cb, cb + SFH) into registers
+#pragma unroll
+    for (int r = 0; r < SFR; ++r) {
+      const int i = i0 + tid + SFT * r;
+#pragma unroll
+      for (int c = 0; c < SFH; ++c)
+        a[r][c] = (i < n) ? cconj(dm_ldg(M.A, (size_t)(k0 + cb + c) * M.lda + i)) : make_double2(0.0, 0.0);
+    }
+    // ---- the reflectors of the earlier sub-panels: a_c <- a_c - conj(tau_q) v_q (v_q^H a_c), q = 0 .. cb - 1 in turn
+    __syncthreads();  // their vectors are in memory (this workgroup wrote them: L1 holds no older copy)
+#pragma unroll 1
+    for (int q = 0; q < cb && q < nrf; ++q) {
+      cplx v[SFR];
+#pragma unroll
+      for (int r = 0; r < SFR; ++r) {
+        const int i = i0 + tid + SFT * r;
+        v[r] = (i < n) ? dm_ldg(M.Vp, (size_t)q * n + i) : make_double2(0.0, 0.0);
+      }
+      const cplx tq = M.tau[k0 + q];
+      double y[2 * SFH];
+#pragma unroll
+      for (int c = 0; c < SFH; ++c) {
+        cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int r = 0; r < SFR; ++r) {
+          acc.x += v[r].x * a[r][c].x + v[r].y * a[r][c].y;
+          acc.y += v[r].x * a[r][c].y - v[r].y * a[r][c].x;
+        }
+        y[2 * c] = acc.x;
+        y[2 * c + 1] = acc.y;
+      }
+      sb_wg_reduce<2 * SFH>(y, red, phase);
+      const cplx ct = cconj(tq);
+#pragma unroll
+      for (int c = 0; c < SFH; ++c) {
+        const cplx f = cmul(ct, make_double2(y[2 * c], y[2 * c + 1]));
+#pragma unroll
+        for (int r = 0; r < SFR; ++r) a[r][c] = csub(a[r][c], cmul(v[r], f));
+      }
+    }
+    sb_fused_half(M, a, k0, cb, nrf, red, phase);
+  }
+}
+
 // make the 64-aligned diagonal tiles complete (lower part <- conj of the upper part): the products
 // Y = A22 X of the first stage read whole diagonal tiles, the her2k updates keep them complete
 struct sb_dmat { cplx* A; int lda; int n; };
@@ -237,62 +528,6 @@ struct sb_chase_mat {
 struct sb_chase_ctl { int* qhead; const int* qent; int* err; unsigned long long* dbg; int qoff[9]; };
 
 constexpr unsigned SB_DONE = 0xffffu;
-
-// Butterfly sums without the LDS crossbar: DPP moves inside a 16-lane row (quad_perm for xor 1 and 2, row_half_mirror
-// once the quads are uniform, row_ror:8 for xor 8) and the gfx950 lane swaps across rows: v_permlane16_swap(x, x) leaves
-// {row0, row0, row2, row2} and {row1, row1, row3, row3}, v_permlane32_swap(x, x) the two halves, each in every lane.
-__device__ __forceinline__ double sb_swap16_sum(double v) {
-  const long long b = __double_as_longlong(v);
-  const unsigned lo = (unsigned)(b & 0xffffffffll), hi = (unsigned)(b >> 32);
-  const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-  const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-  return __longlong_as_double(((long long)rh[0] << 32) | rl[0]) + __longlong_as_double(((long long)rh[1] << 32) | rl[1]);
-}
-__device__ __forceinline__ double sb_swap32_sum(double v) {
-  const long long b = __double_as_longlong(v);
-  const unsigned lo = (unsigned)(b & 0xffffffffll), hi = (unsigned)(b >> 32);
-  const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-  const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  return __longlong_as_double(((long long)rh[0] << 32) | rl[0]) + __longlong_as_double(((long long)rh[1] << 32) | rl[1]);
-}
-__device__ __forceinline__ double sb_quad_sum(double v) {  // sum over the four lanes of a quad
-  v += dm_dpp_f64<0xB1>(v);  // quad_perm [1, 0, 3, 2]
-  v += dm_dpp_f64<0x4E>(v);  // quad_perm [2, 3, 0, 1]
-  return v;
-}
-// sum over the lanes that share the row set (bits 0..2 of the lane differ)
-__device__ __forceinline__ cplx sb_sum_bc(cplx v) {
-  v.x = sb_quad_sum(v.x); v.y = sb_quad_sum(v.y);
-  v.x += dm_dpp_f64<0x141>(v.x); v.y += dm_dpp_f64<0x141>(v.y);  // row_half_mirror: the other quad of the 8 lanes
-  return v;
-}
-// sum over the lanes that share the column set (bits 3..5 differ)
-__device__ __forceinline__ cplx sb_sum_br(cplx v) {
-  v.x += dm_dpp_f64<0x128>(v.x); v.y += dm_dpp_f64<0x128>(v.y);  // row_ror:8
-  v.x = sb_swap16_sum(v.x); v.y = sb_swap16_sum(v.y);
-  v.x = sb_swap32_sum(v.x); v.y = sb_swap32_sum(v.y);
-  return v;
-}
-__device__ __forceinline__ cplx sb_from_lane(cplx v, int src) {
-  return make_double2(__shfl(v.x, src, 64), __shfl(v.y, src, 64));
-}
-
-// Householder scalars from alpha and the squared norm of the rest (zlarfg), every lane the same
-__device__ __forceinline__ trd_refl sb_reflector(double xnorm2, cplx alpha) {
-  trd_refl R;
-  if (xnorm2 == 0.0 && alpha.y == 0.0) {
-    R.tau = make_double2(0.0, 0.0);
-    R.beta = alpha.x;
-    R.scal = make_double2(0.0, 0.0);
-  } else {
-    R.beta = -copysign(sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xnorm2), alpha.x);
-    R.tau = make_double2((R.beta - alpha.x) / R.beta, -alpha.y / R.beta);
-    const double dr = alpha.x - R.beta, di = alpha.y;
-    const double den = dr * dr + di * di;
-    R.scal = make_double2(dr / den, -di / den);
-  }
-  return R;
-}
 
 typedef unsigned int sb_u4 __attribute__((ext_vector_type(4)));
 // sc1 loads: served by the XCD's L2, bypassing the vector L1 of this CU (element index in units of cplx / dwords)

@@ -1841,11 +1841,17 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
     for (int k0 = 0; cmax - k0 - SB >= 2; k0 += SB) {
       const int i0 = k0 + SB;        // first row of the trailing matrix
       const int a0 = i0 & ~63;       // its 64-aligned tile origin (the panel vectors are zero on [a0, i0))
-      hipLaunchKernelGGL(sb_panel_load_kernel, dim3((cmax - a0 + 255) / 256, nc), dim3(256), 0, ctx->stream, d_sm, k0, a0);
-      const int nchmax = (cmax - i0 + SQR - 1) / SQR;
-      for (int q = 0; q <= SB; ++q) {
-        hipLaunchKernelGGL(sb_qr_update_kernel, dim3(nchmax, nc), dim3(256), 0, ctx->stream, d_sm, k0, q);
-        if (q < SB) hipLaunchKernelGGL(sb_qr_dots_kernel, dim3(nchmax, nc), dim3(256), 0, ctx->stream, d_sm, k0, q);
+      static const bool nofuse = getenv("DM_SB_NOFUSE") != nullptr;
+      if (cmax - i0 <= SFR * SFT && !nofuse) {
+        // panels that fit the registers of one workgroup per matrix: the whole QR in one launch
+        hipLaunchKernelGGL(sb_panel_fused_kernel, dim3(nc), dim3(SFT), 0, ctx->stream, d_sm, k0, a0);
+      } else {
+        hipLaunchKernelGGL(sb_panel_load_kernel, dim3((cmax - a0 + 255) / 256, nc), dim3(256), 0, ctx->stream, d_sm, k0, a0);
+        const int nchmax = (cmax - i0 + SQR - 1) / SQR;
+        for (int q = 0; q <= SB; ++q) {
+          hipLaunchKernelGGL(sb_qr_update_kernel, dim3(nchmax, nc), dim3(256), 0, ctx->stream, d_sm, k0, q);
+          if (q < SB) hipLaunchKernelGGL(sb_qr_dots_kernel, dim3(nchmax, nc), dim3(256), 0, ctx->stream, d_sm, k0, q);
+        }
       }
       // T factor of the panel (zlarft from the Gram matrix), straight into the slot the back-transformation reads
       std::vector<dm_gemm_desc> gg, gx, gy1, gy2, gm, gs, gw, gh;
