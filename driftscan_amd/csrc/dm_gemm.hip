@@ -609,7 +609,7 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
     for (int a = 0; a < tm; ++a)
       for (int b = 0; b < tn; ++b) {
         if ((d.flags & DM_GEMM_LOWER) && b > a) continue;
-        if ((d.flags & DM_GEMM_UPPER) && b < a) continue;
+        if ((d.flags & DM_GEMM_UPPER) && b < ((d.flags & DM_GEMM_UPPER128) ? (a & ~1) : a)) continue;
         dm_gemm_tile t{(int)i, a, b};
         const double rows = std::min(BM, d.M - a * BM), cols = std::min(BN, d.N - b * BN);
         if (d.flags & DM_GEMM_ALL_REAL) { tiles_dd.push_back(t); fl_d += 2.0 * rows * cols * d.K; }

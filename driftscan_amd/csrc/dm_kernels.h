@@ -17,6 +17,7 @@ enum {
   DM_GEMM_LOWER = 8,   // only compute 64x64 tiles on or below the block diagonal
   DM_GEMM_ALL_REAL = 16,  // A, B and C are arrays of doubles (strides in doubles)
   DM_GEMM_UPPER = 32,  // only compute 64x64 tiles on or above the block diagonal
+  DM_GEMM_UPPER128 = 128,  // with DM_GEMM_UPPER: also the tile left of an odd diagonal tile (whole 128 x 128 diagonal blocks)
   DM_GEMM_B_GATHER = 64,  // columns of B are gathered through desc.bgather and carry their own K weights
 };
 

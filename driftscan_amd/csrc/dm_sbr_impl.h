@@ -27,6 +27,24 @@ constexpr int SQR = 256;      // indices per workgroup in the launched panel-QR 
 constexpr int SBG = 32;       // sweeps per group in the second-stage back-transformation
 constexpr int SBW = SBG + SB; // window rows of a diamond block (SBG + SB - 1, padded)
 
+// complex multiply-adds spelled as four FMAs (the compiler turns a*b + c*d + e into mul + fma + add)
+__device__ __forceinline__ void sb_cfma(cplx& acc, cplx a, cplx b) {        // acc += a b
+  acc.x = fma(a.x, b.x, acc.x); acc.x = fma(-a.y, b.y, acc.x);
+  acc.y = fma(a.x, b.y, acc.y); acc.y = fma(a.y, b.x, acc.y);
+}
+__device__ __forceinline__ void sb_cfma_ca(cplx& acc, cplx a, cplx b) {     // acc += conj(a) b
+  acc.x = fma(a.x, b.x, acc.x); acc.x = fma(a.y, b.y, acc.x);
+  acc.y = fma(a.x, b.y, acc.y); acc.y = fma(-a.y, b.x, acc.y);
+}
+__device__ __forceinline__ void sb_cfms(cplx& x, cplx a, cplx b) {          // x -= a b
+  x.x = fma(-a.x, b.x, x.x); x.x = fma(a.y, b.y, x.x);
+  x.y = fma(-a.x, b.y, x.y); x.y = fma(-a.y, b.x, x.y);
+}
+__device__ __forceinline__ void sb_cfms_cb(cplx& x, cplx a, cplx b) {       // x -= a conj(b)
+  x.x = fma(-a.x, b.x, x.x); x.x = fma(-a.y, b.y, x.x);
+  x.y = fma(-a.y, b.x, x.y); x.y = fma(a.x, b.y, x.y);
+}
+
 struct sb_mat {
   cplx* A; int lda; int n;
   cplx* Vt;     // n x n: row k = reflector of column k (first stage): zero below index k + SB, 1 at k + SB
@@ -364,8 +382,7 @@ __device__ __forceinline__ void sb_fused_half(const sb_mat& M, cplx (&a)[SFR][SF
         cplx acc = make_double2(0.0, 0.0);
 #pragma unroll
         for (int r = 0; r < SFR; ++r) {
-          acc.x += v[r].x * a[r][c].x + v[r].y * a[r][c].y;  // conj(v) * a
-          acc.y += v[r].x * a[r][c].y - v[r].y * a[r][c].x;
+          sb_cfma_ca(acc, v[r], a[r][c]);  // conj(v) * a
         }
         y[2 * (c - 1)] = acc.x;
         y[2 * (c - 1) + 1] = acc.y;
@@ -376,7 +393,7 @@ __device__ __forceinline__ void sb_fused_half(const sb_mat& M, cplx (&a)[SFR][SF
       for (int c = 1; c < SFH; ++c) {
         const cplx f = cmul(ct, make_double2(y[2 * (c - 1)], y[2 * (c - 1) + 1]));
 #pragma unroll
-        for (int r = 0; r < SFR; ++r) a[r][c] = csub(a[r][c], cmul(v[r], f));
+        for (int r = 0; r < SFR; ++r) sb_cfms(a[r][c], v[r], f);
       }
     }
     // outputs: v into the panel buffers and Vt, the column of R into the band part of A, tau
@@ -452,8 +469,7 @@ __global__ __launch_bounds__(SFT) void sb_panel_fused_kernel(const sb_mat* __res
         cplx acc = make_double2(0.0, 0.0);
 #pragma unroll
         for (int r = 0; r < SFR; ++r) {
-          acc.x += v[r].x * a[r][c].x + v[r].y * a[r][c].y;
-          acc.y += v[r].x * a[r][c].y - v[r].y * a[r][c].x;
+          sb_cfma_ca(acc, v[r], a[r][c]);
         }
         y[2 * c] = acc.x;
         y[2 * c + 1] = acc.y;
@@ -464,22 +480,22 @@ __global__ __launch_bounds__(SFT) void sb_panel_fused_kernel(const sb_mat* __res
       for (int c = 0; c < SFH; ++c) {
         const cplx f = cmul(ct, make_double2(y[2 * c], y[2 * c + 1]));
 #pragma unroll
-        for (int r = 0; r < SFR; ++r) a[r][c] = csub(a[r][c], cmul(v[r], f));
+        for (int r = 0; r < SFR; ++r) sb_cfms(a[r][c], v[r], f);
       }
     }
     sb_fused_half(M, a, k0, cb, nrf, red, phase);
   }
 }
 
-// make the 64-aligned diagonal tiles complete (lower part <- conj of the upper part): the products
+// make the 128-aligned diagonal blocks complete (lower part <- conj of the upper part): the products
 // Y = A22 X of the first stage read whole diagonal tiles, the her2k updates keep them complete
 struct sb_dmat { cplx* A; int lda; int n; };
 __global__ __launch_bounds__(256) void sb_diag_tiles_kernel(const sb_dmat* __restrict__ ms) {
   const sb_dmat M = ms[blockIdx.y];
-  const int t0 = blockIdx.x * 64;
+  const int t0 = blockIdx.x * 128;
   if (t0 >= M.n) return;
-  for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
-    const int r = t0 + idx / 64, c = t0 + idx % 64;
+  for (int idx = threadIdx.x; idx < 128 * 128; idx += 256) {
+    const int r = t0 + idx / 128, c = t0 + idx % 128;
     if (r < M.n && c < r) dm_stg(M.A, (size_t)r * M.lda + c, cconj(dm_ldg(M.A, (size_t)c * M.lda + r)));
   }
 }
@@ -631,13 +647,13 @@ __device__ __forceinline__ void sb_chase_sweep(const sb_chase_mat& M, __amdgpu_b
       for (int a = 0; a < 4; ++a) {
         cplx acc = make_double2(0.0, 0.0);
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb) acc = cadd(acc, cmul(e[a][bb], vcol[bb]));
+        for (int bb = 0; bb < 4; ++bb) sb_cfma(acc, e[a][bb], vcol[bb]);
         w[a] = cmul(tau, sb_sum_bc(acc));
       }
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb) e[a][bb] = csub(e[a][bb], cmulc(w[a], vcol[bb]));
+        for (int bb = 0; bb < 4; ++bb) sb_cfms_cb(e[a][bb], w[a], vcol[bb]);
       reflect = nr >= 2;
       cplx tauj = make_double2(0.0, 0.0);
       cplx vnew[4];
@@ -667,14 +683,13 @@ __device__ __forceinline__ void sb_chase_sweep(const sb_chase_mat& M, __amdgpu_b
         for (int bb = 0; bb < 4; ++bb) {
           cplx acc = make_double2(0.0, 0.0);
 #pragma unroll
-          for (int a = 0; a < 4; ++a) acc = cadd(acc, make_double2(vnew[a].x * e[a][bb].x + vnew[a].y * e[a][bb].y,
-                                                                    vnew[a].x * e[a][bb].y - vnew[a].y * e[a][bb].x));
+          for (int a = 0; a < 4; ++a) sb_cfma_ca(acc, vnew[a], e[a][bb]);
           y[bb] = cmul(cconj(tauj), sb_sum_br(acc));
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-          for (int bb = 0; bb < 4; ++bb) e[a][bb] = csub(e[a][bb], cmul(vnew[a], y[bb]));
+          for (int bb = 0; bb < 4; ++bb) sb_cfms(e[a][bb], vnew[a], y[bb]);
         if (bc == 0) {
 #pragma unroll
           for (int a = 0; a < 4; ++a) e[a][0] = (br + 8 * a == 0) ? make_double2(beta, 0.0) : make_double2(0.0, 0.0);
@@ -736,10 +751,10 @@ __device__ __forceinline__ void sb_chase_sweep(const sb_chase_mat& M, __amdgpu_b
       for (int a = 0; a < 4; ++a) {
         cplx acc = make_double2(0.0, 0.0);
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb) acc = cadd(acc, cmul(d[a][bb], vcol[bb]));
+        for (int bb = 0; bb < 4; ++bb) sb_cfma(acc, d[a][bb], vcol[bb]);
         x[a] = cmul(tau, sb_sum_bc(acc));
         // x^H v over the rows of this lane (the same in all lanes that share the rows)
-        xv = cadd(xv, make_double2(x[a].x * vrow[a].x + x[a].y * vrow[a].y, x[a].x * vrow[a].y - x[a].y * vrow[a].x));
+        sb_cfma_ca(xv, x[a], vrow[a]);
       }
       xv = sb_sum_br(xv);
       const cplx al = cmul(make_double2(-0.5 * tau.x, -0.5 * tau.y), xv);
@@ -755,7 +770,9 @@ __device__ __forceinline__ void sb_chase_sweep(const sb_chase_mat& M, __amdgpu_b
         for (int bb = 0; bb < 4; ++bb) {
           const int c = r0 + bc + 8 * bb;
           if (r < n && c <= r) {
-            cplx v = csub(csub(d[a][bb], cmulc(vrow[a], wc[bb])), cmulc(wv[a], vcol[bb]));
+            cplx v = d[a][bb];
+            sb_cfms_cb(v, vrow[a], wc[bb]);
+            sb_cfms_cb(v, wv[a], vcol[bb]);
             if (r == c) v.y = 0.0;
             dm_stg(AB, (size_t)c * SLD + (r - c), v);
           }
@@ -893,9 +910,7 @@ __global__ __launch_bounds__(64 * NW) void sb_q2_apply_kernel(const sb_q2_mat* _
             for (int t = 0; t < 9; ++t) {
               v[t] = (iq + t < NU) ? vv[4 * (iq + t)] : make_double2(0.0, 0.0);
               if (iq + t < NU) {
-                const cplx xx = xw[iq + t];
-                acc.x += v[t].x * xx.x + v[t].y * xx.y;  // conj(v) * x
-                acc.y += v[t].x * xx.y - v[t].y * xx.x;
+                sb_cfma_ca(acc, v[t], xw[iq + t]);  // conj(v) * x
               }
             }
             acc.x = sb_quad_sum(acc.x);
@@ -903,7 +918,7 @@ __global__ __launch_bounds__(64 * NW) void sb_q2_apply_kernel(const sb_q2_mat* _
             const cplx f = cmul(tq, acc);  // H x = x - tau v (v^H x)
 #pragma unroll
             for (int t = 0; t < 9; ++t)
-              if (iq + t < NU) xw[iq + t] = csub(xw[iq + t], cmul(v[t], f));
+              if (iq + t < NU) sb_cfms(xw[iq + t], v[t], f);
           }
         }
       }

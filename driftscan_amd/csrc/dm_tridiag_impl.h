@@ -1836,11 +1836,11 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
     DM_TRY(dm_fill_zero(ctx, Tbig, sizeof(cplx) * tottb));
     DM_TRY(dm_fill_zero(ctx, sbVd, sizeof(cplx) * totvd));
     DM_TRY(dm_fill_zero(ctx, sbTau2, sizeof(cplx) * tott2));
-    hipLaunchKernelGGL(sb_diag_tiles_kernel, dim3((cmax + 63) / 64, nc), dim3(256), 0, ctx->stream, d_dm);
+    hipLaunchKernelGGL(sb_diag_tiles_kernel, dim3((cmax + 127) / 128, nc), dim3(256), 0, ctx->stream, d_dm);
     // ---- S1: dense -> band, one panel of SB columns at a time, all matrices in lock-step
     for (int k0 = 0; cmax - k0 - SB >= 2; k0 += SB) {
       const int i0 = k0 + SB;        // first row of the trailing matrix
-      const int a0 = i0 & ~63;       // its 64-aligned tile origin (the panel vectors are zero on [a0, i0))
+      const int a0 = i0 & ~127;      // its 128-aligned block origin (the panel vectors are zero on [a0, i0))
       static const bool nofuse = getenv("DM_SB_NOFUSE") != nullptr;
       if (cmax - i0 <= SFR * SFT && !nofuse) {
         // panels that fit the registers of one workgroup per matrix: the whole QR in one launch
@@ -1874,9 +1874,9 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
         tf.push_back(tf_mat{G, tau + offn[p] + k0, T, kb, NBB});
         // Xt = T^T Vp  (SB x m)
         gx.push_back(dm_gemm_make(T, 1, NBB, false, Vp + i0, n, 1, false, Xt + i0, n, SB, m, SB));
-        // Yt = Xt A22 by 64-column blocks: stored part (rows >= block start, whole diagonal tile) + mirrored part
-        for (int cb = a0; cb < n; cb += 64) {
-          const int c_lo = std::max(cb, i0), c_hi = std::min(cb + 64, n);
+        // Yt = Xt A22 by 128-column blocks: stored part (rows >= block start, whole diagonal block) + mirrored part
+        for (int cb = a0; cb < n; cb += 128) {
+          const int c_lo = std::max(cb, i0), c_hi = std::min(cb + 128, n);
           if (c_hi <= c_lo) continue;
           gy1.push_back(dm_gemm_make(Xt + c_lo, n, 1, false, C + (size_t)c_lo * lda + c_lo, 1, lda, false, Wp + c_lo, n, SB,
                                      c_hi - c_lo, n - c_lo));
@@ -1892,7 +1892,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
         gw.push_back(dm_gemm_make(S, 1, SB, false, Vp + i0, n, 1, false, Wp + i0, n, SB, m, SB, -0.5, 1.0));
         // A22 -= V W^H + W V^H on the tiles on or above the diagonal (64-aligned origin a0)
         gh.push_back(dm_gemm_make(pp + a0, 1, n, false, pp + (size_t)n * TNB + a0, n, 1, true, C + (size_t)a0 * lda + a0, lda,
-                                  n - a0, n - a0, 2 * TNB, -1.0, 1.0, nullptr, DM_GEMM_UPPER));
+                                  n - a0, n - a0, 2 * TNB, -1.0, 1.0, nullptr, DM_GEMM_UPPER | DM_GEMM_UPPER128));
       }
       if (gg.empty()) continue;
       DM_TRY(dm_gemm_grouped_launch(ctx, gg));
