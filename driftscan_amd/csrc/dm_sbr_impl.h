@@ -487,6 +487,23 @@ __global__ __launch_bounds__(SFT) void sb_panel_fused_kernel(const sb_mat* __res
   }
 }
 
+// Split-K for the skinny products of the first stage (32 x 32 Gram matrices and 32 x 128 blocks of Y with K = the whole
+// trailing size): the host cuts K into slices that are separate problems of the grouped ZGEMM writing partial results,
+// this kernel adds the slices up:  dst = alpha * sum_s src[s] + beta * dst.
+struct sb_sum_desc { cplx* dst; const cplx* src; int nslice; int rows, cols, ldd; double alpha, beta; };  // src: nslice x rows x cols
+__global__ __launch_bounds__(256) void sb_sum_partials_kernel(const sb_sum_desc* __restrict__ ds) {
+  const sb_sum_desc D = ds[blockIdx.y];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= D.rows * D.cols) return;
+  const int r = idx / D.cols, c = idx % D.cols;
+  const size_t ss = (size_t)D.rows * D.cols;
+  cplx acc = make_double2(0.0, 0.0);
+  for (int t = 0; t < D.nslice; ++t) acc = cadd(acc, dm_ldg(D.src, (size_t)t * ss + idx));
+  cplx out = cscale(acc, D.alpha);
+  if (D.beta != 0.0) out = cadd(out, cscale(dm_ldg(D.dst, (size_t)r * D.ldd + c), D.beta));
+  dm_stg(D.dst, (size_t)r * D.ldd + c, out);
+}
+
 // make the 128-aligned diagonal blocks complete (lower part <- conj of the upper part): the products
 // Y = A22 X of the first stage read whole diagonal tiles, the her2k updates keep them complete
 struct sb_dmat { cplx* A; int lda; int n; };

@@ -1777,6 +1777,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
   const int shift = two_stage ? TNB : 1;  // reflector k has its leading 1 at row k + shift
   auto nrefl_of = [&](int n) { return two_stage ? std::max(0, n - TNB - 1) : std::max(0, n - 1); };
 #if DM_TNB == 32
+  cplx* sbPart = nullptr;
   cplx *sbPw = nullptr, *sbXt = nullptr, *sbYp = nullptr, *sbAB = nullptr, *sbVd = nullptr, *sbTau2 = nullptr, *sbM1 = nullptr,
        *sbS = nullptr;
   double* sbNp = nullptr;
@@ -1804,6 +1805,9 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
     sbM1 = dm_ws_alloc_t<cplx>(ctx, (size_t)np * SB * SB);
     sbS = dm_ws_alloc_t<cplx>(ctx, (size_t)np * SB * SB);
     sbProg = dm_ws_alloc_t<unsigned>(ctx, std::max<size_t>(totn, 1));
+    // split-K partials: at most 32 slices of the 32 x n block of Y per matrix (the Gram matrices need far less)
+    sbPart = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * SB * 32 + (size_t)np * SB * SB * 32, 1));
+    if (!sbPart) return DM_ENOMEM;
     sbNext = dm_ws_alloc_t<int>(ctx, 2 * (size_t)np + 9);  // sweep counters, owners, queue heads, error flag
     if (!sbPw || !sbXt || !sbYp || !sbNp || !sbAB || !sbVd || !sbTau2 || !sbM1 || !sbS || !sbProg || !sbNext) return DM_ENOMEM;
   }
@@ -1855,7 +1859,24 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       }
       // T factor of the panel (zlarft from the Gram matrix), straight into the slot the back-transformation reads
       std::vector<dm_gemm_desc> gg, gx, gy1, gy2, gm, gs, gw, gh;
+      std::vector<sb_sum_desc> sg, sy, smm;
       std::vector<tf_mat> tf;
+      // split-K: the products with K = trailing size have few output tiles (one 32 x 32 tile per matrix for the Gram
+      // matrices, one 32 x 128 tile per 128 columns of Y): cut K so that a launch carries ~1000 tiles
+      int nact = 0, ytiles = 0;
+      for (int p : ch) {
+        const int m = probs[p].n - i0;
+        if (m < 2) continue;
+        ++nact;
+        ytiles += (probs[p].n - a0 + 127) / 128;
+      }
+      if (nact == 0) continue;
+      const int kmax = cmax - i0;
+      auto slices_for = [&](int tiles) { return std::max(1, std::min(30, std::min((1024 + tiles - 1) / tiles, (kmax + 127) / 128))); };
+      static const bool nosplit = getenv("DM_SB_NOSPLITK") != nullptr;
+      const int SG = nosplit ? 1 : slices_for(nact), SY = nosplit ? 1 : slices_for(ytiles);
+      cplx* part_y = sbPart;                               // per matrix: SY x (32 x n) at offn * SB * 32
+      cplx* part_g = sbPart + totn * SB * 32;              // per matrix: 32 x (32 x 32)
       for (int p : ch) {
         const int n = probs[p].n;
         const int m = n - i0;
@@ -1870,32 +1891,77 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
         const cplx* Vb = Vt + off[p] + (size_t)k0 * n + i0;
         cplx* G = Gs + offg[p] + (size_t)(k0 / TNB) * TNB * TNB;
         cplx* T = Tbig + offtb[p] + (size_t)(k0 / NBB) * NBB * NBB + (size_t)(k0 % NBB) * NBB + (k0 % NBB);
-        gg.push_back(dm_gemm_make(Vb, n, 1, true, Vb, 1, n, false, G, TNB, kb, kb, m));
+        cplx* pg = part_g + (size_t)p * SB * SB * 32;
+        // Gram matrix G = V^H V (kb x kb, K = m)
+        if (SG == 1) {
+          gg.push_back(dm_gemm_make(Vb, n, 1, true, Vb, 1, n, false, G, TNB, kb, kb, m));
+        } else {
+          const int kc = (m + SG - 1) / SG;
+          int ns = 0;
+          for (int kk = 0; kk < m; kk += kc, ++ns)
+            gg.push_back(dm_gemm_make(Vb + kk, n, 1, true, Vb + kk, 1, n, false, pg + (size_t)ns * kb * kb, kb, kb, kb, std::min(kc, m - kk)));
+          sg.push_back(sb_sum_desc{G, pg, ns, kb, kb, TNB, 1.0, 0.0});
+        }
         tf.push_back(tf_mat{G, tau + offn[p] + k0, T, kb, NBB});
         // Xt = T^T Vp  (SB x m)
         gx.push_back(dm_gemm_make(T, 1, NBB, false, Vp + i0, n, 1, false, Xt + i0, n, SB, m, SB));
         // Yt = Xt A22 by 128-column blocks: stored part (rows >= block start, whole diagonal block) + mirrored part
+        cplx* py = part_y + offn[p] * SB * 32;
+        size_t pyoff = 0;
         for (int cb = a0; cb < n; cb += 128) {
           const int c_lo = std::max(cb, i0), c_hi = std::min(cb + 128, n);
           if (c_hi <= c_lo) continue;
-          gy1.push_back(dm_gemm_make(Xt + c_lo, n, 1, false, C + (size_t)c_lo * lda + c_lo, 1, lda, false, Wp + c_lo, n, SB,
-                                     c_hi - c_lo, n - c_lo));
-          if (c_lo > i0)
-            gy2.push_back(dm_gemm_make(Xt + i0, n, 1, false, C + (size_t)i0 * lda + c_lo, lda, 1, true, Wp + c_lo, n, SB,
-                                       c_hi - c_lo, c_lo - i0, 1.0, 1.0));
+          const int wN = c_hi - c_lo;
+          if (SY == 1) {
+            gy1.push_back(dm_gemm_make(Xt + c_lo, n, 1, false, C + (size_t)c_lo * lda + c_lo, 1, lda, false, Wp + c_lo, n, SB, wN,
+                                       n - c_lo));
+            if (c_lo > i0)
+              gy2.push_back(dm_gemm_make(Xt + i0, n, 1, false, C + (size_t)i0 * lda + c_lo, lda, 1, true, Wp + c_lo, n, SB, wN,
+                                         c_lo - i0, 1.0, 1.0));
+          } else {
+            const int kc = std::max(128, ((m + SY - 1) / SY + 127) & ~127);
+            cplx* pb = py + pyoff;
+            int ns = 0;
+            for (int kk = c_lo; kk < n; kk += kc, ++ns)   // stored part: rows kk .. of the columns [c_lo, c_hi)
+              gy1.push_back(dm_gemm_make(Xt + kk, n, 1, false, C + (size_t)c_lo * lda + kk, 1, lda, false, pb + (size_t)ns * SB * wN, wN,
+                                         SB, wN, std::min(kc, n - kk)));
+            for (int kk = i0; kk < c_lo; kk += kc, ++ns)  // mirrored part: rows i0 .. c_lo of the transposed block
+              gy1.push_back(dm_gemm_make(Xt + kk, n, 1, false, C + (size_t)kk * lda + c_lo, lda, 1, true, pb + (size_t)ns * SB * wN, wN,
+                                         SB, wN, std::min(kc, c_lo - kk)));
+            sy.push_back(sb_sum_desc{Wp + c_lo, pb, ns, SB, wN, n, 1.0, 0.0});
+            pyoff += (size_t)ns * SB * wN;
+          }
         }
         cplx* M1 = sbM1 + (size_t)p * SB * SB;
         cplx* S = sbS + (size_t)p * SB * SB;
         // M1 = V^H Y, S = T^H M1, W = Y - V S / 2  (row-stored: Wp += -1/2 S^T Vp)
-        gm.push_back(dm_gemm_make(Vp + i0, n, 1, true, Wp + i0, 1, n, false, M1, SB, SB, SB, m));
+        if (SG == 1) {
+          gm.push_back(dm_gemm_make(Vp + i0, n, 1, true, Wp + i0, 1, n, false, M1, SB, SB, SB, m));
+        } else {
+          const int kc = (m + SG - 1) / SG;
+          int ns = 0;
+          for (int kk = 0; kk < m; kk += kc, ++ns)
+            gm.push_back(dm_gemm_make(Vp + i0 + kk, n, 1, true, Wp + i0 + kk, 1, n, false, pg + (size_t)ns * SB * SB, SB, SB, SB,
+                                      std::min(kc, m - kk)));
+          smm.push_back(sb_sum_desc{M1, pg, ns, SB, SB, SB, 1.0, 0.0});
+        }
         gs.push_back(dm_gemm_make(T, 1, NBB, true, M1, SB, 1, false, S, SB, SB, SB, SB));
         gw.push_back(dm_gemm_make(S, 1, SB, false, Vp + i0, n, 1, false, Wp + i0, n, SB, m, SB, -0.5, 1.0));
-        // A22 -= V W^H + W V^H on the tiles on or above the diagonal (64-aligned origin a0)
+        // A22 -= V W^H + W V^H on the blocks on or above the diagonal (128-aligned origin a0)
         gh.push_back(dm_gemm_make(pp + a0, 1, n, false, pp + (size_t)n * TNB + a0, n, 1, true, C + (size_t)a0 * lda + a0, lda,
                                   n - a0, n - a0, 2 * TNB, -1.0, 1.0, nullptr, DM_GEMM_UPPER | DM_GEMM_UPPER128));
       }
-      if (gg.empty()) continue;
+      auto launch_sums = [&](const std::vector<sb_sum_desc>& v) -> int {
+        if (v.empty()) return DM_OK;
+        int mx = 0;
+        for (const auto& d : v) mx = std::max(mx, d.rows * d.cols);
+        sb_sum_desc* dv = dm_ws_upload(ctx, v);
+        if (!dv) return DM_ENOMEM;
+        hipLaunchKernelGGL(sb_sum_partials_kernel, dim3((mx + 255) / 256, (unsigned)v.size()), dim3(256), 0, ctx->stream, dv);
+        return DM_OK;
+      };
       DM_TRY(dm_gemm_grouped_launch(ctx, gg));
+      DM_TRY(launch_sums(sg));
       {
         tf_mat* d_tf = dm_ws_upload(ctx, tf);
         if (!d_tf) return DM_ENOMEM;
@@ -1911,7 +1977,9 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       DM_TRY(dm_gemm_grouped_launch(ctx, gx));
       DM_TRY(dm_gemm_grouped_launch(ctx, gy1));
       DM_TRY(dm_gemm_grouped_launch(ctx, gy2));
+      DM_TRY(launch_sums(sy));
       DM_TRY(dm_gemm_grouped_launch(ctx, gm));
+      DM_TRY(launch_sums(smm));
       DM_TRY(dm_gemm_grouped_launch(ctx, gs));
       DM_TRY(dm_gemm_grouped_launch(ctx, gw));
       DM_TRY(dm_gemm_grouped_launch(ctx, gh));
