@@ -854,6 +854,403 @@ __global__ __launch_bounds__(64 * NW) void sb_chase_kernel(const sb_chase_mat* _
   }
 }
 
+// ---- S2, two waves per sweep -------------------------------------------------------------------------------------------
+//
+// Inside a sweep the reflectors form a chain  E_j -> v_j -> E_{j+1}  that never reads the diagonal blocks; D_j only needs
+// v_j.  So a sweep is run by a PAIR of waves of one workgroup: the E wave walks the chain and posts each reflector in an
+// LDS mailbox, the D wave applies it to D_j (and has loaded D_j while the E wave was still working).  Sweep s + 1 waits for
+//   E_j(s+1):  E_{j+1}(s) and D_j(s) finished          D_j(s+1):  E_{j+1}(s) and D_{j+1}(s) finished
+// (two progress words per sweep), which makes the lag between consecutive sweeps 2 max(T_E, T_D) instead of 2 (T_E + T_D).
+struct sb_pair_box {
+  int sweep;     // sweep posted by the E wave (-2: no more work)
+  int gen;       // incremented with every post
+  int done_gen;  // last generation the D wave has finished
+  int seq;       // reflectors posted in the current sweep
+  int ack;       // reflectors taken by the D wave
+  int pad[3];
+  cplx tau[4];
+  cplx v[4][SB];
+};
+
+__device__ __forceinline__ int sb_lds_ld(int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void sb_lds_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// poll a global progress word until it reaches `need` (cached in `seen`); false = gave up (error flag set)
+__device__ __forceinline__ bool sb_wait_prog(const unsigned* word, unsigned need, unsigned& seen, int* err, int code, int lane) {
+  if (seen >= need) return true;
+  int spins = 0;
+  for (;;) {
+    const unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v >= need) { seen = v; break; }
+    __builtin_amdgcn_s_sleep(1);
+    ++spins;
+    if (spins > (1 << 20)) {
+      if (lane == 0) atomicCAS(err, 0, code);
+      return false;
+    }
+    if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return true;
+}
+// spin on an LDS word of the pair until pred(value); false = gave up
+template <typename P>
+__device__ __forceinline__ bool sb_wait_lds(int* word, P pred, int* err, int code, int lane) {
+  int spins = 0;
+  for (;;) {
+    if (pred(sb_lds_ld(word))) break;
+    __builtin_amdgcn_s_sleep(1);
+    ++spins;
+    if (spins > (1 << 22)) {
+      if (lane == 0) atomicCAS(err, 0, code);
+      return false;
+    }
+    if ((spins & 4095) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return true;
+}
+
+// progress words of sweep s: prog[2 s] = E tasks finished, prog[2 s + 1] = D tasks finished
+__device__ __forceinline__ bool sb_chase_E(const sb_chase_mat& M, __amdgpu_buffer_rsrc_t rsAB, sb_pair_box* box, int* err, int s, int lane) {
+  const int n = M.n;
+  const int br = lane >> 3, bc = lane & 7;
+  cplx* AB = M.AB;
+  const int G = s / SBG, gi = s % SBG;
+  unsigned seenE = (s == 0) ? SB_DONE : 0u, seenD = seenE;
+  cplx vcol[4];
+  cplx tau = make_double2(0.0, 0.0);
+  for (int j = 0;; ++j) {
+    const int r0 = s + 1 + j * SB;
+    if (r0 >= n) break;
+    const int nr = min(SB, n - r0);
+    if (!sb_wait_prog(M.prog + 2 * (s - 1), (unsigned)(j + 2), seenE, err, 1 + s, lane)) return false;
+    if (!sb_wait_prog(M.prog + 2 * (s - 1) + 1, (unsigned)(j + 1), seenD, err, 1 + s, lane)) return false;
+    bool reflect = true;
+    double beta = 0.0;
+    cplx vrow[4];
+    if (j == 0) {
+      cplx x[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) x[a] = sb_ld(rsAB, (unsigned)s * SLD + 1u + (unsigned)(br + 8 * a));
+      if (lane == 0) M.d[s] = sb_ld(rsAB, (unsigned)s * SLD).x;
+      double sq = 0.0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        if (br + 8 * a > 0) sq += cabs2(x[a]);
+      cplx t = sb_sum_br(make_double2(sq, 0.0));
+      const double xn2 = __shfl(t.x, 0, 64);
+      const cplx alpha = sb_from_lane(x[0], 0);
+      const trd_refl R = sb_reflector(xn2, alpha);
+      tau = R.tau;
+      beta = R.beta;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int rr = br + 8 * a;
+        cplx v = cmul(x[a], R.scal);
+        if (rr == 0) v = make_double2(1.0, 0.0);
+        if (rr >= nr) v = make_double2(0.0, 0.0);
+        vrow[a] = v;
+      }
+      if (bc == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int rr = br + 8 * a;
+          if (rr < nr) dm_stg(AB, (size_t)s * SLD + 1 + rr, rr == 0 ? make_double2(beta, 0.0) : make_double2(0.0, 0.0));
+        }
+      }
+      if (lane == 0) M.e[s] = beta;
+    } else {
+      const int c0 = r0 - SB;
+      cplx e[4][4];
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const int c = c0 + bc + 8 * bb;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int r = r0 + br + 8 * a;
+          e[a][bb] = sb_ld(rsAB, (unsigned)c * SLD + (unsigned)(r - c));
+        }
+      }
+      cplx w[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) sb_cfma(acc, e[a][bb], vcol[bb]);
+        w[a] = cmul(tau, sb_sum_bc(acc));
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) sb_cfms_cb(e[a][bb], w[a], vcol[bb]);
+      reflect = nr >= 2;
+      cplx tauj = make_double2(0.0, 0.0);
+      if (reflect) {
+        double sq = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          if (br + 8 * a > 0 && br + 8 * a < nr) sq += cabs2(e[a][0]);
+        if (bc != 0) sq = 0.0;
+        cplx t = sb_sum_br(make_double2(sq, 0.0));
+        const double xn2 = __shfl(t.x, 0, 64);
+        const cplx alpha = sb_from_lane(e[0][0], 0);
+        const trd_refl R = sb_reflector(xn2, alpha);
+        tauj = R.tau;
+        beta = R.beta;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int rr = br + 8 * a;
+          cplx x = sb_from_lane(e[a][0], lane & ~7);
+          cplx v = cmul(x, R.scal);
+          if (rr == 0) v = make_double2(1.0, 0.0);
+          if (rr >= nr) v = make_double2(0.0, 0.0);
+          vrow[a] = v;
+        }
+        cplx y[4];
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+          cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+          for (int a = 0; a < 4; ++a) sb_cfma_ca(acc, vrow[a], e[a][bb]);
+          y[bb] = cmul(cconj(tauj), sb_sum_br(acc));
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) sb_cfms(e[a][bb], vrow[a], y[bb]);
+        if (bc == 0) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) e[a][0] = (br + 8 * a == 0) ? make_double2(beta, 0.0) : make_double2(0.0, 0.0);
+        }
+      }
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const int c = c0 + bc + 8 * bb;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int r = r0 + br + 8 * a;
+          if (r < n) dm_stg(AB, (size_t)c * SLD + (r - c), e[a][bb]);
+        }
+      }
+      tau = tauj;
+    }
+    if (reflect) {
+      // ---- post the reflector for the D wave (ring of four), keep it for the back-transformation
+      const int slot = j & 3;
+      if (j >= 4 && !sb_wait_lds(&box->ack, [&](int a) { return a > j - 4; }, err, 1 + s, lane)) return false;
+      if (bc == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) box->v[slot][br + 8 * a] = vrow[a];
+      }
+      if (lane == 0) box->tau[slot] = tau;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) sb_lds_st(&box->seq, j + 1);
+      const size_t blk = (size_t)G * M.jb + j;
+      if (bc == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int rr = br + 8 * a;
+          if (rr < nr) dm_stg(M.Vd, (blk * SBG + gi) * SBW + gi + rr, vrow[a]);
+        }
+      }
+      if (lane == 0) M.tau2[blk * SBG + gi] = tau;
+      // the vector by columns for the next block: straight from the mailbox (this wave wrote it)
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) vcol[bb] = box->v[slot][bc + 8 * bb];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(M.prog + 2 * s, (unsigned)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!reflect) break;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_store(M.prog + 2 * s, SB_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+
+__device__ __forceinline__ bool sb_chase_D(const sb_chase_mat& M, __amdgpu_buffer_rsrc_t rsAB, sb_pair_box* box, int* err, int s, int lane) {
+  const int n = M.n;
+  const int br = lane >> 3, bc = lane & 7;
+  cplx* AB = M.AB;
+  unsigned seenE = (s == 0) ? SB_DONE : 0u, seenD = seenE;
+  for (int j = 0;; ++j) {
+    const int r0 = s + 1 + j * SB;
+    if (r0 >= n) break;
+    const int nr = min(SB, n - r0);
+    if (j > 0 && nr < 2) break;  // the E wave ends the sweep without a reflector
+    if (!sb_wait_prog(M.prog + 2 * (s - 1), (unsigned)(j + 2), seenE, err, 1 + s, lane)) return false;
+    if (!sb_wait_prog(M.prog + 2 * (s - 1) + 1, (unsigned)(j + 2), seenD, err, 1 + s, lane)) return false;
+    // D_j is final as far as sweep s - 1 goes: fetch it while the E wave is still working on v_j
+    cplx d[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int r = r0 + br + 8 * a;
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const int c = r0 + bc + 8 * bb;
+        d[a][bb] = (r >= c) ? sb_ld(rsAB, (unsigned)c * SLD + (unsigned)(r - c)) : sb_ld(rsAB, (unsigned)r * SLD + (unsigned)(c - r));
+      }
+    }
+    if (!sb_wait_lds(&box->seq, [&](int q) { return q > j; }, err, 1 + s, lane)) return false;
+    const int slot = j & 3;
+    cplx vrow[4], vcol[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      vrow[a] = box->v[slot][br + 8 * a];
+      vcol[a] = box->v[slot][bc + 8 * a];
+    }
+    const cplx tau = box->tau[slot];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the reads above are done before the slot is handed back
+    if (lane == 0) sb_lds_st(&box->ack, j + 1);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int r = br + 8 * a;
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const int c = bc + 8 * bb;
+        if (r < c) d[a][bb] = cconj(d[a][bb]);
+        if (r == c) d[a][bb].y = 0.0;
+      }
+    }
+    cplx x[4];
+    cplx xv = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) sb_cfma(acc, d[a][bb], vcol[bb]);
+      x[a] = cmul(tau, sb_sum_bc(acc));
+      sb_cfma_ca(xv, x[a], vrow[a]);
+    }
+    xv = sb_sum_br(xv);
+    const cplx al = cmul(make_double2(-0.5 * tau.x, -0.5 * tau.y), xv);
+    cplx wv[4], wc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) wv[a] = cadd(x[a], cmul(al, vrow[a]));
+#pragma unroll
+    for (int a = 0; a < 4; ++a) wc[a] = sb_from_lane(wv[a], bc * 8);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int r = r0 + br + 8 * a;
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const int c = r0 + bc + 8 * bb;
+        if (r < n && c <= r) {
+          cplx v = d[a][bb];
+          sb_cfms_cb(v, vrow[a], wc[bb]);
+          sb_cfms_cb(v, wv[a], vcol[bb]);
+          if (r == c) v.y = 0.0;
+          dm_stg(AB, (size_t)c * SLD + (r - c), v);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(M.prog + 2 * s + 1, (unsigned)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (s == n - 2 && lane == 0) M.d[n - 1] = sb_ld(rsAB, (unsigned)(n - 1) * SLD).x;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_store(M.prog + 2 * s + 1, SB_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+
+// NP pairs of waves per workgroup (wave 2 p = E, wave 2 p + 1 = D); queues and ownership as in sb_chase_kernel
+template <int NP>
+__global__ __launch_bounds__(128 * NP) void sb_chase2_kernel(const sb_chase_mat* __restrict__ ms, const sb_chase_ctl ctl) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = wave >> 1;
+  const bool isE = (wave & 1) == 0;
+  const int xcd = __builtin_amdgcn_s_getreg(6164) & 7;  // hwreg(HW_REG_XCC_ID, 0, 4)
+  __shared__ int s_mat;
+  __shared__ sb_pair_box boxes[NP];
+  sb_pair_box* box = &boxes[pair];
+  if (threadIdx.x < NP) {
+    boxes[threadIdx.x].sweep = -1; boxes[threadIdx.x].gen = 0; boxes[threadIdx.x].done_gen = 0;
+    boxes[threadIdx.x].seq = 0; boxes[threadIdx.x].ack = 0;
+  }
+  int my_gen = 0;
+  for (int qq = 0; qq < 8; ++qq) {
+    const int q = (xcd + qq) & 7;
+    const int qlen = ctl.qoff[q + 1] - ctl.qoff[q];
+    for (;;) {
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int m = -1;
+        const int ent = atomicAdd(ctl.qhead + q, 1);
+        if (ent < qlen) {
+          m = ctl.qent[ctl.qoff[q] + ent];
+          const int old = atomicCAS(ms[m].owner, -1, xcd);
+          if (old != -1 && old != xcd) m = -2;
+        }
+        s_mat = m;
+      }
+      __syncthreads();
+      const int m = s_mat;
+      if (m == -1) break;
+      if (m == -2) continue;
+      const sb_chase_mat M = ms[m];
+      if (M.n == 1) {
+        if (threadIdx.x == 0) M.d[0] = dm_ldg(M.AB, 0).x;
+        continue;
+      }
+      const __amdgpu_buffer_rsrc_t rsAB =
+          __builtin_amdgcn_make_buffer_rsrc((void*)M.AB, 0, (int)min((size_t)M.n * SLD * sizeof(cplx), (size_t)0x7fffffff), 0x00020000);
+      if (isE) {
+        for (;;) {
+          int s = 0;
+          if (lane == 0) s = atomicAdd(M.next, 1);
+          s = __builtin_amdgcn_readfirstlane(s);
+          bool stop = s >= M.n - 1 || __hip_atomic_load(ctl.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+          // the D wave must be through with the previous sweep before the mailbox is reused
+          if (!sb_wait_lds(&box->done_gen, [&](int g) { return g == my_gen; }, ctl.err, 9, lane)) stop = true;
+          ++my_gen;
+          if (lane == 0) {
+            box->sweep = stop ? -2 : s;
+            sb_lds_st(&box->seq, 0);
+            sb_lds_st(&box->ack, 0);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) sb_lds_st(&box->gen, my_gen);
+          if (stop) break;
+          if (!sb_chase_E(M, rsAB, box, ctl.err, s, lane)) {
+            // failed: make sure the partner is released as well
+            ++my_gen;
+            sb_wait_lds(&box->done_gen, [&](int g) { return g == my_gen - 1; }, ctl.err, 9, lane);
+            if (lane == 0) { box->sweep = -2; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) sb_lds_st(&box->gen, my_gen);
+            break;
+          }
+        }
+      } else {
+        for (;;) {
+          ++my_gen;
+          if (!sb_wait_lds(&box->gen, [&](int g) { return g >= my_gen; }, ctl.err, 10, lane)) break;
+          const int s = __builtin_amdgcn_readfirstlane(box->sweep);
+          if (s == -2) {
+            if (lane == 0) sb_lds_st(&box->done_gen, my_gen);
+            break;
+          }
+          const bool ok = sb_chase_D(M, rsAB, box, ctl.err, s, lane);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) sb_lds_st(&box->done_gen, my_gen);
+          if (!ok) {
+            // take the stop post (if the partner still makes one) so that generations stay in step
+            ++my_gen;
+            sb_wait_lds(&box->gen, [&](int g) { return g >= my_gen; }, ctl.err, 10, lane);
+            if (lane == 0) sb_lds_st(&box->done_gen, my_gen);
+            break;
+          }
+        }
+      }
+    }
+  }
+}
+
 // ---- B2: X <- Q2 X, column slabs in registers ------------------------------------------------------------------------
 //
 // A wave owns 16 columns of X; the four lanes of a quad share a column and take the window rows w = 4 u + part (any 32 consecutive
@@ -911,33 +1308,37 @@ __global__ __launch_bounds__(64 * NW) void sb_q2_apply_kernel(const sb_q2_mat* _
         for (int idx = tid; idx < SBG * SBW; idx += 64 * NW) sv[buf ^ 1][idx] = dm_ldg(src, idx);
         if (tid < SBG) st[buf ^ 1][tid] = dm_ldg(M.tau2, ((size_t)G * M.jb + j + 1) * SBG + tid);
       }
-      const int nsw = min(SBG, nsweep - s0);
+      // Sweeps last to first.  A sweep the group does not have (the last group, or a block below the end of the matrix)
+      // has tau = 0 and a zero vector: applying it changes nothing, so the loop is straight-line code and the reflector of
+      // the next step is fetched from LDS while the current one is applied.
+      cplx vn[9];
 #pragma unroll
-      for (int iq = SBG / 4 - 1; iq >= 0; --iq) {
+      for (int t = 0; t < 9; ++t) vn[t] = sv[buf][(SBG - 1) * SBW + part + 4 * ((SBG - 1) / 4 + t)];
 #pragma unroll
-        for (int ir = 3; ir >= 0; --ir) {
-          const int i = 4 * iq + ir;
-          if (i < nsw) {
-            const cplx tq = st[buf][i];
-            const cplx* vv = &sv[buf][i * SBW + part];
-            // rows w = 4 u + part, u = iq .. iq + 8 cover [i, i + SB) (zeros outside the vector)
-            cplx acc = make_double2(0.0, 0.0);
-            cplx v[9];
+      for (int i = SBG - 1; i >= 0; --i) {
+        const int iq = i >> 2;
+        const cplx tq = st[buf][i];
+        cplx v[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-              v[t] = (iq + t < NU) ? vv[4 * (iq + t)] : make_double2(0.0, 0.0);
-              if (iq + t < NU) {
-                sb_cfma_ca(acc, v[t], xw[iq + t]);  // conj(v) * x
-              }
-            }
-            acc.x = sb_quad_sum(acc.x);
-            acc.y = sb_quad_sum(acc.y);
-            const cplx f = cmul(tq, acc);  // H x = x - tau v (v^H x)
+        for (int t = 0; t < 9; ++t) v[t] = vn[t];
+        if (i > 0) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
-              if (iq + t < NU) sb_cfms(xw[iq + t], v[t], f);
-          }
+          for (int t = 0; t < 9; ++t) vn[t] = sv[buf][(i - 1) * SBW + part + 4 * (((i - 1) >> 2) + t)];
         }
+        // rows w = 4 u + part, u = iq .. iq + 8 cover [i, i + SB) (zeros outside the vector)
+        cplx a0 = make_double2(0.0, 0.0), a1 = a0, a2 = a0;
+#pragma unroll
+        for (int t = 0; t < 9; t += 3) {
+          sb_cfma_ca(a0, v[t], xw[iq + t]);  // conj(v) * x
+          sb_cfma_ca(a1, v[t + 1], xw[iq + t + 1]);
+          sb_cfma_ca(a2, v[t + 2], xw[iq + t + 2]);
+        }
+        cplx acc = cadd(cadd(a0, a1), a2);
+        acc.x = sb_quad_sum(acc.x);
+        acc.y = sb_quad_sum(acc.y);
+        const cplx f = cmul(tq, acc);  // H x = x - tau v (v^H x)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) sb_cfms(xw[iq + t], v[t], f);
       }
       // slide: the first SB rows of the window are final for this group
       const int wr0 = row0 + j * SB;

@@ -1804,7 +1804,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
     sbTau2 = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(tott2, 1));
     sbM1 = dm_ws_alloc_t<cplx>(ctx, (size_t)np * SB * SB);
     sbS = dm_ws_alloc_t<cplx>(ctx, (size_t)np * SB * SB);
-    sbProg = dm_ws_alloc_t<unsigned>(ctx, std::max<size_t>(totn, 1));
+    sbProg = dm_ws_alloc_t<unsigned>(ctx, std::max<size_t>(2 * totn, 1));  // two progress words per sweep
     // split-K partials: at most 32 slices of the 32 x n block of Y per matrix (the Gram matrices need far less)
     sbPart = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * SB * 32 + (size_t)np * SB * SB * 32, 1));
     if (!sbPart) return DM_ENOMEM;
@@ -1830,7 +1830,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       dmv[i] = sb_dmat{probs[p].C, probs[p].ldc, probs[p].n};
       bm[i] = sb_bmat{probs[p].C, probs[p].ldc, probs[p].n, sbAB + offn[p] * SLD};
       cm[i] = sb_chase_mat{sbAB + offn[p] * SLD, probs[p].n, sbVd + offvd[p], sbTau2 + offt2[p], dd + offn[p], ee + offn[p],
-                           sb_jb[p], sbProg + offn[p], sbNext + p, sbNext + np + p};
+                           sb_jb[p], sbProg + 2 * offn[p], sbNext + p, sbNext + np + p};
     }
     sb_mat* d_sm = dm_ws_upload(ctx, sm);
     sb_dmat* d_dm = dm_ws_upload(ctx, dmv);
@@ -1999,7 +1999,9 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       if (dump) DM_TRY(dump_arr(".band", sbAB, sizeof(cplx) * totn * SLD));
       // One persistent launch: per-XCD queues of matrix ids; a matrix gets as many entries (= workgroups) as its
       // pipeline of sweeps can keep busy (sweep s + 1 trails sweep s by two blocks: n / (2 SB) sweeps in flight).
-      constexpr int NW = 8;
+      constexpr int NW = 8, NP = 4;
+      static const bool pairs = !getenv("DM_SB_NOPAIRS");  // two waves per sweep (E chain + D updates) or one
+      const int per_wg = pairs ? NP : NW;                  // sweeps a workgroup runs at a time
       std::vector<int> order(nc);
       for (int i = 0; i < nc; ++i) order[i] = i;
       std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cm[a].n > cm[b].n; });
@@ -2007,10 +2009,17 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       if (const char* e = getenv("DM_SB_WGPM")) wgmax = std::max(1, atoi(e));
       std::vector<std::vector<int>> qs(8);
       double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      // workgroups are resident for the whole launch and stay with a matrix until its sweeps are taken: hand out at most
+      // as many entries as there are workgroups (one per CU), in proportion to the sweeps each matrix can keep in flight
+      double want = 0.0;
+      for (int i : order)
+        if (cm[i].n >= 1) want += std::max(1.0, (double)cm[i].n / (2 * SB * per_wg));
+      const double scale = want > 256.0 ? 256.0 / want : 1.0;
       for (int i : order) {
         const int n = cm[i].n;
         if (n < 1) continue;
-        int k = std::max(1, std::min(wgmax, (n + 2 * SB * NW - 1) / (2 * SB * NW)));
+        int k = std::max(1, std::min(wgmax, (int)(scale * n / (2 * SB * per_wg) + 0.999)));
+        if (scale < 1.0) k = std::max(1, (int)(scale * n / (2 * SB * per_wg) + 0.5));
         int q = 0;
         for (int t = 1; t < 8; ++t)
           if (load[t] < load[q]) q = t;
@@ -2028,7 +2037,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       if (!d_qent) return DM_ENOMEM;
       ctl.qent = d_qent;
       ctl.qhead = sbNext + 2 * (size_t)np;
-      DM_TRY(dm_fill_zero(ctx, sbProg, sizeof(unsigned) * totn));
+      DM_TRY(dm_fill_zero(ctx, sbProg, sizeof(unsigned) * 2 * totn));
       DM_TRY(dm_fill_zero(ctx, sbNext, sizeof(int) * np));
       DM_HIP(ctx, hipMemsetAsync(sbNext + np, 0xff, sizeof(int) * np, ctx->stream));
       DM_TRY(dm_fill_zero(ctx, sbNext + 2 * (size_t)np, sizeof(int) * 9));
@@ -2040,14 +2049,15 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
         DM_TRY(dm_fill_zero(ctx, ctl.dbg, sizeof(unsigned long long) * (2 * (size_t)cmax + 2)));
       }
       const int nwg = 256;  // one per CU: a matrix is served by the workgroups of ONE XCD, whichever claims it first
-      hipLaunchKernelGGL((sb_chase_kernel<NW>), dim3(nwg), dim3(64 * NW), 0, ctx->stream, d_cmat, ctl);
+      if (pairs) hipLaunchKernelGGL((sb_chase2_kernel<NP>), dim3(nwg), dim3(128 * NP), 0, ctx->stream, d_cmat, ctl);
+      else hipLaunchKernelGGL((sb_chase_kernel<NW>), dim3(nwg), dim3(64 * NW), 0, ctx->stream, d_cmat, ctl);
       {
         int herr = 0;  // (the eigenvalue selection synchronises right after this stage anyway)
         DM_TRY(dm_download(ctx, &herr, sbNext + 2 * (size_t)np + 8, sizeof(int)));
         if (herr) {
           if (dump) {
             DM_TRY(dump_arr(".dbg", ctl.dbg, sizeof(unsigned long long) * (2 * (size_t)cmax + 2)));
-            DM_TRY(dump_arr(".prog", sbProg, sizeof(unsigned) * totn));
+            DM_TRY(dump_arr(".prog", sbProg, sizeof(unsigned) * 2 * totn));
             DM_TRY(dump_arr(".next", sbNext, sizeof(int) * (2 * (size_t)np + 9)));
           }
           ctx->err = "bulge chase: a sweep waited for its predecessor for too long";
