@@ -54,8 +54,14 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
     fprintf(stderr, "\n");
   }
   // the two-stage reduction (dm_sbr_impl.h) lives in the 32-wide instantiation: its bandwidth is the panel width
-  if (const char* e = getenv("DM_TRD_TWOSTAGE"))
-    if (atoi(e) == 1) width = 32;
+  // (the policy in herm_eig_tridiag decides; these are the batches it can say yes to)
+  {
+    size_t totn = 0;
+    for (const auto& p : probs) totn += p.n;
+    const char* e = getenv("DM_TRD_TWOSTAGE");
+    const int mode = e ? atoi(e) : -1;
+    if (mode == 1 || (mode != 0 && ((maxn >= 3500 && totn >= 24000) || maxn >= 14000))) width = 32;
+  }
   if (const char* e = getenv("DM_TRD_PANEL")) width = atoi(e) == 64 ? 64 : 32;
   return width == 32 ? dm_trd32::herm_eig_tridiag(ctx, probs, evals, evals_stride, sel)
                      : dm_trd64::herm_eig_tridiag(ctx, probs, evals, evals_stride, sel);

@@ -1763,13 +1763,15 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
 #if DM_TNB == 32
   bool two_stage = false;
   {
-    // DM_TRD_TWOSTAGE = 1 / 0 forces / forbids it; by default batches whose largest matrix has at least
-    // DM_TRD_TWOSTAGE_MIN rows take it (below that the one-stage chain of small launches is as fast)
+    // DM_TRD_TWOSTAGE = 1 / 0 forces / forbids it.  By default it is taken where it was measured faster than the
+    // one-stage reduction with ALL eigenvectors wanted (scratch/twostage_sweep.py; with a selection it gains more): the
+    // bulge chase needs n / 64 sweeps in flight per matrix to be busy, so either many matrices of a few hundred rows or
+    // a few large ones — 111 x <= 1218 (configs[1]) 1.08 x, 512 x 864 1.15 x, 8 x 4000 1.17 x, 8 x 6000 1.19 x, 1 x 16384
+    // 1.03 x; 32 x 1200 0.89 x, 8 x 2000 0.81 x, 1 x 8192 0.75 x stay on the one-stage path.
     int mode = -1;
     if (const char* e = getenv("DM_TRD_TWOSTAGE")) mode = atoi(e);
-    int minn = 100000000;
-    if (const char* e = getenv("DM_TRD_TWOSTAGE_MIN")) minn = atoi(e);
-    two_stage = use_dc && maxn > TSM && maxn > SB + 2 && (mode == 1 || (mode != 0 && maxn >= minn));
+    const bool pays = (maxn >= 700 && np >= 64) || (maxn >= 3500 && totn >= 24000) || maxn >= 14000;
+    two_stage = use_dc && maxn > TSM && maxn > SB + 2 && (mode == 1 || (mode != 0 && pays));
   }
 #else
   const bool two_stage = false;
