@@ -16,8 +16,8 @@ SIGNATURES = {
     "dm_comm_destroy": (c_int, [c_vp]),
     "dm_comm_rank": (c_int, [c_vp]),
     "dm_comm_size": (c_int, [c_vp]),
-    "dm_allreduce_f64": (c_int, [c_vp, c_vp, c_sz]),
-    "dm_gather_f64": (c_int, [c_vp, c_vp, c_vp, c_sz, c_int]),
+    "dm_allreduce_f64": (c_int, [c_vp, c_vp, c_sz, c_vp]),
+    "dm_gather_f64": (c_int, [c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
     "dm_comm_sync": (c_int, [c_vp]),
 }
 ID_BYTES = 128
@@ -66,13 +66,23 @@ class Communicator(object):
     def size(self):
         return self.lib.dm_comm_size(self.h)
 
-    def allreduce(self, t):
-        """In-place sum of a float64 device tensor over the ranks."""
-        self._check(self.lib.dm_allreduce_f64(self.h, c_vp(t.data_ptr()), int(t.numel())))
+    @staticmethod
+    def _user_stream(stream):
+        """The stream the buffers live on: the caller's, or torch's current stream (the collective is ordered after the
+        work enqueued there, and later work there after the collective — include/driftcomm.h)."""
+        if stream is None:
+            import torch
 
-    def gather(self, send, recv, root=0):
+            stream = torch.cuda.current_stream().cuda_stream
+        return c_vp(stream) if stream else None
+
+    def allreduce(self, t, stream=None):
+        """In-place sum of a float64 device tensor over the ranks."""
+        self._check(self.lib.dm_allreduce_f64(self.h, c_vp(t.data_ptr()), int(t.numel()), self._user_stream(stream)))
+
+    def gather(self, send, recv, root=0, stream=None):
         self._check(self.lib.dm_gather_f64(self.h, c_vp(send.data_ptr()), c_vp(recv.data_ptr()) if recv is not None else None,
-                                           int(send.numel()), int(root)))
+                                           int(send.numel()), int(root), self._user_stream(stream)))
 
     def sync(self):
         self._check(self.lib.dm_comm_sync(self.h))

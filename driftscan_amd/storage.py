@@ -103,7 +103,21 @@ def backend():
         return "driftio"
     if HAVE_H5PY:
         return "h5py"
-    return "driftio" if load_driftio() is not None else "npz"
+    if load_driftio() is not None:
+        return "driftio"
+    global _warned_npz
+    if not _warned_npz:
+        _warned_npz = True
+        import warnings
+
+        warnings.warn("driftscan_amd.storage: no HDF5 back-end (neither h5py nor libdriftio.so / libhdf5): product files are "
+                      "written as .npz archives under their *.hdf5 names and are NOT readable by the reference; build "
+                      "libdriftio (csrc/Makefile, needs the HDF5 C library) or set DRIFTMI_STORAGE=npz to silence this",
+                      RuntimeWarning, stacklevel=2)
+    return "npz"
+
+
+_warned_npz = False
 
 
 def _is_hdf5(path):
@@ -153,16 +167,57 @@ class _MemDataset(object):
         return self.shape[0]
 
 
+class _Attrs(dict):
+    """Attribute dictionary of a write-at-close file: any change marks the file dirty (h5py persists ``f.attrs[k] = v``
+    on a file opened "a" / "r+" whether or not a dataset was touched)."""
+
+    def __init__(self, owner):
+        dict.__init__(self)
+        self._owner = owner
+
+    def _touch(self):
+        if self._owner.mode != "r":
+            self._owner._dirty = True
+
+    def __setitem__(self, k, v):
+        dict.__setitem__(self, k, v)
+        self._touch()
+
+    def __delitem__(self, k):
+        dict.__delitem__(self, k)
+        self._touch()
+
+    def update(self, *a, **kw):
+        dict.update(self, *a, **kw)
+        self._touch()
+
+    def pop(self, *a):
+        r = dict.pop(self, *a)
+        self._touch()
+        return r
+
+    def clear(self):
+        dict.clear(self)
+        self._touch()
+
+    def setdefault(self, k, d=None):
+        if k not in self:
+            self[k] = d
+        return dict.__getitem__(self, k)
+
+
 class _BaseFile(object):
     """Write-at-close file: datasets live as numpy arrays until ``close`` writes them to a temporary file that is
     then renamed.  Subclasses provide ``_open_existing``, ``_read``, ``_write_all``."""
 
     def __init__(self, path, mode="r"):
         self.path, self.mode = path, mode
-        self._data, self._opts, self.attrs, self._dirty = {}, {}, {}, False
+        self._data, self._opts, self._dirty = {}, {}, False
+        self.attrs = _Attrs(self)
         self._h = None
         if mode in ("r", "r+", "a") and os.path.exists(path):
             self._open_existing()
+            self._dirty = False   # (reading the stored attributes in is not a change)
         elif mode in ("r", "r+"):
             raise IOError("no such file: %s" % path)
         if mode == "w":
@@ -236,7 +291,7 @@ class _BaseFile(object):
         return self._data.keys()
 
     def close(self):
-        if self.mode != "r" and (self._dirty or (self.attrs and self.mode == "w")):
+        if self.mode != "r" and self._dirty:
             for k in self._data:   # read-modify-write: everything must be in memory before the old file goes away
                 self._load(k)
                 if k not in self._opts:
@@ -256,7 +311,13 @@ class _BaseFile(object):
     def __enter__(self):
         return self
 
-    def __exit__(self, *exc):
+    def __exit__(self, et, ev, tb):
+        if et is not None:
+            # the with-body failed: nothing is written, no partial file appears under the final name (every stage of the
+            # pipeline resumes with "skip if the file exists", so a half-written product would be kept for ever)
+            self._dirty = False
+            self._close_handle()
+            return False
         self.close()
         return False
 

@@ -9,6 +9,15 @@
  * One communicator per process = one rank per GPU.  The 128-byte id made by dm_comm_unique_id on rank 0 travels to the
  * other ranks by whatever channel the host has (a file, a socket, MPI_Bcast).
  * Every function returns 0 on success, < 0 on failure (dm_comm_last_error()).
+ *
+ * Stream ordering.  A collective is enqueued on the communicator's stream (the one given to dm_comm_init_rank, or a
+ * private non-blocking stream).  Its buffers are produced and consumed on the CALLER's stream, which every collective
+ * takes as `user_stream` (a hipStream_t; NULL = the legacy default stream): the library makes the communicator's stream
+ * wait for everything enqueued on `user_stream` so far before the collective starts, and makes `user_stream` wait for the
+ * collective afterwards (events, nothing blocks the host).  So kernels enqueued on `user_stream` before the call have
+ * finished writing the buffer when it is read, and kernels enqueued on it after the call see the result.  Work on any
+ * OTHER stream is the caller's to order; the host itself reads a result only after dm_comm_sync (or a synchronisation
+ * of `user_stream`).
  */
 #ifndef DRIFTCOMM_H
 #define DRIFTCOMM_H
@@ -32,10 +41,10 @@ int dm_comm_init_rank(int nranks, int rank, const void* id, int device, void* st
 int dm_comm_destroy(dm_comm* comm);
 int dm_comm_rank(const dm_comm* comm);
 int dm_comm_size(const dm_comm* comm);
-/* in place, SUM over ranks, n doubles of device memory; enqueued on the communicator's stream */
-int dm_allreduce_f64(dm_comm* comm, double* data_dev, size_t n);
+/* in place, SUM over ranks, n doubles of device memory; ordered against user_stream as described above */
+int dm_allreduce_f64(dm_comm* comm, double* data_dev, size_t n, void* user_stream);
 /* every rank sends n doubles; rank `root` receives nranks * n (rank-major) in recv_dev (ignored elsewhere) */
-int dm_gather_f64(dm_comm* comm, const double* send_dev, double* recv_dev, size_t n, int root);
+int dm_gather_f64(dm_comm* comm, const double* send_dev, double* recv_dev, size_t n, int root, void* user_stream);
 /* block the host until everything enqueued so far on the communicator's stream is done */
 int dm_comm_sync(dm_comm* comm);
 

@@ -261,3 +261,33 @@ def test_driftcomm_single_rank(ctx):
     c.sync()
     assert torch.equal(x, ref) and torch.equal(out, ref)
     c.close()
+
+
+def test_driftcomm_orders_against_the_producer_stream(ctx):
+    """include/driftcomm.h, "Stream ordering": a collective on the communicator's private stream starts only after the
+    kernels enqueued on the caller's stream have written the buffer, and later work on the caller's stream sees its
+    result — checked with a producer that is still in flight when the collective is enqueued (a long chain of fills on
+    a side stream), without any host synchronisation in between."""
+    import torch
+
+    from driftscan_amd import comm
+
+    c = comm.Communicator(1, 0, comm.unique_id(), device=0)
+    n = 1 << 24  # 128 MB of doubles
+    side = torch.cuda.Stream()
+    send = torch.zeros(n, dtype=torch.float64, device="cuda")
+    recv = torch.zeros(n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for k in range(40):  # ~40 passes over 128 MB: still running when the gather below is enqueued
+            send.add_(1.0)
+        c.gather(send, recv, root=0)          # user stream = torch's current stream = `side`
+        out = recv * 2.0                      # consumer on the same stream, enqueued right behind the collective
+        c.allreduce(send)                     # in place, one rank: the identity, ordered behind the gather's read
+        tail = send + 1.0
+    side.synchronize()
+    c.sync()
+    assert float(recv.min()) == 40.0 and float(recv.max()) == 40.0
+    assert float(out.min()) == 80.0 and float(out.max()) == 80.0
+    assert float(tail.min()) == 41.0 and float(tail.max()) == 41.0
+    c.close()

@@ -197,3 +197,34 @@ def test_npz_files_still_open(tmp_path, monkeypatch):
     monkeypatch.setenv("DRIFTMI_STORAGE", "hdf5")
     with storage.File(p, "r") as f:
         assert isinstance(f, storage.NpzFile) and np.array_equal(f["evals"][:], np.arange(3.0)) and int(f.attrs["m"]) == 2
+
+
+@pytest.mark.parametrize("backend", ["hdf5", "npz"])
+def test_failed_body_leaves_no_file_and_attrs_persist(tmp_path, monkeypatch, backend):
+    """A with-body that raises writes nothing (no partial product under the final name: every stage resumes with
+    "skip if the file exists"); `f.attrs[k] = v` on a file opened "r+" is persisted even when no dataset is touched,
+    as h5py does."""
+    monkeypatch.setenv("DRIFTMI_STORAGE", backend)
+    if backend == "hdf5" and not storage.HAVE_H5PY and storage.load_driftio() is None:
+        pytest.skip("no HDF5 back-end in this environment")
+    p = str(tmp_path / "svd.hdf5")
+    with pytest.raises(RuntimeError):
+        with storage.File(p, "w") as f:
+            f.create_dataset("beam_svd", data=np.arange(6.0).reshape(2, 3))
+            raise RuntimeError("the stage failed between two datasets")
+    assert not os.path.exists(p) and not [x for x in os.listdir(str(tmp_path)) if x.startswith("svd.hdf5")]
+    with storage.File(p, "w") as f:
+        f.create_dataset("beam_svd", data=np.arange(6.0).reshape(2, 3))
+        f.attrs["m"] = 3
+    with storage.File(p, "r+") as f:
+        f.attrs["note"] = 7
+    with storage.File(p, "r") as f:
+        assert int(f.attrs["m"]) == 3 and int(f.attrs["note"]) == 7
+        assert np.array_equal(f["beam_svd"][:], np.arange(6.0).reshape(2, 3))
+    # a failing read-modify-write keeps the old content
+    with pytest.raises(RuntimeError):
+        with storage.File(p, "r+") as f:
+            f.attrs["note"] = 9
+            raise RuntimeError("no")
+    with storage.File(p, "r") as f:
+        assert int(f.attrs["note"]) == 7
