@@ -658,6 +658,126 @@ def gen_inverse(ref):
     print("svdkl_inverse.npz")
 
 
+def gen_timestream(ref):
+    """drift/pipeline/timestream.py by the unmodified reference class: the m-mode transform of a synthetic timestream
+    (`generate_mmodes`, :129-185), its SVD and KL projections (`generate_mmodes_svd` :215-236, `generate_mmodes_kl`
+    :331-356) and the a_lm stage of the three map-makers (`_make_alm` of `mapmake_full` :239-246, `mapmake_svd` :272-279,
+    `mapmake_kl` :408-425; the synthesis `hputil.sphtrans_inv_sky` behind them is cora's and is not run).  Products of all
+    m = 0 .. mmax come from the reference too (SVD chain, KL transform with `inverse`)."""
+    import tempfile
+
+    import h5py  # the in-memory stand-in
+    import scipy.linalg as _sla
+
+    from drift.pipeline import timestream as tsmod
+
+    btmod, klmod = ref["beamtransfer"], ref["kltransform"]
+    _pinv = _sla.pinv
+
+    def _pinv_compat(a, *args, rcond=None, **kw):  # scipy >= 1.14: rcond -> rtol (see gen_projections)
+        if rcond is not None:
+            kw["rtol"] = rcond
+        return _pinv(a, *args, **kw)
+
+    _sla.pinv = _pinv_compat
+
+    # the h5py stand-in keeps files in memory: let the reference's `os.path.exists` checks see them
+    class _OsShim(object):
+        def __getattr__(self, name):
+            return getattr(os, name)
+
+    class _PathShim(object):
+        def __getattr__(self, name):
+            return getattr(os.path, name)
+
+        @staticmethod
+        def exists(path):
+            return h5py.exists(path) or os.path.exists(path)
+
+    shim = _OsShim()
+    shim.path = _PathShim()
+    klmod.os = shim
+    tsmod.os = shim
+    rng = np.random.default_rng(4101)
+    F, B, P, lmax = 3, 5, 4, 8
+    L, mmax = lmax + 1, lmax
+    redundancy = rng.integers(1, 6, size=B).astype(np.float64)
+    npower = (2.5e-7 * (1.0 + 0.1 * np.arange(F))[:, None] / redundancy[None, :]).astype(np.float64)
+    tel = FakeTelescope(F, B, P, lmax, mmax, npower, tsys_flat=1.0)
+    bt = btmod.BeamTransfer("/mem/ts/bt", telescope=tel)
+    bt.polsvcut, bt.svcut = 1e-4, 1e-6
+    cv_sg = analytic_cl(tel.frequencies, L, P, "signal")
+    out = dict(dims=np.array([F, B, P, lmax]), npower=npower, cv_sg=cv_sg, polsvcut=bt.polsvcut, svcut=bt.svcut)
+    for mi in range(mmax + 1):
+        beam = synth_beam_m(rng, F, B, P, L, mi)
+        write_beam_file(ref, bt, mi, beam)
+        bt._generate_svdfile_m(mi)
+        out["m%d_beam_m" % mi] = beam
+    kl = klmod.KLTransform(bt, subdir="kl")
+    kl._cvsg, kl._cvfg = cv_sg, np.zeros_like(cv_sg)
+    kl.use_foregrounds = False
+    kl.inverse = True
+    kl.threshold = 0.0
+    # the cut of the data projection: a value that no eigenvalue of any m comes near (5 %), so that the kept count is
+    # not a matter of rounding
+    allev = []
+    for mi in range(mmax + 1):
+        kl.transform_save(mi)
+        ev = kl.evals_m(mi)
+        if ev is not None:
+            allev.append(ev)
+    allev = np.sort(np.concatenate(allev))
+    cand = np.sqrt(allev[:-1] * allev[1:])
+    gap = allev[1:] / allev[:-1]
+    mid = np.argsort(np.abs(np.arange(cand.size) - cand.size // 2))
+    thr = next(float(cand[i]) for i in mid if gap[i] > 1.1 and cand[i] > 0)
+    out["kl_threshold"] = thr
+
+    class PM(object):
+        beamtransfer = bt
+        kltransforms = {"kl": kl}
+
+    tsdir = tempfile.mkdtemp(prefix="refts_")
+    ts = tsmod.Timestream(tsdir, PM())
+    ntime = 2 * mmax + 5
+    data = rng.standard_normal((F, B, ntime)) + 1j * rng.standard_normal((F, B, ntime))
+    out["timestream"] = data
+    for fi in range(F):
+        f = h5py.File(ts._ffile(fi), "w")
+        f.create_dataset("timestream", data=data[fi])
+        f.attrs["ntime"] = ntime
+        f.close()
+    ts.generate_mmodes()
+    ts.generate_mmodes_svd()
+    ts.set_kltransform("kl", threshold=thr)
+    ts.generate_mmodes_kl()
+    alm_full = np.zeros((F, P, L, L), dtype=np.complex128)
+    alm_svd, alm_kl, alm_klw = np.zeros_like(alm_full), np.zeros_like(alm_full), np.zeros_like(alm_full)
+    svd_norm, nkl = np.zeros(mmax + 1), np.zeros(mmax + 1, dtype=np.int64)
+    for mi in range(mmax + 1):
+        mm = ts.mmode(mi)
+        out["m%d_mmode" % mi] = mm
+        alm_full[..., mi] = bt.project_vector_telescope_to_sky(mi, mm)
+        sv = ts.mmode_svd(mi)
+        svd_norm[mi] = np.linalg.norm(sv)
+        alm_svd[..., mi] = bt.project_vector_svd_to_sky(mi, sv)
+        klm = ts.mmode_kl(mi)
+        nkl[mi] = klm.size
+        if mi >= 1:  # no_m_zero
+            alm_kl[..., mi] = bt.project_vector_svd_to_sky(mi, kl.project_vector_kl_to_svd(mi, klm.copy(), threshold=thr))
+            kw = klm.copy()
+            ev = kl.evals_m(mi, thr)
+            if ev is not None:
+                kw *= ev / (1.0 + ev)
+            alm_klw[..., mi] = bt.project_vector_svd_to_sky(mi, kl.project_vector_kl_to_svd(mi, kw, threshold=thr))
+    out.update(alm_full=alm_full, alm_svd=alm_svd, alm_kl=alm_kl, alm_kl_wiener=alm_klw, svd_norm=svd_norm, nkl=nkl)
+    _sla.pinv = _pinv
+    klmod.os = os
+    tsmod.os = os
+    np.savez_compressed(os.path.join(OUT, "timestream.npz"), **out)
+    print("timestream.npz", "threshold", thr, "kl modes per m", nkl.tolist())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = refimport.load()
@@ -675,6 +795,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "projections":
         gen_projections(ref)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "timestream":
+        gen_timestream(ref)
         return
     gen_matrix_ops(ref)
     gen_eigh_gen(ref)
@@ -694,6 +817,7 @@ def main():
     gen_psfisher(ref)
     gen_inverse(ref)
     gen_telescopes(ref)
+    gen_timestream(ref)
 
 
 if __name__ == "__main__":

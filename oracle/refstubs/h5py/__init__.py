@@ -55,14 +55,14 @@ class File(object):
         else:
             arr = np.zeros(shape, dtype=dtype)
         d = Dataset(arr)
-        self._f["dsets"][name] = d
+        self._f["dsets"][name.lstrip("/")] = d   # "/mmode" and "mmode" name the same dataset of the root group
         return d
 
     def __getitem__(self, name):
-        return self._f["dsets"][name]
+        return self._f["dsets"][name.lstrip("/")]
 
     def __contains__(self, name):
-        return name in self._f["dsets"]
+        return name.lstrip("/") in self._f["dsets"]
 
     def keys(self):
         return self._f["dsets"].keys()

@@ -1,7 +1,9 @@
 """Consumers of the operators: timestream simulation, the m-mode transform and the
-map-makers of drift/pipeline/timestream.py on top of the GPU-backed BeamTransfer / KLTransform.  cora's sky <-> a_lm
-transforms are not available, so there is nothing of the reference to pin the maps on; what is checked are the
-identities the reference's code path implies, on a small polarised cylinder."""
+map-makers of drift/pipeline/timestream.py on top of the GPU-backed BeamTransfer / KLTransform.
+`test_against_reference_timestream` pins the m-mode transform, the SVD / KL projections of the data and the a_lm stage of
+the three map-makers on outputs of the unmodified reference class (tests/golden/timestream.npz).  cora's sky <-> a_lm
+transforms are not available, so the synthesis to maps and `simulate` are checked through the identities the
+reference's code path implies, on a small polarised cylinder."""
 import os
 
 import numpy as np
@@ -114,3 +116,85 @@ def test_simulate_mmodes_and_maps(prod):
     assert np.array_equal(n1, n2) and np.abs(n1).max() > 0
     again = timestream.Timestream.load(ts.directory)
     assert again.ntime == ts.ntime and np.array_equal(again.mmode(1), ts.mmode(1))
+
+
+class _FixtureTelescope(object):
+    def __init__(self, F, B, P, lmax, npower):
+        self.nfreq, self.nbase, self.npairs = F, B, B
+        self.num_pol_sky = P
+        self.lmax = self.mmax = lmax
+        self.included_freq = np.arange(F)
+        self.included_baseline = np.arange(B)
+        self.included_pol = np.arange(P)
+        self.frequencies = np.linspace(400.0, 450.0, F)
+        self.baselines = np.zeros((B, 2))
+        self.tsys_flat = 1.0
+        self._npower = npower
+
+    def noisepower(self, bl_indices, f_indices, ndays=None):
+        bl, fi = np.broadcast_arrays(bl_indices, f_indices)
+        return self._npower[fi, bl]
+
+
+def test_against_reference_timestream(golden_dir, tmp_path):
+    """`Timestream` against outputs of the UNMODIFIED reference class (drift/pipeline/timestream.py driven through
+    oracle/refstubs by oracle/gen_golden.py -> tests/golden/timestream.npz): the m-mode transform of the same synthetic
+    timestream (`generate_mmodes`), the SVD and KL projections of the data and the a_lm stage of `mapmake_full`,
+    `mapmake_svd` and `mapmake_kl` (with and without the Wiener weights) on the same beam blocks.  Vectors in the SVD /
+    KL bases are gauge dependent and are compared through their norms, counts and their images on the sky."""
+    from driftscan_amd import beamtransfer, device, kltransform, storage, timestream
+
+    device.reset_context()
+    g = np.load(os.path.join(golden_dir, "timestream.npz"))
+    F, B, P, lmax = (int(x) for x in g["dims"])
+    tel = _FixtureTelescope(F, B, P, lmax, g["npower"])
+    bt = beamtransfer.BeamTransfer(str(tmp_path / "bt"), telescope=tel)
+    bt.polsvcut, bt.svcut = float(g["polsvcut"]), float(g["svcut"])
+    bt._generate_dirs()
+    for mi in range(lmax + 1):
+        with storage.File(bt._mfile(mi), "w") as f:
+            f.create_dataset("beam_m", data=g["m%d_beam_m" % mi][..., mi:])
+    bt._generate_svdfiles(regen=True)
+    kl = kltransform.KLTransform.from_config(dict(threshold=0.0, inverse=True, use_foregrounds=False), bt, subdir="kl")
+    kl._cvsg, kl._cvfg = g["cv_sg"], np.zeros_like(g["cv_sg"])
+    kl.generate(regen=True)
+
+    class PM(object):
+        beamtransfer = bt
+        kltransforms = {"kl": kl}
+
+    ts = timestream.Timestream(str(tmp_path / "ts"), PM())
+    data = g["timestream"]
+    for fi in range(F):
+        os.makedirs(ts._fdir(fi), exist_ok=True)
+        with storage.File(ts._ffile(fi), "w") as f:
+            f.create_dataset("timestream", data=data[fi])
+            f.attrs["ntime"] = data.shape[-1]
+    assert ts.ntime == data.shape[-1]
+    ts.generate_mmodes()
+    ts.generate_mmodes_svd()
+    thr = float(g["kl_threshold"])
+    ts.set_kltransform("kl", threshold=thr)
+    ts.generate_mmodes_kl()
+    sc = np.abs(g["alm_full"]).max()
+    for mi in range(lmax + 1):
+        mm = ts.mmode(mi)
+        ref = g["m%d_mmode" % mi]
+        assert mm.shape == ref.shape and np.abs(mm - ref).max() <= 1e-13 * np.abs(ref).max(), mi
+        a = bt.project_vector_telescope_to_sky(mi, mm)
+        assert np.abs(a - g["alm_full"][..., mi]).max() <= 1e-9 * sc, mi
+        sv = ts.mmode_svd(mi)
+        assert abs(np.linalg.norm(sv) - g["svd_norm"][mi]) <= 1e-9 * max(g["svd_norm"][mi], 1e-300), mi
+        a = bt.project_vector_svd_to_sky(mi, sv)
+        assert np.abs(a - g["alm_svd"][..., mi]).max() <= 1e-8 * np.abs(g["alm_svd"]).max(), mi
+        klm = ts.mmode_kl(mi)
+        assert klm.size == int(g["nkl"][mi]), mi
+        if mi >= 1:
+            a = bt.project_vector_svd_to_sky(mi, kl.project_vector_kl_to_svd(mi, klm.copy(), threshold=thr))
+            assert np.abs(a - g["alm_kl"][..., mi]).max() <= 1e-7 * np.abs(g["alm_kl"]).max(), mi
+            ev = kl.evals_m(mi, thr)
+            kw = klm.copy()
+            if ev is not None:
+                kw *= ev / (1.0 + ev)
+            a = bt.project_vector_svd_to_sky(mi, kl.project_vector_kl_to_svd(mi, kw, threshold=thr))
+            assert np.abs(a - g["alm_kl_wiener"][..., mi]).max() <= 1e-7 * np.abs(g["alm_kl_wiener"]).max(), mi
