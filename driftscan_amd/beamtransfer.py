@@ -20,6 +20,17 @@ from .device import get_context
 logger = logging.getLogger(__name__)
 
 
+def _contiguous_runs(ms):
+    """[(first, last), ...] of a sorted list of integers."""
+    runs = []
+    for mi in ms:
+        if runs and mi == runs[-1][1] + 1:
+            runs[-1][1] = mi
+        else:
+            runs.append([mi, mi])
+    return [(a, b) for a, b in runs]
+
+
 def _find_index_sorted(a, v):
     ind = np.searchsorted(a, v)
     return ind if (ind < len(a) and v == a[ind]) else None
@@ -59,6 +70,7 @@ class BeamTransfer(config.Reader):
     device_chunk_gb = config.Property(proptype=float, default=6.0)  # BT-gen working set per launch group
     svd_chunk_gb = config.Property(proptype=float, default=16.0)    # SVD working set per batch of m
     beam_chunk_gb = config.Property(proptype=float, default=96.0)   # beam_m blocks resident per BT-gen call
+    keep_products_gb = config.Property(proptype=float, default=32.0)  # SVD products of finished batches stay in HBM up to this
 
     noise_weight = True
 
@@ -66,6 +78,7 @@ class BeamTransfer(config.Reader):
         self.directory = directory
         self.telescope = telescope
         self._dev = {}  # m -> dict of device tensors kept resident for the KL stage
+        self._sv_host = {}  # m -> (nfreq, svd_len) singular values on the host (survive the eviction of _dev)
         if parallel.rank0() and not os.path.exists(directory):
             os.makedirs(directory)
         parallel.barrier()
@@ -158,16 +171,59 @@ class BeamTransfer(config.Reader):
             return f["singularvalues"][:]
 
     # ---- generation -------------------------------------------------------------------
-    def generate(self, regen=False, skip_svd=False, skip_svd_inv=False):
-        """Generate and save all products (beamtransfer.py:447-480)."""
+    def generate(self, regen=False, skip_svd=False, skip_svd_inv=False, after_batch=None):
+        """Generate and save all products (beamtransfer.py:447-480).
+
+        The reference runs the stages one after the other over all m, through the files.  Here a rank owns ONE
+        contiguous, cost-balanced range of m (`_my_ms`) and takes it through the stages while the blocks are resident in
+        HBM: beam-transfer generation of as many of its m as `beam_chunk_gb` holds, then batch by batch (`svd_chunk_gb`)
+        the SVD chain on the resident blocks and — through `after_batch(ms)`, which `ProductManager.generate` uses for the
+        KL transforms — everything downstream that wants the SVD products of those m.  Finished products go to the
+        writer pool; nothing is read back from a file during generation."""
         st = time.time()
         self._generate_dirs()
-        if parallel.rank0():
+        if parallel.rank0() and not storage.discard():
             with open(self._picklefile, "wb") as f:
                 pickle.dump(self.telescope, f)
-        self._generate_mfiles(regen)
+        tel = self.telescope
+        ctx = get_context()
+        marker = self.directory + "/beam_m/COMPLETED"
+        mine = self._my_ms()
+        per_block = tel.nfreq * 2 * tel.nbase * tel.num_pol_sky * (tel.lmax + 1) * 16
+        nb_max = max(1, int(self.beam_chunk_gb * (1 << 30) // per_block))
+        runs = _contiguous_runs(mine)
+        ranges = [(a0, min(a0 + nb_max, b + 1) - 1) for (a, b) in runs for a0 in range(a, b + 1, nb_max)]
+        have_beams = os.path.exists(marker) and not regen
+        self._beam_all = None
+        for (a, b) in ranges:
+            ms = list(range(a, b + 1))
+            need_bt = not have_beams and (regen or not all(os.path.exists(self._mfile(mi)) for mi in ms))
+            need_svd = not skip_svd and (regen or not all(storage.can_open(self._svdfile(mi)) for mi in ms))
+            beam_all = None
+            if need_bt:
+                whole = a == 0 and b == tel.mmax
+                beam_all = btgen.beam_m_all(tel, ctx=ctx, max_bytes=int(self.device_chunk_gb * (1 << 30)),
+                                            m_range=None if whole else (a, b))
+                if self.truncate:
+                    # beamtransfer.py:641-646: rows of the m-ordered array (runs over l) truncated to
+                    # max(truncate_rel |z|, truncate_maxl max_l |z|); in place, so the SVD stage sees what the files hold
+                    ctx.bit_truncate_max_complex(beam_all, self.truncate_rel, self.truncate_maxl)
+                self._write_beam_files(beam_all, a, b, regen)
+            self._beam_all, self._beam_all_m0 = beam_all, a
+            if need_svd:
+                self._svd_batches(ms, regen, skip_svd_inv, after_batch)
+            elif after_batch is not None and not skip_svd:
+                for batch in self._svd_batch_lists(ms):
+                    after_batch(batch)
+                    self._evict(batch)
+            self._beam_all = None
+            del beam_all
+        storage.flush()
+        parallel.barrier()
+        if parallel.rank0() and not storage.discard():
+            open(marker, "a").close()
         if not skip_svd:
-            self._generate_svdfiles(regen, skip_svd_inv)
+            self._collect_svd_spectrum()
         parallel.barrier()
         if parallel.rank0():
             logger.info("Beam generation time: %f" % (time.time() - st))
@@ -181,66 +237,70 @@ class BeamTransfer(config.Reader):
                 os.makedirs(self._mdir(mi), exist_ok=True)
         parallel.barrier()
 
+    def _m_cost(self, m):
+        """Relative cost of one m-block through the whole path: beam-transfer generation is about the same for every m,
+        the SVD chain follows the number of l >= m, the KL stage its cube (ndof falls with m)."""
+        x = float(self.telescope.lmax + 1 - m) / float(self.telescope.lmax + 1)
+        return 0.15 + 0.6 * x + 0.25 * x ** 3
+
     def _my_ms(self, mlist=None):
-        """m-blocks owned by this rank.  Cost model for the LPT assignment: SVD + KL work of a
-        block scales like (lmax + 1 - m)."""
+        """m-blocks owned by this rank: ONE contiguous range with (nearly) the same summed cost on every rank
+        (`parallel.partition_contiguous`) — a rank keeps its blocks in HBM from generation to the KL stage, and
+        beam-transfer generation produces a contiguous range of m per call.  (The reference's split is contiguous with
+        equal counts, beamtransfer.py:720-722; any assignment gives the same files.)"""
         tel = self.telescope
         mlist = list(range(tel.mmax + 1)) if mlist is None else list(mlist)
-        costs = [float(tel.lmax + 1 - m) + 1.0 for m in mlist]
-        return parallel.partition(mlist, costs)
+        return parallel.partition_contiguous(mlist, [self._m_cost(m) for m in mlist])
+
+    def _write_beam_files(self, beam_all, a, b, regen):
+        """Hand the beam_m files of m = a..b (device tensor, first axis = m - a) to the writer pool."""
+        if storage.discard():
+            return
+        tel = self.telescope
+        ctx = get_context()
+        finc, binc, pinc = tel.included_freq, tel.included_baseline, tel.included_pol
+
+        def write_m(mi, blk):
+            with storage.File(self._mfile(mi), "w") as f:
+                data = blk[np.ix_(finc, np.arange(2), binc, pinc, np.arange(mi, tel.lmax + 1))]
+                # chunk shape and compression of beamtransfer.py:548-571
+                f.create_dataset("beam_m", data=data, **storage.compression_kwargs(
+                    (1, 2, min(10, len(binc)), len(pinc), tel.lmax + 1 - mi)))
+                f.attrs["m"] = mi
+                f.attrs["frequencies"] = tel.frequencies
+
+        host_all = ctx.to_host(beam_all) if beam_all.numel() * 16 <= (8 << 30) else None
+        for mi in range(a, b + 1):
+            if os.path.exists(self._mfile(mi)) and not regen:
+                continue
+            storage.submit(write_m, mi, host_all[mi - a] if host_all is not None else ctx.to_host(beam_all[mi - a]))
 
     def _generate_mfiles(self, regen=False):
-        """beam_m files (beamtransfer.py:502-676).  The reference computes (f, b) chunks on
-        each rank and transposes to m-order with an all-to-all; here every rank synthesises
-        the maps it needs and keeps only its own m-blocks — map synthesis is a few percent of
-        the per-m cost, so replicating it is cheaper than an exchange step."""
+        """beam_m files alone (beamtransfer.py:502-676), for callers that want the stage by itself; `generate` runs
+        it fused with the SVD stage.  The reference computes (f, b) chunks on each rank and transposes to m-order with
+        an all-to-all; here every rank synthesises the maps it needs and keeps only its own m-blocks — map synthesis is
+        a few percent of the per-m cost, so replicating it is cheaper than an exchange step."""
         marker = self.directory + "/beam_m/COMPLETED"
         if os.path.exists(marker) and not regen:
             return
         tel = self.telescope
         ctx = get_context()
         st = time.time()
-        finc, binc, pinc = tel.included_freq, tel.included_baseline, tel.included_pol
-        nranks, r = parallel.size(), parallel.rank()
-        M = tel.mmax + 1
-        if nranks == 1:
-            m_lo, m_hi = 0, M - 1
-        else:
-            # BT-gen costs about the same for every m: contiguous ranges, each rank transforms only its
-            # own blocks (dm_bt_sht_range); the SVD / KL stages re-read the files under their own
-            # cost-balanced assignment
-            m_lo, m_hi = (M * r) // nranks, (M * (r + 1)) // nranks - 1
-        # the blocks of one call stay in HBM until they are written: bound them (config 3: 1.8 GB per block,
-        # 934 GB for all m).  Every call synthesises all (f, b) maps again, so the ranges are as long as fit.
+        mine = self._my_ms()
         per_block = tel.nfreq * 2 * tel.nbase * tel.num_pol_sky * (tel.lmax + 1) * 16
         nb_max = max(1, int(self.beam_chunk_gb * (1 << 30) // per_block))
-        ranges = [(a, min(a + nb_max, m_hi + 1) - 1) for a in range(m_lo, m_hi + 1, nb_max)]
+        runs = _contiguous_runs(mine)
+        ranges = [(a0, min(a0 + nb_max, b + 1) - 1) for (a, b) in runs for a0 in range(a, b + 1, nb_max)]
         self._beam_all = None
         for (a, b) in ranges:
-            whole = nranks == 1 and len(ranges) == 1
+            whole = a == 0 and b == tel.mmax
             beam_all = btgen.beam_m_all(tel, ctx=ctx, max_bytes=int(self.device_chunk_gb * (1 << 30)),
                                         m_range=None if whole else (a, b))
             if self.truncate:
-                # beamtransfer.py:641-646: rows of the m-ordered array (runs over l) truncated to
-                # max(truncate_rel |z|, truncate_maxl max_l |z|); in place, so the SVD stage sees what the files hold
                 ctx.bit_truncate_max_complex(beam_all, self.truncate_rel, self.truncate_maxl)
             if whole:
-                self._beam_all = beam_all  # (mmax+1, F, 2, B, P, L), kept for the SVD stage
-
-            def write_m(mi, blk):
-                with storage.File(self._mfile(mi), "w") as f:
-                    data = blk[np.ix_(finc, np.arange(2), binc, pinc, np.arange(mi, tel.lmax + 1))]
-                    # chunk shape and compression of beamtransfer.py:548-571
-                    f.create_dataset("beam_m", data=data, **storage.compression_kwargs(
-                        (1, 2, min(10, len(binc)), len(pinc), tel.lmax + 1 - mi)))
-                    f.attrs["m"] = mi
-                    f.attrs["frequencies"] = tel.frequencies
-
-            host_all = ctx.to_host(beam_all) if beam_all.numel() * 16 <= (8 << 30) else None
-            for mi in range(a, b + 1):
-                if os.path.exists(self._mfile(mi)) and not regen:
-                    continue
-                storage.submit(write_m, mi, host_all[mi - a] if host_all is not None else ctx.to_host(beam_all[mi - a]))
+                self._beam_all, self._beam_all_m0 = beam_all, 0  # kept for a following _generate_svdfiles
+            self._write_beam_files(beam_all, a, b, regen)
             del beam_all
         storage.flush()
         parallel.barrier()
@@ -276,70 +336,107 @@ class BeamTransfer(config.Reader):
         nw = self._noisew_device()
         return ctx.svd_chain(beam_blocks.reshape(nblk, F, T, P, L), nw, self.polsvcut, skip_svd_inv=skip_svd_inv)
 
-    def _generate_svdfiles(self, regen=False, skip_svd_inv=False):
-        """svd.hdf5 for every m (beamtransfer.py:678-728, :730-929)."""
+    def _svd_batch_lists(self, ms):
         tel = self.telescope
-        ctx = get_context()
-        todo = [mi for mi in self._my_ms() if regen or not storage.can_open(self._svdfile(mi))]
         F, T, P, L, K = tel.nfreq, self.ntel, tel.num_pol_sky, tel.lmax + 1, self.svd_len
         per_m = F * (T * (P * L + T) * 2 + K * P * L * 2 + K * T) * 16
         nb = max(1, int(self.svd_chunk_gb * (1 << 30) // per_m))
-        for c0 in range(0, len(todo), nb):
-            ms = todo[c0 : c0 + nb]
-            blocks = self._device_beam_blocks(ms)
-            res = self.svd_device(blocks, skip_svd_inv=skip_svd_inv)
-            host = {k: ctx.to_host(res[k]) for k in ("beam_svd", "beam_ut", "singularvalues")}
-            host["invbeam_svd"] = None if skip_svd_inv else ctx.to_host(res["invbeam_svd"])
-            def write_svd(mi, bsvd, ibsvd, but, sig):
-                with storage.File(self._svdfile(mi), "w") as fs:   # chunk shapes of beamtransfer.py:741-798
-                    k10 = min(10, K)
-                    fs.create_dataset("beam_svd", data=bsvd, **storage.compression_kwargs((1, k10, P, L)))
-                    if ibsvd is not None:
-                        fs.create_dataset("invbeam_svd", data=ibsvd, **storage.compression_kwargs((1, P, L, k10)))
-                    fs.create_dataset("beam_ut", data=but, **storage.compression_kwargs((1, k10, T)))
-                    fs.create_dataset("singularvalues", data=sig)
-                    fs.attrs["baselines"] = tel.baselines
-                    fs.attrs["m"] = mi
-                    fs.attrs["frequencies"] = tel.frequencies
+        ms = list(ms)
+        return [ms[c0 : c0 + nb] for c0 in range(0, len(ms), nb)]
 
-            for i, mi in enumerate(ms):
-                self._dev[mi] = dict(beam_svd=res["beam_svd"][i], beam_ut=res["beam_ut"][i],
-                                     singularvalues=host["singularvalues"][i])
-                storage.submit(write_svd, mi, host["beam_svd"][i], None if skip_svd_inv else host["invbeam_svd"][i],
-                               host["beam_ut"][i], host["singularvalues"][i])
+    def _svd_batches(self, ms, regen=False, skip_svd_inv=False, after_batch=None):
+        """SVD chain of the given m in batches that fit `svd_chunk_gb` (beamtransfer.py:730-929): the products stay on
+        the device (`_dev`) for whoever comes next, the files go to the writer pool; `after_batch(ms)` runs right after a
+        batch while its products are resident, then they are evicted (unless `keep_products`)."""
+        tel = self.telescope
+        ctx = get_context()
+        T, P, L, K = self.ntel, tel.num_pol_sky, tel.lmax + 1, self.svd_len
+        todo = [mi for mi in ms if regen or not storage.can_open(self._svdfile(mi))]
+        for batch in self._svd_batch_lists(todo):
+            blocks = self._device_beam_blocks(batch)
+            res = self.svd_device(blocks, skip_svd_inv=skip_svd_inv)
+            del blocks
+            sv_host = ctx.to_host(res["singularvalues"])
+            if not storage.discard():
+                host = {k: ctx.to_host(res[k]) for k in ("beam_svd", "beam_ut")}
+                host["invbeam_svd"] = None if skip_svd_inv else ctx.to_host(res["invbeam_svd"])
+
+                def write_svd(mi, bsvd, ibsvd, but, sig):
+                    with storage.File(self._svdfile(mi), "w") as fs:   # chunk shapes of beamtransfer.py:741-798
+                        k10 = min(10, K)
+                        fs.create_dataset("beam_svd", data=bsvd, **storage.compression_kwargs((1, k10, P, L)))
+                        if ibsvd is not None:
+                            fs.create_dataset("invbeam_svd", data=ibsvd, **storage.compression_kwargs((1, P, L, k10)))
+                        fs.create_dataset("beam_ut", data=but, **storage.compression_kwargs((1, k10, T)))
+                        fs.create_dataset("singularvalues", data=sig)
+                        fs.attrs["baselines"] = tel.baselines
+                        fs.attrs["m"] = mi
+                        fs.attrs["frequencies"] = tel.frequencies
+
+            for i, mi in enumerate(batch):
+                self._sv_host[mi] = sv_host[i]
+                self._dev[mi] = dict(beam_svd=res["beam_svd"][i], beam_ut=res["beam_ut"][i], singularvalues=sv_host[i])
+                if not storage.discard():
+                    storage.submit(write_svd, mi, host["beam_svd"][i], None if skip_svd_inv else host["invbeam_svd"][i],
+                                   host["beam_ut"][i], sv_host[i])
+            del res
+            if after_batch is not None:
+                after_batch(batch)
+                self._evict(batch)
+
+    def _evict(self, ms):
+        """Drop the device copies of the SVD products of these m (they are re-read from their files when wanted again);
+        the singular values stay on the host for `_svd_num` and the spectrum file."""
+        tel = self.telescope
+        per_m = tel.nfreq * self.svd_len * (tel.num_pol_sky * (tel.lmax + 1) + self.ntel) * 16   # beam_svd + beam_ut
+        if per_m * len(self._dev) <= self.keep_products_gb * (1 << 30):
+            return
+        for mi in ms:
+            self._dev.pop(mi, None)
+
+    def _generate_svdfiles(self, regen=False, skip_svd_inv=False):
+        """svd.hdf5 for every m of this rank (beamtransfer.py:678-728, :730-929) as a stage of its own."""
+        self._svd_batches(self._my_ms(), regen, skip_svd_inv)
         storage.flush()
         parallel.barrier()
         self._collect_svd_spectrum()
 
     def _device_beam_blocks(self, ms):
         """(len(ms), F, 2, B, P, L) device tensor of the given m-blocks: from the resident
-        generation result when available, else re-read from the beam_m files."""
+        generation result when it covers them, else re-read from the beam_m files."""
         ctx = get_context()
-        if getattr(self, "_beam_all", None) is not None:
-            import torch
+        ba = getattr(self, "_beam_all", None)
+        if ba is not None:
+            m0 = getattr(self, "_beam_all_m0", 0)
+            if all(m0 <= mi < m0 + int(ba.shape[0]) for mi in ms):
+                ms = list(ms)
+                if ms == list(range(ms[0], ms[0] + len(ms))):
+                    return ba[ms[0] - m0 : ms[0] - m0 + len(ms)]   # a view: no copy of the blocks
+                import torch
 
-            return self._beam_all[torch.as_tensor(list(ms), device=self._beam_all.device)]
+                return ba[torch.as_tensor([mi - m0 for mi in ms], device=ba.device)]
         return ctx.to_device(np.stack([self.beam_m(mi) for mi in ms]))
 
     def _collect_svd_spectrum(self):
         """svdspectrum.hdf5: (mmax+1, nfreq, svd_len) (beamtransfer.py:931-947)."""
-        mine = [(mi, self._dev[mi]["singularvalues"] if mi in self._dev else self.beam_singularvalues(mi))
-                for mi in self._my_ms()]
+        mine = [(mi, self._sv_host[mi] if mi in self._sv_host else self.beam_singularvalues(mi)) for mi in self._my_ms()]
         allparts = parallel.gather_objects(mine)
         if parallel.rank0():
             spec = np.zeros((self.telescope.mmax + 1, self.nfreq, self.svd_len))
             for part in allparts:
                 for mi, sv in part:
                     spec[mi] = sv
-            with storage.File(self.directory + "/svdspectrum.hdf5", "w") as f:
-                f.create_dataset("singularvalues", data=spec)
+            if not storage.discard():
+                with storage.File(self.directory + "/svdspectrum.hdf5", "w") as f:
+                    f.create_dataset("singularvalues", data=spec)
         parallel.barrier()
 
     # ---- SVD bookkeeping (beamtransfer.py:1116-1133) ------------------------------------
     def _svd_num(self, mi):
         """(svnum, svbounds) of one m (beamtransfer.py:1116-1133); memoised per singular-value array,
         the KL stage asks for it several times per m."""
-        sv = self._dev[mi]["singularvalues"] if mi in self._dev else self.beam_singularvalues(mi)
+        sv = self._sv_host[mi] if mi in self._sv_host else (
+            self._dev[mi]["singularvalues"] if mi in self._dev else self.beam_singularvalues(mi))
         memo = self.__dict__.setdefault("_svnum_memo", {})
         hit = memo.get(mi)
         if hit is not None and hit[0] is sv and hit[1] == self.svcut:

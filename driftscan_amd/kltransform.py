@@ -267,14 +267,41 @@ class KLTransform(config.Reader):
             out.append(cur)
         return out
 
-    def generate(self, regen=False):
-        """KL-transform every m of this rank and save (kltransform.py:480-513)."""
-        st = time.time()
-        todo = [mi for mi in self.beamtransfer._my_ms() if regen or not os.path.exists(self._evfile % mi)]
+    def generate_ms(self, ms, regen=False):
+        """KL-transform the given m (of this rank) and hand the files to the writer pool: the per-batch step that
+        `ProductManager.generate` runs while the SVD products of these m are still resident.  No barrier, no collect."""
+        done = self.__dict__.setdefault("_done", set())
+        full = self.__dict__.setdefault("_evals_full_mem", {})
+        todo = [mi for mi in ms if mi not in done and (regen or not os.path.exists(self._evfile % mi))]
         for batch in self._batches(todo):
+            if storage.discard():
+                res = self._transform_batch(batch, to_host=False)   # products stay in HBM, no file
+                for mi, r in zip(batch, res):
+                    nside = int(self.beamtransfer.ndof(mi))
+                    evf = np.zeros(nside)
+                    ev = r[0].cpu().numpy()
+                    if ev.size:
+                        evf[-ev.size :] = ev
+                    full[mi] = evf
+                    done.add(mi)
+                continue
             for mi, res in zip(batch, self._transform_batch(batch)):
+                nside = int(self.beamtransfer.ndof(mi))
+                evf = np.zeros(nside)
+                if res[0].size:
+                    evf[-res[0].size :] = res[0]
+                full[mi] = evf
+                done.add(mi)
                 # written in the background while the next batch is computed
-                storage.submit(self._save, mi, *res, int(self.beamtransfer.ndof(mi)))
+                storage.submit(self._save, mi, *res, nside)
+
+    def generate(self, regen=False):
+        """KL-transform every m of this rank and save (kltransform.py:480-513); m already done by `generate_ms` during
+        beam-transfer generation are skipped."""
+        st = time.time()
+        if regen:
+            self.__dict__.pop("_done", None)
+        self.generate_ms(self.beamtransfer._my_ms(), regen)
         storage.flush()
         parallel.barrier()
         if parallel.rank0():
@@ -288,6 +315,11 @@ class KLTransform(config.Reader):
 
     def _evfunc(self, mi):
         evf = np.zeros(self.beamtransfer.ndofmax)
+        mem = self.__dict__.get("_evals_full_mem", {}).get(mi)
+        if mem is not None:   # this process made the m: no need to open its file again
+            if mem.size > 0:
+                evf[-mem.size :] = mem
+            return evf
         with storage.File(self._evfile % mi, "r") as f:
             if f["evals_full"].shape[0] > 0:
                 ev = f["evals_full"][:]
@@ -299,7 +331,7 @@ class KLTransform(config.Reader):
         mine = [(mi, self._evfunc(mi)) for mi in self.beamtransfer._my_ms()]
         parts = parallel.gather_objects(mine)
         if parallel.rank0():
-            if os.path.exists(self.evdir + "/evals.hdf5"):
+            if os.path.exists(self.evdir + "/evals.hdf5") or storage.discard():
                 return
             arr = np.zeros((self.telescope.mmax + 1, self.beamtransfer.ndofmax))
             for part in parts:

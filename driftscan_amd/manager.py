@@ -5,7 +5,7 @@ import os
 
 import yaml
 
-from . import beamtransfer, cylinder, doublekl, kltransform, parallel, psestimation
+from . import beamtransfer, cylinder, doublekl, kltransform, parallel, psestimation, storage
 
 logger = logging.getLogger(__name__)
 
@@ -126,11 +126,21 @@ class ProductManager(object):
         if parallel.rank0():
             with open(os.path.join(self.directory, "configdump.yaml"), "w") as fh:
                 yaml.dump(self.config, fh)
+        # manager.py:278-305 runs the stages one after the other through the files.  Here the KL transforms of a batch of
+        # m run right behind its SVD chain, while the SVD products are resident in HBM (BeamTransfer.generate's
+        # `after_batch`); `klobj.generate()` then only finishes what is left (nothing, unless the beams existed already),
+        # waits for the writers and collects the spectra.
+        kls = list(self.kltransforms.values()) if self.gen_kl else []
         if self.gen_beams:
-            self.beamtransfer.generate(skip_svd=self.skip_svd)
+            def after_batch(ms):
+                for klobj in kls:
+                    klobj.generate_ms(ms)
+
+            self.beamtransfer.generate(skip_svd=self.skip_svd, after_batch=after_batch if (kls and not self.skip_svd) else None)
         if self.gen_kl:
             for klname, klobj in self.kltransforms.items():
                 klobj.generate()
+        storage.trace_mark("beam transfer and KL products generated")
         if self.gen_ps:
             for psname, psobj in self.psestimators.items():
                 if psobj is None:

@@ -18,14 +18,41 @@ def _dist():
     return dist if (dist.is_available() and dist.is_initialized()) else None
 
 
+# One rank's SHARE of an N-rank job in a single process (no process group): partitions are those of rank r of N, the
+# gathers and reductions see this rank's part only (rank 0 writes the collected files from what it has).  m-blocks
+# are independent and the path has no data-path collective, so the share's wall time is the N-rank job's —
+# `bench.py --workload configs2 --share r/N` measures the north-star job this way on a one-GPU box.
+_virtual = None
+
+
+def set_virtual(r=None, n=None):
+    """Emulate rank `r` of `n` (None: off).  Also read from DRIFT_VIRTUAL_RANK / DRIFT_VIRTUAL_SIZE."""
+    global _virtual
+    _virtual = None if r is None else (int(r), int(n))
+
+
+def _virt():
+    if _virtual is not None:
+        return _virtual
+    if "DRIFT_VIRTUAL_SIZE" in os.environ:
+        return int(os.environ.get("DRIFT_VIRTUAL_RANK", "0")), int(os.environ["DRIFT_VIRTUAL_SIZE"])
+    return None
+
+
 def rank():
     d = _dist()
-    return d.get_rank() if d else 0
+    if d:
+        return d.get_rank()
+    v = _virt()
+    return v[0] if v else 0
 
 
 def size():
     d = _dist()
-    return d.get_world_size() if d else 1
+    if d:
+        return d.get_world_size()
+    v = _virt()
+    return v[1] if v else 1
 
 
 def rank0():

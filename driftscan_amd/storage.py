@@ -93,7 +93,7 @@ def load_driftio():
 
 def backend():
     forced = os.environ.get("DRIFTMI_STORAGE", "").lower()
-    if forced == "npz":
+    if forced in ("npz", "discard"):
         return "npz"
     if forced == "hdf5":
         if HAVE_H5PY:
@@ -538,6 +538,12 @@ class _H5pyTmp(object):
 def File(path, mode="r", **kwargs):
     """Open a product file.  Existing files are opened by what they ARE (HDF5 or npz); new files are written
     with the configured back-end."""
+    trace = os.environ.get("DRIFTMI_TRACE_OPEN")   # debugging / test aid: one "mode path" line per open
+    if trace and (mode == "w" or os.path.exists(path)):
+        with open(trace, "a") as fh:
+            fh.write("%s %s\n" % (mode, path))
+    if discard() and mode == "w":
+        raise IOError("DRIFTMI_STORAGE=discard: %s would be written" % path)
     if mode in ("r", "r+", "a") and os.path.exists(path):
         if _is_hdf5(path):
             if HAVE_H5PY:
@@ -552,6 +558,14 @@ def File(path, mode="r", **kwargs):
     if be == "driftio":
         return DriftioFile(path, mode)
     return NpzFile(path, mode)
+
+
+def trace_mark(text):
+    """A marker line in the DRIFTMI_TRACE_OPEN file (test aid: "which files were opened before this point")."""
+    trace = os.environ.get("DRIFTMI_TRACE_OPEN")
+    if trace:
+        with open(trace, "a") as fh:
+            fh.write("# %s\n" % text)
 
 
 def compression_kwargs(chunks):
@@ -569,9 +583,18 @@ _pending = []
 _plock = threading.Lock()   # submit() may be called from several driver threads (bench --streams)
 
 
+def discard():
+    """``DRIFTMI_STORAGE=discard``: products are computed and left in HBM, no file is written (and none can be read
+    back).  For measuring the compute part of a job on its own — the boundary of the hot path hands over device
+    buffers; `bench.py --workload configs2` times the job both ways and reports the difference as file output."""
+    return os.environ.get("DRIFTMI_STORAGE", "").lower() == "discard"
+
+
 def submit(fn, *args):
     """Run ``fn(*args)`` (a closure that writes one file) on the writer pool."""
     global _pool
+    if discard():
+        return
     nthreads = int(os.environ.get("DRIFTMI_IO_THREADS", "8"))
     if nthreads <= 0:
         fn(*args)

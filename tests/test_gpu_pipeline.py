@@ -385,8 +385,9 @@ dist.destroy_process_group()
 
 def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     """ProductManager.generate() with two ranks (gloo between the processes, both on this GPU, sharing the
-    output directory as MPI ranks of the reference do) against the single-process run: m-sharded BT-gen
-    (contiguous ranges), cost-balanced SVD / KL, gathered spectra, all-reduced Fisher matrix."""
+    output directory as MPI ranks of the reference do) against the single-process run: every rank takes ONE contiguous,
+    cost-balanced range of m through BT-gen -> SVD -> KL while the blocks are resident, gathered spectra, all-reduced
+    Fisher matrix.  The beam_m files of the two runs are byte-identical and no rank reads one back."""
     import socket
     import subprocess
     import sys
@@ -422,11 +423,23 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     script = tmp_path / "rank.py"
     script.write_text(_RANK_SCRIPT % dict(root=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), port=port,
                                           cfile=str(c2)))
-    env = dict(os.environ, DRIFTMI_DEVICE="0", DRIFTMI_WORKSPACE_GB="2")
+    trace = tmp_path / "opens.txt"
+    env = dict(os.environ, DRIFTMI_DEVICE="0", DRIFTMI_WORKSPACE_GB="2", DRIFTMI_TRACE_OPEN=str(trace))
     procs = [subprocess.Popen([sys.executable, str(script), str(r)], env=env, stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+    # the blocks of a rank go from generation through the SVD chain to the KL stage while they are resident: no beam_m
+    # file and no svd file is opened for reading before every product of the run has been written
+    lines = trace.read_text().splitlines()
+    first_ps = next(i for i, l in enumerate(lines) if l.startswith("#"))   # both ranks are past the KL barrier here
+    opens = [l.split(" ", 1) for l in lines if not l.startswith("#")]
+    first_ps -= sum(1 for l in lines[:first_ps] if l.startswith("#"))
+    assert any(mode == "w" and "/beam_m/" in path for mode, path in opens)
+    assert any(mode == "w" and path.endswith("beam.hdf5") for mode, path in opens)
+    assert not [path for mode, path in opens[:first_ps] if mode != "w" and "/beam_m/" in path]   # neither beam nor svd files
+    assert not [path for mode, path in opens if mode != "w" and path.endswith("beam.hdf5")]
 
     t, bt1 = pm.telescope, pm.beamtransfer
     one, two = str(tmp_path / "one"), str(tmp_path / "two")

@@ -186,3 +186,26 @@ def test_partition_contiguous_balances_cost():
     # more ranks than items: everybody gets at most one, nothing is lost
     parts = [parallel.partition_contiguous([7, 8, 9], [1, 1, 1], n=5, r=r) for r in range(5)]
     assert sorted(sum(parts, [])) == [7, 8, 9] and max(len(p) for p in parts) == 1
+
+
+def test_virtual_rank_share():
+    """`parallel.set_virtual(r, n)`: a single process sees the partitions of rank r of n (what `bench.py --share r/n`
+    uses to time one GPU's share of the north-star job through the product classes); collectives keep to this rank."""
+    from driftscan_amd import parallel
+
+    items = list(range(129))
+    costs = [130.0 - m for m in items]
+    try:
+        for n in (2, 8):
+            parts = []
+            for r in range(n):
+                parallel.set_virtual(r, n)
+                assert (parallel.rank(), parallel.size(), parallel.rank0()) == (r, n, r == 0)
+                parts.append(parallel.partition_contiguous(items, costs))
+                assert parts[-1] == parallel.partition_contiguous(items, costs, n=n, r=r)
+                assert parallel.gather_objects("x") == ["x"]
+                assert np.array_equal(parallel.allreduce_sum(np.arange(3.0)), np.arange(3.0))
+            assert sum(parts, []) == items
+    finally:
+        parallel.set_virtual(None)
+    assert (parallel.rank(), parallel.size()) == (0, 1)
