@@ -54,7 +54,16 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--prime-passes", type=int, default=10,
                     help="untimed passes of the hot path before the warm-up steps (settles a fresh box; 0 to skip)")
-    ap.add_argument("--mode", choices=["weak", "sharded"], default="weak")
+    ap.add_argument("--mode", choices=["weak", "sharded"], default=None,
+                    help="default: weak at --gpus 1 (one full workload), sharded at --gpus N > 1 (ONE workload in m-ranges)")
+    ap.add_argument("--workload", choices=["configs1", "configs2", "configs3"], default="configs1",
+                    help="configs1 = BASELINE configs[1] (the default line); configs2 / configs3 = the north-star job "
+                         "(128-feed polarised cylinder, nfreq 64, lmax 512; configs3 adds DoubleKL + the exact Fisher matrix) "
+                         "through ProductManager.generate(): one rank's share of the 8-GPU job on this GPU")
+    ap.add_argument("--share", default="0/8", help="--workload configs2|configs3: which rank's share, as r/N")
+    ap.add_argument("--files", action="store_true",
+                    help="--workload configs2|configs3: write the product files (default: products stay in HBM)")
+    ap.add_argument("--share-mmax", type=int, default=None, help=argparse.SUPPRESS)  # any value: toy telescope (rehearsal)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo + --one-gpu rehearses the multi-rank path on a single card (RCCL refuses two ranks per GPU)")
     ap.add_argument("--one-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal on a one-GPU box)")
@@ -347,11 +356,113 @@ def stage_work(tel, bt, ms):
     return WA, WB, WC
 
 
+CFG3 = dict(num_freq=64, freq_start=400.0, freq_end=500.0, freq_mode="edge", num_cylinders=4, cylinder_width=12.0,
+            num_feeds=16, feed_spacing=0.4, tsys=1.0, force_lmax=512, force_mmax=512)
+
+
+def run_share(args):
+    """BASELINE configs[2] / configs[3] — the north-star job — through ProductManager.generate(): rank r of N is
+    emulated in this process (`parallel.set_virtual`: its contiguous, cost-balanced range of m; no process group), so
+    the share's wall time is the N-GPU job's (m-blocks are independent, the only collective is the all-reduce of the
+    Fisher matrix at the very end).  Without --files the products stay in HBM (DRIFTMI_STORAGE=discard); with --files
+    they go through the writer pool to a temporary directory and the difference is the file output."""
+    import tempfile
+
+    import numpy as np
+    import torch
+    import yaml
+
+    r, n = (int(x) for x in args.share.split("/"))
+    if not args.files:
+        os.environ["DRIFTMI_STORAGE"] = "discard"
+    os.environ.setdefault("DRIFTMI_WORKSPACE_GB", "80")
+    from driftscan_amd import device, manager, parallel
+
+    parallel.set_virtual(r, n)
+    tcfg = dict(CFG3, type="PolarisedCylinder")
+    if args.share_mmax:   # rehearsal of the mode on a toy telescope (tests, CPU-sized boxes)
+        tcfg = dict(type="PolarisedCylinder", num_freq=4, freq_start=400.0, freq_end=440.0, freq_mode="edge", num_cylinders=2,
+                    cylinder_width=2.0, num_feeds=4, feed_spacing=0.4, tsys=1.0)
+    kls = [dict(type="KLTransform", name="kl", threshold=0.1)]
+    conf = dict(config=dict(beamtransfers=True, kltransform=True, psfisher=False, truncate=False,
+                            beam_chunk_gb=float(os.environ.get("DRIFT_BENCH_BEAM_GB", "125")),
+                            device_chunk_gb=float(os.environ.get("DRIFT_BENCH_BT_GB", "48")),
+                            svd_chunk_gb=float(os.environ.get("DRIFT_BENCH_SVD_GB", "16")), keep_products_gb=0.0),
+                telescope=tcfg, kltransform=kls)
+    if args.workload == "configs3":
+        kls.append(dict(type="DoubleKL", name="dk", threshold=0.1, foreground_threshold=100.0))
+        conf["config"]["psfisher"] = True
+        conf["psfisher"] = [dict(type="Full", name="ps", klname="kl", threshold=0.1, bandtype="polar", num_theta=3,
+                                 k_bands=[dict(spacing="linear", start=0.0, stop=0.25, num=4)])]
+    ctx = device.get_context(workspace_bytes=int(os.environ["DRIFTMI_WORKSPACE_GB"]) << 30)
+    with tempfile.TemporaryDirectory() as tmp:
+        conf["config"]["output_directory"] = os.path.join(tmp, "prod")
+        cfile = os.path.join(tmp, "params.yaml")
+        with open(cfile, "w") as fh:
+            yaml.dump(conf, fh)
+        pm = manager.ProductManager.from_config(cfile)
+        tel, bt = pm.telescope, pm.beamtransfer
+        mine = bt._my_ms()
+        # the host-side C_l(nu, nu') tables are made once per job (cora's models in the reference): untimed
+        t0 = time.perf_counter()
+        for kl in pm.kltransforms.values():
+            kl.signal(); kl.foreground()
+        t_cl = time.perf_counter() - t0
+        ctx.prof_reset(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pm.generate()
+        ctx.sync()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        pr = ctx.prof_report()
+        nbytes = 0
+        if args.files:
+            for root, _, files in os.walk(conf["config"]["output_directory"]):
+                nbytes += sum(os.path.getsize(os.path.join(root, f)) for f in files)
+        nm = tel.mmax + 1
+        line = {
+            "metric": "m-blocks/sec (BT-gen + SVD + KL)",
+            "value": len(mine) / dt,
+            "unit": "m-blocks/s",
+            "n_gpus": 1, "steps": 1, "warmup": 0,
+            "ms_per_step": 1e3 * dt,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: share %d/%d of the %s job (nfreq=%d, nbase=%d, lmax=mmax=%d) "
+                                   "through ProductManager.generate(): m = %d..%d (%d of %d m-blocks), %s%s"
+                                   % ("configs[2]" if args.workload == "configs2" else "configs[3]", r, n,
+                                      "toy-telescope REHEARSAL" if args.share_mmax else "128-feed polarised cylinder", tel.nfreq,
+                                      tel.nbase, tel.lmax,
+                                      mine[0], mine[-1], len(mine), nm, "KLTransform" if args.workload == "configs2"
+                                      else "KLTransform + DoubleKL + PSExact (9 polar bands)",
+                                      ", product files written" if args.files else ", products left in HBM (no files)"),
+                       "nfreq": tel.nfreq, "nbase": tel.nbase, "lmax": tel.lmax, "mmax": tel.mmax, "share": args.share,
+                       "files": bool(args.files)},
+            "share_s": dt,
+            "projected_job_s": dt,
+            "projected_job_note": "m-blocks are independent and rank %d of %d has the most expensive range (lowest m): its "
+                                  "share is the wall time of the %d-GPU job; C_l tables %.1f s (host, once per job) not included"
+                                  % (r, n, n, t_cl),
+            "job_m_blocks_per_s": nm / dt,
+            "file_bytes": nbytes,
+            "kernels_ms": {k: v["ms"] for k, v in pr.items()},
+            "hbm_peak_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "roofline": None, "cpu_baseline": None,
+        }
+        print(json.dumps(line))
+        sys.stdout.flush()
+    return 0
+
+
 def main():
     args = parse_args()
     if args.cpu_worker:
         cpu_worker_main(*args.cpu_worker)
         return 0
+    if args.workload != "configs1":
+        return run_share(args)
+    if args.mode is None:
+        args.mode = "sharded" if args.gpus > 1 else "weak"
     launched = "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not launched:
         # no launcher: start the ranks ourselves, before anything here touches the GPU

@@ -79,7 +79,7 @@ class BeamTransfer(config.Reader):
         self.telescope = telescope
         self._dev = {}  # m -> dict of device tensors kept resident for the KL stage
         self._sv_host = {}  # m -> (nfreq, svd_len) singular values on the host (survive the eviction of _dev)
-        if parallel.rank0() and not os.path.exists(directory):
+        if parallel.io_root() and not os.path.exists(directory):
             os.makedirs(directory)
         parallel.barrier()
         if self.telescope is None:
@@ -182,7 +182,7 @@ class BeamTransfer(config.Reader):
         writer pool; nothing is read back from a file during generation."""
         st = time.time()
         self._generate_dirs()
-        if parallel.rank0() and not storage.discard():
+        if parallel.io_root() and not storage.discard():
             with open(self._picklefile, "wb") as f:
                 pickle.dump(self.telescope, f)
         tel = self.telescope
@@ -231,7 +231,7 @@ class BeamTransfer(config.Reader):
     generate_cache = generate  # beamtransfer.py: old name kept by the reference
 
     def _generate_dirs(self):
-        if parallel.rank0():
+        if parallel.io_root():
             os.makedirs(self.directory, exist_ok=True)
             for mi in range(self.telescope.mmax + 1):
                 os.makedirs(self._mdir(mi), exist_ok=True)

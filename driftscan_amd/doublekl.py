@@ -148,6 +148,14 @@ class DoubleKL(kltransform.KLTransform):
 
         def evfunc(mi):
             ta = np.zeros((2, nd))
+            mem = self.__dict__.get("_evals_full_mem", {}).get(mi)
+            if mem is not None:   # this process made the m: no need to open its file again
+                fev = self.__dict__["_extra_mem"][mi]["f_evals"]
+                fev = np.asarray(fev.cpu().numpy() if hasattr(fev, "cpu") else fev)
+                if mem.size > 0:
+                    ta[0, -mem.size :] = mem
+                    ta[1, -fev.size :] = fev
+                return ta
             with storage.File(self._evfile % mi, "r") as f:
                 if f["evals_full"].shape[0] > 0:
                     ev, fev = f["evals_full"][:], f["f_evals"][:]
@@ -159,7 +167,7 @@ class DoubleKL(kltransform.KLTransform):
         parts = parallel.gather_objects(mine)
         if parallel.rank0():
             fname = self.evdir + "/evals.hdf5"
-            if os.path.exists(fname):
+            if os.path.exists(fname) or storage.discard():
                 return
             arr = np.zeros((self.telescope.mmax + 1, 2, nd))
             for part in parts:

@@ -60,7 +60,7 @@ class KLTransform(config.Reader):
         self.telescope = bt.telescope
         subdir = "ev" if subdir is None else subdir
         self.evdir = bt.directory + "/" + subdir
-        if parallel.rank0() and not os.path.exists(self.evdir):
+        if parallel.io_root() and not os.path.exists(self.evdir):
             os.makedirs(self.evdir)
         parallel.barrier()
 
@@ -273,27 +273,24 @@ class KLTransform(config.Reader):
         done = self.__dict__.setdefault("_done", set())
         full = self.__dict__.setdefault("_evals_full_mem", {})
         todo = [mi for mi in ms if mi not in done and (regen or not os.path.exists(self._evfile % mi))]
+        cache = self.__dict__.get("_mode_cache")   # set by whoever wants the modes of the batch right away (PS estimation)
         for batch in self._batches(todo):
-            if storage.discard():
-                res = self._transform_batch(batch, to_host=False)   # products stay in HBM, no file
-                for mi, r in zip(batch, res):
-                    nside = int(self.beamtransfer.ndof(mi))
-                    evf = np.zeros(nside)
-                    ev = r[0].cpu().numpy()
-                    if ev.size:
-                        evf[-ev.size :] = ev
-                    full[mi] = evf
-                    done.add(mi)
-                continue
-            for mi, res in zip(batch, self._transform_batch(batch)):
+            to_host = cache is not None or not storage.discard()   # discard mode: products stay in HBM, no file
+            for mi, res in zip(batch, self._transform_batch(batch, to_host=to_host)):
                 nside = int(self.beamtransfer.ndof(mi))
                 evf = np.zeros(nside)
-                if res[0].size:
-                    evf[-res[0].size :] = res[0]
+                ev = res[0] if isinstance(res[0], np.ndarray) else res[0].cpu().numpy()
+                if ev.size:
+                    evf[-ev.size :] = ev
                 full[mi] = evf
+                self.__dict__.setdefault("_extra_mem", {})[mi] = res[3]
                 done.add(mi)
+                if cache is not None:
+                    i_ev = int(np.searchsorted(ev, self.threshold)) if self.subset else 0
+                    cache[mi] = (ev[i_ev:], res[1][i_ev:]) if ev.size else (ev, res[1])
                 # written in the background while the next batch is computed
-                storage.submit(self._save, mi, *res, nside)
+                if not storage.discard():
+                    storage.submit(self._save, mi, *res, nside)
 
     def generate(self, regen=False):
         """KL-transform every m of this rank and save (kltransform.py:480-513); m already done by `generate_ms` during
@@ -345,6 +342,15 @@ class KLTransform(config.Reader):
 
     @util.cache_last
     def modes_m(self, mi, threshold=None):
+        mc = self.__dict__.get("_mode_cache")
+        if mc is not None and mi in mc:   # modes of the batch in flight (generate_ms), exactly what the file will hold
+            evals, evecs = mc[mi]
+            if evals.shape[0] == 0:
+                return None, None
+            startind = np.searchsorted(evals, threshold) if threshold is not None else 0
+            if startind == evals.size:
+                return None, None
+            return evals[startind:], evecs[startind:]
         if not os.path.exists(self._evfile % mi):
             return self.transform_save(mi)
         with storage.File(self._evfile % mi, "r") as f:

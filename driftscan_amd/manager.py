@@ -57,7 +57,7 @@ class ProductManager(object):
             yconf = yaml.safe_load(f)
         outdir = yconf["config"]["output_directory"]
         dfile = os.path.join(outdir, "config.yaml")
-        if parallel.rank0():
+        if parallel.io_root():
             if not os.path.isabs(outdir):
                 outdir_abs = os.path.abspath(os.path.normpath(os.path.join(os.path.dirname(configfile), outdir)))
             else:
@@ -123,7 +123,7 @@ class ProductManager(object):
 
     def generate(self):
         os.makedirs(self.directory, exist_ok=True)
-        if parallel.rank0():
+        if parallel.io_root():
             with open(os.path.join(self.directory, "configdump.yaml"), "w") as fh:
                 yaml.dump(self.config, fh)
         # manager.py:278-305 runs the stages one after the other through the files.  Here the KL transforms of a batch of
@@ -131,15 +131,26 @@ class ProductManager(object):
         # `after_batch`); `klobj.generate()` then only finishes what is left (nothing, unless the beams existed already),
         # waits for the writers and collects the spectra.
         kls = list(self.kltransforms.values()) if self.gen_kl else []
+        pss = [p for p in self.psestimators.values() if p is not None] if (self.gen_ps and self.gen_kl) else []
         if self.gen_beams:
+            for psobj in pss:   # the estimators take the modes of a batch from memory, right behind its KL transform
+                psobj.kltrans.__dict__.setdefault("_mode_cache", {})
+
             def after_batch(ms):
                 for klobj in kls:
                     klobj.generate_ms(ms)
+                for psobj in pss:
+                    psobj.accumulate_ms(ms)
+                for klobj in kls:
+                    if "_mode_cache" in klobj.__dict__:
+                        klobj.__dict__["_mode_cache"].clear()
 
             self.beamtransfer.generate(skip_svd=self.skip_svd, after_batch=after_batch if (kls and not self.skip_svd) else None)
         if self.gen_kl:
             for klname, klobj in self.kltransforms.items():
                 klobj.generate()
+        for klobj in kls:
+            klobj.__dict__.pop("_mode_cache", None)
         storage.trace_mark("beam transfer and KL products generated")
         if self.gen_ps:
             for psname, psobj in self.psestimators.items():

@@ -59,6 +59,12 @@ def rank0():
     return rank() == 0
 
 
+def io_root():
+    """The process that creates the shared directories and the configuration copies: rank 0 of a process group — or
+    this process when it emulates a share on its own (`set_virtual`: there is nobody else to do it)."""
+    return rank0() or _dist() is None
+
+
 def barrier():
     d = _dist()
     if d:

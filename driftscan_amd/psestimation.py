@@ -92,7 +92,7 @@ class PSEstimation(config.Reader):
         self.kltrans = kltrans
         self.telescope = kltrans.telescope
         self.psdir = self.kltrans.evdir + "/" + subdir + "/"
-        if parallel.rank0() and not os.path.exists(self.psdir):
+        if parallel.io_root() and not os.path.exists(self.psdir):
             os.makedirs(self.psdir)
         parallel.barrier()
 
@@ -164,6 +164,21 @@ class PSEstimation(config.Reader):
         if cur:
             yield cur
 
+    def accumulate_ms(self, ms):
+        """Add the Fisher matrix / bias of the given m (of this rank) to the local sums: the per-batch step that
+        `ProductManager.generate` runs right behind the KL transform of those m, while their SVD products are resident
+        and their modes are in the KL object's mode cache.  `generate` finishes the rest and does the all-reduce."""
+        if self.clarray is None:
+            self.genbands()
+        acc = self.__dict__.setdefault("_acc", dict(fisher=np.zeros((self.nbands, self.nbands)), bias=np.zeros(self.nbands),
+                                                    done=set()))
+        todo = [mi for mi in ms if mi not in acc["done"]]
+        for batch in self._batches(todo):
+            for f, b in self.fisher_bias_batch(batch):
+                acc["fisher"] += f.real
+                acc["bias"] += b.real
+            acc["done"].update(batch)
+
     # ---- total Fisher (psestimation.py:463-560) ----------------------------------------------------
     def generate(self, regen=False):
         st = time.time()
@@ -173,11 +188,18 @@ class PSEstimation(config.Reader):
             return
         parallel.barrier()
         self.genbands()
-        ms = parallel.partition(list(range(self.telescope.mmax + 1)),
-                                costs=[float(self.kltrans.beamtransfer.ndof(mi)) ** 3 + 1.0 for mi in
-                                       range(self.telescope.mmax + 1)])
+        acc = self.__dict__.pop("_acc", None)
         fisher_loc = np.zeros((self.nbands, self.nbands), dtype=np.float64)
         bias_loc = np.zeros(self.nbands, dtype=np.float64)
+        if acc is not None:
+            # the resident pipeline has done (some of) this rank's own m already: keep to its partition
+            fisher_loc += acc["fisher"]
+            bias_loc += acc["bias"]
+            ms = [mi for mi in self.kltrans.beamtransfer._my_ms() if mi not in acc["done"]]
+        else:
+            ms = parallel.partition(list(range(self.telescope.mmax + 1)),
+                                    costs=[float(self.kltrans.beamtransfer.ndof(mi)) ** 3 + 1.0 for mi in
+                                           range(self.telescope.mmax + 1)])
         for batch in self._batches(ms):
             for f, b in self.fisher_bias_batch(batch):
                 fisher_loc += f.real  # "be careful of the .real here" (psestimation.py:497-502)
@@ -196,6 +218,9 @@ class PSEstimation(config.Reader):
                 cv = np.zeros_like(self.fisher)
                 err = cv.diagonal()
                 cr = np.zeros_like(self.fisher)
+            if storage.discard():
+                parallel.barrier()
+                return
             with storage.File(ffile, "w") as f:
                 f.attrs["bandtype"] = np.bytes_(self.bandtype)
                 f.create_dataset("fisher", data=self.fisher)
