@@ -599,15 +599,19 @@ def submit(fn, *args):
     if nthreads <= 0:
         fn(*args)
         return
+    # bound the host memory held by queued products: by count and by bytes (a configs[2] m-block is 1.8 GB of beam_m
+    # and 2.6 GB of SVD products: thirty-two of them queued would be most of a host's memory)
+    nbytes = sum(int(a.nbytes) for a in args if isinstance(a, np.ndarray))
+    cap = float(os.environ.get("DRIFTMI_IO_PENDING_GB", "8")) * (1 << 30)
     with _plock:
         if _pool is None:
             from concurrent.futures import ThreadPoolExecutor
 
             _pool = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="driftmi-io")
         wait = []
-        while len(_pending) >= 4 * nthreads:   # bound the host memory held by queued products
-            wait.append(_pending.pop(0))
-        _pending.append(_pool.submit(fn, *args))
+        while _pending and (len(_pending) >= 4 * nthreads or sum(b for _, b in _pending) + nbytes > cap):
+            wait.append(_pending.pop(0)[0])
+        _pending.append((_pool.submit(fn, *args), nbytes))
     for w in wait:
         w.result()
 
@@ -618,7 +622,7 @@ def flush():
         with _plock:
             if not _pending:
                 return
-            w = _pending.pop(0)
+            w = _pending.pop(0)[0]
         w.result()
 
 
