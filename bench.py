@@ -387,7 +387,7 @@ def run_share(args):
     conf = dict(config=dict(beamtransfers=True, kltransform=True, psfisher=False, truncate=False,
                             beam_chunk_gb=float(os.environ.get("DRIFT_BENCH_BEAM_GB", "125")),
                             device_chunk_gb=float(os.environ.get("DRIFT_BENCH_BT_GB", "48")),
-                            svd_chunk_gb=float(os.environ.get("DRIFT_BENCH_SVD_GB", "16")), keep_products_gb=0.0),
+                            svd_chunk_gb=float(os.environ.get("DRIFT_BENCH_SVD_GB", "48")), keep_products_gb=0.0),
                 telescope=tcfg, kltransform=kls)
     if args.workload == "configs3":
         kls.append(dict(type="DoubleKL", name="dk", threshold=0.1, foreground_threshold=100.0))
