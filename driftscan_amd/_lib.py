@@ -592,7 +592,8 @@ Context.bt_sht = _bt_sht
 
 
 PROF_CLASSES = ["zgemm_grouped", "gemm_grouped_realB", "jac_gram", "jac_inner", "jac_apply", "dgemm_grouped",
-                "trd_symv", "trd_wx"]  # the last two report algorithmic BYTES in the "flops" field (HBM-bound kernels)
+                "trd_symv", "trd_wx",  # these two report algorithmic BYTES in the "flops" field (HBM-bound kernels)
+                "sb_panel_qr", "sb_chase", "sb_q2_apply", "unused"]  # two-stage tridiagonalisation (fp64 VALU)
 
 
 def _prof_reset(self, enable=True):
@@ -600,9 +601,9 @@ def _prof_reset(self, enable=True):
 
 
 def _prof_report(self):
-    ms = (c_dbl * 8)()
-    fl = (c_dbl * 8)()
-    ln = (ctypes.c_longlong * 8)()
+    ms = (c_dbl * 12)()
+    fl = (c_dbl * 12)()
+    ln = (ctypes.c_longlong * 12)()
     self.check(self.lib.dm_prof_report(self.h, ms, fl, ln), "dm_prof_report")
     return {name: dict(ms=ms[i], flops=fl[i], launches=int(ln[i])) for i, name in enumerate(PROF_CLASSES) if ln[i] > 0}
 

@@ -51,7 +51,9 @@ constexpr int DM_PROF_SMALL_STRIDE = 4;
 constexpr double DM_PROF_BIG = 2.0e9;
 // classes 0-5 carry algorithmic FLOPs, 6-7 (the HBM-bound tridiagonalisation kernels) algorithmic BYTES
 enum { DM_PROF_GEMM = 0, DM_PROF_GEMM_REAL = 1, DM_PROF_JAC_GRAM = 2, DM_PROF_JAC_INNER = 3, DM_PROF_JAC_APPLY = 4,
-       DM_PROF_DGEMM = 5, DM_PROF_TRD_SYMV = 6, DM_PROF_TRD_WX = 7, DM_PROF_NCLASS = 8 };
+       DM_PROF_DGEMM = 5, DM_PROF_TRD_SYMV = 6, DM_PROF_TRD_WX = 7,
+       // the two-stage tridiagonalisation (dm_sbr_impl.h): fp64 VALU kernels, algorithmic FLOPs
+       DM_PROF_SB_PANEL = 8, DM_PROF_SB_CHASE = 9, DM_PROF_SB_Q2 = 10, DM_PROF_NCLASS = 12 };
 
 hipEvent_t dm_prof_event(dm_ctx* ctx);
 // bracket one launch: DM_PROF(ctx, cls, flops) { launch; }

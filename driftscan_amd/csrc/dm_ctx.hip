@@ -149,7 +149,7 @@ int dm_prof_reset(dm_ctx* ctx, int enable) {
   return DM_OK;
 }
 
-// ms[c], flops[c], launches[c] for c < DM_PROF_NCLASS (= 8): summed event time, algorithmic
+// ms[c], flops[c], launches[c] for c < DM_PROF_NCLASS (= 12): summed event time, algorithmic
 // flops and launch count of each kernel class since dm_prof_reset.
 int dm_prof_trd_stride(void) { return DM_PROF_TRD_STRIDE; }
 

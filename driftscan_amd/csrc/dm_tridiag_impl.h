@@ -1850,6 +1850,12 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       static const bool nofuse = getenv("DM_SB_NOFUSE") != nullptr;
       if (cmax - i0 <= SFR * SFT && !nofuse) {
         // panels that fit the registers of one workgroup per matrix: the whole QR in one launch
+        double fl = 0.0;  // Householder QR of an m x SB panel: 2 SB^2 (m - SB / 3) complex multiply-adds
+        for (int p : ch) {
+          const double m = probs[p].n - i0;
+          if (m >= 2) fl += 8.0 * 2.0 * SB * SB * std::max(m - SB / 3.0, 1.0);
+        }
+        dm_prof_scope ps(ctx, DM_PROF_SB_PANEL, fl);
         hipLaunchKernelGGL(sb_panel_fused_kernel, dim3(nc), dim3(SFT), 0, ctx->stream, d_sm, k0, a0);
       } else {
         hipLaunchKernelGGL(sb_panel_load_kernel, dim3((cmax - a0 + 255) / 256, nc), dim3(256), 0, ctx->stream, d_sm, k0, a0);
@@ -2051,8 +2057,17 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
         DM_TRY(dm_fill_zero(ctx, ctl.dbg, sizeof(unsigned long long) * (2 * (size_t)cmax + 2)));
       }
       const int nwg = 256;  // one per CU: a matrix is served by the workgroups of ONE XCD, whichever claims it first
-      if (pairs) hipLaunchKernelGGL((sb_chase2_kernel<NP>), dim3(nwg), dim3(128 * NP), 0, ctx->stream, d_cmat, ctl);
-      else hipLaunchKernelGGL((sb_chase_kernel<NW>), dim3(nwg), dim3(64 * NW), 0, ctx->stream, d_cmat, ctl);
+      {
+        // one task = E <- H^H (E H) and the two-sided update of the Hermitian D: ~6 SB^2 complex multiply-adds
+        double fl = 0.0;
+        for (int i = 0; i < nc; ++i) {
+          const double n = cm[i].n;
+          fl += 8.0 * 6.0 * SB * SB * (n * n / (2.0 * SB));
+        }
+        dm_prof_scope ps(ctx, DM_PROF_SB_CHASE, fl);
+        if (pairs) hipLaunchKernelGGL((sb_chase2_kernel<NP>), dim3(nwg), dim3(128 * NP), 0, ctx->stream, d_cmat, ctl);
+        else hipLaunchKernelGGL((sb_chase_kernel<NW>), dim3(nwg), dim3(64 * NW), 0, ctx->stream, d_cmat, ctl);
+      }
       {
         int herr = 0;  // (the eigenvalue selection synchronises right after this stage anyway)
         DM_TRY(dm_download(ctx, &herr, sbNext + 2 * (size_t)np + 8, sizeof(int)));
@@ -2106,6 +2121,9 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr = true;
     }
+    double fl = 0.0;  // n^2 / (2 SB) reflectors of length SB on ncol columns: 2 SB complex multiply-adds per column each
+    for (const auto& q : qm) fl += 8.0 * (double)q.n * q.n * q.ncol;
+    dm_prof_scope ps(ctx, DM_PROF_SB_Q2, fl);
     hipLaunchKernelGGL((sb_q2_apply_kernel<NW>), dim3((unsigned)wgs.size()), dim3(64 * NW), lds, ctx->stream, d_qm, d_wgs);
     DM_HIP(ctx, hipGetLastError());
     return DM_OK;

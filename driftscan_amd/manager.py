@@ -121,6 +121,14 @@ class ProductManager(object):
             else:
                 self.psestimators[psname] = psclass.from_config(psentry, self.kltransforms[klname], subdir=psname)
 
+        if self.gen_kl and self.kltransforms and "kl_cost_weight" not in yconf["config"]:
+            # the cost of an m-block downstream of the SVD chain, for the m-ranges of the ranks: a DoubleKL is two
+            # eigenproblems plus, at low m, the non-positive-definite rescue; a Fisher estimator projects every band
+            w = sum(0.625 if isinstance(k, doublekl.DoubleKL) else 0.25 for k in self.kltransforms.values())
+            if self.gen_ps:
+                w += 0.125 * sum(1 for p in self.psestimators.values() if p is not None)
+            self.beamtransfer.kl_cost_weight = float(w)
+
     def generate(self):
         os.makedirs(self.directory, exist_ok=True)
         if parallel.io_root():
@@ -132,11 +140,7 @@ class ProductManager(object):
         # waits for the writers and collects the spectra.
         kls = list(self.kltransforms.values()) if self.gen_kl else []
         pss = [p for p in self.psestimators.values() if p is not None] if (self.gen_ps and self.gen_kl) else []
-        if kls and "kl_cost_weight" not in self.config.get("config", {}):
-            # the cost of an m-block downstream of the SVD chain, for the m-ranges of the ranks: a DoubleKL is two
-            # eigenproblems plus, at low m, the non-positive-definite rescue; a Fisher estimator projects every band
-            w = sum(0.625 if isinstance(k, doublekl.DoubleKL) else 0.25 for k in kls) + 0.125 * len(pss)
-            self.beamtransfer.kl_cost_weight = float(w)
+
         if self.gen_beams:
             for psobj in pss:   # the estimators take the modes of a batch from memory, right behind its KL transform
                 psobj.kltrans.__dict__.setdefault("_mode_cache", {})

@@ -52,9 +52,11 @@ int dm_prof_trd_stride(void);
 
 /* Per-kernel-class instrumentation for bench.py: when enabled every launch of the
  * MFMA kernels is bracketed by HIP events on the context's stream.  dm_prof_report
- * fills 8-entry arrays (class 0 grouped ZGEMM, 1 real-B GEMM, 2 Jacobi Gram,
- * 3 Jacobi inner solver, 4 Jacobi apply) with summed event time [ms], algorithmic
- * flops actually executed, and launch counts since the last reset. */
+ * fills 12-entry arrays (class 0 grouped ZGEMM, 1 real-B GEMM, 2 Jacobi Gram,
+ * 3 Jacobi inner solver, 4 Jacobi apply, 5 real GEMM of the D&C merges, 6 / 7 the one-stage
+ * tridiagonalisation kernels [algorithmic BYTES], 8 panel QR, 9 bulge chase, 10 second-stage
+ * back-transformation of the two-stage tridiagonalisation, 11 unused) with summed event time [ms],
+ * algorithmic flops actually executed, and launch counts since the last reset. */
 int dm_prof_reset(dm_ctx* ctx, int enable);
 int dm_prof_report(dm_ctx* ctx, double* ms, double* flops, long long* launches);
 

@@ -300,6 +300,31 @@ def ring_dft(maps, nside, mlist, sign=+1):
     return out
 
 
+def ring_dft_fft(maps, nside, mlist, sign=+1):
+    """`ring_dft` with one FFT per ring instead of the explicit twiddle matrix (what a production SHT does; libsharp's
+    ring transforms are FFTs): sum_j f_j exp(s i m (phi0 + 2 pi j / n)) = exp(s i m phi0) * n * ifft(f)[m mod n] for
+    s = +1 (fft for s = -1).  Same result to rounding (tests/test_oracle_btgen.py); used by the CPU baseline of
+    bench.py so that the host figure is not dominated by an O(npix * nm) loop the reference does not have."""
+    z, nphi, phi0, start = ring_info(nside)
+    maps = np.asarray(maps)
+    lead = maps.shape[:-1]
+    mlist = np.asarray(mlist)
+    out = np.zeros((mlist.size, z.size) + lead, dtype=np.complex128)
+    r = 0
+    while r < z.size:   # runs of rings with the same number of pixels (the whole equatorial belt is one run)
+        r1 = r
+        while r1 + 1 < z.size and nphi[r1 + 1] == nphi[r] and start[r1 + 1] == start[r1] + nphi[r1]:
+            r1 += 1
+        n = int(nphi[r])
+        seg = maps[..., start[r] : start[r1] + n].reshape(lead + (r1 - r + 1, n))
+        spec = np.fft.ifft(seg, axis=-1) * n if sign > 0 else np.fft.fft(seg, axis=-1)     # (..., nring_run, n)
+        pick = spec[..., np.mod(mlist, n)]                                                  # (..., nring_run, nm)
+        ph = np.exp(sign * 1j * np.outer(phi0[r : r1 + 1], mlist))                          # (nring_run, nm)
+        out[:, r : r1 + 1] = np.moveaxis(pick * ph, (-2, -1), (1, 0))
+        r = r1 + 1
+    return out
+
+
 def _analysis(maps, nside, lmax, polarised, ms, ring_w=None):
     """c[p, l, m] = sum_pix w f_p Y_lm(pix) for the m in `ms` (the reference's conj(SHT(conj f))); returns
     {m: (P, lmax + 1 - |m|)} with (T, E, B, V) for polarised maps."""
@@ -354,7 +379,7 @@ def _synthesis(coef, nside, lmax, polarised, npol):
     return maps
 
 
-def transfer_single(maps, nside, lmax, lside, polarised, mabs=None, niter=0, ring_w=None):
+def transfer_single(maps, nside, lmax, lside, polarised, mabs=None, niter=0, ring_w=None, fft=False):
     """The reference's ``_transfer_single``: conj(SHT(conj(map))) zero-embedded into
     (P, lside+1, 2*lside+1) with non-centred m (negative m wrapped to the end).
 
@@ -390,7 +415,8 @@ def transfer_single(maps, nside, lmax, lside, polarised, mabs=None, niter=0, rin
     if mabs is not None:
         keep = sorted({int(a) for a in mabs if 0 <= int(a) <= lmax})
         ms = np.array(sorted({-a for a in keep} | set(keep)), dtype=np.int64)
-    G = ring_dft(maps, nside, ms, sign=+1)  # (nm, nring, P): conj-trick turns e^{-im phi} into e^{+im phi}
+    # (nm, nring, P): conj-trick turns e^{-im phi} into e^{+im phi}
+    G = (ring_dft_fft if fft else ring_dft)(maps, nside, ms, sign=+1)
     for mi, m in enumerate(ms):
         am = abs(m)
         lam = lambda_lm(lmax, am, z) * w  # (L-am, nring)
@@ -500,7 +526,7 @@ def beam_transfer_m(tel, mlist=None):
                 t = transfer_single(maps, nside, lmax_bf, lside, pol, niter=int(tel.get("sht_iter", 0)),
                                     ring_w=None if rw is None else rw.get(int(nside)))
             else:
-                t = transfer_single(maps, nside, lmax_bf, lside, pol, mabs=mlist)
+                t = transfer_single(maps, nside, lmax_bf, lside, pol, mabs=mlist, fft=bool(tel.get("sht_fft", False)))
             for m in mlist:
                 out[m][f, 0, b, :, m:] = t[:, m:, m]
                 if m > 0:

@@ -261,6 +261,10 @@ def gen_geometry(ref):
         "cfg3": ("pol", dict(num_freq=64, freq_start=400.0, freq_end=500.0, freq_mode="edge",
                              num_cylinders=4, cylinder_width=12.0, num_feeds=16, feed_spacing=0.4, tsys=1.0,
                              force_lmax=512, force_mmax=512)),
+        # BASELINE configs[4]: CHIME-like stress case; the 512 x 512 feed tables are left out
+        "cfg5": ("pol", dict(num_freq=256, freq_start=400.0, freq_end=800.0, freq_mode="edge",
+                             num_cylinders=4, cylinder_width=14.5, num_feeds=64, feed_spacing=0.3, tsys=1.0,
+                             force_lmax=1024, force_mmax=1024)),
         "skip": ("pol", dict(num_freq=8, freq_start=400.0, freq_end=450.0, freq_mode="edge",
                              num_cylinders=2, cylinder_width=5.0, num_feeds=5, feed_spacing=0.5, tsys=1.0,
                              skip_freq=[0, 3, 4], skip_baselines=[17, 18, 25])),
@@ -281,9 +285,10 @@ def gen_geometry(ref):
         out[name + "_uniquepairs"] = t.uniquepairs
         out[name + "_baselines"] = t.baselines
         out[name + "_redundancy"] = t.redundancy
-        out[name + "_feedmap"] = t.feedmap
-        out[name + "_feedmask"] = t.feedmask
-        out[name + "_feedconj"] = t.feedconj
+        if name != "cfg5":
+            out[name + "_feedmap"] = t.feedmap
+            out[name + "_feedmask"] = t.feedmask
+            out[name + "_feedconj"] = t.feedconj
         out[name + "_frequencies"] = t.frequencies
         out[name + "_wavelengths"] = t.wavelengths
         out[name + "_lmax"] = t.lmax
@@ -795,6 +800,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "projections":
         gen_projections(ref)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "geometry":
+        gen_geometry(ref)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "timestream":
         gen_timestream(ref)

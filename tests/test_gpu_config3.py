@@ -10,9 +10,12 @@ configs[2]  128-feed polarised cylinder (4 x 16 dual-pol feeds), nfreq = 64, lma
             and the whole KL spectrum + kept count against the oracle chain on the same block.
 configs[3]  the same blocks through DoubleKL (foreground_threshold 100, doublekl.py:30-87) and PSExact
             (psestimation.py:672-815), the smallest block against the oracle.
-configs[4]  reduced CHIME-sized stress shapes that fit the test budget: one 3552 x 4100 frequency slice pushed
-            through `svd_chain(max_bytes=...)` (the frequency-sliced path), and `eigh_gen` at n = 8192 (merge
-            nodes of 8192 > 4096: the global-scratch <BIG> divide-and-conquer kernels).
+configs[4]  the CHIME-like telescope itself (4 x 64 dual-pol feeds, nfreq = 256, lmax = mmax = 1024; geometry pinned on
+            the reference): one real m-block (m = 300, 59.6 GB) generated on the device, two (f, b) columns against the
+            oracle at nside 1024, the SVD chain on four of its frequencies through the frequency-sliced path with the
+            chain's properties, singular values / nmodes of one frequency against the oracle chain; plus synthetic
+            CHIME-shaped slices (`svd_chain(max_bytes=...)`) and `eigh_gen` at n = 8192 (merge nodes of 8192 > 4096:
+            the global-scratch <BIG> divide-and-conquer kernels).
 """
 import os
 import sys
@@ -48,7 +51,7 @@ def c3(tmp_path_factory, golden_dir):
     # the geometry itself is pinned bit-exactly against the reference in tests/test_host_geometry.py (`cfg3`)
     geo = np.load(os.path.join(golden_dir, "geometry.npz"))
     assert tel.nbase == 432 and tel.lmax == 512 and tel.mmax == 512 and tel.num_pol_sky == 4
-    assert np.array_equal(tel.baselines, geo["cfg3_baselines"]) if "cfg3_baselines" in geo else True
+    assert np.array_equal(tel.baselines, geo["cfg3_baselines"])
     bt = beamtransfer.BeamTransfer(str(tmp_path_factory.mktemp("c3")), telescope=tel)
     t0 = time.perf_counter()
     blocks = [btgen.beam_m_all(tel, ctx=ctx, max_bytes=24 << 30, m_range=(m, m)) for m in MS]
@@ -159,6 +162,9 @@ def test_smallest_block_against_oracle_chain(c3):
     _log("m 460: ndof %d, KL spectrum vs oracle %.2e of lambda_max (bound %.1e)" % (ev_o.size, err, tol))
     assert_spectrum(ours[0], ev_o, tol, "KL evals m=460")
     i_o, i_g = int(np.searchsorted(ev_o, kl.threshold)), int(np.searchsorted(ours[0], kl.threshold))
+    if i_o != i_g:   # only acceptable when an eigenvalue sits within the tolerance of the cut: say so
+        _log("m 460: kept-mode count %d vs oracle %d — an eigenvalue lies within %.1e lambda_max of the threshold"
+             % (ev_o.size - i_g, ev_o.size - i_o, tol))
     assert i_o == i_g or np.abs(ev_o - kl.threshold).min() < tol * np.abs(ev_o).max()
     assert ours[3]["ac"] == ac_o == 0.0
     c3["cs460"], c3["cn460"] = cs, cn
@@ -232,6 +238,8 @@ def test_doublekl_and_fisher_config4(c3):
     near = np.abs(fev_o - 100.0).min() < tol1 * np.abs(fev_o).max()
     _log("m 460: DoubleKL keeps %d of %d modes past the foreground cut (oracle %d); f_evals error %.2e (bound %.1e)"
          % (ev_g.size, fev_o.size, ev_o.size, np.abs(extra["f_evals"] - fev_o).max() / np.abs(fev_o).max(), tol1))
+    if ev_g.size != ev_o.size:   # only acceptable when an f_eval sits within the tolerance of the foreground cut
+        _log("m 460: DoubleKL kept %d modes, the oracle %d — an f_eval lies within %.1e of the cut" % (ev_g.size, ev_o.size, tol1))
     assert ev_g.size == ev_o.size or near
     if ev_g.size == ev_o.size and ev_o.size:
         assert_spectrum(ev_g, ev_o, max(1e-8, 100 * tol1), "DoubleKL evals m=460")
@@ -346,6 +354,95 @@ def test_config5_svd_slice_frequency_chunks():
         _log("  f %d: n %d  |U U^H - I| %.2e  |U^H w B - beam_svd| %.2e  |beam_svd pinv - I| %.2e" % (f, n, e_orth, e_proj, e_pinv))
         assert e_orth < 1e-12 and e_proj < 1e-11 and e_pinv < 1e-7
     del beam, sliced, whole
+    device.reset_context()
+    torch.cuda.empty_cache()
+
+
+CFG5 = dict(num_freq=256, freq_start=400.0, freq_end=800.0, freq_mode="edge", num_cylinders=4, cylinder_width=14.5,
+            num_feeds=64, feed_spacing=0.3, tsys=1.0, force_lmax=1024, force_mmax=1024)
+
+
+def test_config5_real_block(golden_dir, tmp_path):
+    """BASELINE configs[4] on its own workload: the 512-feed telescope (geometry bit-exact against the reference,
+    tests/golden/geometry.npz `cfg5`), one m-block of the real beam-transfer matrix (m = 300: 256 x 3552 x 4100 complex,
+    59.6 GB, nside 1024), two of its 454 656 (f, b) columns against the oracle, the SVD chain of four of its frequencies
+    (3552 x 4100 each) in frequency slices, and one frequency against the oracle's chain (beamtransfer.py:802-924)."""
+    import torch
+
+    from driftscan_amd import beamtransfer, btgen, cylinder, device
+    from oracle import btgen as ob
+    from oracle import svdchain as osvd
+
+    device.reset_context()
+    torch.cuda.empty_cache()
+    ctx = device.get_context(workspace_bytes=40 << 30)
+    tel = cylinder.PolarisedCylinderTelescope.from_config(CFG5)
+    geo = np.load(os.path.join(golden_dir, "geometry.npz"))
+    assert tel.nbase == 1776 and tel.lmax == 1024 and tel.mmax == 1024 and tel.nfreq == 256
+    assert np.array_equal(tel.baselines, geo["cfg5_baselines"]) and np.array_equal(tel.uniquepairs, geo["cfg5_uniquepairs"])
+    bt = beamtransfer.BeamTransfer(str(tmp_path / "c5"), telescope=tel)
+    m = 300
+    t0 = time.perf_counter()
+    beam = btgen.beam_m_all(tel, ctx=ctx, max_bytes=24 << 30, m_range=(m, m))   # (1, F, 2, B, P, L)
+    ctx.sync()
+    _log("configs[4]: BT-gen of the m = %d block (%.1f GB): %.1f s" % (m, beam.numel() * 16 / 2 ** 30, time.perf_counter() - t0))
+    assert tuple(beam.shape) == (1, 256, 2, 1776, 4, 1025)
+    # ---- two (f, b) columns against the oracle's pixel-space restatement (12.6 M pixels, four Stokes maps)
+    b_long = int(np.argmax(np.abs(tel.baselines[:, 0])))
+    for fi, bi in ((100, 700), (tel.nfreq - 1, b_long)):
+        desc = dict(polarised=True, zenith=tel.zenith, baselines=tel.baselines, uniquepairs=tel.uniquepairs,
+                    beamclass=tel.beamclass, wavelengths=tel.wavelengths, cylinder_width=tel.cylinder_width,
+                    fwhm_e=tel.fwhm_e, fwhm_h=tel.fwhm_h, lmax=tel.lmax, mmax=tel.mmax, l_boost=tel.l_boost,
+                    included_freq=np.array([fi]), included_baseline=np.array([bi]), accuracy_boost=tel.accuracy_boost)
+        t0 = time.perf_counter()
+        ref = ob.beam_transfer_m(desc, mlist=[m])[m][fi, :, bi]
+        got = beam[0, fi, :, bi].cpu().numpy()
+        scale = np.abs(ref).max()
+        err = np.abs(got - ref).max()
+        _log("configs[4] beam_m column (f %d, b %d) m %d: max |diff| %.2e of scale %.2e (oracle %.1f s)"
+             % (fi, bi, m, err, scale, time.perf_counter() - t0))
+        assert scale > 0 and err < 1e-10 * scale
+        assert not got[..., :m].any()
+    # ---- SVD chain of four real frequencies, one frequency per call of the library (the sliced path)
+    fsel = [0, 85, 170, 255]
+    T, P, L = bt.ntel, tel.num_pol_sky, tel.lmax + 1
+    blk = beam[:, fsel].contiguous().reshape(1, len(fsel), T, P, L)
+    del beam
+    torch.cuda.empty_cache()
+    noisew = bt._noisew()[fsel]
+    nw = ctx.to_device(noisew)
+    per_chain = 16.0 * (2.0 * T * (P * L + T) + 16.0 * T * T)
+    t0 = time.perf_counter()
+    res = ctx.svd_chain(blk, nw, bt.polsvcut, max_bytes=1.5 * per_chain)
+    ctx.sync()
+    sv = res["singularvalues"].cpu().numpy()
+    _log("configs[4]: SVD chain of 4 real frequencies (3552 x 4100): %.1f s, sweeps %s, nmodes %s"
+         % (time.perf_counter() - t0, res["sweeps"], res["nmodes"].tolist()))
+    K = min(L, T)
+    smax = sv.max()
+    for k in range(len(fsel)):
+        n = int((sv[0, k] > smax * bt.svcut).sum())
+        assert 0 < n <= K and (np.diff(sv[0, k]) <= 1e-12 * smax).all()
+        ut = res["beam_ut"][0, k, :n]
+        U = ut / nw[k][None, :]
+        eye = torch.eye(n, dtype=torch.complex128, device="cuda")
+        bs = res["beam_svd"][0, k, :n].reshape(n, P * L)
+        ib = res["invbeam_svd"][0, k].reshape(P * L, K)[:, :n]
+        B = blk[0, k].reshape(T, P * L) * nw[k][:, None]
+        e_orth = (U @ U.conj().T - eye).abs().max().item()
+        e_proj = ((U @ B - bs).abs().max() / sv[0, k, 0]).item()
+        e_pinv = (bs @ ib - eye).abs().max().item()
+        _log("  f %d: n %d  |U U^H - I| %.2e  |U^H w B - beam_svd| %.2e  |beam_svd pinv - I| %.2e" % (fsel[k], n, e_orth, e_proj, e_pinv))
+        assert e_orth < 1e-12 and e_proj < 1e-11 and e_pinv < 1e-6
+    # ---- one frequency against the oracle's chain on the same block
+    k = 2
+    t0 = time.perf_counter()
+    o = osvd.svd_m(blk[0, k : k + 1].cpu().numpy().reshape(1, 2, tel.nbase, P, L), noisew[k : k + 1, : tel.nbase], polsvcut=bt.polsvcut)
+    err = np.abs(o["singularvalues"][0] - sv[0, k]).max() / sv[0, k].max()
+    _log("configs[4] f %d: singular values vs oracle %.2e of sigma_max (oracle %.1f s)" % (fsel[k], err, time.perf_counter() - t0))
+    assert err < 1e-10
+    assert int((o["singularvalues"][0] > smax * bt.svcut).sum()) == int((sv[0, k] > smax * bt.svcut).sum())
+    del blk, res
     device.reset_context()
     torch.cuda.empty_cache()
 

@@ -14,7 +14,7 @@ def geo(golden_dir):
     return np.load(os.path.join(golden_dir, "geometry.npz"))
 
 
-@pytest.mark.parametrize("name", ["testparams", "cfg2", "cfg3", "skip", "noincyl"])
+@pytest.mark.parametrize("name", ["testparams", "cfg2", "cfg3", "cfg5", "skip", "noincyl"])
 def test_feedpairs_and_friends(geo, name):
     cfg = {k: ast.literal_eval(v) for k, v in zip(geo[name + "_cfg_keys"], geo[name + "_cfg_vals"])}
     klass = cylinder.PolarisedCylinderTelescope if str(geo[name + "_kind"]) == "pol" else cylinder.UnpolarisedCylinderTelescope
@@ -24,9 +24,10 @@ def test_feedpairs_and_friends(geo, name):
     # bit-exact indexing
     assert np.array_equal(t.uniquepairs, geo[name + "_uniquepairs"])
     assert np.array_equal(t.redundancy, geo[name + "_redundancy"])
-    assert np.array_equal(t.feedmap, geo[name + "_feedmap"])
-    assert np.array_equal(t.feedmask, geo[name + "_feedmask"])
-    assert np.array_equal(t.feedconj, geo[name + "_feedconj"])
+    if name + "_feedmap" in geo:   # (left out of the fixture for the 512-feed telescope of configs[4]: 3 x 512 x 512)
+        assert np.array_equal(t.feedmap, geo[name + "_feedmap"])
+        assert np.array_equal(t.feedmask, geo[name + "_feedmask"])
+        assert np.array_equal(t.feedconj, geo[name + "_feedconj"])
     assert np.array_equal(t.baselines, geo[name + "_baselines"])
     assert np.array_equal(t.frequencies, geo[name + "_frequencies"])
     assert np.allclose(t.wavelengths, geo[name + "_wavelengths"], rtol=1e-15)

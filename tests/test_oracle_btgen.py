@@ -189,3 +189,22 @@ def test_sht_against_healpy_fixture(golden_dir):
             if key in g:
                 t = ob.transfer_single(m, nside, lmax, lmax, False, niter=it, ring_w=np.ones(4 * nside - 1))[0]
                 assert np.abs(t - g[key]).max() < 1e-10 * np.abs(g[key]).max(), key
+
+
+def test_ring_dft_by_fft_matches_the_explicit_sum():
+    """`ring_dft_fft` (one FFT per ring, used by the CPU baseline of bench.py) against the explicit twiddle sums of
+    `ring_dft`, including |m| beyond the pixel count of the polar rings (aliasing) and negative m."""
+    from oracle import btgen as ob
+
+    rng = np.random.default_rng(11)
+    nside = 8
+    maps = rng.standard_normal((4, 12 * nside**2)) + 1j * rng.standard_normal((4, 12 * nside**2))
+    ms = np.arange(-40, 41)
+    for sign in (+1, -1):
+        a = ob.ring_dft(maps, nside, ms, sign=sign)
+        b = ob.ring_dft_fft(maps, nside, ms, sign=sign)
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
+    lmax = 12
+    t0 = ob.transfer_single(maps, nside, lmax, lmax, True)
+    t1 = ob.transfer_single(maps, nside, lmax, lmax, True, fft=True)
+    assert np.abs(t0 - t1).max() <= 1e-12 * np.abs(t0).max()
