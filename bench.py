@@ -44,6 +44,21 @@ CFG2 = dict(num_freq=16, freq_start=400.0, freq_end=450.0, freq_mode="edge", num
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (AMD datasheet)
 HBM_PEAK_GBS = 8000.0         # HBM3E spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 achievable)
 HBM_CLASSES = ("trd_symv", "trd_wx")
+VALU_CLASSES = ("sb_panel_qr", "sb_chase", "sb_q2_apply")   # fp64 vector kernels of the two-stage tridiagonalisation
+
+
+def build_id():
+    """Identity of the kernels this process runs: sha256 over the sources of libdriftmi (the GPU box has no .git).  The
+    PMC records under profiles/ carry the id they were taken at; counters of another build are not reported."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "driftscan_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "driftscan_amd", "csrc", "*.c"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 CPU_SAMPLE_M = (0, 32, 64, 96)
 
 
@@ -184,7 +199,7 @@ def cpu_baseline(tel, bt, kl, blocks):
                 beamclass=tel.beamclass, wavelengths=tel.wavelengths, cylinder_width=tel.cylinder_width,
                 fwhm_e=tel.fwhm_e, fwhm_h=tel.fwhm_h, lmax=tel.lmax, mmax=tel.mmax, l_boost=tel.l_boost,
                 included_freq=np.array([0]), included_baseline=np.array([0, tel.nbase - 1]),
-                accuracy_boost=tel.accuracy_boost)
+                accuracy_boost=tel.accuracy_boost, sht_fft=True)   # one FFT per ring, Legendre sums as matrix products
     ncol = tel.nfreq * tel.nbase
     t_bt_block = _cpu_bt_columns(desc) / 2.0 * ncol / M    # 2 columns, all m -> seconds per m-block
     ms = sorted(blocks)
@@ -220,7 +235,8 @@ def cpu_baseline(tel, bt, kl, blocks):
     return dict(value=max(wk["m_blocks_per_s"], thr["m_blocks_per_s"]), unit="m-blocks/s", cores=ncores, kind="port",
                 mode=best, threaded=thr, workers=wk, sample_m=ms, sample_ndof=ndofs,
                 sample="oracle (numpy %s / scipy %s) on the real configs[1] blocks m = %s copied back from the device: SVD "
-                       "chain + covariance projections + KL per block, BT-gen on 2 of %d (f,b) columns scaled to all; "
+                       "chain + covariance projections + KL per block, BT-gen (pixel kernels, one FFT per ring, Legendre matrix "
+                       "products) on 2 of %d (f,b) columns scaled to all; "
                        "`threaded` = one process, BLAS on %d cores, median of 3; `workers` = single-threaded processes "
                        "over m (the reference's MPI mode), per-core rate x %d cores"
                        % (np.__version__, scipy.__version__, ms, ncol, ncores, ncores))
@@ -239,6 +255,7 @@ def build_objects(tmpdir):
 
 
 _pool = None
+_NKEEP = {}   # m -> eigenvectors actually back-transformed in the last pass (the modes transform_save keeps)
 
 
 def _svd_kl_group(bt, kl, beam_all, ms, m0=0):
@@ -258,9 +275,14 @@ def _svd_kl_group(bt, kl, beam_all, ms, m0=0):
     for i, mi in enumerate(ms):
         bt._dev[mi] = dict(beam_svd=res["beam_svd"][i], beam_ut=res["beam_ut"][i], singularvalues=sv[i])
     out = []
+    nkeep = {}
     for batch in kl._batches(list(ms)):
         out += kl._transform_batch(batch, to_host=False)             # projections + eigh_gen, products stay in HBM
+        lk = getattr(ctx, "last_nkeep", None)
+        if lk is not None and len(lk) == len(batch):
+            nkeep.update({mi: int(k) for mi, k in zip(batch, lk)})
     ctx.sync()
+    _NKEEP.update(nkeep)
     return t1 - t0, time.perf_counter() - t1, out, sv
 
 
@@ -320,7 +342,7 @@ def hot_path_step(tel, bt, kl, ctx, stage_times=None, streams=1, m_range=None, c
     return parts[0][2]
 
 
-def stage_work(tel, bt, ms):
+def stage_work(tel, bt, ms, nkeep=None):
     """Algorithmic work per stage, SURVEY.md §8(d): W_A (Legendre, 8 Nr Lm F B P per m), W_B (SVD chain),
     W_C (covariance projections + eig), summed over the given m."""
     import numpy as np
@@ -352,7 +374,12 @@ def stage_work(tel, bt, ms):
                 WB += svd(T, P * Lm) + svd(r1, (P - 1) * Lm) + svd(r2, Lm) + svd(n, P * Lm) \
                     + 8.0 * T * P * Lm * (r1 + r2 + n) + 8.0 * T * (r2 * r1 + n * r2)
         nF = 1 if P == 1 else 3
-        WC += 8.0 * ndof * ndof * Lm * (1 + nF) + 8.0 * T * float((svnum.astype(np.float64) ** 2).sum()) + 68.0 * ndof ** 3 / 3.0
+        # eig(n) of SURVEY.md section 8(d) = 4 (n^3/3 potrf + n^3 hegst + 4n^3/3 hetrd + 2n^3 back-transform + n^3
+        # back-solve) = 68 n^3 / 3 forms EVERY eigenvector; only the nkeep modes that are kept are back-transformed
+        # here, so the EXECUTED work is counted: the last two terms scale with nkeep / n
+        nk = float(nkeep.get(mi, ndof)) if nkeep is not None else ndof
+        eig = 4.0 * (ndof ** 3 / 3.0 + ndof ** 3 + 4.0 * ndof ** 3 / 3.0 + 3.0 * ndof * ndof * nk)
+        WC += 8.0 * ndof * ndof * Lm * (1 + nF) + 8.0 * T * float((svnum.astype(np.float64) ** 2).sum()) + eig
     return WA, WB, WC
 
 
@@ -561,13 +588,23 @@ def main():
             try:
                 import glob
 
+                bid = build_id()
                 tj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
                 if tj and dom is not None:
                     rec = json.load(open(tj[-1]))
+                    if rec.get("_build_id") != bid:
+                        # counters of another build of the kernels say nothing about this one
+                        traffic_src = "%s is stale (build %s, running %s): traffic not reported" % (
+                            os.path.relpath(tj[-1], ROOT), rec.get("_build_id"), bid)
+                        rec = {}
                     key = {"zgemm_grouped": "zgemm_grouped_kernel<false, false>", "trd_symv": "trd_symv_kernel",
                            "trd_wx": "trd_wx_kernel", "gemm_grouped_realB": "zgemm_grouped_kernel<true, false>",
                            "dgemm_grouped": "dgemm_grouped_kernel", "jac_inner": "jac_inner_kernel<false>",
-                           "jac_gram": "jac_gram_kernel", "jac_apply": "jac_apply_kernel"}.get(dom)
+                           "jac_gram": "jac_gram_kernel", "jac_apply": "jac_apply_kernel",
+                           "sb_chase": "sb_chase2_kernel<4>", "sb_q2_apply": "sb_q2_apply_kernel<4>",
+                           "sb_panel_qr": "sb_panel_fused_kernel"}.get(dom)
+                    if dom == "zgemm_grouped" and key not in rec:
+                        key = "zgemm4_grouped_kernel<false, false, 1>"
                     if key is not None and key not in rec:  # kernels compiled inside a namespace (dm_trd32::trd_symv_kernel)
                         key = next((k for k in rec if k.endswith("::" + key)), key)
                     if key in rec:
@@ -575,7 +612,12 @@ def main():
                         traffic_src = os.path.relpath(tj[-1], ROOT)
                 mj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_mfma.json")))
                 if mj:
-                    mfma_busy = dict(json.load(open(mj[-1])), source=os.path.relpath(mj[-1], ROOT))
+                    mrec = json.load(open(mj[-1]))
+                    if mrec.get("_build_id") == bid:
+                        mfma_busy = dict(mrec, source=os.path.relpath(mj[-1], ROOT))
+                    else:
+                        mfma_busy = dict(stale="%s was taken at build %s, this is %s" % (os.path.relpath(mj[-1], ROOT),
+                                                                                          mrec.get("_build_id"), bid))
             except Exception:
                 traffic, traffic_src = None, None
             if dom is not None:
@@ -598,6 +640,15 @@ def main():
                                     traffic_source=traffic_src, launches=p["launches"],
                                     avg_launch_us=1e3 * p["ms"] / max(p["launches"], 1),
                                     flops_per_launch=p["flops"] / max(p["launches"], 1))
+                    if dom in VALU_CLASSES:
+                        roofline["pipe"] = ("fp64 VALU (the kernel issues no MFMA; on MI355X the fp64 vector peak equals the "
+                                            "fp64 matrix peak, 78.6 TFLOP/s)")
+                roofline["build_id"] = build_id()
+                # every instrumented class, so that the cross-checks (sum of kernel time <= wall time) can be made
+                roofline["classes"] = {k: dict(ms_per_step=v["ms"] / args.steps, launches_per_step=v["launches"] / args.steps,
+                                               rate=(v["flops"] / (v["ms"] * 1e-3) / (1e9 if k in HBM_CLASSES else 1e12)
+                                                     if v["ms"] > 0 else None),
+                                               unit="GB/s" if k in HBM_CLASSES else "TFLOP/s") for k, v in prof.items()}
                 # the runner-up class of the other kind, for context (MFMA vs HBM side of the step)
                 others = [k for k in prof if (k in HBM_CLASSES) != (dom in HBM_CLASSES)]
                 if others:
@@ -615,7 +666,7 @@ def main():
                     roofline["mfma_busy"] = mfma_busy
             # per-stage fractions of SURVEY.md §8(d): algorithmic work of the stage / its wall time / fp64 MFMA peak
             my_ms = list(range(nblocks)) if m_range is None else list(range(m_range[0], m_range[1] + 1))
-            WA, WB, WC = stage_work(tel, bt, my_ms)
+            WA, WB, WC = stage_work(tel, bt, my_ms, nkeep=dict(_NKEEP) if _NKEEP else None)
             stages = {}
             for name, W, secs in (("btgen", WA, st[0]), ("svd", WB, st[1]), ("kl", WC, st[2])):
                 tf = W / secs / 1e12 if secs > 0 else 0.0

@@ -63,6 +63,23 @@ def main():
             print("   fused vs maps path: %.2e of the block scale" % rec["max_abs_diff_over_scale"], flush=True)
         del res
         torch.cuda.empty_cache()
+        # algorithmic flops of the two MFMA kernels of the fused path: the ring transform does
+        # 8 npix_above_horizon nm P real flops per (f, b) column (half of the sphere lies below the horizon: npix / 2),
+        # the Legendre products W_A = 8 Nring sum_m (L - m) P per column (real x complex: 4 per multiply-add pair)
+        from driftscan_amd import healpix
+
+        bb, ff = [x.ravel() for x in np.meshgrid(np.arange(tel.nbase), np.arange(tel.nfreq), indexing="ij")]
+        lm, _ = tel.baseline_lmax(bb, ff)
+        P = tel.num_pol_sky
+        nm = min(b, tel.mmax) - a + 1
+        ring = leg = 0.0
+        for l in np.unique(lm):
+            ncol = int((lm == l).sum())
+            nside = healpix.nside_for_lmax(int(l), tel.accuracy_boost if P == 1 else 1)
+            ring += 8.0 * (6.0 * nside * nside) * nm * (2 if a > 0 or nm > 1 else 1) * ncol * P
+            leg += 4.0 * (4 * nside - 1) * sum(max(int(l) + 1 - m, 0) for m in range(a, a + nm)) * 2 * ncol * P
+        rec["ring_transform_flops"] = ring   # +m and -m are separate output columns of the transform
+        rec["legendre_flops"] = leg
         out["runs"].append(rec)
         json.dump(out, open(args.out, "w"), indent=1)
 

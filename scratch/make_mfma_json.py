@@ -28,5 +28,9 @@ for k, v in val.items():
                                sq_busy_cycles=v.get("SQ_BUSY_CYCLES", 0.0), util=busy / (act / 8.0 * 1024.0))))
 for _, k, rec in sorted(rows, reverse=True)[:12]:
     out[k] = rec
+import os, sys as _sys
+_sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as _bench
+out["_build_id"] = _bench.build_id()
 json.dump(out, open("profiles/%s_pmc_mfma.json" % tag, "w"), indent=1)
 print(json.dumps(out, indent=1)[:2500])

@@ -19,5 +19,9 @@ out = {"_note": "bench.py --steps 1 --warmup 1 under rocprofv3 --pmc (2 passes o
 for k in sorted(ft, key=lambda k: -(ft[k] + wt.get(k, 0)))[:12]:
     n = max(fc.get(k, 1), 1)
     out[k] = {"launches": n, "fetch_bytes_per_launch": ft[k] * 1024 * 2 / n, "write_bytes_per_launch": wt.get(k, 0.0) * 1024 / max(wc.get(k, 1), 1)}
+import os, sys as _sys
+_sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as _bench
+out["_build_id"] = _bench.build_id()
 json.dump(out, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
