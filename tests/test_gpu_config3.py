@@ -388,8 +388,12 @@ def test_config5_real_block(golden_dir, tmp_path):
     _log("configs[4]: BT-gen of the m = %d block (%.1f GB): %.1f s" % (m, beam.numel() * 16 / 2 ** 30, time.perf_counter() - t0))
     assert tuple(beam.shape) == (1, 256, 2, 1776, 4, 1025)
     # ---- two (f, b) columns against the oracle's pixel-space restatement (12.6 M pixels, four Stokes maps)
-    b_long = int(np.argmax(np.abs(tel.baselines[:, 0])))
-    for fi, bi in ((100, 700), (tel.nfreq - 1, b_long)):
+    # (baselines long enough East-West to have power at m = 300; errors against the scale of the whole block, as for
+    # configs[2]: a column that is ~0 at this m is compared at the rounding level of the block, not of itself)
+    order = np.argsort(-np.abs(tel.baselines[:, 0]))
+    b_long, b_mid = int(order[0]), int(order[len(order) // 4])
+    block_scale = float(beam.abs().max().item())
+    for fi, bi in ((100, b_mid), (tel.nfreq - 1, b_long)):
         desc = dict(polarised=True, zenith=tel.zenith, baselines=tel.baselines, uniquepairs=tel.uniquepairs,
                     beamclass=tel.beamclass, wavelengths=tel.wavelengths, cylinder_width=tel.cylinder_width,
                     fwhm_e=tel.fwhm_e, fwhm_h=tel.fwhm_h, lmax=tel.lmax, mmax=tel.mmax, l_boost=tel.l_boost,
@@ -401,7 +405,7 @@ def test_config5_real_block(golden_dir, tmp_path):
         err = np.abs(got - ref).max()
         _log("configs[4] beam_m column (f %d, b %d) m %d: max |diff| %.2e of scale %.2e (oracle %.1f s)"
              % (fi, bi, m, err, scale, time.perf_counter() - t0))
-        assert scale > 0 and err < 1e-10 * scale
+        assert scale > 1e-3 * block_scale and err < 1e-10 * block_scale
         assert not got[..., :m].any()
     # ---- SVD chain of four real frequencies, one frequency per call of the library (the sliced path)
     fsel = [0, 85, 170, 255]
