@@ -1216,7 +1216,10 @@ __global__ __launch_bounds__(128 * NP) void sb_chase2_kernel(const sb_chase_mat*
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           if (lane == 0) sb_lds_st(&box->gen, my_gen);
           if (stop) break;
-          if (!sb_chase_E(M, rsAB, box, ctl.err, s, lane)) {
+          const unsigned long long t0 = ctl.dbg ? wall_clock64() : 0ull;
+          const bool okE = sb_chase_E(M, rsAB, box, ctl.err, s, lane);
+          if (ctl.dbg && lane == 0) { ctl.dbg[2 * s] = t0; ctl.dbg[2 * s + 1] = wall_clock64(); }
+          if (!okE) {
             // failed: make sure the partner is released as well
             ++my_gen;
             sb_wait_lds(&box->done_gen, [&](int g) { return g == my_gen - 1; }, ctl.err, 9, lane);
