@@ -1268,20 +1268,24 @@ struct sb_q2_mat {
   int slab0;                           // first slab (of 16 columns) id of this matrix in the launch
 };
 
-template <int NW>
+// LPC = lanes per column of X: 4 (16 columns per wave, 9 rows of a reflector per lane) or 8 (8 columns per wave, 5 rows per
+// lane: twice the waves for the same X — the choice when the columns alone cannot fill the chip)
+template <int NW, int LPC>
 __global__ __launch_bounds__(64 * NW) void sb_q2_apply_kernel(const sb_q2_mat* __restrict__ ms, const int2* __restrict__ wgs) {
   // wgs[blockIdx.x] = (matrix, first slab of this workgroup)
   const int2 wg = wgs[blockIdx.x];
   const sb_q2_mat M = ms[wg.x];
   const int n = M.n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = (wg.y + wave) * 16 + (lane >> 2);
-  const int part = lane & 3;
+  constexpr int NCW = 64 / LPC;          // columns per wave
+  constexpr int NRL = SB / LPC + 1;      // rows of one reflector a lane can meet
+  const int col = (wg.y + wave) * NCW + lane / LPC;
+  const int part = lane % LPC;
   const bool cvalid = col < M.ncol;
   extern __shared__ __align__(16) unsigned char sb_q2_smem[];
   cplx (*sv)[SBG * SBW] = reinterpret_cast<cplx (*)[SBG * SBW]>(sb_q2_smem);
   cplx (*st)[SBG] = reinterpret_cast<cplx (*)[SBG]>(sb_q2_smem + sizeof(cplx) * 2 * SBG * SBW);
-  constexpr int NU = SBW / 4;  // window rows per lane
+  constexpr int NU = SBW / LPC;  // window rows per lane
   const int nsweep = n - 1;
   if (nsweep <= 0) return;
   const int ngroup = (nsweep + SBG - 1) / SBG;
@@ -1299,73 +1303,97 @@ __global__ __launch_bounds__(64 * NW) void sb_q2_apply_kernel(const sb_q2_mat* _
     }
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      const int r = row0 + 4 * u + part;
+      const int r = row0 + LPC * u + part;
       xw[u] = (cvalid && r < n) ? dm_ldg(M.X, (size_t)r * M.ldx + col) : make_double2(0.0, 0.0);
     }
     __syncthreads();
     for (int j = 0; j < nb; ++j) {
       const int buf = j & 1;
-      // prefetch the next block of reflectors into the other buffer
+      // The next block of reflectors goes straight from global memory into the other LDS buffer (global_load_lds:
+      // no registers, nothing waits for it until the end of this block), and the 32 rows of X that enter the window at
+      // the slide are requested now as well: a block's worth of arithmetic hides both latencies.
+      const int wr0 = row0 + j * SB;
+      cplx xn[SB / LPC];
       if (j + 1 < nb) {
         const cplx* src = M.Vd + ((size_t)G * M.jb + j + 1) * SBG * SBW;
-        for (int idx = tid; idx < SBG * SBW; idx += 64 * NW) sv[buf ^ 1][idx] = dm_ldg(src, idx);
-        if (tid < SBG) st[buf ^ 1][tid] = dm_ldg(M.tau2, ((size_t)G * M.jb + j + 1) * SBG + tid);
+#pragma unroll
+        for (int k = 0; k < SBG * SBW / (64 * NW); ++k) {
+          const int i0 = (k * NW + wave) * 64;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i0 + lane),
+                                           (__attribute__((address_space(3))) void*)(&sv[buf ^ 1][i0]), 16, 0, 0);
+        }
+        if (tid < SBG)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(M.tau2 + ((size_t)G * M.jb + j + 1) * SBG + tid),
+                                           (__attribute__((address_space(3))) void*)(&st[buf ^ 1][0]), 16, 0, 0);
+#pragma unroll
+        for (int u = 0; u < SB / LPC; ++u) {
+          const int r = wr0 + SB + LPC * (u + NU - SB / LPC) + part;
+          xn[u] = (cvalid && r < n) ? dm_ldg(M.X, (size_t)r * M.ldx + col) : make_double2(0.0, 0.0);
+        }
       }
       // Sweeps last to first.  A sweep the group does not have (the last group, or a block below the end of the matrix)
       // has tau = 0 and a zero vector: applying it changes nothing, so the loop is straight-line code and the reflector of
       // the next step is fetched from LDS while the current one is applied.
-      cplx vn[9];
+      // (two register sets for the reflector, used in turn: no copies between the fetch and the use)
+      auto fetch = [&](cplx (&v)[NRL], int i) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t) vn[t] = sv[buf][(SBG - 1) * SBW + part + 4 * ((SBG - 1) / 4 + t)];
-#pragma unroll
-      for (int i = SBG - 1; i >= 0; --i) {
-        const int iq = i >> 2;
+        for (int t = 0; t < NRL; ++t) v[t] = sv[buf][i * SBW + part + LPC * (i / LPC + t)];
+      };
+      auto apply = [&](const cplx (&v)[NRL], int i) {
+        const int iq = i / LPC;
         const cplx tq = st[buf][i];
-        cplx v[9];
+        // rows w = LPC u + part, u = iq .. iq + NRL - 1 cover [i, i + SB) (zeros outside the vector); three partial sums,
+        // each started by a product (no zeroing of accumulators)
+        cplx a[3];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) v[t] = vn[t];
-        if (i > 0) {
-#pragma unroll
-          for (int t = 0; t < 9; ++t) vn[t] = sv[buf][(i - 1) * SBW + part + 4 * (((i - 1) >> 2) + t)];
+        for (int t = 0; t < NRL; ++t) {
+          if (t < 3) {
+            a[t].x = v[t].x * xw[iq + t].x; a[t].x = fma(v[t].y, xw[iq + t].y, a[t].x);      // conj(v) * x
+            a[t].y = v[t].x * xw[iq + t].y; a[t].y = fma(-v[t].y, xw[iq + t].x, a[t].y);
+          } else {
+            sb_cfma_ca(a[t % 3], v[t], xw[iq + t]);
+          }
         }
-        // rows w = 4 u + part, u = iq .. iq + 8 cover [i, i + SB) (zeros outside the vector)
-        cplx a0 = make_double2(0.0, 0.0), a1 = a0, a2 = a0;
-#pragma unroll
-        for (int t = 0; t < 9; t += 3) {
-          sb_cfma_ca(a0, v[t], xw[iq + t]);  // conj(v) * x
-          sb_cfma_ca(a1, v[t + 1], xw[iq + t + 1]);
-          sb_cfma_ca(a2, v[t + 2], xw[iq + t + 2]);
-        }
-        cplx acc = cadd(cadd(a0, a1), a2);
+        cplx acc = cadd(cadd(a[0], a[1]), a[2]);
         acc.x = sb_quad_sum(acc.x);
         acc.y = sb_quad_sum(acc.y);
+        if (LPC == 8) {
+          acc.x += dm_dpp_f64<0x141>(acc.x);   // row_half_mirror: the other quad of the eight lanes
+          acc.y += dm_dpp_f64<0x141>(acc.y);
+        }
         const cplx f = cmul(tq, acc);  // H x = x - tau v (v^H x)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) sb_cfms(xw[iq + t], v[t], f);
+        for (int t = 0; t < NRL; ++t) sb_cfms(xw[iq + t], v[t], f);
+      };
+      cplx va[NRL], vb[NRL];
+      fetch(va, SBG - 1);
+#pragma unroll
+      for (int i = SBG - 1; i >= 1; i -= 2) {
+        fetch(vb, i - 1);
+        apply(va, i);
+        if (i >= 2) fetch(va, i - 2);
+        apply(vb, i - 1);
       }
       // slide: the first SB rows of the window are final for this group
-      const int wr0 = row0 + j * SB;
 #pragma unroll
-      for (int u = 0; u < SB / 4; ++u) {
-        const int r = wr0 + 4 * u + part;
+      for (int u = 0; u < SB / LPC; ++u) {
+        const int r = wr0 + LPC * u + part;
         if (cvalid && r < n) dm_stg(M.X, (size_t)r * M.ldx + col, xw[u]);
       }
       if (j + 1 < nb) {
 #pragma unroll
-        for (int u = 0; u + SB / 4 < NU; ++u) xw[u] = xw[u + SB / 4];
+        for (int u = 0; u + SB / LPC < NU; ++u) xw[u] = xw[u + SB / LPC];
 #pragma unroll
-        for (int u = NU - SB / 4; u < NU; ++u) {
-          const int r = wr0 + SB + 4 * u + part;
-          xw[u] = (cvalid && r < n) ? dm_ldg(M.X, (size_t)r * M.ldx + col) : make_double2(0.0, 0.0);
-        }
+        for (int u = NU - SB / LPC; u < NU; ++u) xw[u] = xn[u - (NU - SB / LPC)];
       } else {
         // last block: the rest of the window is final too
 #pragma unroll
-        for (int u = SB / 4; u < NU; ++u) {
-          const int r = wr0 + 4 * u + part;
+        for (int u = SB / LPC; u < NU; ++u) {
+          const int r = wr0 + LPC * u + part;
           if (cvalid && r < n) dm_stg(M.X, (size_t)r * M.ldx + col, xw[u]);
         }
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the reflectors of the next block have landed in LDS
       __syncthreads();
     }
   }

@@ -2094,22 +2094,29 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
   // X <- Q2 X (X = probs[p].C, n x ncolv[p]): workgroups of NW column slabs, large matrices first
   auto apply_q2 = [&](const std::vector<int>& ch, const std::vector<int>& ncolv) -> int {
     constexpr int NW = 4;
-    std::vector<sb_q2_mat> qm;
-    std::vector<int2> wgs;
     std::vector<int> order(ch);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return probs[a].n > probs[b].n; });
+    // 16 columns per wave (four lanes per column).  Eight lanes per column (twice the waves, five instead of nine rows
+    // of a reflector per lane) were measured slower in both regimes — configs[1] batch 11.3 against 9.2 ms, one matrix of
+    // 32 576 rows 8.8 against 7.6 s: the fixed cost per reflector (fetch, fold, scale) weighs more than the extra waves
+    // hide — and stay behind DM_SB_Q2_LPC=8.
+    int lpc = 4;
+    if (const char* e = getenv("DM_SB_Q2_LPC")) lpc = atoi(e) == 8 ? 8 : 4;
+    const int ncw = 64 / lpc;
+    std::vector<sb_q2_mat> qm;
+    std::vector<int2> wgs;
     for (int p : order) {
       if (probs[p].n < 2 || ncolv[p] <= 0) continue;
       const int mi = (int)qm.size();
       qm.push_back(sb_q2_mat{sbVd + offvd[p], sbTau2 + offt2[p], sb_jb[p], probs[p].C, probs[p].ldc, probs[p].n, ncolv[p], 0});
-      const int nslab = (ncolv[p] + 15) / 16;
+      const int nslab = (ncolv[p] + ncw - 1) / ncw;
       for (int s0 = 0; s0 < nslab; s0 += NW) wgs.push_back(make_int2(mi, s0));
     }
     if (wgs.empty()) return DM_OK;
     if (getenv("DM_TRD_SIZES")) {
       fprintf(stderr, "[apply_q2] n:ncol");
       for (const auto& q : qm) fprintf(stderr, " %d:%d", q.n, q.ncol);
-      fprintf(stderr, " -> %zu workgroups\n", wgs.size());
+      fprintf(stderr, " -> %zu workgroups, %d lanes per column\n", wgs.size(), lpc);
     }
     sb_q2_mat* d_qm = dm_ws_upload(ctx, qm);
     int2* d_wgs = dm_ws_upload(ctx, wgs);
@@ -2117,14 +2124,19 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
     const size_t lds = sizeof(cplx) * (2 * SBG * SBW + 2 * SBG);
     static bool attr = false;
     if (!attr) {
-      DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sb_q2_apply_kernel<NW>),
+      DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sb_q2_apply_kernel<NW, 4>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sb_q2_apply_kernel<NW, 8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr = true;
     }
     double fl = 0.0;  // n^2 / (2 SB) reflectors of length SB on ncol columns: 2 SB complex multiply-adds per column each
     for (const auto& q : qm) fl += 8.0 * (double)q.n * q.n * q.ncol;
     dm_prof_scope ps(ctx, DM_PROF_SB_Q2, fl);
-    hipLaunchKernelGGL((sb_q2_apply_kernel<NW>), dim3((unsigned)wgs.size()), dim3(64 * NW), lds, ctx->stream, d_qm, d_wgs);
+    if (lpc == 8)
+      hipLaunchKernelGGL((sb_q2_apply_kernel<NW, 8>), dim3((unsigned)wgs.size()), dim3(64 * NW), lds, ctx->stream, d_qm, d_wgs);
+    else
+      hipLaunchKernelGGL((sb_q2_apply_kernel<NW, 4>), dim3((unsigned)wgs.size()), dim3(64 * NW), lds, ctx->stream, d_qm, d_wgs);
     DM_HIP(ctx, hipGetLastError());
     return DM_OK;
   };

@@ -18,13 +18,13 @@ def rnd(rows, cols):
 
 
 def make():
-    r = n // 8
+    r = int(n * 17234 / 32576)   # the signal covariance has this many modes above the cut (configs[4], m = 300: 17 234)
     X = rnd(n, r)
-    d = torch.logspace(2, -4, r, device="cuda", dtype=torch.float64)
+    d = torch.logspace(2, 0, r, device="cuda", dtype=torch.float64)
     S = (X * d) @ X.conj().T
     del X
-    Y = rnd(n, r)
-    N = Y @ Y.conj().T / r + torch.eye(n, device="cuda", dtype=torch.complex128)
+    Y = rnd(n, n // 8)
+    N = Y @ Y.conj().T / (n // 8) + torch.eye(n, device="cuda", dtype=torch.complex128)
     del Y
     return S.contiguous(), N.contiguous()
 
@@ -36,6 +36,7 @@ for mode in modes:
     thr = 0.0
     off, tot = block_offsets([n])
     torch.cuda.synchronize()
+    ctx.prof_reset(True)
     t0 = time.time()
     ev, evoff, E, ac, _ = ctx.eigh_gen(S.reshape(-1), N.reshape(-1), [n], off, cut=("upper", 1e-2))
     ctx.sync(); torch.cuda.synchronize()
@@ -44,6 +45,7 @@ for mode in modes:
     del S, N
     torch.cuda.empty_cache()
     S, N = make() if False else (None, None)
+    print({k: (round(v["ms"] / 1e3, 2), round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)) for k, v in ctx.prof_report().items()}, flush=True)
     print("n %d twostage %s: %.2f s, kept %d modes, ac %g, evals %.3e .. %.3e" % (n, mode, dt, nk, ac[0], float(ev[0]), float(ev[-1])), flush=True)
     del ev, E
     torch.cuda.empty_cache()
