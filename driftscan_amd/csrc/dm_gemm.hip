@@ -575,8 +575,12 @@ __global__ __launch_bounds__(256) void dgemm_grouped_kernel(const dm_gemm_desc* 
 
 }  // namespace
 
-// Host side: flatten descriptors into tiles, upload, launch.
-int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) {
+// Host side: flatten descriptors into tiles (plan), upload, launch (run).  A plan is the host image of one grouped
+// launch — descriptors and tile lists in ONE blob; a caller with a chain of launches (a panel of the two-stage
+// tridiagonalisation: a dozen of them) builds all its plans, sends the blobs in one copy and runs them in turn: every
+// staged upload is a copy kernel of its own in the stream, in front of the launch that needs it.
+int dm_gemm_plan_build(const std::vector<dm_gemm_desc>& descs, dm_gemm_plan& plan) {
+  plan = dm_gemm_plan();
   if (descs.empty()) return DM_OK;
   // DM_GEMM4 = 1 / 0 selects the register-only 4x4x4 kernel (default) / the LDS-staged 16x16x4 kernel
   static const int use4_env = getenv("DM_GEMM4") ? atoi(getenv("DM_GEMM4")) : -1;
@@ -623,37 +627,77 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
   auto by_k = [&](const dm_gemm_tile& a, const dm_gemm_tile& b) { return descs[a.desc].K > descs[b.desc].K; };
   for (auto* tl : {&tiles, &tiles_real, &tiles_dd, &tiles_gat})
     if (!std::is_sorted(tl->begin(), tl->end(), by_k)) std::stable_sort(tl->begin(), tl->end(), by_k);
-  size_t mark = dm_ws_mark(ctx);
   // descriptors and all tile lists travel in ONE host-to-device copy: on the chains of short
   // dependent products (triangular solves, Cholesky) the API calls per launch are what the GPU waits for
   const size_t nd = descs.size(), n0 = tiles.size(), n1 = tiles_real.size(), n2 = tiles_dd.size(), n3 = tiles_gat.size();
   const size_t desc_bytes = (nd * sizeof(dm_gemm_desc) + 15) & ~size_t(15);
   const size_t tile_bytes = (n0 + n1 + n2 + n3) * sizeof(dm_gemm_tile);
-  std::vector<char> blob(desc_bytes + tile_bytes);
-  std::memcpy(blob.data(), descs.data(), nd * sizeof(dm_gemm_desc));
+  plan.blob.resize(desc_bytes + tile_bytes);
+  std::memcpy(plan.blob.data(), descs.data(), nd * sizeof(dm_gemm_desc));
   {
-    char* tp = blob.data() + desc_bytes;
+    char* tp = plan.blob.data() + desc_bytes;
     for (const auto* tl : {&tiles, &tiles_real, &tiles_dd, &tiles_gat}) {
       if (!tl->empty()) std::memcpy(tp, tl->data(), tl->size() * sizeof(dm_gemm_tile));
       tp += tl->size() * sizeof(dm_gemm_tile);
     }
   }
-  char* dblob = dm_ws_upload(ctx, blob);
-  if (!dblob) return DM_ENOMEM;
-  dm_gemm_desc* dd = reinterpret_cast<dm_gemm_desc*>(dblob);
-  dm_gemm_tile* dtiles = reinterpret_cast<dm_gemm_tile*>(dblob + desc_bytes);
-  dm_gemm_tile* const dt_c = dtiles;
-  dm_gemm_tile* const dt_r = dtiles + n0;
-  dm_gemm_tile* const dt_d = dtiles + n0 + n1;
-  dm_gemm_tile* const dt_g = dtiles + n0 + n1 + n2;
-  if (!tiles.empty()) {
-    dm_gemm_tile* dt = dt_c;
-    // deep operand prefetch (two waves per SIMD) pays on long inner dimensions only
-    static const int deep_env = getenv("DM_GEMM4_DEEP") ? atoi(getenv("DM_GEMM4_DEEP")) : -1;
-    int kmin_c = 1 << 30;
-    for (const auto& d : descs)
-      if (d.M > 0 && d.N > 0 && !(d.flags & (DM_GEMM_ALL_REAL | DM_GEMM_B_REAL | DM_GEMM_B_GATHER))) kmin_c = std::min(kmin_c, d.K);
-    const bool deep = deep_env >= 0 ? deep_env != 0 : kmin_c >= 512;
+  plan.desc_bytes = desc_bytes;
+  plan.n0 = n0; plan.n1 = n1; plan.n2 = n2; plan.n3 = n3;
+  plan.fl_c = fl_c; plan.fl_r = fl_r; plan.fl_d = fl_d; plan.fl_g = fl_g;
+  plan.use4 = use4;
+  // deep operand prefetch (two waves per SIMD) pays on long inner dimensions only
+  static const int deep_env = getenv("DM_GEMM4_DEEP") ? atoi(getenv("DM_GEMM4_DEEP")) : -1;
+  int kmin_c = 1 << 30;
+  for (const auto& d : descs)
+    if (d.M > 0 && d.N > 0 && !(d.flags & (DM_GEMM_ALL_REAL | DM_GEMM_B_REAL | DM_GEMM_B_GATHER))) kmin_c = std::min(kmin_c, d.K);
+  plan.deep = deep_env >= 0 ? deep_env != 0 : kmin_c >= 512;
+  // figures for DM_GEMM_LOG
+  plan.log_kmin = 1 << 30; plan.log_kmax = 0; plan.log_mmax = 0; plan.log_nmax = 0; plan.log_rmw = 0; plan.log_full = 0.0;
+  for (const auto& d : descs) {
+    if (d.M <= 0 || d.N <= 0 || (d.flags & (DM_GEMM_ALL_REAL | DM_GEMM_B_REAL))) continue;
+    plan.log_kmin = std::min(plan.log_kmin, d.K); plan.log_kmax = std::max(plan.log_kmax, d.K);
+    plan.log_mmax = std::max(plan.log_mmax, d.M); plan.log_nmax = std::max(plan.log_nmax, d.N);
+    plan.log_rmw |= d.beta != 0.0;
+  }
+  for (const auto& t : tiles) plan.log_full += 8.0 * BM * BN * descs[t.desc].K;
+  plan.log_ndesc = nd;
+  return DM_OK;
+}
+
+// Upload the blobs of several plans in one staged copy; dev[i] = device address of plan i (nullptr for an empty plan).
+int dm_gemm_plans_upload(dm_ctx* ctx, const std::vector<const dm_gemm_plan*>& plans, std::vector<const char*>& dev) {
+  dev.assign(plans.size(), nullptr);
+  size_t tot = 0;
+  std::vector<size_t> off(plans.size(), 0);
+  for (size_t i = 0; i < plans.size(); ++i) {
+    off[i] = tot;
+    tot += (plans[i]->blob.size() + 15) & ~size_t(15);
+  }
+  if (tot == 0) return DM_OK;
+  std::vector<char> all(tot);
+  for (size_t i = 0; i < plans.size(); ++i)
+    if (!plans[i]->blob.empty()) std::memcpy(all.data() + off[i], plans[i]->blob.data(), plans[i]->blob.size());
+  char* d = dm_ws_upload(ctx, all);
+  if (!d) return DM_ENOMEM;
+  for (size_t i = 0; i < plans.size(); ++i)
+    if (!plans[i]->blob.empty()) dev[i] = d + off[i];
+  return DM_OK;
+}
+
+int dm_gemm_plan_run(dm_ctx* ctx, const dm_gemm_plan& plan, const char* dblob) {
+  if (plan.blob.empty()) return DM_OK;
+  const bool use4 = plan.use4;
+  const size_t n0 = plan.n0, n1 = plan.n1, n2 = plan.n2, n3 = plan.n3;
+  const double fl_c = plan.fl_c, fl_r = plan.fl_r, fl_d = plan.fl_d, fl_g = plan.fl_g;
+  const dm_gemm_desc* dd = reinterpret_cast<const dm_gemm_desc*>(dblob);
+  const dm_gemm_tile* dtiles = reinterpret_cast<const dm_gemm_tile*>(dblob + plan.desc_bytes);
+  const dm_gemm_tile* const dt_c = dtiles;
+  const dm_gemm_tile* const dt_r = dtiles + n0;
+  const dm_gemm_tile* const dt_d = dtiles + n0 + n1;
+  const dm_gemm_tile* const dt_g = dtiles + n0 + n1 + n2;
+  if (n0) {
+    const dm_gemm_tile* dt = dt_c;
+    const bool deep = plan.deep;
     static const bool log = getenv("DM_GEMM_LOG") != nullptr;  // debugging aid: per-launch shape and rate
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (log) {
@@ -665,65 +709,64 @@ int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) 
       dm_prof_scope ps(ctx, DM_PROF_GEMM, fl_c);
       if (use4)
         if (deep)
-          hipLaunchKernelGGL((zgemm4_grouped_kernel<false, false, 2>), dim3((unsigned)tiles.size()), dim3(256), 0, ctx->stream,
-                             dd, dt, (int)tiles.size());
+          hipLaunchKernelGGL((zgemm4_grouped_kernel<false, false, 2>), dim3((unsigned)n0), dim3(256), 0, ctx->stream,
+                             dd, dt, (int)n0);
         else
-          hipLaunchKernelGGL((zgemm4_grouped_kernel<false, false, 1>), dim3((unsigned)tiles.size()), dim3(256), 0, ctx->stream,
-                             dd, dt, (int)tiles.size());
+          hipLaunchKernelGGL((zgemm4_grouped_kernel<false, false, 1>), dim3((unsigned)n0), dim3(256), 0, ctx->stream,
+                             dd, dt, (int)n0);
       else
-        hipLaunchKernelGGL((zgemm_grouped_kernel<false, false>), dim3((unsigned)tiles.size()), dim3(256), 0, ctx->stream, dd,
-                           dt, (int)tiles.size());
+        hipLaunchKernelGGL((zgemm_grouped_kernel<false, false>), dim3((unsigned)n0), dim3(256), 0, ctx->stream, dd,
+                           dt, (int)n0);
     }
     if (log) {
       (void)hipEventRecord(e1, ctx->stream);
       (void)hipEventSynchronize(e1);
       float ms = 0.f;
       (void)hipEventElapsedTime(&ms, e0, e1);
-      int kmin = 1 << 30, kmax = 0, mmax = 0, nmax = 0, rmw = 0;
-      double full = 0.0;
-      for (const auto& d : descs) {
-        if (d.M <= 0 || d.N <= 0 || (d.flags & (DM_GEMM_ALL_REAL | DM_GEMM_B_REAL))) continue;
-        kmin = std::min(kmin, d.K); kmax = std::max(kmax, d.K);
-        mmax = std::max(mmax, d.M); nmax = std::max(nmax, d.N);
-        rmw |= d.beta != 0.0;
-      }
-      for (const auto& t : tiles) full += 8.0 * BM * BN * descs[t.desc].K;
       fprintf(stderr, "GEMMLOG tiles %6zu descs %5zu Mmax %5d Nmax %5d K %4d..%4d rmw %d  %8.3f ms  %6.2f TF (padded %6.2f)\n",
-              tiles.size(), descs.size(), mmax, nmax, kmin, kmax, rmw, ms, fl_c / ms / 1e9, full / ms / 1e9);
+              n0, plan.log_ndesc, plan.log_mmax, plan.log_nmax, plan.log_kmin, plan.log_kmax, plan.log_rmw, ms, fl_c / ms / 1e9,
+              plan.log_full / ms / 1e9);
       (void)hipEventDestroy(e0);
       (void)hipEventDestroy(e1);
     }
   }
-  if (!tiles_gat.empty()) {
-    dm_gemm_tile* dt = dt_g;
+  if (n3) {
+    const dm_gemm_tile* dt = dt_g;
     dm_prof_scope ps(ctx, DM_PROF_GEMM, fl_g);
     if (use4)
-      hipLaunchKernelGGL((zgemm4_grouped_kernel<false, true, 1>), dim3((unsigned)tiles_gat.size()), dim3(256), 0, ctx->stream,
-                         dd, dt, (int)tiles_gat.size());
+      hipLaunchKernelGGL((zgemm4_grouped_kernel<false, true, 1>), dim3((unsigned)n3), dim3(256), 0, ctx->stream,
+                         dd, dt, (int)n3);
     else
-      hipLaunchKernelGGL((zgemm_grouped_kernel<false, true>), dim3((unsigned)tiles_gat.size()), dim3(256), 0, ctx->stream,
-                         dd, dt, (int)tiles_gat.size());
+      hipLaunchKernelGGL((zgemm_grouped_kernel<false, true>), dim3((unsigned)n3), dim3(256), 0, ctx->stream,
+                         dd, dt, (int)n3);
   }
-  if (!tiles_real.empty()) {
-    dm_gemm_tile* dt = dt_r;
+  if (n1) {
+    const dm_gemm_tile* dt = dt_r;
     dm_prof_scope ps(ctx, DM_PROF_GEMM_REAL, fl_r);
     if (use4)
-      hipLaunchKernelGGL((zgemm4_grouped_kernel<true, false, 1>), dim3((unsigned)tiles_real.size()), dim3(256), 0, ctx->stream,
-                         dd, dt, (int)tiles_real.size());
+      hipLaunchKernelGGL((zgemm4_grouped_kernel<true, false, 1>), dim3((unsigned)n1), dim3(256), 0, ctx->stream,
+                         dd, dt, (int)n1);
     else
-      hipLaunchKernelGGL((zgemm_grouped_kernel<true, false>), dim3((unsigned)tiles_real.size()), dim3(256), 0, ctx->stream,
-                         dd, dt, (int)tiles_real.size());
+      hipLaunchKernelGGL((zgemm_grouped_kernel<true, false>), dim3((unsigned)n1), dim3(256), 0, ctx->stream,
+                         dd, dt, (int)n1);
   }
-  if (!tiles_dd.empty()) {
-    dm_gemm_tile* dt = dt_d;
+  if (n2) {
+    const dm_gemm_tile* dt = dt_d;
     dm_prof_scope ps(ctx, DM_PROF_DGEMM, fl_d);
-    hipLaunchKernelGGL(dgemm_grouped_kernel, dim3((unsigned)tiles_dd.size()), dim3(256), 0, ctx->stream, dd, dt,
-                       (int)tiles_dd.size());
+    hipLaunchKernelGGL(dgemm_grouped_kernel, dim3((unsigned)n2), dim3(256), 0, ctx->stream, dd, dt, (int)n2);
   }
   DM_HIP(ctx, hipGetLastError());
-  // descriptors live in the bump arena until the caller's enclosing mark is
-  // released; kernels on the stream read them asynchronously, so we only rewind
-  // when the caller synchronises (see dm_ws_release contract).
-  (void)mark;
   return DM_OK;
+}
+
+int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs) {
+  if (descs.empty()) return DM_OK;
+  dm_gemm_plan plan;
+  DM_TRY(dm_gemm_plan_build(descs, plan));
+  if (plan.blob.empty()) return DM_OK;
+  // descriptors live in the bump arena until the caller's enclosing mark is released; kernels on the stream read them
+  // asynchronously, so the arena is only rewound when the caller synchronises (see dm_ws_release contract)
+  char* dblob = dm_ws_upload(ctx, plan.blob);
+  if (!dblob) return DM_ENOMEM;
+  return dm_gemm_plan_run(ctx, plan, dblob);
 }

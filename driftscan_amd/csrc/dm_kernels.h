@@ -41,6 +41,20 @@ struct dm_gemm_tile {
 
 int dm_gemm_grouped_launch(dm_ctx* ctx, const std::vector<dm_gemm_desc>& descs);
 
+// The same in two steps, for chains of launches whose host images can travel in one copy (dm_gemm.hip).
+struct dm_gemm_plan {
+  std::vector<char> blob;   // descriptors + tile lists as the kernels read them
+  size_t desc_bytes = 0, n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+  double fl_c = 0.0, fl_r = 0.0, fl_d = 0.0, fl_g = 0.0;
+  bool use4 = true, deep = false;
+  int log_kmin = 0, log_kmax = 0, log_mmax = 0, log_nmax = 0, log_rmw = 0;
+  size_t log_ndesc = 0;
+  double log_full = 0.0;
+};
+int dm_gemm_plan_build(const std::vector<dm_gemm_desc>& descs, dm_gemm_plan& plan);
+int dm_gemm_plans_upload(dm_ctx* ctx, const std::vector<const dm_gemm_plan*>& plans, std::vector<const char*>& dev);
+int dm_gemm_plan_run(dm_ctx* ctx, const dm_gemm_plan& plan, const char* dblob);
+
 static inline dm_gemm_desc dm_gemm_make(const cplx* A, int rsA, int csA, bool conjA, const void* B, int rsB, int csB,
                                         bool conjB, cplx* C, int ldc, int M, int N, int K, double alpha = 1.0,
                                         double beta = 0.0, const double* kscale = nullptr, int extra_flags = 0) {

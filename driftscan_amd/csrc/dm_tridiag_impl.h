@@ -1959,20 +1959,45 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
         gh.push_back(dm_gemm_make(pp + a0, 1, n, false, pp + (size_t)n * TNB + a0, n, 1, true, C + (size_t)a0 * lda + a0, lda,
                                   n - a0, n - a0, 2 * TNB, -1.0, 1.0, nullptr, DM_GEMM_UPPER | DM_GEMM_UPPER128));
       }
-      auto launch_sums = [&](const std::vector<sb_sum_desc>& v) -> int {
+      // every descriptor of the panel travels in ONE staged copy: the eight grouped products as plans, the three lists
+      // of slice sums and the T-factor descriptors behind them
+      dm_gemm_plan pg, px, py1, py2, pm, pss, pw, ph;
+      DM_TRY(dm_gemm_plan_build(gg, pg));
+      DM_TRY(dm_gemm_plan_build(gx, px));
+      DM_TRY(dm_gemm_plan_build(gy1, py1));
+      DM_TRY(dm_gemm_plan_build(gy2, py2));
+      DM_TRY(dm_gemm_plan_build(gm, pm));
+      DM_TRY(dm_gemm_plan_build(gs, pss));
+      DM_TRY(dm_gemm_plan_build(gw, pw));
+      DM_TRY(dm_gemm_plan_build(gh, ph));
+      dm_gemm_plan extra;   // not a product: the raw arrays of the sum / larft kernels, carried by the same upload
+      size_t o_sg, o_sy, o_sm, o_tf;
+      {
+        auto put = [&](const void* src, size_t bytes) {
+          const size_t o = (extra.blob.size() + 15) & ~size_t(15);
+          extra.blob.resize(o + bytes);
+          if (bytes) std::memcpy(extra.blob.data() + o, src, bytes);
+          return o;
+        };
+        o_sg = put(sg.data(), sg.size() * sizeof(sb_sum_desc));
+        o_sy = put(sy.data(), sy.size() * sizeof(sb_sum_desc));
+        o_sm = put(smm.data(), smm.size() * sizeof(sb_sum_desc));
+        o_tf = put(tf.data(), tf.size() * sizeof(tf_mat));
+        if (extra.blob.empty()) extra.blob.resize(16);
+      }
+      std::vector<const char*> dv;
+      DM_TRY(dm_gemm_plans_upload(ctx, {&pg, &px, &py1, &py2, &pm, &pss, &pw, &ph, &extra}, dv));
+      auto launch_sums = [&](const std::vector<sb_sum_desc>& v, size_t o) -> int {
         if (v.empty()) return DM_OK;
         int mx = 0;
         for (const auto& d : v) mx = std::max(mx, d.rows * d.cols);
-        sb_sum_desc* dv = dm_ws_upload(ctx, v);
-        if (!dv) return DM_ENOMEM;
-        hipLaunchKernelGGL(sb_sum_partials_kernel, dim3((mx + 255) / 256, (unsigned)v.size()), dim3(256), 0, ctx->stream, dv);
+        hipLaunchKernelGGL(sb_sum_partials_kernel, dim3((mx + 255) / 256, (unsigned)v.size()), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<const sb_sum_desc*>(dv[8] + o));
         return DM_OK;
       };
-      DM_TRY(dm_gemm_grouped_launch(ctx, gg));
-      DM_TRY(launch_sums(sg));
+      DM_TRY(dm_gemm_plan_run(ctx, pg, dv[0]));
+      DM_TRY(launch_sums(sg, o_sg));
       {
-        tf_mat* d_tf = dm_ws_upload(ctx, tf);
-        if (!d_tf) return DM_ENOMEM;
         static bool attr = false;
         const size_t lds = sizeof(cplx) * TNB * (TNB + 1);
         if (!attr) {
@@ -1980,17 +2005,18 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           attr = true;
         }
-        hipLaunchKernelGGL(larft_kernel, dim3((unsigned)tf.size()), dim3(64), lds, ctx->stream, d_tf);
+        hipLaunchKernelGGL(larft_kernel, dim3((unsigned)tf.size()), dim3(64), lds, ctx->stream,
+                           reinterpret_cast<const tf_mat*>(dv[8] + o_tf));
       }
-      DM_TRY(dm_gemm_grouped_launch(ctx, gx));
-      DM_TRY(dm_gemm_grouped_launch(ctx, gy1));
-      DM_TRY(dm_gemm_grouped_launch(ctx, gy2));
-      DM_TRY(launch_sums(sy));
-      DM_TRY(dm_gemm_grouped_launch(ctx, gm));
-      DM_TRY(launch_sums(smm));
-      DM_TRY(dm_gemm_grouped_launch(ctx, gs));
-      DM_TRY(dm_gemm_grouped_launch(ctx, gw));
-      DM_TRY(dm_gemm_grouped_launch(ctx, gh));
+      DM_TRY(dm_gemm_plan_run(ctx, px, dv[1]));
+      DM_TRY(dm_gemm_plan_run(ctx, py1, dv[2]));
+      DM_TRY(dm_gemm_plan_run(ctx, py2, dv[3]));
+      DM_TRY(launch_sums(sy, o_sy));
+      DM_TRY(dm_gemm_plan_run(ctx, pm, dv[4]));
+      DM_TRY(launch_sums(smm, o_sm));
+      DM_TRY(dm_gemm_plan_run(ctx, pss, dv[5]));
+      DM_TRY(dm_gemm_plan_run(ctx, pw, dv[6]));
+      DM_TRY(dm_gemm_plan_run(ctx, ph, dv[7]));
     }
     // ---- S2: band -> tridiagonal
     const char* dump = getenv("DM_SB_DUMP");  // debugging aid: the band and the tridiagonal of every matrix to files
