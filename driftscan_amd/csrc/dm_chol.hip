@@ -205,42 +205,47 @@ int dm_potrf_batched(dm_ctx* ctx, const std::vector<dm_mat>& mats, int* info_dev
   DM_HIP(ctx, hipMemsetAsync(info_dev, 0, sizeof(int) * nbatch, ctx->stream));
   // Two-level blocking: the LDS factor/substitution kernels work on 32-wide blocks, but the big
   // trailing update runs once per 64 columns so that the MFMA GEMM sees K = 64 and full tiles.
-  for (int k0 = 0; k0 < maxn; k0 += 2 * NB) {
-    for (int half = 0; half < 2; ++half) {
-      const int kk = k0 + half * NB;
-      if (kk >= maxn) break;
-      hipLaunchKernelGGL(potf2_kernel, dim3(nbatch), dim3(256), 0, ctx->stream, dd, kk, info_dev);
-      if (kk + NB >= maxn) break;
-      const int rt = (maxn - kk - NB + 63) / 64;
-      hipLaunchKernelGGL(panel_trsm_kernel, dim3(rt, nbatch), dim3(256), 0, ctx->stream, dd, kk, info_dev);
-      if (half == 0) {
-        // update only the next 32 columns so that the second factor step sees current data:
-        // A[kk+NB:, kk+NB:kk+2NB] -= L[kk+NB:, kk:kk+NB] L[kk+NB:kk+2NB, kk:kk+NB]^H
-        std::vector<dm_gemm_desc> g;
-        for (int i = 0; i < nbatch; ++i) {
-          const int rem = mats[i].n - kk - NB;
-          if (rem <= 0) continue;
-          cplx* L21 = mats[i].p + (size_t)(kk + NB) * mats[i].ld + kk;
-          cplx* A22 = mats[i].p + (size_t)(kk + NB) * mats[i].ld + (kk + NB);
-          g.push_back(dm_gemm_make(L21, mats[i].ld, 1, false, L21, 1, mats[i].ld, true, A22, mats[i].ld, rem,
-                                   std::min(NB, rem), NB, -1.0, 1.0));
+  // (two passes: the descriptors of all updates are recorded and sent in one copy, then everything is launched)
+  dm_gemm_chain chain(ctx);
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1) DM_TRY(chain.upload());
+    for (int k0 = 0; k0 < maxn; k0 += 2 * NB) {
+      for (int half = 0; half < 2; ++half) {
+        const int kk = k0 + half * NB;
+        if (kk >= maxn) break;
+        if (!chain.dry) hipLaunchKernelGGL(potf2_kernel, dim3(nbatch), dim3(256), 0, ctx->stream, dd, kk, info_dev);
+        if (kk + NB >= maxn) break;
+        const int rt = (maxn - kk - NB + 63) / 64;
+        if (!chain.dry) hipLaunchKernelGGL(panel_trsm_kernel, dim3(rt, nbatch), dim3(256), 0, ctx->stream, dd, kk, info_dev);
+        if (half == 0) {
+          // update only the next 32 columns so that the second factor step sees current data:
+          // A[kk+NB:, kk+NB:kk+2NB] -= L[kk+NB:, kk:kk+NB] L[kk+NB:kk+2NB, kk:kk+NB]^H
+          DM_TRY(chain.gemm([&](std::vector<dm_gemm_desc>& g) {
+            for (int i = 0; i < nbatch; ++i) {
+              const int rem = mats[i].n - kk - NB;
+              if (rem <= 0) continue;
+              cplx* L21 = mats[i].p + (size_t)(kk + NB) * mats[i].ld + kk;
+              cplx* A22 = mats[i].p + (size_t)(kk + NB) * mats[i].ld + (kk + NB);
+              g.push_back(dm_gemm_make(L21, mats[i].ld, 1, false, L21, 1, mats[i].ld, true, A22, mats[i].ld, rem,
+                                       std::min(NB, rem), NB, -1.0, 1.0));
+            }
+          }));
         }
-        DM_TRY(dm_gemm_grouped_launch(ctx, g));
       }
-    }
-    // trailing update with both 32-wide panels at once (K = 64), lower tiles only
-    const int k2 = k0 + 2 * NB;
-    if (k2 < maxn) {
-      std::vector<dm_gemm_desc> g;
-      for (int i = 0; i < nbatch; ++i) {
-        const int rem = mats[i].n - k2;
-        if (rem <= 0) continue;
-        cplx* L21 = mats[i].p + (size_t)k2 * mats[i].ld + k0;
-        cplx* A22 = mats[i].p + (size_t)k2 * mats[i].ld + k2;
-        g.push_back(dm_gemm_make(L21, mats[i].ld, 1, false, L21, 1, mats[i].ld, true, A22, mats[i].ld, rem, rem,
-                                 2 * NB, -1.0, 1.0, nullptr, DM_GEMM_LOWER));
+      // trailing update with both 32-wide panels at once (K = 64), lower tiles only
+      const int k2 = k0 + 2 * NB;
+      if (k2 < maxn) {
+        DM_TRY(chain.gemm([&](std::vector<dm_gemm_desc>& g) {
+          for (int i = 0; i < nbatch; ++i) {
+            const int rem = mats[i].n - k2;
+            if (rem <= 0) continue;
+            cplx* L21 = mats[i].p + (size_t)k2 * mats[i].ld + k0;
+            cplx* A22 = mats[i].p + (size_t)k2 * mats[i].ld + k2;
+            g.push_back(dm_gemm_make(L21, mats[i].ld, 1, false, L21, 1, mats[i].ld, true, A22, mats[i].ld, rem, rem,
+                                     2 * NB, -1.0, 1.0, nullptr, DM_GEMM_LOWER));
+          }
+        }));
       }
-      DM_TRY(dm_gemm_grouped_launch(ctx, g));
     }
   }
   hipLaunchKernelGGL(zero_upper_kernel, dim3((maxn + 255) / 256, maxn, nbatch), dim3(256), 0, ctx->stream, dd);
@@ -270,6 +275,9 @@ int dm_trsm_left_lower_batched(dm_ctx* ctx, const std::vector<dm_trsm_problem>& 
   const int NB2 = 2 * NB;
   const int nblk = (maxn + NB2 - 1) / NB2;   // 64-row super blocks
   const int nblk32 = (maxn + NB - 1) / NB;   // the substitution kernels still count 32-row blocks
+  dm_gemm_chain chain(ctx);   // two passes: record the descriptors of every update, one copy, then launch
+  for (int pass = 0; pass < 2; ++pass) {
+  if (pass == 1) DM_TRY(chain.upload());
   for (int s = 0; s < nblk; ++s) {
     // (1) GEMM updates in the order of the recursive algorithm (solve the first half, update the
     // second half with ONE product, solve the second half), unrolled: before super block u is
@@ -277,7 +285,7 @@ int dm_trsm_left_lower_batched(dm_ctx* ctx, const std::vector<dm_trsm_problem>& 
     // solved just before.  Same flops as the left-looking sweep, but half of them sit in one
     // (n/2 x nrhs x n/2) product, a quarter in two (n/4 x nrhs x n/4) products, ... instead of
     // n/64 skinny 64-row products with K up to n.
-    std::vector<dm_gemm_desc> g;
+    DM_TRY(chain.gemm([&](std::vector<dm_gemm_desc>& g) {
     for (int i = 0; i < nbatch; ++i) {
       const dm_trsm_problem& P = probs[i];
       const int pn = (P.n + NB2 - 1) / NB2;
@@ -303,7 +311,7 @@ int dm_trsm_left_lower_batched(dm_ctx* ctx, const std::vector<dm_trsm_problem>& 
                                  false, P.B + (size_t)t0 * P.ldb, P.ldb, t1 - t0, P.nrhs, k2 - k1, -1.0, 1.0));
       }
     }
-    DM_TRY(dm_gemm_grouped_launch(ctx, g));
+    }));
     // (2) inside the super block: substitution on one 32-row half, a small GEMM, the other half
     for (int half = 0; half < 2; ++half) {
       // forward: halves in order 0, 1 ; backward: 1, 0
@@ -312,13 +320,14 @@ int dm_trsm_left_lower_batched(dm_ctx* ctx, const std::vector<dm_trsm_problem>& 
       int s32;
       if (!conjtrans) s32 = 2 * s + h;
       else s32 = 2 * s + half;  // backward kernel maps its step to the block row itself
-      if (!conjtrans)
+      if (chain.dry) {
+      } else if (!conjtrans)
         hipLaunchKernelGGL(diag_solve_kernel<false>, dim3(ct, nbatch), dim3(64), 0, ctx->stream, dd, s32, nblk32,
                            upper_only ? 1 : 0);
       else
         hipLaunchKernelGGL(diag_solve_kernel<true>, dim3(ct, nbatch), dim3(64), 0, ctx->stream, dd, s32, 2 * nblk, 0);
       if (half == 0) {
-        std::vector<dm_gemm_desc> g2;
+        DM_TRY(chain.gemm([&](std::vector<dm_gemm_desc>& g2) {
         for (int i = 0; i < nbatch; ++i) {
           const dm_trsm_problem& P = probs[i];
           const int pn = (P.n + NB2 - 1) / NB2;
@@ -343,9 +352,10 @@ int dm_trsm_left_lower_batched(dm_ctx* ctx, const std::vector<dm_trsm_problem>& 
                                       1, false, P.B + (size_t)k0 * P.ldb, P.ldb, NB, P.nrhs, nb2, -1.0, 1.0));
           }
         }
-        DM_TRY(dm_gemm_grouped_launch(ctx, g2));
+        }));
       }
     }
+  }
   }
   DM_HIP(ctx, hipGetLastError());
   return DM_OK;

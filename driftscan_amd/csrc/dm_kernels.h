@@ -5,6 +5,7 @@
 
 #include "dm_common.h"
 
+#include <deque>
 #include <functional>
 
 // ---------------------------------------------------------------------------
@@ -54,6 +55,36 @@ struct dm_gemm_plan {
 int dm_gemm_plan_build(const std::vector<dm_gemm_desc>& descs, dm_gemm_plan& plan);
 int dm_gemm_plans_upload(dm_ctx* ctx, const std::vector<const dm_gemm_plan*>& plans, std::vector<const char*>& dev);
 int dm_gemm_plan_run(dm_ctx* ctx, const dm_gemm_plan& plan, const char* dblob);
+
+// A chain of dependent launches (grouped products with other kernels in between) whose descriptors depend on sizes only:
+// the driver's loops run twice — a dry pass that records the plan of every product, one staged copy of all of them, then
+// the pass that launches.  `gemm(fill)` calls `fill(descs)` in the dry pass only.
+struct dm_gemm_chain {
+  dm_ctx* ctx;
+  bool dry = true;
+  std::deque<dm_gemm_plan> plans;
+  std::vector<const char*> dev;
+  size_t cur = 0;
+  explicit dm_gemm_chain(dm_ctx* c) : ctx(c) {}
+  template <typename F>
+  int gemm(F&& fill) {
+    if (dry) {
+      std::vector<dm_gemm_desc> g;
+      fill(g);
+      plans.emplace_back();
+      return dm_gemm_plan_build(g, plans.back());
+    }
+    const size_t i = cur++;
+    return dm_gemm_plan_run(ctx, plans[i], dev[i]);
+  }
+  int upload() {
+    std::vector<const dm_gemm_plan*> pp;
+    for (const auto& pl : plans) pp.push_back(&pl);
+    dry = false;
+    cur = 0;
+    return dm_gemm_plans_upload(ctx, pp, dev);
+  }
+};
 
 static inline dm_gemm_desc dm_gemm_make(const cplx* A, int rsA, int csA, bool conjA, const void* B, int rsB, int csB,
                                         bool conjB, cplx* C, int ldc, int M, int N, int K, double alpha = 1.0,

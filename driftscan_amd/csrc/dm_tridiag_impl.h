@@ -2446,6 +2446,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
         hipLaunchKernelGGL(larft_kernel, dim3((unsigned)tf.size()), dim3(64), lds, ctx->stream, d_tf);
       }
     }
+    std::deque<dm_gemm_plan> plans;
     for (int sz = TNB; sz < NBB; sz *= 2) {
       std::vector<dm_gemm_desc> ga, gb, gc;
       for (int p : ch) {
@@ -2469,9 +2470,10 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
           gc.push_back(dm_gemm_make(H, sz, 1, false, Tr, NBB, 1, false, T12, NBB, kl, kr, kr, -1.0, 0.0));
         }
       }
-      DM_TRY(dm_gemm_grouped_launch(ctx, ga));
-      DM_TRY(dm_gemm_grouped_launch(ctx, gb));
-      DM_TRY(dm_gemm_grouped_launch(ctx, gc));
+      for (const auto* gv : {&ga, &gb, &gc}) {
+        plans.emplace_back();
+        DM_TRY(dm_gemm_plan_build(*gv, plans.back()));
+      }
     }
     {
       std::vector<dm_gemm_desc> g;
@@ -2486,7 +2488,8 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
                                    Ut + off[p] + (size_t)k0 * n + r0, n, kb, nr, kb));
         }
       }
-      DM_TRY(dm_gemm_grouped_launch(ctx, g));
+      plans.emplace_back();
+      DM_TRY(dm_gemm_plan_build(g, plans.back()));
     }
     // ---- apply the blocks, last to first
     const int nblk = (nrefl_of(cmax) + NBB - 1) / NBB;
@@ -2509,8 +2512,19 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
                                   nx, kb, -1.0, 1.0));
       }
       if (g2.empty()) continue;
-      DM_TRY(dm_gemm_grouped_launch(ctx, g2));
-      DM_TRY(dm_gemm_grouped_launch(ctx, g4));
+      for (const auto* gv : {&g2, &g4}) {
+        plans.emplace_back();
+        DM_TRY(dm_gemm_plan_build(*gv, plans.back()));
+      }
+    }
+    // the merges of the T factors, U^H = T V^H and the two products per block are a chain of ~25 dependent launches:
+    // their descriptors travel in one staged copy, then the launches follow each other without a copy in between
+    {
+      std::vector<const dm_gemm_plan*> pp;
+      for (const auto& pl : plans) pp.push_back(&pl);
+      std::vector<const char*> dv;
+      DM_TRY(dm_gemm_plans_upload(ctx, pp, dv));
+      for (size_t i = 0; i < plans.size(); ++i) DM_TRY(dm_gemm_plan_run(ctx, plans[i], dv[i]));
     }
     {
       std::vector<dm_tdesc> tr;
