@@ -532,6 +532,12 @@ __global__ __launch_bounds__(256) void sb_band_extract_kernel(const sb_bmat* __r
   dm_stg(M.AB, idx, v);
 }
 
+// The back-transformation reads every diamond block (G, j), j < nb(G) = (n - 2 - G SBG) / SB + 1, whole.  The paired
+// chase writes complete rows, and a sweep of a full group reaches every block j <= nb(G) - 3 with a full-length vector;
+// what it may leave untouched lies in the last two blocks of a group (short or missing vectors at the end of the matrix)
+// and in the last group (missing sweeps): those are cleared here, 64 KB per group instead of the whole n^2 array.
+__global__ __launch_bounds__(256) void sb_vd_tail_zero_kernel(const struct sb_chase_mat* __restrict__ ms);
+
 // ---- S2: bulge chasing ---------------------------------------------------------------------------------------------
 //
 // Sweep s, task 0:   x = A[s+1 : s+1+SB, s]  ->  H_0 (zlarfg);  A[s+1, s] = beta = e[s];  D_0 <- H_0^H D_0 H_0
@@ -1046,13 +1052,13 @@ __device__ __forceinline__ bool sb_chase_E(const sb_chase_mat& M, __amdgpu_buffe
       if (lane == 0) box->tau[slot] = tau;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) sb_lds_st(&box->seq, j + 1);
+      // (the whole SBW-wide row of the diamond block in one store, zeros outside the vector: nothing has to clear
+      // the reflector array beforehand — see sb_vd_tail_zero_kernel for the slots no sweep reaches)
       const size_t blk = (size_t)G * M.jb + j;
-      if (bc == 0) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          const int rr = br + 8 * a;
-          if (rr < nr) dm_stg(M.Vd, (blk * SBG + gi) * SBW + gi + rr, vrow[a]);
-        }
+      {
+        const int o = lane - gi;
+        const cplx vv = (o >= 0 && o < SB) ? box->v[slot][o] : make_double2(0.0, 0.0);
+        dm_stg(M.Vd, (blk * SBG + gi) * SBW + lane, vv);
       }
       if (lane == 0) M.tau2[blk * SBG + gi] = tau;
       // the vector by columns for the next block: straight from the mailbox (this wave wrote it)
@@ -1251,6 +1257,17 @@ __global__ __launch_bounds__(128 * NP) void sb_chase2_kernel(const sb_chase_mat*
         }
       }
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void sb_vd_tail_zero_kernel(const sb_chase_mat* __restrict__ ms) {
+  const sb_chase_mat M = ms[blockIdx.y];
+  const int n = M.n, G = blockIdx.x;
+  if (n < 2 || G * SBG > n - 2) return;
+  const int nb = (n - 2 - G * SBG) / SB + 1;
+  for (int j = max(0, nb - 2); j < nb; ++j) {
+    cplx* dst = M.Vd + ((size_t)G * M.jb + j) * SBG * SBW;
+    for (int idx = threadIdx.x; idx < SBG * SBW; idx += 256) dm_stg(dst, idx, make_double2(0.0, 0.0));
   }
 }
 

@@ -1840,7 +1840,12 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
     sb_chase_mat* d_cmat = dm_ws_upload(ctx, cm);
     if (!d_sm || !d_dm || !d_bm || !d_cmat) return DM_ENOMEM;
     DM_TRY(dm_fill_zero(ctx, Tbig, sizeof(cplx) * tottb));
-    DM_TRY(dm_fill_zero(ctx, sbVd, sizeof(cplx) * totvd));
+    {
+      // the paired chase writes whole rows of the reflector array: only the slots no sweep reaches are cleared
+      static const bool pairs = !getenv("DM_SB_NOPAIRS") && !getenv("DM_SB_FULLFILL");
+      if (!pairs) DM_TRY(dm_fill_zero(ctx, sbVd, sizeof(cplx) * totvd));
+      else hipLaunchKernelGGL(sb_vd_tail_zero_kernel, dim3((cmax + SBG - 1) / SBG, nc), dim3(256), 0, ctx->stream, d_cmat);
+    }
     DM_TRY(dm_fill_zero(ctx, sbTau2, sizeof(cplx) * tott2));
     hipLaunchKernelGGL(sb_diag_tiles_kernel, dim3((cmax + 127) / 128, nc), dim3(256), 0, ctx->stream, d_dm);
     // ---- S1: dense -> band, one panel of SB columns at a time, all matrices in lock-step
