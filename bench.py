@@ -272,8 +272,9 @@ def _svd_kl_group(bt, kl, beam_all, ms, m0=0):
     sv = res["singularvalues"].cpu().numpy()
     ctx.sync()
     t1 = time.perf_counter()
+    views = bt._register_sv(ms, sv)
     for i, mi in enumerate(ms):
-        bt._dev[mi] = dict(beam_svd=res["beam_svd"][i], beam_ut=res["beam_ut"][i], singularvalues=sv[i])
+        bt._dev[mi] = dict(beam_svd=res["beam_svd"][i], beam_ut=res["beam_ut"][i], singularvalues=views[i])
     out = []
     nkeep = {}
     for batch in kl._batches(list(ms)):

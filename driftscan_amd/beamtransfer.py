@@ -377,9 +377,10 @@ class BeamTransfer(config.Reader):
                         fs.attrs["m"] = mi
                         fs.attrs["frequencies"] = tel.frequencies
 
+            views = self._register_sv(batch, sv_host)
             for i, mi in enumerate(batch):
-                self._sv_host[mi] = sv_host[i]
-                self._dev[mi] = dict(beam_svd=res["beam_svd"][i], beam_ut=res["beam_ut"][i], singularvalues=sv_host[i])
+                self._sv_host[mi] = views[i]
+                self._dev[mi] = dict(beam_svd=res["beam_svd"][i], beam_ut=res["beam_ut"][i], singularvalues=views[i])
                 if not storage.discard():
                     storage.submit(write_svd, mi, host["beam_svd"][i], None if skip_svd_inv else host["invbeam_svd"][i],
                                    host["beam_ut"][i], sv_host[i])
@@ -446,9 +447,27 @@ class BeamTransfer(config.Reader):
         if hit is not None and hit[0] is sv and hit[1] == self.svcut:
             return hit[2], hit[3]
         svnum = (sv > sv.max() * self.svcut).sum(axis=1)
-        svbounds = np.cumsum(np.insert(svnum, 0, 0))
+        svbounds = np.zeros(svnum.size + 1, dtype=svnum.dtype)
+        np.cumsum(svnum, out=svbounds[1:])
         memo[mi] = (sv, self.svcut, svnum, svbounds)
         return svnum, svbounds
+
+    def _register_sv(self, ms, sv_all):
+        """Per-m views of the (len(ms), nfreq, svd_len) singular values of a batch, with the (svnum, svbounds) of every m
+        computed in one vectorised pass — the KL stage asks for them several times per m, and 10^2..10^3 tiny numpy
+        calls between two stages are a millisecond of idle GPU."""
+        sv_all = np.asarray(sv_all)
+        memo = self.__dict__.setdefault("_svnum_memo", {})
+        top = sv_all.reshape(sv_all.shape[0], -1).max(axis=1) if sv_all.size else np.zeros(sv_all.shape[0])
+        svnum = (sv_all > (top * self.svcut)[:, None, None]).sum(axis=2)
+        bounds = np.zeros((sv_all.shape[0], sv_all.shape[1] + 1), dtype=svnum.dtype)
+        np.cumsum(svnum, axis=1, out=bounds[:, 1:])
+        views = []
+        for i, mi in enumerate(ms):
+            v = sv_all[i]
+            memo[mi] = (v, self.svcut, svnum[i], bounds[i])
+            views.append(v)
+        return views
 
     def _svd_freq_iter(self, mi):
         num = self._svd_num(mi)[0]

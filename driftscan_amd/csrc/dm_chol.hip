@@ -254,30 +254,20 @@ int dm_potrf_batched(dm_ctx* ctx, const std::vector<dm_mat>& mats, int* info_dev
   return DM_OK;
 }
 
-int dm_trsm_left_lower_batched(dm_ctx* ctx, const std::vector<dm_trsm_problem>& probs, bool conjtrans, bool upper_only) {
-  // upper_only (forward solves with nrhs == n only): X = L^-1 B is wanted on and above the diagonal only —
-  // row block i then needs the rows j < i at columns >= i, which lie above the diagonal too, so
-  // every update and substitution simply starts at the first column of its row block (1/3 of the flops).
-  if (conjtrans) upper_only = false;
+namespace {
+// one pass over the launches of a batched solve: the dry pass of `chain` records the grouped products, the other launches
+int trsm_pass(dm_ctx* ctx, const std::vector<dm_trsm_problem>& probs, bool conjtrans, bool upper_only, dm_gemm_chain& chain,
+              const trsm_desc* dd) {
   const int nbatch = (int)probs.size();
-  if (nbatch == 0) return DM_OK;
-  std::vector<trsm_desc> ds(nbatch);
   int maxn = 0, maxrhs = 0;
   for (int i = 0; i < nbatch; ++i) {
-    ds[i] = trsm_desc{probs[i].L, probs[i].ldl, probs[i].n, probs[i].B, probs[i].ldb, probs[i].nrhs};
     maxn = std::max(maxn, probs[i].n);
     maxrhs = std::max(maxrhs, probs[i].nrhs);
   }
-  if (maxn == 0 || maxrhs == 0) return DM_OK;
-  trsm_desc* dd = dm_ws_upload(ctx, ds);
-  if (!dd) return DM_ENOMEM;
   const int ct = (maxrhs + 63) / 64;
   const int NB2 = 2 * NB;
   const int nblk = (maxn + NB2 - 1) / NB2;   // 64-row super blocks
   const int nblk32 = (maxn + NB - 1) / NB;   // the substitution kernels still count 32-row blocks
-  dm_gemm_chain chain(ctx);   // two passes: record the descriptors of every update, one copy, then launch
-  for (int pass = 0; pass < 2; ++pass) {
-  if (pass == 1) DM_TRY(chain.upload());
   for (int s = 0; s < nblk; ++s) {
     // (1) GEMM updates in the order of the recursive algorithm (solve the first half, update the
     // second half with ONE product, solve the second half), unrolled: before super block u is
@@ -356,7 +346,44 @@ int dm_trsm_left_lower_batched(dm_ctx* ctx, const std::vector<dm_trsm_problem>& 
       }
     }
   }
-  }
+  return DM_OK;
+}
+}  // namespace
+
+// The products of a solve depend on sizes and addresses only: `build` runs the dry pass (host work that can be done
+// while the GPU is still busy with whatever decides if the solve happens at all), `run` sends the descriptors and launches.
+int dm_trsm_plan_build(dm_ctx* ctx, const std::vector<dm_trsm_problem>& probs, bool conjtrans, bool upper_only, dm_trsm_plan& plan) {
+  // upper_only (forward solves with nrhs == n only): X = L^-1 B is wanted on and above the diagonal only —
+  // row block i then needs the rows j < i at columns >= i, which lie above the diagonal too, so
+  // every update and substitution simply starts at the first column of its row block (1/3 of the flops).
+  if (conjtrans) upper_only = false;
+  plan.probs = probs;
+  plan.conjtrans = conjtrans;
+  plan.upper_only = upper_only;
+  plan.chain.reset(new dm_gemm_chain(ctx));
+  plan.empty = true;
+  for (const auto& P : probs)
+    if (P.n > 0 && P.nrhs > 0) plan.empty = false;
+  if (plan.empty) return DM_OK;
+  return trsm_pass(ctx, plan.probs, conjtrans, upper_only, *plan.chain, nullptr);
+}
+
+int dm_trsm_plan_run(dm_ctx* ctx, dm_trsm_plan& plan) {
+  if (plan.empty || !plan.chain) return DM_OK;
+  const int nbatch = (int)plan.probs.size();
+  std::vector<trsm_desc> ds(nbatch);
+  for (int i = 0; i < nbatch; ++i)
+    ds[i] = trsm_desc{plan.probs[i].L, plan.probs[i].ldl, plan.probs[i].n, plan.probs[i].B, plan.probs[i].ldb, plan.probs[i].nrhs};
+  trsm_desc* dd = dm_ws_upload(ctx, ds);
+  if (!dd) return DM_ENOMEM;
+  DM_TRY(plan.chain->upload());
+  DM_TRY(trsm_pass(ctx, plan.probs, plan.conjtrans, plan.upper_only, *plan.chain, dd));
   DM_HIP(ctx, hipGetLastError());
   return DM_OK;
+}
+
+int dm_trsm_left_lower_batched(dm_ctx* ctx, const std::vector<dm_trsm_problem>& probs, bool conjtrans, bool upper_only) {
+  dm_trsm_plan plan;
+  DM_TRY(dm_trsm_plan_build(ctx, probs, conjtrans, upper_only, plan));
+  return dm_trsm_plan_run(ctx, plan);
 }

@@ -6,6 +6,7 @@
 #include "dm_common.h"
 
 #include <deque>
+#include <memory>
 #include <functional>
 
 // ---------------------------------------------------------------------------
@@ -151,7 +152,8 @@ int dm_jacobi_herm(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, d
 // (natural, unsorted order) are handed to `pick`, which returns the indices of the eigenvectors to
 // back-transform in the order the rows of W shall have.  Only those rows of W are written
 // (rows [0, nsel[p])); the back-transformation and everything downstream then cost nsel/n of the
-// full amount.  `evals` still receives ALL eigenvalues in natural order.
+// full amount.  `evals` still receives ALL eigenvalues in natural order.  `pick` is called from several host threads
+// at once, each call with a different p: it may only touch state that belongs to problem p.
 struct dm_eig_select {
   std::function<void(int p, const double* ev, int n, std::vector<int>& cols)> pick;
   std::vector<int> nsel;  // out
@@ -181,6 +183,15 @@ struct dm_trsm_problem {
   cplx* B; int ldb; int nrhs;
 };
 int dm_trsm_left_lower_batched(dm_ctx* ctx, const std::vector<dm_trsm_problem>& probs, bool conjtrans, bool upper_only = false);
+// the same in two steps: build = host-only dry pass over the chain of launches, run = one descriptor copy + the launches
+struct dm_gemm_chain;
+struct dm_trsm_plan {
+  std::vector<dm_trsm_problem> probs;
+  bool conjtrans = false, upper_only = false, empty = true;
+  std::shared_ptr<dm_gemm_chain> chain;
+};
+int dm_trsm_plan_build(dm_ctx* ctx, const std::vector<dm_trsm_problem>& probs, bool conjtrans, bool upper_only, dm_trsm_plan& plan);
+int dm_trsm_plan_run(dm_ctx* ctx, dm_trsm_plan& plan);
 
 // ---------------------------------------------------------------------------
 // small utility kernels (dm_util.hip)

@@ -310,12 +310,54 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
   if (!d_bdA) return DM_ENOMEM;
   hipLaunchKernelGGL(flag_set_kernel, dim3((nblk + 255) / 256), dim3(256), 0, ctx->stream, zflag_dev, nblk, 1);
   hipLaunchKernelGGL(allzero_kernel, dim3(BLK_SPLIT, nblk), dim3(256), 0, ctx->stream, d_bdA, zflag_dev);
+  // ---- Cholesky of B (on a copy, the rescue needs B itself)
+  auto factor_launch = [&](const std::vector<int>& blks) -> int {
+    std::vector<dm_mat> mats;
+    std::vector<dm_cdesc> cp;
+    for (int b : blks) {
+      cp.push_back(dm_cdesc{B + off_host[b], Lw + loff[b], sizeof(cplx) * (size_t)n_host[b] * n_host[b]});
+      mats.push_back(dm_mat{Lw + loff[b], n_host[b], n_host[b]});
+    }
+    DM_TRY(dm_copy_batched(ctx, cp));
+    return dm_potrf_batched(ctx, mats, info_dev);
+  };
+  auto factor = [&](const std::vector<int>& blks, std::vector<int>& info) -> int {
+    DM_TRY(factor_launch(blks));
+    info.resize(blks.size());
+    if (!blks.empty()) DM_TRY(dm_download(ctx, info.data(), info_dev, sizeof(int) * blks.size()));
+    return DM_OK;
+  };
+  // The flags of the all-zero test and of the factorisation come back in ONE wait: the factorisation of every
+  // non-empty block is queued before anything is read (an all-zero block fails it harmlessly — its factor is never
+  // used), and the host builds the launch chains of the two triangular solves while the GPU is busy with it.
+  auto trsm_lists = [&](const std::vector<int>& blks, std::vector<dm_trsm_problem>& t1, std::vector<dm_trsm_problem>& t2) {
+    t1.clear();
+    t2.clear();
+    for (int b : blks) {
+      t1.push_back(dm_trsm_problem{Lw + loff[b], n_host[b], n_host[b], A + off_host[b], n_host[b], n_host[b]});
+      t2.push_back(dm_trsm_problem{Lw + loff[b], n_host[b], n_host[b], Tw + loff[b], n_host[b], n_host[b]});
+    }
+  };
+  std::vector<int> cand;
+  for (int b = 0; b < nblk; ++b)
+    if (n_host[b] > 0) cand.push_back(b);
+  DM_TRY(factor_launch(cand));
+  dm_trsm_plan plan1, plan2;
+  {
+    std::vector<dm_trsm_problem> t1, t2;
+    trsm_lists(cand, t1, t2);
+    DM_TRY(dm_trsm_plan_build(ctx, t1, false, false, plan1));   // X = L^-1 A
+    DM_TRY(dm_trsm_plan_build(ctx, t2, false, true, plan2));    // Y = L^-1 X^H, on and above the diagonal
+  }
   std::vector<int> zflag(nblk);
   DM_TRY(dm_download(ctx, zflag.data(), zflag_dev, sizeof(int) * nblk));
+  std::vector<int> info_c(cand.size());
+  if (!cand.empty()) DM_TRY(dm_download(ctx, info_c.data(), info_dev, sizeof(int) * cand.size()));
 
   std::vector<int> work;  // blocks that go through the solver
-  for (int b = 0; b < nblk; ++b) {
-    if (n_host[b] == 0) continue;
+  std::vector<int> info;
+  for (size_t i = 0; i < cand.size(); ++i) {
+    const int b = cand[i];
     if (zflag[b]) {
       DM_TRY(dm_fill_zero(ctx, evals_dev + evoff_host[b], sizeof(double) * n_host[b]));
       DM_TRY(dm_set_identity(ctx, E + off_host[b], n_host[b], n_host[b]));
@@ -325,25 +367,15 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
       }
     } else {
       work.push_back(b);
+      info.push_back(info_c[i]);
     }
   }
-
-  // ---- Cholesky of B (on a copy, the rescue needs B itself)
-  auto factor = [&](const std::vector<int>& blks, std::vector<int>& info) -> int {
-    std::vector<dm_mat> mats;
-    std::vector<dm_cdesc> cp;
-    for (int b : blks) {
-      cp.push_back(dm_cdesc{B + off_host[b], Lw + loff[b], sizeof(cplx) * (size_t)n_host[b] * n_host[b]});
-      mats.push_back(dm_mat{Lw + loff[b], n_host[b], n_host[b]});
-    }
-    DM_TRY(dm_copy_batched(ctx, cp));
-    DM_TRY(dm_potrf_batched(ctx, mats, info_dev));
-    info.resize(blks.size());
-    if (!blks.empty()) DM_TRY(dm_download(ctx, info.data(), info_dev, sizeof(int) * blks.size()));
-    return DM_OK;
-  };
-  std::vector<int> info;
-  DM_TRY(factor(work, info));
+  if (work.size() != cand.size()) {  // some block took the shortcut: the solves run on the others only
+    std::vector<dm_trsm_problem> t1, t2;
+    trsm_lists(work, t1, t2);
+    DM_TRY(dm_trsm_plan_build(ctx, t1, false, false, plan1));
+    DM_TRY(dm_trsm_plan_build(ctx, t2, false, true, plan2));
+  }
   std::vector<int> bad;
   for (size_t i = 0; i < work.size(); ++i)
     if (info[i] != 0) bad.push_back(work[i]);
@@ -390,21 +422,13 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
 
   // ---- C = L^-1 A L^-H
   {
-    std::vector<dm_trsm_problem> t1, t2;
-    for (int b : work) t1.push_back(dm_trsm_problem{Lw + loff[b], n_host[b], n_host[b], A + off_host[b], n_host[b], n_host[b]});
-    DM_TRY(dm_trsm_left_lower_batched(ctx, t1, false));  // X = L^-1 A
+    DM_TRY(dm_trsm_plan_run(ctx, plan1));  // X = L^-1 A
     std::vector<dm_tdesc> tr;
-    std::vector<dm_mat> hm;
-    for (int b : work) {
-      tr.push_back(dm_tdesc{A + off_host[b], n_host[b], Tw + loff[b], n_host[b], n_host[b], n_host[b]});
-      t2.push_back(dm_trsm_problem{Lw + loff[b], n_host[b], n_host[b], Tw + loff[b], n_host[b], n_host[b]});
-      hm.push_back(dm_mat{Tw + loff[b], n_host[b], n_host[b]});
-    }
+    for (int b : work) tr.push_back(dm_tdesc{A + off_host[b], n_host[b], Tw + loff[b], n_host[b], n_host[b], n_host[b]});
     DM_TRY(dm_conj_transpose_batched(ctx, tr));
     // Y = L^-1 X^H = C^H = C, on and above the diagonal only: the eigensolver reads the upper
     // triangle (LAPACK's zhegst/zheevd with one `uplo` do the same), so no symmetrisation pass either
-    DM_TRY(dm_trsm_left_lower_batched(ctx, t2, false, true));
-    (void)hm;
+    DM_TRY(dm_trsm_plan_run(ctx, plan2));
   }
 
   // ---- Hermitian eigendecomposition C = W^H diag(ev) W.  The eigenvalues come back to the host

@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <deque>
+#include <thread>
 
 // The panel width is a compile-time constant of the kernels (LDS arrays, T-factor layout): the body is
 // compiled twice.  Narrow panels halve the traffic on the panel vectors V, W (a third of what trd_symv and

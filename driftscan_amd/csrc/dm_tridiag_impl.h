@@ -2359,11 +2359,34 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       std::vector<int> hidx;
       std::vector<size_t> ioff(np, 0), zoff(np, 0);
       size_t ztot = 0;
-      std::vector<int> cols;
-      for (int p : ch) {
+      // The callback sorts the spectrum of a matrix: a millisecond of host time for a batch of 10^2 matrices, during
+      // which the GPU has nothing queued — the matrices are independent, so a few host threads share them
+      // (the callback writes per-matrix state only; see dm_eig_select).
+      std::vector<std::vector<int>> colsv(ch.size());
+      {
+        size_t work = 0;
+        for (int p : ch) work += (size_t)probs[p].n;
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int nth = (work >= 16384 && ch.size() >= 8) ? (int)std::min<size_t>(std::min<unsigned>(8u, std::max(1u, hw / 2)), ch.size()) : 1;
+        auto run = [&](int t) {
+          for (size_t i = t; i < ch.size(); i += nth) {
+            const int p = ch[i];
+            if (probs[p].n > 0) sel->pick(p, hev.data() + offn[p], probs[p].n, colsv[i]);
+          }
+        };
+        if (nth == 1) {
+          run(0);
+        } else {
+          std::vector<std::thread> th;
+          for (int t = 1; t < nth; ++t) th.emplace_back(run, t);
+          run(0);
+          for (auto& t : th) t.join();
+        }
+      }
+      for (size_t ci = 0; ci < ch.size(); ++ci) {
+        const int p = ch[ci];
         const int n = probs[p].n;
-        cols.clear();
-        if (n > 0) sel->pick(p, hev.data() + offn[p], n, cols);
+        const std::vector<int>& cols = colsv[ci];
         for (int c : cols) DM_ARG(ctx, c >= 0 && c < n);
         ioff[p] = hidx.size();
         hidx.insert(hidx.end(), cols.begin(), cols.end());

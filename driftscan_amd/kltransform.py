@@ -170,9 +170,22 @@ class KLTransform(config.Reader):
         if self.inverse:
             inv = self._inverse_device(ctx, evecs, Nk, ndofs, off, ac, [ev_h[evoff[i] : evoff[i + 1]] for i in range(len(ms))])
         if not to_host:
-            return [(evals[evoff[i] : evoff[i] + int(ndofs[i])],
-                     evecs[off[i] : off[i] + int(ndofs[i]) ** 2].view(int(ndofs[i]), int(ndofs[i])),
-                     None if inv is None else inv[off[i] : off[i] + int(ndofs[i]) ** 2].view(int(ndofs[i]), int(ndofs[i])),
+            nn = [int(n) for n in ndofs]
+            sq = [n * n for n in nn]
+            if all(int(off[i + 1]) == int(off[i]) + sq[i] for i in range(len(ms) - 1)):
+                # blocks stored back to back (the usual case): the per-m views come out of one split call each — a
+                # few hundred tensor slicings in Python are a millisecond at the end of every batch
+                import torch
+
+                o0 = int(off[0]) if len(ms) else 0
+                evs = torch.split(evals[int(evoff[0]) : int(evoff[0]) + sum(nn)], nn)
+                vecs = torch.split(evecs[o0 : o0 + sum(sq)], sq)
+                invs = None if inv is None else torch.split(inv[o0 : o0 + sum(sq)], sq)
+                return [(evs[i], vecs[i].view(nn[i], nn[i]), None if invs is None else invs[i].view(nn[i], nn[i]),
+                         {"ac": float(ac[i])}) for i in range(len(ms))]
+            return [(evals[evoff[i] : evoff[i] + nn[i]],
+                     evecs[off[i] : off[i] + sq[i]].view(nn[i], nn[i]),
+                     None if inv is None else inv[off[i] : off[i] + sq[i]].view(nn[i], nn[i]),
                      {"ac": float(ac[i])}) for i in range(len(ms))]
         out = []
         for i, mi in enumerate(ms):
