@@ -247,6 +247,11 @@ __global__ void bt_maps_c_kernel(ring_geo g, frame3 fr, int polarised, int ncol,
 // Algorithmic bytes per (pixel, column): 2 beams x ncomp x 8 B from L1/L2 (beams are shared by all baselines of a
 // frequency), 16 P nm / npix-th of the G row written — compute-bound, see DESIGN.md section 4.5.
 struct fdft_col { double u, v, pre; int bi, bj; };   // pre = 1 / sqrt(Omega_i Omega_j); bi < 0: padding
+__global__ __launch_bounds__(256) void bt_fdft_pre_kernel(fdft_col* __restrict__ cols, int ncol, const double* __restrict__ omega) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncol) return;
+  cols[c].pre = 1.0 / sqrt(omega[cols[c].bi] * omega[cols[c].bj]);
+}
 template <int P, int NMG, int NCG>
 __global__ __launch_bounds__(256) void bt_fused_dft_kernel(ring_geo g, frame3 fr, const double* __restrict__ beams, size_t bstride,
                                                            const fdft_col* __restrict__ cols, int ncol16, int m_lo, int cnt,
@@ -935,16 +940,17 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
     if (!omega) return DM_ENOMEM;
     hipLaunchKernelGGL(bt_omega_kernel, dim3(syn->nbeam), dim3(256), 0, ctx->stream, gh.g, fr, syn->beams_dev, ncomp, bstride,
                        omega);
-    std::vector<double> om(syn->nbeam);
-    DM_TRY(dm_download(ctx, om.data(), omega, sizeof(double) * syn->nbeam));
+    // (the solid angles stay on the device: the per-column factor 1 / sqrt(Omega_i Omega_j) is filled in by a small
+    // kernel, so the host never waits inside the call)
     const int ncol16 = (ncol + 15) / 16;
     std::vector<fdft_col> fc((size_t)ncol16 * 16, fdft_col{0.0, 0.0, 0.0, -1, -1});
     for (int c = 0; c < ncol; ++c) {
       const int bi = syn->bi_host[c], bj = syn->bj_host[c];
       DM_ARG(ctx, bi >= 0 && bi < syn->nbeam && bj >= 0 && bj < syn->nbeam);
-      fc[c] = fdft_col{syn->uv_host[2 * c], syn->uv_host[2 * c + 1], 1.0 / std::sqrt(om[bi] * om[bj]), bi, bj};
+      fc[c] = fdft_col{syn->uv_host[2 * c], syn->uv_host[2 * c + 1], 0.0, bi, bj};
     }
     fdft_col* d_fc = dm_ws_upload(ctx, fc);
+    if (d_fc) hipLaunchKernelGGL(bt_fdft_pre_kernel, dim3((ncol + 255) / 256), dim3(256), 0, ctx->stream, d_fc, ncol, omega);
     double* d_rw = nullptr;
     if (ring_w_host) {
       std::vector<double> rw(ring_w_host, ring_w_host + nring);
@@ -1136,7 +1142,9 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
       DM_TRY(legendre_analysis(true));
     }
   }
-  DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // The fused path returns once everything is queued (stream-ordered with the caller's later work on the context's stream,
+  // workspace re-use included: dm_ws_release); the refinement path keeps its wait.
+  if (niter > 0 || !fused) DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   dm_ws_release(ctx, mark);
   return DM_OK;
 }

@@ -15,6 +15,7 @@
 #include "../../include/driftmi.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 
 namespace {
@@ -341,7 +342,10 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
   std::vector<int> cand;
   for (int b = 0; b < nblk; ++b)
     if (n_host[b] > 0) cand.push_back(b);
+  static const bool host_times = getenv("DM_TIME_HOST") != nullptr;  // debugging aid: host time of the planning steps
+  const auto ht0 = std::chrono::steady_clock::now();
   DM_TRY(factor_launch(cand));
+  const auto ht1 = std::chrono::steady_clock::now();
   dm_trsm_plan plan1, plan2;
   {
     std::vector<dm_trsm_problem> t1, t2;
@@ -349,8 +353,15 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
     DM_TRY(dm_trsm_plan_build(ctx, t1, false, false, plan1));   // X = L^-1 A
     DM_TRY(dm_trsm_plan_build(ctx, t2, false, true, plan2));    // Y = L^-1 X^H, on and above the diagonal
   }
+  const auto ht2 = std::chrono::steady_clock::now();
   std::vector<int> zflag(nblk);
   DM_TRY(dm_download(ctx, zflag.data(), zflag_dev, sizeof(int) * nblk));
+  if (host_times) {
+    const auto ht3 = std::chrono::steady_clock::now();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "HOSTTIME eigh_gen: potrf plan+launch %.3f ms, trsm plans %.3f ms, wait for flags %.3f ms\n", ms(ht0, ht1),
+            ms(ht1, ht2), ms(ht2, ht3));
+  }
   std::vector<int> info_c(cand.size());
   if (!cand.empty()) DM_TRY(dm_download(ctx, info_c.data(), info_dev, sizeof(int) * cand.size()));
 

@@ -6,6 +6,10 @@ Restated from Gorski et al. (2005); replaces ``cora.util.hputil.ang_positions`` 
 import numpy as np
 
 
+import functools
+
+
+@functools.lru_cache(maxsize=None)
 def nside_for_lmax(lmax, accuracy_boost=1):
     return int(2 ** (accuracy_boost + np.ceil(np.log((lmax + 1) / 3.0) / np.log(2.0))))
 
@@ -20,6 +24,7 @@ def ring_z(nside):
     return np.where(i < nside, cap_n, np.where(i <= 3 * nside, belt, cap_s))
 
 
+@functools.lru_cache(maxsize=16)
 def ring_trig(nside):
     """(cos theta, sin theta) per ring, through theta = arccos(z) as pix2ang does."""
     theta = np.arccos(ring_z(nside))

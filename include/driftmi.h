@@ -311,6 +311,8 @@ int dm_bt_sht_opts(dm_ctx* ctx, int nside, const double* ring_cth_host, const do
 /* dm_bt_columns: dm_bt_maps + dm_bt_sht_range in one call — the visibility response of every pixel is formed in
  * registers inside the ring transform (v_mfma_f64_4x4x4 over the pixels of a ring) and the (ncol, P, npix) Stokes
  * maps are never written to memory; pixels below the horizon are skipped.  Arguments as for those two calls.
+ * Returns when the work is queued on the context's stream (host arrays are copied before it returns): call dm_ctx_sync
+ * before reading beam_m_dev from the host or from another stream.
  * Replaces: _beam_map_single + _transfer_single + the +/-m fold (drift/core/telescope.py:1156-1193, :1268-1316;
  * drift/util/_fast_tools.pyx:18-164; drift/core/beamtransfer.py:620-624). */
 int dm_bt_columns(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, const double* frame_host,
