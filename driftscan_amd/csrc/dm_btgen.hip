@@ -76,11 +76,9 @@ __device__ __forceinline__ double spline_eval(const double* __restrict__ x, cons
 }
 
 // kind 0: unpolarised amplitude (1 component); 1: X dipole; 2: Y dipole (2 components theta, phi)
-__global__ void bt_beam_kernel(ring_geo g, frame3 fr, int kind, const double* __restrict__ tx,
-                               const double* __restrict__ ty, const double* __restrict__ ty2, int ntab,
-                               double alpha_ns, double* __restrict__ out) {
-  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pix >= g.npix) return;
+__device__ __forceinline__ void bt_beam_pixel(const ring_geo& g, const frame3& fr, int kind, const double* __restrict__ tx,
+                                              const double* __restrict__ ty, const double* __restrict__ ty2, int ntab,
+                                              double alpha_ns, double* __restrict__ out, int pix) {
   const int r = ring_of_pixel(g, pix);
   const int j = pix - g.start[r];
   const double phi = g.phi0[r] + 2.0 * kPi * (double)j / (double)g.nphi[r];
@@ -110,6 +108,51 @@ __global__ void bt_beam_kernel(ring_geo g, frame3 fr, int kind, const double* __
   if (nrm == 0.0) nrm = 1.0;
   out[2 * (size_t)pix] = amp * pt / nrm;
   out[2 * (size_t)pix + 1] = amp * pp / nrm;
+}
+__global__ void bt_beam_kernel(ring_geo g, frame3 fr, int kind, const double* __restrict__ tx,
+                               const double* __restrict__ ty, const double* __restrict__ ty2, int ntab,
+                               double alpha_ns, double* __restrict__ out) {
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= g.npix) return;
+  bt_beam_pixel(g, fr, kind, tx, ty, ty2, ntab, alpha_ns, out, pix);
+}
+// several patterns in one launch: blockIdx.y = beam
+struct bt_beam_desc { int kind, ntab; const double* tx; const double* ty; const double* ty2; double alpha_ns; double* out; };
+__global__ void bt_beams_kernel(ring_geo g, frame3 fr, const bt_beam_desc* __restrict__ descs) {
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= g.npix) return;
+  const bt_beam_desc d = descs[blockIdx.y];
+  bt_beam_pixel(g, fr, d.kind, d.tx, d.ty, d.ty2, d.ntab, d.alpha_ns, d.out, pix);
+}
+
+// the solid angle in two steps that keep the chip busy: NOMEGA partial sums per beam, then their sum in a fixed order
+constexpr int NOMEGA = 64;
+__global__ __launch_bounds__(256) void bt_omega_part_kernel(ring_geo g, const double* __restrict__ beams, int ncomp, size_t bstride,
+                                                            double* __restrict__ part) {
+  __shared__ double red[4];
+  const double* b = beams + (size_t)blockIdx.x * bstride;
+  const int per = (g.npix + NOMEGA - 1) / NOMEGA;
+  const int p0 = blockIdx.y * per, p1 = min(p0 + per, g.npix);
+  double s = 0.0;
+  for (int pix = p0 + threadIdx.x; pix < p1; pix += 256) {
+    double v = 0.0;
+    for (int c = 0; c < ncomp; ++c) {
+      const double x = b[(size_t)pix * ncomp + c];
+      v += x * x;
+    }
+    s += v;
+  }
+  s = dm_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[(size_t)blockIdx.x * NOMEGA + blockIdx.y] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void bt_omega_fin_kernel(const double* __restrict__ part, int nbeam, double scale, double* __restrict__ omega) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbeam) return;
+  double s = 0.0;
+  for (int i = 0; i < NOMEGA; ++i) s += part[(size_t)b * NOMEGA + i];
+  omega[b] = s * scale;
 }
 
 // omega[b] = (4 pi / npix) sum_pix h |beam_b|^2 ; one block per beam (beams already carry h)
@@ -798,13 +841,16 @@ int dm_bt_beams_cyl(dm_ctx* ctx, int nside, const double* ring_cth_host, const d
   double* dt = dm_ws_upload(ctx, tabs);
   if (!dt) return DM_ENOMEM;
   frame3 fr = make_frame(frame_host, frame_host + 3, frame_host + 6);
+  std::vector<bt_beam_desc> bd(nbeam);
   for (int b = 0; b < nbeam; ++b) {
     const int o = tab_off_host[b], nt = tab_off_host[b + 1] - o;
     const double th = tan(fwhm_ns_host[b] / 2.0);
     const double alpha = log(2.0) / (2.0 * th * th);
-    hipLaunchKernelGGL(bt_beam_kernel, dim3((gh.g.npix + 255) / 256), dim3(256), 0, ctx->stream, gh.g, fr, kind_host[b],
-                       dt + o, dt + ntot + o, dt + 2 * (size_t)ntot + o, nt, alpha, out_dev + (size_t)b * out_stride);
+    bd[b] = bt_beam_desc{kind_host[b], nt, dt + o, dt + ntot + o, dt + 2 * (size_t)ntot + o, alpha, out_dev + (size_t)b * out_stride};
   }
+  bt_beam_desc* d_bd = dm_ws_upload(ctx, bd);
+  if (!d_bd) return DM_ENOMEM;
+  hipLaunchKernelGGL(bt_beams_kernel, dim3((gh.g.npix + 255) / 256, nbeam), dim3(256), 0, ctx->stream, gh.g, fr, d_bd);
   DM_HIP(ctx, hipGetLastError());
   return DM_OK;
 }
@@ -937,9 +983,12 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
     const size_t bstride = (size_t)npix * ncomp;
     frame3 fr = make_frame(syn->frame_host, syn->frame_host + 3, syn->frame_host + 6);
     double* omega = dm_ws_alloc_t<double>(ctx, syn->nbeam);
-    if (!omega) return DM_ENOMEM;
-    hipLaunchKernelGGL(bt_omega_kernel, dim3(syn->nbeam), dim3(256), 0, ctx->stream, gh.g, fr, syn->beams_dev, ncomp, bstride,
-                       omega);
+    double* opart = dm_ws_alloc_t<double>(ctx, (size_t)syn->nbeam * NOMEGA);
+    if (!omega || !opart) return DM_ENOMEM;
+    hipLaunchKernelGGL(bt_omega_part_kernel, dim3(syn->nbeam, NOMEGA), dim3(256), 0, ctx->stream, gh.g, syn->beams_dev, ncomp,
+                       bstride, opart);
+    hipLaunchKernelGGL(bt_omega_fin_kernel, dim3((syn->nbeam + 63) / 64), dim3(64), 0, ctx->stream, opart, syn->nbeam,
+                       4.0 * kPi / (double)npix, omega);
     // (the solid angles stay on the device: the per-column factor 1 / sqrt(Omega_i Omega_j) is filled in by a small
     // kernel, so the host never waits inside the call)
     const int ncol16 = (ncol + 15) / 16;
