@@ -517,6 +517,30 @@ __global__ __launch_bounds__(256) void sb_diag_tiles_kernel(const sb_dmat* __res
   }
 }
 
+// S = T^H M1 for one matrix per workgroup, M1 given as `nslice` split-K slices (SB x SB each; nslice = 0: M1 itself):
+// the slice sum and the 32 x 32 x 32 product were two launches of their own in every panel.
+struct sb_s_desc { const cplx* T; int ldt; const cplx* M1; int nslice; cplx* S; };
+__global__ __launch_bounds__(256) void sb_s_kernel(const sb_s_desc* __restrict__ ds) {
+  const sb_s_desc D = ds[blockIdx.x];
+  __shared__ cplx sT[SB][SB + 1];
+  __shared__ cplx sM[SB][SB + 1];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < SB * SB; idx += 256) {
+    const int r = idx / SB, c = idx % SB;
+    sT[r][c] = dm_ldg(D.T, (size_t)r * D.ldt + c);
+    cplx m = dm_ldg(D.M1, (size_t)idx);
+    for (int sl = 1; sl < D.nslice; ++sl) m = cadd(m, dm_ldg(D.M1, (size_t)sl * SB * SB + idx));
+    sM[r][c] = m;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < SB * SB; idx += 256) {
+    const int i = idx / SB, j = idx % SB;
+    cplx acc = make_double2(0.0, 0.0);
+    for (int k = 0; k <= i; ++k) sb_cfma_ca(acc, sT[k][i], sM[k][j]);   // T upper triangular: (T^H)[i][k] = conj(T[k][i]), k <= i
+    dm_stg(D.S, (size_t)idx, acc);
+  }
+}
+
 // band extraction: AB[c][i] = A_math[c + i][c] = conj(C[c][c + i]), i <= SB; the bulge rows start at zero
 struct sb_bmat { const cplx* A; int lda; int n; cplx* AB; };
 __global__ __launch_bounds__(256) void sb_band_extract_kernel(const sb_bmat* __restrict__ ms) {

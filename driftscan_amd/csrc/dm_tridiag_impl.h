@@ -984,20 +984,39 @@ __global__ void zt_to_x_kernel(const cvt_mat* __restrict__ cs) {
 }
 
 // ---- T4 helper: T factor of a block of reflectors from its Gram matrix (zlarft, forward/columnwise) ----
-struct tf_mat { const cplx* G; const cplx* tau; cplx* T; int kb; int ldt; };  // G: TNB x TNB row-major; T: leading dimension ldt
+struct tf_mat {
+  cplx* G; const cplx* tau; cplx* T; int kb; int ldt;  // G: TNB x TNB row-major; T: leading dimension ldt
+  const cplx* part; int nslice;                         // nslice > 0: G = sum of nslice (kb x kb) slices at `part` (stored to G)
+};
+// The Gram matrix goes to LDS first (summed over the split-K slices if there are any): the recurrence then runs at LDS
+// latency — 32 dependent steps that each waited for a global load took 50 us per call.
 __global__ __launch_bounds__(64) void larft_kernel(const tf_mat* __restrict__ ts) {
   const tf_mat F = ts[blockIdx.x];
   extern __shared__ __align__(16) unsigned char larft_smem[];
   cplx (*T)[TNB + 1] = reinterpret_cast<cplx (*)[TNB + 1]>(larft_smem);
+  cplx (*Gl)[TNB + 1] = reinterpret_cast<cplx (*)[TNB + 1]>(larft_smem + sizeof(cplx) * TNB * (TNB + 1));
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < TNB * TNB; idx += 64) T[idx / TNB][idx % TNB] = make_double2(0.0, 0.0);
+  for (int idx = tid; idx < TNB * TNB; idx += 64) {
+    const int r = idx / TNB, c = idx % TNB;
+    T[r][c] = make_double2(0.0, 0.0);
+    cplx g = make_double2(0.0, 0.0);
+    if (r < F.kb && c < F.kb) {
+      if (F.nslice > 0) {
+        for (int sl = 0; sl < F.nslice; ++sl) g = cadd(g, F.part[((size_t)sl * F.kb + r) * F.kb + c]);
+        F.G[r * TNB + c] = g;
+      } else {
+        g = F.G[r * TNB + c];
+      }
+    }
+    Gl[r][c] = g;
+  }
   __syncthreads();
   for (int j = 0; j < F.kb; ++j) {
     const cplx tj = F.tau[j];
     // T[0:j, j] = -tau_j * T[0:j, 0:j] * G[0:j, j]
     if (tid < j) {
       cplx acc = make_double2(0.0, 0.0);
-      for (int c = tid; c < j; ++c) acc = cadd(acc, cmul(T[tid][c], F.G[c * TNB + j]));  // T upper triangular
+      for (int c = tid; c < j; ++c) acc = cadd(acc, cmul(T[tid][c], Gl[c][j]));  // T upper triangular
       acc = cmul(make_double2(-tj.x, -tj.y), acc);
       T[tid][j] = acc;
     }
@@ -1871,8 +1890,9 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
         }
       }
       // T factor of the panel (zlarft from the Gram matrix), straight into the slot the back-transformation reads
-      std::vector<dm_gemm_desc> gg, gx, gy1, gy2, gm, gs, gw, gh;
-      std::vector<sb_sum_desc> sg, sy, smm;
+      std::vector<dm_gemm_desc> gg, gx, gy1, gy2, gm, gw, gh;
+      std::vector<sb_sum_desc> sy;
+      std::vector<sb_s_desc> ssv;
       std::vector<tf_mat> tf;
       // split-K: the products with K = trailing size have few output tiles (one 32 x 32 tile per matrix for the Gram
       // matrices, one 32 x 128 tile per 128 columns of Y): cut K so that a launch carries ~1000 tiles
@@ -1906,6 +1926,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
         cplx* T = Tbig + offtb[p] + (size_t)(k0 / NBB) * NBB * NBB + (size_t)(k0 % NBB) * NBB + (k0 % NBB);
         cplx* pg = part_g + (size_t)p * SB * SB * 32;
         // Gram matrix G = V^H V (kb x kb, K = m)
+        int gram_slices = 0;
         if (SG == 1) {
           gg.push_back(dm_gemm_make(Vb, n, 1, true, Vb, 1, n, false, G, TNB, kb, kb, m));
         } else {
@@ -1913,9 +1934,9 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
           int ns = 0;
           for (int kk = 0; kk < m; kk += kc, ++ns)
             gg.push_back(dm_gemm_make(Vb + kk, n, 1, true, Vb + kk, 1, n, false, pg + (size_t)ns * kb * kb, kb, kb, kb, std::min(kc, m - kk)));
-          sg.push_back(sb_sum_desc{G, pg, ns, kb, kb, TNB, 1.0, 0.0});
+          gram_slices = ns;   // summed by the T-factor kernel
         }
-        tf.push_back(tf_mat{G, tau + offn[p] + k0, T, kb, NBB});
+        tf.push_back(tf_mat{G, tau + offn[p] + k0, T, kb, NBB, gram_slices ? pg : nullptr, gram_slices});
         // Xt = T^T Vp  (SB x m)
         gx.push_back(dm_gemm_make(T, 1, NBB, false, Vp + i0, n, 1, false, Xt + i0, n, SB, m, SB));
         // Yt = Xt A22 by 128-column blocks: stored part (rows >= block start, whole diagonal block) + mirrored part
@@ -1948,6 +1969,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
         cplx* M1 = sbM1 + (size_t)p * SB * SB;
         cplx* S = sbS + (size_t)p * SB * SB;
         // M1 = V^H Y, S = T^H M1, W = Y - V S / 2  (row-stored: Wp += -1/2 S^T Vp)
+        int m1_slices = 0;
         if (SG == 1) {
           gm.push_back(dm_gemm_make(Vp + i0, n, 1, true, Wp + i0, 1, n, false, M1, SB, SB, SB, m));
         } else {
@@ -1956,9 +1978,9 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
           for (int kk = 0; kk < m; kk += kc, ++ns)
             gm.push_back(dm_gemm_make(Vp + i0 + kk, n, 1, true, Wp + i0 + kk, 1, n, false, pg + (size_t)ns * SB * SB, SB, SB, SB,
                                       std::min(kc, m - kk)));
-          smm.push_back(sb_sum_desc{M1, pg, ns, SB, SB, SB, 1.0, 0.0});
+          m1_slices = ns;
         }
-        gs.push_back(dm_gemm_make(T, 1, NBB, true, M1, SB, 1, false, S, SB, SB, SB, SB));
+        ssv.push_back(sb_s_desc{T, NBB, m1_slices ? pg : M1, m1_slices, S});   // S = T^H (sum of the slices of M1)
         gw.push_back(dm_gemm_make(S, 1, SB, false, Vp + i0, n, 1, false, Wp + i0, n, SB, m, SB, -0.5, 1.0));
         // A22 -= V W^H + W V^H on the blocks on or above the diagonal (128-aligned origin a0)
         gh.push_back(dm_gemm_make(pp + a0, 1, n, false, pp + (size_t)n * TNB + a0, n, 1, true, C + (size_t)a0 * lda + a0, lda,
@@ -1966,17 +1988,16 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       }
       // every descriptor of the panel travels in ONE staged copy: the eight grouped products as plans, the three lists
       // of slice sums and the T-factor descriptors behind them
-      dm_gemm_plan pg, px, py1, py2, pm, pss, pw, ph;
+      dm_gemm_plan pg, px, py1, py2, pm, pw, ph;
       DM_TRY(dm_gemm_plan_build(gg, pg));
       DM_TRY(dm_gemm_plan_build(gx, px));
       DM_TRY(dm_gemm_plan_build(gy1, py1));
       DM_TRY(dm_gemm_plan_build(gy2, py2));
       DM_TRY(dm_gemm_plan_build(gm, pm));
-      DM_TRY(dm_gemm_plan_build(gs, pss));
       DM_TRY(dm_gemm_plan_build(gw, pw));
       DM_TRY(dm_gemm_plan_build(gh, ph));
       dm_gemm_plan extra;   // not a product: the raw arrays of the sum / larft kernels, carried by the same upload
-      size_t o_sg, o_sy, o_sm, o_tf;
+      size_t o_sy, o_ss, o_tf;
       {
         auto put = [&](const void* src, size_t bytes) {
           const size_t o = (extra.blob.size() + 15) & ~size_t(15);
@@ -1984,44 +2005,43 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
           if (bytes) std::memcpy(extra.blob.data() + o, src, bytes);
           return o;
         };
-        o_sg = put(sg.data(), sg.size() * sizeof(sb_sum_desc));
         o_sy = put(sy.data(), sy.size() * sizeof(sb_sum_desc));
-        o_sm = put(smm.data(), smm.size() * sizeof(sb_sum_desc));
+        o_ss = put(ssv.data(), ssv.size() * sizeof(sb_s_desc));
         o_tf = put(tf.data(), tf.size() * sizeof(tf_mat));
         if (extra.blob.empty()) extra.blob.resize(16);
       }
       std::vector<const char*> dv;
-      DM_TRY(dm_gemm_plans_upload(ctx, {&pg, &px, &py1, &py2, &pm, &pss, &pw, &ph, &extra}, dv));
+      DM_TRY(dm_gemm_plans_upload(ctx, {&pg, &px, &py1, &py2, &pm, &pw, &ph, &extra}, dv));
       auto launch_sums = [&](const std::vector<sb_sum_desc>& v, size_t o) -> int {
         if (v.empty()) return DM_OK;
         int mx = 0;
         for (const auto& d : v) mx = std::max(mx, d.rows * d.cols);
         hipLaunchKernelGGL(sb_sum_partials_kernel, dim3((mx + 255) / 256, (unsigned)v.size()), dim3(256), 0, ctx->stream,
-                           reinterpret_cast<const sb_sum_desc*>(dv[8] + o));
+                           reinterpret_cast<const sb_sum_desc*>(dv[7] + o));
         return DM_OK;
       };
       DM_TRY(dm_gemm_plan_run(ctx, pg, dv[0]));
-      DM_TRY(launch_sums(sg, o_sg));
       {
         static bool attr = false;
-        const size_t lds = sizeof(cplx) * TNB * (TNB + 1);
+        const size_t lds = 2 * sizeof(cplx) * TNB * (TNB + 1);
         if (!attr) {
           DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(larft_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           attr = true;
         }
         hipLaunchKernelGGL(larft_kernel, dim3((unsigned)tf.size()), dim3(64), lds, ctx->stream,
-                           reinterpret_cast<const tf_mat*>(dv[8] + o_tf));
+                           reinterpret_cast<const tf_mat*>(dv[7] + o_tf));
       }
       DM_TRY(dm_gemm_plan_run(ctx, px, dv[1]));
       DM_TRY(dm_gemm_plan_run(ctx, py1, dv[2]));
       DM_TRY(dm_gemm_plan_run(ctx, py2, dv[3]));
       DM_TRY(launch_sums(sy, o_sy));
       DM_TRY(dm_gemm_plan_run(ctx, pm, dv[4]));
-      DM_TRY(launch_sums(smm, o_sm));
-      DM_TRY(dm_gemm_plan_run(ctx, pss, dv[5]));
-      DM_TRY(dm_gemm_plan_run(ctx, pw, dv[6]));
-      DM_TRY(dm_gemm_plan_run(ctx, ph, dv[7]));
+      if (!ssv.empty())
+        hipLaunchKernelGGL(sb_s_kernel, dim3((unsigned)ssv.size()), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<const sb_s_desc*>(dv[7] + o_ss));
+      DM_TRY(dm_gemm_plan_run(ctx, pw, dv[5]));
+      DM_TRY(dm_gemm_plan_run(ctx, ph, dv[6]));
     }
     // ---- S2: band -> tridiagonal
     const char* dump = getenv("DM_SB_DUMP");  // debugging aid: the band and the tridiagonal of every matrix to files
@@ -2457,7 +2477,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
           cplx* G = Gs + offg[p] + (size_t)(k0 / TNB) * TNB * TNB;
           cplx* T = Tbig + offtb[p] + (size_t)(k0 / NBB) * NBB * NBB + (size_t)(k0 % NBB) * NBB + (k0 % NBB);
           g.push_back(dm_gemm_make(Vb, n, 1, true, Vb, 1, n, false, G, TNB, kb, kb, nr));
-          tf.push_back(tf_mat{G, tau + offn[p] + k0, T, kb, NBB});
+          tf.push_back(tf_mat{G, tau + offn[p] + k0, T, kb, NBB, nullptr, 0});
         }
       }
       if (!g.empty()) {
@@ -2465,7 +2485,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
         tf_mat* d_tf = dm_ws_upload(ctx, tf);
         if (!d_tf) return DM_ENOMEM;
         static bool attr = false;
-        const size_t lds = sizeof(cplx) * TNB * (TNB + 1);
+        const size_t lds = 2 * sizeof(cplx) * TNB * (TNB + 1);
         if (!attr) {
           DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(larft_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
