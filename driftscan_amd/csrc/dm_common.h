@@ -198,8 +198,10 @@ __device__ __forceinline__ double dm_mfma4(double a, double b, double c) {
 template <int CTRL>
 __device__ __forceinline__ double dm_dpp_f64(double v) {
   const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  // bound_ctrl = true: lanes without a source read 0 and the destination needs no initial value — with `false` the
+  // compiler writes the `old` operand first, one more v_mov per half (every control used here has a source for all lanes)
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 template <int S>
