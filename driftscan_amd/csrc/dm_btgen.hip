@@ -299,10 +299,10 @@ template <int P, int NMG, int NCG>
 __global__ __launch_bounds__(256) void bt_fused_dft_kernel(ring_geo g, frame3 fr, const double* __restrict__ beams, size_t bstride,
                                                            const fdft_col* __restrict__ cols, int ncol16, int m_lo, int cnt,
                                                            const double* __restrict__ ring_w, cplx* __restrict__ G, int ncp,
-                                                           int ring0) {
+                                                           const int* __restrict__ ring_list) {
   constexpr int NCOMP = P == 4 ? 2 : 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = ring0 + blockIdx.y;
+  const int r = ring_list ? ring_list[blockIdx.y] : (int)blockIdx.y;   // (the polar caps only, when the belt goes by FFT)
   const int cg0 = (blockIdx.x * 4 + wave) * NCG;          // first column group of this wave
   if (cg0 >= ncol16) return;                              // (wave-uniform; no workgroup barrier follows)
   const int mg0 = blockIdx.z * NMG;                       // first group of four m-values of this pass
@@ -459,12 +459,13 @@ __global__ __launch_bounds__(256) void bt_fused_dft_kernel(ring_geo g, frame3 fr
 template <int P, int NMG, int NCG>
 __global__ __launch_bounds__(256) void bt_fused_dft2_kernel(ring_geo g, frame3 fr, const double* __restrict__ beams, size_t bstride,
                                                             const fdft_col* __restrict__ cols, int ncol16, int m_lo, int cnt,
-                                                            const double* __restrict__ ring_w, cplx* __restrict__ G, int ncp) {
+                                                            const double* __restrict__ ring_w, cplx* __restrict__ G, int ncp,
+                                                            const int* __restrict__ ring_list) {
   constexpr int NCOMP = P == 4 ? 2 : 1;
   constexpr int QC = 4;  // quads per chunk = waves per workgroup
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r = blockIdx.y;
+  const int r = ring_list ? ring_list[blockIdx.y] : (int)blockIdx.y;
   const int cg0 = blockIdx.x * NCG;
   if (cg0 >= ncol16) return;  // uniform over the workgroup
   const int nm = 2 * cnt;
@@ -615,6 +616,164 @@ __global__ __launch_bounds__(256) void bt_fused_dft2_kernel(ring_geo g, frame3 f
       cplx* out = G + ((size_t)mm * g.nring + r) * ncp + (size_t)col * P;
 #pragma unroll
       for (int p = 0; p < P; ++p) dm_stg(out, p, make_double2(w * acc_re[c][a][p], w * acc_im[c][a][p]));
+    }
+  }
+}
+
+// ---- the equatorial belt by FFT -----------------------------------------------------------------------------
+// The 2 nside + 1 rings of the belt all have N = 4 nside pixels (a power of two): 2/3 of the sphere.  There the sum over
+// the pixels of a ring is a length-N FFT per (column, Stokes map) — 5 N log2 N flops for EVERY m at once against
+// 8 N flops per m-value of the matrix form (19 x fewer for a rank's 130 m-values at nside 512).  One workgroup owns a
+// ring and walks over `cpw` columns: the pixel geometry of its NPT pixels per thread is computed once, per column the
+// map values go to LDS in bit-reversed order, a radix-8 pass and radix-4 passes (one barrier each) transform them in
+// place, and the wanted rows  G[+-m] = w exp(i m phi_0) X[(+-m) mod N]  are written out.  The map values are formed
+// by the same expressions as in the two kernels above (the caps still go through those).
+// LDS: P N complex values + N / 2 twiddles (144 KB at nside 512 with four Stokes maps; beyond 160 KB the caller
+// keeps the matrix form for the belt too).  The result of a ring does not depend on the m-range asked for.
+template <int P, int NPT, int TPB>
+__global__ __launch_bounds__(TPB) void bt_fused_fft_kernel(ring_geo g, frame3 fr, const double* __restrict__ beams, size_t bstride,
+                                                           const fdft_col* __restrict__ cols, int ncol, int m_lo, int cnt,
+                                                           const double* __restrict__ ring_w, cplx* __restrict__ G, int ncp,
+                                                           int ring0, int cpw) {
+  constexpr int NCOMP = P == 4 ? 2 : 1;
+  extern __shared__ __align__(16) unsigned char fft_smem[];
+  const int tid = threadIdx.x;
+  const int r = ring0 + blockIdx.y;
+  const int N = g.nphi[r];
+  const int logn = 31 - __clz(N);
+  // Bit-reversed and strided accesses would put all lanes of a wave on one LDS bank: element a lives at a + (a >> sh)
+  // (one empty slot per 2^sh values), which spreads them (the synthesis writes went 64-way conflicted without it).
+  const int sh = max(5, logn - 6);
+  auto ph = [&](int a2) { return a2 + (a2 >> sh); };
+  const int Np = N + (N >> sh) + 1;                        // padded length of one map
+  cplx* X = reinterpret_cast<cplx*>(fft_smem);            // [P][Np]
+  cplx* TW = X + (size_t)P * Np;                           // [N / 2] (padded likewise): exp(+2 pi i k / N)
+  const double phi0 = g.phi0[r], st = g.sth[r], ct = g.cth[r];
+  const int pix0 = g.start[r];
+  for (int k = tid; k < N / 2; k += TPB) {
+    double s_, c_;
+    sincospi(2.0 * (double)k / (double)N, &s_, &c_);
+    TW[ph(k)] = make_double2(c_, s_);
+  }
+  // geometry of this thread's pixels j = tid + TPB q
+  double nxv[NPT], nyv[NPT], hzv[NPT];
+#pragma unroll
+  for (int q = 0; q < NPT; ++q) {
+    const int j = tid + TPB * q;
+    double sp, cp;
+    sincos(phi0 + 2.0 * kPi * (double)j / (double)N, &sp, &cp);  // as in bt_fused_dft_kernel: same map bits
+    const double n0 = st * cp, n1 = st * sp, n2 = ct;
+    hzv[q] = (j < N && (n0 * fr.z[0] + n1 * fr.z[1] + n2 * fr.z[2]) > 0.0) ? 1.0 : 0.0;
+    nxv[q] = n0 * fr.x[0] + n1 * fr.x[1] + n2 * fr.x[2];
+    nyv[q] = n0 * fr.y[0] + n1 * fr.y[1] + n2 * fr.y[2];
+  }
+  const int nm = 2 * cnt;
+  const double w = ring_w ? ring_w[r] : 1.0;
+  const int c_lo = blockIdx.x * cpw, c_hi = min(c_lo + cpw, ncol);
+  for (int col = c_lo; col < c_hi; ++col) {
+    const fdft_col cdc = cols[col];
+    __syncthreads();   // the previous column's outputs have been read; the twiddles are there
+    // ---- synthesis into bit-reversed positions
+#pragma unroll
+    for (int q = 0; q < NPT; ++q) {
+      const int j = tid + TPB * q;
+      if (j >= N) continue;
+      const int jr = (int)(__brev((unsigned)j) >> (32 - logn));
+      const size_t pix = (size_t)pix0 + j;
+      const bool on = cdc.bi >= 0 && hzv[q] != 0.0;
+      const double* a = beams + (size_t)max(cdc.bi, 0) * bstride + NCOMP * pix;
+      const double* b = beams + (size_t)max(cdc.bj, 0) * bstride + NCOMP * pix;
+      double sf, cf;
+      sincospi(2.0 * (cdc.u * nxv[q] + cdc.v * nyv[q]), &sf, &cf);
+      const double pre = on ? cdc.pre : 0.0;
+      const double tre = pre * cf, tim = pre * sf;
+      if constexpr (P == 1) {
+        const double bb = dm_ldg(a) * dm_ldg(b);
+        X[ph(jr)] = make_double2(tre * bb, tim * bb);
+      } else {
+        const double a0 = dm_ldg(a), a1 = dm_ldg(a, 1), b0 = dm_ldg(b), b1 = dm_ldg(b, 1);
+        const double sI = a0 * b0 + a1 * b1, sQ = a0 * b0 - a1 * b1, sU = a0 * b1 + a1 * b0, sV = a0 * b1 - a1 * b0;
+        const int jp = ph(jr);
+        X[jp] = make_double2(tre * sI, tim * sI);
+        X[(size_t)Np + jp] = make_double2(tre * sQ, tim * sQ);
+        X[2 * (size_t)Np + jp] = make_double2(tre * sU, tim * sU);
+        X[3 * (size_t)Np + jp] = make_double2(-tim * sV, tre * sV);  // 1j * fringe * sV
+      }
+    }
+    __syncthreads();
+    // ---- stages 1..3: eight consecutive values per unit, in registers
+    for (int U = tid; U < P * N / 8; U += TPB) {
+      const int p = U / (N / 8), u = U - p * (N / 8);
+      cplx* x = X + (size_t)p * Np + ph(u * 8);   // eight values never straddle a padding slot (2^sh >= 32)
+      cplx e[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) e[i] = x[i];
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) { const cplx t = e[i + 1]; e[i + 1] = csub(e[i], t); e[i] = cadd(e[i], t); }
+#pragma unroll
+      for (int i = 0; i < 8; i += 4) {
+        cplx t = e[i + 2]; e[i + 2] = csub(e[i], t); e[i] = cadd(e[i], t);
+        t = make_double2(-e[i + 3].y, e[i + 3].x);   // times exp(2 pi i / 4) = +i
+        e[i + 3] = csub(e[i + 1], t); e[i + 1] = cadd(e[i + 1], t);
+      }
+      {
+        const double h = 0.70710678118654752440;
+        cplx t = e[4]; e[4] = csub(e[0], t); e[0] = cadd(e[0], t);
+        t = make_double2(h * (e[5].x - e[5].y), h * (e[5].x + e[5].y));        // times exp(i pi / 4)
+        e[5] = csub(e[1], t); e[1] = cadd(e[1], t);
+        t = make_double2(-e[6].y, e[6].x);                                       // times i
+        e[6] = csub(e[2], t); e[2] = cadd(e[2], t);
+        t = make_double2(-h * (e[7].x + e[7].y), h * (e[7].x - e[7].y));       // times exp(3 i pi / 4)
+        e[7] = csub(e[3], t); e[3] = cadd(e[3], t);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = e[i];
+    }
+    __syncthreads();
+    // ---- the remaining stages two at a time (h = half size of the first of the two), a single one at the end if odd
+    int sdone = 3;
+    for (; sdone + 2 <= logn; sdone += 2) {
+      const int h = 1 << sdone;
+      const int s1 = N / (2 * h), s2 = N / (4 * h);
+      for (int U = tid; U < P * N / 4; U += TPB) {
+        const int p = U / (N / 4), u = U - p * (N / 4);
+        const int blk = u / h, pos = u - blk * h;
+        cplx* x = X + (size_t)p * Np;
+        const int a0 = blk * 4 * h + pos;
+        const int i0 = ph(a0), i1 = ph(a0 + h), i2 = ph(a0 + 2 * h), i3 = ph(a0 + 3 * h);
+        cplx e0 = x[i0], e1 = x[i1], e2 = x[i2], e3 = x[i3];
+        const cplx w1 = TW[ph(pos * s1)], w2 = TW[ph(pos * s2)], w3 = TW[ph((pos + h) * s2)];
+        cplx t = cmul(w1, e1); e1 = csub(e0, t); e0 = cadd(e0, t);
+        t = cmul(w1, e3); e3 = csub(e2, t); e2 = cadd(e2, t);
+        t = cmul(w2, e2); e2 = csub(e0, t); e0 = cadd(e0, t);
+        t = cmul(w3, e3); e3 = csub(e1, t); e1 = cadd(e1, t);
+        x[i0] = e0; x[i1] = e1; x[i2] = e2; x[i3] = e3;
+      }
+      __syncthreads();
+    }
+    if (sdone < logn) {
+      const int h = N / 2;
+      for (int U = tid; U < P * N / 2; U += TPB) {
+        const int p = U / h, u = U - p * h;
+        cplx* x = X + (size_t)p * Np;
+        const int i0 = ph(u), i1 = ph(u + h);
+        const cplx t = cmul(TW[ph(u)], x[i1]);
+        const cplx e0 = x[i0];
+        x[i0] = cadd(e0, t);
+        x[i1] = csub(e0, t);
+      }
+      __syncthreads();
+    }
+    // ---- the wanted rows: G[mm][ring][col P + p] = w exp(i m phi_0) X_p[m mod N]
+    for (int mm = tid; mm < nm; mm += TPB) {
+      const int m = mm < cnt ? m_lo + mm : -(m_lo + mm - cnt);
+      const int idx = ((m % N) + N) % N;
+      double s_, c_;
+      sincos((double)m * phi0, &s_, &c_);
+      const cplx phs = make_double2(w * c_, w * s_);
+      cplx* out = G + ((size_t)mm * g.nring + r) * ncp + (size_t)col * P;
+#pragma unroll
+      for (int p = 0; p < P; ++p) dm_stg(out, p, cmul(phs, X[(size_t)p * Np + ph(idx)]));
     }
   }
 }
@@ -1008,10 +1167,70 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
     }
     if (!d_fc) return DM_ENOMEM;
     const int nmg = (nm + 3) / 4;  // groups of four m-values
+    // The belt (rings nside - 1 .. 3 nside - 1, all with N = 4 nside pixels) goes by FFT when N is a power of two and the
+    // P maps of a column fit the LDS; the matrix-form kernels below then see the rings of the two caps only.  The choice
+    // depends on nside and P alone — never on the m-range — so that any partition of m gives the same bits.
+    static const bool fft_off = getenv("DM_BT_FFT") && atoi(getenv("DM_BT_FFT")) == 0;
+    const int N = 4 * nside;
+    int fft_logn = 0;
+    while ((1 << fft_logn) < N) ++fft_logn;
+    const int fft_sh = std::max(5, fft_logn - 6);   // padding of the LDS arrays, as in the kernel
+    const size_t fft_lds = sizeof(cplx) * ((size_t)P * (N + (N >> fft_sh) + 1) + (N / 2 + ((N / 2) >> fft_sh) + 1));
+    const bool use_fft = !fft_off && nside >= 2 && (N & (N - 1)) == 0 && N <= 4096 && fft_lds <= 160u * 1024u - 256u;
+    int nring_dft = nring;
+    const int* d_caps = nullptr;
+    if (use_fft) {
+      std::vector<int> caps;
+      for (int r = 0; r < nring; ++r)
+        if (r < nside - 1 || r > 3 * nside - 1) caps.push_back(r);
+      nring_dft = (int)caps.size();
+      if (nring_dft > 0) {
+        d_caps = dm_ws_upload(ctx, caps);
+        if (!d_caps) return DM_ENOMEM;
+      }
+      const int nring_eq = 2 * nside + 1;
+      const int cpw = std::max(4, std::min(32, (int)(((size_t)ncol * nring_eq) / 4096)));
+      const dim3 grid((unsigned)((ncol + cpw - 1) / cpw), (unsigned)nring_eq);
+      static const int wide_env = getenv("DM_BT_FFT_WIDE") ? atoi(getenv("DM_BT_FFT_WIDE")) : -1;
+      // (measured at nside 512 with four maps: 256 threads 3.6 s per rank call, 1024 threads 6.4 s — the barriers of
+      // sixteen waves cost more than their latency hiding brings; the wide variant stays behind DM_BT_FFT_WIDE=1)
+      const bool wide = wide_env > 0 && (polarised ? N >= 1024 : N == 4096);
+      auto fft_launch = [&](auto kern, int tpb) -> int {
+        DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)fft_lds));
+        hipLaunchKernelGGL(kern, grid, dim3(tpb), fft_lds, ctx->stream, gh.g, fr, syn->beams_dev, bstride, d_fc, ncol, m_lo,
+                           cnt, d_rw, G, ncp, nside - 1, cpw);
+        return DM_OK;
+      };
+      if (wide) {
+        const int npt = std::max(1, N / 1024);
+        if (polarised) {
+          if (npt == 1) DM_TRY(fft_launch(bt_fused_fft_kernel<4, 1, 1024>, 1024));
+          else DM_TRY(fft_launch(bt_fused_fft_kernel<4, 2, 1024>, 1024));   // N = 2048 (4096 x 4 maps does not fit)
+        } else {
+          DM_TRY(fft_launch(bt_fused_fft_kernel<1, 4, 1024>, 1024));         // N = 4096
+        }
+      } else {
+        const int npt = std::max(1, N / 256);
+        if (polarised) {
+          if (npt == 1) DM_TRY(fft_launch(bt_fused_fft_kernel<4, 1, 256>, 256));
+          else if (npt == 2) DM_TRY(fft_launch(bt_fused_fft_kernel<4, 2, 256>, 256));      // N = 512
+          else if (npt == 4) DM_TRY(fft_launch(bt_fused_fft_kernel<4, 4, 256>, 256));
+          else DM_TRY(fft_launch(bt_fused_fft_kernel<4, 8, 256>, 256));
+        } else {
+          if (npt == 1) DM_TRY(fft_launch(bt_fused_fft_kernel<1, 1, 256>, 256));
+          else if (npt == 2) DM_TRY(fft_launch(bt_fused_fft_kernel<1, 2, 256>, 256));
+          else if (npt == 4) DM_TRY(fft_launch(bt_fused_fft_kernel<1, 4, 256>, 256));
+          else if (npt == 8) DM_TRY(fft_launch(bt_fused_fft_kernel<1, 8, 256>, 256));      // N = 2048
+          else DM_TRY(fft_launch(bt_fused_fft_kernel<1, 16, 256>, 256));
+        }
+      }
+    }
     auto launch = [&](auto kern, int NMG, int NCG) {
-      const dim3 grid((unsigned)((ncol16 + 4 * NCG - 1) / (4 * NCG)), (unsigned)nring, (unsigned)((nmg + NMG - 1) / NMG));
+      if (nring_dft == 0) return;
+      const dim3 grid((unsigned)((ncol16 + 4 * NCG - 1) / (4 * NCG)), (unsigned)nring_dft, (unsigned)((nmg + NMG - 1) / NMG));
       hipLaunchKernelGGL(kern, grid, dim3(256), 0, ctx->stream, gh.g, fr, syn->beams_dev, bstride, d_fc, ncol16, m_lo, cnt, d_rw, G,
-                         ncp, 0);
+                         ncp, d_caps);
     };
     // 32 complex accumulators per lane (64 AGPRs) keep two waves per SIMD: the sincos of one wave runs under
     // the MFMAs of the other
@@ -1019,9 +1238,10 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
     // synthesis but cost a wave per SIMD — no faster on configs[1] or configs[2]
     // shared-synthesis kernel: the four waves of a workgroup take different m-values (16 NMG per pass)
     auto launch2 = [&](auto kern, int NMG, int NCG) {
-      const dim3 grid((unsigned)((ncol16 + NCG - 1) / NCG), (unsigned)nring, (unsigned)((nmg + 4 * NMG - 1) / (4 * NMG)));
+      if (nring_dft == 0) return;
+      const dim3 grid((unsigned)((ncol16 + NCG - 1) / NCG), (unsigned)nring_dft, (unsigned)((nmg + 4 * NMG - 1) / (4 * NMG)));
       hipLaunchKernelGGL(kern, grid, dim3(256), 0, ctx->stream, gh.g, fr, syn->beams_dev, bstride, d_fc, ncol16, m_lo, cnt, d_rw, G,
-                         ncp);
+                         ncp, d_caps);
     };
     static const int shared_env = getenv("DM_FDFT_SHARED") ? atoi(getenv("DM_FDFT_SHARED")) : 1;
     if (polarised) {
