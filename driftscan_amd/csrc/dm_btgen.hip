@@ -29,6 +29,7 @@
 #include "../../include/driftmi.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 
 namespace {
@@ -778,6 +779,27 @@ __global__ __launch_bounds__(TPB) void bt_fused_fft_kernel(ring_geo g, frame3 fr
   }
 }
 
+// ---- north / south fold of the ring transform --------------------------------------------------------------
+// HEALPix rings come in mirror pairs (r, nring - 1 - r) with z -> -z, and lambda_lm, W_lm are even / odd under z -> -z
+// with l + m (X_lm the other way round): the sum over rings of the Legendre stage needs only the northern half once the
+// pairs are combined — half the flops of that stage.  In place:  G[r] <- G[r] + G[r'],  G[r'] <- G[r'] - G[r]  (r < mid);
+// symmetric functions then run over rings 0 .. mid, antisymmetric ones over mid + 1 .. nring - 1 (where the table value
+// f(z_r') = -f(z_r) restores the sign).
+__global__ __launch_bounds__(256) void bt_fold_kernel(cplx* __restrict__ G, int nm, int nring, size_t ncp) {
+  const int mid = nring / 2;                       // nring = 4 nside - 1 is odd: ring `mid` is the equator
+  const size_t per = (size_t)mid * ncp;            // elements of the northern rows of one m
+  const size_t tot = (size_t)nm * per;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * 256) {
+    const size_t mm = idx / per, rem = idx - mm * per;
+    const size_t r = rem / ncp, c = rem - r * ncp;
+    cplx* gn = G + (mm * nring + r) * ncp + c;
+    cplx* gs = G + (mm * nring + (nring - 1 - r)) * ncp + c;
+    const cplx a = *gn, b = *gs;
+    *gn = cadd(a, b);
+    *gs = csub(b, a);
+  }
+}
+
 // tw[pix][mm] laid out per ring as (2*mmax+1) x nphi row-major: tw[off_r + mm*nphi + j] = exp(i (mm - mmax) phi_j)
 __global__ void bt_twiddle_kernel(ring_geo g, int m_lo, int cnt, const size_t* __restrict__ toff, cplx* __restrict__ tw) {
   // rows [0, cnt): m = +m_lo .. +(m_lo + cnt - 1);  rows [cnt, 2 cnt): the same with a minus sign
@@ -1310,6 +1332,14 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
   }
   // Terms whose outputs accumulate (E and B each take two products) go in separate launches
   // so that no two tiles of one launch touch the same C entries.
+  // (the refinement path synthesises from G-shaped buffers and keeps the plain sum; DM_BT_FOLD=0 switches the fold off)
+  static const bool fold_off = getenv("DM_BT_FOLD") && atoi(getenv("DM_BT_FOLD")) == 0;
+  const bool folded = niter == 0 && !fold_off && cnt > 0 && nring >= 3;
+  if (folded) {
+    const size_t tot = (size_t)nm * (nring / 2) * ncp;
+    const unsigned nb = (unsigned)std::min<size_t>((tot + 255) / 256, 65536);
+    hipLaunchKernelGGL(bt_fold_kernel, dim3(nb), dim3(256), 0, ctx->stream, G, nm, nring, (size_t)ncp);
+  }
   auto legendre_analysis = [&](bool accumulate) -> int {
   for (int pass = 0; pass < (polarised ? 2 : 1); ++pass) {
     std::vector<dm_gemm_desc> g;
@@ -1322,11 +1352,32 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
         for (const run& rn : runs) {
           cplx* out = bm + ((((size_t)(m - m_lo) * F + rn.f) * 2 + s) * B + rn.b0) * P * L + m;
           auto add = [&](int pa, const double* tab, int pout, double are, double aim, double beta) {
-            dm_gemm_desc d = dm_gemm_make(Gm + (size_t)rn.c0 * P + pa, P, ncp, s == 1, tab + loff[m - m_lo], 1, nring, false,
-                                          out + (size_t)pout * L, P * L, rn.n, Lm, nring, are, beta, nullptr,
-                                          DM_GEMM_B_REAL);
-            d.alpha_im = aim;
-            g.push_back(d);
+            if (!folded) {
+              dm_gemm_desc d = dm_gemm_make(Gm + (size_t)rn.c0 * P + pa, P, ncp, s == 1, tab + loff[m - m_lo], 1, nring, false,
+                                            out + (size_t)pout * L, P * L, rn.n, Lm, nring, are, beta, nullptr,
+                                            DM_GEMM_B_REAL);
+              d.alpha_im = aim;
+              g.push_back(d);
+              return;
+            }
+            // folded rings: the outputs l = m + 2 j (+ 1) are interleaved (column stride 2 of C), each parity sums over one
+            // half of the rings — the northern one (with the equator) where the function is even in z, the southern one
+            // where it is odd; lambda and W are even for even l - m, X for odd l - m
+            const int mid = nring / 2;
+            for (int par = 0; par < 2; ++par) {
+              const int nl = (Lm - par + 1) / 2;       // l' = par, par + 2, ... < Lm
+              if (nl <= 0) continue;
+              const bool even_fn = (tab == Xt) ? par == 1 : par == 0;
+              const int r0 = even_fn ? 0 : mid + 1, nr = even_fn ? mid + 1 : mid;
+              if (nr <= 0) continue;
+              dm_gemm_desc d = dm_gemm_make(Gm + (size_t)r0 * ncp + (size_t)rn.c0 * P + pa, P, ncp, s == 1,
+                                            tab + loff[m - m_lo] + (size_t)par * nring + r0, 1, 2 * nring, false,
+                                            out + (size_t)pout * L + par, P * L, rn.n, nl, nr, are, beta, nullptr,
+                                            DM_GEMM_B_REAL);
+              d.csc = 2;
+              d.alpha_im = aim;
+              g.push_back(d);
+            }
           };
           const double b0 = accumulate ? 1.0 : 0.0;
           if (!polarised) {
@@ -1351,7 +1402,14 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
   DM_HIP(ctx, hipGetLastError());
   return DM_OK;
   };
-  DM_TRY(legendre_analysis(false));
+  {
+    static const bool host_times = getenv("DM_TIME_HOST") != nullptr;  // debugging aid
+    const auto t0 = std::chrono::steady_clock::now();
+    DM_TRY(legendre_analysis(false));
+    if (host_times)
+      fprintf(stderr, "HOSTTIME bt_sht_impl: Legendre descriptors + launch %.3f ms (ncol %d, m %d..%d)\n",
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), ncol, m_lo, m_hi);
+  }
 
   // ---- Jacobi refinement (healpy map2alm `iter`): coefficients += analysis(map - synthesis(coefficients)).
   // With c_lm = sum_pix w f Y_lm (the reference's conj(SHT(conj f))) the synthesis is f = sum_lm c_lm conj(Y_lm):

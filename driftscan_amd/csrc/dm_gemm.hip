@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, 3) void zgemm_grouped_kernel(const dm_gemm_des
         for (int r = 0; r < 4; ++r) {
           const int gm = min(m0 + wm * 32 + i * 16 + crow + 4 * r, d.M - 1);
           const int gn = min(n0 + wn * 32 + j * 16 + ccol, d.N - 1);
-          cold[i][j][r] = dm_ldg(C, (size_t)gm * d.ldc + gn);
+          cold[i][j][r] = dm_ldg(C, (size_t)gm * d.ldc + (size_t)gn * d.csc);
         }
   };
 
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 3) void zgemm_grouped_kernel(const dm_gemm_des
           v.x += d.beta * cold[i][j][r].x;
           v.y += d.beta * cold[i][j][r].y;
         }
-        if (gm < d.M && gn < d.N) dm_stg(C, (size_t)gm * d.ldc + gn, v);
+        if (gm < d.M && gn < d.N) dm_stg(C, (size_t)gm * d.ldc + (size_t)gn * d.csc, v);
       }
 }
 
@@ -459,11 +459,11 @@ __global__ __launch_bounds__(256, 2) void zgemm4_grouped_kernel(const dm_gemm_de
         const double are = acc_re[i][j][s], aim = acc_im[i][j][s];
         cplx v = make_double2(d.alpha * are - d.alpha_im * aim, d.alpha * aim + d.alpha_im * are);
         if (rmw) {
-          const cplx o = dm_ldg(C, (size_t)gm * d.ldc + gn);
+          const cplx o = dm_ldg(C, (size_t)gm * d.ldc + (size_t)gn * d.csc);
           v.x += d.beta * o.x;
           v.y += d.beta * o.y;
         }
-        dm_stg(C, (size_t)gm * d.ldc + gn, v);
+        dm_stg(C, (size_t)gm * d.ldc + (size_t)gn * d.csc, v);
       }
 }
 

@@ -32,6 +32,7 @@ struct dm_gemm_desc {
                          //   y = offset of its weight run relative to kscale): B(k, n) = B[x + k rsB] * kscale[y + k]
   int M, N, K;
   int rsA, csA, rsB, csB, ldc;
+  int csc;               // element stride between the columns of C (1 unless the caller interleaves outputs; complex kernels only)
   int flags;
   double alpha, beta;
   double alpha_im;  // imaginary part of alpha (0 for the usual real scaling)
@@ -94,6 +95,7 @@ static inline dm_gemm_desc dm_gemm_make(const cplx* A, int rsA, int csA, bool co
   d.A = A; d.B = B; d.C = C; d.kscale = kscale;
   d.M = M; d.N = N; d.K = K;
   d.rsA = rsA; d.csA = csA; d.rsB = rsB; d.csB = csB; d.ldc = ldc;
+  d.csc = 1;
   d.flags = (conjA ? DM_GEMM_CONJ_A : 0) | (conjB ? DM_GEMM_CONJ_B : 0) | extra_flags;
   d.alpha = alpha; d.beta = beta; d.alpha_im = 0.0;
   d.bgather = nullptr;

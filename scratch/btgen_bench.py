@@ -50,10 +50,9 @@ def main():
                 dt = time.perf_counter() - t0
                 if rep == 0:
                     rec[mode + "_first_s"] = dt
-                    if len(args.ranges) * 2 > 2:
-                        del bm
-                        torch.cuda.empty_cache()
-                        continue
+                    del bm            # the timed repeat must not allocate a second block array next to the first
+                    torch.cuda.empty_cache()
+                    continue
                 rec[mode + "_s"] = dt
             res[mode] = bm
             print(time.strftime("%H:%M:%S"), "config", args.config, "m", rg, mode, "%.3f s" % rec[mode + "_s"], flush=True)
