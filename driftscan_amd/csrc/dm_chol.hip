@@ -30,8 +30,10 @@ struct chol_desc {
 // ---- diagonal block factorisation ------------------------------------------------
 // grid = batch; 256 threads.  info[b] = first failing 1-based index (sticky).
 __global__ __launch_bounds__(256) void potf2_kernel(const chol_desc* __restrict__ ds, int k0, int* __restrict__ info) {
+  // One barrier per column: the trailing update reads the UNSCALED column j of T (every thread forms 1 / d_jj itself),
+  // the scaled column goes to a second array — no thread waits for a square root or for a scaled column.
   __shared__ cplx T[NB][NB + 1];
-  __shared__ int fail;
+  __shared__ cplx Lo[NB][NB + 1];
   const chol_desc d = ds[blockIdx.x];
   if (k0 >= d.n) return;
   if (info[blockIdx.x] != 0) return;
@@ -40,40 +42,33 @@ __global__ __launch_bounds__(256) void potf2_kernel(const chol_desc* __restrict_
   for (int idx = tid; idx < NB * NB; idx += 256) {
     int r = idx / NB, c = idx % NB;
     T[r][c] = (r < nb && c < nb && c <= r) ? d.A[(size_t)(k0 + r) * d.ld + k0 + c] : make_double2(0.0, 0.0);
+    Lo[r][c] = make_double2(0.0, 0.0);
   }
-  if (tid == 0) fail = 0;
-  __syncthreads();
+  int fail = 0;
   for (int j = 0; j < nb; ++j) {
-    // diagonal
-    if (tid == 0) {
-      double djj = T[j][j].x;
-      if (!(djj > 0.0) || !isfinite(djj)) {
-        fail = j + 1;
-      } else {
-        T[j][j] = make_double2(sqrt(djj), 0.0);
-      }
+    __syncthreads();   // column j of T is final
+    const double djj = T[j][j].x;
+    if (!(djj > 0.0) || !isfinite(djj)) {  // every thread reads the same value: a uniform exit
+      fail = j + 1;
+      break;
     }
-    __syncthreads();
-    if (fail) break;
-    const double inv = 1.0 / T[j][j].x;
-    // scale column j below the diagonal
-    if (tid > j && tid < nb) T[tid][j] = cscale(T[tid][j], inv);
-    __syncthreads();
-    // trailing update of the lower triangle: T[r][c] -= T[r][j] conj(T[c][j]),  j < c <= r
+    const double inv = 1.0 / djj, invs = 1.0 / sqrt(djj);
+    if (tid >= j && tid < nb) Lo[tid][j] = tid == j ? make_double2(sqrt(djj), 0.0) : cscale(T[tid][j], invs);
+    // trailing update of the lower triangle: T[r][c] -= T[r][j] conj(T[c][j]) / d_jj,  j < c <= r
     for (int idx = tid; idx < NB * NB; idx += 256) {
       int r = idx / NB, c = idx % NB;
-      if (c > j && c <= r && r < nb) T[r][c] = csub(T[r][c], cmulc(T[r][j], T[c][j]));
+      if (c > j && c <= r && r < nb) T[r][c] = csub(T[r][c], cscale(cmulc(T[r][j], T[c][j]), inv));
     }
-    __syncthreads();
   }
   if (fail) {
     if (tid == 0) info[blockIdx.x] = k0 + fail;
     return;
   }
+  __syncthreads();
   for (int idx = tid; idx < NB * NB; idx += 256) {
     int r = idx / NB, c = idx % NB;
     if (r < nb && c < nb) {
-      cplx v = (c <= r) ? T[r][c] : make_double2(0.0, 0.0);
+      cplx v = (c <= r) ? Lo[r][c] : make_double2(0.0, 0.0);
       if (c == r) v.y = 0.0;
       d.A[(size_t)(k0 + r) * d.ld + k0 + c] = v;
     }
@@ -101,14 +96,21 @@ __global__ __launch_bounds__(256) void panel_trsm_kernel(const chol_desc* __rest
     R[r][c] = (r0 + r < d.n) ? d.A[(size_t)(r0 + r) * d.ld + k0 + c] : make_double2(0.0, 0.0);
   }
   __syncthreads();
-  // row x: x[c] = (a[c] - sum_{j<c} x[j] conj(L[c][j])) / L[c][c]; one thread per row
+  // row x: x[c] = (a[c] - sum_{j<c} x[j] conj(L[c][j])) / L[c][c]; one thread per row, the row in registers and the
+  // substitution column-oriented (x[c] leaves all later entries at once: independent multiply-adds, not one chain)
   if (tid < 64) {
     const int r = tid;
+    cplx x[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) x[c] = R[r][c];
+#pragma unroll
     for (int c = 0; c < NB; ++c) {
-      cplx s = R[r][c];
-      for (int j = 0; j < c; ++j) s = csub(s, cmulc(R[r][j], Lk[c][j]));
-      R[r][c] = cscale(s, 1.0 / Lk[c][c].x);
+      x[c] = cscale(x[c], 1.0 / Lk[c][c].x);
+#pragma unroll
+      for (int j = c + 1; j < NB; ++j) x[j] = csub(x[j], cmulc(x[c], Lk[j][c]));
     }
+#pragma unroll
+    for (int c = 0; c < NB; ++c) R[r][c] = x[c];
   }
   __syncthreads();
   for (int idx = tid; idx < 64 * NB; idx += 256) {
@@ -129,9 +131,9 @@ struct trsm_desc {
 };
 
 // Solve L_kk X_k = B_k (forward) or L_kk^H X_k = B_k (backward) for one block row.
-// grid = (column tiles of 64, batch); one thread per right-hand-side column.
+// grid = (column tiles of 256, batch); one thread per right-hand-side column.
 template <bool CONJTRANS>
-__global__ __launch_bounds__(64) void diag_solve_kernel(const trsm_desc* __restrict__ ds, int s, int nblk, int upper_only) {
+__global__ __launch_bounds__(256) void diag_solve_kernel(const trsm_desc* __restrict__ ds, int s, int nblk, int upper_only) {
   __shared__ cplx Lk[NB][NB + 1];
   const trsm_desc d = ds[blockIdx.y];
   int k0;
@@ -145,40 +147,40 @@ __global__ __launch_bounds__(64) void diag_solve_kernel(const trsm_desc* __restr
   }
   if (k0 >= d.n || k0 < 0) return;
   const int nb = min(NB, d.n - k0);
-  const int col = blockIdx.x * 64 + threadIdx.x;
+  const int col = blockIdx.x * 256 + threadIdx.x;
   // upper_only: only the columns >= the first row of the 64-row super block are wanted (and valid)
-  if (upper_only && (int)(blockIdx.x + 1) * 64 <= (k0 / (2 * NB)) * (2 * NB)) return;
-  for (int idx = threadIdx.x; idx < NB * NB; idx += 64) {
+  const int first_col = upper_only ? (k0 / (2 * NB)) * (2 * NB) : 0;
+  if ((int)(blockIdx.x + 1) * 256 <= first_col) return;   // (uniform over the workgroup)
+  for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
     int r = idx / NB, c = idx % NB;
     Lk[r][c] = (r < nb && c < nb) ? d.L[(size_t)(k0 + r) * d.ldl + k0 + c] : make_double2(0.0, 0.0);
   }
   __syncthreads();
-  if (col >= d.nrhs) return;
+  if (col >= d.nrhs || (col / 64 + 1) * 64 <= first_col) return;
   cplx x[NB];
 #pragma unroll
   for (int r = 0; r < NB; ++r) x[r] = (r < nb) ? d.B[(size_t)(k0 + r) * d.ldb + col] : make_double2(0.0, 0.0);
+  // Column-oriented substitution: once x[r] is final it is taken out of every later row at once — 31, 30, ... independent
+  // multiply-adds per step instead of one accumulator walking along a row (a chain of 496 dependent complex products,
+  // which set the duration of the kernel).  Rows beyond nb are zero in Lk and in x.
   if (!CONJTRANS) {
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
       if (r < nb) {
-        cplx s = x[r];
+        x[r] = cscale(x[r], 1.0 / Lk[r][r].x);
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
-          if (j < r) s = csub(s, cmul(Lk[r][j], x[j]));
-        x[r] = cscale(s, 1.0 / Lk[r][r].x);
+        for (int j = r + 1; j < NB; ++j) x[j] = csub(x[j], cmul(Lk[j][r], x[r]));
       }
     }
   } else {
-    // (L^H)[r][j] = conj(L[j][r]), upper triangular: back substitution
+    // (L^H)[j][r] = conj(L[r][j]), upper triangular: back substitution
 #pragma unroll
     for (int rr = 0; rr < NB; ++rr) {
       const int r = NB - 1 - rr;
       if (r < nb) {
-        cplx s = x[r];
+        x[r] = cscale(x[r], 1.0 / Lk[r][r].x);
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
-          if (j > r && j < nb) s = csub(s, cmul(cconj(Lk[j][r]), x[j]));
-        x[r] = cscale(s, 1.0 / Lk[r][r].x);
+        for (int j = 0; j < r; ++j) x[j] = csub(x[j], cmul(cconj(Lk[r][j]), x[r]));
       }
     }
   }
@@ -264,7 +266,7 @@ int trsm_pass(dm_ctx* ctx, const std::vector<dm_trsm_problem>& probs, bool conjt
     maxn = std::max(maxn, probs[i].n);
     maxrhs = std::max(maxrhs, probs[i].nrhs);
   }
-  const int ct = (maxrhs + 63) / 64;
+  const int ct = (maxrhs + 255) / 256;   // column tiles of the substitution kernel
   const int NB2 = 2 * NB;
   const int nblk = (maxn + NB2 - 1) / NB2;   // 64-row super blocks
   const int nblk32 = (maxn + NB - 1) / NB;   // the substitution kernels still count 32-row blocks
@@ -312,10 +314,10 @@ int trsm_pass(dm_ctx* ctx, const std::vector<dm_trsm_problem>& probs, bool conjt
       else s32 = 2 * s + half;  // backward kernel maps its step to the block row itself
       if (chain.dry) {
       } else if (!conjtrans)
-        hipLaunchKernelGGL(diag_solve_kernel<false>, dim3(ct, nbatch), dim3(64), 0, ctx->stream, dd, s32, nblk32,
+        hipLaunchKernelGGL(diag_solve_kernel<false>, dim3(ct, nbatch), dim3(256), 0, ctx->stream, dd, s32, nblk32,
                            upper_only ? 1 : 0);
       else
-        hipLaunchKernelGGL(diag_solve_kernel<true>, dim3(ct, nbatch), dim3(64), 0, ctx->stream, dd, s32, 2 * nblk, 0);
+        hipLaunchKernelGGL(diag_solve_kernel<true>, dim3(ct, nbatch), dim3(256), 0, ctx->stream, dd, s32, 2 * nblk, 0);
       if (half == 0) {
         DM_TRY(chain.gemm([&](std::vector<dm_gemm_desc>& g2) {
         for (int i = 0; i < nbatch; ++i) {

@@ -988,15 +988,16 @@ struct tf_mat {
   cplx* G; const cplx* tau; cplx* T; int kb; int ldt;  // G: TNB x TNB row-major; T: leading dimension ldt
   const cplx* part; int nslice;                         // nslice > 0: G = sum of nslice (kb x kb) slices at `part` (stored to G)
 };
-// The Gram matrix goes to LDS first (summed over the split-K slices if there are any): the recurrence then runs at LDS
-// latency — 32 dependent steps that each waited for a global load took 50 us per call.
-__global__ __launch_bounds__(64) void larft_kernel(const tf_mat* __restrict__ ts) {
+// The Gram matrix goes to LDS first (summed over the split-K slices if there are any) and the recurrence runs from LDS with
+// eight threads per row of T sharing each dot product: 32 dependent steps of a few operations each (one thread per row
+// walking along it, waiting for a global load per element, took 50 us per call).
+__global__ __launch_bounds__(256) void larft_kernel(const tf_mat* __restrict__ ts) {
   const tf_mat F = ts[blockIdx.x];
   extern __shared__ __align__(16) unsigned char larft_smem[];
   cplx (*T)[TNB + 1] = reinterpret_cast<cplx (*)[TNB + 1]>(larft_smem);
   cplx (*Gl)[TNB + 1] = reinterpret_cast<cplx (*)[TNB + 1]>(larft_smem + sizeof(cplx) * TNB * (TNB + 1));
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < TNB * TNB; idx += 64) {
+  const int tid = threadIdx.x, nth = blockDim.x;
+  for (int idx = tid; idx < TNB * TNB; idx += nth) {
     const int r = idx / TNB, c = idx % TNB;
     T[r][c] = make_double2(0.0, 0.0);
     cplx g = make_double2(0.0, 0.0);
@@ -1011,19 +1012,24 @@ __global__ __launch_bounds__(64) void larft_kernel(const tf_mat* __restrict__ ts
     Gl[r][c] = g;
   }
   __syncthreads();
+  constexpr int TPR = 256 / TNB >= 8 ? 8 : 4;   // threads per row of T (8 for the 32-wide panels, 4 for the 64-wide ones)
+  const int row = tid / TPR, part = tid % TPR;
   for (int j = 0; j < F.kb; ++j) {
     const cplx tj = F.tau[j];
-    // T[0:j, j] = -tau_j * T[0:j, 0:j] * G[0:j, j]
-    if (tid < j) {
-      cplx acc = make_double2(0.0, 0.0);
-      for (int c = tid; c < j; ++c) acc = cadd(acc, cmul(T[tid][c], Gl[c][j]));  // T upper triangular
-      acc = cmul(make_double2(-tj.x, -tj.y), acc);
-      T[tid][j] = acc;
+    // T[0:j, j] = -tau_j * T[0:j, 0:j] * G[0:j, j]   (T upper triangular: columns c >= row)
+    cplx acc = make_double2(0.0, 0.0);
+    if (row < j)
+      for (int c = row + part; c < j; c += TPR) acc = cadd(acc, cmul(T[row][c], Gl[c][j]));
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) {
+      acc.x += __shfl_xor(acc.x, o, 64);
+      acc.y += __shfl_xor(acc.y, o, 64);
     }
+    if (part == 0 && row < j) T[row][j] = cmul(make_double2(-tj.x, -tj.y), acc);
     if (tid == 0) T[j][j] = tj;
     __syncthreads();
   }
-  for (int idx = tid; idx < TNB * TNB; idx += 64) F.T[(size_t)(idx / TNB) * F.ldt + idx % TNB] = T[idx / TNB][idx % TNB];
+  for (int idx = tid; idx < TNB * TNB; idx += nth) F.T[(size_t)(idx / TNB) * F.ldt + idx % TNB] = T[idx / TNB][idx % TNB];
 }
 
 
@@ -2031,7 +2037,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           attr = true;
         }
-        hipLaunchKernelGGL(larft_kernel, dim3((unsigned)tf.size()), dim3(64), lds, ctx->stream,
+        hipLaunchKernelGGL(larft_kernel, dim3((unsigned)tf.size()), dim3(256), lds, ctx->stream,
                            reinterpret_cast<const tf_mat*>(dv[7] + o_tf));
       }
       DM_TRY(dm_gemm_plan_run(ctx, px, dv[1]));
@@ -2493,7 +2499,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           attr = true;
         }
-        hipLaunchKernelGGL(larft_kernel, dim3((unsigned)tf.size()), dim3(64), lds, ctx->stream, d_tf);
+        hipLaunchKernelGGL(larft_kernel, dim3((unsigned)tf.size()), dim3(256), lds, ctx->stream, d_tf);
       }
     }
     std::deque<dm_gemm_plan> plans;
