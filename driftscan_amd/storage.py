@@ -38,7 +38,7 @@ _dio_tried = False
 _dio_lock = threading.Lock()   # the first caller may be any of the writer threads
 
 F64, C128, I64, I32, BOOL, STR, F32, OTHER = 0, 1, 2, 3, 4, 5, 6, 99
-COMP_NONE, COMP_LZF = 0, 1
+COMP_NONE, COMP_LZF, COMP_BSHUF_LZ4 = 0, 1, 2
 _NP2DIO = {np.dtype(np.float64): F64, np.dtype(np.complex128): C128, np.dtype(np.int64): I64,
            np.dtype(np.int32): I32, np.dtype(np.bool_): BOOL, np.dtype(np.float32): F32}
 _DIO2NP = {v: k for k, v in _NP2DIO.items()}
@@ -69,6 +69,15 @@ DIO_SIGNATURES = {
     "dio_list_attrs": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_char_p, ctypes.c_int64]),
     "dio_lzf_compress": (ctypes.c_size_t, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]),
     "dio_lzf_decompress": (ctypes.c_size_t, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]),
+    "dio_bitshuffle": (ctypes.c_size_t, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int]),
+    "dio_bitshuffle_blocked": (ctypes.c_size_t, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
+                                                 ctypes.c_size_t, ctypes.c_int]),
+    "dio_lz4_compress": (ctypes.c_size_t, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]),
+    "dio_lz4_decompress": (ctypes.c_size_t, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]),
+    "dio_bshuf_lz4_encode": (ctypes.c_size_t, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t,
+                                               ctypes.c_void_p, ctypes.c_size_t]),
+    "dio_bshuf_lz4_decode": (ctypes.c_size_t, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p,
+                                               ctypes.c_size_t]),
 }
 
 
@@ -296,7 +305,7 @@ class _BaseFile(object):
                 self._load(k)
                 if k not in self._opts:
                     chunks, comp = self._layout(k)   # keep the chunk shape / compression the dataset had
-                    self._opts[k] = (chunks, comp if comp in (None, "lzf") else None)
+                    self._opts[k] = (chunks, comp if comp in (None, "lzf", "bitshuffle") else None)
             self._close_handle()
             tmp = self.path + ".tmp%d_%d" % (os.getpid(), threading.get_ident())
             try:
@@ -415,7 +424,7 @@ class DriftioFile(_BaseFile):
             shp = tuple(int(shape[i]) for i in range(nd.value))
             chk = tuple(int(chunks[i]) for i in range(nd.value))
             self._infos[name] = (_DIO2NP.get(dt.value, np.dtype(np.float64)), shp, chk if any(chk) else None,
-                                 {COMP_NONE: None, COMP_LZF: "lzf"}.get(comp.value, "unknown"), dt.value)
+                                 {COMP_NONE: None, COMP_LZF: "lzf", COMP_BSHUF_LZ4: "bitshuffle"}.get(comp.value, "unknown"), dt.value)
         return self._infos[name]
 
     def _read(self, name, start=None, count=None):
@@ -464,15 +473,15 @@ class DriftioFile(_BaseFile):
                     arr = arr.astype(np.complex128 if arr.dtype.kind == "c" else (np.int64 if arr.dtype.kind in "iu" else np.float64))
                 arr = np.ascontiguousarray(arr).reshape(arr.shape)   # ascontiguousarray turns 0-d into 1-d
                 chunks, comp = self._opts.get(name, (None, None))
-                if comp not in (None, "lzf"):
-                    raise IOError("compression %r is not available (libdriftio writes lzf)" % (comp,))
-                if comp == "lzf" and chunks is None:
+                if comp not in (None, "lzf", "bitshuffle"):
+                    raise IOError("compression %r is not available (libdriftio writes lzf and bitshuffle + LZ4)" % (comp,))
+                if comp is not None and chunks is None:
                     chunks = arr.shape   # h5py would guess a chunk shape; one chunk keeps small datasets simple
                 if arr.ndim == 0 or arr.size == 0:
                     chunks, comp = None, None
                 self._check(self._lib.dio_write_dataset(h, name.encode(), _NP2DIO[arr.dtype], arr.ndim, _u64(arr.shape),
                                                         _u64(chunks) if chunks is not None else None,
-                                                        COMP_LZF if comp == "lzf" else COMP_NONE,
+                                                        {"lzf": COMP_LZF, "bitshuffle": COMP_BSHUF_LZ4}.get(comp, COMP_NONE),
                                                         arr.ctypes.data_as(ctypes.c_void_p)), "write %s" % name)
             for k, v in self.attrs.items():
                 self._write_attr(h, k, v)
@@ -569,9 +578,11 @@ def trace_mark(text):
 
 
 def compression_kwargs(chunks):
-    """create_dataset keywords for a chunked, lzf-compressed product dataset (drift/core/beamtransfer.py:548-555,
-    :741-792).  The npz mirror ignores them."""
-    return dict(chunks=tuple(int(c) for c in chunks), compression="lzf")
+    """create_dataset keywords for a chunked, compressed product dataset (drift/core/beamtransfer.py:548-555,
+    :741-792): lzf, or bitshuffle + LZ4 (the reference's choice for truncated blocks) with DRIFTMI_H5_CODEC=bitshuffle.
+    The npz mirror ignores them."""
+    codec = "bitshuffle" if os.environ.get("DRIFTMI_H5_CODEC", "lzf") == "bitshuffle" else "lzf"
+    return dict(chunks=tuple(int(c) for c in chunks), compression=codec)
 
 
 # ---- background writers -------------------------------------------------------------------------

@@ -39,7 +39,7 @@ enum {
   DIO_OTHER = 99
 };
 
-enum { DIO_COMP_NONE = 0, DIO_COMP_LZF = 1 };
+enum { DIO_COMP_NONE = 0, DIO_COMP_LZF = 1, DIO_COMP_BSHUF_LZ4 = 2 };
 
 #define DIO_MAX_DIMS 8
 
@@ -83,6 +83,20 @@ int64_t dio_list_attrs(int64_t file, char* buf, int64_t buflen);
  * output does not fit (for compression: "does not shrink"). */
 size_t dio_lzf_compress(const void* in, size_t in_len, void* out, size_t out_len);
 size_t dio_lzf_decompress(const void* in, size_t in_len, void* out, size_t out_len);
+
+/* bitshuffle + LZ4, HDF5 filter 32008 — what the reference writes when `truncate` is on
+ * (drift/core/beamtransfer.py:548-555); own restatement of the published formats (dm_h5io.c), registered for reading
+ * and, with DIO_COMP_BSHUF_LZ4, for writing.  The pieces, exposed for the parity tests:
+ *   dio_bitshuffle        bit transpose of nelem (a multiple of 8) elements of elem_size bytes; inverse != 0 undoes it
+ *   dio_lz4_compress / _decompress   one LZ4 block (returns the size, 0 on failure / if it does not fit)
+ *   dio_bshuf_lz4_encode / _decode   one HDF5 chunk: 12-byte header, per-block length + LZ4 data, raw tail */
+size_t dio_bitshuffle(const void* in, void* out, size_t nelem, size_t elem_size, int inverse);
+/* any nelem, cut into blocks as the bitshuffle library does (block_elems = 0: its default, 8192 bytes worth) */
+size_t dio_bitshuffle_blocked(const void* in, void* out, size_t nelem, size_t elem_size, size_t block_elems, int inverse);
+size_t dio_lz4_compress(const void* in, size_t in_len, void* out, size_t out_cap);
+size_t dio_lz4_decompress(const void* in, size_t in_len, void* out, size_t out_cap);
+size_t dio_bshuf_lz4_encode(const void* in, size_t nbytes, size_t elem_size, size_t block_elems, void* out, size_t cap);
+size_t dio_bshuf_lz4_decode(const void* in, size_t in_len, size_t elem_size, void* out, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -228,3 +228,125 @@ def test_failed_body_leaves_no_file_and_attrs_persist(tmp_path, monkeypatch, bac
             raise RuntimeError("no")
     with storage.File(p, "r") as f:
         assert int(f.attrs["note"]) == 7
+
+
+# ---- bitshuffle + LZ4 (HDF5 filter 32008: what the reference writes when `truncate` is on) -----------------------------
+def _dio_buf(lib, fn, src, cap, *extra):
+    out = (ctypes.c_ubyte * max(cap, 1))()
+    got = fn(bytes(src), len(src), *extra, out, cap) if extra else fn(bytes(src), len(src), out, cap)
+    return bytes(out[:got]), got
+
+
+def test_bitshuffle_lz4_codec_roundtrip_and_edges():
+    lib = storage.load_driftio()
+    rng = np.random.default_rng(11)
+    # LZ4 blocks: incompressible, highly compressible, short, long matches, empty-ish
+    for data in (rng.integers(0, 256, 5000, dtype=np.uint8).tobytes(), bytes(70000), b"abcd" * 3000 + b"xyz", b"q" * 11,
+                 b"0123456789ab" * 2, rng.integers(0, 4, 9000, dtype=np.uint8).tobytes()):
+        enc, got = _dio_buf(lib, lib.dio_lz4_compress, data, len(data) + len(data) // 255 + 64)
+        assert got > 0
+        dec, n = _dio_buf(lib, lib.dio_lz4_decompress, enc, len(data))
+        assert n == len(data) and dec == data
+    assert lib.dio_lz4_decompress(b"\xf0", 1, (ctypes.c_ubyte * 8)(), 8) == 0          # truncated length
+    assert lib.dio_lz4_decompress(b"\x00\x01\x00", 3, (ctypes.c_ubyte * 8)(), 8) == 0  # offset beyond the output
+    # the bit transpose and its inverse, every element size the products use
+    for es, n in ((16, 512), (8, 64), (4, 8), (1, 24)):
+        a = rng.integers(0, 256, n * es, dtype=np.uint8).tobytes()
+        t = (ctypes.c_ubyte * (n * es))()
+        b = (ctypes.c_ubyte * (n * es))()
+        assert lib.dio_bitshuffle(a, t, n, es, 0) == n * es and lib.dio_bitshuffle(bytes(t), b, n, es, 1) == n * es
+        assert bytes(b) == a
+    assert lib.dio_bitshuffle(b"x" * 7, (ctypes.c_ubyte * 7)(), 7, 1, 0) == 0   # not a multiple of eight elements
+    # whole chunks: full blocks + a shorter block + a tail of fewer than eight elements
+    for es, n in ((16, 512 * 3 + 77), (8, 5), (16, 512), (4, 2048 * 2 + 8)):
+        a = (rng.integers(0, 3, n * es, dtype=np.uint8) * 5).tobytes()
+        cap = n * es + 4096
+        out = (ctypes.c_ubyte * cap)()
+        got = lib.dio_bshuf_lz4_encode(a, len(a), es, 0, out, cap)
+        assert got >= 12
+        hdr = bytes(out[:12])
+        assert int.from_bytes(hdr[:8], "big") == len(a) and int.from_bytes(hdr[8:], "big") == (8192 // es // 8 * 8) * es
+        back = (ctypes.c_ubyte * len(a))()
+        assert lib.dio_bshuf_lz4_decode(bytes(out[:got]), got, es, back, len(a)) == len(a) and bytes(back) == a
+        assert lib.dio_bshuf_lz4_decode(bytes(out[: got - 1]), got - 1, es, back, len(a)) == 0 or n * es % (8 * es) != 0
+
+
+@pytest.mark.skipif(not os.path.exists(CONDA_PY), reason="no interpreter with imagecodecs")
+def test_bitshuffle_and_lz4_against_the_real_libraries(tmp_path):
+    """The bit transpose against the bitshuffle library and the LZ4 blocks against liblz4, both through imagecodecs under
+    /opt/conda (it wraps the two C libraries).  The HDF5 chunk framing around them follows bshuf_h5filter.c and has no
+    counterpart in this image (no bitshuffle HDF5 plugin): unpinned."""
+    probe = subprocess.run([CONDA_PY, "-c", "import imagecodecs; imagecodecs.bitshuffle_encode; imagecodecs.lz4_encode"],
+                           capture_output=True)
+    if probe.returncode != 0:
+        pytest.skip("imagecodecs with bitshuffle / lz4 not importable")
+    lib = storage.load_driftio()
+    rng = np.random.default_rng(5)
+    a = (rng.standard_normal(512) + 1j * rng.standard_normal(512)).astype(np.complex128)
+    a.real = np.round(a.real * 64) / 64
+    a.imag = np.round(a.imag * 64) / 64          # truncated-looking values: the low mantissa bits are zero
+    raw = a.tobytes()
+    mine = (ctypes.c_ubyte * len(raw))()
+    assert lib.dio_bitshuffle(raw, mine, 512, 16, 0) == len(raw)
+    enc, got = _dio_buf(lib, lib.dio_lz4_compress, bytes(mine), len(raw) + 256)
+    np.save(tmp_path / "a.npy", a)
+    (tmp_path / "mine_lz4.bin").write_bytes(enc)
+    script = (
+        "import sys, numpy as np, imagecodecs\n"
+        "d = sys.argv[1]\n"
+        "a = np.load(d + '/a.npy')\n"
+        "ref = imagecodecs.bitshuffle_encode(a, blocksize=512)   # element size from the dtype: 16\n"
+        "open(d + '/ref_shuf.bin', 'wb').write(bytes(ref))\n"
+        "open(d + '/ref_lz4.bin', 'wb').write(bytes(imagecodecs.lz4_encode(bytes(ref), header=False)))\n"
+        "back = imagecodecs.lz4_decode(open(d + '/mine_lz4.bin', 'rb').read(), header=False, out=len(bytes(ref)))\n"
+        "open(d + '/mine_decoded_by_liblz4.bin', 'wb').write(bytes(back))\n")
+    res = subprocess.run([CONDA_PY, "-c", script, str(tmp_path)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    ref_shuf = (tmp_path / "ref_shuf.bin").read_bytes()
+    assert ref_shuf == bytes(mine)                                        # the transform of the bitshuffle library
+    assert (tmp_path / "mine_decoded_by_liblz4.bin").read_bytes() == bytes(mine)   # liblz4 reads this encoder's block
+    ref_lz4 = (tmp_path / "ref_lz4.bin").read_bytes()
+    dec, n = _dio_buf(lib, lib.dio_lz4_decompress, ref_lz4, len(raw))
+    assert n == len(raw) and dec == ref_shuf                              # this decoder reads liblz4's block
+    assert got < len(raw) // 2                                            # and the truncated block does shrink
+    # the blocking of a whole buffer (three default blocks of 512 elements, one of 72, five elements copied) against
+    # bshuf_bitshuffle with its default block size
+    n = 512 * 3 + 77
+    b = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex128)
+    np.save(tmp_path / "b.npy", b)
+    res = subprocess.run([CONDA_PY, "-c", "import sys, numpy as np, imagecodecs\nd = sys.argv[1]\n"
+                          "open(d + '/ref_blocked.bin', 'wb').write(bytes(imagecodecs.bitshuffle_encode(np.load(d + '/b.npy'))))\n",
+                          str(tmp_path)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    blocked = (ctypes.c_ubyte * (n * 16))()
+    assert lib.dio_bitshuffle_blocked(b.tobytes(), blocked, n, 16, 0, 0) == n * 16
+    assert bytes(blocked) == (tmp_path / "ref_blocked.bin").read_bytes()
+    undone = (ctypes.c_ubyte * (n * 16))()
+    assert lib.dio_bitshuffle_blocked(bytes(blocked), undone, n, 16, 0, 1) == n * 16 and bytes(undone) == b.tobytes()
+
+
+def test_bitshuffle_files_roundtrip(tmp_path, monkeypatch):
+    """A product dataset written with filter 32008 reads back through the library's own filter (dataset info names the codec);
+    plain h5py sees the filter id and the five cd_values bitshuffle's plugin leaves in a file."""
+    monkeypatch.setenv("DRIFTMI_STORAGE", "hdf5")
+    monkeypatch.setenv("DRIFTMI_H5_CODEC", "bitshuffle")
+    rng = np.random.default_rng(2)
+    beam = np.round((rng.standard_normal((3, 2, 7, 1, 41)) + 1j * rng.standard_normal((3, 2, 7, 1, 41))) * 256) / 256
+    path = str(tmp_path / "beam.hdf5")
+    with storage.File(path, "w") as f:
+        f.create_dataset("beam_m", data=beam, **storage.compression_kwargs((1, 2, 7, 1, 41)))
+        f.create_dataset("dense", data=rng.standard_normal((5, 300)), **storage.compression_kwargs((1, 300)))
+    with storage.File(path, "r") as f:
+        assert f["beam_m"].compression == "bitshuffle" and f["beam_m"].chunks == (1, 2, 7, 1, 41)
+        assert np.array_equal(f["beam_m"][:], beam)
+        assert np.array_equal(f["beam_m"][1, :, 2:5], beam[1, :, 2:5])
+        assert f["dense"][:].shape == (5, 300)
+    if os.path.exists(CONDA_PY):
+        script = ("import h5py, json, sys\n"
+                  "f = h5py.File(sys.argv[1], 'r')\n"
+                  "pl = f['beam_m'].id.get_create_plist()\n"
+                  "print(json.dumps([pl.get_nfilters(), list(pl.get_filter(0)[:1]), list(pl.get_filter(0)[2])]))\n")
+        res = subprocess.run([CONDA_PY, "-c", script, path], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+        nf, fid, cd = json.loads(res.stdout)
+        assert nf == 1 and fid == [32008] and cd == [0, 4, 16, 0, 2]
