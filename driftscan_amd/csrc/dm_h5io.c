@@ -235,30 +235,33 @@ static const H5Z_class2_t g_lzf_class = {H5Z_CLASS_T_VERS, (H5Z_filter_t)DIO_LZF
 #define DIO_BSHUF_LZ4 2
 #define DIO_BSHUF_TARGET 8192
 
+/* 8 x 8 bit-matrix transpose of eight bytes packed little-endian in a 64-bit word (three masked swaps; its own inverse):
+ * byte k of the result holds bit k of the eight input bytes, bit j from byte j */
+static inline uint64_t bshuf_t8x8(uint64_t x) {
+  uint64_t t;
+  t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAULL;  x = x ^ t ^ (t << 7);
+  t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCULL; x = x ^ t ^ (t << 14);
+  t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ULL; x = x ^ t ^ (t << 28);
+  return x;
+}
 static void bshuf_trans(const unsigned char* in, unsigned char* out, size_t n, size_t es) {
   const size_t nr = n / 8;
-  memset(out, 0, n * es);
   for (size_t b = 0; b < es; ++b)
     for (size_t i = 0; i < nr; ++i) {
-      unsigned char v[8];
-      for (int j = 0; j < 8; ++j) v[j] = in[(8 * i + j) * es + b];
-      for (int k = 0; k < 8; ++k) {
-        unsigned char o = 0;
-        for (int j = 0; j < 8; ++j) o |= (unsigned char)(((v[j] >> k) & 1u) << j);
-        out[(b * 8 + k) * nr + i] = o;
-      }
+      uint64_t x = 0;
+      for (int j = 0; j < 8; ++j) x |= (uint64_t)in[(8 * i + j) * es + b] << (8 * j);
+      x = bshuf_t8x8(x);
+      for (int k = 0; k < 8; ++k) out[(b * 8 + k) * nr + i] = (unsigned char)(x >> (8 * k));
     }
 }
 static void bshuf_untrans(const unsigned char* in, unsigned char* out, size_t n, size_t es) {
   const size_t nr = n / 8;
   for (size_t b = 0; b < es; ++b)
     for (size_t i = 0; i < nr; ++i) {
-      unsigned char v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int k = 0; k < 8; ++k) {
-        const unsigned char o = in[(b * 8 + k) * nr + i];
-        for (int j = 0; j < 8; ++j) v[j] |= (unsigned char)(((o >> j) & 1u) << k);
-      }
-      for (int j = 0; j < 8; ++j) out[(8 * i + j) * es + b] = v[j];
+      uint64_t x = 0;
+      for (int k = 0; k < 8; ++k) x |= (uint64_t)in[(b * 8 + k) * nr + i] << (8 * k);
+      x = bshuf_t8x8(x);
+      for (int j = 0; j < 8; ++j) out[(8 * i + j) * es + b] = (unsigned char)(x >> (8 * j));
     }
 }
 size_t dio_bitshuffle(const void* in, void* out, size_t nelem, size_t elem_size, int inverse) {
