@@ -112,6 +112,14 @@ def partition(items, costs=None):
     return sorted(mine, key=items.index)
 
 
+def partition_for(items, r, n):
+    """The contiguous equal-count slice rank r of n owns (what `partition(items)` returns on that rank)."""
+    items = list(items)
+    base, rem = divmod(len(items), n)
+    start = r * base + min(r, rem)
+    return items[start : start + base + (1 if r < rem else 0)]
+
+
 def partition_contiguous(items, costs, n=None, r=None):
     """Contiguous ranges of `items` with (nearly) equal summed cost: the slice this rank owns.  Beam-transfer
     generation produces a contiguous range of m per call, so a rank that keeps its blocks in HBM from
@@ -141,6 +149,25 @@ def gather_objects(obj):
     out = [None] * size() if rank0() else None
     d.gather_object(obj, out, dst=0)
     return out
+
+
+def exchange(parts):
+    """Personalised all-to-all of picklable objects: `parts[d]` goes to rank d; returns the list over source ranks of what
+    they sent here (the MPI transposes of drift/pipeline/timestream.py:129-185, :700-760 — frequency-partitioned arrays
+    regrouped by m and back).  Without a process group (one rank) the single part comes straight back."""
+    d = _dist()
+    n = size()
+    if len(parts) != (n if d else 1) and not (not d and len(parts) == n):
+        raise ValueError("exchange: one part per rank expected (%d given, %d ranks)" % (len(parts), n))
+    if not d:
+        return [parts[rank()]] if len(parts) > 1 else [parts[0]]
+    mine = None
+    for dst in range(n):
+        out = [None] * n if rank() == dst else None
+        d.gather_object(parts[dst], out, dst=dst)
+        if rank() == dst:
+            mine = out
+    return mine
 
 
 def bcast_object(obj):

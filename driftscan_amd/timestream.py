@@ -73,19 +73,31 @@ class Timestream(object):
             return
         tel = self.telescope
         mmax, nfreq, ntime = tel.mmax, tel.nfreq, self.ntime
-        mine = parallel.partition(list(range(mmax + 1)))
+        # Each rank transforms ITS frequencies, the result is regrouped by m across ranks (the reference's MPI transpose,
+        # timestream.py:150-170): no rank reads every timestream file or holds the full (nfreq, 2, npairs, mmax + 1) array.
+        nranks = parallel.size() if parallel._dist() else 1
+        all_m = list(range(mmax + 1))
+        m_of = [parallel.partition_for(all_m, r, nranks) for r in range(nranks)]
+        f_of = [parallel.partition_for(list(range(nfreq)), r, nranks) for r in range(nranks)]
+        me = parallel.rank() if parallel._dist() else 0
+        local_f = f_of[me]
+        pairs = np.zeros((len(local_f), 2, tel.npairs, mmax + 1), dtype=np.complex128)
+        for k, fi in enumerate(local_f):
+            row = np.fft.fft(self.timestream_f(fi), axis=-1) / ntime        # (npairs, ntime)
+            pairs[k, 0, :, 0] = row[:, 0]
+            pairs[k, 0, :, 1:] = row[:, 1 : mmax + 1]
+            pairs[k, 1, :, 1:] = row[:, : -mmax - 1 : -1].conj()
+        got = parallel.exchange([np.ascontiguousarray(pairs[..., m_of[r]]) for r in range(nranks)])
+        mine = m_of[me]
         if mine:
-            pairs = np.zeros((nfreq, 2, tel.npairs, mmax + 1), dtype=np.complex128)
-            for fi in range(nfreq):
-                row = np.fft.fft(self.timestream_f(fi), axis=-1) / ntime        # (npairs, ntime)
-                pairs[fi, 0, :, 0] = row[:, 0]
-                for mi in range(1, mmax + 1):
-                    pairs[fi, 0, :, mi] = row[:, mi]
-                    pairs[fi, 1, :, mi] = row[:, -mi].conj()
-            for mi in mine:
+            full = np.zeros((nfreq, 2, tel.npairs, len(mine)), dtype=np.complex128)
+            for src, part in enumerate(got):
+                if len(f_of[src]):
+                    full[f_of[src]] = part
+            for k, mi in enumerate(mine):
                 os.makedirs(self._mdir(mi), exist_ok=True)
                 with storage.File(self._mfile(mi), "w") as f:
-                    f.create_dataset("mmode", data=np.ascontiguousarray(pairs[..., mi]))
+                    f.create_dataset("mmode", data=np.ascontiguousarray(full[..., k]))
                     f.attrs["m"] = mi
         parallel.barrier()
         if parallel.rank0():
@@ -266,26 +278,43 @@ def simulate(m, outdir, maps=(), ndays=None, resolution=0, seed=None, **kwargs):
     if ndays is None:
         ndays = tel.ndays
     ntime = 2 * mmax + 1 if resolution == 0 else int(np.round(24 * 3600.0 / resolution))
-    local_freq = parallel.partition(list(range(nfreq)))
+    nranks = parallel.size() if parallel._dist() else 1
+    me = parallel.rank() if parallel._dist() else 0
+    local_freq = parallel.partition_for(list(range(nfreq)), me, nranks)
     lfreq = len(local_freq)
     col_vis = np.zeros((tel.npairs, lfreq, ntime), dtype=np.complex128)
 
     if len(maps) > 0:
+        # The reference's two MPI transposes (timestream.py:700-760): every rank transforms the maps of ITS frequencies,
+        # the a_lm are regrouped by m, every rank projects ITS m through the beam (all frequencies of an m in one grouped
+        # product on the device), and the visibilities come back regrouped by frequency.
+        m_of = [parallel.partition_for(list(range(mmax + 1)), r, nranks) for r in range(nranks)]
+        f_of = [parallel.partition_for(list(range(nfreq)), r, nranks) for r in range(nranks)]
         skymap = None
         for mapfile in maps:
             with storage.File(mapfile, "r") as f:
-                part = f["map"][:]
+                part = f["map"][local_freq[0] : local_freq[-1] + 1] if lfreq else None
             skymap = part if skymap is None else skymap + part
-        alm = healpix.sphtrans_sky(skymap, lmax)                          # (nfreq, npol, L, L): [l, m]
-        for mi in range(mmax + 1):
-            # all frequencies of one m through the beam (a grouped product on the device)
-            vis = bt.project_vector_sky_to_telescope(mi, np.ascontiguousarray(alm[..., mi]))   # (nfreq, ntel)
-            vis = vis.reshape(nfreq, 2, tel.npairs)[local_freq]
-            if mi == 0:
-                col_vis[..., 0] = vis[:, 0].T
-            else:
-                col_vis[..., mi] = vis[:, 0].T
-                col_vis[..., -mi] = vis[:, 1].T.conj()   # conjugate only, not (-1)^m (timestream.py:759-761)
+        alm_loc = (healpix.sphtrans_sky(skymap, lmax) if lfreq else
+                   np.zeros((0, npol, lmax + 1, lmax + 1), dtype=np.complex128))       # (lfreq, npol, L, L): [l, m]
+        got = parallel.exchange([np.ascontiguousarray(alm_loc[..., m_of[r]]) for r in range(nranks)])
+        my_m = m_of[me]
+        alm_m = np.zeros((nfreq, npol, lmax + 1, len(my_m)), dtype=np.complex128)
+        for src, part in enumerate(got):
+            if len(f_of[src]):
+                alm_m[f_of[src]] = part
+        vis_m = np.zeros((len(my_m), nfreq, 2, tel.npairs), dtype=np.complex128)
+        for k, mi in enumerate(my_m):
+            vis_m[k] = bt.project_vector_sky_to_telescope(mi, np.ascontiguousarray(alm_m[..., k])).reshape(nfreq, 2, tel.npairs)
+        back = parallel.exchange([np.ascontiguousarray(vis_m[:, f_of[r]]) for r in range(nranks)])
+        for src, part in enumerate(back):
+            for k, mi in enumerate(m_of[src]):
+                vis = part[k]                                  # (lfreq, 2, npairs)
+                if mi == 0:
+                    col_vis[..., 0] = vis[:, 0].T
+                else:
+                    col_vis[..., mi] = vis[:, 0].T
+                    col_vis[..., -mi] = vis[:, 1].T.conj()   # conjugate only, not (-1)^m (timestream.py:759-761)
 
     if ndays > 0 and lfreq > 0:
         noise_ps = np.asarray(tel.noisepower(np.arange(tel.npairs)[:, np.newaxis], np.array(local_freq)[np.newaxis, :],

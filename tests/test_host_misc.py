@@ -209,3 +209,54 @@ def test_virtual_rank_share():
     finally:
         parallel.set_virtual(None)
     assert (parallel.rank(), parallel.size()) == (0, 1)
+
+
+def _exchange_worker(rank, world, port, q):
+    import os
+
+    import numpy as np
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from driftscan_amd import parallel
+
+    # a frequency-partitioned array regrouped by m and back (the two transposes of the timestream simulation)
+    nfreq, nm = 5, 7
+    f_of = [parallel.partition_for(range(nfreq), r, world) for r in range(world)]
+    m_of = [parallel.partition_for(range(nm), r, world) for r in range(world)]
+    full = np.arange(nfreq * nm, dtype=np.float64).reshape(nfreq, nm)
+    loc = full[f_of[rank]]
+    got = parallel.exchange([np.ascontiguousarray(loc[:, m_of[d]]) for d in range(world)])
+    by_m = np.zeros((nfreq, len(m_of[rank])))
+    for src, part in enumerate(got):
+        by_m[f_of[src]] = part
+    ok1 = np.array_equal(by_m, full[:, m_of[rank]])
+    back = parallel.exchange([np.ascontiguousarray(by_m[f_of[d]]) for d in range(world)])
+    again = np.zeros((len(f_of[rank]), nm))
+    for src, part in enumerate(back):
+        again[:, m_of[src]] = part
+    q.put((rank, bool(ok1), bool(np.array_equal(again, loc)), parallel.partition(list(range(nm))) == m_of[rank]))
+    dist.destroy_process_group()
+
+
+def test_exchange_two_ranks_gloo():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+    assert res == [(0, True, True, True), (1, True, True, True)]
+
+
+def test_exchange_single_process():
+    from driftscan_amd import parallel
+
+    assert parallel.exchange([("a", 1)]) == [("a", 1)]
+    assert parallel.partition_for(range(7), 1, 3) == [3, 4] and parallel.partition_for(range(2), 2, 3) == []
