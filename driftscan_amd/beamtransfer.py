@@ -398,6 +398,7 @@ class BeamTransfer(config.Reader):
             return
         for mi in ms:
             self._dev.pop(mi, None)
+        self.__dict__.pop("_stack_memo", None)   # its views would keep the evicted batch alive
 
     def _generate_svdfiles(self, regen=False, skip_svd_inv=False):
         """svd.hdf5 for every m of this rank (beamtransfer.py:678-728, :730-929) as a stage of its own."""
@@ -502,13 +503,33 @@ class BeamTransfer(config.Reader):
 
     _clcache = {}
 
-    def project_matrix_sky_to_svd_device(self, ms, mat, out, off, temponly=False, zero_first=True):
-        """Batched form: project `mat` for all m in `ms` into the flat device buffer `out`."""
+    def _stacked_products(self, ms, key):
+        """The per-m device products `key` of a batch as ONE tensor (len(ms), ...).  The products of a batch are views of
+        the SVD chain's output, back to back in memory: then the stack is a view as well (no copy, no per-m Python work);
+        the last result is remembered, the KL stage asks for `beam_svd` once per covariance."""
         import torch
 
+        memo = self.__dict__.setdefault("_stack_memo", {})
+        tens = [self._dev_products(mi)[key] for mi in ms]
+        sig = (key, tuple(ms), tuple(t.data_ptr() for t in tens[:2]), tens[-1].data_ptr() if tens else 0)
+        hit = memo.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        t0 = tens[0]
+        step = t0.numel() * t0.element_size()
+        same = all(t.shape == t0.shape and t.is_contiguous() and t.data_ptr() == t0.data_ptr() + i * step
+                   and t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr() for i, t in enumerate(tens))
+        if same and t0.numel() > 0:
+            out = torch.as_strided(t0, (len(tens),) + tuple(t0.shape), (t0.numel(),) + tuple(t0.stride()))
+        else:
+            out = torch.stack(tens)
+        memo[key] = (sig, out)
+        return out
+
+    def project_matrix_sky_to_svd_device(self, ms, mat, out, off, temponly=False, zero_first=True):
+        """Batched form: project `mat` for all m in `ms` into the flat device buffer `out`."""
         ctx = get_context()
-        prods = [self._dev_products(mi) for mi in ms]
-        bsvd = torch.stack([p["beam_svd"] for p in prods])
+        bsvd = self._stacked_products(ms, "beam_svd")
         svnum = np.stack([self._svd_num(mi)[0] for mi in ms])
         cl, mask, sym = self._cl_device(mat)
         ctx.project_cov(bsvd, svnum, cl, out, off, npol=1 if temponly else None, polmask=mask, l0=np.array(ms),

@@ -67,7 +67,7 @@ class DoubleKL(kltransform.KLTransform):
         # ---- stage 2 covariances (doublekl.py:70-74)
         nc1 = (1e-3 / self.telescope.tsys_flat) ** 2
         bt = self.beamtransfer
-        but = torch.stack([bt._dev_products(mi)["beam_ut"] for mi in ms])
+        but = bt._stacked_products(ms, "beam_ut")
         svnum = np.stack([bt._svd_num(mi)[0] for mi in ms])
         if self.use_thermal:  # always true here; spelled out to mirror sn_covariance
             ctx.project_diag(but, svnum, self._npower_device(1.0), N2, off, alpha=1.0 - nc1, accumulate=True)

@@ -125,9 +125,7 @@ class KLTransform(config.Reader):
         ctx.regularise(N, ndofs, off, self._foreground_regulariser)
         # even without thermal noise keep a 1 mK floor (kltransform.py:292-296)
         nc = 1.0 if self.use_thermal else (1e-3 / self.telescope.tsys_flat) ** 2
-        import torch
-
-        but = torch.stack([bt._dev_products(mi)["beam_ut"] for mi in ms])
+        but = bt._stacked_products(ms, "beam_ut")
         svnum = np.stack([bt._svd_num(mi)[0] for mi in ms])
         ctx.project_diag(but, svnum, self._npower_device(nc), N, off, alpha=1.0, accumulate=True)
         return S, N, ndofs, off
@@ -159,6 +157,7 @@ class KLTransform(config.Reader):
 
             for mi in ms:
                 self.beamtransfer._dev.pop(mi, None)
+            self.beamtransfer.__dict__.pop("_stack_memo", None)
             BeamTransfer._clcache.clear()
             ctx.sync()
             torch.cuda.empty_cache()

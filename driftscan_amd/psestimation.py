@@ -270,8 +270,7 @@ class PSExact(PSEstimation):
             return [zero for _ in ms]
         import torch
 
-        prods = [bt._dev_products(mi) for mi in ms]
-        bsvd = torch.stack([p["beam_svd"] for p in prods])
+        bsvd = bt._stacked_products(ms, "beam_svd")
         svnum = np.stack([bt._svd_num(mi)[0] for mi in ms])
         ndofs = svnum.sum(axis=1)
         eoff, etot = _linear_offsets(nmodes * ndofs)
