@@ -105,6 +105,10 @@ SIGNATURES = {
         c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_int, c_vp, c_int,
                 ctypes.POINTER(c_dbl), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int,
                 ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_vp, ctypes.POINTER(c_dbl)]),
+    "dm_bt_columns_c": (
+        c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_int, c_vp, c_int,
+                ctypes.POINTER(c_dbl), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int,
+                ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_vp, ctypes.POINTER(c_dbl)]),
     "dm_bit_truncate_max_complex": (c_int, [c_vp, c_vp, c_i64, c_int, c_i64, c_dbl, c_dbl]),
 }
 
@@ -578,9 +582,11 @@ def _bt_columns(self, nside, cth, sth, frame, polarised, beams, uv, bi, bj, lsid
     l_, lp = _iarr(col_lmax)
     m_lo, m_hi = (0, int(mmax)) if m_range is None else (int(m_range[0]), int(m_range[1]))
     w, wp = (None, None) if ring_w is None else _darr(ring_w)
-    rc = self.lib.dm_bt_columns(self.h, int(nside), cp, sp, frp, int(bool(polarised)), int(beams.shape[0]), self.ptr(beams),
-                                len(i_), up, ip, jp, int(lside), m_lo, m_hi, int(lmax_grp), int(F), int(B), fp, bp, lp,
-                                self.ptr(beam_m), wp)
+    # complex field patterns (a complex128 beams tensor) take the entry that forms _construct_pol_complex in the kernels
+    fn = self.lib.dm_bt_columns_c if beams.is_complex() else self.lib.dm_bt_columns
+    rc = fn(self.h, int(nside), cp, sp, frp, int(bool(polarised)), int(beams.shape[0]), self.ptr(beams),
+            len(i_), up, ip, jp, int(lside), m_lo, m_hi, int(lmax_grp), int(F), int(B), fp, bp, lp,
+            self.ptr(beam_m), wp)
     self.check(rc, "dm_bt_columns")
 
 

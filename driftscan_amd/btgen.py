@@ -70,9 +70,9 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
         nmr = (2 * mtop + 1) if m_range is None else 2 * max(min(m_range[1], mtop) - m_range[0] + 1, 1)
         # default: the fused path (dm_bt_columns) — the Stokes maps are never written; with the SHT refinement the
         # maps are needed (residual), and DRIFTMI_BT_MAPS=1 forces the two-call path for comparisons
-        # (a telescope class with complex field patterns declares `complex_beams = True`: those go through the
-        # two-call path with the complex-pattern map kernel)
-        fused = not niter and os.environ.get("DRIFTMI_BT_MAPS") != "1" and not getattr(tel, "complex_beams", False)
+        # (complex field patterns — a class that declares `complex_beams = True`, or whose beam() returns complex maps —
+        # go through the same fused path: dm_bt_columns_c forms _construct_pol_complex inside the kernels)
+        fused = not niter and os.environ.get("DRIFTMI_BT_MAPS") != "1"
         if niter:   # residual maps, all m of the group's columns in G and in the private coefficient buffer
             nmr = 2 * (lgrp + 1)
         per_col = P * 16 * ((0 if fused else (2 if niter else 1)) * npix + nmr * nring
@@ -119,9 +119,6 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
             # all device-evaluated patterns of the chunk in one call (geometry and tables staged once)
             ctx.bt_beams_cyl(int(nside), cth, sth, frame, dev_specs, beams, dev_rows)
             del hostb
-            if cbeams and fused:
-                raise ValueError("%s.beam() returned a complex field pattern: set `complex_beams = True` on the class "
-                                 "(the memory plan of the fused path has no room for the Stokes maps)" % type(tel).__name__)
             uv = tel.baselines[b_list[cols]] / wl[f_list[cols]][:, None]
             if fused:
                 ctx.bt_columns(int(nside), cth, sth, frame, pol, beams, uv, bi, bj, lside, mmax, int(lmax_bf[cols].max()), F, B,

@@ -291,12 +291,35 @@ __global__ void bt_maps_c_kernel(ring_geo g, frame3 fr, int polarised, int ncol,
 // Algorithmic bytes per (pixel, column): 2 beams x ncomp x 8 B from L1/L2 (beams are shared by all baselines of a
 // frequency), 16 P nm / npix-th of the G row written — compute-bound, see DESIGN.md section 4.5.
 struct fdft_col { double u, v, pre; int bi, bj; };   // pre = 1 / sqrt(Omega_i Omega_j); bi < 0: padding
+// Map values of one (pixel, column) from COMPLEX field patterns (drift/util/_fast_tools.pyx:169-242, _construct_pol_complex,
+// and telescope.py:1156-1176 with complex beams): a, b point at the NCOMP complex components of the two beams at this
+// pixel (interleaved re, im), (tre, tim) = pre * fringe.  The real-pattern kernels keep their own (cheaper) expressions.
+template <int P>
+__device__ __forceinline__ void bt_synth_complex(const double* __restrict__ a, const double* __restrict__ b, double tre, double tim,
+                                                 double (&m_re)[P], double (&m_im)[P]) {
+  const cplx tc = make_double2(tre, tim);
+  if constexpr (P == 1) {
+    const cplx bb = cmulc(make_double2(dm_ldg(a), dm_ldg(a, 1)), make_double2(dm_ldg(b), dm_ldg(b, 1)));  // b_i conj(b_j)
+    const cplx v = cmul(tc, bb);
+    m_re[0] = v.x; m_im[0] = v.y;
+  } else {
+    const cplx a0 = make_double2(dm_ldg(a), dm_ldg(a, 1)), a1 = make_double2(dm_ldg(a, 2), dm_ldg(a, 3));
+    const cplx b0 = make_double2(dm_ldg(b), dm_ldg(b, 1)), b1 = make_double2(dm_ldg(b, 2), dm_ldg(b, 3));
+    const cplx p00 = cmulc(a0, b0), p11 = cmulc(a1, b1), p01 = cmulc(a0, b1), p10 = cmulc(a1, b0);
+    const cplx vI = cmul(tc, cadd(p00, p11)), vQ = cmul(tc, csub(p00, p11)), vU = cmul(tc, cadd(p01, p10));
+    const cplx sv = cmul(tc, csub(p01, p10));
+    m_re[0] = vI.x; m_im[0] = vI.y;
+    m_re[1] = vQ.x; m_im[1] = vQ.y;
+    m_re[2] = vU.x; m_im[2] = vU.y;
+    m_re[3] = -sv.y; m_im[3] = sv.x;   // 1j * tc * (p01 - p10)
+  }
+}
 __global__ __launch_bounds__(256) void bt_fdft_pre_kernel(fdft_col* __restrict__ cols, int ncol, const double* __restrict__ omega) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= ncol) return;
   cols[c].pre = 1.0 / sqrt(omega[cols[c].bi] * omega[cols[c].bj]);
 }
-template <int P, int NMG, int NCG>
+template <int P, int NMG, int NCG, bool CB = false>
 __global__ __launch_bounds__(256) void bt_fused_dft_kernel(ring_geo g, frame3 fr, const double* __restrict__ beams, size_t bstride,
                                                            const fdft_col* __restrict__ cols, int ncol16, int m_lo, int cnt,
                                                            const double* __restrict__ ring_w, cplx* __restrict__ G, int ncp,
@@ -393,15 +416,18 @@ __global__ __launch_bounds__(256) void bt_fused_dft_kernel(ring_geo g, frame3 fr
       // branch-free: padding columns and pixels below the horizon read beam 0 and are zeroed through `pre`, so the
       // loads and the sincos of all NCG groups of a quad can be in flight together
       const bool on = cdc.bi >= 0 && hz != 0.0;
-      const double* a = beams + (size_t)max(cdc.bi, 0) * bstride + NCOMP * pix;
-      const double* b = beams + (size_t)max(cdc.bj, 0) * bstride + NCOMP * pix;
+      constexpr int BW = CB ? 2 : 1;   // doubles per beam component (complex patterns: interleaved re, im)
+      const double* a = beams + (size_t)max(cdc.bi, 0) * bstride + BW * NCOMP * pix;
+      const double* b = beams + (size_t)max(cdc.bj, 0) * bstride + BW * NCOMP * pix;
       // the fringe phase in turns: sincospi reduces 2 t exactly (no large-argument path, no branches), which is
       // also closer to the true phase than sin(fl(2 pi t)) once |u| reaches hundreds of wavelengths
       double sf, cf;
       sincospi(2.0 * (cdc.u * nx + cdc.v * ny), &sf, &cf);
       const double pre = on ? cdc.pre : 0.0;
       const double tre = pre * cf, tim = pre * sf;
-      if constexpr (P == 1) {
+      if constexpr (CB) {
+        bt_synth_complex<P>(a, b, tre, tim, m_re, m_im);
+      } else if constexpr (P == 1) {
         const double bb = dm_ldg(a) * dm_ldg(b);
         m_re[0] = tre * bb;
         m_im[0] = tim * bb;
@@ -457,7 +483,7 @@ __global__ __launch_bounds__(256) void bt_fused_dft_kernel(ring_geo g, frame3 fr
 // LDS: two buffers x 4 quads x NCG groups x P x (re, im) x 64 lanes x 8 B (32 KB for <4, *, 1> and <1, *, 4>); one
 // barrier per chunk (the buffers alternate: a wave can only reach the second write of a buffer through the barrier
 // that every reader of its previous content has passed).
-template <int P, int NMG, int NCG>
+template <int P, int NMG, int NCG, bool CB = false>
 __global__ __launch_bounds__(256) void bt_fused_dft2_kernel(ring_geo g, frame3 fr, const double* __restrict__ beams, size_t bstride,
                                                             const fdft_col* __restrict__ cols, int ncol16, int m_lo, int cnt,
                                                             const double* __restrict__ ring_w, cplx* __restrict__ G, int ncp,
@@ -531,13 +557,22 @@ __global__ __launch_bounds__(256) void bt_fused_dft2_kernel(ring_geo g, frame3 f
         for (int c = 0; c < NCG; ++c) {
           const fdft_col cdc = s_cd[c * 16 + (lane & 15)];
           const bool on = cdc.bi >= 0 && hz != 0.0;
-          const double* a = beams + (size_t)max(cdc.bi, 0) * bstride + NCOMP * pix;
-          const double* b = beams + (size_t)max(cdc.bj, 0) * bstride + NCOMP * pix;
+          constexpr int BW = CB ? 2 : 1;
+          const double* a = beams + (size_t)max(cdc.bi, 0) * bstride + BW * NCOMP * pix;
+          const double* b = beams + (size_t)max(cdc.bj, 0) * bstride + BW * NCOMP * pix;
           double sf, cf;
           sincospi(2.0 * (cdc.u * nx + cdc.v * ny), &sf, &cf);
           const double pre = on ? cdc.pre : 0.0;
           const double tre = pre * cf, tim = pre * sf;
-          if constexpr (P == 1) {
+          if constexpr (CB) {
+            double m_re[P], m_im[P];
+            bt_synth_complex<P>(a, b, tre, tim, m_re, m_im);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+              s_map[buf][wave][c][p][0][lane] = m_re[p];
+              s_map[buf][wave][c][p][1][lane] = m_im[p];
+            }
+          } else if constexpr (P == 1) {
             const double bb = dm_ldg(a) * dm_ldg(b);
             s_map[buf][wave][c][0][0][lane] = tre * bb;
             s_map[buf][wave][c][0][1][lane] = tim * bb;
@@ -631,7 +666,7 @@ __global__ __launch_bounds__(256) void bt_fused_dft2_kernel(ring_geo g, frame3 f
 // by the same expressions as in the two kernels above (the caps still go through those).
 // LDS: P N complex values + N / 2 twiddles (144 KB at nside 512 with four Stokes maps; beyond 160 KB the caller
 // keeps the matrix form for the belt too).  The result of a ring does not depend on the m-range asked for.
-template <int P, int NPT, int TPB>
+template <int P, int NPT, int TPB, bool CB = false>
 __global__ __launch_bounds__(TPB) void bt_fused_fft_kernel(ring_geo g, frame3 fr, const double* __restrict__ beams, size_t bstride,
                                                            const fdft_col* __restrict__ cols, int ncol, int m_lo, int cnt,
                                                            const double* __restrict__ ring_w, cplx* __restrict__ G, int ncp,
@@ -682,13 +717,20 @@ __global__ __launch_bounds__(TPB) void bt_fused_fft_kernel(ring_geo g, frame3 fr
       const int jr = (int)(__brev((unsigned)j) >> (32 - logn));
       const size_t pix = (size_t)pix0 + j;
       const bool on = cdc.bi >= 0 && hzv[q] != 0.0;
-      const double* a = beams + (size_t)max(cdc.bi, 0) * bstride + NCOMP * pix;
-      const double* b = beams + (size_t)max(cdc.bj, 0) * bstride + NCOMP * pix;
+      constexpr int BW = CB ? 2 : 1;
+      const double* a = beams + (size_t)max(cdc.bi, 0) * bstride + BW * NCOMP * pix;
+      const double* b = beams + (size_t)max(cdc.bj, 0) * bstride + BW * NCOMP * pix;
       double sf, cf;
       sincospi(2.0 * (cdc.u * nxv[q] + cdc.v * nyv[q]), &sf, &cf);
       const double pre = on ? cdc.pre : 0.0;
       const double tre = pre * cf, tim = pre * sf;
-      if constexpr (P == 1) {
+      if constexpr (CB) {
+        double m_re[P], m_im[P];
+        bt_synth_complex<P>(a, b, tre, tim, m_re, m_im);
+        const int jp = ph(jr);
+#pragma unroll
+        for (int p = 0; p < P; ++p) X[(size_t)p * Np + jp] = make_double2(m_re[p], m_im[p]);
+      } else if constexpr (P == 1) {
         const double bb = dm_ldg(a) * dm_ldg(b);
         X[ph(jr)] = make_double2(tre * bb, tim * bb);
       } else {
@@ -1120,6 +1162,7 @@ struct bt_synth_in {
   const double* uv_host;
   const int* bi_host;
   const int* bj_host;
+  int complex_beams;   // beams_dev holds complex patterns (interleaved re, im): _construct_pol_complex inside the kernels
 };
 
 static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised,
@@ -1160,7 +1203,8 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
                        tw);
   if (fused && cnt > 0) {
     // beam solid angles, per-column constants, then synthesis + DFT in one kernel (no Stokes maps in HBM)
-    const int ncomp = polarised ? 2 : 1;
+    const bool cbm = syn->complex_beams != 0;
+    const int ncomp = (polarised ? 2 : 1) * (cbm ? 2 : 1);   // doubles per pixel of a beam (complex patterns: re, im)
     const size_t bstride = (size_t)npix * ncomp;
     frame3 fr = make_frame(syn->frame_host, syn->frame_host + 3, syn->frame_host + 6);
     double* omega = dm_ws_alloc_t<double>(ctx, syn->nbeam);
@@ -1227,24 +1271,24 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
       if (wide) {
         const int npt = std::max(1, N / 1024);
         if (polarised) {
-          if (npt == 1) DM_TRY(fft_launch(bt_fused_fft_kernel<4, 1, 1024>, 1024));
-          else DM_TRY(fft_launch(bt_fused_fft_kernel<4, 2, 1024>, 1024));   // N = 2048 (4096 x 4 maps does not fit)
+          if (npt == 1) DM_TRY(fft_launch((cbm ? bt_fused_fft_kernel<4, 1, 1024, true> : bt_fused_fft_kernel<4, 1, 1024>), 1024));
+          else DM_TRY(fft_launch((cbm ? bt_fused_fft_kernel<4, 2, 1024, true> : bt_fused_fft_kernel<4, 2, 1024>), 1024));   // N = 2048 (4096 x 4 maps does not fit)
         } else {
-          DM_TRY(fft_launch(bt_fused_fft_kernel<1, 4, 1024>, 1024));         // N = 4096
+          DM_TRY(fft_launch((cbm ? bt_fused_fft_kernel<1, 4, 1024, true> : bt_fused_fft_kernel<1, 4, 1024>), 1024));         // N = 4096
         }
       } else {
         const int npt = std::max(1, N / 256);
         if (polarised) {
-          if (npt == 1) DM_TRY(fft_launch(bt_fused_fft_kernel<4, 1, 256>, 256));
-          else if (npt == 2) DM_TRY(fft_launch(bt_fused_fft_kernel<4, 2, 256>, 256));      // N = 512
-          else if (npt == 4) DM_TRY(fft_launch(bt_fused_fft_kernel<4, 4, 256>, 256));
-          else DM_TRY(fft_launch(bt_fused_fft_kernel<4, 8, 256>, 256));
+          if (npt == 1) DM_TRY(fft_launch((cbm ? bt_fused_fft_kernel<4, 1, 256, true> : bt_fused_fft_kernel<4, 1, 256>), 256));
+          else if (npt == 2) DM_TRY(fft_launch((cbm ? bt_fused_fft_kernel<4, 2, 256, true> : bt_fused_fft_kernel<4, 2, 256>), 256));      // N = 512
+          else if (npt == 4) DM_TRY(fft_launch((cbm ? bt_fused_fft_kernel<4, 4, 256, true> : bt_fused_fft_kernel<4, 4, 256>), 256));
+          else DM_TRY(fft_launch((cbm ? bt_fused_fft_kernel<4, 8, 256, true> : bt_fused_fft_kernel<4, 8, 256>), 256));
         } else {
-          if (npt == 1) DM_TRY(fft_launch(bt_fused_fft_kernel<1, 1, 256>, 256));
-          else if (npt == 2) DM_TRY(fft_launch(bt_fused_fft_kernel<1, 2, 256>, 256));
-          else if (npt == 4) DM_TRY(fft_launch(bt_fused_fft_kernel<1, 4, 256>, 256));
-          else if (npt == 8) DM_TRY(fft_launch(bt_fused_fft_kernel<1, 8, 256>, 256));      // N = 2048
-          else DM_TRY(fft_launch(bt_fused_fft_kernel<1, 16, 256>, 256));
+          if (npt == 1) DM_TRY(fft_launch((cbm ? bt_fused_fft_kernel<1, 1, 256, true> : bt_fused_fft_kernel<1, 1, 256>), 256));
+          else if (npt == 2) DM_TRY(fft_launch((cbm ? bt_fused_fft_kernel<1, 2, 256, true> : bt_fused_fft_kernel<1, 2, 256>), 256));
+          else if (npt == 4) DM_TRY(fft_launch((cbm ? bt_fused_fft_kernel<1, 4, 256, true> : bt_fused_fft_kernel<1, 4, 256>), 256));
+          else if (npt == 8) DM_TRY(fft_launch((cbm ? bt_fused_fft_kernel<1, 8, 256, true> : bt_fused_fft_kernel<1, 8, 256>), 256));      // N = 2048
+          else DM_TRY(fft_launch((cbm ? bt_fused_fft_kernel<1, 16, 256, true> : bt_fused_fft_kernel<1, 16, 256>), 256));
         }
       }
     }
@@ -1267,15 +1311,15 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
     };
     static const int shared_env = getenv("DM_FDFT_SHARED") ? atoi(getenv("DM_FDFT_SHARED")) : 1;
     if (polarised) {
-      if (nmg <= 1) launch(bt_fused_dft_kernel<4, 1, 4>, 1, 4);
-      else if (shared_env == 2 && nmg > 8) launch2(bt_fused_dft2_kernel<4, 4, 1>, 4, 1);
-      else if (shared_env >= 1 && nmg > 2) launch2(bt_fused_dft2_kernel<4, 2, 1>, 2, 1);
-      else launch(bt_fused_dft_kernel<4, 2, 2>, 2, 2);
+      if (nmg <= 1) launch((cbm ? bt_fused_dft_kernel<4, 1, 4, true> : bt_fused_dft_kernel<4, 1, 4>), 1, 4);
+      else if (shared_env == 2 && nmg > 8) launch2((cbm ? bt_fused_dft2_kernel<4, 4, 1, true> : bt_fused_dft2_kernel<4, 4, 1>), 4, 1);
+      else if (shared_env >= 1 && nmg > 2) launch2((cbm ? bt_fused_dft2_kernel<4, 2, 1, true> : bt_fused_dft2_kernel<4, 2, 1>), 2, 1);
+      else launch((cbm ? bt_fused_dft_kernel<4, 2, 2, true> : bt_fused_dft_kernel<4, 2, 2>), 2, 2);
     } else {
-      if (nmg <= 1) launch(bt_fused_dft_kernel<1, 1, 8>, 1, 8);
-      else if (shared_env == 2 && nmg > 8) launch2(bt_fused_dft2_kernel<1, 4, 4>, 4, 4);
-      else if (shared_env >= 1 && nmg > 4) launch2(bt_fused_dft2_kernel<1, 2, 4>, 2, 4);
-      else launch(bt_fused_dft_kernel<1, 4, 4>, 4, 4);
+      if (nmg <= 1) launch((cbm ? bt_fused_dft_kernel<1, 1, 8, true> : bt_fused_dft_kernel<1, 1, 8>), 1, 8);
+      else if (shared_env == 2 && nmg > 8) launch2((cbm ? bt_fused_dft2_kernel<1, 4, 4, true> : bt_fused_dft2_kernel<1, 4, 4>), 4, 4);
+      else if (shared_env >= 1 && nmg > 4) launch2((cbm ? bt_fused_dft2_kernel<1, 2, 4, true> : bt_fused_dft2_kernel<1, 2, 4>), 2, 4);
+      else launch((cbm ? bt_fused_dft_kernel<1, 4, 4, true> : bt_fused_dft_kernel<1, 4, 4>), 4, 4);
     }
     DM_HIP(ctx, hipGetLastError());
   }
@@ -1517,7 +1561,19 @@ int dm_bt_columns(dm_ctx* ctx, int nside, const double* ring_cth_host, const dou
                   const int* col_b_host, const int* col_lmax_host, void* beam_m_dev, const double* ring_w_host) {
   if (!ctx) return DM_EARG;
   DM_ARG(ctx, frame_host && nbeam > 0 && beams_dev && uv_host && bi_host && bj_host);
-  bt_synth_in syn{frame_host, nbeam, beams_dev, uv_host, bi_host, bj_host};
+  bt_synth_in syn{frame_host, nbeam, beams_dev, uv_host, bi_host, bj_host, 0};
+  return bt_sht_impl(ctx, nside, ring_cth_host, ring_sth_host, polarised, lside, m_lo, m_hi, lmax_grp, F, B, ncol, col_f_host,
+                     col_b_host, col_lmax_host, nullptr, beam_m_dev, 0, ring_w_host, &syn);
+}
+
+// dm_bt_columns for COMPLEX field patterns (beams_dev: nbeam maps of npix * ncomp complex128, zero below the horizon)
+int dm_bt_columns_c(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, const double* frame_host,
+                    int polarised, int nbeam, const void* beams_dev, int ncol, const double* uv_host, const int* bi_host,
+                    const int* bj_host, int lside, int m_lo, int m_hi, int lmax_grp, int F, int B, const int* col_f_host,
+                    const int* col_b_host, const int* col_lmax_host, void* beam_m_dev, const double* ring_w_host) {
+  if (!ctx) return DM_EARG;
+  DM_ARG(ctx, frame_host && nbeam > 0 && beams_dev && uv_host && bi_host && bj_host);
+  bt_synth_in syn{frame_host, nbeam, reinterpret_cast<const double*>(beams_dev), uv_host, bi_host, bj_host, 1};
   return bt_sht_impl(ctx, nside, ring_cth_host, ring_sth_host, polarised, lside, m_lo, m_hi, lmax_grp, F, B, ncol, col_f_host,
                      col_b_host, col_lmax_host, nullptr, beam_m_dev, 0, ring_w_host, &syn);
 }

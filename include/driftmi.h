@@ -320,6 +320,14 @@ int dm_bt_columns(dm_ctx* ctx, int nside, const double* ring_cth_host, const dou
                   const int* bj_host, int lside, int m_lo, int m_hi, int lmax_grp, int F, int B, const int* col_f_host,
                   const int* col_b_host, const int* col_lmax_host, void* beam_m_dev, const double* ring_w_host);
 
+/* dm_bt_columns_c: the same for COMPLEX field patterns — beams_dev holds nbeam maps of npix * ncomp complex128 (zero
+ * below the horizon), the map values are formed as drift/util/_fast_tools.pyx:169-242 (_construct_pol_complex) and
+ * drift/core/telescope.py:1156-1176 form them, inside the ring transform. */
+int dm_bt_columns_c(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, const double* frame_host,
+                    int polarised, int nbeam, const void* beams_dev, int ncol, const double* uv_host, const int* bi_host,
+                    const int* bj_host, int lside, int m_lo, int m_hi, int lmax_grp, int F, int B, const int* col_f_host,
+                    const int* col_b_host, const int* col_lmax_host, void* beam_m_dev, const double* ring_w_host);
+
 /* ---- bit truncation of beam-transfer blocks before they are written ------------------------------- */
 /* In place on `nrows` rows of `ncols` complex128 values (`ld` elements between rows): every real and
  * imaginary part is rounded to the coarsest multiple of a power of two that keeps its error below

@@ -207,7 +207,8 @@ def test_complex_patterns_pixel_kernel(ctx):
 @pytest.mark.parametrize("pol", [False, True])
 def test_complex_beam_telescope_vs_oracle(ctx, pol):
     """A dish array whose apertures carry a phase gradient (complex field patterns): beam() -> complex host maps ->
-    dm_bt_maps_c -> dm_bt_sht, against the oracle fed with the same patterns."""
+    the fused path (dm_bt_columns_c: _construct_pol_complex inside the ring-transform kernels, FFT belt and caps) and the
+    two-call path (dm_bt_maps_c -> dm_bt_sht), both against the oracle fed with the same patterns."""
     from driftscan_amd import btgen, disharray
 
     base = disharray.PolarisedDishArray if pol else disharray.UnpolarisedDishArray
@@ -231,10 +232,21 @@ def test_complex_beam_telescope_vs_oracle(ctx, pol):
         return amp[:, None] * (np.array([0.0, 1.0]) if t.polarisation[feed] == "X" else np.array([1.0, 0.0]))
 
     _check_beam_m(t, ctx, _oracle_desc(t, beam_fn), mlist=[0, 1, 7, t.mmax])
+    fused = btgen.beam_m_all(t, ctx=ctx).cpu().numpy()
+    import os
 
-    # without the declaration the fused memory plan refuses complex patterns instead of dropping the imaginary part
+    os.environ["DRIFTMI_BT_MAPS"] = "1"
+    try:
+        two_call = btgen.beam_m_all(t, ctx=ctx).cpu().numpy()
+    finally:
+        os.environ.pop("DRIFTMI_BT_MAPS", None)
+    assert np.abs(fused - two_call).max() <= 1e-12 * np.abs(two_call).max()
+    # a partition of m gives the same bits as the whole range (FFT belt + caps, complex patterns)
+    part = btgen.beam_m_all(t, ctx=ctx, m_range=(3, 9)).cpu().numpy()
+    assert np.array_equal(part, fused[3:10])
+
+    # the declaration is not needed: complex maps returned by beam() are recognised (nothing drops the imaginary part)
     class Undeclared(PhasedDishes):
         complex_beams = False
 
-    with pytest.raises(ValueError, match="complex_beams"):
-        btgen.beam_m_all(Undeclared.from_config(cfg), ctx=ctx)
+    assert np.array_equal(btgen.beam_m_all(Undeclared.from_config(cfg), ctx=ctx).cpu().numpy(), fused)
