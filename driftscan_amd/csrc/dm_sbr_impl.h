@@ -56,6 +56,9 @@ struct sb_mat {
   cplx* Yp;     // (n / SQR + 1) x SB: partial dot products v_q^H P[:, c]
   double* Np;   // 2 x (n / SQR + 1): partial norms (double-buffered over q)
   int npstride; // n / SQR + 1
+  cplx* Rb;     // look-ahead only (else NULL): n x SB, row c holds the part of R of column c that lies beyond its diagonal
+                // block, A[c][i0 ..] with i0 = (c / SB + 1) SB — the trailing update of the previous panel is still
+                // writing the rows of A this panel would put it in
 };
 
 // ---- S1: launched panel QR (any size; two launches per column, all matrices in lock-step) ----------------------
@@ -404,7 +407,10 @@ __device__ __forceinline__ void sb_fused_half(const sb_mat& M, cplx (&a)[SFR][SF
         dm_stg(M.Vp, (size_t)qq * n + i, v[r]);
         dm_stg(M.Vp2, (size_t)qq * n + i, v[r]);
         dm_stg(M.Vt, (size_t)(k0 + qq) * n + i, v[r]);
-        if (has) {
+        if (M.Rb) {
+          if (has ? i <= lead : i - i0 < SB)
+            dm_stg(M.Rb, (size_t)(k0 + qq) * SB + (i - i0), (!has || i < lead) ? cconj(a[r][0]) : make_double2(R.beta, 0.0));
+        } else if (has) {
           if (i <= lead) dm_stg(M.A, (size_t)(k0 + qq) * M.lda + i, i < lead ? cconj(a[r][0]) : make_double2(R.beta, 0.0));
         } else {
           dm_stg(M.A, (size_t)(k0 + qq) * M.lda + i, cconj(a[r][0]));
@@ -422,7 +428,9 @@ __device__ __forceinline__ void sb_fused_half(const sb_mat& M, cplx (&a)[SFR][SF
   }
 }
 
-__global__ __launch_bounds__(SFT) void sb_panel_fused_kernel(const sb_mat* __restrict__ ms, int k0, int a0) {
+// snap != 0: the panel is read from the snapshot M.Pw (row q = column k0 + q, already updated by the previous panel's
+// reflectors: the look-ahead copy made before that panel's trailing update started) instead of from A.
+__global__ __launch_bounds__(SFT) void sb_panel_fused_kernel(const sb_mat* __restrict__ ms, int k0, int a0, int snap) {
   const sb_mat M = ms[blockIdx.x];
   const int n = M.n;
   const int m = n - k0 - SB;
@@ -450,7 +458,8 @@ __global__ __launch_bounds__(SFT) void sb_panel_fused_kernel(const sb_mat* __res
       const int i = i0 + tid + SFT * r;
 #pragma unroll
       for (int c = 0; c < SFH; ++c)
-        a[r][c] = (i < n) ? cconj(dm_ldg(M.A, (size_t)(k0 + cb + c) * M.lda + i)) : make_double2(0.0, 0.0);
+        a[r][c] = (i < n) ? cconj(snap ? dm_ldg(M.Pw, (size_t)(cb + c) * n + i) : dm_ldg(M.A, (size_t)(k0 + cb + c) * M.lda + i))
+                          : make_double2(0.0, 0.0);
     }
     // ---- the reflectors of the earlier sub-panels: a_c <- a_c - conj(tau_q) v_q (v_q^H a_c), q = 0 .. cb - 1 in turn
     __syncthreads();  // their vectors are in memory (this workgroup wrote them: L1 holds no older copy)
@@ -541,8 +550,19 @@ __global__ __launch_bounds__(256) void sb_s_kernel(const sb_s_desc* __restrict__
   }
 }
 
+// look-ahead: snapshot of the rows [i0, i0 + SB) of A at the columns >= i0 + SB (the next panel, as the trailing update of
+// the previous panel left it) into Pw; the grouped product that follows applies the current panel's update to the copy
+__global__ __launch_bounds__(256) void sb_strip_copy_kernel(const sb_mat* __restrict__ ms, int i0) {
+  const sb_mat M = ms[blockIdx.z];
+  const int q = blockIdx.y;
+  const int c = i0 + SB + blockIdx.x * 256 + threadIdx.x;
+  if (c >= M.n || i0 + q >= M.n) return;
+  dm_stg(M.Pw, (size_t)q * M.n + c, dm_ldg(M.A, (size_t)(i0 + q) * M.lda + c));
+}
+
 // band extraction: AB[c][i] = A_math[c + i][c] = conj(C[c][c + i]), i <= SB; the bulge rows start at zero
-struct sb_bmat { const cplx* A; int lda; int n; cplx* AB; };
+// (rows c < nrb: the entries beyond the diagonal block of c come from the look-ahead's R buffer, see sb_mat::Rb)
+struct sb_bmat { const cplx* A; int lda; int n; cplx* AB; const cplx* Rb; int nrb; };
 __global__ __launch_bounds__(256) void sb_band_extract_kernel(const sb_bmat* __restrict__ ms) {
   const sb_bmat M = ms[blockIdx.y];
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -550,7 +570,9 @@ __global__ __launch_bounds__(256) void sb_band_extract_kernel(const sb_bmat* __r
   const int c = (int)(idx / SLD), i = (int)(idx % SLD);
   cplx v = make_double2(0.0, 0.0);
   if (i <= SB && c + i < M.n) {
-    v = cconj(dm_ldg(M.A, (size_t)c * M.lda + c + i));
+    const int i0 = (c / SB + 1) * SB;
+    if (M.Rb && c < M.nrb && c + i >= i0) v = cconj(dm_ldg(M.Rb, (size_t)c * SB + (c + i - i0)));
+    else v = cconj(dm_ldg(M.A, (size_t)c * M.lda + c + i));
     if (i == 0) v.y = 0.0;
   }
   dm_stg(M.AB, idx, v);

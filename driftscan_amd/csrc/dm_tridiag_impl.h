@@ -1663,6 +1663,7 @@ struct tri_side {
   std::vector<hipEvent_t> ev;
 };
 tri_side g_side;
+hipStream_t g_la_stream = nullptr;   // high-priority stream of the first-stage look-ahead
 hipEvent_t side_event(size_t i) {
   while (g_side.ev.size() <= i) {
     hipEvent_t e = nullptr;
@@ -1807,6 +1808,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
   auto nrefl_of = [&](int n) { return two_stage ? std::max(0, n - TNB - 1) : std::max(0, n - 1); };
 #if DM_TNB == 32
   cplx* sbPart = nullptr;
+  cplx *sbPP2 = nullptr, *sbRb = nullptr;   // look-ahead of the first stage: second set of panel buffers, R blocks
   cplx *sbPw = nullptr, *sbXt = nullptr, *sbYp = nullptr, *sbAB = nullptr, *sbVd = nullptr, *sbTau2 = nullptr, *sbM1 = nullptr,
        *sbS = nullptr;
   double* sbNp = nullptr;
@@ -1838,6 +1840,12 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
     sbPart = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * SB * 32 + (size_t)np * SB * SB * 32, 1));
     if (!sbPart) return DM_ENOMEM;
     sbNext = dm_ws_alloc_t<int>(ctx, 2 * (size_t)np + 9);  // sweep counters, owners, queue heads, error flag
+    if (maxn - SB <= SFR * SFT && getenv("DM_SB_LOOKAHEAD") && atoi(getenv("DM_SB_LOOKAHEAD")) != 0) {   // (look-ahead experiment)
+      sbPP2 = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * 3 * TNB, 1));
+      sbRb = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(totn * SB, 1));
+      if (!sbPP2 || !sbRb) return DM_ENOMEM;
+      DM_TRY(dm_fill_zero(ctx, sbPP2, sizeof(cplx) * totn * 3 * TNB));
+    }
     if (!sbPw || !sbXt || !sbYp || !sbNp || !sbAB || !sbVd || !sbTau2 || !sbM1 || !sbS || !sbProg || !sbNext) return DM_ENOMEM;
   }
 
@@ -1855,17 +1863,17 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       cmax = std::max(cmax, probs[p].n);
       cplx* pp = PP + offn[p] * 3 * TNB;
       sm[i] = sb_mat{probs[p].C, probs[p].ldc, probs[p].n, Vt + off[p], pp, pp + n * TNB, pp + 2 * n * TNB,
-                     sbPw + offn[p] * SB, tau + offn[p], sbYp + offyp[p] * SB, sbNp + offyp[p] * 2, (int)(n / SQR + 1)};
+                     sbPw + offn[p] * SB, tau + offn[p], sbYp + offyp[p] * SB, sbNp + offyp[p] * 2, (int)(n / SQR + 1), nullptr};
       dmv[i] = sb_dmat{probs[p].C, probs[p].ldc, probs[p].n};
-      bm[i] = sb_bmat{probs[p].C, probs[p].ldc, probs[p].n, sbAB + offn[p] * SLD};
+      bm[i] = sb_bmat{probs[p].C, probs[p].ldc, probs[p].n, sbAB + offn[p] * SLD, nullptr, 0};
       cm[i] = sb_chase_mat{sbAB + offn[p] * SLD, probs[p].n, sbVd + offvd[p], sbTau2 + offt2[p], dd + offn[p], ee + offn[p],
                            sb_jb[p], sbProg + 2 * offn[p], sbNext + p, sbNext + np + p};
     }
     sb_mat* d_sm = dm_ws_upload(ctx, sm);
     sb_dmat* d_dm = dm_ws_upload(ctx, dmv);
-    sb_bmat* d_bm = dm_ws_upload(ctx, bm);
+    sb_bmat* d_bm = nullptr;   // uploaded before the band extraction (the look-ahead decides where R lives)
     sb_chase_mat* d_cmat = dm_ws_upload(ctx, cm);
-    if (!d_sm || !d_dm || !d_bm || !d_cmat) return DM_ENOMEM;
+    if (!d_sm || !d_dm || !d_cmat) return DM_ENOMEM;
     DM_TRY(dm_fill_zero(ctx, Tbig, sizeof(cplx) * tottb));
     {
       // the paired chase writes whole rows of the reflector array: only the slots no sweep reaches are cleared
@@ -1876,77 +1884,117 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
     DM_TRY(dm_fill_zero(ctx, sbTau2, sizeof(cplx) * tott2));
     hipLaunchKernelGGL(sb_diag_tiles_kernel, dim3((cmax + 127) / 128, nc), dim3(256), 0, ctx->stream, d_dm);
     // ---- S1: dense -> band, one panel of SB columns at a time, all matrices in lock-step
-    for (int k0 = 0; cmax - k0 - SB >= 2; k0 += SB) {
-      const int i0 = k0 + SB;        // first row of the trailing matrix
-      const int a0 = i0 & ~127;      // its 128-aligned block origin (the panel vectors are zero on [a0, i0))
-      static const bool nofuse = getenv("DM_SB_NOFUSE") != nullptr;
-      if (cmax - i0 <= SFR * SFT && !nofuse) {
-        // panels that fit the registers of one workgroup per matrix: the whole QR in one launch
-        double fl = 0.0;  // Householder QR of an m x SB panel: 2 SB^2 (m - SB / 3) complex multiply-adds
-        for (int p : ch) {
-          const double m = probs[p].n - i0;
-          if (m >= 2) fl += 8.0 * 2.0 * SB * SB * std::max(m - SB / 3.0, 1.0);
-        }
-        dm_prof_scope ps(ctx, DM_PROF_SB_PANEL, fl);
-        hipLaunchKernelGGL(sb_panel_fused_kernel, dim3(nc), dim3(SFT), 0, ctx->stream, d_sm, k0, a0);
-      } else {
-        hipLaunchKernelGGL(sb_panel_load_kernel, dim3((cmax - a0 + 255) / 256, nc), dim3(256), 0, ctx->stream, d_sm, k0, a0);
-        const int nchmax = (cmax - i0 + SQR - 1) / SQR;
-        for (int q = 0; q <= SB; ++q) {
-          hipLaunchKernelGGL(sb_qr_update_kernel, dim3(nchmax, nc), dim3(256), 0, ctx->stream, d_sm, k0, q);
-          if (q < SB) hipLaunchKernelGGL(sb_qr_dots_kernel, dim3(nchmax, nc), dim3(256), 0, ctx->stream, d_sm, k0, q);
-        }
+    //
+    // A panel is two chains of launches.  The "side" chain needs nothing but the panel itself: QR, Gram slices, T factor,
+    // X^T = T^T V^H.  The "main" chain needs the trailing matrix: Y (slices + sum), M = V^H Y (slices), S, W, and the
+    // rank-64 update.  LOOK-AHEAD (all panels of the chunk small enough for the one-workgroup QR): before the update of
+    // panel k starts, the rows of the NEXT panel are copied and updated on their own (32 rows: a small product), and the
+    // side chain of panel k + 1 runs on a second stream from that snapshot WHILE the main stream updates the trailing
+    // matrix — the latency-bound QR hides behind the HBM-bound update.  What the concurrent chains share is kept apart:
+    // the panel buffers (V, W, V) alternate between two sets, the QR puts its R block into a buffer of its own instead of
+    // into rows of A that the running update still writes (the band extraction collects it from there).
+    static const bool nofuse = getenv("DM_SB_NOFUSE") != nullptr;
+    // MEASURED, OFF BY DEFAULT (DM_SB_LOOKAHEAD=1 turns it on): correct (scratch/twostage_check.py, the GPU suite), but the
+    // QR does not actually overlap — its 512-thread workgroups at 180 VGPRs need two of a CU's three update workgroups to
+    // leave at the same time, and every slot an update tile frees is taken by the next tile first, stream priority or
+    // not: the QR ran 755 us instead of 205, finishing as late as without look-ahead (configs[1]: 135.7-136.3 ms per step
+    // against 133.9-134.2, the snapshot product being extra work).
+    static const bool la_on = getenv("DM_SB_LOOKAHEAD") && atoi(getenv("DM_SB_LOOKAHEAD")) != 0;
+    const bool la = la_on && !nofuse && sbPP2 && sbRb && cmax - SB <= SFR * SFT && cmax - 2 * SB >= 2;
+    sb_mat* d_sm2 = nullptr;   // the descriptors with the second set of panel buffers (odd panels)
+    if (la) {
+      std::vector<sb_mat> sm_a(sm), sm_b(sm);
+      for (int i = 0; i < nc; ++i) {
+        const int p = ch[i];
+        const size_t n = probs[p].n;
+        cplx* pp2 = sbPP2 + offn[p] * 3 * TNB;
+        sm_a[i].Rb = sbRb + offn[p] * SB;
+        sm_b[i].Rb = sm_a[i].Rb;
+        sm_b[i].Vp = pp2; sm_b[i].Wp = pp2 + n * TNB; sm_b[i].Vp2 = pp2 + 2 * n * TNB;
       }
-      // T factor of the panel (zlarft from the Gram matrix), straight into the slot the back-transformation reads
-      std::vector<dm_gemm_desc> gg, gx, gy1, gy2, gm, gw, gh;
-      std::vector<sb_sum_desc> sy;
-      std::vector<sb_s_desc> ssv;
-      std::vector<tf_mat> tf;
-      // split-K: the products with K = trailing size have few output tiles (one 32 x 32 tile per matrix for the Gram
-      // matrices, one 32 x 128 tile per 128 columns of Y): cut K so that a launch carries ~1000 tiles
+      d_sm = dm_ws_upload(ctx, sm_a);
+      d_sm2 = dm_ws_upload(ctx, sm_b);
+      if (!d_sm || !d_sm2) return DM_ENOMEM;
+      // HIGH priority: the one-workgroup-per-matrix QR must get CUs while the update's ten thousand tiles keep arriving —
+      // on an ordinary stream its workgroups were only placed as the update drained (755 us instead of 205)
+      if (!g_la_stream) {
+        int lo = 0, hi = 0;
+        DM_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        DM_HIP(ctx, hipStreamCreateWithPriority(&g_la_stream, hipStreamNonBlocking, hi));
+      }
+    }
+    auto pp_of = [&](int p, int k0) { return ((la && ((k0 / SB) & 1)) ? sbPP2 : PP) + offn[p] * 3 * TNB; };
+    auto sm_of = [&](int k0) { return (la && ((k0 / SB) & 1)) ? d_sm2 : d_sm; };
+    static const bool nosplit = getenv("DM_SB_NOSPLITK") != nullptr;
+    cplx* part_y = sbPart;                               // per matrix: SY x (32 x n) at offn * SB * 32
+    cplx* part_g = sbPart + totn * SB * 32;              // per matrix: 32 x (32 x 32)
+    struct panel_split { int nact, SG, SY; };
+    auto split_of = [&](int k0) {
+      const int i0 = k0 + SB, a0 = i0 & ~127;
       int nact = 0, ytiles = 0;
       for (int p : ch) {
-        const int m = probs[p].n - i0;
-        if (m < 2) continue;
+        if (probs[p].n - i0 < 2) continue;
         ++nact;
         ytiles += (probs[p].n - a0 + 127) / 128;
       }
-      if (nact == 0) continue;
       const int kmax = cmax - i0;
+      // split-K: the products with K = trailing size have few output tiles (one 32 x 32 tile per matrix for the Gram
+      // matrices, one 32 x 128 tile per 128 columns of Y): cut K so that a launch carries ~1000 tiles
       auto slices_for = [&](int tiles) { return std::max(1, std::min(30, std::min((1024 + tiles - 1) / tiles, (kmax + 127) / 128))); };
-      static const bool nosplit = getenv("DM_SB_NOSPLITK") != nullptr;
-      const int SG = nosplit ? 1 : slices_for(nact), SY = nosplit ? 1 : slices_for(ytiles);
-      cplx* part_y = sbPart;                               // per matrix: SY x (32 x n) at offn * SB * 32
-      cplx* part_g = sbPart + totn * SB * 32;              // per matrix: 32 x (32 x 32)
+      return panel_split{nact, (nosplit || nact == 0) ? 1 : slices_for(nact), (nosplit || nact == 0) ? 1 : slices_for(std::max(ytiles, 1))};
+    };
+    // side chain of panel k0: Gram slices (summed by the T-factor kernel), T, X^T = T^T V^H
+    struct side_set { dm_gemm_plan pg, px; std::vector<tf_mat> tf; };
+    auto build_side = [&](int k0, side_set& S_) -> int {
+      const int i0 = k0 + SB;
+      const panel_split sp = split_of(k0);
+      std::vector<dm_gemm_desc> gg, gx;
       for (int p : ch) {
         const int n = probs[p].n;
         const int m = n - i0;
         if (m < 2) continue;
         const int kb = std::min(SB, m - 1);
-        const int lda = probs[p].ldc;
-        cplx* C = probs[p].C;
-        cplx* pp = PP + offn[p] * 3 * TNB;
-        cplx* Vp = pp;
-        cplx* Wp = pp + (size_t)n * TNB;
+        cplx* Vp = pp_of(p, k0);
         cplx* Xt = sbXt + offn[p] * SB;
         const cplx* Vb = Vt + off[p] + (size_t)k0 * n + i0;
         cplx* G = Gs + offg[p] + (size_t)(k0 / TNB) * TNB * TNB;
         cplx* T = Tbig + offtb[p] + (size_t)(k0 / NBB) * NBB * NBB + (size_t)(k0 % NBB) * NBB + (k0 % NBB);
         cplx* pg = part_g + (size_t)p * SB * SB * 32;
-        // Gram matrix G = V^H V (kb x kb, K = m)
         int gram_slices = 0;
-        if (SG == 1) {
+        if (sp.SG == 1) {
           gg.push_back(dm_gemm_make(Vb, n, 1, true, Vb, 1, n, false, G, TNB, kb, kb, m));
         } else {
-          const int kc = (m + SG - 1) / SG;
+          const int kc = (m + sp.SG - 1) / sp.SG;
           int ns = 0;
           for (int kk = 0; kk < m; kk += kc, ++ns)
             gg.push_back(dm_gemm_make(Vb + kk, n, 1, true, Vb + kk, 1, n, false, pg + (size_t)ns * kb * kb, kb, kb, kb, std::min(kc, m - kk)));
           gram_slices = ns;   // summed by the T-factor kernel
         }
-        tf.push_back(tf_mat{G, tau + offn[p] + k0, T, kb, NBB, gram_slices ? pg : nullptr, gram_slices});
-        // Xt = T^T Vp  (SB x m)
-        gx.push_back(dm_gemm_make(T, 1, NBB, false, Vp + i0, n, 1, false, Xt + i0, n, SB, m, SB));
+        S_.tf.push_back(tf_mat{G, tau + offn[p] + k0, T, kb, NBB, gram_slices ? pg : nullptr, gram_slices});
+        gx.push_back(dm_gemm_make(T, 1, NBB, false, Vp + i0, n, 1, false, Xt + i0, n, SB, m, SB));   // Xt = T^T Vp (SB x m)
+      }
+      DM_TRY(dm_gemm_plan_build(gg, S_.pg));
+      DM_TRY(dm_gemm_plan_build(gx, S_.px));
+      return DM_OK;
+    };
+    // main chain of panel k0
+    struct main_set { dm_gemm_plan py1, py2, pm, pw, ph; std::vector<sb_sum_desc> sy; std::vector<sb_s_desc> ssv; };
+    auto build_main = [&](int k0, main_set& M_) -> int {
+      const int i0 = k0 + SB, a0 = i0 & ~127;
+      const panel_split sp = split_of(k0);
+      std::vector<dm_gemm_desc> gy1, gy2, gm, gw, gh;
+      for (int p : ch) {
+        const int n = probs[p].n;
+        const int m = n - i0;
+        if (m < 2) continue;
+        const int lda = probs[p].ldc;
+        cplx* C = probs[p].C;
+        cplx* pp = pp_of(p, k0);
+        cplx* Vp = pp;
+        cplx* Wp = pp + (size_t)n * TNB;
+        cplx* Xt = sbXt + offn[p] * SB;
+        cplx* T = Tbig + offtb[p] + (size_t)(k0 / NBB) * NBB * NBB + (size_t)(k0 % NBB) * NBB + (k0 % NBB);
+        cplx* pg = part_g + (size_t)p * SB * SB * 32;
         // Yt = Xt A22 by 128-column blocks: stored part (rows >= block start, whole diagonal block) + mirrored part
         cplx* py = part_y + offn[p] * SB * 32;
         size_t pyoff = 0;
@@ -1954,14 +2002,14 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
           const int c_lo = std::max(cb, i0), c_hi = std::min(cb + 128, n);
           if (c_hi <= c_lo) continue;
           const int wN = c_hi - c_lo;
-          if (SY == 1) {
+          if (sp.SY == 1) {
             gy1.push_back(dm_gemm_make(Xt + c_lo, n, 1, false, C + (size_t)c_lo * lda + c_lo, 1, lda, false, Wp + c_lo, n, SB, wN,
                                        n - c_lo));
             if (c_lo > i0)
               gy2.push_back(dm_gemm_make(Xt + i0, n, 1, false, C + (size_t)i0 * lda + c_lo, lda, 1, true, Wp + c_lo, n, SB, wN,
                                          c_lo - i0, 1.0, 1.0));
           } else {
-            const int kc = std::max(128, ((m + SY - 1) / SY + 127) & ~127);
+            const int kc = std::max(128, ((m + sp.SY - 1) / sp.SY + 127) & ~127);
             cplx* pb = py + pyoff;
             int ns = 0;
             for (int kk = c_lo; kk < n; kk += kc, ++ns)   // stored part: rows kk .. of the columns [c_lo, c_hi)
@@ -1970,7 +2018,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
             for (int kk = i0; kk < c_lo; kk += kc, ++ns)  // mirrored part: rows i0 .. c_lo of the transposed block
               gy1.push_back(dm_gemm_make(Xt + kk, n, 1, false, C + (size_t)kk * lda + c_lo, lda, 1, true, pb + (size_t)ns * SB * wN, wN,
                                          SB, wN, std::min(kc, c_lo - kk)));
-            sy.push_back(sb_sum_desc{Wp + c_lo, pb, ns, SB, wN, n, 1.0, 0.0});
+            M_.sy.push_back(sb_sum_desc{Wp + c_lo, pb, ns, SB, wN, n, 1.0, 0.0});
             pyoff += (size_t)ns * SB * wN;
           }
         }
@@ -1978,34 +2026,109 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
         cplx* S = sbS + (size_t)p * SB * SB;
         // M1 = V^H Y, S = T^H M1, W = Y - V S / 2  (row-stored: Wp += -1/2 S^T Vp)
         int m1_slices = 0;
-        if (SG == 1) {
+        if (sp.SG == 1) {
           gm.push_back(dm_gemm_make(Vp + i0, n, 1, true, Wp + i0, 1, n, false, M1, SB, SB, SB, m));
         } else {
-          const int kc = (m + SG - 1) / SG;
+          const int kc = (m + sp.SG - 1) / sp.SG;
           int ns = 0;
           for (int kk = 0; kk < m; kk += kc, ++ns)
             gm.push_back(dm_gemm_make(Vp + i0 + kk, n, 1, true, Wp + i0 + kk, 1, n, false, pg + (size_t)ns * SB * SB, SB, SB, SB,
                                       std::min(kc, m - kk)));
           m1_slices = ns;
         }
-        ssv.push_back(sb_s_desc{T, NBB, m1_slices ? pg : M1, m1_slices, S});   // S = T^H (sum of the slices of M1)
+        M_.ssv.push_back(sb_s_desc{T, NBB, m1_slices ? pg : M1, m1_slices, S});   // S = T^H (sum of the slices of M1)
         gw.push_back(dm_gemm_make(S, 1, SB, false, Vp + i0, n, 1, false, Wp + i0, n, SB, m, SB, -0.5, 1.0));
         // A22 -= V W^H + W V^H on the blocks on or above the diagonal (128-aligned origin a0)
         gh.push_back(dm_gemm_make(pp + a0, 1, n, false, pp + (size_t)n * TNB + a0, n, 1, true, C + (size_t)a0 * lda + a0, lda,
                                   n - a0, n - a0, 2 * TNB, -1.0, 1.0, nullptr, DM_GEMM_UPPER | DM_GEMM_UPPER128));
       }
-      // every descriptor of the panel travels in ONE staged copy: the eight grouped products as plans, the three lists
-      // of slice sums and the T-factor descriptors behind them
-      dm_gemm_plan pg, px, py1, py2, pm, pw, ph;
-      DM_TRY(dm_gemm_plan_build(gg, pg));
-      DM_TRY(dm_gemm_plan_build(gx, px));
-      DM_TRY(dm_gemm_plan_build(gy1, py1));
-      DM_TRY(dm_gemm_plan_build(gy2, py2));
-      DM_TRY(dm_gemm_plan_build(gm, pm));
-      DM_TRY(dm_gemm_plan_build(gw, pw));
-      DM_TRY(dm_gemm_plan_build(gh, ph));
-      dm_gemm_plan extra;   // not a product: the raw arrays of the sum / larft kernels, carried by the same upload
-      size_t o_sy, o_ss, o_tf;
+      DM_TRY(dm_gemm_plan_build(gy1, M_.py1));
+      DM_TRY(dm_gemm_plan_build(gy2, M_.py2));
+      DM_TRY(dm_gemm_plan_build(gm, M_.pm));
+      DM_TRY(dm_gemm_plan_build(gw, M_.pw));
+      DM_TRY(dm_gemm_plan_build(gh, M_.ph));
+      return DM_OK;
+    };
+    // look-ahead: the update of panel k0 applied to the snapshot of the rows of panel k0 + SB
+    //   P[q][c] -= sum_j V[i0 + q][j] conj(W[c][j]) + W[i0 + q][j] conj(V[c][j]),   c >= i0 + SB
+    auto build_strip = [&](int k0, dm_gemm_plan& pl) -> int {
+      const int i0 = k0 + SB, i1 = i0 + SB;
+      std::vector<dm_gemm_desc> g;
+      for (int p : ch) {
+        const int n = probs[p].n;
+        if (n - i1 < 2) continue;
+        cplx* pp = pp_of(p, k0);
+        cplx* Pw = sbPw + offn[p] * SB;
+        g.push_back(dm_gemm_make(pp + i0, 1, n, false, pp + (size_t)n * TNB + i1, n, 1, true, Pw + i1, n, SB, n - i1, 2 * TNB, -1.0,
+                                 1.0));
+      }
+      return dm_gemm_plan_build(g, pl);
+    };
+    auto qr_flops = [&](int k0) {
+      double fl = 0.0;  // Householder QR of an m x SB panel: 2 SB^2 (m - SB / 3) complex multiply-adds
+      for (int p : ch) {
+        const double m = probs[p].n - k0 - SB;
+        if (m >= 2) fl += 8.0 * 2.0 * SB * SB * std::max(m - SB / 3.0, 1.0);
+      }
+      return fl;
+    };
+    struct stream_swap {   // grouped launches go to ctx->stream: point it at the side stream for a scope
+      dm_ctx* c; hipStream_t keep;
+      stream_swap(dm_ctx* c_, hipStream_t s) : c(c_), keep(c_->stream) { if (s) c->stream = s; }
+      ~stream_swap() { c->stream = keep; }
+    };
+    static bool larft_attr = false;
+    const size_t larft_lds = 2 * sizeof(cplx) * TNB * (TNB + 1);
+    if (!larft_attr) {
+      DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(larft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)larft_lds));
+      larft_attr = true;
+    }
+    // QR (one-workgroup kernel, or the launched one) + side chain of panel k0 on stream `st` (nullptr: the main stream)
+    auto run_side = [&](int k0, const side_set& S_, const char* d_pg, const char* d_px, const tf_mat* d_tf, hipStream_t st,
+                        int snap) -> int {
+      const int i0 = k0 + SB, a0 = i0 & ~127;
+      stream_swap sw(ctx, st);
+      if (cmax - i0 <= SFR * SFT && !nofuse) {
+        // panels that fit the registers of one workgroup per matrix: the whole QR in one launch
+        dm_prof_scope ps(ctx, DM_PROF_SB_PANEL, qr_flops(k0));
+        hipLaunchKernelGGL(sb_panel_fused_kernel, dim3(nc), dim3(SFT), 0, ctx->stream, sm_of(k0), k0, a0, snap);
+      } else {
+        hipLaunchKernelGGL(sb_panel_load_kernel, dim3((cmax - a0 + 255) / 256, nc), dim3(256), 0, ctx->stream, d_sm, k0, a0);
+        const int nchmax = (cmax - i0 + SQR - 1) / SQR;
+        for (int q = 0; q <= SB; ++q) {
+          hipLaunchKernelGGL(sb_qr_update_kernel, dim3(nchmax, nc), dim3(256), 0, ctx->stream, d_sm, k0, q);
+          if (q < SB) hipLaunchKernelGGL(sb_qr_dots_kernel, dim3(nchmax, nc), dim3(256), 0, ctx->stream, d_sm, k0, q);
+        }
+      }
+      if (S_.tf.empty()) return DM_OK;
+      DM_TRY(dm_gemm_plan_run(ctx, S_.pg, d_pg));
+      // T factor of the panel (zlarft from the Gram matrix), straight into the slot the back-transformation reads
+      hipLaunchKernelGGL(larft_kernel, dim3((unsigned)S_.tf.size()), dim3(256), larft_lds, ctx->stream, d_tf);
+      DM_TRY(dm_gemm_plan_run(ctx, S_.px, d_px));
+      return DM_OK;
+    };
+    side_set side_next;        // look-ahead: the side chain of the panel after the current one (built one iteration early)
+    bool side_next_ready = false;
+    for (int k0 = 0; cmax - k0 - SB >= 2; k0 += SB) {
+      const int i0 = k0 + SB;
+      if (split_of(k0).nact == 0) continue;
+      const bool have_next = la && cmax - (k0 + SB) - SB >= 2 && split_of(k0 + SB).nact > 0;
+      side_set side_cur;
+      const bool run_cur_side = !(la && side_next_ready);   // else it already ran on the side stream
+      if (run_cur_side) DM_TRY(build_side(k0, side_cur));
+      main_set mn;
+      DM_TRY(build_main(k0, mn));
+      side_set side_new;
+      dm_gemm_plan pstrip;
+      if (have_next) {
+        DM_TRY(build_side(k0 + SB, side_new));
+        DM_TRY(build_strip(k0, pstrip));
+      }
+      // every descriptor of the iteration travels in ONE staged copy: the grouped products as plans, the lists of slice
+      // sums, the S and the T-factor descriptors behind them
+      dm_gemm_plan extra;   // not a product: raw arrays carried by the same upload
+      size_t o_sy, o_ss, o_tf, o_tf2;
       {
         auto put = [&](const void* src, size_t bytes) {
           const size_t o = (extra.blob.size() + 15) & ~size_t(15);
@@ -2013,43 +2136,50 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
           if (bytes) std::memcpy(extra.blob.data() + o, src, bytes);
           return o;
         };
-        o_sy = put(sy.data(), sy.size() * sizeof(sb_sum_desc));
-        o_ss = put(ssv.data(), ssv.size() * sizeof(sb_s_desc));
-        o_tf = put(tf.data(), tf.size() * sizeof(tf_mat));
+        o_sy = put(mn.sy.data(), mn.sy.size() * sizeof(sb_sum_desc));
+        o_ss = put(mn.ssv.data(), mn.ssv.size() * sizeof(sb_s_desc));
+        o_tf = put(side_cur.tf.data(), side_cur.tf.size() * sizeof(tf_mat));
+        o_tf2 = put(side_new.tf.data(), side_new.tf.size() * sizeof(tf_mat));
         if (extra.blob.empty()) extra.blob.resize(16);
       }
       std::vector<const char*> dv;
-      DM_TRY(dm_gemm_plans_upload(ctx, {&pg, &px, &py1, &py2, &pm, &pw, &ph, &extra}, dv));
+      DM_TRY(dm_gemm_plans_upload(ctx, {&side_cur.pg, &side_cur.px, &mn.py1, &mn.py2, &mn.pm, &mn.pw, &mn.ph, &side_new.pg,
+                                        &side_new.px, &pstrip, &extra}, dv));
+      const char* d_extra = dv[10];
       auto launch_sums = [&](const std::vector<sb_sum_desc>& v, size_t o) -> int {
         if (v.empty()) return DM_OK;
         int mx = 0;
         for (const auto& d : v) mx = std::max(mx, d.rows * d.cols);
         hipLaunchKernelGGL(sb_sum_partials_kernel, dim3((mx + 255) / 256, (unsigned)v.size()), dim3(256), 0, ctx->stream,
-                           reinterpret_cast<const sb_sum_desc*>(dv[7] + o));
+                           reinterpret_cast<const sb_sum_desc*>(d_extra + o));
         return DM_OK;
       };
-      DM_TRY(dm_gemm_plan_run(ctx, pg, dv[0]));
-      {
-        static bool attr = false;
-        const size_t lds = 2 * sizeof(cplx) * TNB * (TNB + 1);
-        if (!attr) {
-          DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(larft_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          attr = true;
-        }
-        hipLaunchKernelGGL(larft_kernel, dim3((unsigned)tf.size()), dim3(256), lds, ctx->stream,
-                           reinterpret_cast<const tf_mat*>(dv[7] + o_tf));
+      if (run_cur_side) {
+        DM_TRY(run_side(k0, side_cur, dv[0], dv[1], reinterpret_cast<const tf_mat*>(d_extra + o_tf), nullptr, 0));
+      } else {
+        DM_HIP(ctx, hipStreamWaitEvent(ctx->stream, side_event(18 + ((k0 / SB) & 1)), 0));   // the side chain of this panel
       }
-      DM_TRY(dm_gemm_plan_run(ctx, px, dv[1]));
-      DM_TRY(dm_gemm_plan_run(ctx, py1, dv[2]));
-      DM_TRY(dm_gemm_plan_run(ctx, py2, dv[3]));
-      DM_TRY(launch_sums(sy, o_sy));
-      DM_TRY(dm_gemm_plan_run(ctx, pm, dv[4]));
-      if (!ssv.empty())
-        hipLaunchKernelGGL(sb_s_kernel, dim3((unsigned)ssv.size()), dim3(256), 0, ctx->stream,
-                           reinterpret_cast<const sb_s_desc*>(dv[7] + o_ss));
-      DM_TRY(dm_gemm_plan_run(ctx, pw, dv[5]));
-      DM_TRY(dm_gemm_plan_run(ctx, ph, dv[6]));
+      DM_TRY(dm_gemm_plan_run(ctx, mn.py1, dv[2]));
+      DM_TRY(dm_gemm_plan_run(ctx, mn.py2, dv[3]));
+      DM_TRY(launch_sums(mn.sy, o_sy));
+      DM_TRY(dm_gemm_plan_run(ctx, mn.pm, dv[4]));
+      if (!mn.ssv.empty())
+        hipLaunchKernelGGL(sb_s_kernel, dim3((unsigned)mn.ssv.size()), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<const sb_s_desc*>(d_extra + o_ss));
+      DM_TRY(dm_gemm_plan_run(ctx, mn.pw, dv[5]));
+      side_next_ready = false;
+      if (have_next) {
+        // snapshot of the next panel's rows + this panel's update of them, then its side chain on the second stream
+        hipLaunchKernelGGL(sb_strip_copy_kernel, dim3((cmax - i0 - SB + 255) / 256, SB, nc), dim3(256), 0, ctx->stream, d_sm, i0);
+        DM_TRY(dm_gemm_plan_run(ctx, pstrip, dv[9]));
+        hipEvent_t e_go = side_event(16 + ((k0 / SB) & 1));
+        DM_HIP(ctx, hipEventRecord(e_go, ctx->stream));
+        DM_HIP(ctx, hipStreamWaitEvent(g_la_stream, e_go, 0));
+        DM_TRY(run_side(k0 + SB, side_new, dv[7], dv[8], reinterpret_cast<const tf_mat*>(d_extra + o_tf2), g_la_stream, 1));
+        DM_HIP(ctx, hipEventRecord(side_event(18 + (((k0 + SB) / SB) & 1)), g_la_stream));
+        side_next_ready = true;
+      }
+      DM_TRY(dm_gemm_plan_run(ctx, mn.ph, dv[6]));
     }
     // ---- S2: band -> tridiagonal
     const char* dump = getenv("DM_SB_DUMP");  // debugging aid: the band and the tridiagonal of every matrix to files
@@ -2062,6 +2192,14 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
     };
     {
       size_t maxel = (size_t)cmax * SLD;
+      if (la)
+        for (int i = 0; i < nc; ++i) {
+          const int p = ch[i], n = probs[p].n;
+          bm[i].Rb = sbRb + offn[p] * SB;
+          bm[i].nrb = n - SB - 2 >= 0 ? ((n - SB - 2) / SB) * SB + SB : 0;   // rows of the panels this matrix went through
+        }
+      d_bm = dm_ws_upload(ctx, bm);
+      if (!d_bm) return DM_ENOMEM;
       hipLaunchKernelGGL(sb_band_extract_kernel, dim3((unsigned)((maxel + 255) / 256), nc), dim3(256), 0, ctx->stream, d_bm);
       if (dump) DM_TRY(dump_arr(".band", sbAB, sizeof(cplx) * totn * SLD));
       // One persistent launch: per-XCD queues of matrix ids; a matrix gets as many entries (= workgroups) as its
