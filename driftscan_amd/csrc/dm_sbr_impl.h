@@ -347,10 +347,15 @@ __device__ __forceinline__ void sb_wg_reduce(double (&v)[K], double* red /* [2][
 // Right-looking Householder QR of the SFH columns [cb, cb + SFH) of the panel held in a[][] (nrf = reflectors of the
 // panel).  The column being factorised is always a[.][0]: the array is shifted by one column after every step, so the
 // loop body is the same code for every column (columns past the end are zero and cost nothing but their flops).
-__device__ __forceinline__ void sb_fused_half(const sb_mat& M, cplx (&a)[SFR][SFH], int k0, int cb, int nrf, double* red, int& phase) {
+// gpair[j] = v_{2j+1}^H v_{2j} is left for the later sub-panels, which apply the reflectors two at a time.
+__device__ __forceinline__ void sb_fused_half(const sb_mat& M, cplx (&a)[SFR][SFH], int k0, int cb, int nrf, double* red, int& phase,
+                                              cplx* gpair) {
   const int n = M.n;
   const int tid = threadIdx.x;
   const int i0 = k0 + SB;
+  cplx vprev[SFR];
+#pragma unroll
+  for (int r = 0; r < SFR; ++r) vprev[r] = make_double2(0.0, 0.0);
 #pragma unroll 1
   for (int q = 0; q < SFH; ++q) {
     const int qq = cb + q;          // column of the panel
@@ -378,8 +383,16 @@ __device__ __forceinline__ void sb_fused_half(const sb_mat& M, cplx (&a)[SFR][SF
       if (i < lead || i >= n || !has) x = make_double2(0.0, 0.0);
       v[r] = x;
     }
+    // the coupling of an odd reflector with its predecessor rides along with the dot products (or takes a small
+    // reduction of its own at the last column of a sub-panel, where there are none)
+    const bool want_g = (qq & 1) && cb + SFH < SB;
+    cplx gacc = make_double2(0.0, 0.0);
+    if (want_g) {
+#pragma unroll
+      for (int r = 0; r < SFR; ++r) sb_cfma_ca(gacc, v[r], vprev[r]);   // conj(v_qq) * v_{qq-1}
+    }
     if (has && q + 1 < SFH) {
-      double y[2 * (SFH - 1)];
+      double y[2 * SFH];
 #pragma unroll
       for (int c = 1; c < SFH; ++c) {
         cplx acc = make_double2(0.0, 0.0);
@@ -390,7 +403,10 @@ __device__ __forceinline__ void sb_fused_half(const sb_mat& M, cplx (&a)[SFR][SF
         y[2 * (c - 1)] = acc.x;
         y[2 * (c - 1) + 1] = acc.y;
       }
-      sb_wg_reduce<2 * (SFH - 1)>(y, red, phase);
+      y[2 * (SFH - 1)] = gacc.x;
+      y[2 * (SFH - 1) + 1] = gacc.y;
+      sb_wg_reduce<2 * SFH>(y, red, phase);
+      if (want_g && tid == 0) gpair[qq >> 1] = make_double2(y[2 * (SFH - 1)], y[2 * (SFH - 1) + 1]);
       const cplx ct = cconj(R.tau);
 #pragma unroll
       for (int c = 1; c < SFH; ++c) {
@@ -399,6 +415,13 @@ __device__ __forceinline__ void sb_fused_half(const sb_mat& M, cplx (&a)[SFR][SF
         for (int r = 0; r < SFR; ++r) sb_cfms(a[r][c], v[r], f);
       }
     }
+    else if (want_g) {   // (uniform over the workgroup)
+      double g2[2] = {gacc.x, gacc.y};
+      sb_wg_reduce<2>(g2, red, phase);
+      if (tid == 0) gpair[qq >> 1] = make_double2(g2[0], g2[1]);
+    }
+#pragma unroll
+    for (int r = 0; r < SFR; ++r) vprev[r] = v[r];
     // outputs: v into the panel buffers and Vt, the column of R into the band part of A, tau
 #pragma unroll
     for (int r = 0; r < SFR; ++r) {
@@ -439,6 +462,7 @@ __global__ __launch_bounds__(SFT) void sb_panel_fused_kernel(const sb_mat* __res
   const int tid = threadIdx.x;
   const int i0 = k0 + SB;
   __shared__ double red[2 * (8 * 32 + 32)];
+  __shared__ cplx gpair[SB / 2];
   int phase = 0;
   // the panel rows above the trailing matrix inside its first 64-aligned tile are zero in V and W
   for (int i = a0 + tid; i < i0; i += SFT) {
@@ -463,8 +487,46 @@ __global__ __launch_bounds__(SFT) void sb_panel_fused_kernel(const sb_mat* __res
     }
     // ---- the reflectors of the earlier sub-panels: a_c <- a_c - conj(tau_q) v_q (v_q^H a_c), q = 0 .. cb - 1 in turn
     __syncthreads();  // their vectors are in memory (this workgroup wrote them: L1 holds no older copy)
+    // two reflectors per workgroup reduction:  H_{q+1}^H H_q^H a = a - v_q f_q - v_{q+1} f_{q+1},  f_q = conj(tau_q) v_q^H a,
+    // f_{q+1} = conj(tau_{q+1}) (v_{q+1}^H a - (v_{q+1}^H v_q) f_q)  — the coupling v_{q+1}^H v_q was left in gpair
+    int q = 0;
 #pragma unroll 1
-    for (int q = 0; q < cb && q < nrf; ++q) {
+    for (; q + 1 < cb && q + 1 < nrf; q += 2) {
+      cplx v1[SFR], v2[SFR];
+#pragma unroll
+      for (int r = 0; r < SFR; ++r) {
+        const int i = i0 + tid + SFT * r;
+        v1[r] = (i < n) ? dm_ldg(M.Vp, (size_t)q * n + i) : make_double2(0.0, 0.0);
+        v2[r] = (i < n) ? dm_ldg(M.Vp, (size_t)(q + 1) * n + i) : make_double2(0.0, 0.0);
+      }
+      double y[4 * SFH];
+#pragma unroll
+      for (int c = 0; c < SFH; ++c) {
+        cplx a1 = make_double2(0.0, 0.0), a2 = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int r = 0; r < SFR; ++r) {
+          sb_cfma_ca(a1, v1[r], a[r][c]);
+          sb_cfma_ca(a2, v2[r], a[r][c]);
+        }
+        y[2 * c] = a1.x; y[2 * c + 1] = a1.y;
+        y[2 * SFH + 2 * c] = a2.x; y[2 * SFH + 2 * c + 1] = a2.y;
+      }
+      sb_wg_reduce<4 * SFH>(y, red, phase);
+      const cplx t1 = cconj(M.tau[k0 + q]), t2 = cconj(M.tau[k0 + q + 1]);
+      const cplx g = gpair[q >> 1];
+#pragma unroll
+      for (int c = 0; c < SFH; ++c) {
+        const cplx f1 = cmul(t1, make_double2(y[2 * c], y[2 * c + 1]));
+        const cplx f2 = cmul(t2, csub(make_double2(y[2 * SFH + 2 * c], y[2 * SFH + 2 * c + 1]), cmul(g, f1)));
+#pragma unroll
+        for (int r = 0; r < SFR; ++r) {
+          sb_cfms(a[r][c], v1[r], f1);
+          sb_cfms(a[r][c], v2[r], f2);
+        }
+      }
+    }
+#pragma unroll 1
+    for (; q < cb && q < nrf; ++q) {
       cplx v[SFR];
 #pragma unroll
       for (int r = 0; r < SFR; ++r) {
@@ -492,7 +554,7 @@ __global__ __launch_bounds__(SFT) void sb_panel_fused_kernel(const sb_mat* __res
         for (int r = 0; r < SFR; ++r) sb_cfms(a[r][c], v[r], f);
       }
     }
-    sb_fused_half(M, a, k0, cb, nrf, red, phase);
+    sb_fused_half(M, a, k0, cb, nrf, red, phase, gpair);
   }
 }
 
