@@ -356,6 +356,16 @@ __device__ __forceinline__ void sb_fused_half(const sb_mat& M, cplx (&a)[SFR][SF
   cplx vprev[SFR];
 #pragma unroll
   for (int r = 0; r < SFR; ++r) vprev[r] = make_double2(0.0, 0.0);
+  // The norm of the NEXT column below its diagonal and its diagonal element after this column's reflector follow from
+  // sums over the rows i > lead + 1 of quantities known BEFORE the update (|a_i|^2, conj(v_i) a_i, |v_i|^2) and from two
+  // single elements — all of which ride along with the dot products of this column:
+  //   sigma'^2 = P1 - 2 Re(conj(f) P2) + |f|^2 P3,   alpha' = a_{lead+1} - v_{lead+1} f,   f = conj(tau) v^H a.
+  // The downdated norm is taken only when it keeps at least half of P1 (then it is as accurate as a direct sum: the
+  // rounding errors of the three terms are ~eps P1); otherwise the column gets its own reduction as before.
+  bool pre_ok = false;
+  double pre_sig = 0.0;
+  cplx pre_alpha = make_double2(0.0, 0.0);
+  static_assert(2 * SFH + 8 <= 32, "the workgroup reduction carries at most 32 values");
 #pragma unroll 1
   for (int q = 0; q < SFH; ++q) {
     const int qq = cb + q;          // column of the panel
@@ -364,7 +374,9 @@ __device__ __forceinline__ void sb_fused_half(const sb_mat& M, cplx (&a)[SFR][SF
     trd_refl R;
     R.tau = make_double2(0.0, 0.0); R.scal = make_double2(0.0, 0.0); R.beta = 0.0;
     cplx v[SFR];
-    if (has) {
+    if (has && pre_ok) {
+      R = sb_reflector(pre_sig, pre_alpha);
+    } else if (has) {
       double t3[3] = {0.0, 0.0, 0.0};
 #pragma unroll
       for (int r = 0; r < SFR; ++r) {
@@ -391,8 +403,9 @@ __device__ __forceinline__ void sb_fused_half(const sb_mat& M, cplx (&a)[SFR][SF
 #pragma unroll
       for (int r = 0; r < SFR; ++r) sb_cfma_ca(gacc, v[r], vprev[r]);   // conj(v_qq) * v_{qq-1}
     }
+    pre_ok = false;
     if (has && q + 1 < SFH) {
-      double y[2 * SFH];
+      double y[2 * SFH + 8];
 #pragma unroll
       for (int c = 1; c < SFH; ++c) {
         cplx acc = make_double2(0.0, 0.0);
@@ -405,9 +418,37 @@ __device__ __forceinline__ void sb_fused_half(const sb_mat& M, cplx (&a)[SFR][SF
       }
       y[2 * (SFH - 1)] = gacc.x;
       y[2 * (SFH - 1) + 1] = gacc.y;
-      sb_wg_reduce<2 * SFH>(y, red, phase);
+      {
+        // the look at the next column (c = 1): sums over the rows below ITS diagonal, and the two single elements
+        double p1 = 0.0, p3 = 0.0;
+        cplx p2 = make_double2(0.0, 0.0), an = make_double2(0.0, 0.0), vn = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int r = 0; r < SFR; ++r) {
+          const int i = i0 + tid + SFT * r;
+          if (i < n && i > lead + 1) {
+            p1 += cabs2(a[r][1]);
+            p3 += cabs2(v[r]);
+            sb_cfma_ca(p2, v[r], a[r][1]);
+          }
+          if (i == lead + 1) { an = a[r][1]; vn = v[r]; }
+        }
+        y[2 * SFH] = p1; y[2 * SFH + 1] = p3;
+        y[2 * SFH + 2] = p2.x; y[2 * SFH + 3] = p2.y;
+        y[2 * SFH + 4] = an.x; y[2 * SFH + 5] = an.y;
+        y[2 * SFH + 6] = vn.x; y[2 * SFH + 7] = vn.y;
+      }
+      sb_wg_reduce<2 * SFH + 8>(y, red, phase);
       if (want_g && tid == 0) gpair[qq >> 1] = make_double2(y[2 * (SFH - 1)], y[2 * (SFH - 1) + 1]);
       const cplx ct = cconj(R.tau);
+      if (qq + 1 < nrf) {
+        const cplx f1 = cmul(ct, make_double2(y[0], y[1]));
+        const double p1 = y[2 * SFH], p3 = y[2 * SFH + 1];
+        const cplx p2 = make_double2(y[2 * SFH + 2], y[2 * SFH + 3]);
+        const double sig = p1 - 2.0 * (f1.x * p2.x + f1.y * p2.y) + cabs2(f1) * p3;
+        pre_alpha = csub(make_double2(y[2 * SFH + 4], y[2 * SFH + 5]), cmul(make_double2(y[2 * SFH + 6], y[2 * SFH + 7]), f1));
+        pre_sig = sig > 0.0 ? sig : 0.0;
+        pre_ok = p1 > 0.0 && sig >= 0.5 * p1;   // (uniform over the workgroup: every thread holds the same sums)
+      }
 #pragma unroll
       for (int c = 1; c < SFH; ++c) {
         const cplx f = cmul(ct, make_double2(y[2 * (c - 1)], y[2 * (c - 1) + 1]));
