@@ -273,8 +273,9 @@ def _svd_kl_group(bt, kl, beam_all, ms, m0=0):
     ctx.sync()
     t1 = time.perf_counter()
     views = bt._register_sv(ms, sv)
+    bsvd, but = res["beam_svd"].unbind(0), res["beam_ut"].unbind(0)    # all per-m views in one call each
     for i, mi in enumerate(ms):
-        bt._dev[mi] = dict(beam_svd=res["beam_svd"][i], beam_ut=res["beam_ut"][i], singularvalues=views[i])
+        bt._dev[mi] = dict(beam_svd=bsvd[i], beam_ut=but[i], singularvalues=views[i])
     out = []
     nkeep = {}
     for batch in kl._batches(list(ms)):

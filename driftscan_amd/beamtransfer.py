@@ -378,9 +378,10 @@ class BeamTransfer(config.Reader):
                         fs.attrs["frequencies"] = tel.frequencies
 
             views = self._register_sv(batch, sv_host)
+            bsvd_v, but_v = res["beam_svd"].unbind(0), res["beam_ut"].unbind(0)   # all per-m views in one call each
             for i, mi in enumerate(batch):
                 self._sv_host[mi] = views[i]
-                self._dev[mi] = dict(beam_svd=res["beam_svd"][i], beam_ut=res["beam_ut"][i], singularvalues=views[i])
+                self._dev[mi] = dict(beam_svd=bsvd_v[i], beam_ut=but_v[i], singularvalues=views[i])
                 if not storage.discard():
                     storage.submit(write_svd, mi, host["beam_svd"][i], None if skip_svd_inv else host["invbeam_svd"][i],
                                    host["beam_ut"][i], sv_host[i])
@@ -516,9 +517,11 @@ class BeamTransfer(config.Reader):
         if hit is not None and hit[0] == sig:
             return hit[1]
         t0 = tens[0]
-        step = t0.numel() * t0.element_size()
-        same = all(t.shape == t0.shape and t.is_contiguous() and t.data_ptr() == t0.data_ptr() + i * step
-                   and t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr() for i, t in enumerate(tens))
+        base, o0, ne, shp = t0._base, t0.storage_offset(), t0.numel(), t0.shape
+        # views of one base tensor, equally spaced and dense (what `unbind` of a batch result gives)
+        same = base is not None and t0.is_contiguous() and all(
+            t._base is base and t.shape == shp and t.storage_offset() == o0 + i * ne and t.stride() == t0.stride()
+            for i, t in enumerate(tens))
         if same and t0.numel() > 0:
             out = torch.as_strided(t0, (len(tens),) + tuple(t0.shape), (t0.numel(),) + tuple(t0.stride()))
         else:
