@@ -157,3 +157,34 @@ def test_beam_m_sht_iterations_and_ring_weights(ctx, pol, niter):
             part = btgen.beam_m_all(t, ctx=ctx, m_range=(1, 2)).cpu().numpy()
             assert np.array_equal(part, bm[1:3])
     t.sht_iter, t.sht_ring_weights = 0, None
+
+
+@pytest.mark.parametrize("pol", [False, True])
+def test_fft_belt_and_fold_against_the_matrix_form(ctx, pol, tmp_path):
+    """The round-3 ring transform (FFT in LDS on the equatorial belt, matrix-form sums on the caps) and the north/south
+    fold of the Legendre stage against the round-2 path (matrix form on every ring, no fold; DM_BT_FFT=0 DM_BT_FOLD=0 —
+    the switches are read once per process, hence the child process), on the same telescope."""
+    import os
+    import subprocess
+    import sys
+
+    from driftscan_amd import btgen
+
+    t = _tel(pol, cylinder_width=4.0, num_feeds=3, feed_spacing=0.5)
+    new = btgen.beam_m_all(t, ctx=ctx).cpu().numpy()
+    out = str(tmp_path / "old.npy")
+    script = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from driftscan_amd import btgen, cylinder\n"
+        "cfg = dict(num_freq=2, freq_start=400.0, freq_end=450.0, freq_mode='edge', num_cylinders=2, cylinder_width=4.0,\n"
+        "           num_feeds=3, feed_spacing=0.5, tsys=1.0)\n"
+        "cls = cylinder.PolarisedCylinderTelescope if %r else cylinder.UnpolarisedCylinderTelescope\n"
+        "np.save(%r, btgen.beam_m_all(cls.from_config(cfg)).cpu().numpy())\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), bool(pol), out)
+    env = dict(os.environ, DM_BT_FFT="0", DM_BT_FOLD="0")
+    res = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    old = np.load(out)
+    assert old.shape == new.shape
+    assert np.abs(new - old).max() <= 2e-13 * np.abs(old).max()
