@@ -444,27 +444,46 @@ __global__ __launch_bounds__(256, 2) void zgemm4_grouped_kernel(const dm_gemm_de
     }
   }
   // epilogue: lane 16 i' + 4 g + j' of rotation s holds C[4 g + i'][4 ((g + s) & 3) + j']
+  // For beta != 0 the old values of EIGHT outputs (one 16-row half of the wave's block) are requested together from
+  // clamped, always valid addresses and waited for once: element by element (load, wait, combine, store) a wave paid
+  // sixteen memory latencies per tile — more than the K loop of a rank-64 update takes.
   cplx* __restrict__ C = reinterpret_cast<cplx*>(d.C);
   const int ip = lane >> 4, jp = lane & 3;
   const bool rmw = d.beta != 0.0;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
+    size_t off[2][4];
+    bool ok[2][4];
+    cplx old[2][4];
+    const int gm = mrow + i * 16 + 4 * g + ip;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const int gm = mrow + i * 16 + 4 * g + ip;
         const int gn = ncol + j * 16 + 4 * ((g + s) & 3) + jp;
-        if (gm >= d.M || gn >= d.N) continue;
+        ok[j][s] = gm < d.M && gn < d.N;
+        off[j][s] = (size_t)min(gm, d.M - 1) * d.ldc + (size_t)min(gn, d.N - 1) * d.csc;
+        old[j][s] = make_double2(0.0, 0.0);
+      }
+    if (rmw) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) old[j][s] = dm_ldg(C, off[j][s]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
         const double are = acc_re[i][j][s], aim = acc_im[i][j][s];
         cplx v = make_double2(d.alpha * are - d.alpha_im * aim, d.alpha * aim + d.alpha_im * are);
         if (rmw) {
-          const cplx o = dm_ldg(C, (size_t)gm * d.ldc + (size_t)gn * d.csc);
-          v.x += d.beta * o.x;
-          v.y += d.beta * o.y;
+          v.x += d.beta * old[j][s].x;
+          v.y += d.beta * old[j][s].y;
         }
-        dm_stg(C, (size_t)gm * d.ldc + (size_t)gn * d.csc, v);
+        if (ok[j][s]) dm_stg(C, off[j][s], v);
       }
+  }
 }
 
 // ---- all-real variant: C[M x N] (double) = alpha * A * B + beta * C, same tiling, one MFMA per
