@@ -1003,7 +1003,13 @@ __global__ __launch_bounds__(256) void larft_kernel(const tf_mat* __restrict__ t
     cplx g = make_double2(0.0, 0.0);
     if (r < F.kb && c < F.kb) {
       if (F.nslice > 0) {
-        for (int sl = 0; sl < F.nslice; ++sl) g = cadd(g, F.part[((size_t)sl * F.kb + r) * F.kb + c]);
+        const size_t ss = (size_t)F.kb * F.kb, o = (size_t)r * F.kb + c;
+        int sl = 0;
+        for (; sl + 4 <= F.nslice; sl += 4) {   // four slices in flight (the sum keeps its order)
+          const cplx v0 = F.part[sl * ss + o], v1 = F.part[(sl + 1) * ss + o], v2 = F.part[(sl + 2) * ss + o], v3 = F.part[(sl + 3) * ss + o];
+          g = cadd(cadd(cadd(cadd(g, v0), v1), v2), v3);
+        }
+        for (; sl < F.nslice; ++sl) g = cadd(g, F.part[sl * ss + o]);
         F.G[r * TNB + c] = g;
       } else {
         g = F.G[r * TNB + c];
