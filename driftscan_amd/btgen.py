@@ -47,10 +47,18 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
     pol = tel.num_pol_sky > 1
     P = 4 if pol else 1
     frame = telescope_frame(tel.zenith)
-    lmax_bf, _ = tel.baseline_lmax(b_list, f_list)
-    if (lmax_bf > lside).any():
-        raise ValueError("a baseline's natural lmax exceeds the telescope lmax (force_lmax too small)")
-    nsides = _nside_of(tel, lmax_bf)
+    # the band limits and resolutions of the columns depend on the telescope and the column list only: remembered per list
+    # (a rank calls this once per m-range with the same columns; the host work between two calls is idle GPU time)
+    memo = tel.__dict__.setdefault("_btgen_memo", {})
+    mkey = (f_list.tobytes(), b_list.tobytes(), lside)
+    if mkey not in memo:
+        if len(memo) > 8:
+            memo.clear()
+        lmax_bf, _ = tel.baseline_lmax(b_list, f_list)
+        if (lmax_bf > lside).any():
+            raise ValueError("a baseline's natural lmax exceeds the telescope lmax (force_lmax too small)")
+        memo[mkey] = (lmax_bf, _nside_of(tel, lmax_bf))
+    lmax_bf, nsides = memo[mkey]
     pairs = tel.uniquepairs
     cls = np.asarray(tel.beamclass)
     wl = tel.wavelengths
