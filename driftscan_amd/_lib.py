@@ -109,6 +109,13 @@ SIGNATURES = {
         c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_int, c_vp, c_int,
                 ctypes.POINTER(c_dbl), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int,
                 ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_vp, ctypes.POINTER(c_dbl)]),
+    "dm_bt_columns_iter": (
+        c_int, [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_int, c_vp, c_int, c_int,
+                ctypes.POINTER(c_dbl), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_int,
+                ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_vp, ctypes.POINTER(c_dbl), c_int]),
+    "dm_bt_alias_info": (
+        c_int, [c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_int, c_int, ctypes.POINTER(c_int),
+                ctypes.POINTER(c_int)]),
     "dm_bit_truncate_max_complex": (c_int, [c_vp, c_vp, c_i64, c_int, c_i64, c_dbl, c_dbl]),
 }
 
@@ -569,8 +576,9 @@ def _bt_sht(self, nside, cth, sth, polarised, lside, mmax, lmax_grp, F, B, col_f
 
 
 def _bt_columns(self, nside, cth, sth, frame, polarised, beams, uv, bi, bj, lside, mmax, lmax_grp, F, B, col_f, col_b,
-                col_lmax, beam_m, m_range=None, ring_w=None):
-    """Beams -> beam_m rows of the given columns without materialising the Stokes maps (dm_bt_columns)."""
+                col_lmax, beam_m, m_range=None, ring_w=None, niter=0):
+    """Beams -> beam_m rows of the given columns without materialising the Stokes maps (dm_bt_columns); with
+    niter > 0 healpy's `iter` refinements in harmonic space (dm_bt_columns_iter)."""
     c, cp = _darr(cth)
     s_, sp = _darr(sth)
     fr, frp = _darr(frame)
@@ -583,11 +591,28 @@ def _bt_columns(self, nside, cth, sth, frame, polarised, beams, uv, bi, bj, lsid
     m_lo, m_hi = (0, int(mmax)) if m_range is None else (int(m_range[0]), int(m_range[1]))
     w, wp = (None, None) if ring_w is None else _darr(ring_w)
     # complex field patterns (a complex128 beams tensor) take the entry that forms _construct_pol_complex in the kernels
+    if niter:
+        rc = self.lib.dm_bt_columns_iter(self.h, int(nside), cp, sp, frp, int(bool(polarised)), int(beams.shape[0]),
+                                         self.ptr(beams), int(beams.is_complex()), len(i_), up, ip, jp, int(lside), m_lo, m_hi,
+                                         int(lmax_grp), int(F), int(B), fp, bp, lp, self.ptr(beam_m), wp, int(niter))
+        self.check(rc, "dm_bt_columns_iter")
+        return
     fn = self.lib.dm_bt_columns_c if beams.is_complex() else self.lib.dm_bt_columns
     rc = fn(self.h, int(nside), cp, sp, frp, int(bool(polarised)), int(beams.shape[0]), self.ptr(beams),
             len(i_), up, ip, jp, int(lside), m_lo, m_hi, int(lmax_grp), int(F), int(B), fp, bp, lp,
             self.ptr(beam_m), wp)
     self.check(rc, "dm_bt_columns")
+
+
+def bt_alias_info(nside, cth, sth, polarised, lmax_grp):
+    """(alias rings per cap, mcut) of the harmonic-space refinement for one nside group (dm_bt_alias_info; host only)."""
+    c, cp = _darr(cth)
+    s_, sp = _darr(sth)
+    nr, mc = c_int(0), c_int(0)
+    rc = load().dm_bt_alias_info(int(nside), cp, sp, int(bool(polarised)), int(lmax_grp), ctypes.byref(nr), ctypes.byref(mc))
+    if rc != 0:
+        raise DriftMIError("dm_bt_alias_info failed (%d)" % rc)
+    return nr.value, mc.value
 
 
 Context.bt_columns = _bt_columns

@@ -62,8 +62,8 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
     pairs = tel.uniquepairs
     cls = np.asarray(tel.beamclass)
     wl = tel.wavelengths
-    # healpy.map2alm knobs the reference reaches through cora (telescope.py:1179-1191, :1288-1312); the
-    # defaults (no refinement, equal weights) are the restatement the oracle is built on
+    # healpy.map2alm knobs the reference reaches through cora (telescope.py:1179-1191, :1288-1312): `iter` (healpy's
+    # documented default 3 is the telescope's default) and ring weights
     niter = int(getattr(tel, "sht_iter", 0) or 0)
     ringw = getattr(tel, "sht_ring_weights", None)   # None, or {nside: (4 nside - 1) factors}
 
@@ -76,15 +76,29 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
         lgrp = int(lmax_bf[sel].max())
         mtop = min(mmax, lgrp)
         nmr = (2 * mtop + 1) if m_range is None else 2 * max(min(m_range[1], mtop) - m_range[0] + 1, 1)
-        # default: the fused path (dm_bt_columns) — the Stokes maps are never written; with the SHT refinement the
-        # maps are needed (residual), and DRIFTMI_BT_MAPS=1 forces the two-call path for comparisons
+        # default: the fused path (dm_bt_columns / dm_bt_columns_iter) — the Stokes maps are never written, and healpy's
+        # `iter` refinements run in harmonic space (dm_bt_columns_iter); DRIFTMI_BT_MAPS=1 forces the two-call path
+        # (maps materialised, dm_bt_sht_opts) for comparisons
         # (complex field patterns — a class that declares `complex_beams = True`, or whose beam() returns complex maps —
-        # go through the same fused path: dm_bt_columns_c forms _construct_pol_complex inside the kernels)
-        fused = not niter and os.environ.get("DRIFTMI_BT_MAPS") != "1"
-        if niter:   # residual maps, all m of the group's columns in G and in the private coefficient buffer
+        # go through the same fused path: the kernels form _construct_pol_complex themselves)
+        fused = os.environ.get("DRIFTMI_BT_MAPS") != "1"
+        pixel_refine = niter and not fused and os.environ.get("DM_SHT_PIXEL_REFINE") == "1"
+        priv = 0
+        if pixel_refine:   # residual maps, all m of the group's columns in G and in the private coefficient buffer
             nmr = 2 * (lgrp + 1)
-        per_col = P * 16 * ((0 if fused else (2 if niter else 1)) * npix + nmr * nring
-                            + (2 * (lgrp + 1) * (lside + 1) if niter else 0))
+            priv = 2 * (lgrp + 1) * (lside + 1)
+        elif niter:
+            # private coefficient buffers of the refinement (sum, increment, product): the caller's m, or 0 .. max(m_hi, mcut)
+            # when the range reaches into the m the polar rings couple
+            from ._lib import bt_alias_info
+            _, mcut = bt_alias_info(int(nside), cth, sth, pol, lgrp)
+            e_lo, e_hi = (0, mmax) if m_range is None else (int(m_range[0]), int(m_range[1]))
+            if mcut >= 0 and e_lo <= mcut:
+                e_lo, e_hi = 0, max(e_hi, mcut)
+            ncnt = max(min(e_hi, lgrp) - e_lo + 1, 1)
+            nmr = 2 * ncnt
+            priv = 3 * 2 * (e_hi - e_lo + 1) * (lgrp + 1) + (4 * (mcut + 1) * 2 * 200 if mcut >= 0 else 0)
+        per_col = P * 16 * ((0 if fused else (2 if pixel_refine else 1)) * npix + nmr * nring + priv)
         fixed = 0 if fused else nmr * npix * 16
         ncol_max = max(1, int((max_bytes - fixed) // per_col)) if max_bytes > fixed else 1
         # keep all baselines of a frequency together and in order: dm_bt_sht merges such runs
@@ -129,14 +143,18 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
             del hostb
             uv = tel.baselines[b_list[cols]] / wl[f_list[cols]][:, None]
             if fused:
-                ctx.bt_columns(int(nside), cth, sth, frame, pol, beams, uv, bi, bj, lside, mmax, int(lmax_bf[cols].max()), F, B,
+                # (with the refinement every chunk of the group is transformed against the GROUP's band limit: the set of
+                # aliased (ring, m) pairs follows from it, and the bits of a block must not depend on how the columns were
+                # chunked — the chunking depends on the m-range of the caller)
+                ctx.bt_columns(int(nside), cth, sth, frame, pol, beams, uv, bi, bj, lside, mmax,
+                               lgrp if niter else int(lmax_bf[cols].max()), F, B,
                                row_f[cols], row_b[cols], lmax_bf[cols], beam_m, m_range=m_range,
-                               ring_w=None if ringw is None else ringw.get(int(nside)))
+                               ring_w=None if ringw is None else ringw.get(int(nside)), niter=niter)
                 del beams
                 continue
             maps = ctx.empty((cols.size, P, npix), np.complex128)
             ctx.bt_maps(int(nside), cth, sth, frame, pol, beams, uv, bi, bj, maps)
-            ctx.bt_sht(int(nside), cth, sth, pol, lside, mmax, int(lmax_bf[cols].max()), F, B, row_f[cols],
+            ctx.bt_sht(int(nside), cth, sth, pol, lside, mmax, lgrp if niter else int(lmax_bf[cols].max()), F, B, row_f[cols],
                        row_b[cols], lmax_bf[cols], maps, beam_m, m_range=m_range, niter=niter,
                        ring_w=None if ringw is None else ringw.get(int(nside)))
             del maps, beams

@@ -31,6 +31,9 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <map>
+#include <mutex>
+#include <tuple>
 
 namespace {
 
@@ -950,6 +953,174 @@ __global__ void bt_scatter_kernel(const cplx* __restrict__ src, int msrc, cplx* 
   dst[((((size_t)mo * F + colf[col]) * 2 + s) * B + colb[col]) * P * L + pl] = v;
 }
 
+
+// ---- harmonic-space Jacobi refinement (healpy.map2alm `iter`) ------------------------------------------------------
+// healpy refines the quadrature as  a <- a + A(map - S a)  (A: map2alm with iter = 0, S: alm2map), i.e.
+//   a_{k+1} = a_0 + a_k - (A o S) a_k,   a_0 = A(map).
+// A o S never needs the map: the synthesis on ring r is F_m[r] = sum_l lambda_lm(z_r) a_lm and the ring DFT of the
+// synthesised ring is  G_m'[r] = N_r sum_{m = m' (mod N_r)} e^{i (m' - m) phi0_r} F_m[r].  On a ring with N_r > 2 lmax only
+// m = m' survives and A o S is, per m, the real (L - m) x (L - m) Gram matrix of the ring functions under the quadrature,
+//   K_m[l][l'] = sum_r w_r N_r lambda_lm(z_r) lambda_l'm(z_r)
+// (for the spin-2 pair the Hermitian block [[K_P, -i K_X], [i K_X, K_P]], K_P = W D W^T + X D X^T, K_X = W D X^T + X D W^T)
+// — the same for every column, so an iteration is ONE real-B grouped product per (m, Stokes term) against K_m instead of
+// a synthesis and an analysis over all rings.  The polar rings with N_r = 4 i <= 2 lmax alias m' with m' - 4 i k
+// (e^{i k N phi0} = (-1)^k there); lambda_lm(z_i) falls off super-exponentially once m exceeds l sin(theta_i), so only the
+// rings next to the poles couple anything above rounding: ring i is treated as aliasing when some m >= 2 i still has
+// max_l |lambda_lm(z_i)| >= 1e-20 (mlim(i) = the last such m), which bounds both the ring set (a few dozen per cap) and the
+// m involved (m <= mcut, around 50 - 160).  Those terms are formed explicitly: synthesis on the alias rings, the fold
+// over k, analysis.  Everything is carried in the beam_m convention b0 = a_{l,+m}, b1 = (-1)^m conj(a_{l,-m}), in which
+// analysis and synthesis use the same real tables for both slots; F_{-m} = conj(h1_m).
+struct bt_alias_info {
+  int ia = 0;              // rings 0 .. ia - 1 of the north cap (and their mirrors) carry alias terms
+  int mcut = -1;           // largest m coupled to another m by them
+  std::vector<int> mlim;   // per north alias ring: m above this are negligible on it
+};
+
+// max_l |lambda_lm(z)| (and |W|, |X|) over l = m .. lmax, unweighted; the recurrences of bt_legendre_kernel
+static double bt_table_peak(int lmax, int m, double z, double st, bool pol) {
+  const double s2 = st * st;
+  double logpre = 0.5 * (std::log(2.0 * m + 1.0) - std::log(4.0 * kPi));
+  for (int k = 1; k <= m; ++k) logpre += 0.5 * std::log((2.0 * k - 1.0) / (2.0 * k));
+  double lmm = (m > 0) ? std::exp(logpre + (double)m * std::log(st)) : std::exp(logpre);
+  double peak = std::fabs(lmm);
+  if (pol && m >= 2) {
+    const double l = m;
+    const double nl = 2.0 * std::sqrt(1.0 / ((l - 1.0) * l * (l + 1.0) * (l + 2.0)));
+    peak = std::max(peak, std::fabs(nl * (-((l - l * l) / s2 + 0.5 * l * (l - 1.0)) * lmm)));
+    peak = std::max(peak, std::fabs(nl * (l / s2) * ((l - 1.0) * z * lmm)));
+  }
+  double pm2 = 0.0, pm1 = lmm;
+  for (int l = m + 1; l <= lmax; ++l) {
+    double cur;
+    if (l == m + 1) {
+      cur = std::sqrt(2.0 * m + 3.0) * z * pm1;
+    } else {
+      const double a = std::sqrt((4.0 * l * l - 1.0) / ((double)l * l - (double)m * m));
+      const double b = std::sqrt(((l - 1.0) * (l - 1.0) - (double)m * m) / (4.0 * (l - 1.0) * (l - 1.0) - 1.0));
+      cur = a * (z * pm1 - b * pm2);
+    }
+    peak = std::max(peak, std::fabs(cur));
+    if (pol && l >= 2) {
+      const double dl = l, dm = m;
+      const double nl = 2.0 * std::sqrt(1.0 / ((dl - 1.0) * dl * (dl + 1.0) * (dl + 2.0)));
+      const double c = std::sqrt((2.0 * dl + 1.0) / (2.0 * dl - 1.0) * (dl * dl - dm * dm));
+      peak = std::max(peak, std::fabs(nl * (-((dl - dm * dm) / s2 + 0.5 * dl * (dl - 1.0)) * cur + c * z / s2 * pm1)));
+      peak = std::max(peak, std::fabs(nl * (dm / s2) * ((dl - 1.0) * z * cur - c * pm1)));
+    }
+    pm2 = pm1;
+    pm1 = cur;
+  }
+  return peak;
+}
+
+constexpr double kAliasEps = 1e-20;
+
+// Alias rings and their m limits for (nside, lmax, polarised); a function of these three alone (every rank, every column
+// chunk and every m-range sees the same sets, so the refined blocks do not depend on how m is partitioned).  Cached.
+static const bt_alias_info& bt_alias_lookup(int nside, int lmax, bool pol, const double* cth, const double* sth) {
+  static std::mutex mu;
+  static std::map<std::tuple<int, int, bool>, bt_alias_info> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  const auto key = std::make_tuple(nside, lmax, pol);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  bt_alias_info info;
+  int quiet = 0;
+  for (int i = 1; i < nside && 4 * i <= 2 * lmax; ++i) {
+    // beyond m = 2 i every l <= lmax is past its turning point on this ring: the tables fall monotonically with m
+    const double z = cth[i - 1], st = sth[i - 1];
+    int ml = -1, below = 0;
+    for (int m = 2 * i; m <= lmax && below < 3; ++m) {
+      if (bt_table_peak(lmax, m, z, st, pol) >= kAliasEps) { ml = m; below = 0; } else ++below;
+    }
+    if (ml >= 2 * i) {
+      info.mlim.resize(i, -1);
+      info.mlim[i - 1] = ml;
+      info.ia = i;
+      info.mcut = std::max(info.mcut, ml);
+      quiet = 0;
+    } else if (++quiet >= 8) {
+      break;
+    }
+  }
+  info.mlim.resize(info.ia, -1);
+  return cache.emplace(key, std::move(info)).first->second;
+}
+
+// out[idx] = in[idx] * sc[idx % nring]   (tables scaled by the per-ring factor of A o S)
+__global__ __launch_bounds__(256) void bt_scale_table_kernel(const double* __restrict__ in, double* __restrict__ out, size_t n,
+                                                             int nring, const double* __restrict__ sc) {
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256)
+    out[idx] = in[idx] * sc[idx % (size_t)nring];
+}
+
+// Alias fold on the alias rings: Ha, Ga are (2 (Mc + 1), nra, ncp), block mm = s (Mc + 1) + m; Ha holds h0_m = F_m and
+// h1_m = conj(F_-m).  Ga[s' = 0][m'] = sc sum_{k != 0} (-1)^k F_{m' - k N},  Ga[s' = 1][m'] = sc sum_{k != 0} (-1)^k conj(F_{-m' - k N}),
+// over the |m' - k N| <= mlim of the ring (sc = ring weight x N).
+__global__ __launch_bounds__(256) void bt_alias_fold_kernel(const cplx* __restrict__ Ha, cplx* __restrict__ Ga, int Mc, int nra,
+                                                            size_t ncp, const int* __restrict__ nphiA,
+                                                            const int* __restrict__ mlimA, const double* __restrict__ scA) {
+  const int ja = blockIdx.y, mmp = blockIdx.z;
+  const int sp = mmp / (Mc + 1), mp = mmp - sp * (Mc + 1);
+  const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncp) return;
+  const int N = nphiA[ja], ml = min(mlimA[ja], Mc);
+  double are = 0.0, aim = 0.0;
+  if (mp <= ml && !(sp == 1 && mp == 0)) {
+    const int base = sp == 0 ? mp : -mp;
+    // mu = base - k N in [-ml, ml]
+    int klo = base - ml, khi = base + ml;
+    klo = klo >= 0 ? (klo + N - 1) / N : -((-klo) / N);
+    khi = khi >= 0 ? khi / N : -((-khi + N - 1) / N);
+    for (int k = klo; k <= khi; ++k) {
+      if (k == 0) continue;
+      const int mu = base - k * N;
+      cplx f;
+      if (mu >= 0) f = Ha[((size_t)mu * nra + ja) * ncp + c];
+      else { f = Ha[((size_t)(Mc + 1 - mu) * nra + ja) * ncp + c]; f.y = -f.y; }
+      if (sp == 1) f.y = -f.y;
+      if (k & 1) { are -= f.x; aim -= f.y; } else { are += f.x; aim += f.y; }
+    }
+  }
+  const double s = scA[ja];
+  Ga[((size_t)mmp * nra + ja) * ncp + c] = make_double2(s * are, s * aim);
+}
+
+// d <- mask(d - t), acc += d on the private coefficient buffers (nm, 2, ncol, P, L); entries l < m stay zero, the -m slot
+// of m = 0 stays zero, l > lmax of the column is cut (the column's own band limit, telescope.py:792-802)
+__global__ __launch_bounds__(256) void bt_refine_update_kernel(cplx* __restrict__ acc, cplx* __restrict__ d, const cplx* __restrict__ t,
+                                                               int m_lo, int ncol, int P, int L,
+                                                               const int* __restrict__ collmax) {
+  const int col = blockIdx.y;
+  const int mi = blockIdx.z >> 1, s = blockIdx.z & 1;
+  const int m = m_lo + mi;
+  const int idx = blockIdx.x * 256 + threadIdx.x;   // over (p, l)
+  if (idx >= P * L) return;
+  const int l = idx % L;
+  if (l < m || (m == 0 && s == 1)) return;
+  const size_t o = ((((size_t)mi * 2 + s) * ncol + col) * P) * L + idx;
+  cplx dn = make_double2(0.0, 0.0);
+  if (l <= collmax[col]) dn = csub(d[o], t[o]);
+  d[o] = dn;
+  acc[o] = cadd(acc[o], dn);
+}
+
+// private coefficient buffer (blocks m = src_mlo .. src_mlo + src_nm - 1, layout (src_nm, 2, ncol, P, Ls)) -> the
+// caller's beam_m blocks (m_hi - m_lo + 1, F, 2, B, P, L): l >= Ls and blocks outside the source are zero
+__global__ void bt_scatter2_kernel(const cplx* __restrict__ src, int src_mlo, int src_nm, int Ls, cplx* __restrict__ dst, int m_lo,
+                                   int F, int B, int P, int L, int ncol, const int* __restrict__ colf,
+                                   const int* __restrict__ colb) {
+  const int col = blockIdx.y;
+  const int mo = blockIdx.z;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over (s, p, l)
+  if (idx >= 2 * P * L) return;
+  const int s = idx / (P * L), pl = idx % (P * L), p = pl / L, l = pl % L;
+  const int ms = m_lo + mo - src_mlo;
+  cplx v = make_double2(0.0, 0.0);
+  if (ms >= 0 && ms < src_nm && l < Ls) v = src[((((size_t)ms * 2 + s) * ncol + col) * P + p) * Ls + l];
+  dst[((((size_t)mo * F + colf[col]) * 2 + s) * B + colb[col]) * P * L + pl] = v;
+}
+
 struct geo_host {
   ring_geo g;
   std::vector<double> cth, sth, phi0;
@@ -1168,13 +1339,15 @@ struct bt_synth_in {
 static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised,
                        int lside, int m_lo, int m_hi, int lmax_grp, int F, int B, int ncol, const int* col_f_host,
                        const int* col_b_host, const int* col_lmax_host, const void* maps_dev, void* beam_m_dev, int niter,
-                       const double* ring_w_host, const bt_synth_in* syn = nullptr) {
+                       const double* ring_w_host, const bt_synth_in* syn = nullptr, bool harmonic = false) {
   if (!ctx) return DM_EARG;
-  DM_ARG(ctx, maps_dev || (syn && niter == 0));
+  DM_ARG(ctx, maps_dev || (syn && (niter == 0 || harmonic)));
   DM_ARG(ctx, nside > 0 && ring_cth_host && ring_sth_host && lside >= 0 && m_lo >= 0 && m_hi >= m_lo && lmax_grp >= 0 &&
                   lmax_grp <= lside && F > 0 && B > 0 && ncol >= 0 && col_f_host && col_b_host && col_lmax_host &&
                   beam_m_dev && niter >= 0);
-  DM_ARG(ctx, niter == 0 || (m_lo == 0 && m_hi >= lmax_grp));  // the residual needs every m of a column
+  DM_ARG(ctx, niter == 0 || harmonic || (m_lo == 0 && m_hi >= lmax_grp));  // the residual map needs every m of a column
+  // the harmonic-space refinement runs on a private coefficient buffer laid out (m, 2, col, P, L) (bt_sht_refined)
+  DM_ARG(ctx, !(niter > 0 && harmonic) || (F == 1 && B == ncol && lside == lmax_grp));
   if (ncol == 0) return DM_OK;
   dm_ws_scope ws_scope__(ctx);  // releases on every return path
   const size_t mark = ws_scope__.mark;
@@ -1378,7 +1551,7 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
   // so that no two tiles of one launch touch the same C entries.
   // (the refinement path synthesises from G-shaped buffers and keeps the plain sum; DM_BT_FOLD=0 switches the fold off)
   static const bool fold_off = getenv("DM_BT_FOLD") && atoi(getenv("DM_BT_FOLD")) == 0;
-  const bool folded = niter == 0 && !fold_off && cnt > 0 && nring >= 3;
+  const bool folded = (niter == 0 || harmonic) && !fold_off && cnt > 0 && nring >= 3;
   if (folded) {
     const size_t tot = (size_t)nm * (nring / 2) * ncp;
     const unsigned nb = (unsigned)std::min<size_t>((tot + 255) / 256, 65536);
@@ -1461,7 +1634,203 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
   //   f[col][ring, j]  = sum_mm conj(tw[mm][j]) H[mm][col][ring]
   // and for the spin-2 pair the Hermitian 2x2 block [[W, -iX], [iX, W]] of the analysis applied once more.
   // The tables carry the quadrature weight w = 4 pi / npix: the synthesis divides it out again.
-  if (niter > 0 && cnt > 0) {
+  if (niter > 0 && harmonic && cnt > 0) {
+    for (int c = 0; c < ncol; ++c) DM_ARG(ctx, cf[c] == 0 && cb[c] == c);
+    const double wq = 4.0 * kPi / (double)npix, iw = 1.0 / wq;
+    const bt_alias_info& al = bt_alias_lookup(nside, lmax_grp, polarised != 0, ring_cth_host, ring_sth_host);
+    // alias terms couple the m <= mcut among themselves: a call that touches them must hold all of them (bt_sht_refined)
+    const int Mc = (al.ia > 0 && m_lo == 0) ? std::min(al.mcut, mtop) : -1;
+    DM_ARG(ctx, al.ia == 0 || m_lo == 0 || m_lo > al.mcut);
+    DM_ARG(ctx, Mc < 0 || mtop >= std::min(al.mcut, lmax_grp));
+    // ---- per-ring factor of A o S and the Gram matrices K_m
+    std::vector<double> sc(nring);
+    for (int r = 0; r < nring; ++r) sc[r] = (ring_w_host ? ring_w_host[r] : 1.0) * (double)gh.nphi[r] * iw;
+    double* d_sc = dm_ws_upload(ctx, sc);
+    std::vector<size_t> koff(cnt);
+    size_t ktot = 0;
+    for (int m = m_lo; m <= mtop; ++m) { koff[m - m_lo] = ktot; const size_t Lm = lmax_grp + 1 - m; ktot += Lm * Lm; }
+    double* Kl = dm_ws_alloc_t<double>(ctx, ktot);
+    double* Kp = polarised ? dm_ws_alloc_t<double>(ctx, ktot) : nullptr;
+    double* Kx = polarised ? dm_ws_alloc_t<double>(ctx, ktot) : nullptr;
+    if (!d_sc || !Kl || (polarised && (!Kp || !Kx))) return DM_ENOMEM;
+    {
+      dm_ws_scope tmp_scope(ctx);   // scaled tables: released (stream-ordered) once the K products are queued
+      double* lamS = dm_ws_alloc_t<double>(ctx, ltot);
+      double* WS = polarised ? dm_ws_alloc_t<double>(ctx, ltot) : nullptr;
+      double* XS = polarised ? dm_ws_alloc_t<double>(ctx, ltot) : nullptr;
+      if (!lamS || (polarised && (!WS || !XS))) return DM_ENOMEM;
+      const unsigned nb = (unsigned)std::min<size_t>((ltot + 255) / 256, 65536);
+      hipLaunchKernelGGL(bt_scale_table_kernel, dim3(nb), dim3(256), 0, ctx->stream, lam, lamS, ltot, nring, d_sc);
+      if (polarised) {
+        hipLaunchKernelGGL(bt_scale_table_kernel, dim3(nb), dim3(256), 0, ctx->stream, Wt, WS, ltot, nring, d_sc);
+        hipLaunchKernelGGL(bt_scale_table_kernel, dim3(nb), dim3(256), 0, ctx->stream, Xt, XS, ltot, nring, d_sc);
+      }
+      for (int pass = 0; pass < (polarised ? 2 : 1); ++pass) {
+        std::vector<dm_gemm_desc> g;
+        for (int m = m_lo; m <= mtop; ++m) {
+          const int Lm = lmax_grp + 1 - m;
+          const size_t lo = loff[m - m_lo], ko = koff[m - m_lo];
+          auto kadd = [&](const double* a, const double* b, double* c, double beta) {
+            g.push_back(dm_gemm_make(reinterpret_cast<const cplx*>(a + lo), nring, 1, false, b + lo, 1, nring, false,
+                                     reinterpret_cast<cplx*>(c + ko), Lm, Lm, Lm, nring, 1.0, beta, nullptr, DM_GEMM_ALL_REAL));
+          };
+          if (pass == 0) {
+            kadd(lam, lamS, Kl, 0.0);
+            if (polarised) { kadd(Wt, WS, Kp, 0.0); kadd(Wt, XS, Kx, 0.0); }
+          } else {
+            kadd(Xt, XS, Kp, 1.0);
+            kadd(Xt, WS, Kx, 1.0);
+          }
+        }
+        DM_TRY(dm_gemm_grouped_launch(ctx, g));
+      }
+    }
+    // ---- alias rings: their own small tables (same recurrences, same bits as the full tables)
+    const int nra = Mc >= 0 ? 2 * al.ia : 0;
+    const int nmmA = 2 * (Mc + 1);
+    double *lamA = nullptr, *WA = nullptr, *XA = nullptr, *d_scA = nullptr;
+    int *d_nphiA = nullptr, *d_mlimA = nullptr;
+    cplx *Ha = nullptr, *Ga = nullptr;
+    std::vector<size_t> loffA(std::max(Mc + 1, 1), 0);
+    if (Mc >= 0) {
+      std::vector<double> geoA(2 * (size_t)nra), scA(nra);
+      std::vector<int> nphiA(nra), mlimA(nra);
+      for (int ja = 0; ja < nra; ++ja) {
+        const int r = ja < al.ia ? ja : nring - nra + ja;
+        geoA[ja] = gh.cth[r];
+        geoA[nra + ja] = gh.sth[r];
+        nphiA[ja] = gh.nphi[r];
+        mlimA[ja] = al.mlim[ja < al.ia ? ja : nra - 1 - ja];
+        scA[ja] = (ring_w_host ? ring_w_host[r] : 1.0) * (double)gh.nphi[r];
+      }
+      double* d_geoA = dm_ws_upload(ctx, geoA);
+      d_scA = dm_ws_upload(ctx, scA);
+      d_nphiA = dm_ws_upload(ctx, nphiA);
+      d_mlimA = dm_ws_upload(ctx, mlimA);
+      size_t ltotA = 0;
+      for (int m = 0; m <= Mc; ++m) { loffA[m] = ltotA; ltotA += (size_t)(lmax_grp + 1 - m) * nra; }
+      size_t* d_loffA = dm_ws_upload(ctx, loffA);
+      lamA = dm_ws_alloc_t<double>(ctx, ltotA);
+      if (polarised) { WA = dm_ws_alloc_t<double>(ctx, ltotA); XA = dm_ws_alloc_t<double>(ctx, ltotA); }
+      Ha = dm_ws_alloc_t<cplx>(ctx, (size_t)nmmA * nra * ncp);
+      Ga = dm_ws_alloc_t<cplx>(ctx, (size_t)nmmA * nra * ncp);
+      if (!d_geoA || !d_scA || !d_nphiA || !d_mlimA || !d_loffA || !lamA || (polarised && (!WA || !XA)) || !Ha || !Ga)
+        return DM_ENOMEM;
+      ring_geo ga = gh.g;
+      ga.cth = d_geoA;
+      ga.sth = d_geoA + nra;
+      ga.nring = nra;
+      hipLaunchKernelGGL(bt_legendre_kernel, dim3((nra + 63) / 64, Mc + 1), dim3(64), 0, ctx->stream, ga, lmax_grp, 0, Mc, wq,
+                         d_loffA, lamA, WA, XA);
+    }
+    // ---- iteration on the increments:  d_0 = a_0,  d_{k+1} = d_k - mask((A o S) d_k),  a_n = sum_k d_k
+    const size_t nacc = (size_t)nmblk * 2 * ncol * P * L;
+    cplx* dbuf = dm_ws_alloc_t<cplx>(ctx, nacc);
+    cplx* tbuf = dm_ws_alloc_t<cplx>(ctx, nacc);
+    if (!dbuf || !tbuf) return DM_ENOMEM;
+    DM_HIP(ctx, hipMemcpyAsync(dbuf, bm, sizeof(cplx) * nacc, hipMemcpyDeviceToDevice, ctx->stream));
+    auto blk = [&](cplx* base, int m, int s2) { return base + ((size_t)(m - m_lo) * 2 + s2) * ncol * P * L + m; };
+    for (int it = 0; it < niter; ++it) {
+      for (int pass = 0; pass < (polarised ? 2 : 1); ++pass) {   // t = K d
+        std::vector<dm_gemm_desc> g;
+        for (int m = m_lo; m <= mtop; ++m) {
+          const int Lm = lmax_grp + 1 - m;
+          const size_t ko = koff[m - m_lo];
+          for (int s2 = 0; s2 < 2; ++s2) {
+            if (m == 0 && s2 == 1) continue;
+            const cplx* in = blk(dbuf, m, s2);
+            cplx* out = blk(tbuf, m, s2);
+            auto add = [&](int pin, const double* Km, int pout, double are, double aim, double beta) {
+              dm_gemm_desc dsc = dm_gemm_make(in + (size_t)pin * L, P * L, 1, false, Km + ko, Lm, 1, false, out + (size_t)pout * L,
+                                              P * L, ncol, Lm, Lm, are, beta, nullptr, DM_GEMM_B_REAL);
+              dsc.alpha_im = aim;
+              g.push_back(dsc);
+            };
+            if (!polarised) {
+              add(0, Kl, 0, 1.0, 0.0, 0.0);
+            } else if (pass == 0) {
+              add(0, Kl, 0, 1.0, 0.0, 0.0);
+              add(3, Kl, 3, 1.0, 0.0, 0.0);
+              add(1, Kp, 1, 1.0, 0.0, 0.0);   // E' = K_P E - i K_X B
+              add(2, Kp, 2, 1.0, 0.0, 0.0);   // B' = K_P B + i K_X E
+            } else {
+              add(2, Kx, 1, 0.0, -1.0, 1.0);
+              add(1, Kx, 2, 0.0, 1.0, 1.0);
+            }
+          }
+        }
+        DM_TRY(dm_gemm_grouped_launch(ctx, g));
+      }
+      if (Mc >= 0) {
+        // synthesis on the alias rings: Ha[mm][ja][col p] = (1 / w) sum_l tabA[l][ja] d[col][p][l]
+        for (int pass = 0; pass < (polarised ? 2 : 1); ++pass) {
+          std::vector<dm_gemm_desc> g;
+          for (int m = 0; m <= Mc; ++m) {
+            const int Lm = lmax_grp + 1 - m;
+            for (int s2 = 0; s2 < 2; ++s2) {
+              cplx* Hm = Ha + (size_t)(s2 * (Mc + 1) + m) * nra * ncp;
+              if (m == 0 && s2 == 1) continue;   // never read by the fold
+              const cplx* in = blk(dbuf, m, s2);
+              auto add = [&](int pin, const double* tab, int pout, double are, double aim, double beta) {
+                dm_gemm_desc dsc = dm_gemm_make(in + (size_t)pin * L, P * L, 1, false, tab + loffA[m], nra, 1, false, Hm + pout, P,
+                                                ncol, nra, Lm, are * iw, beta, nullptr, DM_GEMM_B_REAL);
+                dsc.csc = ncp;
+                dsc.alpha_im = aim * iw;
+                g.push_back(dsc);
+              };
+              if (!polarised) {
+                add(0, lamA, 0, 1.0, 0.0, 0.0);
+              } else if (pass == 0) {
+                add(0, lamA, 0, 1.0, 0.0, 0.0);
+                add(3, lamA, 3, 1.0, 0.0, 0.0);
+                add(1, WA, 1, 1.0, 0.0, 0.0);   // Q = W E - i X B
+                add(2, WA, 2, 1.0, 0.0, 0.0);   // U = W B + i X E
+              } else {
+                add(2, XA, 1, 0.0, -1.0, 1.0);
+                add(1, XA, 2, 0.0, 1.0, 1.0);
+              }
+            }
+          }
+          DM_TRY(dm_gemm_grouped_launch(ctx, g));
+        }
+        hipLaunchKernelGGL(bt_alias_fold_kernel, dim3((unsigned)((ncp + 255) / 256), nra, nmmA), dim3(256), 0, ctx->stream, Ha, Ga,
+                           Mc, nra, (size_t)ncp, d_nphiA, d_mlimA, d_scA);
+        // analysis of the folded rings, added to t
+        for (int pass = 0; pass < (polarised ? 2 : 1); ++pass) {
+          std::vector<dm_gemm_desc> g;
+          for (int m = 0; m <= Mc; ++m) {
+            const int Lm = lmax_grp + 1 - m;
+            for (int s2 = 0; s2 < 2; ++s2) {
+              if (m == 0 && s2 == 1) continue;
+              const cplx* Gm = Ga + (size_t)(s2 * (Mc + 1) + m) * nra * ncp;
+              cplx* out = blk(tbuf, m, s2);
+              auto add = [&](int pa, const double* tab, int pout, double are, double aim) {
+                dm_gemm_desc dsc = dm_gemm_make(Gm + pa, P, ncp, false, tab + loffA[m], 1, nra, false, out + (size_t)pout * L, P * L,
+                                                ncol, Lm, nra, are, 1.0, nullptr, DM_GEMM_B_REAL);
+                dsc.alpha_im = aim;
+                g.push_back(dsc);
+              };
+              if (!polarised) {
+                add(0, lamA, 0, 1.0, 0.0);
+              } else if (pass == 0) {
+                add(0, lamA, 0, 1.0, 0.0);
+                add(3, lamA, 3, 1.0, 0.0);
+                add(1, WA, 1, 1.0, 0.0);
+                add(2, WA, 2, 1.0, 0.0);
+              } else {
+                add(2, XA, 1, 0.0, -1.0);
+                add(1, XA, 2, 0.0, 1.0);
+              }
+            }
+          }
+          DM_TRY(dm_gemm_grouped_launch(ctx, g));
+        }
+      }
+      hipLaunchKernelGGL(bt_refine_update_kernel, dim3((P * L + 255) / 256, ncol, 2 * cnt), dim3(256), 0, ctx->stream, bm, dbuf,
+                         tbuf, m_lo, ncol, P, L, d_cl);
+      DM_HIP(ctx, hipGetLastError());
+    }
+  } else if (niter > 0 && cnt > 0) {
     const double iw = (double)npix / (4.0 * kPi);
     cplx* res = dm_ws_alloc_t<cplx>(ctx, (size_t)ncp * npix);
     if (!res) return DM_ENOMEM;
@@ -1515,8 +1884,44 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
   }
   // The fused path returns once everything is queued (stream-ordered with the caller's later work on the context's stream,
   // workspace re-use included: dm_ws_release); the refinement path keeps its wait.
-  if (niter > 0 || !fused) DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if ((niter > 0 && !harmonic) || !fused) DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   dm_ws_release(ctx, mark);
+  return DM_OK;
+}
+
+// healpy's `iter` without the maps: the first analysis and the harmonic-space refinement run on a private coefficient
+// buffer that holds the blocks the refinement of [m_lo, m_hi] depends on — the range itself, plus every m <= mcut when the
+// range reaches into the m the polar rings alias (those couple among themselves only) — and the requested blocks are
+// copied out.  The private buffer is (nm, 2, ncol, P, lmax_grp + 1): compact in l, columns adjacent.
+static int bt_sht_refined(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised,
+                          int lside, int m_lo, int m_hi, int lmax_grp, int F, int B, int ncol, const int* col_f_host,
+                          const int* col_b_host, const int* col_lmax_host, const void* maps_dev, void* beam_m_dev, int niter,
+                          const double* ring_w_host, const bt_synth_in* syn) {
+  if (!ctx) return DM_EARG;
+  DM_ARG(ctx, nside > 0 && ring_cth_host && ring_sth_host && lside >= 0 && m_lo >= 0 && m_hi >= m_lo && lmax_grp >= 0 &&
+                  lmax_grp <= lside && F > 0 && B > 0 && ncol >= 0 && col_f_host && col_b_host && col_lmax_host && beam_m_dev &&
+                  niter > 0);
+  if (ncol == 0) return DM_OK;
+  dm_ws_scope ws_scope__(ctx);
+  const int P = polarised ? 4 : 1, L = lside + 1, Ls = lmax_grp + 1;
+  for (int c = 0; c < ncol; ++c) DM_ARG(ctx, col_f_host[c] >= 0 && col_f_host[c] < F && col_b_host[c] >= 0 && col_b_host[c] < B);
+  const bt_alias_info& al = bt_alias_lookup(nside, lmax_grp, polarised != 0, ring_cth_host, ring_sth_host);
+  int e_lo = m_lo, e_hi = m_hi;
+  if (al.ia > 0 && m_lo <= al.mcut) { e_lo = 0; e_hi = std::max(m_hi, std::min(al.mcut, lmax_grp)); }
+  const int enm = e_hi - e_lo + 1;
+  cplx* acc = dm_ws_alloc_t<cplx>(ctx, (size_t)enm * 2 * ncol * P * Ls);
+  if (!acc) return DM_ENOMEM;
+  std::vector<int> zf(ncol, 0), ib(ncol);
+  for (int c = 0; c < ncol; ++c) ib[c] = c;
+  DM_TRY(bt_sht_impl(ctx, nside, ring_cth_host, ring_sth_host, polarised, lmax_grp, e_lo, e_hi, lmax_grp, 1, ncol, ncol,
+                     zf.data(), ib.data(), col_lmax_host, maps_dev, acc, niter, ring_w_host, syn, true));
+  std::vector<int> cfv(col_f_host, col_f_host + ncol), cbv(col_b_host, col_b_host + ncol);
+  int* d_cf = dm_ws_upload(ctx, cfv);
+  int* d_cb = dm_ws_upload(ctx, cbv);
+  if (!d_cf || !d_cb) return DM_ENOMEM;
+  hipLaunchKernelGGL(bt_scatter2_kernel, dim3((2 * P * L + 255) / 256, ncol, m_hi - m_lo + 1), dim3(256), 0, ctx->stream, acc, e_lo,
+                     enm, Ls, reinterpret_cast<cplx*>(beam_m_dev), m_lo, F, B, P, L, ncol, d_cf, d_cb);
+  DM_HIP(ctx, hipGetLastError());
   return DM_OK;
 }
 
@@ -1528,6 +1933,16 @@ int dm_bt_sht_opts(dm_ctx* ctx, int nside, const double* ring_cth_host, const do
   if (niter <= 0)
     return bt_sht_impl(ctx, nside, ring_cth_host, ring_sth_host, polarised, lside, m_lo, m_hi, lmax_grp, F, B, ncol,
                        col_f_host, col_b_host, col_lmax_host, maps_dev, beam_m_dev, 0, ring_w_host);
+  // default: the refinement in harmonic space (no residual maps; bt_sht_refined).  DM_SHT_PIXEL_REFINE=1 keeps the
+  // map-space form (synthesis, inverse ring DFT, residual map, re-analysis) for cross-checks.
+  static const bool pixel_refine = getenv("DM_SHT_PIXEL_REFINE") && atoi(getenv("DM_SHT_PIXEL_REFINE")) == 1;
+  if (!pixel_refine) {
+    DM_ARG(ctx, maps_dev != nullptr);
+    DM_TRY(bt_sht_refined(ctx, nside, ring_cth_host, ring_sth_host, polarised, lside, m_lo, m_hi, lmax_grp, F, B, ncol,
+                          col_f_host, col_b_host, col_lmax_host, maps_dev, beam_m_dev, niter, ring_w_host, nullptr));
+    DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DM_OK;
+  }
   // The refinement synthesises the map from EVERY (l, m) of a column, whatever range of m the caller keeps (and the
   // telescope's mmax may lie below a column's lmax): it runs on a private coefficient buffer holding m = 0 .. lmax_grp
   // of this group's columns, laid out like beam_m with F = 1, B = ncol; the requested blocks are copied out at the end.
@@ -1576,6 +1991,35 @@ int dm_bt_columns_c(dm_ctx* ctx, int nside, const double* ring_cth_host, const d
   bt_synth_in syn{frame_host, nbeam, reinterpret_cast<const double*>(beams_dev), uv_host, bi_host, bj_host, 1};
   return bt_sht_impl(ctx, nside, ring_cth_host, ring_sth_host, polarised, lside, m_lo, m_hi, lmax_grp, F, B, ncol, col_f_host,
                      col_b_host, col_lmax_host, nullptr, beam_m_dev, 0, ring_w_host, &syn);
+}
+
+// dm_bt_columns / dm_bt_columns_c with healpy's `iter`: niter Jacobi refinements of the quadrature carried out in harmonic
+// space (no Stokes maps, no residual maps); complex_beams selects the complex-pattern kernels.
+int dm_bt_columns_iter(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, const double* frame_host,
+                       int polarised, int nbeam, const void* beams_dev, int complex_beams, int ncol, const double* uv_host,
+                       const int* bi_host, const int* bj_host, int lside, int m_lo, int m_hi, int lmax_grp, int F, int B,
+                       const int* col_f_host, const int* col_b_host, const int* col_lmax_host, void* beam_m_dev,
+                       const double* ring_w_host, int niter) {
+  if (!ctx) return DM_EARG;
+  DM_ARG(ctx, frame_host && nbeam > 0 && beams_dev && uv_host && bi_host && bj_host && niter >= 0);
+  bt_synth_in syn{frame_host, nbeam, reinterpret_cast<const double*>(beams_dev), uv_host, bi_host, bj_host, complex_beams ? 1 : 0};
+  if (niter == 0)
+    return bt_sht_impl(ctx, nside, ring_cth_host, ring_sth_host, polarised, lside, m_lo, m_hi, lmax_grp, F, B, ncol, col_f_host,
+                       col_b_host, col_lmax_host, nullptr, beam_m_dev, 0, ring_w_host, &syn);
+  return bt_sht_refined(ctx, nside, ring_cth_host, ring_sth_host, polarised, lside, m_lo, m_hi, lmax_grp, F, B, ncol, col_f_host,
+                        col_b_host, col_lmax_host, nullptr, beam_m_dev, niter, ring_w_host, &syn);
+}
+
+// The m the refinement of one nside group couples through the polar rings: n_alias_rings per cap, and mcut — a call for a
+// range of m that starts at or below mcut transforms m = 0 .. max(m_hi, mcut) internally (-1: no coupling).  A function of
+// (nside, lmax_grp, polarised) alone; callers use it to size their column chunks.
+int dm_bt_alias_info(int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised, int lmax_grp,
+                     int* n_alias_rings, int* mcut) {
+  if (nside <= 0 || !ring_cth_host || !ring_sth_host || lmax_grp < 0 || !n_alias_rings || !mcut) return DM_EARG;
+  const bt_alias_info& al = bt_alias_lookup(nside, lmax_grp, polarised != 0, ring_cth_host, ring_sth_host);
+  *n_alias_rings = al.ia;
+  *mcut = al.ia > 0 ? std::min(al.mcut, lmax_grp) : -1;
+  return DM_OK;
 }
 
 int dm_bt_sht_range(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised,

@@ -328,6 +328,27 @@ int dm_bt_columns_c(dm_ctx* ctx, int nside, const double* ring_cth_host, const d
                     const int* bj_host, int lside, int m_lo, int m_hi, int lmax_grp, int F, int B, const int* col_f_host,
                     const int* col_b_host, const int* col_lmax_host, void* beam_m_dev, const double* ring_w_host);
 
+/* dm_bt_columns_iter: dm_bt_columns / dm_bt_columns_c (complex_beams != 0) with healpy.map2alm's `iter`: after the plain
+ * quadrature the coefficients are refined niter times,  a <- a_0 + a - (A o S) a  with A = map2alm(iter = 0), S = alm2map —
+ * what healpy does with the residual map, carried out in harmonic space: per m one real Gram matrix of the ring functions
+ * under the quadrature (the same for every column) plus the explicit alias terms of the few dozen polar rings with fewer
+ * than 2 lmax + 1 pixels.  No Stokes map and no residual map is ever formed; blocks are bit-identical under any partition
+ * of m.  healpy's documented default is iter = 3; what cora passes is not verifiable here.  niter = 0 is
+ * dm_bt_columns.  Returns when the work is queued on the context's stream.
+ * Replaces: the same call sites as dm_bt_columns (cora.util.hputil.sphtrans_complex[_pol] -> healpy.map2alm behind
+ * drift/core/telescope.py:1179-1191, :1288-1312). */
+int dm_bt_columns_iter(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, const double* frame_host,
+                       int polarised, int nbeam, const void* beams_dev, int complex_beams, int ncol, const double* uv_host,
+                       const int* bi_host, const int* bj_host, int lside, int m_lo, int m_hi, int lmax_grp, int F, int B,
+                       const int* col_f_host, const int* col_b_host, const int* col_lmax_host, void* beam_m_dev,
+                       const double* ring_w_host, int niter);
+
+/* dm_bt_alias_info: which m the refinement of an nside group couples through the polar rings (host only, no GPU work):
+ * n_alias_rings per cap and mcut (-1: none).  A refined call whose m-range starts at or below mcut transforms
+ * m = 0 .. max(m_hi, mcut) internally; callers size their column chunks with it. */
+int dm_bt_alias_info(int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised, int lmax_grp,
+                     int* n_alias_rings, int* mcut);
+
 /* ---- bit truncation of beam-transfer blocks before they are written ------------------------------- */
 /* In place on `nrows` rows of `ncols` complex128 values (`ld` elements between rows): every real and
  * imaginary part is rounded to the coarsest multiple of a power of two that keeps its error below
