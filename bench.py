@@ -199,7 +199,7 @@ def cpu_baseline(tel, bt, kl, blocks):
                 beamclass=tel.beamclass, wavelengths=tel.wavelengths, cylinder_width=tel.cylinder_width,
                 fwhm_e=tel.fwhm_e, fwhm_h=tel.fwhm_h, lmax=tel.lmax, mmax=tel.mmax, l_boost=tel.l_boost,
                 included_freq=np.array([0]), included_baseline=np.array([0, tel.nbase - 1]),
-                accuracy_boost=tel.accuracy_boost, sht_fft=True)   # one FFT per ring, Legendre sums as matrix products
+                accuracy_boost=tel.accuracy_boost, sht_iter=tel.sht_iter, sht_fft=True)   # one FFT per ring, Legendre sums as matrix products
     ncol = tel.nfreq * tel.nbase
     t_bt_block = _cpu_bt_columns(desc) / 2.0 * ncol / M    # 2 columns, all m -> seconds per m-block
     ms = sorted(blocks)

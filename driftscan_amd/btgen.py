@@ -91,13 +91,15 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
             # private coefficient buffers of the refinement (sum, increment, product): the caller's m, or 0 .. max(m_hi, mcut)
             # when the range reaches into the m the polar rings couple
             from ._lib import bt_alias_info
-            _, mcut = bt_alias_info(int(nside), cth, sth, pol, lgrp)
+            nalias, mcut = bt_alias_info(int(nside), cth, sth, pol, lgrp)
             e_lo, e_hi = (0, mmax) if m_range is None else (int(m_range[0]), int(m_range[1]))
+            pad = 0
             if mcut >= 0 and e_lo <= mcut:
-                e_lo, e_hi = 0, max(e_hi, mcut)
+                e_lo, e_hi, pad = 0, max(e_hi, mcut), 2 * nalias
             ncnt = max(min(e_hi, lgrp) - e_lo + 1, 1)
             nmr = 2 * ncnt
-            priv = 3 * 2 * (e_hi - e_lo + 1) * (lgrp + 1) + (4 * (mcut + 1) * 2 * 200 if mcut >= 0 else 0)
+            # three buffers of (m, 2, P, coefficients + alias slots) per column + the alias-ring synthesis
+            priv = 3 * 2 * (e_hi - e_lo + 1) * (lgrp + 1 + pad) + (2 * (mcut + 1) * pad if pad else 0)
         per_col = P * 16 * ((0 if fused else (2 if pixel_refine else 1)) * npix + nmr * nring + priv)
         fixed = 0 if fused else nmr * npix * 16
         ncol_max = max(1, int((max_bytes - fixed) // per_col)) if max_bytes > fixed else 1

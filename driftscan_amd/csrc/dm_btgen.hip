@@ -966,7 +966,7 @@ __global__ void bt_scatter_kernel(const cplx* __restrict__ src, int msrc, cplx* 
 // a synthesis and an analysis over all rings.  The polar rings with N_r = 4 i <= 2 lmax alias m' with m' - 4 i k
 // (e^{i k N phi0} = (-1)^k there); lambda_lm(z_i) falls off super-exponentially once m exceeds l sin(theta_i), so only the
 // rings next to the poles couple anything above rounding: ring i is treated as aliasing when some m >= 2 i still has
-// max_l |lambda_lm(z_i)| >= 1e-20 (mlim(i) = the last such m), which bounds both the ring set (a few dozen per cap) and the
+// max_l |lambda_lm(z_i)| >= 1e-13 (mlim(i) = the last such m; the terms left out are below 1e-15 of the coefficients), which bounds both the ring set (a few dozen per cap) and the
 // m involved (m <= mcut, around 50 - 160).  Those terms are formed explicitly: synthesis on the alias rings, the fold
 // over k, analysis.  Everything is carried in the beam_m convention b0 = a_{l,+m}, b1 = (-1)^m conj(a_{l,-m}), in which
 // analysis and synthesis use the same real tables for both slots; F_{-m} = conj(h1_m).
@@ -1013,7 +1013,7 @@ static double bt_table_peak(int lmax, int m, double z, double st, bool pol) {
   return peak;
 }
 
-constexpr double kAliasEps = 1e-20;
+constexpr double kAliasEps = 1e-13;
 
 // Alias rings and their m limits for (nside, lmax, polarised); a function of these three alone (every rank, every column
 // chunk and every m-range sees the same sets, so the refined blocks do not depend on how m is partitioned).  Cached.
@@ -1054,16 +1054,17 @@ __global__ __launch_bounds__(256) void bt_scale_table_kernel(const double* __res
     out[idx] = in[idx] * sc[idx % (size_t)nring];
 }
 
-// Alias fold on the alias rings: Ha, Ga are (2 (Mc + 1), nra, ncp), block mm = s (Mc + 1) + m; Ha holds h0_m = F_m and
-// h1_m = conj(F_-m).  Ga[s' = 0][m'] = sc sum_{k != 0} (-1)^k F_{m' - k N},  Ga[s' = 1][m'] = sc sum_{k != 0} (-1)^k conj(F_{-m' - k N}),
-// over the |m' - k N| <= mlim of the ring (sc = ring weight x N).
-__global__ __launch_bounds__(256) void bt_alias_fold_kernel(const cplx* __restrict__ Ha, cplx* __restrict__ Ga, int Mc, int nra,
-                                                            size_t ncp, const int* __restrict__ nphiA,
+// Alias fold on the alias rings.  Ha is (2 (Mc + 1), ncp, nra), block mm = s (Mc + 1) + m, holding h0_m = F_m and
+// h1_m = conj(F_-m).  g[s' = 0][m'] = sc sum_{k != 0} (-1)^k F_{m' - k N},  g[s' = 1][m'] = sc sum_{k != 0} (-1)^k conj(F_{-m' - k N}),
+// over the |m' - k N| <= mlim of the ring (sc = ring weight x N), written into the alias slots of the increment rows:
+// d[(m', s', col, p)][Lg + ja] — the K dimension of the next product runs over the coefficients AND these slots.
+__global__ __launch_bounds__(256) void bt_alias_fold_kernel(const cplx* __restrict__ Ha, cplx* __restrict__ d, int Mc, int nra,
+                                                            size_t ncp, int L, int Lg, const int* __restrict__ nphiA,
                                                             const int* __restrict__ mlimA, const double* __restrict__ scA) {
-  const int ja = blockIdx.y, mmp = blockIdx.z;
+  const int ja = blockIdx.y * 64 + threadIdx.x, mmp = blockIdx.z;
+  const size_t c = (size_t)blockIdx.x * 4 + threadIdx.y;
+  if (ja >= nra || c >= ncp) return;
   const int sp = mmp / (Mc + 1), mp = mmp - sp * (Mc + 1);
-  const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (c >= ncp) return;
   const int N = nphiA[ja], ml = min(mlimA[ja], Mc);
   double are = 0.0, aim = 0.0;
   if (mp <= ml && !(sp == 1 && mp == 0)) {
@@ -1076,20 +1077,37 @@ __global__ __launch_bounds__(256) void bt_alias_fold_kernel(const cplx* __restri
       if (k == 0) continue;
       const int mu = base - k * N;
       cplx f;
-      if (mu >= 0) f = Ha[((size_t)mu * nra + ja) * ncp + c];
-      else { f = Ha[((size_t)(Mc + 1 - mu) * nra + ja) * ncp + c]; f.y = -f.y; }
+      if (mu >= 0) f = Ha[((size_t)mu * ncp + c) * nra + ja];
+      else { f = Ha[((size_t)(Mc + 1 - mu) * ncp + c) * nra + ja]; f.y = -f.y; }
       if (sp == 1) f.y = -f.y;
       if (k & 1) { are -= f.x; aim -= f.y; } else { are += f.x; aim += f.y; }
     }
   }
-  const double s = scA[ja];
-  Ga[((size_t)mmp * nra + ja) * ncp + c] = make_double2(s * are, s * aim);
+  const double sc = scA[ja];
+  d[(((size_t)mp * 2 + sp) * ncp + c) * L + Lg + ja] = make_double2(sc * are, sc * aim);
 }
 
-// d <- mask(d - t), acc += d on the private coefficient buffers (nm, 2, ncol, P, L); entries l < m stay zero, the -m slot
-// of m = 0 stays zero, l > lmax of the column is cut (the column's own band limit, telescope.py:792-802)
+// The alias rows of the extended Gram matrices: element (k = Lm + ja, n = l) of the (Lm + nra) x Lm operand of block m is
+// the alias-ring table value tabA_m[l][ja] (the analysis of the folded rings rides in the K dimension of the product)
+__global__ __launch_bounds__(256) void bt_kext_fill_kernel(const double* __restrict__ tabA, const size_t* __restrict__ loffA,
+                                                           double* __restrict__ Kx, const size_t* __restrict__ kxoff, int lmax_grp,
+                                                           int nra, int kfast) {
+  const int m = blockIdx.y;
+  const int Lm = lmax_grp + 1 - m, Kd = Lm + nra;
+  const size_t tot = (size_t)Lm * nra;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * 256) {
+    const size_t l = idx / nra, ja = idx - l * nra;
+    const double v = tabA[loffA[m] + idx];
+    if (kfast) Kx[kxoff[m] + l * Kd + Lm + ja] = v;
+    else Kx[kxoff[m] + (Lm + ja) * Lm + l] = v;
+  }
+}
+
+// d <- mask(d - t), acc += d on the private coefficient buffers (nm, 2, ncol, P, L) (L = Lg coefficients + alias slots);
+// entries l < m stay zero, the -m slot of m = 0 stays zero, l > lmax of the column is cut (the column's own band limit,
+// telescope.py:792-802)
 __global__ __launch_bounds__(256) void bt_refine_update_kernel(cplx* __restrict__ acc, cplx* __restrict__ d, const cplx* __restrict__ t,
-                                                               int m_lo, int ncol, int P, int L,
+                                                               int m_lo, int ncol, int P, int L, int Lg,
                                                                const int* __restrict__ collmax) {
   const int col = blockIdx.y;
   const int mi = blockIdx.z >> 1, s = blockIdx.z & 1;
@@ -1097,7 +1115,7 @@ __global__ __launch_bounds__(256) void bt_refine_update_kernel(cplx* __restrict_
   const int idx = blockIdx.x * 256 + threadIdx.x;   // over (p, l)
   if (idx >= P * L) return;
   const int l = idx % L;
-  if (l < m || (m == 0 && s == 1)) return;
+  if (l < m || l >= Lg || (m == 0 && s == 1)) return;
   const size_t o = ((((size_t)mi * 2 + s) * ncol + col) * P) * L + idx;
   cplx dn = make_double2(0.0, 0.0);
   if (l <= collmax[col]) dn = csub(d[o], t[o]);
@@ -1105,10 +1123,11 @@ __global__ __launch_bounds__(256) void bt_refine_update_kernel(cplx* __restrict_
   acc[o] = cadd(acc[o], dn);
 }
 
-// private coefficient buffer (blocks m = src_mlo .. src_mlo + src_nm - 1, layout (src_nm, 2, ncol, P, Ls)) -> the
-// caller's beam_m blocks (m_hi - m_lo + 1, F, 2, B, P, L): l >= Ls and blocks outside the source are zero
-__global__ void bt_scatter2_kernel(const cplx* __restrict__ src, int src_mlo, int src_nm, int Ls, cplx* __restrict__ dst, int m_lo,
-                                   int F, int B, int P, int L, int ncol, const int* __restrict__ colf,
+// private coefficient buffer (blocks m = src_mlo .. src_mlo + src_nm - 1, layout (src_nm, 2, ncol, P, Lrow) with Ls
+// coefficients per row) -> the caller's beam_m blocks (m_hi - m_lo + 1, F, 2, B, P, L): l >= Ls and blocks outside the
+// source are zero
+__global__ void bt_scatter2_kernel(const cplx* __restrict__ src, int src_mlo, int src_nm, int Ls, int Lrow, cplx* __restrict__ dst,
+                                   int m_lo, int F, int B, int P, int L, int ncol, const int* __restrict__ colf,
                                    const int* __restrict__ colb) {
   const int col = blockIdx.y;
   const int mo = blockIdx.z;
@@ -1117,7 +1136,7 @@ __global__ void bt_scatter2_kernel(const cplx* __restrict__ src, int src_mlo, in
   const int s = idx / (P * L), pl = idx % (P * L), p = pl / L, l = pl % L;
   const int ms = m_lo + mo - src_mlo;
   cplx v = make_double2(0.0, 0.0);
-  if (ms >= 0 && ms < src_nm && l < Ls) v = src[((((size_t)ms * 2 + s) * ncol + col) * P + p) * Ls + l];
+  if (ms >= 0 && ms < src_nm && l < Ls) v = src[((((size_t)ms * 2 + s) * ncol + col) * P + p) * Lrow + l];
   dst[((((size_t)mo * F + colf[col]) * 2 + s) * B + colb[col]) * P * L + pl] = v;
 }
 
@@ -1339,7 +1358,7 @@ struct bt_synth_in {
 static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, const double* ring_sth_host, int polarised,
                        int lside, int m_lo, int m_hi, int lmax_grp, int F, int B, int ncol, const int* col_f_host,
                        const int* col_b_host, const int* col_lmax_host, const void* maps_dev, void* beam_m_dev, int niter,
-                       const double* ring_w_host, const bt_synth_in* syn = nullptr, bool harmonic = false) {
+                       const double* ring_w_host, const bt_synth_in* syn = nullptr, bool harmonic = false, int row_pad = 0) {
   if (!ctx) return DM_EARG;
   DM_ARG(ctx, maps_dev || (syn && (niter == 0 || harmonic)));
   DM_ARG(ctx, nside > 0 && ring_cth_host && ring_sth_host && lside >= 0 && m_lo >= 0 && m_hi >= m_lo && lmax_grp >= 0 &&
@@ -1348,13 +1367,14 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
   DM_ARG(ctx, niter == 0 || harmonic || (m_lo == 0 && m_hi >= lmax_grp));  // the residual map needs every m of a column
   // the harmonic-space refinement runs on a private coefficient buffer laid out (m, 2, col, P, L) (bt_sht_refined)
   DM_ARG(ctx, !(niter > 0 && harmonic) || (F == 1 && B == ncol && lside == lmax_grp));
+  DM_ARG(ctx, row_pad == 0 || (niter > 0 && harmonic));
   if (ncol == 0) return DM_OK;
   dm_ws_scope ws_scope__(ctx);  // releases on every return path
   const size_t mark = ws_scope__.mark;
   geo_host gh;
   DM_TRY(upload_geo(ctx, nside, ring_cth_host, ring_sth_host, gh));
   const int P = polarised ? 4 : 1;
-  const int L = lside + 1;
+  const int L = lside + 1 + row_pad;   // row length of the destination (row_pad: alias slots of the private buffers)
   const int nring = gh.g.nring, npix = gh.g.npix;
   const int mtop = std::min(m_hi, lmax_grp);  // no (l, m) content above the group's band limit
   const int cnt = std::max(mtop - m_lo + 1, 0);  // m values with content in this range
@@ -1636,19 +1656,25 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
   // The tables carry the quadrature weight w = 4 pi / npix: the synthesis divides it out again.
   if (niter > 0 && harmonic && cnt > 0) {
     for (int c = 0; c < ncol; ++c) DM_ARG(ctx, cf[c] == 0 && cb[c] == c);
+    const int Lg = lmax_grp + 1;
     const double wq = 4.0 * kPi / (double)npix, iw = 1.0 / wq;
     const bt_alias_info& al = bt_alias_lookup(nside, lmax_grp, polarised != 0, ring_cth_host, ring_sth_host);
     // alias terms couple the m <= mcut among themselves: a call that touches them must hold all of them (bt_sht_refined)
     const int Mc = (al.ia > 0 && m_lo == 0) ? std::min(al.mcut, mtop) : -1;
     DM_ARG(ctx, al.ia == 0 || m_lo == 0 || m_lo > al.mcut);
     DM_ARG(ctx, Mc < 0 || mtop >= std::min(al.mcut, lmax_grp));
-    // ---- per-ring factor of A o S and the Gram matrices K_m
+    const int nra = Mc >= 0 ? 2 * al.ia : 0;
+    DM_ARG(ctx, row_pad == nra);
+    static const bool kfast = !(getenv("DM_SHT_KNFAST") && atoi(getenv("DM_SHT_KNFAST")) == 1);
+    // ---- per-ring factor of A o S and the Gram matrices K_m, extended by the alias-ring tables for m <= Mc:
+    //      block m is a (Lm + xa) x Lm operand, xa = nra alias rows
     std::vector<double> sc(nring);
     for (int r = 0; r < nring; ++r) sc[r] = (ring_w_host ? ring_w_host[r] : 1.0) * (double)gh.nphi[r] * iw;
     double* d_sc = dm_ws_upload(ctx, sc);
     std::vector<size_t> koff(cnt);
     size_t ktot = 0;
-    for (int m = m_lo; m <= mtop; ++m) { koff[m - m_lo] = ktot; const size_t Lm = lmax_grp + 1 - m; ktot += Lm * Lm; }
+    auto xa = [&](int m) { return m <= Mc ? nra : 0; };
+    for (int m = m_lo; m <= mtop; ++m) { koff[m - m_lo] = ktot; const size_t Lm = lmax_grp + 1 - m; ktot += Lm * (Lm + xa(m)); }
     double* Kl = dm_ws_alloc_t<double>(ctx, ktot);
     double* Kp = polarised ? dm_ws_alloc_t<double>(ctx, ktot) : nullptr;
     double* Kx = polarised ? dm_ws_alloc_t<double>(ctx, ktot) : nullptr;
@@ -1670,9 +1696,11 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
         for (int m = m_lo; m <= mtop; ++m) {
           const int Lm = lmax_grp + 1 - m;
           const size_t lo = loff[m - m_lo], ko = koff[m - m_lo];
+          // K is symmetric: row i of the product lands where the chosen layout keeps (k = i, n) resp. (k, n = i)
+          const int ldk = kfast ? Lm + xa(m) : Lm;
           auto kadd = [&](const double* a, const double* b, double* c, double beta) {
             g.push_back(dm_gemm_make(reinterpret_cast<const cplx*>(a + lo), nring, 1, false, b + lo, 1, nring, false,
-                                     reinterpret_cast<cplx*>(c + ko), Lm, Lm, Lm, nring, 1.0, beta, nullptr, DM_GEMM_ALL_REAL));
+                                     reinterpret_cast<cplx*>(c + ko), ldk, Lm, Lm, nring, 1.0, beta, nullptr, DM_GEMM_ALL_REAL));
           };
           if (pass == 0) {
             kadd(lam, lamS, Kl, 0.0);
@@ -1686,11 +1714,10 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
       }
     }
     // ---- alias rings: their own small tables (same recurrences, same bits as the full tables)
-    const int nra = Mc >= 0 ? 2 * al.ia : 0;
     const int nmmA = 2 * (Mc + 1);
     double *lamA = nullptr, *WA = nullptr, *XA = nullptr, *d_scA = nullptr;
     int *d_nphiA = nullptr, *d_mlimA = nullptr;
-    cplx *Ha = nullptr, *Ga = nullptr;
+    cplx* Ha = nullptr;
     std::vector<size_t> loffA(std::max(Mc + 1, 1), 0);
     if (Mc >= 0) {
       std::vector<double> geoA(2 * (size_t)nra), scA(nra);
@@ -1710,11 +1737,11 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
       size_t ltotA = 0;
       for (int m = 0; m <= Mc; ++m) { loffA[m] = ltotA; ltotA += (size_t)(lmax_grp + 1 - m) * nra; }
       size_t* d_loffA = dm_ws_upload(ctx, loffA);
+      size_t* d_koff = dm_ws_upload(ctx, koff);
       lamA = dm_ws_alloc_t<double>(ctx, ltotA);
       if (polarised) { WA = dm_ws_alloc_t<double>(ctx, ltotA); XA = dm_ws_alloc_t<double>(ctx, ltotA); }
       Ha = dm_ws_alloc_t<cplx>(ctx, (size_t)nmmA * nra * ncp);
-      Ga = dm_ws_alloc_t<cplx>(ctx, (size_t)nmmA * nra * ncp);
-      if (!d_geoA || !d_scA || !d_nphiA || !d_mlimA || !d_loffA || !lamA || (polarised && (!WA || !XA)) || !Ha || !Ga)
+      if (!d_geoA || !d_scA || !d_nphiA || !d_mlimA || !d_loffA || !d_koff || !lamA || (polarised && (!WA || !XA)) || !Ha)
         return DM_ENOMEM;
       ring_geo ga = gh.g;
       ga.cth = d_geoA;
@@ -1722,6 +1749,12 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
       ga.nring = nra;
       hipLaunchKernelGGL(bt_legendre_kernel, dim3((nra + 63) / 64, Mc + 1), dim3(64), 0, ctx->stream, ga, lmax_grp, 0, Mc, wq,
                          d_loffA, lamA, WA, XA);
+      const dim3 fg(64, Mc + 1);
+      hipLaunchKernelGGL(bt_kext_fill_kernel, fg, dim3(256), 0, ctx->stream, lamA, d_loffA, Kl, d_koff, lmax_grp, nra, kfast ? 1 : 0);
+      if (polarised) {
+        hipLaunchKernelGGL(bt_kext_fill_kernel, fg, dim3(256), 0, ctx->stream, WA, d_loffA, Kp, d_koff, lmax_grp, nra, kfast ? 1 : 0);
+        hipLaunchKernelGGL(bt_kext_fill_kernel, fg, dim3(256), 0, ctx->stream, XA, d_loffA, Kx, d_koff, lmax_grp, nra, kfast ? 1 : 0);
+      }
     }
     // ---- iteration on the increments:  d_0 = a_0,  d_{k+1} = d_k - mask((A o S) d_k),  a_n = sum_k d_k
     const size_t nacc = (size_t)nmblk * 2 * ncol * P * L;
@@ -1731,38 +1764,8 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
     DM_HIP(ctx, hipMemcpyAsync(dbuf, bm, sizeof(cplx) * nacc, hipMemcpyDeviceToDevice, ctx->stream));
     auto blk = [&](cplx* base, int m, int s2) { return base + ((size_t)(m - m_lo) * 2 + s2) * ncol * P * L + m; };
     for (int it = 0; it < niter; ++it) {
-      for (int pass = 0; pass < (polarised ? 2 : 1); ++pass) {   // t = K d
-        std::vector<dm_gemm_desc> g;
-        for (int m = m_lo; m <= mtop; ++m) {
-          const int Lm = lmax_grp + 1 - m;
-          const size_t ko = koff[m - m_lo];
-          for (int s2 = 0; s2 < 2; ++s2) {
-            if (m == 0 && s2 == 1) continue;
-            const cplx* in = blk(dbuf, m, s2);
-            cplx* out = blk(tbuf, m, s2);
-            auto add = [&](int pin, const double* Km, int pout, double are, double aim, double beta) {
-              dm_gemm_desc dsc = dm_gemm_make(in + (size_t)pin * L, P * L, 1, false, Km + ko, Lm, 1, false, out + (size_t)pout * L,
-                                              P * L, ncol, Lm, Lm, are, beta, nullptr, DM_GEMM_B_REAL);
-              dsc.alpha_im = aim;
-              g.push_back(dsc);
-            };
-            if (!polarised) {
-              add(0, Kl, 0, 1.0, 0.0, 0.0);
-            } else if (pass == 0) {
-              add(0, Kl, 0, 1.0, 0.0, 0.0);
-              add(3, Kl, 3, 1.0, 0.0, 0.0);
-              add(1, Kp, 1, 1.0, 0.0, 0.0);   // E' = K_P E - i K_X B
-              add(2, Kp, 2, 1.0, 0.0, 0.0);   // B' = K_P B + i K_X E
-            } else {
-              add(2, Kx, 1, 0.0, -1.0, 1.0);
-              add(1, Kx, 2, 0.0, 1.0, 1.0);
-            }
-          }
-        }
-        DM_TRY(dm_gemm_grouped_launch(ctx, g));
-      }
       if (Mc >= 0) {
-        // synthesis on the alias rings: Ha[mm][ja][col p] = (1 / w) sum_l tabA[l][ja] d[col][p][l]
+        // synthesis on the alias rings: Ha[mm][col p][ja] = (1 / w) sum_l tabA[l][ja] d[col][p][l]
         for (int pass = 0; pass < (polarised ? 2 : 1); ++pass) {
           std::vector<dm_gemm_desc> g;
           for (int m = 0; m <= Mc; ++m) {
@@ -1772,9 +1775,9 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
               if (m == 0 && s2 == 1) continue;   // never read by the fold
               const cplx* in = blk(dbuf, m, s2);
               auto add = [&](int pin, const double* tab, int pout, double are, double aim, double beta) {
-                dm_gemm_desc dsc = dm_gemm_make(in + (size_t)pin * L, P * L, 1, false, tab + loffA[m], nra, 1, false, Hm + pout, P,
-                                                ncol, nra, Lm, are * iw, beta, nullptr, DM_GEMM_B_REAL);
-                dsc.csc = ncp;
+                dm_gemm_desc dsc = dm_gemm_make(in + (size_t)pin * L, P * L, 1, false, tab + loffA[m], nra, 1, false,
+                                                Hm + (size_t)pout * nra, P * nra, ncol, nra, Lm, are * iw, beta, nullptr,
+                                                DM_GEMM_B_REAL);
                 dsc.alpha_im = aim * iw;
                 g.push_back(dsc);
               };
@@ -1793,41 +1796,42 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
           }
           DM_TRY(dm_gemm_grouped_launch(ctx, g));
         }
-        hipLaunchKernelGGL(bt_alias_fold_kernel, dim3((unsigned)((ncp + 255) / 256), nra, nmmA), dim3(256), 0, ctx->stream, Ha, Ga,
-                           Mc, nra, (size_t)ncp, d_nphiA, d_mlimA, d_scA);
-        // analysis of the folded rings, added to t
-        for (int pass = 0; pass < (polarised ? 2 : 1); ++pass) {
-          std::vector<dm_gemm_desc> g;
-          for (int m = 0; m <= Mc; ++m) {
-            const int Lm = lmax_grp + 1 - m;
-            for (int s2 = 0; s2 < 2; ++s2) {
-              if (m == 0 && s2 == 1) continue;
-              const cplx* Gm = Ga + (size_t)(s2 * (Mc + 1) + m) * nra * ncp;
-              cplx* out = blk(tbuf, m, s2);
-              auto add = [&](int pa, const double* tab, int pout, double are, double aim) {
-                dm_gemm_desc dsc = dm_gemm_make(Gm + pa, P, ncp, false, tab + loffA[m], 1, nra, false, out + (size_t)pout * L, P * L,
-                                                ncol, Lm, nra, are, 1.0, nullptr, DM_GEMM_B_REAL);
-                dsc.alpha_im = aim;
-                g.push_back(dsc);
-              };
-              if (!polarised) {
-                add(0, lamA, 0, 1.0, 0.0);
-              } else if (pass == 0) {
-                add(0, lamA, 0, 1.0, 0.0);
-                add(3, lamA, 3, 1.0, 0.0);
-                add(1, WA, 1, 1.0, 0.0);
-                add(2, WA, 2, 1.0, 0.0);
-              } else {
-                add(2, XA, 1, 0.0, -1.0);
-                add(1, XA, 2, 0.0, 1.0);
-              }
+        hipLaunchKernelGGL(bt_alias_fold_kernel, dim3((unsigned)((ncp + 3) / 4), (nra + 63) / 64, nmmA), dim3(64, 4), 0, ctx->stream,
+                           Ha, dbuf, Mc, nra, (size_t)ncp, L, Lg, d_nphiA, d_mlimA, d_scA);
+      }
+      // t = [d | folded rings] [K ; alias tables]: the Gram product and the analysis of the folded rings in one K dimension
+      for (int pass = 0; pass < (polarised ? 2 : 1); ++pass) {
+        std::vector<dm_gemm_desc> g;
+        for (int m = m_lo; m <= mtop; ++m) {
+          const int Lm = lmax_grp + 1 - m, Kd = Lm + xa(m);
+          const size_t ko = koff[m - m_lo];
+          for (int s2 = 0; s2 < 2; ++s2) {
+            if (m == 0 && s2 == 1) continue;
+            const cplx* in = blk(dbuf, m, s2);
+            cplx* out = blk(tbuf, m, s2);
+            auto add = [&](int pin, const double* Km, int pout, double are, double aim, double beta) {
+              dm_gemm_desc dsc = dm_gemm_make(in + (size_t)pin * L, P * L, 1, false, Km + ko, kfast ? 1 : Lm, kfast ? Kd : 1, false,
+                                              out + (size_t)pout * L, P * L, ncol, Lm, Kd, are, beta, nullptr, DM_GEMM_B_REAL);
+              dsc.alpha_im = aim;
+              g.push_back(dsc);
+            };
+            if (!polarised) {
+              add(0, Kl, 0, 1.0, 0.0, 0.0);
+            } else if (pass == 0) {
+              add(0, Kl, 0, 1.0, 0.0, 0.0);
+              add(3, Kl, 3, 1.0, 0.0, 0.0);
+              add(1, Kp, 1, 1.0, 0.0, 0.0);   // E' = K_P E - i K_X B  (+ W g_Q - i X g_U from the alias slots)
+              add(2, Kp, 2, 1.0, 0.0, 0.0);   // B' = K_P B + i K_X E  (+ W g_U + i X g_Q)
+            } else {
+              add(2, Kx, 1, 0.0, -1.0, 1.0);
+              add(1, Kx, 2, 0.0, 1.0, 1.0);
             }
           }
-          DM_TRY(dm_gemm_grouped_launch(ctx, g));
         }
+        DM_TRY(dm_gemm_grouped_launch(ctx, g));
       }
       hipLaunchKernelGGL(bt_refine_update_kernel, dim3((P * L + 255) / 256, ncol, 2 * cnt), dim3(256), 0, ctx->stream, bm, dbuf,
-                         tbuf, m_lo, ncol, P, L, d_cl);
+                         tbuf, m_lo, ncol, P, L, Lg, d_cl);
       DM_HIP(ctx, hipGetLastError());
     }
   } else if (niter > 0 && cnt > 0) {
@@ -1909,18 +1913,22 @@ static int bt_sht_refined(dm_ctx* ctx, int nside, const double* ring_cth_host, c
   int e_lo = m_lo, e_hi = m_hi;
   if (al.ia > 0 && m_lo <= al.mcut) { e_lo = 0; e_hi = std::max(m_hi, std::min(al.mcut, lmax_grp)); }
   const int enm = e_hi - e_lo + 1;
-  cplx* acc = dm_ws_alloc_t<cplx>(ctx, (size_t)enm * 2 * ncol * P * Ls);
+  // rows of the private buffers: Ls coefficients + one slot per alias ring (the folded rings ride in the K dimension of
+  // the Gram products)
+  const int pad = (al.ia > 0 && e_lo == 0 && std::min(e_hi, lmax_grp) >= 0) ? 2 * al.ia : 0;
+  const int Lrow = Ls + pad;
+  cplx* acc = dm_ws_alloc_t<cplx>(ctx, (size_t)enm * 2 * ncol * P * Lrow);
   if (!acc) return DM_ENOMEM;
   std::vector<int> zf(ncol, 0), ib(ncol);
   for (int c = 0; c < ncol; ++c) ib[c] = c;
   DM_TRY(bt_sht_impl(ctx, nside, ring_cth_host, ring_sth_host, polarised, lmax_grp, e_lo, e_hi, lmax_grp, 1, ncol, ncol,
-                     zf.data(), ib.data(), col_lmax_host, maps_dev, acc, niter, ring_w_host, syn, true));
+                     zf.data(), ib.data(), col_lmax_host, maps_dev, acc, niter, ring_w_host, syn, true, pad));
   std::vector<int> cfv(col_f_host, col_f_host + ncol), cbv(col_b_host, col_b_host + ncol);
   int* d_cf = dm_ws_upload(ctx, cfv);
   int* d_cb = dm_ws_upload(ctx, cbv);
   if (!d_cf || !d_cb) return DM_ENOMEM;
   hipLaunchKernelGGL(bt_scatter2_kernel, dim3((2 * P * L + 255) / 256, ncol, m_hi - m_lo + 1), dim3(256), 0, ctx->stream, acc, e_lo,
-                     enm, Ls, reinterpret_cast<cplx*>(beam_m_dev), m_lo, F, B, P, L, ncol, d_cf, d_cb);
+                     enm, Ls, Lrow, reinterpret_cast<cplx*>(beam_m_dev), m_lo, F, B, P, L, ncol, d_cf, d_cb);
   DM_HIP(ctx, hipGetLastError());
   return DM_OK;
 }

@@ -81,10 +81,12 @@ class TransitTelescope(config.Reader):
 
     accuracy_boost = config.Property(proptype=float, default=1.0)
     l_boost = config.Property(proptype=float, default=1.0)
-    # MI355X-side knobs for the spherical-harmonic transform behind transfer_matrices (telescope.py:1179-1191,
-    # :1288-1312 reach healpy.map2alm through cora, whose `iter` / ring-weight settings cannot be read here):
-    # Jacobi refinements of the quadrature, and optional per-ring weight factors {nside: array(4 nside - 1)}
-    sht_iter = config.Property(proptype=int, default=0)
+    # The two settings of healpy.map2alm the reference reaches through cora.util.hputil.sphtrans_complex[_pol]
+    # (telescope.py:1179-1191, :1288-1312; neither package can be read here): `iter`, Jacobi refinements of the quadrature
+    # — healpy's documented default is 3 and nothing in the reference overrides it, so 3 is the default here (iter = 0
+    # moves beam_m by up to 6e-3 of the block scale on tests/testparams.yaml, far outside the reference's own
+    # approx(rel=1e-4)) — and optional per-ring weight factors {nside: array(4 nside - 1)}
+    sht_iter = config.Property(proptype=int, default=3)
     sht_ring_weights = None
     force_lmax = config.Property(proptype=int, default=None)
     force_mmax = config.Property(proptype=int, default=None)

@@ -325,6 +325,98 @@ def ring_dft_fft(maps, nside, mlist, sign=+1):
     return out
 
 
+_TABLES = {}
+
+
+def ring_tables(nside, lmax, am, polarised):
+    """(lambda, W, X) of `lambda_lm` / `wx_lm` for l = am..lmax on every ring of `nside`, remembered at the largest lmax
+    asked for (the recurrences run upwards in l: the tables of a smaller lmax are the leading rows).  Only the FFT forms
+    below use the cache — several GB at nside 512; `clear_tables()` drops it."""
+    key = (int(nside), int(am), bool(polarised))
+    hit = _TABLES.get(key)
+    if hit is None or hit[0] < lmax:
+        z = ring_info(nside)[0]
+        lam = lambda_lm(lmax, am, z)
+        W, X = wx_lm(lmax, am, z) if polarised else (None, None)
+        hit = (lmax, lam, W, X)
+        _TABLES[key] = hit
+    n = lmax + 1 - am
+    return hit[1][:n], (hit[2][:n] if polarised else None), (hit[3][:n] if polarised else None)
+
+
+def clear_tables():
+    _TABLES.clear()
+
+
+def ring_synth_fft(F, nside, ms):
+    """maps[..., pix(ring, j)] = sum_m F[m, ring, ...] exp(-i m phi_j): the inverse of `ring_dft_fft(sign=+1)` on
+    band-limited rings, one FFT per ring (m folded into the N bins of the ring first — on the polar rings with
+    N <= 2 lmax several m share a bin, which is the aliasing a map-space refinement sees).  F: (nm, nring) + lead."""
+    z, nphi, phi0, start = ring_info(nside)
+    ms = np.asarray(ms)
+    lead = F.shape[2:]
+    npix = 12 * nside**2
+    maps = np.zeros(lead + (npix,), dtype=np.complex128)
+    r = 0
+    while r < z.size:
+        r1 = r
+        while r1 + 1 < z.size and nphi[r1 + 1] == nphi[r]:
+            r1 += 1
+        n = int(nphi[r])
+        ph = np.exp(-1j * np.outer(ms, phi0[r : r1 + 1]))                                   # (nm, nrun)
+        Fr = F[:, r : r1 + 1] * ph.reshape(ph.shape + (1,) * len(lead))                      # (nm, nrun) + lead
+        X = np.zeros((n, r1 - r + 1) + lead, dtype=np.complex128)
+        np.add.at(X, np.mod(ms, n), Fr)                                                      # fold m into the bins
+        seg = np.fft.fft(X, axis=0)                                                          # sum_q X[q] e^{-2 pi i q j / n}
+        seg = np.moveaxis(seg, (0, 1), (-1, -2))                                             # lead + (nrun, n)
+        maps[..., start[r] : start[r1] + n] = seg.reshape(lead + ((r1 - r + 1) * n,))
+        r = r1 + 1
+    return maps
+
+
+def _analysis_fft(maps, nside, lmax, polarised, ring_w=None):
+    """`_analysis` for every m in -lmax..lmax with one FFT per ring and cached tables: {m: (P, lmax + 1 - |m|)}."""
+    z, nphi, phi0, start = ring_info(nside)
+    w = 4.0 * np.pi / (12 * nside**2)
+    wr = w * (np.ones(z.size) if ring_w is None else np.asarray(ring_w, dtype=np.float64))
+    ms = np.arange(-lmax, lmax + 1)
+    G = ring_dft_fft(maps, nside, ms, sign=+1)           # (nm, nring, P)
+    out = {}
+    for mi, m in enumerate(ms):
+        am = abs(int(m))
+        lam, W, X = ring_tables(nside, lmax, am, polarised)
+        sgn = (-1.0) ** am if m < 0 else 1.0
+        g = G[mi] * wr[:, None]
+        c = np.zeros((g.shape[1], lmax + 1 - am), dtype=np.complex128)
+        c[0] = sgn * (lam @ g[:, 0])
+        if polarised:
+            sx = -sgn if m < 0 else 1.0
+            c[1] = sgn * (W @ g[:, 1]) - 1j * sx * (X @ g[:, 2])
+            c[2] = sgn * (W @ g[:, 2]) + 1j * sx * (X @ g[:, 1])
+            c[3] = sgn * (lam @ g[:, 3])
+        out[int(m)] = c
+    return out
+
+
+def _synthesis_fft(coef, nside, lmax, polarised, npol):
+    """`_synthesis` with cached tables and one FFT per ring."""
+    nring = 4 * nside - 1
+    ms = np.array(sorted(coef))
+    F = np.zeros((ms.size, nring, npol), dtype=np.complex128)
+    for mi, m in enumerate(ms):
+        c = coef[int(m)]
+        am = abs(int(m))
+        lam, W, X = ring_tables(nside, lmax, am, polarised)
+        sgn = (-1.0) ** am if m < 0 else 1.0
+        F[mi, :, 0] = sgn * (c[0] @ lam)
+        if polarised:
+            sx = -sgn if m < 0 else 1.0
+            F[mi, :, 1] = sgn * (c[1] @ W) - 1j * sx * (c[2] @ X)
+            F[mi, :, 2] = sgn * (c[2] @ W) + 1j * sx * (c[1] @ X)
+            F[mi, :, 3] = sgn * (c[3] @ lam)
+    return ring_synth_fft(F, nside, ms)                   # (npol, npix)
+
+
 def _analysis(maps, nside, lmax, polarised, ms, ring_w=None):
     """c[p, l, m] = sum_pix w f_p Y_lm(pix) for the m in `ms` (the reference's conj(SHT(conj f))); returns
     {m: (P, lmax + 1 - |m|)} with (T, E, B, V) for polarised maps."""
@@ -396,10 +488,15 @@ def transfer_single(maps, nside, lmax, lside, polarised, mabs=None, niter=0, rin
         P = 4 if polarised else 1
         m2 = np.asarray(maps).reshape(P, 12 * nside**2)
         ms = np.arange(-lmax, lmax + 1)
-        coef = _analysis(m2, nside, lmax, polarised, ms, ring_w)
+        # healpy.map2alm: alm = A(map); iter times: alm += A(map - S(alm)).  `fft` takes the forms with one FFT per ring
+        # and remembered tables (what libsharp does; equal to the explicit sums to rounding, tests/test_oracle_btgen.py)
+        ana = (lambda mp: _analysis_fft(mp, nside, lmax, polarised, ring_w)) if fft else \
+              (lambda mp: _analysis(mp, nside, lmax, polarised, ms, ring_w))
+        syn = _synthesis_fft if fft else _synthesis
+        coef = ana(m2)
         for _ in range(int(niter)):
-            res = m2 - _synthesis(coef, nside, lmax, polarised, P)
-            d = _analysis(res, nside, lmax, polarised, ms, ring_w)
+            res = m2 - syn(coef, nside, lmax, polarised, P)
+            d = ana(res)
             coef = {m: coef[m] + d[m] for m in coef}
         out = np.zeros((P, lside + 1, 2 * lside + 1), dtype=np.complex128)
         for m, c in coef.items():
@@ -524,7 +621,7 @@ def beam_transfer_m(tel, mlist=None):
             if tel.get("sht_iter", 0) or tel.get("sht_ring_weights") is not None:
                 rw = tel.get("sht_ring_weights")
                 t = transfer_single(maps, nside, lmax_bf, lside, pol, niter=int(tel.get("sht_iter", 0)),
-                                    ring_w=None if rw is None else rw.get(int(nside)))
+                                    ring_w=None if rw is None else rw.get(int(nside)), fft=bool(tel.get("sht_fft", False)))
             else:
                 t = transfer_single(maps, nside, lmax_bf, lside, pol, mabs=mlist, fft=bool(tel.get("sht_fft", False)))
             for m in mlist:

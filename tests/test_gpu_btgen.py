@@ -28,7 +28,7 @@ def _oracle_desc(t):
     return dict(polarised=t.num_pol_sky > 1, zenith=t.zenith, baselines=t.baselines, uniquepairs=t.uniquepairs,
                 beamclass=t.beamclass, wavelengths=t.wavelengths, cylinder_width=t.cylinder_width, fwhm_e=t.fwhm_e,
                 fwhm_h=t.fwhm_h, lmax=t.lmax, mmax=t.mmax, l_boost=t.l_boost, included_freq=t.included_freq,
-                included_baseline=t.included_baseline, accuracy_boost=t.accuracy_boost)
+                included_baseline=t.included_baseline, accuracy_boost=t.accuracy_boost, sht_iter=t.sht_iter, sht_fft=True)
 
 
 def test_beam_and_maps_kernels(ctx):
@@ -125,13 +125,13 @@ def test_sht_m_range_matches_full():
 @pytest.mark.parametrize("pol", [False, True])
 @pytest.mark.parametrize("niter", [0, 3])
 def test_beam_m_sht_iterations_and_ring_weights(ctx, pol, niter):
-    """healpy.map2alm's `iter` (Jacobi refinement through a synthesis + residual analysis on the device) and
-    per-ring weight factors: GPU == oracle.  These are the two settings of the reference's SHT (through cora)
-    that cannot be read in this image; the default (0, equal weights) is unchanged."""
+    """healpy.map2alm's `iter` (Jacobi refinement, carried out in harmonic space on the device) and per-ring weight
+    factors: GPU == oracle.  These are the two settings of the reference's SHT (through cora) that cannot be read in
+    this image; the defaults are healpy's documented ones (iter = 3, equal weights)."""
     from driftscan_amd import btgen
     from oracle import btgen as ob
 
-    t = _tel(pol)
+    t = _tel(pol, sht_iter=0)
     base = btgen.beam_m_all(t, ctx=ctx).cpu().numpy()
     rng = np.random.default_rng(5)
     weights = {}
@@ -156,7 +156,6 @@ def test_beam_m_sht_iterations_and_ring_weights(ctx, pol, niter):
             # an m-range is served from the same refined coefficients
             part = btgen.beam_m_all(t, ctx=ctx, m_range=(1, 2)).cpu().numpy()
             assert np.array_equal(part, bm[1:3])
-    t.sht_iter, t.sht_ring_weights = 0, None
 
 
 @pytest.mark.parametrize("pol", [False, True])

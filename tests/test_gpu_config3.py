@@ -88,7 +88,7 @@ def test_beam_m_columns_against_oracle(c3):
         desc = dict(polarised=True, zenith=tel.zenith, baselines=tel.baselines, uniquepairs=tel.uniquepairs,
                     beamclass=tel.beamclass, wavelengths=tel.wavelengths, cylinder_width=tel.cylinder_width,
                     fwhm_e=tel.fwhm_e, fwhm_h=tel.fwhm_h, lmax=tel.lmax, mmax=tel.mmax, l_boost=tel.l_boost,
-                    included_freq=np.array([fi]), included_baseline=np.array([bi]), accuracy_boost=tel.accuracy_boost)
+                    included_freq=np.array([fi]), included_baseline=np.array([bi]), accuracy_boost=tel.accuracy_boost, sht_iter=tel.sht_iter, sht_fft=True)
         ref = ob.beam_transfer_m(desc, mlist=MS)
         scale = max(np.abs(ref[m][fi, :, bi]).max() for m in MS)
         assert scale > 0
@@ -397,7 +397,7 @@ def test_config5_real_block(golden_dir, tmp_path):
         desc = dict(polarised=True, zenith=tel.zenith, baselines=tel.baselines, uniquepairs=tel.uniquepairs,
                     beamclass=tel.beamclass, wavelengths=tel.wavelengths, cylinder_width=tel.cylinder_width,
                     fwhm_e=tel.fwhm_e, fwhm_h=tel.fwhm_h, lmax=tel.lmax, mmax=tel.mmax, l_boost=tel.l_boost,
-                    included_freq=np.array([fi]), included_baseline=np.array([bi]), accuracy_boost=tel.accuracy_boost)
+                    included_freq=np.array([fi]), included_baseline=np.array([bi]), accuracy_boost=tel.accuracy_boost, sht_iter=tel.sht_iter, sht_fft=True)
         t0 = time.perf_counter()
         ref = ob.beam_transfer_m(desc, mlist=[m])[m][fi, :, bi]
         got = beam[0, fi, :, bi].cpu().numpy()

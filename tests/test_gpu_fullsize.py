@@ -46,7 +46,7 @@ def test_btgen_columns_against_oracle(step):
     desc = dict(polarised=False, zenith=tel.zenith, baselines=tel.baselines, uniquepairs=tel.uniquepairs,
                 beamclass=tel.beamclass, wavelengths=tel.wavelengths, cylinder_width=tel.cylinder_width,
                 fwhm_e=tel.fwhm_e, fwhm_h=tel.fwhm_h, lmax=tel.lmax, mmax=tel.mmax, l_boost=tel.l_boost,
-                included_freq=fsel, included_baseline=bsel, accuracy_boost=tel.accuracy_boost)
+                included_freq=fsel, included_baseline=bsel, accuracy_boost=tel.accuracy_boost, sht_iter=tel.sht_iter, sht_fft=True)
     ms = [0, 37, 90, tel.mmax]  # the last one lies above the natural band limit: an all-zero block
     ref = ob.beam_transfer_m(desc, mlist=ms)  # (F, 2, B, 1, L) per m, non-zero on the selected (f, b)
     got = beam_all.cpu().numpy()

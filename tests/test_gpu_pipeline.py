@@ -306,7 +306,7 @@ def test_product_manager_end_to_end(tmp_path):
     desc = dict(polarised=False, zenith=t.zenith, baselines=t.baselines, uniquepairs=t.uniquepairs,
                 beamclass=t.beamclass, wavelengths=t.wavelengths, cylinder_width=t.cylinder_width, fwhm_e=t.fwhm_e,
                 fwhm_h=t.fwhm_h, lmax=t.lmax, mmax=t.mmax, l_boost=t.l_boost, included_freq=t.included_freq,
-                included_baseline=t.included_baseline, accuracy_boost=t.accuracy_boost)
+                included_baseline=t.included_baseline, accuracy_boost=t.accuracy_boost, sht_iter=t.sht_iter, sht_fft=True)
     ms = [0, 5, t.mmax]
     ref_bm = ob.beam_transfer_m(desc, mlist=ms)
     noisew = bt._noisew()[:, : t.nbase]

@@ -78,7 +78,7 @@ def test_beams_and_maps_vs_reference(gold, ctx, name):
 def _oracle_desc(t, beam_fn=None):
     d = dict(polarised=t.num_pol_sky > 1, zenith=t.zenith, baselines=t.baselines, uniquepairs=t.uniquepairs,
              beamclass=t.beamclass, wavelengths=t.wavelengths, lmax=t.lmax, mmax=t.mmax, l_boost=t.l_boost,
-             included_freq=t.included_freq, included_baseline=t.included_baseline, accuracy_boost=t.accuracy_boost,
+             included_freq=t.included_freq, included_baseline=t.included_baseline, accuracy_boost=t.accuracy_boost, sht_iter=t.sht_iter, sht_fft=True,
              u_width=t.u_width, v_width=t.v_width)
     if beam_fn is not None:
         d["beam_fn"] = beam_fn

@@ -50,7 +50,7 @@ def test_btgen_columns(products):
     desc = dict(polarised=True, zenith=t.zenith, baselines=t.baselines, uniquepairs=t.uniquepairs,
                 beamclass=t.beamclass, wavelengths=t.wavelengths, cylinder_width=t.cylinder_width, fwhm_e=t.fwhm_e,
                 fwhm_h=t.fwhm_h, lmax=t.lmax, mmax=t.mmax, l_boost=t.l_boost, included_freq=fsel,
-                included_baseline=bsel, accuracy_boost=t.accuracy_boost)
+                included_baseline=bsel, accuracy_boost=t.accuracy_boost, sht_iter=t.sht_iter, sht_fft=True)
     ms = [0, 7, t.mmax // 2]
     ref = ob.beam_transfer_m(desc, mlist=ms)
     scale = max(np.abs(ref[0]).max(), 1e-300)
