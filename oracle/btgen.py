@@ -374,6 +374,13 @@ def ring_synth_fft(F, nside, ms):
     return maps
 
 
+def _rmat(tab, v):
+    """real table @ complex array without numpy promoting the table to complex: the product of the real and imaginary
+    parts in one real matmul.  tab (a, b) float64, v (b, k) complex128 -> (a, k) complex128."""
+    v = np.ascontiguousarray(v)
+    return (tab @ v.view(np.float64).reshape(v.shape[0], -1)).view(np.complex128)
+
+
 def _analysis_fft(maps, nside, lmax, polarised, ring_w=None):
     """`_analysis` for every m in -lmax..lmax with one FFT per ring and cached tables: {m: (P, lmax + 1 - |m|)}."""
     z, nphi, phi0, start = ring_info(nside)
@@ -386,14 +393,19 @@ def _analysis_fft(maps, nside, lmax, polarised, ring_w=None):
         am = abs(int(m))
         lam, W, X = ring_tables(nside, lmax, am, polarised)
         sgn = (-1.0) ** am if m < 0 else 1.0
-        g = G[mi] * wr[:, None]
+        g = G[mi] * wr[:, None]                          # (nring, P)
         c = np.zeros((g.shape[1], lmax + 1 - am), dtype=np.complex128)
-        c[0] = sgn * (lam @ g[:, 0])
         if polarised:
             sx = -sgn if m < 0 else 1.0
-            c[1] = sgn * (W @ g[:, 1]) - 1j * sx * (X @ g[:, 2])
-            c[2] = sgn * (W @ g[:, 2]) + 1j * sx * (X @ g[:, 1])
-            c[3] = sgn * (lam @ g[:, 3])
+            tv = _rmat(lam, g[:, [0, 3]])                # (L - am, 2): T and V
+            wq = _rmat(W, g[:, [1, 2]])                  # W g_Q, W g_U
+            xq = _rmat(X, g[:, [1, 2]])                  # X g_Q, X g_U
+            c[0] = sgn * tv[:, 0]
+            c[3] = sgn * tv[:, 1]
+            c[1] = sgn * wq[:, 0] - 1j * sx * xq[:, 1]
+            c[2] = sgn * wq[:, 1] + 1j * sx * xq[:, 0]
+        else:
+            c[0] = sgn * _rmat(lam, g[:, :1])[:, 0]
         out[int(m)] = c
     return out
 
@@ -404,16 +416,21 @@ def _synthesis_fft(coef, nside, lmax, polarised, npol):
     ms = np.array(sorted(coef))
     F = np.zeros((ms.size, nring, npol), dtype=np.complex128)
     for mi, m in enumerate(ms):
-        c = coef[int(m)]
+        c = coef[int(m)]                                  # (P, L - am)
         am = abs(int(m))
         lam, W, X = ring_tables(nside, lmax, am, polarised)
         sgn = (-1.0) ** am if m < 0 else 1.0
-        F[mi, :, 0] = sgn * (c[0] @ lam)
         if polarised:
             sx = -sgn if m < 0 else 1.0
-            F[mi, :, 1] = sgn * (c[1] @ W) - 1j * sx * (c[2] @ X)
-            F[mi, :, 2] = sgn * (c[2] @ W) + 1j * sx * (c[1] @ X)
-            F[mi, :, 3] = sgn * (c[3] @ lam)
+            tv = _rmat(lam.T, c[[0, 3]].T)               # (nring, 2)
+            we = _rmat(W.T, c[[1, 2]].T)                 # E W, B W
+            xe = _rmat(X.T, c[[1, 2]].T)                 # E X, B X
+            F[mi, :, 0] = sgn * tv[:, 0]
+            F[mi, :, 3] = sgn * tv[:, 1]
+            F[mi, :, 1] = sgn * we[:, 0] - 1j * sx * xe[:, 1]
+            F[mi, :, 2] = sgn * we[:, 1] + 1j * sx * xe[:, 0]
+        else:
+            F[mi, :, 0] = sgn * _rmat(lam.T, c[:1].T)[:, 0]
     return ring_synth_fft(F, nside, ms)                   # (npol, npix)
 
 
@@ -469,6 +486,100 @@ def _synthesis(coef, nside, lmax, polarised, npol):
             phi = phi0[r] + 2.0 * np.pi * np.arange(nphi[r]) / nphi[r]
             maps[:, start[r] : start[r] + nphi[r]] += F[:, r : r + 1] * np.exp(-1j * m * phi)[None, :]
     return maps
+
+
+def alias_limits(nside, lmax, polarised, eps=1e-13):
+    """Per north-cap ring i = 1, 2, ... the largest m whose ring functions still reach `eps` there (max over l <= lmax of
+    |lambda_lm|, |W_lm|, |X_lm|), for the rings where that m is at least 2 i — the rings on which two m of the band can
+    share a pixel-frequency bin (N = 4 i <= 2 mlim) with weights above eps.  Returns (mlim per alias ring, mcut)."""
+    z = ring_info(nside)[0]
+    mlim = []
+    for i in range(1, nside):
+        if 4 * i > 2 * lmax:
+            break
+        zi = z[i - 1 : i]
+        best = -1
+        for m in range(2 * i, lmax + 1):
+            peak = np.abs(lambda_lm(lmax, m, zi)).max()
+            if polarised:
+                W, X = wx_lm(lmax, m, zi)
+                peak = max(peak, np.abs(W).max(), np.abs(X).max())
+            if peak >= eps:
+                best = m
+            elif m > best + 3:
+                break
+        if best < 2 * i:
+            if i > len(mlim) + 8:
+                break
+            continue
+        mlim += [-1] * (i - 1 - len(mlim)) + [best]
+    return mlim, (max(mlim) if mlim else -1)
+
+
+def refine_harmonic(a0, nside, lmax, polarised, niter, ring_w=None, eps=None):
+    """healpy's refinement a <- a + A(map - S a) = a_0 + a - (A o S) a WITHOUT the map — the identity the device path
+    (dm_bt_columns_iter) is built on, restated for the CPU tests.  The ring DFT of a synthesised ring is
+    G_m'[r] = N_r sum_{m = m' mod N_r} e^{i (m' - m) phi0_r} F_m[r]: per m the Gram matrix of the ring functions under the
+    quadrature, plus the alias terms of the polar rings with N_r <= 2 lmax.  With `eps` the alias terms are restricted to
+    the rings and m of `alias_limits` (what the device does); None keeps all of them (exact).
+    a0: {m: (P, lmax + 1 - |m|)} from `_analysis`; returns the refined dictionary."""
+    z, nphi, phi0, start = ring_info(nside)
+    w = 4.0 * np.pi / (12 * nside**2)
+    wr = w * (np.ones(z.size) if ring_w is None else np.asarray(ring_w, dtype=np.float64))
+    P = 4 if polarised else 1
+    nring = z.size
+    cull = None
+    if eps is not None:
+        ml, _ = alias_limits(nside, lmax, polarised, eps)
+        cull = np.full(nring, -1)
+        cull[: len(ml)] = ml
+        cull[nring - len(ml) :] = ml[::-1]
+
+    def synth(c, m):      # F_m[r], (P, nring)
+        am = abs(m)
+        lam, W, X = ring_tables(nside, lmax, am, polarised)
+        sgn = (-1.0) ** am if m < 0 else 1.0
+        F = np.zeros((P, nring), dtype=np.complex128)
+        F[0] = sgn * (c[0] @ lam)
+        if polarised:
+            sx = -sgn if m < 0 else 1.0
+            F[1] = sgn * (c[1] @ W) - 1j * sx * (c[2] @ X)
+            F[2] = sgn * (c[2] @ W) + 1j * sx * (c[1] @ X)
+            F[3] = sgn * (c[3] @ lam)
+        return F
+
+    def ana(g, m):        # g (P, nring) -> (P, L - |m|)
+        am = abs(m)
+        lam, W, X = ring_tables(nside, lmax, am, polarised)
+        sgn = (-1.0) ** am if m < 0 else 1.0
+        g = g * wr
+        c = np.zeros((P, lmax + 1 - am), dtype=np.complex128)
+        c[0] = sgn * (lam @ g[0])
+        if polarised:
+            sx = -sgn if m < 0 else 1.0
+            c[1] = sgn * (W @ g[1]) - 1j * sx * (X @ g[2])
+            c[2] = sgn * (W @ g[2]) + 1j * sx * (X @ g[1])
+            c[3] = sgn * (lam @ g[3])
+        return c
+
+    a = {m: c.copy() for m, c in a0.items()}
+    for _ in range(int(niter)):
+        F = {m: synth(a[m], m) for m in a}
+        new = {}
+        for mp in a:
+            G = F[mp] * nphi                                      # the k = 0 term on every ring: the Gram matrix
+            for r in np.nonzero(nphi <= 2 * lmax)[0]:             # rings that can alias
+                N = int(nphi[r])
+                lim = lmax if cull is None else min(int(cull[r]), lmax)
+                if abs(mp) > lim:
+                    continue
+                for k in range(int(np.ceil((mp - lim) / N)), int(np.floor((mp + lim) / N)) + 1):
+                    if k:
+                        m = mp - k * N
+                        G[:, r] += N * np.exp(1j * (mp - m) * phi0[r]) * F[m][:, r]
+            new[mp] = a0[mp] + a[mp] - ana(G, mp)
+        a = new
+    return a
 
 
 def transfer_single(maps, nside, lmax, lside, polarised, mabs=None, niter=0, ring_w=None, fft=False):

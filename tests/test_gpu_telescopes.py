@@ -148,12 +148,17 @@ def test_focalplane_beam_m(ctx):
 
     t = focalplane.FocalPlaneArray.from_config(dict(num_freq=2, freq_start=400.0, freq_end=450.0, beam_num_u=2,
                                                     beam_num_v=1, beam_spacing_u=20.0, beam_size=20.0, beam_pivot=400.0,
-                                                    auto_correlations=True, force_lmax=40, force_mmax=40))
+                                                    auto_correlations=True, force_lmax=40, force_mmax=40, sht_iter=0))
     assert t.nbase == 2
     bm = btgen.beam_m_all(t, ctx=ctx).cpu().numpy()
-    # integral of (beam^2 / Omega) dOmega = 1  ->  a_00 = 1 / sqrt(4 pi)
+    # integral of (beam^2 / Omega) dOmega = 1  ->  a_00 = 1 / sqrt(4 pi): exact for the plain quadrature (sht_iter = 0:
+    # Omega is the same pixel sum), and within the quadrature error of the map once healpy's refinement runs
     a00 = bm[0, :, 0, :, 0, 0]
     assert np.abs(a00 - 1.0 / np.sqrt(4 * np.pi)).max() < 1e-12
+    t.sht_iter = 3
+    a00r = btgen.beam_m_all(t, ctx=ctx).cpu().numpy()[0, :, 0, :, 0, 0]
+    assert 1e-7 < np.abs(a00r - 1.0 / np.sqrt(4 * np.pi)).max() < 1e-3
+    t.sht_iter = 0
     assert np.abs(bm[0, :, 0, :, 0, 0].imag).max() < 1e-14
     # the two beams point 20 degrees apart in azimuth: same |a_lm|, phases differ by exp(-i m dphi)
     m = 3

@@ -208,3 +208,90 @@ def test_ring_dft_by_fft_matches_the_explicit_sum():
     t0 = ob.transfer_single(maps, nside, lmax, lmax, True)
     t1 = ob.transfer_single(maps, nside, lmax, lmax, True, fft=True)
     assert np.abs(t0 - t1).max() <= 1e-12 * np.abs(t0).max()
+
+
+def test_refinement_fft_forms_match_the_explicit_ones():
+    """The map-space refinement with one FFT per ring and remembered tables (what the GPU tests at nside 128 - 512 can
+    afford) against the explicit pixel sums, with polar rings that alias (N = 4 i <= 2 lmax) and ring weights."""
+    from oracle import btgen as ob
+
+    rng = np.random.default_rng(21)
+    for nside, lmax in ((8, 11), (16, 23)):
+        rw = 1.0 + 1e-3 * rng.standard_normal(4 * nside - 1)
+        for pol in (False, True):
+            P = 4 if pol else 1
+            maps = rng.standard_normal((P, 12 * nside**2)) + 1j * rng.standard_normal((P, 12 * nside**2))
+            mp = maps if pol else maps[0]
+            for it, w in ((1, None), (3, rw)):
+                a = ob.transfer_single(mp, nside, lmax, lmax + 2, pol, niter=it, ring_w=w)
+                b = ob.transfer_single(mp, nside, lmax, lmax + 2, pol, niter=it, ring_w=w, fft=True)
+                assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max(), (nside, pol, it)
+    ob.clear_tables()
+
+
+def test_refinement_in_harmonic_space_is_the_map_space_one():
+    """a <- a_0 + a - (A o S) a with A o S formed from the ring functions alone (Gram matrix per m + the alias terms of the
+    polar rings) equals healpy's residual-map iteration: the identity behind dm_bt_columns_iter.  Restricting the alias
+    terms to `alias_limits(eps)` changes the result by ~1e-3 eps."""
+    from oracle import btgen as ob
+
+    rng = np.random.default_rng(22)
+    nside, lmax = 16, 23
+    rw = 1.0 + 1e-3 * rng.standard_normal(4 * nside - 1)
+    for pol in (False, True):
+        P = 4 if pol else 1
+        maps = rng.standard_normal((P, 12 * nside**2)) + 1j * rng.standard_normal((P, 12 * nside**2))
+        ms = np.arange(-lmax, lmax + 1)
+        for w in (None, rw):
+            a0 = ob._analysis(maps, nside, lmax, pol, ms, w)
+            ref = ob.transfer_single(maps if pol else maps[0], nside, lmax, lmax, pol, niter=3, ring_w=np.ones(4 * nside - 1) if w is None else w)
+            scale = np.abs(ref).max()
+            for eps, tol in ((None, 1e-13), (1e-13, 1e-13), (1e-6, 1e-7)):
+                a = ob.refine_harmonic(a0, nside, lmax, pol, 3, ring_w=w, eps=eps)
+                err = max(np.abs(ref[:, abs(m):, m if m >= 0 else 2 * lmax + 1 + m] - c).max() for m, c in a.items())
+                assert err <= tol * scale, (pol, eps, err / scale)
+    # without any alias term the iteration is visibly different: the polar rings matter
+    none = ob.refine_harmonic(a0, nside, lmax, pol, 3, ring_w=rw, eps=1e300)
+    err = max(np.abs(ref[:, abs(m):, m if m >= 0 else 2 * lmax + 1 + m] - c).max() for m, c in none.items())
+    assert err > 1e-6 * scale
+    ob.clear_tables()
+
+
+def test_sht_iter_bracket_on_testparams(golden_dir):
+    """What healpy's `iter` moves on the reference's own test telescope (tests/testparams.yaml): six (f, b) columns,
+    iter = 0 (plain equal-weight quadrature) against iter = 3 (healpy's documented default, the default here), at the
+    m-blocks 0, 14 (the block tests/test_functional.py:175-186 pins at approx(rel=1e-4, abs=1e-8)) and 40.  The beams are
+    horizon-cut, not band-limited: the refinement is not a no-op, and the two settings are not interchangeable."""
+    import os
+
+    import yaml
+
+    from driftscan_amd import cylinder
+    from oracle import btgen as ob
+
+    conf = yaml.safe_load(open(os.path.join(golden_dir, "testparams.yaml")))
+    cfg = dict(conf["telescope"])
+    cfg.pop("type", None)
+    t = cylinder.PolarisedCylinderTelescope.from_config(cfg)
+    assert t.sht_iter == 3                      # healpy's documented default
+    fsel, bsel = np.array([0, t.nfreq - 1]), np.array([0, t.nbase // 2, t.nbase - 1])
+    desc = dict(polarised=True, zenith=t.zenith, baselines=t.baselines, uniquepairs=t.uniquepairs,
+                beamclass=t.beamclass, wavelengths=t.wavelengths, cylinder_width=t.cylinder_width, fwhm_e=t.fwhm_e,
+                fwhm_h=t.fwhm_h, lmax=t.lmax, mmax=t.mmax, l_boost=t.l_boost, included_freq=fsel,
+                included_baseline=bsel, accuracy_boost=t.accuracy_boost, sht_fft=True)
+    ms = [0, 14, 40]
+    b0 = ob.beam_transfer_m(dict(desc, sht_iter=0), mlist=ms)
+    b3 = ob.beam_transfer_m(dict(desc, sht_iter=3), mlist=ms)
+    moved = {}
+    for m in ms:
+        x0, x3 = b0[m][fsel][:, :, bsel], b3[m][fsel][:, :, bsel]
+        scale = np.abs(x3).max()
+        diff = np.abs(x0 - x3)
+        nz = np.abs(x3) > 0
+        outside = (diff > 1e-8 + 1e-4 * np.abs(x3))[nz].mean()
+        moved[m] = diff.max() / scale
+        print("testparams m = %d: max |beam_m(iter 0) - beam_m(iter 3)| = %.2e of the block scale, %.1f %% of the entries "
+              "outside approx(rel=1e-4, abs=1e-8)" % (m, moved[m], 100 * outside))
+        assert outside > 0.05
+    assert moved[0] > 1e-3 and moved[14] > 1e-5 and moved[40] > 1e-5
+    ob.clear_tables()
