@@ -45,6 +45,8 @@ FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (AMD datasheet; BASELINE
 HBM_PEAK_GBS = 8000.0         # HBM3E spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 achievable)
 HBM_CLASSES = ("trd_symv", "trd_wx")
 VALU_CLASSES = ("sb_panel_qr", "sb_chase", "sb_q2_apply")   # fp64 vector kernels of the two-stage tridiagonalisation
+# every remaining kernel of the path, bracketed at profiling level 2 only (time, no work counter)
+EXT_CLASSES = ("bt_ring", "bt_other", "trd_small", "dc", "chol_solve", "util", "eig_other", "svd_other")
 
 
 def build_id():
@@ -83,6 +85,11 @@ def parse_args(argv=None):
                     help="gloo + --one-gpu rehearses the multi-rank path on a single card (RCCL refuses two ranks per GPU)")
     ap.add_argument("--one-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal on a one-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-north-star", action="store_true",
+                    help="skip the north-star leg of the default line (one rank's share of the configs[2] job through "
+                         "ProductManager.generate() after the timed configs[1] region; rank 0 at --gpus 1 only)")
+    ap.add_argument("--north-star-share", default=os.environ.get("DRIFT_BENCH_NS_SHARE", "0/8"),
+                    help="which share the north-star leg runs (r/N of the configs[2] job)")
     ap.add_argument("--all-modes", action="store_true",
                     help="form every KL mode (subset = False) instead of only the ones transform_save keeps")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DRIFT_BENCH_STREAMS", "1")),
@@ -232,7 +239,10 @@ def cpu_baseline(tel, bt, kl, blocks):
     except Exception as e:  # the baseline is reporting only: never lose the bench line over it
         wk = dict(error=repr(e), m_blocks_per_s=0.0)
     best = "workers" if wk["m_blocks_per_s"] > thr["m_blocks_per_s"] else "threaded"
-    return dict(value=max(wk["m_blocks_per_s"], thr["m_blocks_per_s"]), unit="m-blocks/s", cores=ncores, kind="port",
+    return dict(value=max(wk["m_blocks_per_s"], thr["m_blocks_per_s"]),
+                unit="m-blocks/s" + (" (EXTRAPOLATED: per-core rate of %d single-threaded worker processes x %d cores)"
+                                     % (wk.get("processes", 0), ncores) if best == "workers" else ""),
+                extrapolated=best == "workers", cores=ncores, kind="port",
                 mode=best, threaded=thr, workers=wk, sample_m=ms, sample_ndof=ndofs,
                 sample="oracle (numpy %s / scipy %s) on the real configs[1] blocks m = %s copied back from the device: SVD "
                        "chain + covariance projections + KL per block, BT-gen (pixel kernels, one FFT per ring, Legendre matrix "
@@ -390,98 +400,171 @@ CFG3 = dict(num_freq=64, freq_start=400.0, freq_end=500.0, freq_mode="edge", num
             num_feeds=16, feed_spacing=0.4, tsys=1.0, force_lmax=512, force_mmax=512)
 
 
-def run_share(args):
+def class_table(pr, steps=1.0):
+    """Per-class figures of a dm_prof_report: ms, launches, algorithmic rate and the fraction of the peak that bounds the
+    class (fp64 MFMA / VALU 78.6 TFLOP/s, HBM 8 TB/s); the extended classes carry time only."""
+    out = {}
+    for k, v in pr.items():
+        hbm = k in HBM_CLASSES
+        rate = (v["flops"] / (v["ms"] * 1e-3) / (1e9 if hbm else 1e12)) if (v["ms"] > 0 and v["flops"] > 0) else None
+        out[k] = dict(ms_per_step=v["ms"] / steps, launches_per_step=v["launches"] / steps, rate=rate,
+                      unit="GB/s" if hbm else "TFLOP/s",
+                      frac=None if rate is None else rate / (HBM_PEAK_GBS if hbm else FP64_MFMA_PEAK_TFLOPS))
+    return out
+
+
+def measure_share(workload, share, files=False, share_mmax=None):
     """BASELINE configs[2] / configs[3] — the north-star job — through ProductManager.generate(): rank r of N is
     emulated in this process (`parallel.set_virtual`: its contiguous, cost-balanced range of m; no process group), so
-    the share's wall time is the N-GPU job's (m-blocks are independent, the only collective is the all-reduce of the
-    Fisher matrix at the very end).  Without --files the products stay in HBM (DRIFTMI_STORAGE=discard); with --files
-    they go through the writer pool to a temporary directory and the difference is the file output."""
+    the share's wall time is that rank's part of the N-GPU job (m-blocks are independent, the only collective is the
+    all-reduce of the Fisher matrix at the very end); rank 0 holds the lowest m — the largest matrices and the m the polar
+    rings of the SHT refinement couple — and is the slowest share.  Without `files` the products stay in HBM
+    (DRIFTMI_STORAGE=discard); with it they go through the writer pool to a temporary directory."""
     import tempfile
 
-    import numpy as np
     import torch
     import yaml
 
-    r, n = (int(x) for x in args.share.split("/"))
-    if not args.files:
+    r, n = (int(x) for x in share.split("/"))
+    if not files:
         os.environ["DRIFTMI_STORAGE"] = "discard"
     os.environ.setdefault("DRIFTMI_WORKSPACE_GB", "80")
     from driftscan_amd import device, manager, parallel
 
     parallel.set_virtual(r, n)
-    tcfg = dict(CFG3, type="PolarisedCylinder")
-    if args.share_mmax:   # rehearsal of the mode on a toy telescope (tests, CPU-sized boxes)
-        tcfg = dict(type="PolarisedCylinder", num_freq=4, freq_start=400.0, freq_end=440.0, freq_mode="edge", num_cylinders=2,
-                    cylinder_width=2.0, num_feeds=4, feed_spacing=0.4, tsys=1.0)
-    kls = [dict(type="KLTransform", name="kl", threshold=0.1)]
-    conf = dict(config=dict(beamtransfers=True, kltransform=True, psfisher=False, truncate=False,
-                            beam_chunk_gb=float(os.environ.get("DRIFT_BENCH_BEAM_GB", "125")),
-                            device_chunk_gb=float(os.environ.get("DRIFT_BENCH_BT_GB", "48")),
-                            svd_chunk_gb=float(os.environ.get("DRIFT_BENCH_SVD_GB", "48")), keep_products_gb=0.0),
-                telescope=tcfg, kltransform=kls)
-    if args.workload == "configs3":
-        kls.append(dict(type="DoubleKL", name="dk", threshold=0.1, foreground_threshold=100.0))
-        conf["config"]["psfisher"] = True
-        conf["psfisher"] = [dict(type="Full", name="ps", klname="kl", threshold=0.1, bandtype="polar", num_theta=3,
-                                 k_bands=[dict(spacing="linear", start=0.0, stop=0.25, num=4)])]
-    ctx = device.get_context(workspace_bytes=int(os.environ["DRIFTMI_WORKSPACE_GB"]) << 30)
-    with tempfile.TemporaryDirectory() as tmp:
-        conf["config"]["output_directory"] = os.path.join(tmp, "prod")
-        cfile = os.path.join(tmp, "params.yaml")
-        with open(cfile, "w") as fh:
-            yaml.dump(conf, fh)
-        pm = manager.ProductManager.from_config(cfile)
-        tel, bt = pm.telescope, pm.beamtransfer
-        mine = bt._my_ms()
-        # the host-side C_l(nu, nu') tables are made once per job (cora's models in the reference): untimed
-        t0 = time.perf_counter()
-        for kl in pm.kltransforms.values():
-            kl.signal(); kl.foreground()
-        t_cl = time.perf_counter() - t0
-        ctx.prof_reset(True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        pm.generate()
-        ctx.sync()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        pr = ctx.prof_report()
-        nbytes = 0
-        if args.files:
-            for root, _, files in os.walk(conf["config"]["output_directory"]):
-                nbytes += sum(os.path.getsize(os.path.join(root, f)) for f in files)
-        nm = tel.mmax + 1
-        line = {
-            "metric": "m-blocks/sec (BT-gen + SVD + KL)",
-            "value": len(mine) / dt,
-            "unit": "m-blocks/s",
-            "n_gpus": 1, "steps": 1, "warmup": 0,
-            "ms_per_step": 1e3 * dt,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: share %d/%d of the %s job (nfreq=%d, nbase=%d, lmax=mmax=%d) "
-                                   "through ProductManager.generate(): m = %d..%d (%d of %d m-blocks), %s%s"
-                                   % ("configs[2]" if args.workload == "configs2" else "configs[3]", r, n,
-                                      "toy-telescope REHEARSAL" if args.share_mmax else "128-feed polarised cylinder", tel.nfreq,
-                                      tel.nbase, tel.lmax,
-                                      mine[0], mine[-1], len(mine), nm, "KLTransform" if args.workload == "configs2"
-                                      else "KLTransform + DoubleKL + PSExact (9 polar bands)",
-                                      ", product files written" if args.files else ", products left in HBM (no files)"),
-                       "nfreq": tel.nfreq, "nbase": tel.nbase, "lmax": tel.lmax, "mmax": tel.mmax, "share": args.share,
-                       "files": bool(args.files)},
-            "share_s": dt,
-            "projected_job_s": dt,
-            "projected_job_note": "m-blocks are independent and rank %d of %d has the most expensive range (lowest m): its "
-                                  "share is the wall time of the %d-GPU job; C_l tables %.1f s (host, once per job) not included"
-                                  % (r, n, n, t_cl),
-            "job_m_blocks_per_s": nm / dt,
-            "file_bytes": nbytes,
-            "kernels_ms": {k: v["ms"] for k, v in pr.items()},
-            "hbm_peak_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
-            "roofline": None, "cpu_baseline": None,
-        }
-        print(json.dumps(line))
-        sys.stdout.flush()
+    try:
+        tcfg = dict(CFG3, type="PolarisedCylinder")
+        if share_mmax:   # rehearsal of the mode on a toy telescope (tests, CPU-sized boxes)
+            tcfg = dict(type="PolarisedCylinder", num_freq=4, freq_start=400.0, freq_end=440.0, freq_mode="edge", num_cylinders=2,
+                        cylinder_width=2.0, num_feeds=4, feed_spacing=0.4, tsys=1.0)
+        kls = [dict(type="KLTransform", name="kl", threshold=0.1)]
+        conf = dict(config=dict(beamtransfers=True, kltransform=True, psfisher=False, truncate=False,
+                                beam_chunk_gb=float(os.environ.get("DRIFT_BENCH_BEAM_GB", "125")),
+                                device_chunk_gb=float(os.environ.get("DRIFT_BENCH_BT_GB", "48")),
+                                svd_chunk_gb=float(os.environ.get("DRIFT_BENCH_SVD_GB", "48")), keep_products_gb=0.0),
+                    telescope=tcfg, kltransform=kls)
+        if workload == "configs3":
+            kls.append(dict(type="DoubleKL", name="dk", threshold=0.1, foreground_threshold=100.0))
+            conf["config"]["psfisher"] = True
+            conf["psfisher"] = [dict(type="Full", name="ps", klname="kl", threshold=0.1, bandtype="polar", num_theta=3,
+                                     k_bands=[dict(spacing="linear", start=0.0, stop=0.25, num=4)])]
+        ctx = device.get_context(workspace_bytes=int(os.environ["DRIFTMI_WORKSPACE_GB"]) << 30)
+        with tempfile.TemporaryDirectory() as tmp:
+            conf["config"]["output_directory"] = os.path.join(tmp, "prod")
+            cfile = os.path.join(tmp, "params.yaml")
+            with open(cfile, "w") as fh:
+                yaml.dump(conf, fh)
+            pm = manager.ProductManager.from_config(cfile)
+            tel, bt = pm.telescope, pm.beamtransfer
+            mine = bt._my_ms()
+            # the host-side C_l(nu, nu') tables are made once per job (cora's models in the reference): untimed
+            t0 = time.perf_counter()
+            for kl in pm.kltransforms.values():
+                kl.signal(); kl.foreground()
+            t_cl = time.perf_counter() - t0
+            ctx.prof_reset(2)      # every kernel class of the path
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pm.generate()
+            ctx.sync()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            pr = ctx.prof_report()
+            nbytes = 0
+            if files:
+                for root, _, fl in os.walk(conf["config"]["output_directory"]):
+                    nbytes += sum(os.path.getsize(os.path.join(root, f)) for f in fl)
+            nm = tel.mmax + 1
+            classes = class_table(pr)
+            kern_s = sum(v["ms"] for v in pr.values()) * 1e-3
+            cov = pr.get("zgemm_cov")
+            name = "configs[2]" if workload == "configs2" else "configs[3]"
+            line = {
+                "metric": "m-blocks/sec (BT-gen + SVD + KL)",
+                "value": len(mine) / dt,
+                "unit": "m-blocks/s",
+                "n_gpus": 1, "steps": 1, "warmup": 0,
+                "ms_per_step": 1e3 * dt,
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "%s: share %d/%d of the %s job (nfreq=%d, nbase=%d, lmax=mmax=%d) "
+                                       "through ProductManager.generate(): m = %d..%d (%d of %d m-blocks), %s%s"
+                                       % (name, r, n,
+                                          "toy-telescope REHEARSAL" if share_mmax else "128-feed polarised cylinder", tel.nfreq,
+                                          tel.nbase, tel.lmax,
+                                          mine[0], mine[-1], len(mine), nm, "KLTransform" if workload == "configs2"
+                                          else "KLTransform + DoubleKL + PSExact (9 polar bands)",
+                                          ", product files written" if files else ", products left in HBM (no files)"),
+                           "nfreq": tel.nfreq, "nbase": tel.nbase, "lmax": tel.lmax, "mmax": tel.mmax, "share": share,
+                           "sht_iter": int(tel.sht_iter), "files": bool(files)},
+                "share_s": dt,
+                "share_note": "wall time of rank %d of %d for m = %d..%d; the job's wall time is the MAX over the N shares "
+                              "(m-blocks are independent, no data-path collective); rank 0 — lowest m, largest matrices, the m "
+                              "coupled by the polar rings of the SHT refinement — is the slowest share of the cost-balanced "
+                              "partition.  C_l tables %.1f s (host, once per job) not included" % (r, n, mine[0], mine[-1], t_cl),
+                "projected_job_s": dt if r == 0 else None,
+                "job_m_blocks_per_s": (nm / dt) if r == 0 else None,
+                "file_bytes": nbytes,
+                "kernels_ms": {k: v["ms"] for k, v in pr.items()},
+                "classes": classes,
+                "kernel_s": kern_s,
+                "kernel_coverage_of_wall": kern_s / dt,
+                "zgemm_cov": None if cov is None else dict(
+                    ms=cov["ms"], flop=cov["flops"], launches=cov["launches"],
+                    tflops=cov["flops"] / (cov["ms"] * 1e-3) / 1e12 if cov["ms"] > 0 else None,
+                    frac=cov["flops"] / (cov["ms"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS if cov["ms"] > 0 else None,
+                    note="the covariance projections (B_f o C_l) B_f'^H of the KL stage (gathered-B grouped ZGEMM), "
+                         "8 M N K flops per product over the HIP-event time of its launches"),
+                "hbm_peak_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+                "roofline": None, "cpu_baseline": None,
+            }
+            del pm
+            return line
+    finally:
+        parallel.set_virtual(None)
+
+
+def run_share(args):
+    line = measure_share(args.workload, args.share, files=args.files, share_mmax=args.share_mmax)
+    print(json.dumps(line))
+    sys.stdout.flush()
     return 0
+
+
+def north_star_leg(args):
+    """The north-star workload inside the default line: one rank's share (default 0/8: the slowest) of the BASELINE
+    configs[2] job through ProductManager.generate(), with every kernel class timed.  Runs after the timed configs[1]
+    region, on rank 0 at --gpus 1 only."""
+    import gc
+
+    import torch
+
+    from driftscan_amd import beamtransfer, device
+
+    beamtransfer.BeamTransfer._clcache.clear()
+    device.reset_context()
+    gc.collect()
+    torch.cuda.empty_cache()
+    t0 = time.perf_counter()
+    # a child process (started, not exec'ed into: this process keeps its HIP context): a failure of the leg — the share
+    # holds ~150 GB of HBM — must not cost the configs[1] line
+    try:
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "configs2", "--share",
+                              args.north_star_share], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        if res.returncode != 0:
+            return dict(error="north-star leg exited with %d: %s" % (res.returncode, res.stderr.decode()[-400:]))
+        sh = json.loads(res.stdout.decode().strip().splitlines()[-1])
+    except Exception as e:   # reporting only
+        return dict(error=repr(e))
+    keep = ("share_s", "share_note", "projected_job_s", "job_m_blocks_per_s", "classes", "kernel_s",
+            "kernel_coverage_of_wall", "zgemm_cov", "hbm_peak_gb")
+    out = {k: sh[k] for k in keep}
+    out["workload"] = sh["config"]["workload"]
+    out["share"] = args.north_star_share
+    out["sht_iter"] = sh["config"]["sht_iter"]
+    out["m_blocks"] = sh["value"] * sh["share_s"]
+    out["leg_wall_s"] = time.perf_counter() - t0
+    out["target"] = "full configs[2] product set in under 600 s on 8 x MI355X; covariance GEMMs at >= 0.5 of the fp64 MFMA peak"
+    return out
 
 
 def main():
@@ -574,11 +657,39 @@ def main():
         # The per-stage wall times (`stage_ms`, `stages`) come from a few UNTIMED passes after the timed region: they need
         # a wait after BT-gen that the pipeline itself does not have (the host prepares the SVD stage while the GPU still
         # transforms), so their sum is a little above ms_per_step.
+        # ... and they run at profiling level 2: every remaining kernel of the path is bracketed too (the "extended"
+        # classes; their ~200 extra event pairs per step are kept out of the timed region)
+        nstage = min(args.steps, 3)
         for c in list(device._all):
-            c.prof_reset(os.environ.get("DRIFT_BENCH_NOPROF") != "1")   # same instrumentation as the timed passes (discarded)
-        for _ in range(min(args.steps, 3)):
+            c.prof_reset(2 if os.environ.get("DRIFT_BENCH_NOPROF") != "1" else 0)
+        for _ in range(nstage):
             hot_path_step(tel, bt, kl, ctx, stage_times=stage, streams=args.streams, m_range=m_range, collect=collect)
         torch.cuda.synchronize()
+        ext = {}
+        for c in list(device._all):
+            for k, v in c.prof_report().items():
+                if k in EXT_CLASSES:
+                    a = ext.setdefault(k, dict(ms=0.0, flops=0.0, launches=0))
+                    a["ms"] += v["ms"]; a["flops"] += v["flops"]; a["launches"] += v["launches"]
+        # BT-gen alone at both readings of the reference's SHT: plain quadrature (healpy iter = 0) and healpy's documented
+        # default iter = 3 (the telescope's default, what the timed region ran)
+        bt_ms = {}
+        if rank == 0:
+            from driftscan_amd import btgen as _btgen
+
+            it_keep = tel.sht_iter
+            for it in (0, 3):
+                tel.sht_iter = it
+                ts = []
+                for _ in range(4):
+                    ctx.sync(); torch.cuda.synchronize()
+                    tb0 = time.perf_counter()
+                    _bm = _btgen.beam_m_all(tel, ctx=ctx, m_range=m_range)
+                    ctx.sync(); torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - tb0)
+                    del _bm
+                bt_ms[it] = 1e3 * min(ts[1:])
+            tel.sht_iter = it_keep
         parallel.barrier()
         if world > 1 or force_dist:
             import torch.distributed as dist
@@ -656,11 +767,12 @@ def main():
                         roofline["pipe"] = ("fp64 VALU (the kernel issues no MFMA; on MI355X the fp64 vector peak equals the "
                                             "fp64 matrix peak, 78.6 TFLOP/s)")
                 roofline["build_id"] = build_id()
-                # every instrumented class, so that the cross-checks (sum of kernel time <= wall time) can be made
-                roofline["classes"] = {k: dict(ms_per_step=v["ms"] / args.steps, launches_per_step=v["launches"] / args.steps,
-                                               rate=(v["flops"] / (v["ms"] * 1e-3) / (1e9 if k in HBM_CLASSES else 1e12)
-                                                     if v["ms"] > 0 else None),
-                                               unit="GB/s" if k in HBM_CLASSES else "TFLOP/s") for k, v in prof.items()}
+                # every instrumented class, so that the cross-checks (sum of kernel time <= wall time) can be made; the
+                # extended classes come from the untimed stage passes (profiling level 2)
+                roofline["classes"] = class_table(prof, args.steps)
+                roofline["classes"].update({k: dict(v, source="untimed stage passes (profiling level 2)")
+                                            for k, v in class_table(ext, nstage).items()})
+                roofline["classes_ms_sum"] = sum(v["ms_per_step"] for v in roofline["classes"].values())
                 # the runner-up class of the other kind, for context (MFMA vs HBM side of the step)
                 others = [k for k in prof if (k in HBM_CLASSES) != (dom in HBM_CLASSES)]
                 if others:
@@ -707,6 +819,9 @@ def main():
                                        + ("129 m-blocks split over the ranks in cost-balanced contiguous m-ranges"
                                           if sharded else "129 m-blocks per GPU per step") + ", KLTransform with foregrounds",
                            "nfreq": 16, "nbase": 46, "lmax": 128, "mmax": 128,
+                           "sht_iter": int(tel.sht_iter),
+                           "sht_note": "healpy.map2alm `iter` of the reference's SHT (through cora, not readable here): healpy's "
+                                       "documented default 3, refined in harmonic space on the device; `btgen` carries both readings",
                            "sharding": "m-ranges, one job" if sharded else "m-blocks, one full workload per GPU",
                            "mode": args.mode, "ranks": world, "backend": args.backend if world > 1 else None,
                            "collectives_in_timed_region": "gather of sigma/lambda spectra + all-reduce of a 9x9 band matrix"
@@ -716,11 +831,18 @@ def main():
                            "all eigenvalues + the modes with S/N >= threshold (subset = True, what transform_save writes)"},
                 "stage_ms": {"btgen": 1e3 * st[0], "svd": 1e3 * st[1], "kl": 1e3 * st[2], "collectives": 1e3 * st[3]},
                 "stages": stages,
+                "btgen": {"btgen_iter0_ms": bt_ms.get(0), "btgen_iter3_ms": bt_ms.get(3),
+                          "ratio": (bt_ms[3] / bt_ms[0]) if bt_ms.get(0) else None,
+                          "note": "BT-gen of the step alone (all blocks of the rank, best of 3 after one warm-up call) with the "
+                                  "plain equal-weight quadrature (iter 0) and with healpy's default three refinements (iter 3)"},
                 # the two tridiagonalisation classes are timed on every 8th launch: scaled back to all launches
                 "kernels_ms": {k: v["ms"] / args.steps for k, v in prof.items()},
                 "roofline": roofline,
                 "cpu_baseline": cpu,
             }
+            if world == 1 and not force_dist and not args.no_north_star and args.streams == 1 and not args.all_modes:
+                del tel, bt, kl
+                line["north_star"] = north_star_leg(args)
             print(json.dumps(line))
             sys.stdout.flush()
     if world > 1 or force_dist:

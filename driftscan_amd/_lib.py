@@ -624,17 +624,23 @@ Context.bt_sht = _bt_sht
 
 PROF_CLASSES = ["zgemm_grouped", "gemm_grouped_realB", "jac_gram", "jac_inner", "jac_apply", "dgemm_grouped",
                 "trd_symv", "trd_wx",  # these two report algorithmic BYTES in the "flops" field (HBM-bound kernels)
-                "sb_panel_qr", "sb_chase", "sb_q2_apply", "unused"]  # two-stage tridiagonalisation (fp64 VALU)
+                "sb_panel_qr", "sb_chase", "sb_q2_apply",   # two-stage tridiagonalisation (fp64 VALU)
+                "zgemm_cov",                                  # gathered-B ZGEMM: the covariance projections
+                # extended classes (profiling level 2, time only)
+                "bt_ring", "bt_other", "trd_small", "dc", "chol_solve", "util", "eig_other", "svd_other",
+                "unused20", "unused21", "unused22", "unused23"]
+PROF_NCLASS = len(PROF_CLASSES)
 
 
 def _prof_reset(self, enable=True):
+    """enable: False / True (the MFMA and HBM-bound classes) / 2 (every kernel of the path: the extended classes too)."""
     self.check(self.lib.dm_prof_reset(self.h, int(enable)), "dm_prof_reset")
 
 
 def _prof_report(self):
-    ms = (c_dbl * 12)()
-    fl = (c_dbl * 12)()
-    ln = (ctypes.c_longlong * 12)()
+    ms = (c_dbl * PROF_NCLASS)()
+    fl = (c_dbl * PROF_NCLASS)()
+    ln = (ctypes.c_longlong * PROF_NCLASS)()
     self.check(self.lib.dm_prof_report(self.h, ms, fl, ln), "dm_prof_report")
     return {name: dict(ms=ms[i], flops=fl[i], launches=int(ln[i])) for i, name in enumerate(PROF_CLASSES) if ln[i] > 0}
 

@@ -1221,7 +1221,7 @@ int dm_bt_beam_cyl(dm_ctx* ctx, int nside, const double* ring_cth_host, const do
   const double th = tan(fwhm_ns / 2.0);
   const double alpha = log(2.0) / (2.0 * th * th);
   frame3 fr = make_frame(frame_host, frame_host + 3, frame_host + 6);
-  hipLaunchKernelGGL(bt_beam_kernel, dim3((gh.g.npix + 255) / 256), dim3(256), 0, ctx->stream, gh.g, fr, kind, dx, dy,
+  DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_beam_kernel, dim3((gh.g.npix + 255) / 256), dim3(256), 0, ctx->stream, gh.g, fr, kind, dx, dy,
                      dy2, ntab, alpha, out_dev);
   DM_HIP(ctx, hipGetLastError());
   dm_ws_release(ctx, mark);
@@ -1263,7 +1263,7 @@ int dm_bt_beams_cyl(dm_ctx* ctx, int nside, const double* ring_cth_host, const d
   }
   bt_beam_desc* d_bd = dm_ws_upload(ctx, bd);
   if (!d_bd) return DM_ENOMEM;
-  hipLaunchKernelGGL(bt_beams_kernel, dim3((gh.g.npix + 255) / 256, nbeam), dim3(256), 0, ctx->stream, gh.g, fr, d_bd);
+  DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_beams_kernel, dim3((gh.g.npix + 255) / 256, nbeam), dim3(256), 0, ctx->stream, gh.g, fr, d_bd);
   DM_HIP(ctx, hipGetLastError());
   return DM_OK;
 }
@@ -1294,9 +1294,9 @@ int dm_bt_maps(dm_ctx* ctx, int nside, const double* ring_cth_host, const double
   int* dbi = dm_ws_upload(ctx, bi);
   int* dbj = dm_ws_upload(ctx, bj);
   if (!omega || !duv || !dbi || !dbj) return DM_ENOMEM;
-  hipLaunchKernelGGL(bt_omega_kernel, dim3(nbeam), dim3(256), 0, ctx->stream, gh.g, fr, beams_dev, ncomp, bstride,
+  DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_omega_kernel, dim3(nbeam), dim3(256), 0, ctx->stream, gh.g, fr, beams_dev, ncomp, bstride,
                      omega);
-  hipLaunchKernelGGL(bt_maps_kernel, dim3((gh.g.npix + 255) / 256, ncol), dim3(256), 0, ctx->stream, gh.g, fr,
+  DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_maps_kernel, dim3((gh.g.npix + 255) / 256, ncol), dim3(256), 0, ctx->stream, gh.g, fr,
                      polarised, ncol, duv, dbi, dbj, beams_dev, bstride, omega, reinterpret_cast<cplx*>(maps_dev));
   DM_HIP(ctx, hipGetLastError());
   dm_ws_release(ctx, mark);
@@ -1326,8 +1326,8 @@ int dm_bt_maps_c(dm_ctx* ctx, int nside, const double* ring_cth_host, const doub
   int* dbj = dm_ws_upload(ctx, bj);
   if (!omega || !duv || !dbi || !dbj) return DM_ENOMEM;
   const cplx* bc = reinterpret_cast<const cplx*>(beams_dev);
-  hipLaunchKernelGGL(bt_omega_c_kernel, dim3(nbeam), dim3(256), 0, ctx->stream, gh.g, bc, ncomp, bstride, omega);
-  hipLaunchKernelGGL(bt_maps_c_kernel, dim3((gh.g.npix + 255) / 256, ncol), dim3(256), 0, ctx->stream, gh.g, fr,
+  DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_omega_c_kernel, dim3(nbeam), dim3(256), 0, ctx->stream, gh.g, bc, ncomp, bstride, omega);
+  DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_maps_c_kernel, dim3((gh.g.npix + 255) / 256, ncol), dim3(256), 0, ctx->stream, gh.g, fr,
                      polarised, ncol, duv, dbi, dbj, bc, bstride, omega, reinterpret_cast<cplx*>(maps_dev));
   DM_HIP(ctx, hipGetLastError());
   return DM_OK;
@@ -1392,7 +1392,7 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
   cplx* G = dm_ws_alloc_t<cplx>(ctx, (size_t)nm * nring * ncp);
   if (!d_toff || (!fused && !tw) || !G) return DM_ENOMEM;
   if (!fused)
-    hipLaunchKernelGGL(bt_twiddle_kernel, dim3(8, nring), dim3(256), 0, ctx->stream, gh.g, m_lo, std::max(cnt, 1), d_toff,
+    DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_twiddle_kernel, dim3(8, nring), dim3(256), 0, ctx->stream, gh.g, m_lo, std::max(cnt, 1), d_toff,
                        tw);
   if (fused && cnt > 0) {
     // beam solid angles, per-column constants, then synthesis + DFT in one kernel (no Stokes maps in HBM)
@@ -1403,9 +1403,9 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
     double* omega = dm_ws_alloc_t<double>(ctx, syn->nbeam);
     double* opart = dm_ws_alloc_t<double>(ctx, (size_t)syn->nbeam * NOMEGA);
     if (!omega || !opart) return DM_ENOMEM;
-    hipLaunchKernelGGL(bt_omega_part_kernel, dim3(syn->nbeam, NOMEGA), dim3(256), 0, ctx->stream, gh.g, syn->beams_dev, ncomp,
+    DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_omega_part_kernel, dim3(syn->nbeam, NOMEGA), dim3(256), 0, ctx->stream, gh.g, syn->beams_dev, ncomp,
                        bstride, opart);
-    hipLaunchKernelGGL(bt_omega_fin_kernel, dim3((syn->nbeam + 63) / 64), dim3(64), 0, ctx->stream, opart, syn->nbeam,
+    DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_omega_fin_kernel, dim3((syn->nbeam + 63) / 64), dim3(64), 0, ctx->stream, opart, syn->nbeam,
                        4.0 * kPi / (double)npix, omega);
     // (the solid angles stay on the device: the per-column factor 1 / sqrt(Omega_i Omega_j) is filled in by a small
     // kernel, so the host never waits inside the call)
@@ -1417,7 +1417,7 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
       fc[c] = fdft_col{syn->uv_host[2 * c], syn->uv_host[2 * c + 1], 0.0, bi, bj};
     }
     fdft_col* d_fc = dm_ws_upload(ctx, fc);
-    if (d_fc) hipLaunchKernelGGL(bt_fdft_pre_kernel, dim3((ncol + 255) / 256), dim3(256), 0, ctx->stream, d_fc, ncol, omega);
+    if (d_fc) DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_fdft_pre_kernel, dim3((ncol + 255) / 256), dim3(256), 0, ctx->stream, d_fc, ncol, omega);
     double* d_rw = nullptr;
     if (ring_w_host) {
       std::vector<double> rw(ring_w_host, ring_w_host + nring);
@@ -1457,7 +1457,7 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
       auto fft_launch = [&](auto kern, int tpb) -> int {
         DM_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)fft_lds));
-        hipLaunchKernelGGL(kern, grid, dim3(tpb), fft_lds, ctx->stream, gh.g, fr, syn->beams_dev, bstride, d_fc, ncol, m_lo,
+        DM_PLAUNCH(ctx, DM_PROF_BT_RING, kern, grid, dim3(tpb), fft_lds, ctx->stream, gh.g, fr, syn->beams_dev, bstride, d_fc, ncol, m_lo,
                            cnt, d_rw, G, ncp, nside - 1, cpw);
         return DM_OK;
       };
@@ -1488,7 +1488,7 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
     auto launch = [&](auto kern, int NMG, int NCG) {
       if (nring_dft == 0) return;
       const dim3 grid((unsigned)((ncol16 + 4 * NCG - 1) / (4 * NCG)), (unsigned)nring_dft, (unsigned)((nmg + NMG - 1) / NMG));
-      hipLaunchKernelGGL(kern, grid, dim3(256), 0, ctx->stream, gh.g, fr, syn->beams_dev, bstride, d_fc, ncol16, m_lo, cnt, d_rw, G,
+      DM_PLAUNCH(ctx, DM_PROF_BT_RING, kern, grid, dim3(256), 0, ctx->stream, gh.g, fr, syn->beams_dev, bstride, d_fc, ncol16, m_lo, cnt, d_rw, G,
                          ncp, d_caps);
     };
     // 32 complex accumulators per lane (64 AGPRs) keep two waves per SIMD: the sincos of one wave runs under
@@ -1499,7 +1499,7 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
     auto launch2 = [&](auto kern, int NMG, int NCG) {
       if (nring_dft == 0) return;
       const dim3 grid((unsigned)((ncol16 + NCG - 1) / NCG), (unsigned)nring_dft, (unsigned)((nmg + 4 * NMG - 1) / (4 * NMG)));
-      hipLaunchKernelGGL(kern, grid, dim3(256), 0, ctx->stream, gh.g, fr, syn->beams_dev, bstride, d_fc, ncol16, m_lo, cnt, d_rw, G,
+      DM_PLAUNCH(ctx, DM_PROF_BT_RING, kern, grid, dim3(256), 0, ctx->stream, gh.g, fr, syn->beams_dev, bstride, d_fc, ncol16, m_lo, cnt, d_rw, G,
                          ncp, d_caps);
     };
     static const int shared_env = getenv("DM_FDFT_SHARED") ? atoi(getenv("DM_FDFT_SHARED")) : 1;
@@ -1538,7 +1538,7 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
   double* Xt = polarised ? dm_ws_alloc_t<double>(ctx, std::max<size_t>(ltot, 1)) : nullptr;
   if (!d_loff || !lam || (polarised && (!Wt || !Xt))) return DM_ENOMEM;
   if (cnt > 0)
-    hipLaunchKernelGGL(bt_legendre_kernel, dim3((nring + 63) / 64, cnt), dim3(64), 0, ctx->stream, gh.g, lmax_grp, m_lo,
+    DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_legendre_kernel, dim3((nring + 63) / 64, cnt), dim3(64), 0, ctx->stream, gh.g, lmax_grp, m_lo,
                        mtop, 4.0 * kPi / (double)npix, d_loff, lam, Wt, Xt);
   DM_HIP(ctx, hipGetLastError());
 
@@ -1553,7 +1553,7 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
   std::vector<int> neg1(ncol, -1);
   int* d_neg = dm_ws_upload(ctx, neg1);
   if (!d_cf || !d_cb || !d_cl || !d_neg) return DM_ENOMEM;
-  hipLaunchKernelGGL(bt_mask_kernel, dim3((2 * P * L + 255) / 256, ncol, nmblk), dim3(256), 0, ctx->stream, bm, F, B,
+  DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_mask_kernel, dim3((2 * P * L + 255) / 256, ncol, nmblk), dim3(256), 0, ctx->stream, bm, F, B,
                      P, L, m_hi, ncol, d_cf, d_cb, d_neg);
 
   // ---- Legendre products.  Columns of a group are arbitrary (f, b) pairs, so one GEMM row per
@@ -1575,7 +1575,7 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
   if (folded) {
     const size_t tot = (size_t)nm * (nring / 2) * ncp;
     const unsigned nb = (unsigned)std::min<size_t>((tot + 255) / 256, 65536);
-    hipLaunchKernelGGL(bt_fold_kernel, dim3(nb), dim3(256), 0, ctx->stream, G, nm, nring, (size_t)ncp);
+    DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_fold_kernel, dim3(nb), dim3(256), 0, ctx->stream, G, nm, nring, (size_t)ncp);
   }
   auto legendre_analysis = [&](bool accumulate) -> int {
   for (int pass = 0; pass < (polarised ? 2 : 1); ++pass) {
@@ -1634,7 +1634,7 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
     DM_TRY(dm_gemm_grouped_launch(ctx, g));
   }
   // ---- per-column band limit
-  hipLaunchKernelGGL(bt_mask_kernel, dim3((2 * P * L + 255) / 256, ncol, nmblk), dim3(256), 0, ctx->stream, bm, F, B,
+  DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_mask_kernel, dim3((2 * P * L + 255) / 256, ncol, nmblk), dim3(256), 0, ctx->stream, bm, F, B,
                      P, L, m_hi, ncol, d_cf, d_cb, d_cl);
   DM_HIP(ctx, hipGetLastError());
   return DM_OK;
@@ -1686,10 +1686,10 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
       double* XS = polarised ? dm_ws_alloc_t<double>(ctx, ltot) : nullptr;
       if (!lamS || (polarised && (!WS || !XS))) return DM_ENOMEM;
       const unsigned nb = (unsigned)std::min<size_t>((ltot + 255) / 256, 65536);
-      hipLaunchKernelGGL(bt_scale_table_kernel, dim3(nb), dim3(256), 0, ctx->stream, lam, lamS, ltot, nring, d_sc);
+      DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_scale_table_kernel, dim3(nb), dim3(256), 0, ctx->stream, lam, lamS, ltot, nring, d_sc);
       if (polarised) {
-        hipLaunchKernelGGL(bt_scale_table_kernel, dim3(nb), dim3(256), 0, ctx->stream, Wt, WS, ltot, nring, d_sc);
-        hipLaunchKernelGGL(bt_scale_table_kernel, dim3(nb), dim3(256), 0, ctx->stream, Xt, XS, ltot, nring, d_sc);
+        DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_scale_table_kernel, dim3(nb), dim3(256), 0, ctx->stream, Wt, WS, ltot, nring, d_sc);
+        DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_scale_table_kernel, dim3(nb), dim3(256), 0, ctx->stream, Xt, XS, ltot, nring, d_sc);
       }
       for (int pass = 0; pass < (polarised ? 2 : 1); ++pass) {
         std::vector<dm_gemm_desc> g;
@@ -1747,13 +1747,13 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
       ga.cth = d_geoA;
       ga.sth = d_geoA + nra;
       ga.nring = nra;
-      hipLaunchKernelGGL(bt_legendre_kernel, dim3((nra + 63) / 64, Mc + 1), dim3(64), 0, ctx->stream, ga, lmax_grp, 0, Mc, wq,
+      DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_legendre_kernel, dim3((nra + 63) / 64, Mc + 1), dim3(64), 0, ctx->stream, ga, lmax_grp, 0, Mc, wq,
                          d_loffA, lamA, WA, XA);
       const dim3 fg(64, Mc + 1);
-      hipLaunchKernelGGL(bt_kext_fill_kernel, fg, dim3(256), 0, ctx->stream, lamA, d_loffA, Kl, d_koff, lmax_grp, nra, kfast ? 1 : 0);
+      DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_kext_fill_kernel, fg, dim3(256), 0, ctx->stream, lamA, d_loffA, Kl, d_koff, lmax_grp, nra, kfast ? 1 : 0);
       if (polarised) {
-        hipLaunchKernelGGL(bt_kext_fill_kernel, fg, dim3(256), 0, ctx->stream, WA, d_loffA, Kp, d_koff, lmax_grp, nra, kfast ? 1 : 0);
-        hipLaunchKernelGGL(bt_kext_fill_kernel, fg, dim3(256), 0, ctx->stream, XA, d_loffA, Kx, d_koff, lmax_grp, nra, kfast ? 1 : 0);
+        DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_kext_fill_kernel, fg, dim3(256), 0, ctx->stream, WA, d_loffA, Kp, d_koff, lmax_grp, nra, kfast ? 1 : 0);
+        DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_kext_fill_kernel, fg, dim3(256), 0, ctx->stream, XA, d_loffA, Kx, d_koff, lmax_grp, nra, kfast ? 1 : 0);
       }
     }
     // ---- iteration on the increments:  d_0 = a_0,  d_{k+1} = d_k - mask((A o S) d_k),  a_n = sum_k d_k
@@ -1796,7 +1796,7 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
           }
           DM_TRY(dm_gemm_grouped_launch(ctx, g));
         }
-        hipLaunchKernelGGL(bt_alias_fold_kernel, dim3((unsigned)((ncp + 3) / 4), (nra + 63) / 64, nmmA), dim3(64, 4), 0, ctx->stream,
+        DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_alias_fold_kernel, dim3((unsigned)((ncp + 3) / 4), (nra + 63) / 64, nmmA), dim3(64, 4), 0, ctx->stream,
                            Ha, dbuf, Mc, nra, (size_t)ncp, L, Lg, d_nphiA, d_mlimA, d_scA);
       }
       // t = [d | folded rings] [K ; alias tables]: the Gram product and the analysis of the folded rings in one K dimension
@@ -1830,7 +1830,7 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
         }
         DM_TRY(dm_gemm_grouped_launch(ctx, g));
       }
-      hipLaunchKernelGGL(bt_refine_update_kernel, dim3((P * L + 255) / 256, ncol, 2 * cnt), dim3(256), 0, ctx->stream, bm, dbuf,
+      DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_refine_update_kernel, dim3((P * L + 255) / 256, ncol, 2 * cnt), dim3(256), 0, ctx->stream, bm, dbuf,
                          tbuf, m_lo, ncol, P, L, Lg, d_cl);
       DM_HIP(ctx, hipGetLastError());
     }
@@ -1927,7 +1927,7 @@ static int bt_sht_refined(dm_ctx* ctx, int nside, const double* ring_cth_host, c
   int* d_cf = dm_ws_upload(ctx, cfv);
   int* d_cb = dm_ws_upload(ctx, cbv);
   if (!d_cf || !d_cb) return DM_ENOMEM;
-  hipLaunchKernelGGL(bt_scatter2_kernel, dim3((2 * P * L + 255) / 256, ncol, m_hi - m_lo + 1), dim3(256), 0, ctx->stream, acc, e_lo,
+  DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_scatter2_kernel, dim3((2 * P * L + 255) / 256, ncol, m_hi - m_lo + 1), dim3(256), 0, ctx->stream, acc, e_lo,
                      enm, Ls, Lrow, reinterpret_cast<cplx*>(beam_m_dev), m_lo, F, B, P, L, ncol, d_cf, d_cb);
   DM_HIP(ctx, hipGetLastError());
   return DM_OK;
@@ -1970,7 +1970,7 @@ int dm_bt_sht_opts(dm_ctx* ctx, int nside, const double* ring_cth_host, const do
   int* d_cf = dm_ws_upload(ctx, cfv);
   int* d_cb = dm_ws_upload(ctx, cbv);
   if (!d_cf || !d_cb) return DM_ENOMEM;
-  hipLaunchKernelGGL(bt_scatter_kernel, dim3((2 * P * L + 255) / 256, ncol, m_hi - m_lo + 1), dim3(256), 0, ctx->stream, cf, msrc,
+  DM_PLAUNCH(ctx, DM_PROF_BT_OTHER, bt_scatter_kernel, dim3((2 * P * L + 255) / 256, ncol, m_hi - m_lo + 1), dim3(256), 0, ctx->stream, cf, msrc,
                      reinterpret_cast<cplx*>(beam_m_dev), m_lo, F, B, P, L, ncol, d_cf, d_cb);
   DM_HIP(ctx, hipGetLastError());
   DM_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -215,10 +215,10 @@ int dm_potrf_batched(dm_ctx* ctx, const std::vector<dm_mat>& mats, int* info_dev
       for (int half = 0; half < 2; ++half) {
         const int kk = k0 + half * NB;
         if (kk >= maxn) break;
-        if (!chain.dry) hipLaunchKernelGGL(potf2_kernel, dim3(nbatch), dim3(256), 0, ctx->stream, dd, kk, info_dev);
+        if (!chain.dry) DM_PLAUNCH(ctx, DM_PROF_CHOL, potf2_kernel, dim3(nbatch), dim3(256), 0, ctx->stream, dd, kk, info_dev);
         if (kk + NB >= maxn) break;
         const int rt = (maxn - kk - NB + 63) / 64;
-        if (!chain.dry) hipLaunchKernelGGL(panel_trsm_kernel, dim3(rt, nbatch), dim3(256), 0, ctx->stream, dd, kk, info_dev);
+        if (!chain.dry) DM_PLAUNCH(ctx, DM_PROF_CHOL, panel_trsm_kernel, dim3(rt, nbatch), dim3(256), 0, ctx->stream, dd, kk, info_dev);
         if (half == 0) {
           // update only the next 32 columns so that the second factor step sees current data:
           // A[kk+NB:, kk+NB:kk+2NB] -= L[kk+NB:, kk:kk+NB] L[kk+NB:kk+2NB, kk:kk+NB]^H
@@ -250,7 +250,7 @@ int dm_potrf_batched(dm_ctx* ctx, const std::vector<dm_mat>& mats, int* info_dev
       }
     }
   }
-  hipLaunchKernelGGL(zero_upper_kernel, dim3((maxn + 255) / 256, maxn, nbatch), dim3(256), 0, ctx->stream, dd);
+  DM_PLAUNCH(ctx, DM_PROF_CHOL, zero_upper_kernel, dim3((maxn + 255) / 256, maxn, nbatch), dim3(256), 0, ctx->stream, dd);
   DM_HIP(ctx, hipGetLastError());
   (void)mark;  // descriptors stay allocated until the caller releases its own mark
   return DM_OK;
@@ -314,10 +314,10 @@ int trsm_pass(dm_ctx* ctx, const std::vector<dm_trsm_problem>& probs, bool conjt
       else s32 = 2 * s + half;  // backward kernel maps its step to the block row itself
       if (chain.dry) {
       } else if (!conjtrans)
-        hipLaunchKernelGGL(diag_solve_kernel<false>, dim3(ct, nbatch), dim3(256), 0, ctx->stream, dd, s32, nblk32,
+        DM_PLAUNCH(ctx, DM_PROF_CHOL, diag_solve_kernel<false>, dim3(ct, nbatch), dim3(256), 0, ctx->stream, dd, s32, nblk32,
                            upper_only ? 1 : 0);
       else
-        hipLaunchKernelGGL(diag_solve_kernel<true>, dim3(ct, nbatch), dim3(256), 0, ctx->stream, dd, s32, 2 * nblk, 0);
+        DM_PLAUNCH(ctx, DM_PROF_CHOL, diag_solve_kernel<true>, dim3(ct, nbatch), dim3(256), 0, ctx->stream, dd, s32, 2 * nblk, 0);
       if (half == 0) {
         DM_TRY(chain.gemm([&](std::vector<dm_gemm_desc>& g2) {
         for (int i = 0; i < nbatch; ++i) {

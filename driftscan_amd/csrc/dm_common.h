@@ -35,8 +35,9 @@ struct dm_ctx {
   std::string err;
   // optional per-kernel-class timing (HIP events on ctx->stream) and flop accounting
   bool prof_on = false;
+  int prof_level = 1;          // 2: the extended classes (every kernel of the path) are bracketed too
   struct prof_rec { int cls; hipEvent_t a, b; double flops; double weight = 1.0; };
-  unsigned prof_seq[16] = {0};  // per class: launches seen (small launches are timed one in DM_PROF_SMALL_STRIDE)
+  unsigned prof_seq[32] = {0};  // per class: launches seen (small launches are timed one in DM_PROF_SMALL_STRIDE)
   std::vector<prof_rec> prof;
   std::vector<hipEvent_t> ev_pool;
   unsigned long long* prof_dev = nullptr;  // device flop counters, one per class
@@ -53,7 +54,21 @@ constexpr double DM_PROF_BIG = 2.0e9;
 enum { DM_PROF_GEMM = 0, DM_PROF_GEMM_REAL = 1, DM_PROF_JAC_GRAM = 2, DM_PROF_JAC_INNER = 3, DM_PROF_JAC_APPLY = 4,
        DM_PROF_DGEMM = 5, DM_PROF_TRD_SYMV = 6, DM_PROF_TRD_WX = 7,
        // the two-stage tridiagonalisation (dm_sbr_impl.h): fp64 VALU kernels, algorithmic FLOPs
-       DM_PROF_SB_PANEL = 8, DM_PROF_SB_CHASE = 9, DM_PROF_SB_Q2 = 10, DM_PROF_NCLASS = 12 };
+       DM_PROF_SB_PANEL = 8, DM_PROF_SB_CHASE = 9, DM_PROF_SB_Q2 = 10,
+       // gathered-B ZGEMM: the covariance projections (B_f o C_l) B_f'^H of the KL stage, algorithmic FLOPs
+       DM_PROF_GEMM_COV = 11,
+       // "extended" classes: every remaining kernel of the path, time only (bracketed at profiling level 2:
+       // dm_prof_reset(ctx, 2); the timed passes of bench.py run at level 1 and do not pay for these events)
+       DM_PROF_EXT0 = 12,
+       DM_PROF_BT_RING = 12,     // fused map synthesis + ring transform (bt_fused_dft / dft2 / fft)
+       DM_PROF_BT_OTHER = 13,    // beams, solid angles, fold, tables, masks, refinement helpers
+       DM_PROF_TRD_SMALL = 14,   // LDS-resident tridiagonalisation of the small Gram problems
+       DM_PROF_DC = 15,          // divide & conquer on the tridiagonal (everything but its real GEMMs) + QL leaves
+       DM_PROF_CHOL = 16,        // potf2, panel substitutions, diagonal-block solves
+       DM_PROF_UTIL = 17,        // transposes, copies, identities, regularisation / all-zero scans, Fisher helpers
+       DM_PROF_EIG_OTHER = 18,   // T factors, slice sums, band extraction, eigenvector gathers
+       DM_PROF_SVD_OTHER = 19,   // Jacobi engine helpers (norms, ranks, gathers, cleaning) and SVD chain assembly
+       DM_PROF_NCLASS = 24 };
 
 hipEvent_t dm_prof_event(dm_ctx* ctx);
 // bracket one launch: DM_PROF(ctx, cls, flops) { launch; }
@@ -61,9 +76,10 @@ struct dm_prof_scope {
   dm_ctx* c; int cls; double flops; hipEvent_t a = nullptr; double weight = 1.0;
   dm_prof_scope(dm_ctx* ctx, int cls_, double fl) : c(ctx), cls(cls_), flops(fl) {
     if (!c->prof_on) return;
+    if (cls >= DM_PROF_EXT0 && c->prof_level < 2) return;
     const bool gemm_class = cls == DM_PROF_GEMM || cls == DM_PROF_GEMM_REAL || cls == DM_PROF_DGEMM;
     if (gemm_class && fl < DM_PROF_BIG) {  // (the Jacobi classes are a few dozen launches per step: all timed)
-      if (c->prof_seq[cls & 15]++ % DM_PROF_SMALL_STRIDE != 0) return;
+      if (c->prof_seq[cls & 31]++ % DM_PROF_SMALL_STRIDE != 0) return;
       weight = DM_PROF_SMALL_STRIDE;
     }
     a = dm_prof_event(c);
@@ -77,6 +93,14 @@ struct dm_prof_scope {
     }
   }
 };
+
+// a launch of one of the extended classes: bracketed when the context profiles at level 2, a plain launch otherwise
+#define DM_PLAUNCH(ctx_, cls_, ...)                      \
+  do {                                                    \
+    dm_prof_scope dm_ps__((ctx_), (cls_), 0.0);           \
+    hipLaunchKernelGGL(__VA_ARGS__);                      \
+  } while (0)
+
 
 #define DM_OK 0
 #define DM_EARG (-1)

@@ -146,10 +146,11 @@ int dm_prof_reset(dm_ctx* ctx, int enable) {
   if (!ctx->prof_dev) DM_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->prof_dev), sizeof(unsigned long long) * DM_PROF_NCLASS));
   DM_HIP(ctx, hipMemset(ctx->prof_dev, 0, sizeof(unsigned long long) * DM_PROF_NCLASS));
   ctx->prof_on = enable != 0;
+  ctx->prof_level = enable >= 2 ? 2 : 1;
   return DM_OK;
 }
 
-// ms[c], flops[c], launches[c] for c < DM_PROF_NCLASS (= 12): summed event time, algorithmic
+// ms[c], flops[c], launches[c] for c < DM_PROF_NCLASS (= 24): summed event time, algorithmic
 // flops and launch count of each kernel class since dm_prof_reset.
 int dm_prof_trd_stride(void) { return DM_PROF_TRD_STRIDE; }
 

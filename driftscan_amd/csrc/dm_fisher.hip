@@ -92,7 +92,7 @@ extern "C" int dm_fisher(dm_ctx* ctx, int nblk, int F, int K, int P, int L, cons
     scale_desc* d_sd = dm_ws_upload(ctx, sd);
     if (!d_sd) return DM_ENOMEM;
     const unsigned gx = (unsigned)std::min<size_t>((maxel + 255) / 256, 1024);
-    hipLaunchKernelGGL(fisher_scale_rows_kernel, dim3(gx, (unsigned)sd.size()), dim3(256), 0, ctx->stream, d_sd);
+    DM_PLAUNCH(ctx, DM_PROF_UTIL, fisher_scale_rows_kernel, dim3(gx, (unsigned)sd.size()), dim3(256), 0, ctx->stream, d_sd);
   }
   for (int a = 0; a < nbands; ++a) {
     // S_b = B C_l^a B^H (temperature block only: makeproj calls project_matrix_sky_to_svd(temponly=True))
@@ -143,7 +143,7 @@ extern "C" int dm_fisher(dm_ctx* ctx, int nblk, int F, int K, int P, int L, cons
     if (!sd.empty()) {
       sum_desc* d_sd = dm_ws_upload(ctx, sd);
       if (!d_sd) return DM_ENOMEM;
-      hipLaunchKernelGGL(fisher_sum_chunks_kernel, dim3((nbands * nbands + 255) / 256, (unsigned)sd.size()), dim3(256), 0,
+      DM_PLAUNCH(ctx, DM_PROF_UTIL, fisher_sum_chunks_kernel, dim3((nbands * nbands + 255) / 256, (unsigned)sd.size()), dim3(256), 0,
                          ctx->stream, d_sd);
     }
   }

@@ -751,7 +751,7 @@ int dm_gemm_plan_run(dm_ctx* ctx, const dm_gemm_plan& plan, const char* dblob) {
   }
   if (n3) {
     const dm_gemm_tile* dt = dt_g;
-    dm_prof_scope ps(ctx, DM_PROF_GEMM, fl_g);
+    dm_prof_scope ps(ctx, DM_PROF_GEMM_COV, fl_g);
     if (use4)
       hipLaunchKernelGGL((zgemm4_grouped_kernel<false, true, 1>), dim3((unsigned)n3), dim3(256), 0, ctx->stream,
                          dd, dt, (int)n3);

@@ -741,11 +741,11 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
   // rounding residue (rank-deficient inputs) can never be made mutually orthogonal to
   // relative accuracy — there are more of them than dimensions left — so pairs of such
   // rows are left alone, exactly the level at which LAPACK's backward error sits.
-  hipLaunchKernelGGL(jac_rownorm_kernel, dim3((maxrows + 3) / 4, np), dim3(256), 0, ctx->stream, d_pd, d_key,
+  DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, jac_rownorm_kernel, dim3((maxrows + 3) / 4, np), dim3(256), 0, ctx->stream, d_pd, d_key,
                      sigma_stride, maxrows);
   {
     const double e4 = 4.0 * 2.220446049250313e-16;
-    hipLaunchKernelGGL(jac_floor_kernel, dim3(np), dim3(256), 0, ctx->stream, d_key, sigma_stride, d_nrows,
+    DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, jac_floor_kernel, dim3(np), dim3(256), 0, ctx->stream, d_key, sigma_stride, d_nrows,
                        d_floor, e4 * e4);
   }
   // Rows count as orthogonal at |cos| <= K u, K the length of the inner products and u the unit roundoff —
@@ -851,15 +851,15 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
           jac_pdesc* d_pa = dm_ws_upload(ctx, pa);
           jac_clean_desc* d_cd = dm_ws_upload(ctx, cd);
           if (!d_pa || !d_cd) return DM_ENOMEM;
-          hipLaunchKernelGGL(jac_rownorm_kernel, dim3((maxra + 3) / 4, (unsigned)pa.size()), dim3(256), 0, ctx->stream, d_pa,
+          DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, jac_rownorm_kernel, dim3((maxra + 3) / 4, (unsigned)pa.size()), dim3(256), 0, ctx->stream, d_pa,
                              an, sigma_stride, maxra);
           DM_TRY(dm_gemm_grouped_launch(ctx, gC));
-          hipLaunchKernelGGL(jac_theta_kernel, dim3((maxra + 255) / 256, maxrb, (unsigned)cd.size()), dim3(256), 0,
+          DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, jac_theta_kernel, dim3((maxra + 255) / 256, maxrb, (unsigned)cd.size()), dim3(256), 0,
                              ctx->stream, d_cd);
           DM_TRY(dm_gemm_grouped_launch(ctx, gP1));
           DM_TRY(dm_gemm_grouped_launch(ctx, gP2));
           const int gxm = std::max(1, std::min(8, (maxcols + 255) / 256));
-          hipLaunchKernelGGL(jac_clean_mix_kernel, dim3(gxm, maxra + maxrb, (unsigned)cd.size()), dim3(256), 0, ctx->stream,
+          DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, jac_clean_mix_kernel, dim3(gxm, maxra + maxrb, (unsigned)cd.size()), dim3(256), 0, ctx->stream,
                              d_cd);
           DM_TRY(dm_gemm_grouped_launch(ctx, gA));
           DM_TRY(dm_gemm_grouped_launch(ctx, gB));
@@ -912,7 +912,7 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
       size_t* d_toffa = dm_ws_upload(ctx, toffa);
       if (!d_pda || !d_toffa) return DM_ENOMEM;
       const int gx0 = std::max(1, std::min(8, (maxcols + 255) / 256));
-      hipLaunchKernelGGL(jac_scatter_back_kernel, dim3(gx0, subrows, (unsigned)pda.size()), dim3(256), 0, ctx->stream,
+      DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, jac_scatter_back_kernel, dim3(gx0, subrows, (unsigned)pda.size()), dim3(256), 0, ctx->stream,
                          d_pda, d_tmp, d_toffa);
       DM_HIP(ctx, hipGetLastError());
       dbg_mark("level: sort + W Z");
@@ -957,7 +957,7 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
   if (O.drop_below > 0.0) {
     // rows below the caller's level of interest leave the tournament (they sit at the end: the levels are
     // ordered by scale and sorted inside)
-    hipLaunchKernelGGL(jac_rownorm_kernel, dim3((maxrows + 3) / 4, np), dim3(256), 0, ctx->stream, d_pd, d_key,
+    DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, jac_rownorm_kernel, dim3((maxrows + 3) / 4, np), dim3(256), 0, ctx->stream, d_pd, d_key,
                        sigma_stride, maxrows);
     std::vector<double> hk((size_t)np * sigma_stride);
     DM_TRY(dm_download(ctx, hk.data(), d_key, sizeof(double) * hk.size()));
@@ -1034,14 +1034,14 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
 
   dbg_mark("sweeps");
   // sort rows by descending norm over the Gram columns
-  hipLaunchKernelGGL(jac_rownorm_kernel, dim3((maxrows + 3) / 4, np), dim3(256), 0, ctx->stream, d_pd, d_key,
+  DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, jac_rownorm_kernel, dim3((maxrows + 3) / 4, np), dim3(256), 0, ctx->stream, d_pd, d_key,
                      sigma_stride, maxrows);
-  hipLaunchKernelGGL(jac_rank_kernel, dim3((maxrows + 255) / 256, np), dim3(256), 0, ctx->stream, d_key,
+  DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, jac_rank_kernel, dim3((maxrows + 255) / 256, np), dim3(256), 0, ctx->stream, d_key,
                      sigma_stride, d_nrows, d_rank, 1);
   const int gx = std::max(1, std::min(8, (maxcols + 255) / 256));
-  hipLaunchKernelGGL(jac_gather_rows_kernel, dim3(gx, maxrows, np), dim3(256), 0, ctx->stream, d_pd, d_rank,
+  DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, jac_gather_rows_kernel, dim3(gx, maxrows, np), dim3(256), 0, ctx->stream, d_pd, d_rank,
                      sigma_stride, d_tmp, d_toff, d_key, sigma);
-  hipLaunchKernelGGL(jac_scatter_back_kernel, dim3(gx, maxrows, np), dim3(256), 0, ctx->stream, d_pd, d_tmp,
+  DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, jac_scatter_back_kernel, dim3(gx, maxrows, np), dim3(256), 0, ctx->stream, d_pd, d_tmp,
                      d_toff);
   DM_HIP(ctx, hipGetLastError());
   DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1123,7 +1123,7 @@ int dm_jacobi_herm(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, d
 
   // absolute rotation floor: 32 eps * max|C_ij| (a backward-stable solver cannot
   // resolve off-diagonals below this; kltransform's LAPACK path is no different)
-  hipLaunchKernelGGL(jac_absmax_kernel, dim3(np), dim3(256), 0, ctx->stream, d_tdC, d_floor,
+  DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, jac_absmax_kernel, dim3(np), dim3(256), 0, ctx->stream, d_tdC, d_floor,
                      32.0 * 2.220446049250313e-16);
 
   const double tol_outer = 1e-13, tol_inner = 1e-15;
@@ -1160,7 +1160,7 @@ int dm_jacobi_herm(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, d
         hipLaunchKernelGGL(jac_apply_kernel, dim3(ni, chunks), dim3(256), APPLY_LDS, ctx->stream, d_iW + nb,
                            d_active, d_skip, d_Q, fc);
       }
-      hipLaunchKernelGGL(jac_ctrans_kernel, dim3(tb, tb, np), dim3(256), 0, ctx->stream,
+      DM_PLAUNCH(ctx, DM_PROF_UTIL, jac_ctrans_kernel, dim3(tb, tb, np), dim3(256), 0, ctx->stream,
                          cur == 0 ? d_tdC : d_tdT, d_active);
       {
         dm_prof_scope ps(ctx, DM_PROF_JAC_APPLY, 0.0);
@@ -1191,7 +1191,7 @@ int dm_jacobi_herm(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, d
       for (int p : newly_done) only[p] = 1;
       int* d_only = dm_ws_upload(ctx, only);
       if (!d_only) return DM_ENOMEM;
-      hipLaunchKernelGGL(jac_ctrans_kernel, dim3(tb, tb, np), dim3(256), 0, ctx->stream, d_tdT, d_only);
+      DM_PLAUNCH(ctx, DM_PROF_UTIL, jac_ctrans_kernel, dim3(tb, tb, np), dim3(256), 0, ctx->stream, d_tdT, d_only);
     }
     if (!any) { ++sweep; break; }
     DM_TRY(dm_upload(ctx, d_active, active.data(), sizeof(int) * np));
@@ -1203,11 +1203,11 @@ int dm_jacobi_herm(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, d
     if (any_left) {
       int* d_act2 = dm_ws_upload(ctx, active);
       if (!d_act2) return DM_ENOMEM;
-      hipLaunchKernelGGL(jac_ctrans_kernel, dim3(tb, tb, np), dim3(256), 0, ctx->stream, d_tdT, d_act2);
+      DM_PLAUNCH(ctx, DM_PROF_UTIL, jac_ctrans_kernel, dim3(tb, tb, np), dim3(256), 0, ctx->stream, d_tdT, d_act2);
     }
   }
   if (sweeps_out) *sweeps_out = sweep;
-  hipLaunchKernelGGL(jac_diag_kernel, dim3((maxn + 255) / 256, np), dim3(256), 0, ctx->stream, d_tdC, evals,
+  DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, jac_diag_kernel, dim3((maxn + 255) / 256, np), dim3(256), 0, ctx->stream, d_tdC, evals,
                      evals_stride);
   DM_HIP(ctx, hipGetLastError());
   DM_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1245,12 +1245,12 @@ int dm_sort_rows_by_key(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, d
   double* d_ks = dm_ws_alloc_t<double>(ctx, (size_t)np * key_stride);
   cplx* d_tmp = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(ttot, 1));
   if (!d_pd || !d_toff || !d_nrows || !d_rank || !d_ks || !d_tmp) return DM_ENOMEM;
-  hipLaunchKernelGGL(jac_rank_kernel, dim3((maxrows + 255) / 256, np), dim3(256), 0, ctx->stream, key, key_stride,
+  DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, jac_rank_kernel, dim3((maxrows + 255) / 256, np), dim3(256), 0, ctx->stream, key, key_stride,
                      d_nrows, d_rank, descending ? 1 : 0);
   const int gx = std::max(1, std::min(8, (maxcols + 255) / 256));
-  hipLaunchKernelGGL(jac_gather_rows_kernel, dim3(gx, maxrows, np), dim3(256), 0, ctx->stream, d_pd, d_rank,
+  DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, jac_gather_rows_kernel, dim3(gx, maxrows, np), dim3(256), 0, ctx->stream, d_pd, d_rank,
                      key_stride, d_tmp, d_toff, key, d_ks);
-  hipLaunchKernelGGL(jac_scatter_back_kernel, dim3(gx, maxrows, np), dim3(256), 0, ctx->stream, d_pd, d_tmp, d_toff);
+  DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, jac_scatter_back_kernel, dim3(gx, maxrows, np), dim3(256), 0, ctx->stream, d_pd, d_tmp, d_toff);
   // sorted keys back into `key` (only the first nrows entries of each problem)
   {
     std::vector<dm_cdesc> cp;

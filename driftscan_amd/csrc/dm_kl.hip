@@ -253,8 +253,8 @@ int dm_regularise(dm_ctx* ctx, int nblk, const int* n_host, void* mats_dev, cons
   if (!part) return DM_ENOMEM;
   int maxn = 0;
   for (int b = 0; b < nblk; ++b) maxn = std::max(maxn, n_host[b]);
-  hipLaunchKernelGGL(lexmax_partial_kernel, dim3(BLK_SPLIT, nblk), dim3(256), 0, ctx->stream, d, part);
-  hipLaunchKernelGGL(lexmax_adddiag_kernel, dim3((std::max(maxn, 1) + 255) / 256, nblk), dim3(256), 0, ctx->stream, d,
+  DM_PLAUNCH(ctx, DM_PROF_UTIL, lexmax_partial_kernel, dim3(BLK_SPLIT, nblk), dim3(256), 0, ctx->stream, d, part);
+  DM_PLAUNCH(ctx, DM_PROF_UTIL, lexmax_adddiag_kernel, dim3((std::max(maxn, 1) + 255) / 256, nblk), dim3(256), 0, ctx->stream, d,
                      part, reg);
   DM_HIP(ctx, hipGetLastError());
   dm_ws_release(ctx, mark);
@@ -309,8 +309,8 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
   for (int b = 0; b < nblk; ++b) bdA[b] = blk_desc{A + off_host[b], n_host[b]};
   blk_desc* d_bdA = dm_ws_upload(ctx, bdA);
   if (!d_bdA) return DM_ENOMEM;
-  hipLaunchKernelGGL(flag_set_kernel, dim3((nblk + 255) / 256), dim3(256), 0, ctx->stream, zflag_dev, nblk, 1);
-  hipLaunchKernelGGL(allzero_kernel, dim3(BLK_SPLIT, nblk), dim3(256), 0, ctx->stream, d_bdA, zflag_dev);
+  DM_PLAUNCH(ctx, DM_PROF_UTIL, flag_set_kernel, dim3((nblk + 255) / 256), dim3(256), 0, ctx->stream, zflag_dev, nblk, 1);
+  DM_PLAUNCH(ctx, DM_PROF_UTIL, allzero_kernel, dim3(BLK_SPLIT, nblk), dim3(256), 0, ctx->stream, d_bdA, zflag_dev);
   // ---- Cholesky of B (on a copy, the rescue needs B itself)
   auto factor_launch = [&](const std::vector<int>& blks) -> int {
     std::vector<dm_mat> mats;
@@ -419,7 +419,7 @@ int dm_eigh_gen(dm_ctx* ctx, int nblk, const int* n_host, void* A_dev, void* B_d
     blk_desc* d_bdB = dm_ws_upload(ctx, bdB);
     double* d_sh = dm_ws_upload(ctx, sh);
     if (!d_bdB || !d_sh) return DM_ENOMEM;
-    hipLaunchKernelGGL(add_diag_kernel, dim3((maxn + 255) / 256, (unsigned)bad.size()), dim3(256), 0, ctx->stream,
+    DM_PLAUNCH(ctx, DM_PROF_UTIL, add_diag_kernel, dim3((maxn + 255) / 256, (unsigned)bad.size()), dim3(256), 0, ctx->stream,
                        d_bdB, d_sh);
     std::vector<int> info2;
     DM_TRY(factor(bad, info2));

@@ -126,7 +126,7 @@ extern "C" int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, c
   cplx* Z = dm_ws_alloc_t<cplx>(ctx, (size_t)nch * T * ldz);
   double* sig = dm_ws_alloc_t<double>(ctx, (size_t)nch * T);
   if (!Z || !sig) return DM_ENOMEM;
-  hipLaunchKernelGGL(svd_build_z_kernel, dim3((ldz + 255) / 256, T, nch), dim3(256), 0, ctx->stream, beam,
+  DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, svd_build_z_kernel, dim3((ldz + 255) / 256, T, nch), dim3(256), 0, ctx->stream, beam,
                      noisew_dev, Z, F, T, PL, ldz);
   DM_HIP(ctx, hipGetLastError());
 
@@ -224,7 +224,7 @@ extern "C" int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, c
   DM_TRY(dm_fill_zero(ctx, beam_ut, sizeof(cplx) * (size_t)nch * K * T));
   DM_TRY(dm_fill_zero(ctx, sigma_dev, sizeof(double) * (size_t)nch * K));
   if (maxnm > 0) {
-    hipLaunchKernelGGL(svd_extract_kernel, dim3((ldz + 255) / 256, maxnm, nch), dim3(256), 0, ctx->stream, Z, d_row0,
+    DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, svd_extract_kernel, dim3((ldz + 255) / 256, maxnm, nch), dim3(256), 0, ctx->stream, Z, d_row0,
                        d_nm, noisew_dev, sig, beam_svd, beam_ut, sigma_dev, F, T, PL, K, ldz);
     DM_HIP(ctx, hipGetLastError());
   }
@@ -239,7 +239,7 @@ extern "C" int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, c
       double* s4 = dm_ws_alloc_t<double>(ctx, (size_t)nch * K);
       double* w4 = dm_ws_alloc_t<double>(ctx, (size_t)nch * K);
       if (!Z2 || !s4 || !w4) return DM_ENOMEM;
-      hipLaunchKernelGGL(svd_build_pinv_kernel, dim3((ld2 + 255) / 256, maxnm, nch), dim3(256), 0, ctx->stream,
+      DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, svd_build_pinv_kernel, dim3((ld2 + 255) / 256, maxnm, nch), dim3(256), 0, ctx->stream,
                          beam_svd, d_nm, Z2, K, PL, ld2);
       std::vector<dm_jac_problem> pr(nch);
       for (int c = 0; c < nch; ++c)
@@ -251,7 +251,7 @@ extern "C" int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, c
       DM_TRY(dm_jacobi_rows(ctx, pr, s4, K, &sw, &o4));
       if (sweeps_host) sweeps_host[3] = sw;
       const double rtol = (double)std::max(PL, maxnm) * 2.220446049250313e-16;
-      hipLaunchKernelGGL(svd_pinv_weights_kernel, dim3(nch), dim3(256), 0, ctx->stream, s4, d_nm, w4, K, rtol);
+      DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, svd_pinv_weights_kernel, dim3(nch), dim3(256), 0, ctx->stream, s4, d_nm, w4, K, rtol);
       std::vector<dm_gemm_desc> g;
       g.reserve(nch);
       for (int c = 0; c < nch; ++c) {

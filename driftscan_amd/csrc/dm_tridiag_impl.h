@@ -1542,7 +1542,7 @@ static int dc_solve(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, 
     if (!tears.empty()) {
       dc_tear* d_t = dm_ws_upload(ctx, tears);
       if (!d_t) return DM_ENOMEM;
-      hipLaunchKernelGGL(dc_tear_kernel, dim3(((unsigned)tears.size() + 255) / 256), dim3(256), 0, ctx->stream, d_t,
+      DM_PLAUNCH(ctx, DM_PROF_DC, dc_tear_kernel, dim3(((unsigned)tears.size() + 255) / 256), dim3(256), 0, ctx->stream, d_t,
                          (int)tears.size());
     }
     if (nleaf > 0) {
@@ -1558,13 +1558,13 @@ static int dc_solve(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, 
       static const bool leaf_apply = !getenv("DM_QL_LEAF_RECORD");
       if (leaf_apply && maxleaf <= 64) {
         // rotations applied in LDS as they are generated (d, e and the n x n Z of a leaf: 16 n + 8 n^2 bytes)
-        hipLaunchKernelGGL((ql_kernel<true, true>), dim3(nleaf), dim3(64), (size_t)maxleaf * 16 + (size_t)maxleaf * maxleaf * 8,
+        DM_PLAUNCH(ctx, DM_PROF_DC, (ql_kernel<true, true>), dim3(nleaf), dim3(64), (size_t)maxleaf * 16 + (size_t)maxleaf * maxleaf * 8,
                            ctx->stream, d_qm);
       } else {
-        hipLaunchKernelGGL(ql_kernel<true>, dim3(nleaf), dim3(64), (size_t)maxleaf * 16, ctx->stream, d_qm);
-        hipLaunchKernelGGL(zt_identity_kernel, dim3((maxleaf + 255) / 256, maxleaf, nleaf), dim3(256), 0, ctx->stream,
+        DM_PLAUNCH(ctx, DM_PROF_DC, ql_kernel<true>, dim3(nleaf), dim3(64), (size_t)maxleaf * 16, ctx->stream, d_qm);
+        DM_PLAUNCH(ctx, DM_PROF_DC, zt_identity_kernel, dim3((maxleaf + 255) / 256, maxleaf, nleaf), dim3(256), 0, ctx->stream,
                            d_rm);
-        hipLaunchKernelGGL(rot_apply_kernel, dim3((maxleaf + 255) / 256, nleaf), dim3(256), 0, ctx->stream, d_rm);
+        DM_PLAUNCH(ctx, DM_PROF_DC, rot_apply_kernel, dim3((maxleaf + 255) / 256, nleaf), dim3(256), 0, ctx->stream, d_rm);
       }
       DM_HIP(ctx, hipGetLastError());
       std::vector<int> hs(nleaf);
@@ -1606,12 +1606,12 @@ static int dc_solve(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, 
     // levels with a node beyond the LDS capacity take the global-scratch variants (a handful of nodes)
     const bool big = maxnn > DC_MAXNODE;
     if (big)
-      hipLaunchKernelGGL(dc_setup_kernel<true>, dim3(nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
+      DM_PLAUNCH(ctx, DM_PROF_DC, dc_setup_kernel<true>, dim3(nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
     else
-      hipLaunchKernelGGL(dc_setup_kernel<false>, dim3(nn_nodes), dim3(256), (size_t)36 * maxnn + 64, ctx->stream, d_dm,
+      DM_PLAUNCH(ctx, DM_PROF_DC, dc_setup_kernel<false>, dim3(nn_nodes), dim3(256), (size_t)36 * maxnn + 64, ctx->stream, d_dm,
                          d_nodes, d_out);
-    hipLaunchKernelGGL(dc_permute_kernel, dim3(nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
-    hipLaunchKernelGGL(dc_gather_kernel, dim3((maxnn + DCG - 1) / DCG, nn_nodes), dim3(256), 0, ctx->stream, d_dm,
+    DM_PLAUNCH(ctx, DM_PROF_DC, dc_permute_kernel, dim3(nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
+    DM_PLAUNCH(ctx, DM_PROF_DC, dc_gather_kernel, dim3((maxnn + DCG - 1) / DCG, nn_nodes), dim3(256), 0, ctx->stream, d_dm,
                        d_nodes, d_out);
     DM_HIP(ctx, hipGetLastError());
     std::vector<dc_nodeout> ho(nn_nodes);
@@ -1621,13 +1621,13 @@ static int dc_solve(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, 
     if (kmax == 0) continue;
     const int kt = (kmax + 255) / 256;
     if (big)
-      hipLaunchKernelGGL(dc_secular_kernel<true>, dim3(kt, nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
+      DM_PLAUNCH(ctx, DM_PROF_DC, dc_secular_kernel<true>, dim3(kt, nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
     else
-      hipLaunchKernelGGL(dc_secular_kernel<false>, dim3(kt, nn_nodes), dim3(256), (size_t)16 * kmax + 64, ctx->stream,
+      DM_PLAUNCH(ctx, DM_PROF_DC, dc_secular_kernel<false>, dim3(kt, nn_nodes), dim3(256), (size_t)16 * kmax + 64, ctx->stream,
                          d_dm, d_nodes, d_out);
-    hipLaunchKernelGGL(dc_zhat_kernel, dim3(kt, nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
-    hipLaunchKernelGGL(dc_unorm_kernel, dim3(kt, nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
-    hipLaunchKernelGGL(dc_ubuild_kernel, dim3(kt, kmax, nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
+    DM_PLAUNCH(ctx, DM_PROF_DC, dc_zhat_kernel, dim3(kt, nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
+    DM_PLAUNCH(ctx, DM_PROF_DC, dc_unorm_kernel, dim3(kt, nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
+    DM_PLAUNCH(ctx, DM_PROF_DC, dc_ubuild_kernel, dim3(kt, kmax, nn_nodes), dim3(256), 0, ctx->stream, d_dm, d_nodes, d_out);
     DM_HIP(ctx, hipGetLastError());
     std::vector<dm_gemm_desc> g;
     for (int i = 0; i < nn_nodes; ++i) {
@@ -1885,10 +1885,10 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       // the paired chase writes whole rows of the reflector array: only the slots no sweep reaches are cleared
       static const bool pairs = !getenv("DM_SB_NOPAIRS") && !getenv("DM_SB_FULLFILL");
       if (!pairs) DM_TRY(dm_fill_zero(ctx, sbVd, sizeof(cplx) * totvd));
-      else hipLaunchKernelGGL(sb_vd_tail_zero_kernel, dim3((cmax + SBG - 1) / SBG, nc), dim3(256), 0, ctx->stream, d_cmat);
+      else DM_PLAUNCH(ctx, DM_PROF_EIG_OTHER, sb_vd_tail_zero_kernel, dim3((cmax + SBG - 1) / SBG, nc), dim3(256), 0, ctx->stream, d_cmat);
     }
     DM_TRY(dm_fill_zero(ctx, sbTau2, sizeof(cplx) * tott2));
-    hipLaunchKernelGGL(sb_diag_tiles_kernel, dim3((cmax + 127) / 128, nc), dim3(256), 0, ctx->stream, d_dm);
+    DM_PLAUNCH(ctx, DM_PROF_EIG_OTHER, sb_diag_tiles_kernel, dim3((cmax + 127) / 128, nc), dim3(256), 0, ctx->stream, d_dm);
     // ---- S1: dense -> band, one panel of SB columns at a time, all matrices in lock-step
     //
     // A panel is two chains of launches.  The "side" chain needs nothing but the panel itself: QR, Gram slices, T factor,
@@ -2110,7 +2110,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       if (S_.tf.empty()) return DM_OK;
       DM_TRY(dm_gemm_plan_run(ctx, S_.pg, d_pg));
       // T factor of the panel (zlarft from the Gram matrix), straight into the slot the back-transformation reads
-      hipLaunchKernelGGL(larft_kernel, dim3((unsigned)S_.tf.size()), dim3(256), larft_lds, ctx->stream, d_tf);
+      DM_PLAUNCH(ctx, DM_PROF_EIG_OTHER, larft_kernel, dim3((unsigned)S_.tf.size()), dim3(256), larft_lds, ctx->stream, d_tf);
       DM_TRY(dm_gemm_plan_run(ctx, S_.px, d_px));
       return DM_OK;
     };
@@ -2156,7 +2156,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
         if (v.empty()) return DM_OK;
         int mx = 0;
         for (const auto& d : v) mx = std::max(mx, d.rows * d.cols);
-        hipLaunchKernelGGL(sb_sum_partials_kernel, dim3((mx + 255) / 256, (unsigned)v.size()), dim3(256), 0, ctx->stream,
+        DM_PLAUNCH(ctx, DM_PROF_EIG_OTHER, sb_sum_partials_kernel, dim3((mx + 255) / 256, (unsigned)v.size()), dim3(256), 0, ctx->stream,
                            reinterpret_cast<const sb_sum_desc*>(d_extra + o));
         return DM_OK;
       };
@@ -2170,13 +2170,13 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       DM_TRY(launch_sums(mn.sy, o_sy));
       DM_TRY(dm_gemm_plan_run(ctx, mn.pm, dv[4]));
       if (!mn.ssv.empty())
-        hipLaunchKernelGGL(sb_s_kernel, dim3((unsigned)mn.ssv.size()), dim3(256), 0, ctx->stream,
+        DM_PLAUNCH(ctx, DM_PROF_EIG_OTHER, sb_s_kernel, dim3((unsigned)mn.ssv.size()), dim3(256), 0, ctx->stream,
                            reinterpret_cast<const sb_s_desc*>(d_extra + o_ss));
       DM_TRY(dm_gemm_plan_run(ctx, mn.pw, dv[5]));
       side_next_ready = false;
       if (have_next) {
         // snapshot of the next panel's rows + this panel's update of them, then its side chain on the second stream
-        hipLaunchKernelGGL(sb_strip_copy_kernel, dim3((cmax - i0 - SB + 255) / 256, SB, nc), dim3(256), 0, ctx->stream, d_sm, i0);
+        DM_PLAUNCH(ctx, DM_PROF_EIG_OTHER, sb_strip_copy_kernel, dim3((cmax - i0 - SB + 255) / 256, SB, nc), dim3(256), 0, ctx->stream, d_sm, i0);
         DM_TRY(dm_gemm_plan_run(ctx, pstrip, dv[9]));
         hipEvent_t e_go = side_event(16 + ((k0 / SB) & 1));
         DM_HIP(ctx, hipEventRecord(e_go, ctx->stream));
@@ -2206,7 +2206,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
         }
       d_bm = dm_ws_upload(ctx, bm);
       if (!d_bm) return DM_ENOMEM;
-      hipLaunchKernelGGL(sb_band_extract_kernel, dim3((unsigned)((maxel + 255) / 256), nc), dim3(256), 0, ctx->stream, d_bm);
+      DM_PLAUNCH(ctx, DM_PROF_EIG_OTHER, sb_band_extract_kernel, dim3((unsigned)((maxel + 255) / 256), nc), dim3(256), 0, ctx->stream, d_bm);
       if (dump) DM_TRY(dump_arr(".band", sbAB, sizeof(cplx) * totn * SLD));
       // One persistent launch: per-XCD queues of matrix ids; a matrix gets as many entries (= workgroups) as its
       // pipeline of sweeps can keep busy (sweep s + 1 trails sweep s by two blocks: n / (2 SB) sweeps in flight).
@@ -2380,7 +2380,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
       }
-      hipLaunchKernelGGL(trd_small_kernel, dim3(nc), dim3(TST), lds, ctx->stream, d_sm);
+      DM_PLAUNCH(ctx, DM_PROF_TRD_SMALL, trd_small_kernel, dim3(nc), dim3(TST), lds, ctx->stream, d_sm);
       DM_HIP(ctx, hipGetLastError());
       small_path = true;
       return DM_OK;
@@ -2487,9 +2487,9 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
         attr = true;
       }
-      hipLaunchKernelGGL(ql_kernel<true>, dim3(nc), dim3(64), (size_t)cmax * 16, st, d_qm);
+      DM_PLAUNCH(ctx, DM_PROF_DC, ql_kernel<true>, dim3(nc), dim3(64), (size_t)cmax * 16, st, d_qm);
     } else {
-      hipLaunchKernelGGL(ql_kernel<false>, dim3(nc), dim3(64), 0, st, d_qm);
+      DM_PLAUNCH(ctx, DM_PROF_DC, ql_kernel<false>, dim3(nc), dim3(64), 0, st, d_qm);
     }
     if (st != ctx->stream) DM_HIP(ctx, hipEventRecord(side_event(2 * c + 1), st));
     DM_HIP(ctx, hipGetLastError());
@@ -2506,9 +2506,9 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
     for (int p : ch) cmax = std::max(cmax, probs[p].n);
     // T3 (QL path only: D&C delivers the eigenvectors directly)
     if (zfinal.empty()) {
-      hipLaunchKernelGGL(zt_identity_kernel, dim3((cmax + 255) / 256, cmax, nc), dim3(256), 0, ctx->stream,
+      DM_PLAUNCH(ctx, DM_PROF_DC, zt_identity_kernel, dim3((cmax + 255) / 256, cmax, nc), dim3(256), 0, ctx->stream,
                          d_rm_of[c]);
-      hipLaunchKernelGGL(rot_apply_kernel, dim3((cmax + 255) / 256, nc), dim3(256), 0, ctx->stream, d_rm_of[c]);
+      DM_PLAUNCH(ctx, DM_PROF_DC, rot_apply_kernel, dim3((cmax + 255) / 256, nc), dim3(256), 0, ctx->stream, d_rm_of[c]);
     }
     {
       std::vector<dm_cdesc> cp;
@@ -2580,7 +2580,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       if (!zm.empty()) {
         zsel_mat* d_zm = dm_ws_upload(ctx, zm);
         if (!d_zm) return DM_ENOMEM;
-        hipLaunchKernelGGL(zsel_gather_kernel, dim3((maxsel + 3) / 4, (unsigned)zm.size()), dim3(256), 0, ctx->stream, d_zm);
+        DM_PLAUNCH(ctx, DM_PROF_EIG_OTHER, zsel_gather_kernel, dim3((maxsel + 3) / 4, (unsigned)zm.size()), dim3(256), 0, ctx->stream, d_zm);
       }
     }
     // T4: X = Q Z into the (now free) storage of C, block reflectors applied last to first
@@ -2609,7 +2609,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       return DM_OK;
     }
     const int tb = (cmax + 31) / 32;
-    hipLaunchKernelGGL(zt_to_x_kernel, dim3(tb, tb, nc), dim3(256), 0, ctx->stream, d_cm);
+    DM_PLAUNCH(ctx, DM_PROF_EIG_OTHER, zt_to_x_kernel, dim3(tb, tb, nc), dim3(256), 0, ctx->stream, d_cm);
     // two-stage reduction: X <- Q2 X first (the reflectors of the bulge chase), then the blocks of the first stage
     if (two_stage) DM_TRY(apply_q2(ch, ncolv));
     // ---- T factors of all blocks up front (they depend on V only), batched over blocks and matrices:
@@ -2643,7 +2643,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           attr = true;
         }
-        hipLaunchKernelGGL(larft_kernel, dim3((unsigned)tf.size()), dim3(256), lds, ctx->stream, d_tf);
+        DM_PLAUNCH(ctx, DM_PROF_EIG_OTHER, larft_kernel, dim3((unsigned)tf.size()), dim3(256), lds, ctx->stream, d_tf);
       }
     }
     std::deque<dm_gemm_plan> plans;

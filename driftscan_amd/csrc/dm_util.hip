@@ -117,7 +117,7 @@ int dm_conj_transpose_batched(dm_ctx* ctx, const std::vector<dm_tdesc>& v) {
   if (mr == 0 || mc == 0) return DM_OK;
   tdesc* d = dm_ws_upload(ctx, h);
   if (!d) return DM_ENOMEM;
-  hipLaunchKernelGGL(ctrans_batched_kernel, dim3((mc + 31) / 32, (mr + 31) / 32, (unsigned)v.size()), dim3(256), 0,
+  DM_PLAUNCH(ctx, DM_PROF_UTIL, ctrans_batched_kernel, dim3((mc + 31) / 32, (mr + 31) / 32, (unsigned)v.size()), dim3(256), 0,
                      ctx->stream, d);
   DM_HIP(ctx, hipGetLastError());
   return DM_OK;
@@ -132,8 +132,8 @@ static int launch_mdesc(dm_ctx* ctx, const std::vector<dm_mat>& v, int which) {
   mdesc* d = dm_ws_upload(ctx, h);
   if (!d) return DM_ENOMEM;
   dim3 grid((mn + 255) / 256, mn, (unsigned)v.size());
-  if (which == 0) hipLaunchKernelGGL(identity_batched_kernel, grid, dim3(256), 0, ctx->stream, d);
-  else hipLaunchKernelGGL(hermitize_batched_kernel, grid, dim3(256), 0, ctx->stream, d);
+  if (which == 0) DM_PLAUNCH(ctx, DM_PROF_UTIL, identity_batched_kernel, grid, dim3(256), 0, ctx->stream, d);
+  else DM_PLAUNCH(ctx, DM_PROF_UTIL, hermitize_batched_kernel, grid, dim3(256), 0, ctx->stream, d);
   DM_HIP(ctx, hipGetLastError());
   return DM_OK;
 }
@@ -153,14 +153,14 @@ int dm_copy_batched(dm_ctx* ctx, const std::vector<dm_cdesc>& v) {
   cdesc* d = dm_ws_upload(ctx, h);
   if (!d) return DM_ENOMEM;
   const unsigned gx = (unsigned)std::min<size_t>(64, (mb / 16 + 255) / 256 + 1);
-  hipLaunchKernelGGL(copy_batched_kernel, dim3(gx, (unsigned)v.size()), dim3(256), 0, ctx->stream, d);
+  DM_PLAUNCH(ctx, DM_PROF_UTIL, copy_batched_kernel, dim3(gx, (unsigned)v.size()), dim3(256), 0, ctx->stream, d);
   DM_HIP(ctx, hipGetLastError());
   return DM_OK;
 }
 
 int dm_conj_transpose(dm_ctx* ctx, const cplx* src, int lds, cplx* dst, int ldd, int rows, int cols) {
   if (rows <= 0 || cols <= 0) return DM_OK;
-  hipLaunchKernelGGL(ctrans_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, ctx->stream, src, lds,
+  DM_PLAUNCH(ctx, DM_PROF_UTIL, ctrans_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, ctx->stream, src, lds,
                      dst, ldd, rows, cols);
   DM_HIP(ctx, hipGetLastError());
   return DM_OK;
@@ -168,20 +168,21 @@ int dm_conj_transpose(dm_ctx* ctx, const cplx* src, int lds, cplx* dst, int ldd,
 
 int dm_set_identity(dm_ctx* ctx, cplx* a, int ld, int n) {
   if (n <= 0) return DM_OK;
-  hipLaunchKernelGGL(identity_kernel, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream, a, ld, n);
+  DM_PLAUNCH(ctx, DM_PROF_UTIL, identity_kernel, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream, a, ld, n);
   DM_HIP(ctx, hipGetLastError());
   return DM_OK;
 }
 
 int dm_hermitize(dm_ctx* ctx, cplx* a, int ld, int n) {
   if (n <= 0) return DM_OK;
-  hipLaunchKernelGGL(hermitize_kernel, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream, a, ld, n);
+  DM_PLAUNCH(ctx, DM_PROF_UTIL, hermitize_kernel, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream, a, ld, n);
   DM_HIP(ctx, hipGetLastError());
   return DM_OK;
 }
 
 int dm_fill_zero(dm_ctx* ctx, void* p, size_t bytes) {
   if (bytes == 0) return DM_OK;
+  dm_prof_scope ps(ctx, DM_PROF_UTIL, 0.0);
   DM_HIP(ctx, hipMemsetAsync(p, 0, bytes, ctx->stream));
   return DM_OK;
 }

@@ -50,13 +50,18 @@ int dm_version(void);
  * launches and `launches` the number of launches.  Event records cost a marker packet each. */
 int dm_prof_trd_stride(void);
 
-/* Per-kernel-class instrumentation for bench.py: when enabled every launch of the
- * MFMA kernels is bracketed by HIP events on the context's stream.  dm_prof_report
- * fills 12-entry arrays (class 0 grouped ZGEMM, 1 real-B GEMM, 2 Jacobi Gram,
- * 3 Jacobi inner solver, 4 Jacobi apply, 5 real GEMM of the D&C merges, 6 / 7 the one-stage
- * tridiagonalisation kernels [algorithmic BYTES], 8 panel QR, 9 bulge chase, 10 second-stage
- * back-transformation of the two-stage tridiagonalisation, 11 unused) with summed event time [ms],
- * algorithmic flops actually executed, and launch counts since the last reset. */
+/* Per-kernel-class instrumentation for bench.py: when enabled (1) every launch of the MFMA / HBM-bound kernel
+ * classes is bracketed by HIP events on the context's stream (sampled as dm_prof_trd_stride describes); with
+ * enable = 2 every remaining kernel of the path is bracketed as well (the "extended" classes, time only).
+ * dm_prof_report fills 24-entry arrays with summed event time [ms], algorithmic flops actually executed and launch
+ * counts since the last reset:
+ *   0 grouped ZGEMM, 1 real-B GEMM, 2 Jacobi Gram, 3 Jacobi inner solver, 4 Jacobi apply, 5 real GEMM of the D&C merges,
+ *   6 / 7 the one-stage tridiagonalisation kernels [algorithmic BYTES], 8 panel QR, 9 bulge chase, 10 second-stage
+ *   back-transformation of the two-stage tridiagonalisation, 11 gathered-B ZGEMM (the covariance projections);
+ *   extended: 12 fused ring transform of BT-gen, 13 other BT-gen kernels, 14 LDS-resident small tridiagonalisation,
+ *   15 divide & conquer (without its real GEMMs), 16 Cholesky panels + triangular diagonal solves, 17 transposes /
+ *   copies / scans, 18 T factors / slice sums / gathers of the eigensolver, 19 Jacobi-engine and SVD-chain helpers,
+ *   20-23 unused. */
 int dm_prof_reset(dm_ctx* ctx, int enable);
 int dm_prof_report(dm_ctx* ctx, double* ms, double* flops, long long* launches);
 
