@@ -73,11 +73,13 @@ def parse_args(argv=None):
                     help="untimed passes of the hot path before the warm-up steps (settles a fresh box; 0 to skip)")
     ap.add_argument("--mode", choices=["weak", "sharded"], default=None,
                     help="default: weak at --gpus 1 (one full workload), sharded at --gpus N > 1 (ONE workload in m-ranges)")
-    ap.add_argument("--workload", choices=["configs1", "configs2", "configs3"], default="configs1",
+    ap.add_argument("--workload", choices=["configs1", "configs2", "configs3", "configs4"], default="configs1",
                     help="configs1 = BASELINE configs[1] (the default line); configs2 / configs3 = the north-star job "
                          "(128-feed polarised cylinder, nfreq 64, lmax 512; configs3 adds DoubleKL + the exact Fisher matrix) "
                          "through ProductManager.generate(): one rank's share of the 8-GPU job on this GPU")
     ap.add_argument("--share", default="0/8", help="--workload configs2|configs3: which rank's share, as r/N")
+    ap.add_argument("--m", type=int, default=300, help="--workload configs4: which m-block")
+    ap.add_argument("--no-checks", action="store_true", help="--workload configs4: skip the property checks of the products")
     ap.add_argument("--files", action="store_true",
                     help="--workload configs2|configs3: write the product files (default: products stay in HBM)")
     ap.add_argument("--share-mmax", type=int, default=None, help=argparse.SUPPRESS)  # any value: toy telescope (rehearsal)
@@ -530,6 +532,159 @@ def run_share(args):
     return 0
 
 
+CFG5 = dict(num_freq=256, freq_start=400.0, freq_end=800.0, freq_mode="edge", num_cylinders=4, cylinder_width=14.5,
+            num_feeds=64, feed_spacing=0.3, tsys=1.0, force_lmax=1024, force_mmax=1024)
+
+
+def measure_configs4_block(m=300, checks=True, workspace_gb=100, bt_gb=24, log=None):
+    """BASELINE configs[4] (CHIME-like: 512 feeds, nfreq 256, lmax = mmax = 1024, HBM-bound per-m blocks): ONE real m-block
+    through the product classes — BT-gen of the 59.6 GB block, the SVD chain of all 256 frequencies (the library slices
+    them), the KL transform of the block (ndof ~32 600: one generalised eigenproblem in a ~140 GB arena) — with per-stage
+    seconds, every kernel class, and (checks) the size-independent properties of the products."""
+    import tempfile
+
+    import numpy as np
+    import torch
+
+    from driftscan_amd import beamtransfer, btgen, cylinder, device, kltransform
+
+    log = log or (lambda *a: None)
+    os.environ["DRIFTMI_STORAGE"] = "discard"
+    device.reset_context()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    tel = cylinder.PolarisedCylinderTelescope.from_config(dict(CFG5))
+    ctx = device.get_context(workspace_bytes=int(workspace_gb) << 30)
+    rec = dict(m=int(m), nfreq=int(tel.nfreq), nbase=int(tel.nbase), lmax=int(tel.lmax), mmax=int(tel.mmax),
+               sht_iter=int(tel.sht_iter))
+
+    def sync():
+        ctx.sync()
+        torch.cuda.synchronize()
+
+    with tempfile.TemporaryDirectory() as tmp:
+        bt = beamtransfer.BeamTransfer(tmp, telescope=tel)
+        kl = kltransform.KLTransform.from_config(dict(threshold=0.1), bt, subdir="kl")
+        kl.signal(); kl.foreground()                      # host C_l tables: once per job, untimed
+        # ---- BT-gen of the block
+        ctx.prof_reset(2)
+        sync()
+        t0 = time.perf_counter()
+        beam = btgen.beam_m_all(tel, ctx=ctx, max_bytes=int(bt_gb) << 30, m_range=(m, m))
+        sync()
+        rec["btgen_s"] = time.perf_counter() - t0
+        rec["btgen_classes"] = class_table(ctx.prof_report())
+        rec["beam_block_gb"] = beam.numel() * 16 / 2 ** 30
+        log("configs[4] m = %d: BT-gen of the %.1f GB block %.1f s" % (m, rec["beam_block_gb"], rec["btgen_s"]))
+        # ---- SVD chain + pinv, all frequencies
+        ctx.prof_reset(2)
+        sync()
+        t0 = time.perf_counter()
+        out = bt.svd_device(beam)
+        sync()
+        rec["svd_s"] = time.perf_counter() - t0
+        rec["svd_classes"] = class_table(ctx.prof_report())
+        sv = out["singularvalues"].cpu().numpy()
+        bt._dev[m] = dict(beam_svd=out["beam_svd"][0], beam_ut=out["beam_ut"][0], singularvalues=sv[0])
+        svnum, _ = bt._svd_num(m)
+        rec["ndof"] = int(svnum.sum())
+        rec["modes_per_frequency"] = [int(svnum.min()), int(svnum.max())]
+        rec["svd_sweeps"] = [int(x) for x in np.asarray(out.get("sweeps", [])).reshape(-1)][:8]
+        log("configs[4] m = %d: SVD chain + pinv of %d frequencies %.1f s, ndof %d (%d..%d modes per frequency)"
+            % (m, tel.nfreq, rec["svd_s"], rec["ndof"], svnum.min(), svnum.max()))
+        if checks:
+            T, P, L = bt.ntel, tel.num_pol_sky, tel.lmax + 1
+            noisew = bt._noisew()
+            wu = wp = 0.0
+            for fi in (0, tel.nfreq // 2, tel.nfreq - 1):
+                n = int(svnum[fi])
+                if n == 0:
+                    continue
+                u = out["beam_ut"][0, fi, :n].cpu().numpy() / noisew[fi][None, :]
+                b2 = out["beam_svd"][0, fi, :n].cpu().numpy().reshape(n, P * L)
+                i2 = out["invbeam_svd"][0, fi].cpu().numpy().reshape(P * L, -1)[:, :n]
+                wu = max(wu, float(np.abs(u @ u.conj().T - np.eye(n)).max()))
+                wp = max(wp, float(np.abs(b2 @ i2 - np.eye(n)).max()))
+            rec["check_ut_orth"], rec["check_beam_pinv"] = wu, wp
+            log("configs[4] m = %d: |U U^H - I| %.2e, |beam_svd invbeam_svd - I| %.2e" % (m, wu, wp))
+        del beam
+        out.pop("invbeam_svd", None)
+        torch.cuda.empty_cache()
+        # ---- KL: covariance projections + the generalised eigenproblem of the REAL pencil
+        Sh = Nh = None
+        if checks:   # the pencil itself, parked in page-locked host memory (eigh_gen destroys its inputs, and the arena
+            S, N, ndofs, off = kl.sn_covariance_device([m])      # of the eigensolver needs the card to itself)
+            sync()
+            n = int(ndofs[0])
+            Sh, Nh = ctx.to_host(S[: n * n]), ctx.to_host(N[: n * n])
+            del S, N
+            torch.cuda.empty_cache()
+        ctx.prof_reset(2)
+        sync()
+        t0 = time.perf_counter()
+        r = kl._transform_batch([m], to_host=False)[0]
+        ctx = device.get_context()
+        sync()
+        rec["kl_s"] = time.perf_counter() - t0
+        rec["kl_classes"] = class_table(ctx.prof_report())
+        ev = r[0].cpu().numpy()
+        n = ev.size
+        rec["kl_nkept"] = int((ev >= kl.threshold).sum())
+        rec["kl_add_const"] = float(r[3]["ac"])
+        rec["kl_evals_min_max"] = [float(ev.min()), float(ev.max())]
+        rec["workspace_gb"] = ctx.lib.dm_ctx_workspace_bytes(ctx.h) / 2 ** 30
+        log("configs[4] m = %d: KL (projections + eigh_gen, n = %d) %.1f s, %d modes kept, arena %.0f GB"
+            % (m, n, rec["kl_s"], rec["kl_nkept"], rec["workspace_gb"]))
+        if checks and rec["kl_nkept"] > 0:
+            E = r[1]                                       # (n, n) device, rows = modes, ascending eigenvalue
+            ctx.workspace_reset(1 << 30)
+            torch.cuda.empty_cache()
+            i0 = n - rec["kl_nkept"]
+            pick = np.unique(np.linspace(i0, n - 1, min(256, rec["kl_nkept"])).astype(np.int64))
+            Ek = E[torch.as_tensor(pick, device=E.device)]
+            lam = torch.as_tensor(ev[pick], device=E.device)
+            res_ = {}
+            for name, Mh in (("N", Nh), ("S", Sh)):
+                M = ctx.to_device(Mh).view(n, n)
+                res_[name] = (Ek @ M) @ Ek.conj().T        # checker arithmetic (torch), not the product path
+                del M
+            eye = torch.eye(pick.size, dtype=res_["N"].dtype, device=E.device)
+            ese = res_["S"]
+            rec["check_ENE"] = float((res_["N"] - eye).abs().max().item())
+            rec["check_ESE_offdiag"] = float(((ese - torch.diag(torch.diagonal(ese))).abs().max() / ese.abs().max()).item())
+            rec["check_ESE_diag"] = float(((torch.diagonal(ese).real - lam).abs().max() / lam.abs().max()).item())
+            log("configs[4] m = %d: |E N E^H - I| %.2e, offdiag(E S E^H)/max %.2e, diag vs lambda %.2e (sample of %d kept modes)"
+                % (m, rec["check_ENE"], rec["check_ESE_offdiag"], rec["check_ESE_diag"], pick.size))
+        rec["hbm_peak_gb"] = torch.cuda.max_memory_allocated() / 2 ** 30
+        bt._dev.pop(m, None)
+        del r, out
+    beamtransfer.BeamTransfer._clcache.clear()
+    device.reset_context()
+    torch.cuda.empty_cache()
+    # what a whole configs[4] job would cost at this block's rate (1025 blocks over 8 GPUs, BT-gen in calls of two blocks)
+    per_block = rec["svd_s"] + rec["kl_s"] + rec["btgen_s"]
+    rec["per_block_s"] = per_block
+    rec["projected_8gpu_job_h"] = per_block * (tel.mmax + 1) / 8.0 / 3600.0
+    rec["projection_note"] = ("%d m-blocks / 8 GPUs x (BT-gen + SVD + KL of this block); m = %d has about the median ndof — the low-m "
+                              "blocks cost more in KL, the high-m ones less (ndof falls with m)" % (tel.mmax + 1, m))
+    return rec
+
+
+def run_configs4(args):
+    rec = measure_configs4_block(args.m, checks=not args.no_checks,
+                                 log=lambda *a: print(time.strftime("%H:%M:%S"), *a, file=sys.stderr, flush=True))
+    line = {"metric": "m-blocks/sec (BT-gen + SVD + KL)", "value": 1.0 / rec["per_block_s"], "unit": "m-blocks/s", "n_gpus": 1,
+            "steps": 1, "warmup": 0, "ms_per_step": 1e3 * rec["per_block_s"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[4]: CHIME-like 512-feed polarised cylinder, nfreq=256, nbase=1776, lmax=mmax=1024: ONE "
+                                   "real m-block (m = %d) through BeamTransfer / KLTransform" % rec["m"],
+                       "nfreq": 256, "nbase": 1776, "lmax": 1024, "mmax": 1024, "sht_iter": rec["sht_iter"]},
+            "block": rec, "roofline": None, "cpu_baseline": None}
+    print(json.dumps(line))
+    sys.stdout.flush()
+    return 0
+
+
 def north_star_leg(args):
     """The north-star workload inside the default line: one rank's share (default 0/8: the slowest) of the BASELINE
     configs[2] job through ProductManager.generate(), with every kernel class timed.  Runs after the timed configs[1]
@@ -572,6 +727,8 @@ def main():
     if args.cpu_worker:
         cpu_worker_main(*args.cpu_worker)
         return 0
+    if args.workload == "configs4":
+        return run_configs4(args)
     if args.workload != "configs1":
         return run_share(args)
     if args.mode is None:
@@ -616,8 +773,10 @@ def main():
         nblocks = tel.mmax + 1
         m_range = None
         if args.mode == "sharded" and world > 1:
+            # the product's own cost model (BeamTransfer._m_cost: BT-gen flat in m, the SVD chain linear, the KL stage cubic
+            # in the number of l >= m) — the ranges `ProductManager.generate()` would give the ranks
             allm = list(range(nblocks))
-            mine = parallel.partition_contiguous(allm, [float(tel.lmax + 1 - m) + 1.0 for m in allm])
+            mine = parallel.partition_contiguous(allm, [bt._m_cost(m) for m in allm])
             m_range = (mine[0], mine[-1])
         collect = world > 1 or force_dist
         # Device priming, before the W warm-up steps: a fresh box runs its first ~1.5 s of GPU work about 4 % slower
@@ -647,6 +806,7 @@ def main():
         for _ in range(args.steps):
             hot_path_step(tel, bt, kl, ctx, streams=args.streams, m_range=m_range, collect=collect)
         torch.cuda.synchronize()
+        t_own = time.perf_counter() - t0      # this rank's own K steps (before it waits for the others)
         parallel.barrier()
         dt = time.perf_counter() - t0
         prof = {}
@@ -694,10 +854,18 @@ def main():
         if world > 1 or force_dist:
             import torch.distributed as dist
 
-            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dev_ = "cuda" if args.backend == "nccl" else "cpu"
+            tmine = torch.tensor([t_own, float(m_range[0] if m_range else 0), float(m_range[1] if m_range else nblocks - 1)],
+                                 dtype=torch.float64, device=dev_)
+            tall = [torch.zeros_like(tmine) for _ in range(world)]
+            dist.all_gather(tall, tmine)
+            rank_info = [dict(rank=r, step_ms=1e3 * float(t[0]) / args.steps, m_lo=int(t[1]), m_hi=int(t[2])) for r, t in enumerate(tall)]
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev_)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         sharded = m_range is not None
+        if not (world > 1 or force_dist):
+            rank_info = [dict(rank=0, step_ms=1e3 * dt / args.steps, m_lo=0, m_hi=nblocks - 1)]
         value = (nblocks if sharded else world * nblocks) * args.steps / dt
         if rank == 0:
             st = np.array(stage).mean(axis=0)
@@ -829,6 +997,12 @@ def main():
                            "streams_per_gpu": args.streams,
                            "kl_products": "all eigenvalues + every mode" if args.all_modes else
                            "all eigenvalues + the modes with S/N >= threshold (subset = True, what transform_save writes)"},
+                "ranks": {"per_rank": rank_info,
+                          "imbalance_max_over_mean": max(r["step_ms"] for r in rank_info) / (sum(r["step_ms"] for r in rank_info) / len(rank_info)),
+                          "note": "time of each rank over the K timed steps (its own clock between the two barriers); `value` uses the "
+                                  "MAX.  Sharded mode: the step of a rank is a lock-step chain of a few hundred launches whose length "
+                                  "follows the LARGEST matrix of its range, not the number of blocks — strong scaling of this small "
+                                  "workload is bounded by that chain (DESIGN.md section 6)"},
                 "stage_ms": {"btgen": 1e3 * st[0], "svd": 1e3 * st[1], "kl": 1e3 * st[2], "collectives": 1e3 * st[3]},
                 "stages": stages,
                 "btgen": {"btgen_iter0_ms": bt_ms.get(0), "btgen_iter3_ms": bt_ms.get(3),

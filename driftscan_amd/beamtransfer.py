@@ -224,8 +224,8 @@ class BeamTransfer(config.Reader):
             del beam_all
         storage.flush()
         parallel.barrier()
-        if parallel.rank0() and not storage.discard():
-            open(marker, "a").close()
+        if parallel.rank0() and not storage.discard() and not parallel.is_virtual():
+            open(marker, "a").close()     # (an emulated share is not the whole job: no marker)
         if not skip_svd:
             self._collect_svd_spectrum()
         parallel.barrier()
@@ -309,7 +309,8 @@ class BeamTransfer(config.Reader):
         storage.flush()
         parallel.barrier()
         if parallel.rank0():
-            open(marker, "a").close()
+            if not parallel.is_virtual():
+                open(marker, "a").close()
             logger.info("=== beam_m generation took %f s ===" % (time.time() - st))
 
     def _noisew(self):
@@ -433,7 +434,7 @@ class BeamTransfer(config.Reader):
             for part in allparts:
                 for mi, sv in part:
                     spec[mi] = sv
-            if not storage.discard():
+            if not storage.discard() and not parallel.is_virtual():
                 with storage.File(self.directory + "/svdspectrum.hdf5", "w") as f:
                     f.create_dataset("singularvalues", data=spec)
         parallel.barrier()
@@ -492,11 +493,17 @@ class BeamTransfer(config.Reader):
         key = id(mat)
         cache = BeamTransfer._clcache
         if key not in cache or cache[key][0] is not mat:
+            # uploaded as it lies; the pol-pair mask, the symmetry test and the (.., F, F, L) layout are made on the device
+            # (on the host the strided transposition of a configs[2] table — 270 MB — takes two seconds, with the GPU idle
+            # in front of the first KL batch)
+            import torch
+
             P = mat.shape[0]
-            m64 = np.asarray(mat, dtype=np.float64)
-            mask = (np.abs(m64).reshape(P, P, -1).max(axis=-1) > 0).astype(np.int32)
-            sym = bool(np.array_equal(m64, m64.swapaxes(3, 4)))
-            dev = ctx.to_device(np.ascontiguousarray(m64.transpose(0, 1, 3, 4, 2)))
+            dev0 = ctx.to_device(np.ascontiguousarray(np.asarray(mat, dtype=np.float64)))
+            mask = (dev0.abs().reshape(P, P, -1).amax(dim=-1) > 0).to(torch.int32).cpu().numpy()
+            sym = bool(torch.equal(dev0, dev0.transpose(3, 4)))
+            dev = dev0.permute(0, 1, 3, 4, 2).contiguous()
+            del dev0
             if len(cache) > 8:
                 cache.clear()
             cache[key] = (mat, dev, mask, sym)
@@ -512,7 +519,9 @@ class BeamTransfer(config.Reader):
 
         memo = self.__dict__.setdefault("_stack_memo", {})
         tens = [self._dev_products(mi)[key] for mi in ms]
-        sig = (key, tuple(ms), tuple(t.data_ptr() for t in tens[:2]), tens[-1].data_ptr() if tens else 0)
+        if not tens:
+            return torch.empty((0,), dtype=torch.complex128, device="cuda")
+        sig = (key, tuple(ms), tuple(t.data_ptr() for t in tens[:2]), tens[-1].data_ptr())
         hit = memo.get(key)
         if hit is not None and hit[0] == sig:
             return hit[1]
@@ -524,10 +533,10 @@ class BeamTransfer(config.Reader):
             for i, t in enumerate(tens))
         if same and t0.numel() > 0:
             out = torch.as_strided(t0, (len(tens),) + tuple(t0.shape), (t0.numel(),) + tuple(t0.stride()))
-        else:
-            out = torch.stack(tens)
-        memo[key] = (sig, out)
-        return out
+            memo[key] = (sig, out)   # a VIEW of the batch result: valid as long as the addresses in `sig` are
+            return out
+        memo.pop(key, None)          # a stacked COPY is never remembered (the allocator may hand the same addresses out again)
+        return torch.stack(tens)
 
     def project_matrix_sky_to_svd_device(self, ms, mat, out, off, temponly=False, zero_first=True):
         """Batched form: project `mat` for all m in `ms` into the flat device buffer `out`."""

@@ -49,8 +49,12 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
     frame = telescope_frame(tel.zenith)
     # the band limits and resolutions of the columns depend on the telescope and the column list only: remembered per list
     # (a rank calls this once per m-range with the same columns; the host work between two calls is idle GPU time)
+    # (the key carries everything the band limits and resolutions follow from: a telescope changed after a first call
+    # gets new ones; `TransitTelescope.__getstate__` keeps the memo out of the telescope pickle)
     memo = tel.__dict__.setdefault("_btgen_memo", {})
-    mkey = (f_list.tobytes(), b_list.tobytes(), lside)
+    mkey = (f_list.tobytes(), b_list.tobytes(), lside, float(tel.l_boost), float(tel.accuracy_boost), int(tel.num_pol_sky),
+            np.asarray(tel.wavelengths, dtype=np.float64).tobytes(), np.asarray(tel.baselines, dtype=np.float64).tobytes(),
+            float(getattr(tel, "u_width", 0.0)), float(getattr(tel, "v_width", 0.0)))
     if mkey not in memo:
         if len(memo) > 8:
             memo.clear()

@@ -728,6 +728,17 @@ struct sb_chase_mat {
 struct sb_chase_ctl { int* qhead; const int* qent; int* err; unsigned long long* dbg; int qoff[9]; };
 
 constexpr unsigned SB_DONE = 0xffffu;
+// A wave that polls a progress word gives up after this much WALL time (ticks of the constant 100 MHz counter behind
+// wall_clock64: 30 s) — far beyond any chase (the n = 32 576 chase takes 1.5 s in all), so that slow clocks or a
+// time-sliced card cannot turn into a failed batch, while a genuine deadlock still drains the grid.
+constexpr unsigned long long SB_WAIT_TICKS = 30ull * 100000000ull;
+// The hand-off protocol of the chase — band data written with plain stores, read back by another workgroup of the SAME XCD
+// with sc1 loads, progress words as agent-scope atomics — relies on the gfx942 / gfx950 cache behaviour: vector stores
+// write through to the XCD's L2, sc1 loads are served by that L2 and never by a stale L1 line.  The queue hands a matrix
+// to one XCD only (the first workgroup to touch it claims it for its XCC_ID).  Built for gfx950 only:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "dm_sbr_impl.h: the bulge-chase hand-offs assume the gfx942 / gfx950 L2 write-through + sc1 semantics"
+#endif
 
 typedef unsigned int sb_u4 __attribute__((ext_vector_type(4)));
 // sc1 loads: served by the XCD's L2, bypassing the vector L1 of this CU (element index in units of cplx / dwords)
@@ -761,13 +772,16 @@ __device__ __forceinline__ void sb_chase_sweep(const sb_chase_mat& M, __amdgpu_b
       // (an atomic load: a plain one would be hoisted out of the loop; agent scope = sc1 = served by L2)
       int spins = 0;
       bool bail = false;
+      const unsigned long long t_wait0 = wall_clock64();
       for (;;) {
         const unsigned v = __hip_atomic_load(M.prog + (s - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (v >= (unsigned)(j + 2)) { seen = v; break; }
         __builtin_amdgcn_s_sleep(1);
-        // never in a correct run: every wave leaves instead of hanging the GPU (the host reports the failure)
+        // never in a correct run: every wave leaves instead of hanging the GPU (the host reports the failure).  The
+        // limit is WALL time (SB_WAIT_TICKS of the 100 MHz counter), not a poll count: a predecessor that was
+        // descheduled for a while (another process on the card, clock throttling) is not a failure
         ++spins;
-        if (spins > (1 << 20)) {
+        if ((spins & 1023) == 0 && wall_clock64() - t_wait0 > SB_WAIT_TICKS) {
           if (lane == 0) atomicCAS(err, 0, 1 + s + (j << 12) + ((int)(v & 0xff) << 20));  // first failure wins
           bail = true;
         }
@@ -1046,12 +1060,13 @@ __device__ __forceinline__ void sb_lds_st(int* p, int v) { __hip_atomic_store(p,
 __device__ __forceinline__ bool sb_wait_prog(const unsigned* word, unsigned need, unsigned& seen, int* err, int code, int lane) {
   if (seen >= need) return true;
   int spins = 0;
+  const unsigned long long t_wait0 = wall_clock64();
   for (;;) {
     const unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (v >= need) { seen = v; break; }
     __builtin_amdgcn_s_sleep(1);
     ++spins;
-    if (spins > (1 << 20)) {
+    if ((spins & 1023) == 0 && wall_clock64() - t_wait0 > SB_WAIT_TICKS) {   // wall time, not a poll count
       if (lane == 0) atomicCAS(err, 0, code);
       return false;
     }
@@ -1064,11 +1079,12 @@ __device__ __forceinline__ bool sb_wait_prog(const unsigned* word, unsigned need
 template <typename P>
 __device__ __forceinline__ bool sb_wait_lds(int* word, P pred, int* err, int code, int lane) {
   int spins = 0;
+  const unsigned long long t_wait0 = wall_clock64();
   for (;;) {
     if (pred(sb_lds_ld(word))) break;
     __builtin_amdgcn_s_sleep(1);
     ++spins;
-    if (spins > (1 << 22)) {
+    if ((spins & 4095) == 0 && wall_clock64() - t_wait0 > SB_WAIT_TICKS) {
       if (lane == 0) atomicCAS(err, 0, code);
       return false;
     }

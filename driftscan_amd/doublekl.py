@@ -167,7 +167,7 @@ class DoubleKL(kltransform.KLTransform):
         parts = parallel.gather_objects(mine)
         if parallel.rank0():
             fname = self.evdir + "/evals.hdf5"
-            if os.path.exists(fname) or storage.discard():
+            if os.path.exists(fname) or storage.discard() or parallel.is_virtual():
                 return
             arr = np.zeros((self.telescope.mmax + 1, 2, nd))
             for part in parts:

@@ -308,14 +308,28 @@ class KLTransform(config.Reader):
         """KL-transform every m of this rank and save (kltransform.py:480-513); m already done by `generate_ms` during
         beam-transfer generation are skipped."""
         st = time.time()
+        storage.flush()          # the files of the batches `generate_ms` has handed to the writer pool
+        done = self.__dict__.get("_done")
         if regen:
             self.__dict__.pop("_done", None)
+        elif done and not storage.discard():
+            # like the reference, the FILES decide what is done (kltransform.py:497-501): an m this object transformed
+            # earlier whose file has gone since is made again
+            for mi in [mi for mi in done if not os.path.exists(self._evfile % mi)]:
+                done.discard(mi)
+                self.__dict__.get("_evals_full_mem", {}).pop(mi, None)
+                self.__dict__.get("_extra_mem", {}).pop(mi, None)
         self.generate_ms(self.beamtransfer._my_ms(), regen)
         storage.flush()
         parallel.barrier()
         if parallel.rank0():
             logger.info("======== Ending KL calculation (time=%f) ========" % (time.time() - st))
         self._collect()
+        if not storage.discard():
+            # what this run remembered about its own m (spectra for `_collect`, the done set) ends with it: a later call
+            # goes by the files alone
+            for k in ("_done", "_evals_full_mem", "_extra_mem"):
+                self.__dict__.pop(k, None)
 
     # ---- spectra ---------------------------------------------------------------------------
     def evals_all(self):
@@ -340,7 +354,7 @@ class KLTransform(config.Reader):
         mine = [(mi, self._evfunc(mi)) for mi in self.beamtransfer._my_ms()]
         parts = parallel.gather_objects(mine)
         if parallel.rank0():
-            if os.path.exists(self.evdir + "/evals.hdf5") or storage.discard():
+            if os.path.exists(self.evdir + "/evals.hdf5") or storage.discard() or parallel.is_virtual():
                 return
             arr = np.zeros((self.telescope.mmax + 1, self.beamtransfer.ndofmax))
             for part in parts:

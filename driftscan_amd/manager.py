@@ -154,7 +154,14 @@ class ProductManager(object):
                     if "_mode_cache" in klobj.__dict__:
                         klobj.__dict__["_mode_cache"].clear()
 
-            self.beamtransfer.generate(skip_svd=self.skip_svd, after_batch=after_batch if (kls and not self.skip_svd) else None)
+            resident = bool(kls) and not self.skip_svd
+            if resident:
+                # every rank opens its local Fisher sums NOW — also one whose range of m is empty and that never sees a
+                # batch: `PSEstimation.generate` decides between "my range of the resident pipeline" and the file-based
+                # partition by the presence of these sums, and that choice has to be the same on all ranks
+                for psobj in pss:
+                    psobj.accumulate_ms([])
+            self.beamtransfer.generate(skip_svd=self.skip_svd, after_batch=after_batch if resident else None)
         if self.gen_kl:
             for klname, klobj in self.kltransforms.items():
                 klobj.generate()

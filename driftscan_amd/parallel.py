@@ -26,17 +26,18 @@ _virtual = None
 
 
 def set_virtual(r=None, n=None):
-    """Emulate rank `r` of `n` (None: off).  Also read from DRIFT_VIRTUAL_RANK / DRIFT_VIRTUAL_SIZE."""
+    """Emulate rank `r` of `n` (None: off) — for measurements only (`bench.py --share r/n`): while it is on, the
+    collected files and the `beam_m/COMPLETED` marker are NOT written (they would describe one share as the whole job)."""
     global _virtual
     _virtual = None if r is None else (int(r), int(n))
 
 
 def _virt():
-    if _virtual is not None:
-        return _virtual
-    if "DRIFT_VIRTUAL_SIZE" in os.environ:
-        return int(os.environ.get("DRIFT_VIRTUAL_RANK", "0")), int(os.environ["DRIFT_VIRTUAL_SIZE"])
-    return None
+    return _virtual
+
+
+def is_virtual():
+    return _virtual is not None and _dist() is None
 
 
 def rank():

@@ -100,6 +100,13 @@ class TransitTelescope(config.Reader):
     skip_baselines = config.list_type(type_=int, default=[])
 
     _bl_tol = 6  # decimals kept when comparing separations (telescope.py:554)
+
+    def __getstate__(self):
+        """The telescope pickle (bt/telescopeobject.pickle, beamtransfer.py:199-202) holds the description, not the
+        per-process memo of BT-gen band limits."""
+        state = dict(self.__dict__)
+        state.pop("_btgen_memo", None)
+        return state
     _npol_sky_ = 1
 
     def __init__(self, latitude=45, longitude=0, **kwargs):

@@ -1,7 +1,7 @@
 """BASELINE.json configs[2] / [3] / [4] under `pytest -m gpu`.
 
 configs[2]  128-feed polarised cylinder (4 x 16 dual-pol feeds), nfreq = 64, lmax = mmax = 512:
-            three m-blocks (m = 1, 200, 460; 864 x 2052 per frequency, ndof ~5800 / ~3750 / ~450) go through
+            four m-blocks (m = 0, 1, 200, 460; 864 x 2052 per frequency, ndof ~5800 / ~5800 / ~3750 / ~450) go through
             BT-gen -> SVD chain + pinv -> KL on the device.  This reaches what the small fixtures cannot: the
             multi-level Jacobi preconditioner, the 64-wide tridiagonal panels, D&C merge nodes beyond LDS.
             Checked: (f, b) columns of beam_m against the oracle's pixel-space restatement; the size-independent
@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 
 CFG3 = dict(num_freq=64, freq_start=400.0, freq_end=500.0, freq_mode="edge", num_cylinders=4, cylinder_width=12.0,
             num_feeds=16, feed_spacing=0.4, tsys=1.0, force_lmax=512, force_mmax=512)
-MS = [1, 200, 460]
+MS = [0, 1, 200, 460]
 
 
 def _log(*a):
@@ -55,7 +55,7 @@ def c3(tmp_path_factory, golden_dir):
     bt = beamtransfer.BeamTransfer(str(tmp_path_factory.mktemp("c3")), telescope=tel)
     t0 = time.perf_counter()
     blocks = [btgen.beam_m_all(tel, ctx=ctx, max_bytes=24 << 30, m_range=(m, m)) for m in MS]
-    beam = torch.cat(blocks)                         # (3, F, 2, B, P, L)
+    beam = torch.cat(blocks)                         # (len(MS), F, 2, B, P, L)
     del blocks
     ctx.sync()
     t1 = time.perf_counter()
@@ -66,7 +66,7 @@ def c3(tmp_path_factory, golden_dir):
     for i, mi in enumerate(MS):
         bt._dev[mi] = dict(beam_svd=res["beam_svd"][i], beam_ut=res["beam_ut"][i], singularvalues=sv[i])
     kl = kltransform.KLTransform.from_config(dict(threshold=0.1), bt, subdir="kl")
-    _log("configs[2] fixture: BT-gen of 3 blocks %.1f s, SVD chain %.1f s (sweeps %s), ndof %s"
+    _log("configs[2] fixture: BT-gen of %d blocks" % len(MS) + " %.1f s, SVD chain %.1f s (sweeps %s), ndof %s"
          % (t1 - t0, t2 - t1, res["sweeps"], [int(bt.ndof(m)) for m in MS]))
     yield dict(tel=tel, bt=bt, kl=kl, ctx=ctx, beam=beam, res=res, sv=sv)
     bt._dev.clear()
@@ -170,7 +170,7 @@ def test_smallest_block_against_oracle_chain(c3):
     c3["cs460"], c3["cn460"] = cs, cn
 
 
-@pytest.mark.parametrize("mi,bound", [(460, 1e-9), (200, 1e-9), (1, 1e-4)])
+@pytest.mark.parametrize("mi,bound", [(460, 1e-9), (200, 1e-9), (1, 1e-4), (0, 1e-4)])
 def test_kl_properties(c3, mi, bound):
     """E N E^H = I and E S E^H = diag(lambda) on (a sample of) the kept modes (kltransform.py:339-345).  The
     bound is the conditioning of N: at m = 1 foregrounds against thermal noise give cond(N) ~ 1e11 and LAPACK's
@@ -223,7 +223,7 @@ def test_doublekl_and_fisher_config4(c3):
     dk = doublekl.DoubleKL.from_config(dict(threshold=0.1, foreground_threshold=100.0), bt, subdir="dk")
     t0 = time.perf_counter()
     out = dk._transform_batch(MS, to_host=True)
-    _log("DoubleKL of 3 blocks: %.2f s" % (time.perf_counter() - t0))
+    _log("DoubleKL of the blocks: %.2f s" % (time.perf_counter() - t0))
     i = MS.index(460)
     bs, bu = res["beam_svd"][i].cpu().numpy(), res["beam_ut"][i].cpu().numpy()
 
@@ -250,7 +250,8 @@ def test_doublekl_and_fisher_config4(c3):
         fe = ex["f_evals"]
         assert fe.size == int(bt.ndof(mi)) and np.all(np.diff(fe) >= 0)
         assert ev2.size == int((fe > 100.0).sum())
-        if ev2.size == 0 or mi == 1:
+        _log("m %d: DoubleKL stage-1 shift (the reference's non-PD rescue, kltransform.py:101-111) %.3e" % (mi, ex["ac"]))
+        if ev2.size == 0:
             continue
         S, N = kl.sn_covariance(mi)
         i2 = int(np.searchsorted(ev2, dk.threshold))
@@ -264,7 +265,14 @@ def test_doublekl_and_fisher_config4(c3):
         e2 = float(np.abs(np.diag(d).real - ev2[pick]).max() / np.abs(ev2).max())
         _log("m %d: DoubleKL modes %d (S/N >= %.1f: %d): |M N M^H - I| %.2e, diag(M S M^H) vs evals %.2e"
              % (mi, ev2.size, dk.threshold, ev2.size - i2, e1, e2))
-        assert e1 < 1e-7 and e2 < 1e-7
+        # low m: foregrounds against thermal noise, cond(N) ~ 1e11 — the conditioning bound of test_kl_properties
+        lim = 1e-4 if mi < 10 else 1e-7
+        assert e1 < lim and e2 < lim
+    # the foreground covariance of stage 1 is not positive definite at the lowest m (the noise is scaled away,
+    # kltransform.py:294-296): the reference's rescue — shift by 1e-15 lambda_max - 2 lambda_min — must have fired there
+    low = [out[k][3]["ac"] for k, mi in enumerate(MS) if mi <= 1]
+    assert any(a > 0.0 for a in low), low
+    assert out[MS.index(460)][3]["ac"] == 0.0
     # ---- exact Fisher matrix of the KL modes (PSExact), m = 460 against the oracle
     for mi, r in zip(MS, kl._transform_batch(MS, to_host=True)):
         kl._save(mi, *r)
@@ -274,7 +282,7 @@ def test_doublekl_and_fisher_config4(c3):
     ps.genbands()
     t0 = time.perf_counter()
     fb = ps.fisher_bias_batch(MS)
-    _log("PSExact of 3 blocks, %d bands: %.2f s" % (ps.nbands, time.perf_counter() - t0))
+    _log("PSExact of the blocks, %d bands: %.2f s" % (ps.nbands, time.perf_counter() - t0))
     # no mode of m = 460 reaches S/N 0.1: its Fisher matrix is zero there; against the oracle it is taken with
     # every mode of non-negative eigenvalue (threshold 0) through a second KLTransform / PSExact pair
     assert kl.modes_m(460, threshold=0.1)[0] is None and not fb[i][0].any()

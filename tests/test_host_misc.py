@@ -260,3 +260,70 @@ def test_exchange_single_process():
 
     assert parallel.exchange([("a", 1)]) == [("a", 1)]
     assert parallel.partition_for(range(7), 1, 3) == [3, 4] and parallel.partition_for(range(2), 2, 3) == []
+
+
+def _fisher_worker(rank, world, port, q, nm, resident):
+    """One rank of a Fisher assembly with a stand-in per-m estimator (the per-m matrices need the GPU; the partition logic
+    and the all-reduce do not)."""
+    import os
+
+    import numpy as np
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      DRIFTMI_STORAGE="discard")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from driftscan_amd import parallel, psestimation
+
+    class _BT:
+        def _my_ms(self):
+            return parallel.partition_contiguous(list(range(nm)), [float(nm - m) for m in range(nm)])
+
+        def ndof(self, mi):
+            return 4
+
+    class _KL:
+        beamtransfer = _BT()
+        evdir = "/nonexistent"
+
+        class telescope:
+            mmax = nm - 1
+
+    class Fake(psestimation.PSEstimation):
+        nbands = 2
+
+        def genbands(self):
+            self.clarray = np.zeros((2, 1, 1, 1))
+
+        def fisher_bias_batch(self, ms):
+            return [(np.full((2, 2), 10.0 ** mi) + 0j, np.full(2, 10.0 ** mi) + 0j) for mi in ms]
+
+    ps = Fake(_KL())
+    if resident:                        # what ProductManager.generate does around BeamTransfer.generate
+        ps.accumulate_ms([])
+        mine = _BT()._my_ms()
+        if mine:
+            ps.accumulate_ms(mine)
+    ps.generate()
+    q.put((rank, float(ps.fisher[0, 0]), float(ps.bias[0])))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_fisher_assembly_with_more_ranks_than_m_blocks(resident):
+    """world_size 4 over 3 m-blocks (gloo): `partition_contiguous` leaves a rank without a block; every m must enter the
+    all-reduced Fisher matrix exactly once, whether the rank accumulated during the resident pipeline or not."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + (os.getpid() % 2000) + (7 if resident else 0)
+    nm, world = 3, 4
+    ps = [ctx.Process(target=_fisher_worker, args=(r, world, port, q, nm, resident)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(60)
+    want = sum(10.0 ** m for m in range(nm))    # 111: a block counted twice or dropped shows in its own digit
+    assert all(abs(f - want) < 1e-9 and abs(b - want) < 1e-9 for _, f, b in res), res
