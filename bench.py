@@ -267,6 +267,7 @@ def build_objects(tmpdir):
 
 
 _pool = None
+_BUSY = [0.0]   # seconds this rank spent in its own BT-gen + SVD + KL (without the waits inside the collectives)
 _NKEEP = {}   # m -> eigenvectors actually back-transformed in the last pass (the modes transform_save keeps)
 
 
@@ -332,6 +333,7 @@ def hot_path_step(tel, bt, kl, ctx, stage_times=None, streams=1, m_range=None, c
         parts = [f.result() for f in futs]
     torch.cuda.synchronize()
     t3 = time.perf_counter()
+    _BUSY[0] += t3 - t0
     tcoll = 0.0
     if collect:
         mine = []
@@ -802,11 +804,12 @@ def main():
         stage = []
         parallel.barrier()
         torch.cuda.synchronize()
+        _BUSY[0] = 0.0
         t0 = time.perf_counter()
         for _ in range(args.steps):
             hot_path_step(tel, bt, kl, ctx, streams=args.streams, m_range=m_range, collect=collect)
         torch.cuda.synchronize()
-        t_own = time.perf_counter() - t0      # this rank's own K steps (before it waits for the others)
+        t_own = _BUSY[0]                      # this rank's own K steps: BT-gen + SVD + KL, without the waits in the collectives
         parallel.barrier()
         dt = time.perf_counter() - t0
         prof = {}
@@ -999,8 +1002,8 @@ def main():
                            "all eigenvalues + the modes with S/N >= threshold (subset = True, what transform_save writes)"},
                 "ranks": {"per_rank": rank_info,
                           "imbalance_max_over_mean": max(r["step_ms"] for r in rank_info) / (sum(r["step_ms"] for r in rank_info) / len(rank_info)),
-                          "note": "time of each rank over the K timed steps (its own clock between the two barriers); `value` uses the "
-                                  "MAX.  Sharded mode: the step of a rank is a lock-step chain of a few hundred launches whose length "
+                          "note": "compute time of each rank per step (BT-gen + SVD + KL of its m-range, without the waits inside the "
+                                  "collectives); `value` uses the MAX over ranks of the whole timed region.  Sharded mode: the step of a rank is a lock-step chain of a few hundred launches whose length "
                                   "follows the LARGEST matrix of its range, not the number of blocks — strong scaling of this small "
                                   "workload is bounded by that chain (DESIGN.md section 6)"},
                 "stage_ms": {"btgen": 1e3 * st[0], "svd": 1e3 * st[1], "kl": 1e3 * st[2], "collectives": 1e3 * st[3]},

@@ -254,7 +254,49 @@ class BeamTransfer(config.Reader):
         equal counts, beamtransfer.py:720-722; any assignment gives the same files.)"""
         tel = self.telescope
         mlist = list(range(tel.mmax + 1)) if mlist is None else list(mlist)
-        return parallel.partition_contiguous(mlist, [self._m_cost(m) for m in mlist])
+        costs = np.array([self._m_cost(m) for m in mlist], dtype=np.float64)
+        n = parallel.size()
+        mcut = self._sht_mcut() if n > 1 and mlist == list(range(mlist[0], mlist[-1] + 1)) else -1
+        if mcut >= 0:
+            # The SHT refinement couples the m <= mcut through the polar rings: a rank whose range starts among them
+            # transforms ALL of them (DESIGN.md section 4.5).  That is a cost per RANK, not per m — a few fixed-point passes
+            # spread it over the rank's own blocks and move the boundaries (every rank computes the same partition).  A block
+            # transformed on the side costs about 0.3 of the flat BT-gen term of `_m_cost` (calibrated on the configs[2]
+            # shares, profiles/r04b_configs2_share*of8_generate.json: 0.035 s per block against 0.15 units = 0.14 s).
+            base = costs.copy()
+            for _ in range(4):
+                extra = np.zeros_like(base)
+                for r in range(n):
+                    mine = parallel.partition_contiguous(mlist, costs, n=n, r=r)
+                    if not mine or mine[0] > mcut:
+                        continue
+                    side = (min(mcut, mlist[-1]) + 1 - mlist[0]) - sum(1 for m in mine if m <= mcut)
+                    i0 = mine[0] - mlist[0]
+                    extra[i0 : i0 + len(mine)] = 0.3 * 0.15 * max(side, 0) / len(mine)
+                costs = base + extra
+        return parallel.partition_contiguous(mlist, list(costs))
+
+    def _sht_mcut(self):
+        """Largest m the SHT refinement couples to other m (over the nside groups of the telescope's columns); -1 without
+        refinement.  Host arithmetic only (`dm_bt_alias_info`), remembered."""
+        tel = self.telescope
+        if not int(getattr(tel, "sht_iter", 0) or 0):
+            return -1
+        memo = self.__dict__.setdefault("_mcut_memo", {})
+        key = (int(tel.sht_iter), int(tel.lmax), int(tel.nfreq), int(tel.nbase))
+        if key not in memo:
+            from . import healpix
+            from ._lib import bt_alias_info
+
+            ff, bb = np.meshgrid(tel.included_freq, tel.included_baseline, indexing="ij")
+            lmax_bf, _ = tel.baseline_lmax(bb.ravel(), ff.ravel())
+            nsides = btgen._nside_of(tel, lmax_bf)
+            mc = -1
+            for ns in np.unique(nsides):
+                cth, sth = healpix.ring_trig(int(ns))
+                mc = max(mc, bt_alias_info(int(ns), cth, sth, tel.num_pol_sky > 1, int(lmax_bf[nsides == ns].max()))[1])
+            memo[key] = int(mc)
+        return memo[key]
 
     def _write_beam_files(self, beam_all, a, b, regen):
         """Hand the beam_m files of m = a..b (device tensor, first axis = m - a) to the writer pool."""

@@ -9,20 +9,16 @@ for f in glob.glob(d + "/**/*memory_copy_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", "") + " " + r.get("Bytes", r.get("Size", ""))))
 ev.sort()
-# last step: take the final 45 % of the timeline (warmup 1 + steps 1, the first includes one-time setup)
-t_end = ev[-1][1]
-# find the start of the last step: the last bt_beam_kernel burst beginning
-starts = [i for i, e in enumerate(ev) if "bt_beam_kernel" in e[2]]
-# beginning of last contiguous burst
-i0 = starts[-1]
-while i0 - 1 in starts or (i0 > 0 and any(s == i0 - 1 for s in starts)):
-    i0 -= 1
-# go back while previous beam kernels are within 50 ms
-j = len(starts) - 1
-while j > 0 and ev[starts[j]][0] - ev[starts[j - 1]][0] < 30e6:
-    j -= 1
-i0 = starts[j]
-seg = ev[i0:]
+# the TIMED step of `bench.py --steps 1 --warmup 1 --prime-passes 0`: the second pass over the hot path (the first is the
+# warm-up; a stage pass and the BT-gen-only passes follow).  A pass starts with a burst of bt_beam* kernels.
+starts = [i for i, e in enumerate(ev) if "bt_beam" in e[2]]
+bursts = [starts[0]]
+for a_, b_ in zip(starts[:-1], starts[1:]):
+    if ev[b_][0] - ev[a_][0] > 4e6:     # a new pass: more than 4 ms after the previous beam kernel
+        bursts.append(b_)
+i0 = bursts[1]
+i1 = bursts[2] if len(bursts) > 2 else len(ev)
+seg = ev[i0:i1]
 busy = 0; cur_end = seg[0][0]; gaps = []
 for s, e, n in seg:
     if s > cur_end:

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof_${TAG:-r01x}
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG:-r01x} -o bench -- python3 bench.py --steps 1 --warmup 1 --prime-passes 0 --no-cpu-baseline > gpurun_out/prof_${TAG:-r01x}/bench_stdout.json 2> gpurun_out/prof_${TAG:-r01x}/stderr.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG:-r01x} -o bench -- python3 bench.py --steps 1 --warmup 1 --prime-passes 0 --no-cpu-baseline --no-north-star > gpurun_out/prof_${TAG:-r01x}/bench_stdout.json 2> gpurun_out/prof_${TAG:-r01x}/stderr.txt
 ls -R gpurun_out/prof_${TAG:-r01x} | head -30
 f=$(find gpurun_out/prof_${TAG:-r01x} -name "*kernel_stats.csv" | head -1)
 echo "STATS FILE $f"

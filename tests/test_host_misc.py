@@ -327,3 +327,30 @@ def test_fisher_assembly_with_more_ranks_than_m_blocks(resident):
         p.join(60)
     want = sum(10.0 ** m for m in range(nm))    # 111: a block counted twice or dropped shows in its own digit
     assert all(abs(f - want) < 1e-9 and abs(b - want) < 1e-9 for _, f, b in res), res
+
+
+def test_m_ranges_account_for_the_sht_coupling(tmp_path):
+    """`BeamTransfer._my_ms`: contiguous cost-balanced ranges; with healpy's refinement on, the ranks whose range starts among
+    the m the polar rings couple (m <= mcut, `dm_bt_alias_info` — host arithmetic, no GPU) carry the BT-gen of all of those m
+    and get fewer blocks; every rank computes the same partition."""
+    from driftscan_amd import beamtransfer, cylinder, parallel
+
+    cfg = dict(num_freq=4, freq_start=400.0, freq_end=420.0, freq_mode="edge", num_cylinders=2, cylinder_width=8.0,
+               num_feeds=4, feed_spacing=0.5, tsys=1.0, force_lmax=200, force_mmax=200)
+    parts = {}
+    try:
+        for it in (0, 3):
+            tel = cylinder.PolarisedCylinderTelescope.from_config(dict(cfg, sht_iter=it))
+            bt = beamtransfer.BeamTransfer(str(tmp_path / ("bt%d" % it)), telescope=tel)
+            mcut = bt._sht_mcut()
+            assert (mcut == -1) if it == 0 else (0 < mcut < tel.mmax)
+            got = []
+            for r in range(6):
+                parallel.set_virtual(r, 6)
+                got.append(bt._my_ms())
+            assert sum(got, []) == list(range(tel.mmax + 1))
+            assert all(p == list(range(p[0], p[-1] + 1)) for p in got)
+            parts[it] = got
+    finally:
+        parallel.set_virtual(None)
+    assert len(parts[3][0]) < len(parts[0][0]) and len(parts[3][-1]) > len(parts[0][-1])
