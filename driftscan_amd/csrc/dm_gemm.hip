@@ -250,7 +250,10 @@ __global__ __launch_bounds__(256, 3) void zgemm_grouped_kernel(const dm_gemm_des
 //   rotation s (s = 0..3) pairs row block g with column block g' = (g + s) & 3, so four instructions cover a
 //   16x16 tile; D of rotation s lands in lane 16 i + 4 g + j = C[4 g + i][4 ((g + s) & 3) + j].
 // The rotated B operands are the rotation-0 registers moved by DPP row_ror inside each 16-lane row (same k).
-template <bool B_REAL, bool B_GATHER, int PD>
+// NJ = 16-column sub-tiles of B per wave: 2 (a 32 x 32 block per wave, 64 x 64 per workgroup) or 4 (32 x 64 per wave, 64 x 128
+// per workgroup — for the real-B products, whose two MFMAs per output block and K-step would otherwise sit behind the same four
+// loads as the four of a complex product: twice the B columns per wave restore the MFMA-to-load ratio of the complex kernel)
+template <bool B_REAL, bool B_GATHER, int PD, int NJ = 2>
 __global__ __launch_bounds__(256, 2) void zgemm4_grouped_kernel(const dm_gemm_desc* __restrict__ descs,
                                                                 const dm_gemm_tile* __restrict__ tiles, int ntiles) {
   const int bid = dm_xcd_remap(blockIdx.x, ntiles);
@@ -264,21 +267,24 @@ __global__ __launch_bounds__(256, 2) void zgemm4_grouped_kernel(const dm_gemm_de
   // columns — ragged row counts (the per-frequency blocks of 70-92 modes) then waste at most 15 rows instead of 63
   const bool flat = tl.tm < 0;
   const int mrow = flat ? (-tl.tm - 1) * 32 : tl.tm * BM + wm * 32;
-  const int ncol = flat ? tl.tn * 128 + wave * 32 : tl.tn * BN + wn * 32;
+  const int ncol = flat ? tl.tn * (64 * NJ) + wave * (16 * NJ) : tl.tn * (32 * NJ) + wn * (16 * NJ);
   if (mrow >= d.M || ncol >= d.N) return;  // no LDS, no barrier: a wave without outputs just leaves
   const cplx* __restrict__ A = reinterpret_cast<const cplx*>(d.A);
   const cplx* __restrict__ Bc = reinterpret_cast<const cplx*>(d.B);
   const double* __restrict__ Br = reinterpret_cast<const double*>(d.B);
   const double sa = (d.flags & DM_GEMM_CONJ_A) ? -1.0 : 1.0, sb = (d.flags & DM_GEMM_CONJ_B) ? -1.0 : 1.0;
   // this lane's rows / columns of the two 16-wide sub-tiles (clamped; masked by zeroing the operand)
-  size_t aoff[2], boff[2], ksoff[2];
-  bool aok[2], bok[2], tile_i[2], tile_j[2];
+  size_t aoff[2], boff[NJ], ksoff[NJ];
+  bool aok[2], bok[NJ], tile_i[2], tile_j[NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int r = mrow + i * 16 + 4 * g + t;
     aok[i] = r < d.M;
     tile_i[i] = mrow + i * 16 < d.M;
     aoff[i] = (size_t)min(r, d.M - 1) * d.rsA;
+  }
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
     const int c = ncol + i * 16 + 4 * g + t;
     bok[i] = c < d.N;
     tile_j[i] = ncol + i * 16 < d.N;
@@ -292,32 +298,33 @@ __global__ __launch_bounds__(256, 2) void zgemm4_grouped_kernel(const dm_gemm_de
       boff[i] = (size_t)cc * d.csB;
     }
   }
-  double acc_re[2][2][4], acc_im[2][2][4];
+  double acc_re[2][NJ][4], acc_im[2][NJ][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc_re[i][j][s] = acc_im[i][j][s] = 0.0;
 
   // Operands travel as RAW loads: no arithmetic touches a fragment before its compute step, so the loads of step
   // t + 1 stay in flight under the 64 MFMAs of step t (an `s_waitcnt` lands wherever the first use is — conjugation
   // signs, masks and scale factors are therefore applied at compute time).
-  struct raw { cplx a[2], b[2]; double ks, kb[2]; };
+  struct raw { cplx a[2], b[NJ]; double ks, kb[NJ]; };
   // tiles that lie inside the matrix with nothing to scale take the lean steps: no masks, no scale loads
-  const bool plain = !d.kscale && !B_GATHER && mrow + 32 <= d.M && ncol + 32 <= d.N;
+  const bool plain = !d.kscale && !B_GATHER && mrow + 32 <= d.M && ncol + 16 * NJ <= d.N;
   auto load_lean = [&](int k0) {
     raw f;
     const size_t kk = (size_t)(k0 + k);
 #pragma unroll
     for (int i = 0; i < 2; ++i) f.a[i] = dm_ldg(A, aoff[i] + kk * d.csA);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       if (B_REAL) f.b[j] = make_double2(dm_ldg(Br, kk * d.rsB + boff[j]), 0.0);
       else f.b[j] = dm_ldg(Bc, boff[j] + kk * d.rsB);
     }
     f.ks = 1.0;
-    f.kb[0] = f.kb[1] = 1.0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) f.kb[j] = 1.0;
     return f;
   };
   auto load_gen = [&](int k0) {
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void zgemm4_grouped_kernel(const dm_gemm_de
 #pragma unroll
     for (int i = 0; i < 2; ++i) f.a[i] = dm_ldg(A, aoff[i] + kc * d.csA);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       if (B_REAL) f.b[j] = make_double2(dm_ldg(Br, kc * d.rsB + boff[j]), 0.0);
       else f.b[j] = dm_ldg(Bc, boff[j] + kc * d.rsB);
       f.kb[j] = B_GATHER ? dm_ldg(d.kscale, ksoff[j] + kc) : 1.0;
@@ -334,10 +341,10 @@ __global__ __launch_bounds__(256, 2) void zgemm4_grouped_kernel(const dm_gemm_de
     f.ks = (d.kscale && !B_GATHER) ? dm_ldg(d.kscale, kc) : 1.0;
     return f;
   };
-  auto mfmas = [&](const cplx (&fa)[2], const cplx (&fb)[2]) {
-    double bre[2][4], bim[2][4];
+  auto mfmas = [&](const cplx (&fa)[2], const cplx (&fb)[NJ]) {
+    double bre[NJ][4], bim[NJ][4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       bre[j][0] = fb[j].x;
       bim[j][0] = fb[j].y;
       // rotation s needs the operand of the lane 4 s further along its 16-lane row: row_ror:n hands lane i the
@@ -349,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void zgemm4_grouped_kernel(const dm_gemm_de
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         if (!(tile_i[i] && tile_j[j])) continue;
         if (!B_REAL) {
 #pragma unroll
@@ -372,23 +379,23 @@ __global__ __launch_bounds__(256, 2) void zgemm4_grouped_kernel(const dm_gemm_de
       }
   };
   auto compute_lean = [&](const raw& f) {
-    cplx fa[2], fb[2];
+    cplx fa[2], fb[NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i) fa[i] = make_double2(f.a[i].x, f.a[i].y * sa);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) fb[j] = make_double2(f.b[j].x, f.b[j].y * sb);
+    for (int j = 0; j < NJ; ++j) fb[j] = make_double2(f.b[j].x, f.b[j].y * sb);
     mfmas(fa, fb);
   };
   auto compute_gen = [&](const raw& f, int k0) {
     const bool kv = k0 + k < d.K;
-    cplx fa[2], fb[2];
+    cplx fa[2], fb[NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bool on = kv && aok[i];
       fa[i] = on ? make_double2(f.a[i].x * f.ks, f.a[i].y * f.ks * sa) : make_double2(0.0, 0.0);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const bool on = kv && bok[j];
       fb[j] = on ? make_double2(f.b[j].x * f.kb[j], f.b[j].y * f.kb[j] * sb) : make_double2(0.0, 0.0);
     }
@@ -452,12 +459,12 @@ __global__ __launch_bounds__(256, 2) void zgemm4_grouped_kernel(const dm_gemm_de
   const bool rmw = d.beta != 0.0;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    size_t off[2][4];
-    bool ok[2][4];
-    cplx old[2][4];
+    size_t off[NJ][4];
+    bool ok[NJ][4];
+    cplx old[NJ][4];
     const int gm = mrow + i * 16 + 4 * g + ip;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int gn = ncol + j * 16 + 4 * ((g + s) & 3) + jp;
@@ -467,12 +474,12 @@ __global__ __launch_bounds__(256, 2) void zgemm4_grouped_kernel(const dm_gemm_de
       }
     if (rmw) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int s = 0; s < 4; ++s) old[j][s] = dm_ldg(C, off[j][s]);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const double are = acc_re[i][j][s], aim = acc_im[i][j][s];
@@ -611,18 +618,32 @@ int dm_gemm_plan_build(const std::vector<dm_gemm_desc>& descs, dm_gemm_plan& pla
   std::vector<dm_gemm_tile> tiles_gat;
   double fl_g = 0.0;
   double fl_c = 0.0, fl_r = 0.0, fl_d = 0.0;
+  // The real-B class of the register-only kernel runs 64 x 128 tiles (32 x 64 per wave, zgemm4_grouped_kernel<.., NJ = 4>)
+  // when most of the launch's work sits in products wide enough for them — decided per launch (measured: a configs[2] BT-gen rank call 5.16 -> 4.83 s
+  // with N = 170 .. 513, configs[1] with N <= 129 loses 5 % to the padding of the wide tiles)
+  double w_all = 0.0, w_wide = 0.0;   // work of the real-B products, and of those at least 160 columns wide
+  for (const auto& d : descs)
+    if (d.M > 0 && d.N > 0 && (d.flags & DM_GEMM_B_REAL) && !(d.flags & DM_GEMM_ALL_REAL)) {
+      const double w = (double)d.M * d.N * d.K;
+      w_all += w;
+      if (d.N >= 160) w_wide += w;
+    }
+  const bool wide_r = use4 && w_all > 0.0 && w_wide >= 0.6 * w_all;
   for (size_t i = 0; i < descs.size(); ++i) {
     const dm_gemm_desc& d = descs[i];
     if (d.M <= 0 || d.N <= 0) continue;
-    int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
+    if ((d.flags & DM_GEMM_B_REAL) && (d.flags & (DM_GEMM_LOWER | DM_GEMM_UPPER))) return DM_EARG;  // no triangular real-B products
+    const bool wide = wide_r && (d.flags & DM_GEMM_B_REAL) && !(d.flags & DM_GEMM_ALL_REAL);
+    const int BNd = wide ? 2 * BN : BN, FNd = wide ? 256 : 128;
+    int tm = (d.M + BM - 1) / BM, tn = (d.N + BNd - 1) / BNd;
     // flat 32 x 128 tiles of the register-only kernel where the 32-row granularity saves work and the problem is small
     if (use4 && !noflat && !(d.flags & (DM_GEMM_ALL_REAL | DM_GEMM_LOWER | DM_GEMM_UPPER)) && ((d.M + 31) / 32) * 32 < tm * BM &&
         (d.M <= 32 || d.N <= 256)) {  // measured: 32-row panels 36 -> 50 TFLOP/s, 92 x 92 x 129 26 -> 33.5; wide ragged ones lose 5 %
-      const int um = (d.M + 31) / 32, un = (d.N + 127) / 128;
+      const int um = (d.M + 31) / 32, un = (d.N + FNd - 1) / FNd;
       for (int a = 0; a < um; ++a)
         for (int b = 0; b < un; ++b) {
           dm_gemm_tile t{(int)i, -a - 1, b};
-          const double rows = std::min(32, d.M - a * 32), cols = std::min(128, d.N - b * 128);
+          const double rows = std::min(32, d.M - a * 32), cols = std::min(FNd, d.N - b * FNd);
           if (d.flags & DM_GEMM_B_REAL) { tiles_real.push_back(t); fl_r += 4.0 * rows * cols * d.K; }
           else if (d.flags & DM_GEMM_B_GATHER) { tiles_gat.push_back(t); fl_g += 8.0 * rows * cols * d.K; }
           else { tiles.push_back(t); fl_c += 8.0 * rows * cols * d.K; }
@@ -634,7 +655,7 @@ int dm_gemm_plan_build(const std::vector<dm_gemm_desc>& descs, dm_gemm_plan& pla
         if ((d.flags & DM_GEMM_LOWER) && b > a) continue;
         if ((d.flags & DM_GEMM_UPPER) && b < ((d.flags & DM_GEMM_UPPER128) ? (a & ~1) : a)) continue;
         dm_gemm_tile t{(int)i, a, b};
-        const double rows = std::min(BM, d.M - a * BM), cols = std::min(BN, d.N - b * BN);
+        const double rows = std::min(BM, d.M - a * BM), cols = std::min(BNd, d.N - b * BNd);
         if (d.flags & DM_GEMM_ALL_REAL) { tiles_dd.push_back(t); fl_d += 2.0 * rows * cols * d.K; }
         else if (d.flags & DM_GEMM_B_REAL) { tiles_real.push_back(t); fl_r += 4.0 * rows * cols * d.K; }
         else if (d.flags & DM_GEMM_B_GATHER) { tiles_gat.push_back(t); fl_g += 8.0 * rows * cols * d.K; }
@@ -664,6 +685,7 @@ int dm_gemm_plan_build(const std::vector<dm_gemm_desc>& descs, dm_gemm_plan& pla
   plan.n0 = n0; plan.n1 = n1; plan.n2 = n2; plan.n3 = n3;
   plan.fl_c = fl_c; plan.fl_r = fl_r; plan.fl_d = fl_d; plan.fl_g = fl_g;
   plan.use4 = use4;
+  plan.wide_r = wide_r;
   // deep operand prefetch (two waves per SIMD) pays on long inner dimensions only
   static const int deep_env = getenv("DM_GEMM4_DEEP") ? atoi(getenv("DM_GEMM4_DEEP")) : -1;
   int kmin_c = 1 << 30;
@@ -762,7 +784,10 @@ int dm_gemm_plan_run(dm_ctx* ctx, const dm_gemm_plan& plan, const char* dblob) {
   if (n1) {
     const dm_gemm_tile* dt = dt_r;
     dm_prof_scope ps(ctx, DM_PROF_GEMM_REAL, fl_r);
-    if (use4)
+    if (use4 && plan.wide_r)
+      hipLaunchKernelGGL((zgemm4_grouped_kernel<true, false, 1, 4>), dim3((unsigned)n1), dim3(256), 0, ctx->stream,
+                         dd, dt, (int)n1);
+    else if (use4)
       hipLaunchKernelGGL((zgemm4_grouped_kernel<true, false, 1>), dim3((unsigned)n1), dim3(256), 0, ctx->stream,
                          dd, dt, (int)n1);
     else

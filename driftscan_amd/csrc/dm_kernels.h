@@ -49,7 +49,7 @@ struct dm_gemm_plan {
   std::vector<char> blob;   // descriptors + tile lists as the kernels read them
   size_t desc_bytes = 0, n0 = 0, n1 = 0, n2 = 0, n3 = 0;
   double fl_c = 0.0, fl_r = 0.0, fl_d = 0.0, fl_g = 0.0;
-  bool use4 = true, deep = false;
+  bool use4 = true, deep = false, wide_r = false;
   int log_kmin = 0, log_kmax = 0, log_mmax = 0, log_nmax = 0, log_rmw = 0;
   size_t log_ndesc = 0;
   double log_full = 0.0;
