@@ -86,6 +86,11 @@ def parse_args(argv=None):
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo + --one-gpu rehearses the multi-rank path on a single card (RCCL refuses two ranks per GPU)")
     ap.add_argument("--one-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal on a one-GPU box)")
+    ap.add_argument("--shard", default=None, metavar="r/N",
+                    help="configs1, one process: run ONLY the m-range rank r of N would own in --mode sharded (no process group) — "
+                         "the per-rank step time behind the expected strong-scaling curve (DESIGN.md section 6)")
+    ap.add_argument("--no-rebalance", action="store_true",
+                    help="--mode sharded: keep the m-ranges of the static cost model instead of rebalancing them on measured times")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-north-star", action="store_true",
                     help="skip the north-star leg of the default line (one rank's share of the configs[2] job through "
@@ -780,6 +785,12 @@ def main():
             allm = list(range(nblocks))
             mine = parallel.partition_contiguous(allm, [bt._m_cost(m) for m in allm])
             m_range = (mine[0], mine[-1])
+        if args.shard:
+            sr, sn = (int(x) for x in args.shard.split("/"))
+            allm = list(range(nblocks))
+            mine = parallel.partition_contiguous(allm, [bt._m_cost(m) for m in allm], n=sn, r=sr)
+            m_range = (mine[0], mine[-1])
+            args.no_cpu_baseline = args.no_north_star = True
         collect = world > 1 or force_dist
         # Device priming, before the W warm-up steps: a fresh box runs its first ~1.5 s of GPU work about 4 % slower
         # (clocks and page mappings settle; measured: first process of a box 719 m-blocks/s at W = 2, 756 at W = 12,
@@ -790,6 +801,41 @@ def main():
             hot_path_step(tel, bt, kl, ctx, streams=args.streams, m_range=m_range, collect=collect)
         torch.cuda.synchronize()
         t_prime = time.perf_counter() - t_prime
+        rebalance_log = None
+        if args.mode == "sharded" and world > 1 and not args.no_rebalance:
+            # MEASURED load balance (untimed, before the warm-up): the static cost model of `_m_cost` is calibrated on the
+            # configs[2] job; at this small workload a rank's step is a lock-step chain whose length follows the largest
+            # matrix of its range, and the low-m ranks come out up to 1.6 x slower than the high-m ones.  A few rounds of:
+            # every rank times two passes over its range, the times are all-gathered, the cost of an m is taken as its
+            # rank's time / its rank's blocks, and the contiguous partition is recomputed from those costs (every rank
+            # computes the same boundaries); the best partition seen is kept.
+            import torch.distributed as dist
+
+            dev_ = "cuda" if args.backend == "nccl" else "cpu"
+            allm = list(range(nblocks))
+            ranges = None
+            best = (float("inf"), None)
+            rebalance_log = []
+            for rnd in range(4):
+                _BUSY[0] = 0.0
+                for _ in range(2):
+                    hot_path_step(tel, bt, kl, ctx, streams=args.streams, m_range=m_range, collect=collect)
+                mine_t = torch.tensor([_BUSY[0] / 2.0, float(m_range[0]), float(m_range[1])], dtype=torch.float64, device=dev_)
+                allt = [torch.zeros_like(mine_t) for _ in range(world)]
+                dist.all_gather(allt, mine_t)
+                ranges = [(int(t[1]), int(t[2]), float(t[0])) for t in allt]
+                worst = max(t for _, _, t in ranges)
+                rebalance_log.append(dict(ranges=[(a, b) for a, b, _ in ranges], step_ms=[1e3 * t for _, _, t in ranges]))
+                if worst < best[0]:
+                    best = (worst, [(a, b) for a, b, _ in ranges])
+                if rnd == 3:
+                    break
+                dens = np.zeros(nblocks)
+                for a, b, t in ranges:
+                    dens[a : b + 1] = t / (b - a + 1)
+                mine = parallel.partition_contiguous(allm, list(dens))
+                m_range = (mine[0], mine[-1])
+            m_range = best[1][rank]
         for _ in range(args.warmup):
             hot_path_step(tel, bt, kl, ctx, streams=args.streams, m_range=m_range, collect=collect)
         # A full (generation-2) cycle collection walks every object torch/numpy created at import
@@ -868,8 +914,11 @@ def main():
             dt = float(tmax.item())
         sharded = m_range is not None
         if not (world > 1 or force_dist):
-            rank_info = [dict(rank=0, step_ms=1e3 * dt / args.steps, m_lo=0, m_hi=nblocks - 1)]
+            rank_info = [dict(rank=0, step_ms=1e3 * dt / args.steps, m_lo=m_range[0] if m_range else 0,
+                              m_hi=m_range[1] if m_range else nblocks - 1)]
         value = (nblocks if sharded else world * nblocks) * args.steps / dt
+        if args.shard:   # one rank of an emulated N-rank job: its own blocks over its own time
+            value = (m_range[1] - m_range[0] + 1) * args.steps / dt
         if rank == 0:
             st = np.array(stage).mean(axis=0)
             trd_stride = int(ctx.lib.dm_prof_trd_stride())  # the column loop is sampled; the library scales the figures
@@ -994,13 +1043,15 @@ def main():
                            "sht_note": "healpy.map2alm `iter` of the reference's SHT (through cora, not readable here): healpy's "
                                        "documented default 3, refined in harmonic space on the device; `btgen` carries both readings",
                            "sharding": "m-ranges, one job" if sharded else "m-blocks, one full workload per GPU",
+                           "shard": None if not args.shard else "rank %s of an emulated sharded job alone on the GPU: m = %d..%d; "
+                                    "`value` counts this rank's blocks only" % (args.shard, m_range[0], m_range[1]),
                            "mode": args.mode, "ranks": world, "backend": args.backend if world > 1 else None,
                            "collectives_in_timed_region": "gather of sigma/lambda spectra + all-reduce of a 9x9 band matrix"
                            if collect else None,
                            "streams_per_gpu": args.streams,
                            "kl_products": "all eigenvalues + every mode" if args.all_modes else
                            "all eigenvalues + the modes with S/N >= threshold (subset = True, what transform_save writes)"},
-                "ranks": {"per_rank": rank_info,
+                "ranks": {"per_rank": rank_info, "rebalance": rebalance_log,
                           "imbalance_max_over_mean": max(r["step_ms"] for r in rank_info) / (sum(r["step_ms"] for r in rank_info) / len(rank_info)),
                           "note": "compute time of each rank per step (BT-gen + SVD + KL of its m-range, without the waits inside the "
                                   "collectives); `value` uses the MAX over ranks of the whole timed region.  Sharded mode: the step of a rank is a lock-step chain of a few hundred launches whose length "
