@@ -947,7 +947,8 @@ def main():
                            "sb_chase": "sb_chase2_kernel<4>", "sb_q2_apply": "sb_q2_apply_kernel<4>",
                            "sb_panel_qr": "sb_panel_fused_kernel"}.get(dom)
                     if dom == "zgemm_grouped" and key not in rec:
-                        key = "zgemm4_grouped_kernel<false, false, 1>"
+                        key = next((k for k in ("zgemm4_grouped_kernel<false, false, 1, 2>", "zgemm4_grouped_kernel<false, false, 1>")
+                                    if k in rec), key)
                     if key is not None and key not in rec:  # kernels compiled inside a namespace (dm_trd32::trd_symv_kernel)
                         key = next((k for k in rec if k.endswith("::" + key)), key)
                     if key in rec:

@@ -2004,6 +2004,38 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
         // Yt = Xt A22 by 128-column blocks: stored part (rows >= block start, whole diagonal block) + mirrored part
         cplx* py = part_y + offn[p] * SB * 32;
         size_t pyoff = 0;
+        // BLOCK-PAIR order (split products only, at most 30 blocks per side): K is cut at the 128-boundaries of the matrix,
+        // so every piece reads ONE 128 x 128 block of the stored triangle — and the two pieces that read the same block
+        // (the stored part of column block R over the columns of block C, the mirrored part of column block C over the
+        // rows of block R) are emitted next to each other: they run on the same XCD at the same time (the tile list is
+        // dealt to the XCDs in contiguous runs) and the second one finds the block in L2.  Uniform K = 128 tiles instead of
+        // ragged slices; the trailing matrix comes from HBM once per panel for this product instead of twice.
+        static const bool ypair_off = getenv("DM_SB_YPAIR") && atoi(getenv("DM_SB_YPAIR")) == 0;
+        const int nblk = (n - a0 + 127) / 128;
+        if (sp.SY > 1 && !ypair_off && nblk <= 30) {
+          // column block b covers [lo(b), hi(b)); slots of block b: stored pieces over the blocks c >= b (slot c - b),
+          // then mirrored pieces over the blocks r < b (slot (nblk - b) + r)
+          auto lo = [&](int b) { return std::max(a0 + b * 128, i0); };
+          auto hi = [&](int b) { return std::min(a0 + (b + 1) * 128, n); };
+          std::vector<size_t> base(nblk);
+          for (int b = 0; b < nblk; ++b) {
+            base[b] = pyoff;
+            pyoff += (size_t)nblk * SB * (hi(b) - lo(b));
+          }
+          for (int r = 0; r < nblk; ++r)
+            for (int c = r; c < nblk; ++c) {
+              const int wr = hi(r) - lo(r), wc = hi(c) - lo(c);
+              // stored: Y[:, block r] += Xt[:, block c] . C[rows of r, columns of c]^T
+              gy1.push_back(dm_gemm_make(Xt + lo(c), n, 1, false, C + (size_t)lo(r) * lda + lo(c), 1, lda, false,
+                                         py + base[r] + (size_t)(c - r) * SB * wr, wr, SB, wr, wc));
+              // mirrored: Y[:, block c] += Xt[:, block r] . conj(C[rows of r, columns of c])
+              if (c > r)
+                gy1.push_back(dm_gemm_make(Xt + lo(r), n, 1, false, C + (size_t)lo(r) * lda + lo(c), lda, 1, true,
+                                           py + base[c] + (size_t)((nblk - c) + r) * SB * wc, wc, SB, wc, wr));
+            }
+          for (int b = 0; b < nblk; ++b)
+            M_.sy.push_back(sb_sum_desc{Wp + lo(b), py + base[b], nblk, SB, hi(b) - lo(b), n, 1.0, 0.0});
+        } else
         for (int cb = a0; cb < n; cb += 128) {
           const int c_lo = std::max(cb, i0), c_hi = std::min(cb + 128, n);
           if (c_hi <= c_lo) continue;

@@ -5,7 +5,9 @@
 # configs[2] rank call at iter 0 and iter 3.  Every step under its own timeout; stops at the first failure.
 set -o pipefail
 tag=${1:-r04x}
+part=${2:-all}     # "a": bench profiles + rehearsals, "b": kernel stats of a configs[2] share, "c": its MFMA counters, "d": BT-gen, "all"
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
+if [ "$part" = "a" ] || [ "$part" = "all" ]; then
 TAG=$tag timeout -k 10 300 bash scratch/run_rocprof.sh > gpurun_out/prof_$tag.txt 2>&1 || exit 2
 timeout -k 10 300 bash scratch/run_pmc.sh fetch_$tag FETCH_SIZE > /dev/null 2>&1 || exit 3
 timeout -k 10 300 bash scratch/run_pmc.sh write_$tag WRITE_SIZE > /dev/null 2>&1 || exit 4
@@ -33,15 +35,27 @@ echo "$(date +%T) rehearsals"
 timeout -k 10 300 python bench.py --gpus 2 --one-gpu --backend gloo --no-cpu-baseline > gpurun_out/${tag}_bench_2ranks_one_gpu_gloo_sharded.json 2> gpurun_out/${tag}_bench2s.err || exit 7
 timeout -k 10 300 python bench.py --gpus 2 --one-gpu --backend gloo --mode weak --no-cpu-baseline > gpurun_out/${tag}_bench_2ranks_one_gpu_gloo_weak.json 2> gpurun_out/${tag}_bench2w.err || exit 8
 DRIFTMI_WORKSPACE_GB=8 timeout -k 10 400 python bench.py --gpus 6 --one-gpu --backend gloo --no-cpu-baseline --steps 3 --prime-passes 2 > gpurun_out/${tag}_bench_6ranks_one_gpu_gloo_sharded.json 2> gpurun_out/${tag}_bench6s.err || exit 9
+fi
+if [ "$part" = "a" ]; then exit 0; fi
 # a full configs[2] share (0/8) through generate(): kernel stats, then MFMA-busy counters in a pass of their own
+if [ "$part" = "b" ] || [ "$part" = "all" ]; then
 echo "$(date +%T) share kernel stats"
 rm -rf gpurun_out/sharetrace
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/sharetrace -o sh -- python3 bench.py --workload configs2 --share 0/8 > gpurun_out/${tag}_configs2_share0of8_generate.json 2> gpurun_out/share.err || exit 10
 f=$(find gpurun_out/sharetrace -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/${tag}_configs2_share_kernel_stats.csv
 rm -rf gpurun_out/sharetrace
+fi
+if [ "$part" = "b" ]; then exit 0; fi
+if [ "$part" = "c" ] || [ "$part" = "all" ]; then
 echo "$(date +%T) share pmc"
 rm -rf gpurun_out/sharepmc
-timeout -k 10 1100 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/sharepmc -o sh -- python3 bench.py --workload configs2 --share 0/8 > gpurun_out/sharepmc.json 2> gpurun_out/sharepmc.err || exit 11
+# (the counters serialise 220 000 dispatches: ~10 minutes without a line of output — a heartbeat file keeps the run alive)
+( while true; do sleep 45; date +%T >> gpurun_out/sharepmc_heartbeat.txt; done ) &
+hb=$!
+timeout -k 10 1050 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/sharepmc -o sh -- python3 bench.py --workload configs2 --share ${PMC_SHARE:-0/40} > gpurun_out/sharepmc.json 2> gpurun_out/sharepmc.err
+rc=$?
+kill $hb
+[ $rc -eq 0 ] || exit 11
 f=$(find gpurun_out/sharepmc -name "*counter_collection.csv" | head -1)
 python - "$f" gpurun_out/${tag}_configs2_share_pmc_mfma.json $tag <<'PY'
 import csv, sys, re, json, os
@@ -50,7 +64,7 @@ agg = defaultdict(lambda: defaultdict(float)); n = defaultdict(set)
 for r in csv.DictReader(open(sys.argv[1])):
     k = re.sub(r"dm_trd\d+::", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")).split("(")[0]
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
-out = {"_note": "bench.py --workload configs2 --share 0/8 under rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE "
+out = {"_note": "bench.py --workload configs2 --share 0/40 (seven m-blocks, m = 0..6; the counter collection of rocprofv3 segfaults inside the HIP runtime on a full share 0/8) under rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE "
                 "(a pass of its own); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), as profiles/*_pmc_mfma.json"}
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0))[:14]:
     g = v.get("GRBM_GUI_ACTIVE", 0.0)
@@ -63,6 +77,8 @@ json.dump(out, open(sys.argv[2], "w"), indent=1)
 print(json.dumps({k: v for k, v in list(out.items())[:8]}, indent=1)[:1500])
 PY
 rm -rf gpurun_out/sharepmc
+fi
+if [ "$part" = "c" ]; then exit 0; fi
 # BT-gen of a configs[2] rank call under the kernel trace, iter 0 and iter 3
 echo "$(date +%T) btgen"
 bash scratch/bt_iter_prof.sh ${tag}_rank0_iter3 0:32 3 > gpurun_out/${tag}_btgen_rank0_iter3.txt 2>&1 || exit 12
@@ -72,7 +88,10 @@ python scratch/bt_iter_bench.py --config 3 --ranges 0:32 157:212 --reps 2 --out 
 python - $tag <<'PY'
 import json, sys
 tag = sys.argv[1]
+import os
 for f in ("bench_default", "bench_2ranks_one_gpu_gloo_sharded", "bench_2ranks_one_gpu_gloo_weak", "bench_6ranks_one_gpu_gloo_sharded"):
+    if not os.path.exists("gpurun_out/%s_%s.json" % (tag, f)):
+        continue
     d = json.loads(open("gpurun_out/%s_%s.json" % (tag, f)).read().strip().splitlines()[-1])
     print(f, round(d["value"], 1), d["n_gpus"], round(d["ms_per_step"], 1), d["scaling"], {k: round(v, 1) for k, v in d["stage_ms"].items()},
           d["roofline"]["kernel"], round(d["roofline"]["frac"], 3))
