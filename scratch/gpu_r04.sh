@@ -49,7 +49,9 @@ if [ "$part" = "b" ]; then exit 0; fi
 if [ "$part" = "c" ] || [ "$part" = "all" ]; then
 echo "$(date +%T) share pmc"
 rm -rf gpurun_out/sharepmc
-# (the counters serialise 220 000 dispatches: ~10 minutes without a line of output — a heartbeat file keeps the run alive)
+# (round 4: NOT completed on this pool — the counter collection segfaulted inside the HIP runtime on share 0/8, and on share 0/40
+# it had not finished after 17 minutes (the counters serialise the dispatches); the covariance kernel's MFMA-busy figure comes from
+# the configs[1] pass, profiles/*_pmc_mfma.json)
 ( while true; do sleep 45; date +%T >> gpurun_out/sharepmc_heartbeat.txt; done ) &
 hb=$!
 timeout -k 10 1050 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/sharepmc -o sh -- python3 bench.py --workload configs2 --share ${PMC_SHARE:-0/40} > gpurun_out/sharepmc.json 2> gpurun_out/sharepmc.err
