@@ -830,11 +830,7 @@ def main():
                     best = (worst, [(a, b) for a, b, _ in ranges])
                 if rnd == 3:
                     break
-                dens = np.zeros(nblocks)
-                for a, b, t in ranges:
-                    dens[a : b + 1] = t / (b - a + 1)
-                mine = parallel.partition_contiguous(allm, list(dens))
-                m_range = (mine[0], mine[-1])
+                m_range = parallel.rebalance_contiguous([(a, b) for a, b, _ in ranges], [t for _, _, t in ranges])
             m_range = best[1][rank]
         for _ in range(args.warmup):
             hot_path_step(tel, bt, kl, ctx, streams=args.streams, m_range=m_range, collect=collect)

@@ -142,6 +142,28 @@ def partition_contiguous(items, costs, n=None, r=None):
     return items[bounds[r] : bounds[r + 1]]
 
 
+def rebalance_contiguous(ranges, times, r=None):
+    """One round of measured load balancing of contiguous ranges: `ranges` = [(first, last)] of every rank (a partition of
+    0 .. n - 1 in rank order), `times` = what each rank measured for its range.  The cost of an item is taken as its rank's
+    time / its rank's item count, and the contiguous partition is recomputed from those costs.  Returns the new (first, last) of
+    rank `r` (default: this rank) — or of every rank with r = "all".  Pure function of its arguments: every rank that holds the
+    gathered `times` computes the same boundaries (`bench.py --mode sharded` iterates it a few times and keeps the best)."""
+    n_items = ranges[-1][1] + 1
+    dens = np.zeros(n_items)
+    for (a, b), t in zip(ranges, times):
+        dens[a : b + 1] = float(t) / (b - a + 1)
+    n = len(ranges)
+    items = list(range(n_items))
+    if r == "all":
+        out = []
+        for k in range(n):
+            mine = partition_contiguous(items, list(dens), n=n, r=k)
+            out.append((mine[0], mine[-1]))
+        return out
+    mine = partition_contiguous(items, list(dens), n=n, r=rank() if r is None else r)
+    return (mine[0], mine[-1])
+
+
 def gather_objects(obj):
     """Gather picklable objects to rank 0 (list over ranks there, None elsewhere)."""
     d = _dist()

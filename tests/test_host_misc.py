@@ -354,3 +354,26 @@ def test_m_ranges_account_for_the_sht_coupling(tmp_path):
     finally:
         parallel.set_virtual(None)
     assert len(parts[3][0]) < len(parts[0][0]) and len(parts[3][-1]) > len(parts[0][-1])
+
+
+def test_rebalance_contiguous_levels_measured_times():
+    """`parallel.rebalance_contiguous` (the measured load balancing of `bench.py --mode sharded`): with a cost model the static
+    partition does not know — a floor per rank plus a steeply falling cost per item, like the lock-step chains of the small
+    configs[1] matrices — a few rounds bring the slowest rank close to the mean; every rank computes the same ranges."""
+    from driftscan_amd import parallel
+
+    n, nr = 129, 8
+    true = np.array([(1.0 - m / 140.0) ** 3 for m in range(n)])
+
+    def measure(rg):
+        return [0.3 * true[a] + float(true[a : b + 1].sum()) for a, b in rg]    # chain floor ~ largest item + the work
+
+    static = [parallel.partition_contiguous(list(range(n)), [0.15 + 0.6 * (1 - m / n) + 0.25 * (1 - m / n) ** 3 for m in range(n)],
+                                            n=nr, r=r) for r in range(nr)]
+    rg = [(p[0], p[-1]) for p in static]
+    first = max(measure(rg)) / np.mean(measure(rg))
+    for _ in range(4):
+        rg = parallel.rebalance_contiguous(rg, measure(rg), r="all")
+        assert rg[0][0] == 0 and rg[-1][1] == n - 1 and all(rg[k][1] + 1 == rg[k + 1][0] for k in range(nr - 1))
+    last = max(measure(rg)) / np.mean(measure(rg))
+    assert first > 1.3 and last < 1.12, (first, last)

@@ -295,3 +295,17 @@ def test_sht_iter_bracket_on_testparams(golden_dir):
         assert outside > 0.05
     assert moved[0] > 1e-3 and moved[14] > 1e-5 and moved[40] > 1e-5
     ob.clear_tables()
+
+
+def test_alias_limits_of_the_library_match_the_oracle():
+    """`dm_bt_alias_info` (host arithmetic of libdriftmi: which polar rings and which m the harmonic-space refinement couples)
+    against the oracle's `alias_limits` at the same threshold — the two restate the same rule from the same recurrences."""
+    from driftscan_amd import healpix
+    from driftscan_amd._lib import bt_alias_info
+    from oracle import btgen as ob
+
+    for nside, lmax, pol in ((8, 14, False), (32, 47, True), (64, 96, True), (128, 96, False), (128, 191, True)):
+        cth, sth = healpix.ring_trig(nside)
+        nr, mc = bt_alias_info(nside, cth, sth, pol, lmax)
+        ml, mcut = ob.alias_limits(nside, lmax, pol, eps=1e-13)
+        assert nr == len(ml) and mc == min(mcut, lmax), (nside, lmax, pol, nr, len(ml), mc, mcut)
