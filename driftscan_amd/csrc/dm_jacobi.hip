@@ -26,6 +26,7 @@
 #include "dm_kernels.h"
 
 #include <algorithm>
+#include <map>
 #include <cmath>
 #include <chrono>
 #include <cstdio>
@@ -614,33 +615,45 @@ struct round_plan {
 
 template <typename F>
 void plan_rounds(const std::vector<int>& nrows, F make_item, round_plan& plan) {
+  // A batch holds thousands of problems of a handful of distinct block counts (configs[1]: 2064 chains of 3 blocks): the
+  // round-robin schedule is made once per block count and shared — this planning ran three to six times per SVD stage, a
+  // millisecond each with a vector of vectors of vectors per problem.
   const int np = (int)nrows.size();
-  std::vector<std::vector<std::vector<std::pair<int, int>>>> sched(np);
+  typedef std::vector<std::vector<std::pair<int, int>>> sched_t;
+  std::map<int, sched_t> by_nb;                 // key: padded (even) block count; 1: the single-block schedule
+  std::vector<const sched_t*> sched(np, nullptr);
+  std::vector<int> nbs(np, 0);
   int maxrounds = 0;
+  size_t nitems = 0;
   for (int p = 0; p < np; ++p) {
-    int nb = (nrows[p] + JB - 1) / JB;
+    const int nb = (nrows[p] + JB - 1) / JB;
+    nbs[p] = nb;
     if (nb <= 0) continue;
-    if (nb == 1) {
-      sched[p] = {{{0, -1}}};
-    } else {
-      int nbe = nb + (nb & 1);
-      tournament(nbe, sched[p]);
-      for (auto& rd : sched[p])
-        for (auto& pr : rd)
-          if (pr.second >= nb) pr.second = -1;  // phantom block
+    const int key = nb == 1 ? 1 : nb + (nb & 1);
+    auto it = by_nb.find(key);
+    if (it == by_nb.end()) {
+      sched_t sc;
+      if (nb == 1) sc = {{{0, -1}}};
+      else tournament(key, sc);
+      it = by_nb.emplace(key, std::move(sc)).first;
     }
-    maxrounds = std::max(maxrounds, (int)sched[p].size());
+    sched[p] = &it->second;
+    maxrounds = std::max(maxrounds, (int)it->second.size());
+    nitems += it->second.size() * (size_t)std::max(1, key / 2);
   }
   plan.items.clear();
+  plan.items.reserve(nitems);
   plan.round_begin.assign(1, 0);
   plan.max_items_per_round = 0;
   for (int r = 0; r < maxrounds; ++r) {
     int slot = 0;
     for (int p = 0; p < np; ++p) {
-      if (r >= (int)sched[p].size()) continue;
-      for (auto& pr : sched[p][r]) {
-        if (pr.second < 0 && sched[p].size() > 1) continue;  // bye: a lone block needs no work this round
-        plan.items.push_back(make_item(p, pr.first, pr.second, slot));
+      if (!sched[p] || r >= (int)sched[p]->size()) continue;
+      const bool multi = sched[p]->size() > 1;
+      for (const auto& pr0 : (*sched[p])[r]) {
+        const int second = pr0.second >= nbs[p] ? -1 : pr0.second;   // phantom block of an odd count
+        if (second < 0 && multi) continue;  // bye: a lone block needs no work this round
+        plan.items.push_back(make_item(p, pr0.first, second, slot));
         ++slot;
       }
     }
