@@ -82,6 +82,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-checks", action="store_true", help="--workload configs4: skip the property checks of the products")
     ap.add_argument("--files", action="store_true",
                     help="--workload configs2|configs3: write the product files (default: products stay in HBM)")
+    ap.add_argument("--truncate", action="store_true",
+                    help="--workload configs2|configs3: truncate the beam transfer blocks on the device (the reference's truncate=True)")
+    ap.add_argument("--outdir", default=None, help="--files: where the temporary product directory is made (default: TMPDIR)")
     ap.add_argument("--share-mmax", type=int, default=None, help=argparse.SUPPRESS)  # any value: toy telescope (rehearsal)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo + --one-gpu rehearses the multi-rank path on a single card (RCCL refuses two ranks per GPU)")
@@ -425,7 +428,7 @@ def class_table(pr, steps=1.0):
     return out
 
 
-def measure_share(workload, share, files=False, share_mmax=None):
+def measure_share(workload, share, files=False, share_mmax=None, truncate=False, outdir=None):
     """BASELINE configs[2] / configs[3] — the north-star job — through ProductManager.generate(): rank r of N is
     emulated in this process (`parallel.set_virtual`: its contiguous, cost-balanced range of m; no process group), so
     the share's wall time is that rank's part of the N-GPU job (m-blocks are independent, the only collective is the
@@ -450,7 +453,7 @@ def measure_share(workload, share, files=False, share_mmax=None):
             tcfg = dict(type="PolarisedCylinder", num_freq=4, freq_start=400.0, freq_end=440.0, freq_mode="edge", num_cylinders=2,
                         cylinder_width=2.0, num_feeds=4, feed_spacing=0.4, tsys=1.0)
         kls = [dict(type="KLTransform", name="kl", threshold=0.1)]
-        conf = dict(config=dict(beamtransfers=True, kltransform=True, psfisher=False, truncate=False,
+        conf = dict(config=dict(beamtransfers=True, kltransform=True, psfisher=False, truncate=bool(truncate),
                                 beam_chunk_gb=float(os.environ.get("DRIFT_BENCH_BEAM_GB", "125")),
                                 device_chunk_gb=float(os.environ.get("DRIFT_BENCH_BT_GB", "48")),
                                 svd_chunk_gb=float(os.environ.get("DRIFT_BENCH_SVD_GB", "48")), keep_products_gb=0.0),
@@ -461,7 +464,7 @@ def measure_share(workload, share, files=False, share_mmax=None):
             conf["psfisher"] = [dict(type="Full", name="ps", klname="kl", threshold=0.1, bandtype="polar", num_theta=3,
                                      k_bands=[dict(spacing="linear", start=0.0, stop=0.25, num=4)])]
         ctx = device.get_context(workspace_bytes=int(os.environ["DRIFTMI_WORKSPACE_GB"]) << 30)
-        with tempfile.TemporaryDirectory() as tmp:
+        with tempfile.TemporaryDirectory(dir=outdir) as tmp:
             conf["config"]["output_directory"] = os.path.join(tmp, "prod")
             cfile = os.path.join(tmp, "params.yaml")
             with open(cfile, "w") as fh:
@@ -507,7 +510,8 @@ def measure_share(workload, share, files=False, share_mmax=None):
                                           else "KLTransform + DoubleKL + PSExact (9 polar bands)",
                                           ", product files written" if files else ", products left in HBM (no files)"),
                            "nfreq": tel.nfreq, "nbase": tel.nbase, "lmax": tel.lmax, "mmax": tel.mmax, "share": share,
-                           "sht_iter": int(tel.sht_iter), "files": bool(files)},
+                           "sht_iter": int(tel.sht_iter), "files": bool(files), "truncate": bool(truncate),
+                           "codec": os.environ.get("DRIFTMI_H5_CODEC", "lzf") if files else None},
                 "share_s": dt,
                 "share_note": "wall time of rank %d of %d for m = %d..%d; the job's wall time is the MAX over the N shares "
                               "(m-blocks are independent, no data-path collective); rank 0 — lowest m, largest matrices, the m "
@@ -536,7 +540,8 @@ def measure_share(workload, share, files=False, share_mmax=None):
 
 
 def run_share(args):
-    line = measure_share(args.workload, args.share, files=args.files, share_mmax=args.share_mmax)
+    line = measure_share(args.workload, args.share, files=args.files, share_mmax=args.share_mmax, truncate=args.truncate,
+                         outdir=args.outdir)
     print(json.dumps(line))
     sys.stdout.flush()
     return 0

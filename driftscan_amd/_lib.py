@@ -201,6 +201,21 @@ class Context(object):
         h.copy_(t)
         return h.numpy()
 
+    def defer_host(self, t, event=None, resident=False):
+        """Device tensor -> `storage.Deferred`: the host copy is made by the writer pool's copy thread, behind an event
+        recorded here (or ``event``, for several views of one result), so the caller goes straight on.  The tensor must
+        not be written to afterwards."""
+        from . import storage
+
+        if event is None:
+            event = self.record_event()
+        return storage.Deferred(self, t, event, resident=resident)
+
+    def record_event(self):
+        ev = self.torch.cuda.Event()
+        ev.record(self.torch.cuda.current_stream(self.device))
+        return ev
+
     def empty(self, shape, dtype):
         tdt = {np.dtype(np.complex128): self.torch.complex128, np.dtype(np.float64): self.torch.float64,
                np.dtype(np.int32): self.torch.int32, np.dtype(np.int64): self.torch.int64}[np.dtype(dtype)]

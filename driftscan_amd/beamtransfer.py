@@ -147,7 +147,13 @@ class BeamTransfer(config.Reader):
             fi = _find_index_sorted(tel.included_freq, fi)
             if fi is None:
                 return bf
-        bf[np.ix_(*ind_list)] = _load_beam_f(self._mfile(mi), "beam_m", fi)
+        data = _load_beam_f(self._mfile(mi), "beam_m", fi)
+        full = (len(tel.included_baseline) == tel.nbase and len(tel.included_pol) == tel.num_pol_sky
+                and (fi is not None or len(tel.included_freq) == tel.nfreq))
+        if full:   # nothing skipped: a plain slice assignment (the general scatter walks the block element by element)
+            bf[..., mi:] = data
+        else:
+            bf[np.ix_(*ind_list)] = data
         return bf
 
     @util.cache_last
@@ -308,18 +314,27 @@ class BeamTransfer(config.Reader):
 
         def write_m(mi, blk):
             with storage.File(self._mfile(mi), "w") as f:
-                data = blk[np.ix_(finc, np.arange(2), binc, pinc, np.arange(mi, tel.lmax + 1))]
+                # the included frequencies / baselines / polarisations and l >= m (beamtransfer.py:567-577, :649-663): plain
+                # slices where nothing is skipped — a 5-axis fancy index copies a configs[2] block (1.8 GB) element by
+                # element under the GIL, six seconds per file, and was what bounded the file output of a rank
+                data = blk[..., mi:]
+                for ax, inc, full in ((0, finc, tel.nfreq), (2, binc, tel.nbase), (3, pinc, tel.num_pol_sky)):
+                    inc = np.asarray(inc)
+                    if inc.size != full or not np.array_equal(inc, np.arange(full)):
+                        data = np.take(data, inc, axis=ax)
                 # chunk shape and compression of beamtransfer.py:548-571
                 f.create_dataset("beam_m", data=data, **storage.compression_kwargs(
                     (1, 2, min(10, len(binc)), len(pinc), tel.lmax + 1 - mi)))
                 f.attrs["m"] = mi
                 f.attrs["frequencies"] = tel.frequencies
 
-        host_all = ctx.to_host(beam_all) if beam_all.numel() * 16 <= (8 << 30) else None
+        # the host copies are made by the writer pool's copy thread (storage.Deferred) while the SVD stage reads the same
+        # blocks: nothing writes to `beam_all` after this point
+        ev = ctx.record_event()
         for mi in range(a, b + 1):
             if os.path.exists(self._mfile(mi)) and not regen:
                 continue
-            storage.submit(write_m, mi, host_all[mi - a] if host_all is not None else ctx.to_host(beam_all[mi - a]))
+            storage.submit(write_m, mi, ctx.defer_host(beam_all[mi - a], ev, resident=True))
 
     def _generate_mfiles(self, regen=False):
         """beam_m files alone (beamtransfer.py:502-676), for callers that want the stage by itself; `generate` runs
@@ -405,8 +420,7 @@ class BeamTransfer(config.Reader):
             del blocks
             sv_host = ctx.to_host(res["singularvalues"])
             if not storage.discard():
-                host = {k: ctx.to_host(res[k]) for k in ("beam_svd", "beam_ut")}
-                host["invbeam_svd"] = None if skip_svd_inv else ctx.to_host(res["invbeam_svd"])
+                ev = ctx.record_event()   # host copies by the copy thread (storage.Deferred); the products are read-only from here
 
                 def write_svd(mi, bsvd, ibsvd, but, sig):
                     with storage.File(self._svdfile(mi), "w") as fs:   # chunk shapes of beamtransfer.py:741-798
@@ -426,8 +440,9 @@ class BeamTransfer(config.Reader):
                 self._sv_host[mi] = views[i]
                 self._dev[mi] = dict(beam_svd=bsvd_v[i], beam_ut=but_v[i], singularvalues=views[i])
                 if not storage.discard():
-                    storage.submit(write_svd, mi, host["beam_svd"][i], None if skip_svd_inv else host["invbeam_svd"][i],
-                                   host["beam_ut"][i], sv_host[i])
+                    storage.submit(write_svd, mi, ctx.defer_host(bsvd_v[i], ev),
+                                   None if skip_svd_inv else ctx.defer_host(res["invbeam_svd"][i], ev),
+                                   ctx.defer_host(but_v[i], ev), sv_host[i])
             del res
             if after_batch is not None:
                 after_batch(batch)

@@ -463,6 +463,13 @@ class DriftioFile(_BaseFile):
         return part[rest] if rest else part
 
     def _write_all(self, tmp):
+        # large new files handed over by the writer threads go to the writer PROCESSES when there are any (below)
+        if self.mode == "w" and _io_procs() > 0 and threading.current_thread().name.startswith("driftmi-io") and \
+                sum(int(np.asarray(a).nbytes) for a in self._data.values()) >= (1 << 20):
+            return _write_in_process(self, tmp)
+        return self._write_local(tmp)
+
+    def _write_local(self, tmp):
         h = ctypes.c_int64(0)
         expected = sum(int(np.asarray(a).nbytes) for a in self._data.values()) + 65536
         self._check(self._lib.dio_create(tmp.encode(), expected, ctypes.byref(h)), "create %s" % tmp)
@@ -601,30 +608,325 @@ def discard():
     return os.environ.get("DRIFTMI_STORAGE", "").lower() == "discard"
 
 
+# ---- writer processes ------------------------------------------------------------------------------
+# libhdf5 is not thread-safe: inside ONE process every HDF5 call sits behind a lock, and although the writer threads
+# compress their chunks outside it, the chunk writes themselves (file-space allocation, chunk index, the copy into the
+# page cache) run one at a time — 2 GB/s per rank, the larger part of a configs[2] job with files.  With
+# DRIFTMI_IO_PROCS = N > 0 the writer threads keep their role (they run the closures that assemble a file) but hand
+# the assembled file — dataset bytes through POSIX shared memory, names / chunk shapes / attributes pickled — to one of N
+# worker PROCESSES, each with its own libhdf5, and wait for it: N files are compressed AND written at the same time.
+# The workers are fresh interpreters (spawn: started as children, nothing of this process' GPU state is inherited); they
+# import this module only.
+_workers = None            # queue.Queue of idle _Worker objects
+_worker_list = []
+_proc_lock = threading.Lock()
+
+
+class _Worker(object):
+    """One writer process: `python -c "... io_worker.main()"` talking length-prefixed pickles over its pipes (not
+    multiprocessing's spawn, which would re-import the caller's __main__ module in every child)."""
+
+    def __init__(self):
+        import subprocess
+        import sys
+
+        root = os.path.dirname(_HERE)
+        code = "import sys; sys.path.insert(0, %r); from driftscan_amd import io_worker; io_worker.main()" % root
+        env = dict(os.environ, DRIFTMI_IO_PROCS="0", OMP_NUM_THREADS="1")
+        self.p = subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
+
+    def run(self, task):
+        import pickle
+        import struct
+
+        blob = pickle.dumps(task, protocol=pickle.HIGHEST_PROTOCOL)
+        self.p.stdin.write(struct.pack("<Q", len(blob)))
+        self.p.stdin.write(blob)
+        self.p.stdin.flush()
+        hdr = self.p.stdout.read(8)
+        if len(hdr) < 8:
+            raise IOError("writer process died (exit code %s)" % self.p.poll())
+        status, val = pickle.loads(self.p.stdout.read(struct.unpack("<Q", hdr)[0]))
+        if status != "ok":
+            raise IOError("writer process: %s" % val)
+        return val
+
+    def stop(self):
+        try:
+            self.p.stdin.close()
+            self.p.wait(timeout=30)
+        except Exception:
+            self.p.kill()
+
+
+def _io_procs():
+    if backend() != "driftio":
+        return 0
+    return int(os.environ.get("DRIFTMI_IO_PROCS", "0"))
+
+
+def _proc_task(tmp, specs, attrs):
+    """Worker side: attach the shared-memory blocks, write the file `tmp` with this process' libdriftio."""
+    import mmap
+
+    blocks = []
+    try:
+        f = DriftioFile.__new__(DriftioFile)
+        f._lib = load_driftio()
+        if f._lib is None:
+            raise IOError("libdriftio is not available in the writer process")
+        f.path, f.mode, f._h, f._infos = tmp, "w", None, {}
+        f._data, f._opts = {}, {}
+        f.attrs = dict(attrs)
+        for name, shm_name, shape, dtype, chunks, comp in specs:
+            if shm_name is None:
+                f._data[name] = np.zeros(shape, dtype=np.dtype(dtype))
+            else:
+                # mapped by hand (POSIX shared memory lives under /dev/shm): multiprocessing.shared_memory would register the
+                # block with THIS process' resource tracker, which then tries to unlink what the parent owns
+                fd = os.open("/dev/shm/" + shm_name.lstrip("/"), os.O_RDWR)
+                try:
+                    blk = mmap.mmap(fd, 0)
+                finally:
+                    os.close(fd)
+                blocks.append(blk)
+                f._data[name] = np.ndarray(shape, dtype=np.dtype(dtype), buffer=blk)
+            f._opts[name] = (chunks, comp)
+        f._write_local(tmp)
+        f._data.clear()
+    finally:
+        for blk in blocks:
+            try:
+                blk.close()
+            except BufferError:
+                pass
+    return os.path.getsize(tmp)
+
+
+def _write_in_process(f, tmp):
+    """Writer-thread side: copy the datasets of `f` into shared memory, have a worker process write `tmp`, wait."""
+    global _workers
+    from multiprocessing import shared_memory
+
+    with _proc_lock:
+        if _workers is None:
+            import queue
+
+            _workers = queue.Queue()
+            for _ in range(_io_procs()):
+                w = _Worker()
+                _worker_list.append(w)
+                _workers.put(w)
+        workers = _workers
+    blocks, specs = [], []
+    try:
+        for name, arr in f._data.items():
+            arr = np.asarray(arr)
+            chunks, comp = f._opts.get(name, (None, None))
+            if arr.size == 0:
+                specs.append((name, None, arr.shape, arr.dtype.str, chunks, comp))
+                continue
+            blk = shared_memory.SharedMemory(create=True, size=int(arr.nbytes))
+            blocks.append(blk)
+            np.copyto(np.ndarray(arr.shape, dtype=arr.dtype, buffer=blk.buf), arr)
+            specs.append((name, blk.name, arr.shape, arr.dtype.str, chunks, comp))
+        w = workers.get()
+        try:
+            w.run((tmp, specs, dict(f.attrs)))
+        finally:
+            workers.put(w)
+    finally:
+        for blk in blocks:
+            blk.close()
+            blk.unlink()
+
+
+def shutdown_writers():
+    """Stop the writer processes (tests; a long-running driver keeps them)."""
+    global _workers
+    with _proc_lock:
+        for w in _worker_list:
+            w.stop()
+        del _worker_list[:]
+        _workers = None
+
+
+_cap_bytes = None
+
+
+def _pending_cap():
+    """Bytes of products that may wait in the writer queue.  ``DRIFTMI_IO_PENDING_GB`` if set; otherwise a fifth of the
+    host memory available at first use, shared between the ranks of the node, at most 32 GB: with 8 GB (rounds 1-3) a
+    configs[2] rank had three files in flight and the GPU waited for the writers, 39.8 s per 25 m-blocks against 9.4 s of
+    compute."""
+    global _cap_bytes
+    if _cap_bytes is None:
+        e = os.environ.get("DRIFTMI_IO_PENDING_GB")
+        if e:
+            _cap_bytes = float(e) * (1 << 30)
+        else:
+            avail = 16 << 30
+            try:
+                with open("/proc/meminfo") as f:
+                    for line in f:
+                        if line.startswith("MemAvailable:"):
+                            avail = int(line.split()[1]) * 1024
+                            break
+            except OSError:
+                pass
+            local = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+            _cap_bytes = float(min(32 << 30, max(2 << 30, avail // (5 * local))))
+    return _cap_bytes
+
+
+class Deferred:
+    """A device tensor on its way into a file.  `Context.defer_host` records an event behind whatever produced it and
+    hands it over; the COPY THREAD of the writer pool makes the host copy — page-locked allocation (a configs[2] share pins
+    145 GB in its life, 8 GB/s) and the transfer, on a stream of its own behind that event — while the compute stream goes
+    on with the next stage; the device block is let go as soon as its copy is complete.  Done inline (`Context.to_host`,
+    rounds 1-3) the same copies were 8.3 of the 29 s of a share 0/16 with files, with the GPU idle.
+
+    ``resident``: the caller keeps the tensor alive anyway (the beam transfer blocks of a range, which the SVD stage
+    reads next) — it does not count against the bound on device memory held by the queue (``DRIFTMI_IO_DEVICE_GB``)."""
+
+    __slots__ = ("ctx", "t", "event", "nbytes", "resident")
+
+    def __init__(self, ctx, t, event, resident=False):
+        self.ctx, self.t, self.event, self.resident = ctx, t, event, bool(resident)
+        self.nbytes = int(t.numel()) * int(t.element_size())
+
+    def host(self):
+        torch = self.ctx.torch
+        with torch.cuda.device(self.ctx.device):
+            h = torch.empty(self.t.shape, dtype=self.t.dtype, pin_memory=True)
+            s = _copy_stream(self.ctx)
+            s.wait_event(self.event)
+            with torch.cuda.stream(s):
+                h.copy_(self.t, non_blocking=True)
+            s.synchronize()
+        self.t = self.event = None
+        return h.numpy()
+
+
+_copy_streams = {}
+_copier = None
+# what the queue holds: host bytes (products copied or being copied, until their file is written), tasks, and device
+# bytes (deferred products not yet copied, other than `resident` ones)
+_cv = threading.Condition()
+_held = {"host": 0, "count": 0, "dev": 0}
+
+
+def _copy_stream(ctx):
+    if ctx.device not in _copy_streams:
+        _copy_streams[ctx.device] = ctx.torch.cuda.Stream(device=ctx.device)
+    return _copy_streams[ctx.device]
+
+
+def _device_cap():
+    return float(os.environ.get("DRIFTMI_IO_DEVICE_GB", "48")) * (1 << 30)
+
+
+def _host_acquire(nbytes, nthreads):
+    """Blocks until the queue has room for another task of ``nbytes`` (always admits one when it is empty)."""
+    cap = _pending_cap()
+    with _cv:
+        while _held["count"] > 0 and (_held["count"] >= 4 * nthreads or _held["host"] + nbytes > cap):
+            _cv.wait()
+        _held["host"] += nbytes
+        _held["count"] += 1
+
+
+def _release(host=0, dev=0, count=0):
+    with _cv:
+        _held["host"] -= host
+        _held["dev"] -= dev
+        _held["count"] -= count
+        _cv.notify_all()
+
+
+class _Chained:
+    """Future of a task that goes through the copy thread first: the copy, then the write it queued."""
+
+    def __init__(self, outer):
+        self.outer = outer
+
+    def result(self):
+        return self.outer.result().result()
+
+    def done(self):
+        return self.outer.done() and (self.outer.exception() is not None or self.outer.result().done())
+
+    def exception(self):
+        return self.outer.exception() or self.outer.result().exception()
+
+
+def _resolve(args):
+    return tuple(a.host() if isinstance(a, Deferred) else a for a in args)
+
+
 def submit(fn, *args):
-    """Run ``fn(*args)`` (a closure that writes one file) on the writer pool."""
-    global _pool
+    """Run ``fn(*args)`` (a closure that writes one file) on the writer pool.  `Deferred` arguments reach ``fn`` as numpy
+    arrays: the copy thread makes them, in submission order, when the queue has room for them on the host, and then queues
+    the write — the caller only waits if the device memory held that way passes ``DRIFTMI_IO_DEVICE_GB``.  Plain numpy
+    arguments wait for room here."""
+    global _pool, _copier
     if discard():
         return
     nthreads = int(os.environ.get("DRIFTMI_IO_THREADS", "8"))
     if nthreads <= 0:
-        fn(*args)
+        fn(*_resolve(args))
         return
     # bound the host memory held by queued products: by count and by bytes (a configs[2] m-block is 1.8 GB of beam_m
-    # and 2.6 GB of SVD products: thirty-two of them queued would be most of a host's memory)
-    nbytes = sum(int(a.nbytes) for a in args if isinstance(a, np.ndarray))
-    cap = float(os.environ.get("DRIFTMI_IO_PENDING_GB", "8")) * (1 << 30)
+    # and 2.6 GB of SVD products)
+    nbytes = sum(int(a.nbytes) for a in args if isinstance(a, (np.ndarray, Deferred)))
+    deferred = [a for a in args if isinstance(a, Deferred)]
     with _plock:
         if _pool is None:
             from concurrent.futures import ThreadPoolExecutor
 
             _pool = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="driftmi-io")
-        wait = []
-        while _pending and (len(_pending) >= 4 * nthreads or sum(b for _, b in _pending) + nbytes > cap):
-            wait.append(_pending.pop(0)[0])
-        _pending.append((_pool.submit(fn, *args), nbytes))
-    for w in wait:
-        w.result()
+            _copier = ThreadPoolExecutor(max_workers=1, thread_name_prefix="driftmi-copy")
+        pool, copier = _pool, _copier
+
+    def write():
+        try:
+            return fn(*write.args)
+        finally:
+            write.args = None
+            _release(host=nbytes, count=1)
+
+    if deferred:
+        dev = sum(a.nbytes for a in deferred if not a.resident)
+        if dev:
+            cap = _device_cap()
+            with _cv:
+                while _held["dev"] > 0 and _held["dev"] + dev > cap:
+                    _cv.wait()
+                _held["dev"] += dev
+
+        def copy():
+            got = False
+            try:
+                _host_acquire(nbytes, nthreads)
+                got = True
+                write.args = _resolve(args)
+            except BaseException:
+                if got:
+                    _release(host=nbytes, count=1)
+                raise
+            finally:
+                _release(dev=dev)
+            return pool.submit(write)
+
+        fut = _Chained(copier.submit(copy))
+    else:
+        _host_acquire(nbytes, nthreads)
+        write.args = args
+        fut = pool.submit(write)
+    with _plock:
+        while _pending and _pending[0].done() and _pending[0].exception() is None:
+            _pending.pop(0)
+        _pending.append(fut)
 
 
 def flush():
@@ -633,7 +935,7 @@ def flush():
         with _plock:
             if not _pending:
                 return
-            w = _pending.pop(0)[0]
+            w = _pending.pop(0)
         w.result()
 
 

@@ -465,3 +465,44 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     psd = os.path.relpath(pm.psestimators["ps"].psdir, one)
     a, b = load(psd + "/fisher.hdf5", "fisher")
     assert np.abs(a).max() > 0 and np.abs(a - b).max() <= 1e-8 * np.abs(a).max()
+
+
+def test_deferred_host_copies(tmp_path, monkeypatch):
+    """`Context.defer_host` / `storage.Deferred`: the copy thread copies what the tensor held when it was handed over (an
+    event behind its producer), on a stream of its own, while the compute stream goes on with other tensors; the files
+    written from such copies are the ones the inline path writes; the device block is let go after the copy."""
+    import torch
+    from driftscan_amd import device, storage
+
+    device.reset_context()
+    ctx = device.get_context()
+    monkeypatch.setenv("DRIFTMI_IO_THREADS", "3")
+    monkeypatch.delenv("DRIFTMI_STORAGE", raising=False)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    src, want = [], []
+    for i in range(6):
+        t = torch.randn(3, 1 << 20, generator=g, device="cuda", dtype=torch.float64)
+        t = torch.complex(t, t.flip(0))
+        t.mul_(float(i + 1))               # the producer: the event must sit behind it
+        src.append(t)
+        want.append(None)
+
+    def write(i, a, b):
+        with storage.File(str(tmp_path / ("d%d.hdf5" % i)), "w") as f:
+            f.create_dataset("a", data=a, **storage.compression_kwargs((1, 1 << 16)))
+            f.create_dataset("b", data=b)
+
+    for i, t in enumerate(src):
+        ev = ctx.record_event()
+        storage.submit(write, i, ctx.defer_host(t[:2], ev), ctx.defer_host(t[2], ev))
+        # the compute stream moves on at once: work on OTHER memory while the copies run
+        _ = (torch.ones(1 << 22, device="cuda") * 2).sum()
+    before = torch.cuda.memory_allocated()
+    want = [t.cpu().numpy() for t in src]
+    del src, t
+    storage.flush()
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated() <= before - 6 * 3 * (1 << 20) * 16 + (1 << 20)   # the deferred views held the blocks
+    for i in range(6):
+        with storage.File(str(tmp_path / ("d%d.hdf5" % i)), "r") as f:
+            assert np.array_equal(f["a"][...], want[i][:2]) and np.array_equal(f["b"][...], want[i][2])

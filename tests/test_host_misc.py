@@ -377,3 +377,45 @@ def test_rebalance_contiguous_levels_measured_times():
         assert rg[0][0] == 0 and rg[-1][1] == n - 1 and all(rg[k][1] + 1 == rg[k + 1][0] for k in range(nr - 1))
     last = max(measure(rg)) / np.mean(measure(rg))
     assert first > 1.3 and last < 1.12, (first, last)
+
+
+def test_deferred_arguments_go_through_the_copy_thread(tmp_path, monkeypatch):
+    """storage.submit with `Deferred` arguments (device products on their way into a file): the copy thread resolves them
+    in submission order, the write sees numpy arrays, failures of either stage come out of flush(), and the inline mode
+    resolves on the spot.  (The device side of `Deferred.host` is covered by tests/test_gpu_pipeline.py.)"""
+    import threading
+    from driftscan_amd import storage
+
+    order, seen = [], {}
+
+    class Stub(storage.Deferred):
+        __slots__ = ("i", "fail")
+
+        def __init__(self, i, fail=False):
+            self.i, self.fail, self.nbytes = i, fail, 800
+            self.ctx = self.t = self.event = None
+            self.resident = False
+
+        def host(self):
+            assert threading.current_thread().name.startswith(("driftmi-copy", "MainThread"))
+            if self.fail:
+                raise RuntimeError("copy failed")
+            order.append(self.i)
+            return np.full(100, float(self.i))
+
+    def write(i, arr, plain):
+        assert isinstance(arr, np.ndarray) and plain == "x"
+        seen[i] = float(arr[0])
+
+    for threads in ("3", "0"):
+        monkeypatch.setenv("DRIFTMI_IO_THREADS", threads)
+        order.clear(); seen.clear()
+        for i in range(20):
+            storage.submit(write, i, Stub(i), "x")
+        storage.flush()
+        assert order == list(range(20)) and seen == {i: float(i) for i in range(20)}
+    monkeypatch.setenv("DRIFTMI_IO_THREADS", "2")
+    storage.submit(write, 0, Stub(0, fail=True), "x")
+    with pytest.raises(RuntimeError):
+        storage.flush()
+    storage.flush()

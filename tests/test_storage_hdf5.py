@@ -350,3 +350,58 @@ def test_bitshuffle_files_roundtrip(tmp_path, monkeypatch):
         assert res.returncode == 0, res.stderr
         nf, fid, cd = json.loads(res.stdout)
         assert nf == 1 and fid == [32008] and cd == [0, 4, 16, 0, 2]
+
+
+def test_writer_processes_produce_the_same_files(tmp_path, monkeypatch):
+    """DRIFTMI_IO_PROCS: the writer threads hand an assembled file to worker PROCESSES (each with its own libhdf5; dataset
+    bytes through POSIX shared memory) — same bytes, same layout, attributes and chunking as the in-process path, errors
+    surface in flush(), nothing is left in /dev/shm."""
+    monkeypatch.setenv("DRIFTMI_STORAGE", "hdf5")
+    monkeypatch.setenv("DRIFTMI_IO_THREADS", "4")
+    rng = np.random.default_rng(3)
+    data = {i: rng.standard_normal((6, 2, 10, 4, 300)) + 1j * rng.standard_normal((6, 2, 10, 4, 300)) for i in range(5)}
+
+    def write(tag, i):
+        with storage.File(str(tmp_path / ("%s_%d.hdf5" % (tag, i))), "w") as f:
+            f.create_dataset("beam_m", data=data[i], **storage.compression_kwargs((1, 2, 10, 4, 300)))
+            f.create_dataset("singularvalues", data=np.arange(7.0) + i)
+            f.create_dataset("empty", data=np.zeros((0, 3)))
+            f.attrs["m"] = i
+            f.attrs["frequencies"] = np.linspace(400.0, 450.0, 6)
+            f.attrs["FLAGS"] = "Normal"
+            f.attrs["SUBSET"] = True
+
+    shm_before = set(os.listdir("/dev/shm")) if os.path.isdir("/dev/shm") else set()
+    try:
+        for tag, procs in (("thr", "0"), ("proc", "3")):
+            monkeypatch.setenv("DRIFTMI_IO_PROCS", procs)
+            for i in data:
+                storage.submit(write, tag, i)
+            storage.flush()
+        for i in data:
+            pa, pb = str(tmp_path / ("thr_%d.hdf5" % i)), str(tmp_path / ("proc_%d.hdf5" % i))
+            assert os.path.getsize(pa) == os.path.getsize(pb)
+            with storage.File(pa, "r") as a, storage.File(pb, "r") as b:
+                assert np.array_equal(a["beam_m"][:], data[i]) and np.array_equal(b["beam_m"][:], data[i])
+                assert np.array_equal(a["singularvalues"][:], b["singularvalues"][:]) and b["empty"].shape == (0, 3)
+                assert a["beam_m"].chunks == b["beam_m"].chunks == (1, 2, 10, 4, 300)
+                assert a["beam_m"].compression == b["beam_m"].compression == "lzf"
+                assert b.attrs["m"] == i and b.attrs["FLAGS"] == "Normal" and bool(b.attrs["SUBSET"])
+                assert np.array_equal(a.attrs["frequencies"], b.attrs["frequencies"])
+        # a failing write in a worker process surfaces in flush(), and the pool keeps working afterwards
+        monkeypatch.setenv("DRIFTMI_IO_PROCS", "3")
+
+        def bad():
+            with storage.File(str(tmp_path / "no_such_dir" / "x.hdf5"), "w") as f:
+                f.create_dataset("big", data=data[0])
+
+        storage.submit(bad)
+        with pytest.raises(IOError):
+            storage.flush()
+        storage.submit(write, "again", 0)
+        storage.flush()
+        assert os.path.exists(str(tmp_path / "again_0.hdf5")) and not [p for p in os.listdir(str(tmp_path)) if ".tmp" in p]
+    finally:
+        storage.shutdown_writers()
+    if os.path.isdir("/dev/shm"):
+        assert set(os.listdir("/dev/shm")) - shm_before == set()
