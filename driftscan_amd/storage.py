@@ -816,6 +816,15 @@ _cv = threading.Condition()
 _held = {"host": 0, "count": 0, "dev": 0}
 
 
+def _writer_init():
+    """Writer threads (and the chunk compressors they start, which inherit it) run at a lower priority than the thread
+    that drives the GPU: with more of them than the rank has cores, kernel launches would otherwise queue behind LZ4."""
+    try:
+        os.setpriority(os.PRIO_PROCESS, threading.get_native_id(), int(os.environ.get("DRIFTMI_IO_NICE", "10")))
+    except (OSError, AttributeError):
+        pass
+
+
 def _copy_stream(ctx):
     if ctx.device not in _copy_streams:
         _copy_streams[ctx.device] = ctx.torch.cuda.Stream(device=ctx.device)
@@ -829,8 +838,9 @@ def _device_cap():
 def _host_acquire(nbytes, nthreads):
     """Blocks until the queue has room for another task of ``nbytes`` (always admits one when it is empty)."""
     cap = _pending_cap()
+    small = nbytes < (32 << 20)   # a KL or marker file does not wait behind the gigabytes of beam and SVD products
     with _cv:
-        while _held["count"] > 0 and (_held["count"] >= 4 * nthreads or _held["host"] + nbytes > cap):
+        while _held["count"] > 0 and (_held["count"] >= 64 * nthreads or (not small and _held["host"] + nbytes > cap)):
             _cv.wait()
         _held["host"] += nbytes
         _held["count"] += 1
@@ -884,7 +894,7 @@ def submit(fn, *args):
         if _pool is None:
             from concurrent.futures import ThreadPoolExecutor
 
-            _pool = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="driftmi-io")
+            _pool = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="driftmi-io", initializer=_writer_init)
             _copier = ThreadPoolExecutor(max_workers=1, thread_name_prefix="driftmi-copy")
         pool, copier = _pool, _copier
 

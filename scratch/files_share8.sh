@@ -10,11 +10,12 @@ shm_avail=$(df -k --output=avail /dev/shm | tail -1)
 tmp_avail=$(df -k --output=avail /tmp | tail -1)
 if [ "$tmp_avail" -lt 200000000 ] && [ "$shm_avail" -gt 300000000 ]; then out=/dev/shm; fi
 echo "outdir $out" >> gpurun_out/${tag}_env.txt
-export DRIFTMI_H5_CODEC=bitshuffle
-timeout -k 10 400 python3 bench.py --workload configs2 --share $share --truncate > gpurun_out/${tag}_nofiles.log 2>&1 || { tail -5 gpurun_out/${tag}_nofiles.log; exit 1; }
+mode=${3:-bshuf}
+if [ "$mode" = bshuf ]; then export DRIFTMI_H5_CODEC=bitshuffle; trunc=--truncate; else export DRIFTMI_H5_CODEC=lzf; trunc=; fi
+timeout -k 10 400 python3 bench.py --workload configs2 --share $share $trunc > gpurun_out/${tag}_nofiles.log 2>&1 || { tail -5 gpurun_out/${tag}_nofiles.log; exit 1; }
 tail -1 gpurun_out/${tag}_nofiles.log > gpurun_out/${tag}_nofiles.json
 echo "nofiles done" 
-timeout -k 10 600 python3 bench.py --workload configs2 --share $share --truncate --files --outdir $out > gpurun_out/${tag}_files.log 2>&1 || { tail -5 gpurun_out/${tag}_files.log; rm -rf $out/tmp*; exit 1; }
+timeout -k 10 600 python3 bench.py --workload configs2 --share $share $trunc --files --outdir $out > gpurun_out/${tag}_files.log 2>&1 || { tail -5 gpurun_out/${tag}_files.log; rm -rf $out/tmp*; exit 1; }
 tail -1 gpurun_out/${tag}_files.log > gpurun_out/${tag}_files.json
 python3 - <<PY
 import json

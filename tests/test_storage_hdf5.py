@@ -271,6 +271,41 @@ def test_bitshuffle_lz4_codec_roundtrip_and_edges():
         assert lib.dio_bshuf_lz4_decode(bytes(out[: got - 1]), got - 1, es, back, len(a)) == 0 or n * es % (8 * es) != 0
 
 
+def test_bitshuffle_layout_against_its_statement():
+    """The vectorised forward transform (16 x 16 byte transposes + movemask bit rows, csrc/dm_h5io.c) against the layout
+    written out with numpy: bit k of byte b of the elements of a block, eight elements to a byte (bit j from element
+    8 i + j), rows ordered (b, k); blocks as bshuf_bitshuffle cuts them; sizes that exercise the 32-, 16- and 8-wide
+    steps and the element sizes without a vector byte stage."""
+    lib = storage.load_driftio()
+    rng = np.random.default_rng(1)
+
+    def statement(raw, n, es, blk):
+        out = np.empty_like(raw)
+        done = 0
+        while done < n:
+            cur = blk if n - done >= blk else ((n - done) // 8) * 8
+            if cur == 0:
+                break
+            x = raw[done * es : (done + cur) * es].reshape(cur, es)
+            bits = np.unpackbits(x.T.reshape(es, cur, 1), axis=2, bitorder="little")
+            out[done * es : (done + cur) * es] = np.packbits(bits.transpose(0, 2, 1).reshape(es * 8, cur), axis=1,
+                                                              bitorder="little").ravel()
+            done += cur
+        out[done * es :] = raw[done * es :]
+        return out
+
+    for es in (1, 3, 4, 8, 16):
+        for n in (8, 16, 24, 40, 512, 520, 1027, 4099):
+            for blk in (0, 8, 64, 1024):
+                raw = rng.integers(0, 256, n * es, dtype=np.uint8)
+                out, back = np.empty_like(raw), np.empty_like(raw)
+                b = blk if blk else max(8, (8192 // es) // 8 * 8)
+                assert lib.dio_bitshuffle_blocked(raw.ctypes.data, out.ctypes.data, n, es, blk, 0) == n * es
+                assert np.array_equal(out, statement(raw, n, es, b)), (es, n, blk)
+                assert lib.dio_bitshuffle_blocked(out.ctypes.data, back.ctypes.data, n, es, blk, 1) == n * es
+                assert np.array_equal(back, raw)
+
+
 @pytest.mark.skipif(not os.path.exists(CONDA_PY), reason="no interpreter with imagecodecs")
 def test_bitshuffle_and_lz4_against_the_real_libraries(tmp_path):
     """The bit transpose against the bitshuffle library and the LZ4 blocks against liblz4, both through imagecodecs under
