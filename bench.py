@@ -443,7 +443,14 @@ def measure_share(workload, share, files=False, share_mmax=None, truncate=False,
     r, n = (int(x) for x in share.split("/"))
     if not files:
         os.environ["DRIFTMI_STORAGE"] = "discard"
-    os.environ.setdefault("DRIFTMI_WORKSPACE_GB", "80")
+    # batch budgets of a 288 GB card: 11 m-blocks per SVD batch and per eigh_gen call at configs[2] (three equal batches for
+    # rank 0 of 8) — fewer lock-step launch chains, and the KL eigenproblems reach the batch sizes where the two-stage
+    # tridiagonalisation pays (share 0/8: 32.2 -> 28.5 s against 48 / 48 / 80 GB; torch peak 123 GB + the 100 GB arena).
+    # configs[3] keeps four covariance-sized matrices per m alive in its DoubleKL stage: the smaller budgets stay.
+    big = workload == "configs2"
+    os.environ.setdefault("DRIFTMI_WORKSPACE_GB", "100" if big else "80")
+    svd_gb = float(os.environ.get("DRIFT_BENCH_SVD_GB", "96" if big else "48"))
+    kl_gb = float(os.environ.get("DRIFT_BENCH_KL_GB", "110" if big else "48"))
     from driftscan_amd import device, manager, parallel
 
     parallel.set_virtual(r, n)
@@ -452,11 +459,11 @@ def measure_share(workload, share, files=False, share_mmax=None, truncate=False,
         if share_mmax:   # rehearsal of the mode on a toy telescope (tests, CPU-sized boxes)
             tcfg = dict(type="PolarisedCylinder", num_freq=4, freq_start=400.0, freq_end=440.0, freq_mode="edge", num_cylinders=2,
                         cylinder_width=2.0, num_feeds=4, feed_spacing=0.4, tsys=1.0)
-        kls = [dict(type="KLTransform", name="kl", threshold=0.1)]
+        kls = [dict(type="KLTransform", name="kl", threshold=0.1, kl_chunk_gb=kl_gb)]
         conf = dict(config=dict(beamtransfers=True, kltransform=True, psfisher=False, truncate=bool(truncate),
                                 beam_chunk_gb=float(os.environ.get("DRIFT_BENCH_BEAM_GB", "125")),
                                 device_chunk_gb=float(os.environ.get("DRIFT_BENCH_BT_GB", "48")),
-                                svd_chunk_gb=float(os.environ.get("DRIFT_BENCH_SVD_GB", "48")), keep_products_gb=0.0),
+                                svd_chunk_gb=svd_gb, keep_products_gb=0.0),
                     telescope=tcfg, kltransform=kls)
         if workload == "configs3":
             kls.append(dict(type="DoubleKL", name="dk", threshold=0.1, foreground_threshold=100.0))

@@ -404,6 +404,10 @@ class BeamTransfer(config.Reader):
         per_m = F * (T * (P * L + T) * 2 + K * P * L * 2 + K * T) * 16
         nb = max(1, int(self.svd_chunk_gb * (1 << 30) // per_m))
         ms = list(ms)
+        # as many batches as the budget asks for, of equal size: a short last batch runs the same lock-step launch chains
+        # for a fraction of the work (and falls under the batch sizes where the two-stage tridiagonalisation pays)
+        nbat = max(1, -(-len(ms) // nb))
+        nb = -(-len(ms) // nbat)
         return [ms[c0 : c0 + nb] for c0 in range(0, len(ms), nb)]
 
     def _svd_batches(self, ms, regen=False, skip_svd_inv=False, after_batch=None):

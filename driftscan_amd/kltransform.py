@@ -277,6 +277,14 @@ class KLTransform(config.Reader):
             used += need
         if cur:
             out.append(cur)
+        if len(out) > 1:
+            # the same number of batches with about equal counts (still within the budget: blocks of neighbouring m have
+            # about the same ndof) instead of full batches and a short one — see BeamTransfer._svd_batch_lists
+            ms = [mi for b in out for mi in b]
+            nb = -(-len(ms) // len(out))
+            even = [ms[c0 : c0 + nb] for c0 in range(0, len(ms), nb)]
+            if all(sum(16.0 * float(self.beamtransfer.ndof(mi)) ** 2 * 16.0 for mi in b) <= budget for b in even):
+                out = even
         return out
 
     def generate_ms(self, ms, regen=False):
