@@ -259,6 +259,20 @@ __device__ __forceinline__ int dm_xcd_remap(int bid, int nblocks) {
   return (bid % nx) * per + bid / nx;
 }
 
+// The same with the XCDs kept NEAR each other in the tile list: the list is cut into super-blocks of 8 * chunk tiles and
+// XCD x takes the x-th chunk of each — for launches whose problems share an operand that fits the Infinity Cache but not
+// an L2 (the covariance projections: every row-frequency product of an m-block reads all of that block's beam_svd rows,
+// 190 MB at configs[2]): with one contiguous run per XCD eight different m-blocks are in flight and the shared operand
+// comes from HBM every time.
+__device__ __forceinline__ int dm_xcd_remap_chunked(int bid, int nblocks, int chunk) {
+  const int nx = 8;
+  const int S = nx * chunk;
+  const int sb = bid / S;
+  if ((sb + 1) * S > nblocks) return bid;  // ragged last super-block keeps its ids
+  const int r = bid - sb * S;
+  return sb * S + (r % nx) * chunk + r / nx;
+}
+
 __device__ __forceinline__ double dm_wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -255,8 +255,9 @@ __global__ __launch_bounds__(256, 3) void zgemm_grouped_kernel(const dm_gemm_des
 // loads as the four of a complex product: twice the B columns per wave restore the MFMA-to-load ratio of the complex kernel)
 template <bool B_REAL, bool B_GATHER, int PD, int NJ = 2>
 __global__ __launch_bounds__(256, 2) void zgemm4_grouped_kernel(const dm_gemm_desc* __restrict__ descs,
-                                                                const dm_gemm_tile* __restrict__ tiles, int ntiles) {
-  const int bid = dm_xcd_remap(blockIdx.x, ntiles);
+                                                                const dm_gemm_tile* __restrict__ tiles, int ntiles,
+                                                                int xchunk) {
+  const int bid = xchunk > 0 ? dm_xcd_remap_chunked(blockIdx.x, ntiles, xchunk) : dm_xcd_remap(blockIdx.x, ntiles);
   const dm_gemm_tile tl = tiles[bid];
   const dm_gemm_desc d = descs[tl.desc];
   const int lane = threadIdx.x & 63;
@@ -496,9 +497,9 @@ __global__ __launch_bounds__(256, 2) void zgemm4_grouped_kernel(const dm_gemm_de
 // ---- all-real variant: C[M x N] (double) = alpha * A * B + beta * C, same tiling, one MFMA per
 // (tile, k-step).  Used by the divide & conquer eigenvector updates (real orthogonal matrices).
 __global__ __launch_bounds__(256) void dgemm_grouped_kernel(const dm_gemm_desc* __restrict__ descs,
-                                                            const dm_gemm_tile* __restrict__ tiles, int ntiles) {
+                                                            const dm_gemm_tile* __restrict__ tiles, int ntiles, int xchunk) {
   __shared__ double As[BM * LDP], Bs[BN * LDP];
-  const int bid = dm_xcd_remap(blockIdx.x, ntiles);
+  const int bid = xchunk > 0 ? dm_xcd_remap_chunked(blockIdx.x, ntiles, xchunk) : dm_xcd_remap(blockIdx.x, ntiles);
   const dm_gemm_tile t = tiles[bid];
   const dm_gemm_desc d = descs[t.desc];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -746,15 +747,16 @@ int dm_gemm_plan_run(dm_ctx* ctx, const dm_gemm_plan& plan, const char* dblob) {
       (void)hipEventCreate(&e1);
       (void)hipEventRecord(e0, ctx->stream);
     }
+    static const int xchunk_c = getenv("DM_GEMM_XCHUNK") ? atoi(getenv("DM_GEMM_XCHUNK")) : 64;
     {
       dm_prof_scope ps(ctx, DM_PROF_GEMM, fl_c);
       if (use4)
         if (deep)
           hipLaunchKernelGGL((zgemm4_grouped_kernel<false, false, 2>), dim3((unsigned)n0), dim3(256), 0, ctx->stream,
-                             dd, dt, (int)n0);
+                             dd, dt, (int)n0, xchunk_c);
         else
           hipLaunchKernelGGL((zgemm4_grouped_kernel<false, false, 1>), dim3((unsigned)n0), dim3(256), 0, ctx->stream,
-                             dd, dt, (int)n0);
+                             dd, dt, (int)n0, xchunk_c);
       else
         hipLaunchKernelGGL((zgemm_grouped_kernel<false, false>), dim3((unsigned)n0), dim3(256), 0, ctx->stream, dd,
                            dt, (int)n0);
@@ -774,9 +776,14 @@ int dm_gemm_plan_run(dm_ctx* ctx, const dm_gemm_plan& plan, const char* dblob) {
   if (n3) {
     const dm_gemm_tile* dt = dt_g;
     dm_prof_scope ps(ctx, DM_PROF_GEMM_COV, fl_g);
+    // DM_COV_XCHUNK (and DM_GEMM_XCHUNK, DM_GEMMR_XCHUNK, DM_DGEMM_XCHUNK for the other classes): tiles per XCD chunk of the
+    // launch (dm_xcd_remap_chunked); 0 = one contiguous run of the tile list per XCD, the rule of rounds 1-3.  Measured
+    // (round 4, scratch/cov_chunk.sh, scratch/gemm_chunk.sh): covariance projections of a configs[2] share 40.0 -> 45.0
+    // TFLOP/s, its grouped ZGEMM 11.0 -> 10.3 s, configs[1] step 129.3 -> 126 ms; flat between 4 and 1024 tiles per chunk.
+    static const int xchunk = getenv("DM_COV_XCHUNK") ? atoi(getenv("DM_COV_XCHUNK")) : 64;
     if (use4)
       hipLaunchKernelGGL((zgemm4_grouped_kernel<false, true, 1>), dim3((unsigned)n3), dim3(256), 0, ctx->stream,
-                         dd, dt, (int)n3);
+                         dd, dt, (int)n3, xchunk);
     else
       hipLaunchKernelGGL((zgemm_grouped_kernel<false, true>), dim3((unsigned)n3), dim3(256), 0, ctx->stream,
                          dd, dt, (int)n3);
@@ -784,12 +791,13 @@ int dm_gemm_plan_run(dm_ctx* ctx, const dm_gemm_plan& plan, const char* dblob) {
   if (n1) {
     const dm_gemm_tile* dt = dt_r;
     dm_prof_scope ps(ctx, DM_PROF_GEMM_REAL, fl_r);
+    static const int xchunk_r = getenv("DM_GEMMR_XCHUNK") ? atoi(getenv("DM_GEMMR_XCHUNK")) : 64;
     if (use4 && plan.wide_r)
       hipLaunchKernelGGL((zgemm4_grouped_kernel<true, false, 1, 4>), dim3((unsigned)n1), dim3(256), 0, ctx->stream,
-                         dd, dt, (int)n1);
+                         dd, dt, (int)n1, xchunk_r);
     else if (use4)
       hipLaunchKernelGGL((zgemm4_grouped_kernel<true, false, 1>), dim3((unsigned)n1), dim3(256), 0, ctx->stream,
-                         dd, dt, (int)n1);
+                         dd, dt, (int)n1, xchunk_r);
     else
       hipLaunchKernelGGL((zgemm_grouped_kernel<true, false>), dim3((unsigned)n1), dim3(256), 0, ctx->stream,
                          dd, dt, (int)n1);
@@ -797,7 +805,8 @@ int dm_gemm_plan_run(dm_ctx* ctx, const dm_gemm_plan& plan, const char* dblob) {
   if (n2) {
     const dm_gemm_tile* dt = dt_d;
     dm_prof_scope ps(ctx, DM_PROF_DGEMM, fl_d);
-    hipLaunchKernelGGL(dgemm_grouped_kernel, dim3((unsigned)n2), dim3(256), 0, ctx->stream, dd, dt, (int)n2);
+    static const int xchunk_d = getenv("DM_DGEMM_XCHUNK") ? atoi(getenv("DM_DGEMM_XCHUNK")) : 64;
+    hipLaunchKernelGGL(dgemm_grouped_kernel, dim3((unsigned)n2), dim3(256), 0, ctx->stream, dd, dt, (int)n2, xchunk_d);
   }
   DM_HIP(ctx, hipGetLastError());
   return DM_OK;
