@@ -651,8 +651,13 @@ int dm_gemm_plan_build(const std::vector<dm_gemm_desc>& descs, dm_gemm_plan& pla
         }
       continue;
     }
-    for (int a = 0; a < tm; ++a)
-      for (int b = 0; b < tn; ++b) {
+    // tile order inside a problem: groups of GM tile rows, column by column within a group — 64 consecutive tiles (what an
+    // XCD's 32 CUs hold at two workgroups each, and one chunk of the XCD remap) are then an 8 x 8 block of tiles that shares
+    // 8 + 8 operand panels instead of the 1 + 64 of a row of tiles
+    static const int GM = getenv("DM_GEMM_GROUPM") ? std::max(1, atoi(getenv("DM_GEMM_GROUPM"))) : 8;
+    for (int a0 = 0; a0 < tm; a0 += GM)
+     for (int b = 0; b < tn; ++b)
+      for (int a = a0; a < std::min(tm, a0 + GM); ++a) {
         if ((d.flags & DM_GEMM_LOWER) && b > a) continue;
         if ((d.flags & DM_GEMM_UPPER) && b < ((d.flags & DM_GEMM_UPPER128) ? (a & ~1) : a)) continue;
         dm_gemm_tile t{(int)i, a, b};
@@ -747,7 +752,7 @@ int dm_gemm_plan_run(dm_ctx* ctx, const dm_gemm_plan& plan, const char* dblob) {
       (void)hipEventCreate(&e1);
       (void)hipEventRecord(e0, ctx->stream);
     }
-    static const int xchunk_c = getenv("DM_GEMM_XCHUNK") ? atoi(getenv("DM_GEMM_XCHUNK")) : 64;
+    static const int xchunk_c = getenv("DM_GEMM_XCHUNK") ? atoi(getenv("DM_GEMM_XCHUNK")) : 256;
     {
       dm_prof_scope ps(ctx, DM_PROF_GEMM, fl_c);
       if (use4)

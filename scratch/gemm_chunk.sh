@@ -9,4 +9,4 @@ b1() { tag=$1; shift; env "$@" timeout -k 10 300 python3 bench.py --no-cpu-basel
   python3 -c "
 import json;d=json.loads(open('gpurun_out/gc_b_$tag.log').read().strip().splitlines()[-1])
 c=d['roofline']['classes']; print('bench $tag', round(d['value'],1), round(d['ms_per_step'],2), round(d['roofline']['frac'],4), {k:round(c[k]['ms_per_step'],2) for k in ('zgemm_grouped','gemm_grouped_realB','dgemm_grouped')})"; }
-b1 c32 DM_GEMM_XCHUNK=32 DM_GEMMR_XCHUNK=64 DM_DGEMM_XCHUNK=64 && b1 c16r16d16 DM_GEMM_XCHUNK=16 DM_GEMMR_XCHUNK=16 DM_DGEMM_XCHUNK=16 && b1 c256r32d32 DM_GEMM_XCHUNK=256 DM_GEMMR_XCHUNK=32 DM_DGEMM_XCHUNK=32 && b1 c4r4d4 DM_GEMM_XCHUNK=4 DM_GEMMR_XCHUNK=4 DM_DGEMM_XCHUNK=4 && run c32r32 DM_GEMM_XCHUNK=32 DM_GEMMR_XCHUNK=32 DM_DGEMM_XCHUNK=32 DM_COV_XCHUNK=32
+b1 g8 DM_GEMM_GROUPM=8 && b1 g1 DM_GEMM_GROUPM=1 && b1 g4 DM_GEMM_GROUPM=4 && b1 g16 DM_GEMM_GROUPM=16 && run g8 DM_GEMM_GROUPM=8 && run g1 DM_GEMM_GROUPM=1
