@@ -443,14 +443,14 @@ def measure_share(workload, share, files=False, share_mmax=None, truncate=False,
     r, n = (int(x) for x in share.split("/"))
     if not files:
         os.environ["DRIFTMI_STORAGE"] = "discard"
-    # batch budgets of a 288 GB card: 11 m-blocks per SVD batch and per eigh_gen call at configs[2] (three equal batches for
-    # rank 0 of 8) — fewer lock-step launch chains, and the KL eigenproblems reach the batch sizes where the two-stage
-    # tridiagonalisation pays (share 0/8: 32.2 -> 28.5 s against 48 / 48 / 80 GB; torch peak 123 GB + the 100 GB arena).
-    # configs[3] keeps four covariance-sized matrices per m alive in its DoubleKL stage: the smaller budgets stay.
-    big = workload == "configs2"
-    os.environ.setdefault("DRIFTMI_WORKSPACE_GB", "100" if big else "80")
-    svd_gb = float(os.environ.get("DRIFT_BENCH_SVD_GB", "96" if big else "48"))
-    kl_gb = float(os.environ.get("DRIFT_BENCH_KL_GB", "110" if big else "48"))
+    # Batch budgets (GB): resident beam blocks of a BT-gen range / SVD batch / KL batch / eigensolver arena.  Rounds 1-3 ran every
+    # share at 125 / 48 / 48 / 80.  A share whose beam blocks all fit 72 GB (the low-m shares of configs[2]: 33-39 blocks with the
+    # largest matrices) takes 72 / 96 / 110 / 100 instead: 11 m-blocks per SVD batch and per eigh_gen call — fewer lock-step
+    # launch chains, and the KL eigenproblems reach the batch sizes where the two-stage tridiagonalisation pays (share 0/8:
+    # 32.2 -> 28.5 s; torch peak 123 GB + the 100 GB arena of 288).  The shares with many cheap high-m blocks keep the old
+    # budgets: their BT-gen wants long ranges (a call costs ~0.9 s whatever it holds), and 125 + 96 + 100 GB do not fit the card
+    # (share 7/8 ran out of memory there).  configs[3] keeps four covariance-sized matrices per m alive in its DoubleKL stage:
+    # old budgets.  The choice is made below, once the share's m-range is known.
     from driftscan_amd import device, manager, parallel
 
     parallel.set_virtual(r, n)
@@ -459,18 +459,15 @@ def measure_share(workload, share, files=False, share_mmax=None, truncate=False,
         if share_mmax:   # rehearsal of the mode on a toy telescope (tests, CPU-sized boxes)
             tcfg = dict(type="PolarisedCylinder", num_freq=4, freq_start=400.0, freq_end=440.0, freq_mode="edge", num_cylinders=2,
                         cylinder_width=2.0, num_feeds=4, feed_spacing=0.4, tsys=1.0)
-        kls = [dict(type="KLTransform", name="kl", threshold=0.1, kl_chunk_gb=kl_gb)]
+        kls = [dict(type="KLTransform", name="kl", threshold=0.1)]
         conf = dict(config=dict(beamtransfers=True, kltransform=True, psfisher=False, truncate=bool(truncate),
-                                beam_chunk_gb=float(os.environ.get("DRIFT_BENCH_BEAM_GB", "125")),
-                                device_chunk_gb=float(os.environ.get("DRIFT_BENCH_BT_GB", "48")),
-                                svd_chunk_gb=svd_gb, keep_products_gb=0.0),
+                                device_chunk_gb=float(os.environ.get("DRIFT_BENCH_BT_GB", "48")), keep_products_gb=0.0),
                     telescope=tcfg, kltransform=kls)
         if workload == "configs3":
             kls.append(dict(type="DoubleKL", name="dk", threshold=0.1, foreground_threshold=100.0))
             conf["config"]["psfisher"] = True
             conf["psfisher"] = [dict(type="Full", name="ps", klname="kl", threshold=0.1, bandtype="polar", num_theta=3,
                                      k_bands=[dict(spacing="linear", start=0.0, stop=0.25, num=4)])]
-        ctx = device.get_context(workspace_bytes=int(os.environ["DRIFTMI_WORKSPACE_GB"]) << 30)
         with tempfile.TemporaryDirectory(dir=outdir) as tmp:
             conf["config"]["output_directory"] = os.path.join(tmp, "prod")
             cfile = os.path.join(tmp, "params.yaml")
@@ -479,6 +476,16 @@ def measure_share(workload, share, files=False, share_mmax=None, truncate=False,
             pm = manager.ProductManager.from_config(cfile)
             tel, bt = pm.telescope, pm.beamtransfer
             mine = bt._my_ms()
+            share_beam_gb = len(mine) * tel.nfreq * 2 * tel.nbase * tel.num_pol_sky * (tel.lmax + 1) * 16 / float(1 << 30)
+            big = workload == "configs2" and share_beam_gb <= 72.0
+            budgets = dict(beam=float(os.environ.get("DRIFT_BENCH_BEAM_GB", "72" if big else "125")),
+                           svd=float(os.environ.get("DRIFT_BENCH_SVD_GB", "96" if big else "48")),
+                           kl=float(os.environ.get("DRIFT_BENCH_KL_GB", "110" if big else "48")),
+                           arena=float(os.environ.get("DRIFTMI_WORKSPACE_GB", "100" if big else "80")))
+            bt.beam_chunk_gb, bt.svd_chunk_gb = budgets["beam"], budgets["svd"]
+            for kl in pm.kltransforms.values():
+                kl.kl_chunk_gb = budgets["kl"]
+            ctx = device.get_context(workspace_bytes=int(budgets["arena"] * (1 << 30)))
             # the host-side C_l(nu, nu') tables are made once per job (cora's models in the reference): untimed
             t0 = time.perf_counter()
             for kl in pm.kltransforms.values():
@@ -517,7 +524,7 @@ def measure_share(workload, share, files=False, share_mmax=None, truncate=False,
                                           else "KLTransform + DoubleKL + PSExact (9 polar bands)",
                                           ", product files written" if files else ", products left in HBM (no files)"),
                            "nfreq": tel.nfreq, "nbase": tel.nbase, "lmax": tel.lmax, "mmax": tel.mmax, "share": share,
-                           "sht_iter": int(tel.sht_iter), "files": bool(files), "truncate": bool(truncate),
+                           "sht_iter": int(tel.sht_iter), "files": bool(files), "truncate": bool(truncate), "budgets_gb": budgets,
                            "codec": os.environ.get("DRIFTMI_H5_CODEC", "lzf") if files else None},
                 "share_s": dt,
                 "share_note": "wall time of rank %d of %d for m = %d..%d; the job's wall time is the MAX over the N shares "

@@ -70,10 +70,12 @@ class BeamTransfer(config.Reader):
     device_chunk_gb = config.Property(proptype=float, default=6.0)  # BT-gen working set per launch group
     svd_chunk_gb = config.Property(proptype=float, default=16.0)    # SVD working set per batch of m
     beam_chunk_gb = config.Property(proptype=float, default=96.0)   # beam_m blocks resident per BT-gen call
-    # weight of the ndof^3 term in the cost model of an m-block (`_m_cost`): 0.25 per generalised eigenproblem solved
-    # downstream (one KLTransform; ProductManager raises it for DoubleKL and the Fisher estimators) — calibrated on the
-    # configs[2] / configs[3] shares (profiles/r03a_configs*_share*.json: 41.3 / 40.0 / 40.0 s for ranks 0, 4, 7 of 8)
-    kl_cost_weight = config.Property(proptype=float, default=0.25)
+    # weight of the ndof^3 term in the cost model of an m-block (`_m_cost`): 0.19 per generalised eigenproblem solved
+    # downstream (one KLTransform; ProductManager raises it for DoubleKL and the Fisher estimators) — a least-squares fit of
+    # flat + linear + cubic terms to the kernel seconds of five configs[2] shares of the round-4 build
+    # (profiles/r04q_configs2_share{0,1,2,4,7}of8_generate.json: 26.5 / 28.2 / 28.4 / 30.0 / 30.7 s under the round-3
+    # constants 0.6 / 0.25, which had been calibrated before the large-matrix stages got faster)
+    kl_cost_weight = config.Property(proptype=float, default=0.19)
     keep_products_gb = config.Property(proptype=float, default=32.0)  # SVD products of finished batches stay in HBM up to this
 
     noise_weight = True
@@ -251,7 +253,7 @@ class BeamTransfer(config.Reader):
         """Relative cost of one m-block through the whole path: beam-transfer generation is about the same for every m,
         the SVD chain follows the number of l >= m, the KL stage its cube (ndof falls with m)."""
         x = float(self.telescope.lmax + 1 - m) / float(self.telescope.lmax + 1)
-        return 0.15 + 0.6 * x + self.kl_cost_weight * x ** 3
+        return 0.15 + 0.67 * x + self.kl_cost_weight * x ** 3
 
     def _my_ms(self, mlist=None):
         """m-blocks owned by this rank: ONE contiguous range with (nearly) the same summed cost on every rank

@@ -124,7 +124,7 @@ class ProductManager(object):
         if self.gen_kl and self.kltransforms and "kl_cost_weight" not in yconf["config"]:
             # the cost of an m-block downstream of the SVD chain, for the m-ranges of the ranks: a DoubleKL is two
             # eigenproblems plus, at low m, the non-positive-definite rescue; a Fisher estimator projects every band
-            w = sum(0.625 if isinstance(k, doublekl.DoubleKL) else 0.25 for k in self.kltransforms.values())
+            w = sum(0.625 if isinstance(k, doublekl.DoubleKL) else 0.19 for k in self.kltransforms.values())
             if self.gen_ps:
                 w += 0.125 * sum(1 for p in self.psestimators.values() if p is not None)
             self.beamtransfer.kl_cost_weight = float(w)
