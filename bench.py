@@ -444,12 +444,12 @@ def measure_share(workload, share, files=False, share_mmax=None, truncate=False,
     if not files:
         os.environ["DRIFTMI_STORAGE"] = "discard"
     # Batch budgets (GB): resident beam blocks of a BT-gen range / SVD batch / KL batch / eigensolver arena.  Rounds 1-3 ran every
-    # share at 125 / 48 / 48 / 80.  configs[2] now takes 72 / 96 / 110 / 100: 11 low-m blocks per SVD batch and per eigh_gen
+    # share at 125 / 48 / 48 / 80.  Now 72 / 96 / 110 / 100: 11 low-m blocks per SVD batch and per eigh_gen
     # call — a third of the lock-step launch chains, and the KL eigenproblems reach the batch sizes where the two-stage
     # tridiagonalisation pays (share 0/8: 32.2 -> 28.5 s; torch peak 123 GB + the 100 GB arena of 288; the kernels of the high-m
     # shares gain 1.7 s as well).  The beam blocks of a BT-gen range + one SVD batch + the arena must fit the card: with 125 GB of
-    # beam blocks share 7/8 ran out of memory.  configs[3] keeps four covariance-sized matrices per m alive in its DoubleKL
-    # stage: the old budgets stay.
+    # beam blocks share 7/8 ran out of memory.  configs[3] (DoubleKL + Fisher) runs at the same budgets: share 0/8 42.0 -> 35.4 s,
+    # torch peak 106 GB.
     from driftscan_amd import device, manager, parallel
 
     parallel.set_virtual(r, n)
@@ -475,7 +475,7 @@ def measure_share(workload, share, files=False, share_mmax=None, truncate=False,
             pm = manager.ProductManager.from_config(cfile)
             tel, bt = pm.telescope, pm.beamtransfer
             mine = bt._my_ms()
-            big = workload == "configs2"
+            big = True
             budgets = dict(beam=float(os.environ.get("DRIFT_BENCH_BEAM_GB", "72" if big else "125")),
                            svd=float(os.environ.get("DRIFT_BENCH_SVD_GB", "96" if big else "48")),
                            kl=float(os.environ.get("DRIFT_BENCH_KL_GB", "110" if big else "48")),

@@ -124,9 +124,11 @@ class ProductManager(object):
         if self.gen_kl and self.kltransforms and "kl_cost_weight" not in yconf["config"]:
             # the cost of an m-block downstream of the SVD chain, for the m-ranges of the ranks: a DoubleKL is two
             # eigenproblems plus, at low m, the non-positive-definite rescue; a Fisher estimator projects every band
-            w = sum(0.625 if isinstance(k, doublekl.DoubleKL) else 0.19 for k in self.kltransforms.values())
+            # (round 4: 0.19 / 0.35 / 0.085 — refitted to the kernel seconds of configs[2] and configs[3] shares after the
+            # large-matrix stages got faster, profiles/r04q_configs{2,3}_share*; round 3 had 0.25 / 0.625 / 0.125)
+            w = sum(0.35 if isinstance(k, doublekl.DoubleKL) else 0.19 for k in self.kltransforms.values())
             if self.gen_ps:
-                w += 0.125 * sum(1 for p in self.psestimators.values() if p is not None)
+                w += 0.085 * sum(1 for p in self.psestimators.values() if p is not None)
             self.beamtransfer.kl_cost_weight = float(w)
 
     def generate(self):
