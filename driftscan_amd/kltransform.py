@@ -294,9 +294,21 @@ class KLTransform(config.Reader):
         full = self.__dict__.setdefault("_evals_full_mem", {})
         todo = [mi for mi in ms if mi not in done and (regen or not os.path.exists(self._evfile % mi))]
         cache = self.__dict__.get("_mode_cache")   # set by whoever wants the modes of the batch right away (PS estimation)
+        ctx = get_context()
         for batch in self._batches(todo):
-            to_host = cache is not None or not storage.discard()   # discard mode: products stay in HBM, no file
-            for mi, res in zip(batch, self._transform_batch(batch, to_host=to_host)):
+            # The modes stay on the device: whoever wants them right away (the Fisher estimators, through the mode cache)
+            # reads them there, and the files get their host copies from the writer pool's copy thread (storage.Deferred)
+            # while the next batch is computed — round 3 copied every eigenvector matrix to the host here and the estimator
+            # sent it back (2 x 15 GB per configs[3] share through the driver thread).
+            results = self._transform_batch(batch, to_host=False)
+            event = None if storage.discard() else ctx.record_event()
+
+            def on_host(x):
+                if x is None or isinstance(x, np.ndarray):
+                    return x
+                return ctx.defer_host(x, event) if x.numel() else x.cpu().numpy()
+
+            for mi, res in zip(batch, results):
                 nside = int(self.beamtransfer.ndof(mi))
                 evf = np.zeros(nside)
                 ev = res[0] if isinstance(res[0], np.ndarray) else res[0].cpu().numpy()
@@ -310,7 +322,7 @@ class KLTransform(config.Reader):
                     cache[mi] = (ev[i_ev:], res[1][i_ev:]) if ev.size else (ev, res[1])
                 # written in the background while the next batch is computed
                 if not storage.discard():
-                    storage.submit(self._save, mi, *res, nside)
+                    storage.submit(self._save, mi, ev, on_host(res[1]), on_host(res[2]), res[3], nside)
 
     def generate(self, regen=False):
         """KL-transform every m of this rank and save (kltransform.py:480-513); m already done by `generate_ms` during
@@ -378,7 +390,7 @@ class KLTransform(config.Reader):
     def modes_m(self, mi, threshold=None):
         mc = self.__dict__.get("_mode_cache")
         if mc is not None and mi in mc:   # modes of the batch in flight (generate_ms), exactly what the file will hold
-            evals, evecs = mc[mi]
+            evals, evecs = mc[mi]   # (evecs may be a DEVICE tensor here: rows of the batch's eigenvector matrix)
             if evals.shape[0] == 0:
                 return None, None
             startind = np.searchsorted(evals, threshold) if threshold is not None else 0

@@ -275,15 +275,16 @@ class PSExact(PSEstimation):
         ndofs = svnum.sum(axis=1)
         eoff, etot = _linear_offsets(nmodes * ndofs)
         voff, vtot = _linear_offsets(nmodes)
-        Eh = np.zeros(max(etot, 1), dtype=np.complex128)
         Vh = np.zeros(max(vtot, 1), dtype=np.float64)
-        for i, (ev, E) in enumerate(modes):
+        parts = []   # the modes back to back on the device: rows of the batch's eigenvector matrix when they come from the
+        for i, (ev, E) in enumerate(modes):   # KL object's mode cache (generate_ms), host arrays when they come from a file
             if nmodes[i] == 0:
                 continue
             if E.shape[1] != ndofs[i]:
                 raise Exception("KL modes of m=%d have length %d, the SVD basis %d" % (ms[i], E.shape[1], ndofs[i]))
-            Eh[eoff[i] : eoff[i] + nmodes[i] * ndofs[i]] = np.ascontiguousarray(E).ravel()
+            parts.append(ctx.to_device(np.ascontiguousarray(E).ravel()) if isinstance(E, np.ndarray) else E.reshape(-1))
             Vh[voff[i] : voff[i] + nmodes[i]] = ev
+        Ed = torch.cat(parts) if len(parts) > 1 else parts[0].contiguous()
         # (nbands, L, F, F) -> (nbands, F, F, L): the contraction index innermost, as dm_project_cov reads it
         cache = self.__dict__.get("_cl_dev")
         if cache is None or cache[0] is not self.clarray or cache[1].device.index != ctx.device:
@@ -292,7 +293,7 @@ class PSExact(PSEstimation):
                      bool(np.array_equal(c64, c64.swapaxes(2, 3))))  # f <-> f' symmetry, checked not assumed
             self.__dict__["_cl_dev"] = cache  # the band tables do not change between batches (151 MB at config 3)
         cl = cache[1]
-        F = ctx.fisher(bsvd, svnum, np.array(ms), cl, ctx.to_device(Eh), eoff, nmodes, ctx.to_device(Vh), voff,
+        F = ctx.fisher(bsvd, svnum, np.array(ms), cl, Ed, eoff, nmodes, ctx.to_device(Vh), voff,
                        cl_symmetric=cache[2])
         Fh = F.cpu().numpy()
         return [(Fh[i], np.zeros(nb, dtype=np.complex128)) if nmodes[i] > 0 else zero for i in range(len(ms))]
