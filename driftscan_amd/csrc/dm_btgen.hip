@@ -458,7 +458,8 @@ __global__ __launch_bounds__(256) void bt_fused_dft_kernel(ring_geo g, frame3 fr
         }
     }
   }
-  // lane 16 i + (lane & 15) holds m-row i of the group: G[mm][ring][col * P + p]
+  // lane 16 i + (lane & 15) holds m-row i of the group: G[mm][ring][p * ncol + col] (Stokes-major rows: the Legendre
+  // products read ONE Stokes parameter of consecutive columns — 16 lanes x 16 B contiguous instead of every fourth element)
   const double w = ring_w ? ring_w[r] : 1.0;
   const int i = lane >> 4;
 #pragma unroll
@@ -469,9 +470,9 @@ __global__ __launch_bounds__(256) void bt_fused_dft_kernel(ring_geo g, frame3 fr
     for (int a = 0; a < NMG; ++a) {
       const int mm = (mg0 + a) * 4 + i;
       if (mm >= nm) continue;
-      cplx* out = G + ((size_t)mm * g.nring + r) * ncp + (size_t)col * P;
+      cplx* out = G + ((size_t)mm * g.nring + r) * ncp + (size_t)col;
 #pragma unroll
-      for (int p = 0; p < P; ++p) dm_stg(out, p, make_double2(w * acc_re[c][a][p], w * acc_im[c][a][p]));
+      for (int p = 0; p < P; ++p) dm_stg(out, (size_t)p * (ncp / P), make_double2(w * acc_re[c][a][p], w * acc_im[c][a][p]));
     }
   }
 }
@@ -652,9 +653,9 @@ __global__ __launch_bounds__(256) void bt_fused_dft2_kernel(ring_geo g, frame3 f
     for (int a = 0; a < NMG; ++a) {
       const int mm = (mg0 + a) * 4 + i;
       if (mm >= nm) continue;
-      cplx* out = G + ((size_t)mm * g.nring + r) * ncp + (size_t)col * P;
+      cplx* out = G + ((size_t)mm * g.nring + r) * ncp + (size_t)col;
 #pragma unroll
-      for (int p = 0; p < P; ++p) dm_stg(out, p, make_double2(w * acc_re[c][a][p], w * acc_im[c][a][p]));
+      for (int p = 0; p < P; ++p) dm_stg(out, (size_t)p * (ncp / P), make_double2(w * acc_re[c][a][p], w * acc_im[c][a][p]));
     }
   }
 }
@@ -810,16 +811,16 @@ __global__ __launch_bounds__(TPB) void bt_fused_fft_kernel(ring_geo g, frame3 fr
       }
       __syncthreads();
     }
-    // ---- the wanted rows: G[mm][ring][col P + p] = w exp(i m phi_0) X_p[m mod N]
+    // ---- the wanted rows: G[mm][ring][p ncol + col] = w exp(i m phi_0) X_p[m mod N]
     for (int mm = tid; mm < nm; mm += TPB) {
       const int m = mm < cnt ? m_lo + mm : -(m_lo + mm - cnt);
       const int idx = ((m % N) + N) % N;
       double s_, c_;
       sincos((double)m * phi0, &s_, &c_);
       const cplx phs = make_double2(w * c_, w * s_);
-      cplx* out = G + ((size_t)mm * g.nring + r) * ncp + (size_t)col * P;
+      cplx* out = G + ((size_t)mm * g.nring + r) * ncp + (size_t)col;
 #pragma unroll
-      for (int p = 0; p < P; ++p) dm_stg(out, p, cmul(phs, X[(size_t)p * Np + ph(idx)]));
+      for (int p = 0; p < P; ++p) dm_stg(out, (size_t)p * (ncp / P), cmul(phs, X[(size_t)p * Np + ph(idx)]));
     }
   }
 }
@@ -1382,7 +1383,7 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
   const int ncp = ncol * P;  // map columns
   const int nmblk = m_hi - m_lo + 1;
 
-  // ---- twiddles and ring DFT: G[mm][ring][colp]
+  // ---- twiddles and ring DFT: G[mm][ring][colp] — colp = col * P + p from materialised maps, p * ncol + col from the fused kernels
   const bool fused = maps_dev == nullptr;
   std::vector<size_t> toff(nring);
   size_t ttot = 0;
@@ -1590,7 +1591,8 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
           cplx* out = bm + ((((size_t)(m - m_lo) * F + rn.f) * 2 + s) * B + rn.b0) * P * L + m;
           auto add = [&](int pa, const double* tab, int pout, double are, double aim, double beta) {
             if (!folded) {
-              dm_gemm_desc d = dm_gemm_make(Gm + (size_t)rn.c0 * P + pa, P, ncp, s == 1, tab + loff[m - m_lo], 1, nring, false,
+              dm_gemm_desc d = dm_gemm_make(Gm + (fused ? (size_t)pa * ncol + rn.c0 : (size_t)rn.c0 * P + pa), fused ? 1 : P, ncp, s == 1,
+                                            tab + loff[m - m_lo], 1, nring, false,
                                             out + (size_t)pout * L, P * L, rn.n, Lm, nring, are, beta, nullptr,
                                             DM_GEMM_B_REAL);
               d.alpha_im = aim;
@@ -1607,7 +1609,8 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
               const bool even_fn = (tab == Xt) ? par == 1 : par == 0;
               const int r0 = even_fn ? 0 : mid + 1, nr = even_fn ? mid + 1 : mid;
               if (nr <= 0) continue;
-              dm_gemm_desc d = dm_gemm_make(Gm + (size_t)r0 * ncp + (size_t)rn.c0 * P + pa, P, ncp, s == 1,
+              dm_gemm_desc d = dm_gemm_make(Gm + (size_t)r0 * ncp + (fused ? (size_t)pa * ncol + rn.c0 : (size_t)rn.c0 * P + pa),
+                                            fused ? 1 : P, ncp, s == 1,
                                             tab + loff[m - m_lo] + (size_t)par * nring + r0, 1, 2 * nring, false,
                                             out + (size_t)pout * L + par, P * L, rn.n, nl, nr, are, beta, nullptr,
                                             DM_GEMM_B_REAL);
