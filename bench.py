@@ -103,8 +103,9 @@ def parse_args(argv=None):
     ap.add_argument("--all-modes", action="store_true",
                     help="form every KL mode (subset = False) instead of only the ones transform_save keeps")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DRIFT_BENCH_STREAMS", "1")),
-                    help="concurrent m-block groups per GPU (threads x HIP streams); 2 gives +7 %% m-blocks/s but the "
-                         "per-kernel durations (and so the roofline figure) then include the interference")
+                    help="concurrent m-block groups per GPU (threads x HIP streams); 2 gave +7 %% m-blocks/s in round 2, "
+                         "and is slower since the two-stage tridiagonalisation (937 against 1020: the persistent chase kernels of "
+                         "the groups compete for the same CUs)")
     ap.add_argument("--cpu-worker", nargs=2, metavar=("JOBS", "NPROC"), help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
