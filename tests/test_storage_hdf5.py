@@ -440,3 +440,30 @@ def test_writer_processes_produce_the_same_files(tmp_path, monkeypatch):
         storage.shutdown_writers()
     if os.path.isdir("/dev/shm"):
         assert set(os.listdir("/dev/shm")) - shm_before == set()
+
+
+def test_chunk_threads_do_not_change_the_file(tmp_path, monkeypatch):
+    """`dio_write_dataset` compresses blocks of chunks with DRIFTMI_IO_CHUNK_THREADS threads and hands them to HDF5 in order:
+    the same datasets, the same stored sizes and — apart from the modification times in the object headers — the same bytes
+    whatever the thread count; ragged edge chunks, raw-stored (incompressible) and packed chunks in one dataset, both codecs."""
+    monkeypatch.setenv("DRIFTMI_STORAGE", "hdf5")
+    if storage.backend() != "driftio":
+        pytest.skip("libdriftio is not the writer in use")
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((37, 10, 4, 513)) + 1j * rng.standard_normal((37, 10, 4, 513))
+    a[:, 5:] = 0                                         # zero rows, as beam_svd has beyond nmodes
+    b = rng.standard_normal((300, 70, 41))
+    sizes = {}
+    for nt in ("1", "4", "7"):
+        monkeypatch.setenv("DRIFTMI_IO_CHUNK_THREADS", nt)
+        p = str(tmp_path / ("t%s.hdf5" % nt))
+        with storage.File(p, "w") as f:
+            f.create_dataset("a", data=a, chunks=(1, 10, 4, 513), compression="lzf")
+            f.create_dataset("b", data=b, chunks=(16, 70, 41), compression="lzf")
+            f.create_dataset("c", data=b, chunks=(7, 33, 41), compression="bitshuffle")
+        sizes[nt] = os.path.getsize(p)
+        with storage.File(p, "r") as f:
+            assert np.array_equal(f["a"][...], a) and np.array_equal(f["b"][...], b) and np.array_equal(f["c"][...], b)
+    assert sizes["1"] == sizes["4"] == sizes["7"]
+    raw = {nt: np.frombuffer(open(str(tmp_path / ("t%s.hdf5" % nt)), "rb").read(), np.uint8) for nt in sizes}
+    assert (raw["1"] != raw["4"]).sum() <= 16 and (raw["1"] != raw["7"]).sum() <= 16   # object-header time stamps only
