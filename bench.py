@@ -944,7 +944,7 @@ def main():
             # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this
             # process, so the figure comes from the committed rocprofv3 --pmc passes of this same
             # command (profiles/*_pmc_traffic.json, made by scratch/run_profiles.sh + make_traffic_json.py).
-            traffic, traffic_src, mfma_busy = None, None, None
+            traffic, traffic_src, mfma_busy, valu_busy = None, None, None, None
             try:
                 import glob
 
@@ -979,6 +979,15 @@ def main():
                     else:
                         mfma_busy = dict(stale="%s was taken at build %s, this is %s" % (os.path.relpath(mj[-1], ROOT),
                                                                                           mrec.get("_build_id"), bid))
+                vj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_valu.json")))
+                if vj:   # vector-ALU utilisation by counter: what the latency-bound classes (chase, jac_inner, q2, panel QR) have
+                    vrec = json.load(open(vj[-1]))   # instead of a flop rate
+                    if vrec.get("_build_id") == bid:
+                        valu_busy = dict({k: (round(v["valu_busy"], 4) if isinstance(v, dict) else v) for k, v in vrec.items()},
+                                         source=os.path.relpath(vj[-1], ROOT))
+                    else:
+                        valu_busy = dict(stale="%s was taken at build %s, this is %s" % (os.path.relpath(vj[-1], ROOT),
+                                                                                          vrec.get("_build_id"), bid))
             except Exception:
                 traffic, traffic_src = None, None
             if dom is not None:
@@ -1026,6 +1035,8 @@ def main():
                                                 frac=oa / FP64_MFMA_PEAK_TFLOPS, ms_per_step=q["ms"] / args.steps)
                 if mfma_busy is not None:
                     roofline["mfma_busy"] = mfma_busy
+                if valu_busy is not None:
+                    roofline["valu_busy"] = valu_busy
             # per-stage fractions of SURVEY.md §8(d): algorithmic work of the stage / its wall time / fp64 MFMA peak
             my_ms = list(range(nblocks)) if m_range is None else list(range(m_range[0], m_range[1] + 1))
             WA, WB, WC = stage_work(tel, bt, my_ms, nkeep=dict(_NKEEP) if _NKEEP else None)
