@@ -409,8 +409,14 @@ class BeamTransfer(config.Reader):
         # as many batches as the budget asks for, of equal size: a short last batch runs the same lock-step launch chains
         # for a fraction of the work (and falls under the batch sizes where the two-stage tridiagonalisation pays)
         nbat = max(1, -(-len(ms) // nb))
-        nb = -(-len(ms) // nbat)
-        return [ms[c0 : c0 + nb] for c0 in range(0, len(ms), nb)]
+        base, rem = divmod(len(ms), nbat)   # sizes differ by at most one: 34 blocks in three batches are 12 + 11 + 11
+        out, c0 = [], 0
+        for k in range(nbat):
+            n = base + (1 if k < rem else 0)
+            if n:
+                out.append(ms[c0 : c0 + n])
+            c0 += n
+        return out
 
     def _svd_batches(self, ms, regen=False, skip_svd_inv=False, after_batch=None):
         """SVD chain of the given m in batches that fit `svd_chunk_gb` (beamtransfer.py:730-929): the products stay on

@@ -281,8 +281,12 @@ class KLTransform(config.Reader):
             # the same number of batches with about equal counts (still within the budget: blocks of neighbouring m have
             # about the same ndof) instead of full batches and a short one — see BeamTransfer._svd_batch_lists
             ms = [mi for b in out for mi in b]
-            nb = -(-len(ms) // len(out))
-            even = [ms[c0 : c0 + nb] for c0 in range(0, len(ms), nb)]
+            base, rem = divmod(len(ms), len(out))
+            even, c0 = [], 0
+            for k in range(len(out)):
+                n = base + (1 if k < rem else 0)
+                even.append(ms[c0 : c0 + n])
+                c0 += n
             if all(sum(16.0 * float(self.beamtransfer.ndof(mi)) ** 2 * 16.0 for mi in b) <= budget for b in even):
                 out = even
         return out

@@ -419,3 +419,29 @@ def test_deferred_arguments_go_through_the_copy_thread(tmp_path, monkeypatch):
     with pytest.raises(RuntimeError):
         storage.flush()
     storage.flush()
+
+
+def test_batches_are_cut_to_equal_sizes(tmp_path):
+    """`BeamTransfer._svd_batch_lists` / `KLTransform._batches`: as many batches as the budget asks for, of (nearly) equal
+    size — a short last batch would run the same lock-step launch chains for a fraction of the work."""
+    from driftscan_amd import beamtransfer, cylinder, kltransform
+
+    tel = cylinder.PolarisedCylinderTelescope.from_config(dict(num_freq=4, freq_start=400.0, freq_end=420.0, freq_mode="edge",
+                                                               num_cylinders=2, cylinder_width=8.0, num_feeds=4,
+                                                               feed_spacing=0.5, tsys=1.0, force_lmax=60, force_mmax=60))
+    bt = beamtransfer.BeamTransfer(str(tmp_path / "bt"), telescope=tel)
+    F, T, P, L, K = tel.nfreq, bt.ntel, tel.num_pol_sky, tel.lmax + 1, bt.svd_len
+    per_m = F * (T * (P * L + T) * 2 + K * P * L * 2 + K * T) * 16
+    bt.svd_chunk_gb = 12.5 * per_m / float(1 << 30)          # room for 12 blocks
+    assert [len(b) for b in bt._svd_batch_lists(range(34))] == [12, 11, 11]
+    assert [len(b) for b in bt._svd_batch_lists(range(24))] == [12, 12]
+    assert [len(b) for b in bt._svd_batch_lists(range(5))] == [5]
+    assert sum(bt._svd_batch_lists(range(7, 41)), []) == list(range(7, 41))
+    kl = kltransform.KLTransform(bt)
+    bt.ndof = lambda mi: 1000                                   # every block the same size: 16 * n^2 * 16 bytes each
+    kl.kl_chunk_gb = 10.5 * 16.0 * 1000.0 ** 2 * 16.0 / float(1 << 30)
+    assert [len(b) for b in kl._batches(list(range(23)))] == [8, 8, 7]
+    assert sum(kl._batches(list(range(23))), []) == list(range(23))
+    bt.ndof = lambda mi: 3000 if mi < 3 else 1000              # uneven blocks: the even cut must still respect the budget
+    for b in kl._batches(list(range(23))):
+        assert sum(16.0 * bt.ndof(mi) ** 2 * 16.0 for mi in b) <= kl.kl_chunk_gb * (1 << 30) or len(b) == 1
