@@ -787,7 +787,7 @@ class Deferred:
     rounds 1-3) the same copies were 8.3 of the 29 s of a share 0/16 with files, with the GPU idle.
 
     ``resident``: the caller keeps the tensor alive anyway (the beam transfer blocks of a range, which the SVD stage
-    reads next) — it does not count against the bound on device memory held by the queue (``DRIFTMI_IO_DEVICE_GB``, 32)."""
+    reads next) — it does not count against the bound on device memory held by the queue (``DRIFTMI_IO_DEVICE_GB``, 16)."""
 
     __slots__ = ("ctx", "t", "event", "nbytes", "resident")
 
@@ -832,7 +832,7 @@ def _copy_stream(ctx):
 
 
 def _device_cap():
-    return float(os.environ.get("DRIFTMI_IO_DEVICE_GB", "32")) * (1 << 30)
+    return float(os.environ.get("DRIFTMI_IO_DEVICE_GB", "16")) * (1 << 30)
 
 
 def _host_acquire(nbytes, nthreads):
