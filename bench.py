@@ -534,6 +534,7 @@ def measure_share(workload, share, files=False, share_mmax=None, truncate=False,
                 "job_m_blocks_per_s": (nm / dt) if r == 0 else None,
                 "file_bytes": nbytes,
                 "kernels_ms": {k: v["ms"] for k, v in pr.items()},
+                "arena_gb_at_end": float(ctx.lib.dm_ctx_workspace_bytes(ctx.h)) / float(1 << 30),
                 "classes": classes,
                 "kernel_s": kern_s,
                 "kernel_coverage_of_wall": kern_s / dt,
