@@ -61,7 +61,6 @@ def build_id():
         with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
-CPU_SAMPLE_M = (0, 32, 64, 96)
 
 
 def parse_args(argv=None):
@@ -78,6 +77,9 @@ def parse_args(argv=None):
                          "(128-feed polarised cylinder, nfreq 64, lmax 512; configs3 adds DoubleKL + the exact Fisher matrix) "
                          "through ProductManager.generate(): one rank's share of the 8-GPU job on this GPU")
     ap.add_argument("--share", default="0/8", help="--workload configs2|configs3: which rank's share, as r/N")
+    ap.add_argument("--job", action="store_true",
+                    help="--workload configs2|configs3: the WHOLE job on --gpus N real ranks (one process per GPU over --backend), "
+                         "instead of one emulated share")
     ap.add_argument("--m", type=int, default=300, help="--workload configs4: which m-block")
     ap.add_argument("--no-checks", action="store_true", help="--workload configs4: skip the property checks of the products")
     ap.add_argument("--files", action="store_true",
@@ -151,10 +153,35 @@ def launch_ranks(args, argv):
 
 
 # ---------------------------------------------------------------------------------------------------
-# CPU baseline worker (fresh process, no GPU): N single-thread workers over the sample blocks
+# CPU baseline (fresh process, no GPU): the WHOLE configs[1] job with the oracle on single-threaded workers
 # ---------------------------------------------------------------------------------------------------
+def host_cores():
+    """Cores this process may actually use: the affinity mask, cut by the cgroup's CPU quota (a GPU box gives a
+    one-GPU job a share of its host, not all 256 cores)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(round(float(txt[0]) / float(txt[1])))))
+            else:
+                q = float(txt[0])
+                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(round(q / per))))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
 def _cpu_one_block(job):
-    """SVD chain + covariance projections + KL of one m-block with the oracle; per-stage seconds."""
+    """SVD chain + covariance projections + KL of one m-block with the oracle: per-stage seconds, the spectra, and the
+    noise covariance (kept by the caller for the conditioning bound of the pencil, computed outside the timing)."""
     import numpy as np
 
     from oracle import kl as okl
@@ -165,9 +192,9 @@ def _cpu_one_block(job):
     o = osvd.svd_m(blk, noisew, polsvcut=polsvcut)
     t1 = time.perf_counter()
     cs, cn = okl.sn_covariance(o["beam_svd"], o["beam_ut"], o["singularvalues"], cv_sg, cv_fg, npw, svcut=svcut)
-    okl.kl_transform_m(cs, cn)
+    ev = okl.kl_transform_m(cs, cn)[0]
     t2 = time.perf_counter()
-    return t1 - t0, t2 - t1, int(cs.shape[0])
+    return t1 - t0, t2 - t1, int(cs.shape[0]), np.asarray(o["singularvalues"]), np.asarray(ev), cn
 
 
 def _cpu_bt_columns(desc):
@@ -178,89 +205,172 @@ def _cpu_bt_columns(desc):
     return time.perf_counter() - t0
 
 
+def _cpu_worker(wid, tasks, results, shared):
+    """One single-threaded rank of the CPU job (the reference's MPI mode, `OMP_NUM_THREADS=1`): takes tasks from the
+    common queue until it is empty, reports when it ran dry, THEN (untimed) the conditioning bounds of the pencils it solved."""
+    import numpy as np
+
+    jobs, common, desc0 = shared
+    stash = {}
+    while True:
+        t = tasks.get()
+        if t is None:
+            break
+        if t[0] == "block":
+            m = t[1]
+            ts, tk, ndof, sv, ev, cn = _cpu_one_block((jobs[m],) + common)
+            stash[m] = cn
+            results.put(("block", m, ts, tk, ndof, sv, ev))
+        else:   # ("bt", fi, b0, b1): the (f, b) columns of one frequency and a range of baselines, all m
+            desc = dict(desc0, included_freq=np.array([t[1]]), included_baseline=np.arange(t[2], t[3]))
+            results.put(("bt", t[1], t[2], t[3], _cpu_bt_columns(desc)))
+    results.put(("dry", wid, time.perf_counter()))
+    for m, cn in stash.items():
+        tol = 1e-10
+        if cn.shape[0]:
+            w = np.linalg.eigvalsh(0.5 * (cn + cn.conj().T))
+            tol = max(1e-10, 50.0 * 2.220446049250313e-16 * abs(w[-1]) / max(abs(w[0]), 1e-300))   # tests/parity_util.pencil_tol
+        results.put(("tol", m, tol))
+    results.put(("end", wid))
+
+
 def cpu_worker_main(path, nproc):
-    """`bench.py --cpu-worker file nproc`: the reference's MPI mode (one BLAS thread per rank, ranks over m)."""
+    """`bench.py --cpu-worker file nproc`: the whole job on `nproc` single-threaded worker processes over a common task
+    queue (m-blocks largest first, BT-gen column chunks in between); wall = start to the moment the last worker ran dry."""
     os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = os.environ["MKL_NUM_THREADS"] = "1"
     import multiprocessing as mp
     import pickle
 
+    import numpy as np
+
     with open(path, "rb") as fh:
-        jobs, desc = pickle.load(fh)
+        jobs, common, desc0, bt_tasks = pickle.load(fh)
+    nproc = int(nproc)
+    ctxm = mp.get_context("fork")
+    tasks, results = ctxm.Queue(), ctxm.Queue()
+    order = sorted(jobs)                       # ndof (and the cost) falls with m: largest first
+    tl = [("block", m) for m in order]
+    step = max(1, len(tl) // max(len(bt_tasks), 1))
+    merged, bi = [], 0
+    for i, t in enumerate(tl):                 # BT-gen chunks spread through the first part of the queue
+        if bi < len(bt_tasks) and i % step == 0:
+            merged.append(("bt",) + tuple(bt_tasks[bi])); bi += 1
+        merged.append(t)
+    merged += [("bt",) + tuple(t) for t in bt_tasks[bi:]]
+    for t in merged:
+        tasks.put(t)
+    for _ in range(nproc):
+        tasks.put(None)
     t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(min(int(nproc), len(jobs) + 1)) as pool:
-        bt = pool.apply_async(_cpu_bt_columns, (desc,))
-        res = pool.map(_cpu_one_block, jobs)
-        t_bt = bt.get()
-    wall = time.perf_counter() - t0
-    print(json.dumps(dict(wall_s=wall, per_block=[list(r) for r in res], bt_columns_s=t_bt)))
+    procs = [ctxm.Process(target=_cpu_worker, args=(w, tasks, results, (jobs, common, desc0))) for w in range(nproc)]
+    for p_ in procs:
+        p_.start()
+    blocks, bts, tols, dry, ended = {}, [], {}, [], 0
+    while ended < nproc:
+        r = results.get()
+        if r[0] == "block":
+            blocks[r[1]] = r[2:]
+        elif r[0] == "bt":
+            bts.append(r[4])
+        elif r[0] == "dry":
+            dry.append(r[2] - t0)
+        elif r[0] == "tol":
+            tols[r[1]] = r[2]
+        else:
+            ended += 1
+    for p_ in procs:
+        p_.join()
+    out = dict(wall_s=max(dry), workers=nproc, dry_s=dry, bt_core_s=float(sum(bts)), bt_tasks=len(bts),
+               svd_core_s=float(sum(v[0] for v in blocks.values())), kl_core_s=float(sum(v[1] for v in blocks.values())))
+    with open(path + ".out", "wb") as fh:
+        pickle.dump((out, {m: (v[2], v[3], v[4]) for m, v in blocks.items()}, tols), fh)
+    print(json.dumps(out))
 
 
-def cpu_baseline(tel, bt, kl, blocks):
-    """The oracle (numpy/scipy restatement, kind = "port") on the host cores, on the REAL blocks of this
-    workload (`blocks`: {m: (F,2,B,P,L) numpy}, copied back from the device), per stage, in the two modes
-    BASELINE.md section 3 names:
-      threaded   one process, BLAS threads on all cores, blocks one after the other (median of 3);
-      workers    the reference's MPI mode: single-threaded processes over m (one per sample block here;
-                 the all-core figure is that per-core rate times the core count — an extrapolation, m-blocks
-                 are independent).
-    BT-gen is 2 of the F*B columns scaled to all.  The mean over the m-sample (evenly spread in m) stands for
-    the mean over all m-blocks; `value` is the better of the two modes."""
+def cpu_baseline(tel, bt, kl, blocks, gpu_sv, gpu_ev):
+    """The oracle (numpy/scipy restatement, kind = "port") on the host cores: the WHOLE configs[1] job, MEASURED — the
+    SVD chain + covariance projections + KL of ALL 129 real m-blocks (`blocks`: {m: (F,2,B,P,L) numpy}, copied back from
+    the device) and the BT-gen of every (f, b) column (pixel kernels, one FFT per ring, Legendre matrix products), on
+    single-threaded worker processes over m (the reference's MPI mode, `OMP_NUM_THREADS=1` per rank) — as many as this
+    process may use cores (`host_cores`).  value = blocks / wall; nothing is extrapolated.  The spectra the oracle
+    computes are compared with the GPU's (`gpu_sv[m]` (F, K), `gpu_ev[m]` (ndof,)): the `parity` object of the line."""
     import pickle
     import tempfile
 
     import numpy as np
     import scipy
 
-    ncores = os.cpu_count() or 1
+    ncores = host_cores()
     M = tel.mmax + 1
-    desc = dict(polarised=False, zenith=tel.zenith, baselines=tel.baselines, uniquepairs=tel.uniquepairs,
-                beamclass=tel.beamclass, wavelengths=tel.wavelengths, cylinder_width=tel.cylinder_width,
-                fwhm_e=tel.fwhm_e, fwhm_h=tel.fwhm_h, lmax=tel.lmax, mmax=tel.mmax, l_boost=tel.l_boost,
-                included_freq=np.array([0]), included_baseline=np.array([0, tel.nbase - 1]),
-                accuracy_boost=tel.accuracy_boost, sht_iter=tel.sht_iter, sht_fft=True)   # one FFT per ring, Legendre sums as matrix products
-    ncol = tel.nfreq * tel.nbase
-    t_bt_block = _cpu_bt_columns(desc) / 2.0 * ncol / M    # 2 columns, all m -> seconds per m-block
     ms = sorted(blocks)
+    nproc = max(1, min(ncores, len(ms)))
+    desc0 = dict(polarised=False, zenith=tel.zenith, baselines=tel.baselines, uniquepairs=tel.uniquepairs,
+                 beamclass=tel.beamclass, wavelengths=tel.wavelengths, cylinder_width=tel.cylinder_width,
+                 fwhm_e=tel.fwhm_e, fwhm_h=tel.fwhm_h, lmax=tel.lmax, mmax=tel.mmax, l_boost=tel.l_boost,
+                 included_freq=np.array([0]), included_baseline=np.array([0]),
+                 accuracy_boost=tel.accuracy_boost, sht_iter=tel.sht_iter, sht_fft=True)   # one FFT per ring, Legendre sums as matrix products
+    half = (tel.nbase + 1) // 2
+    bt_tasks = [(fi, b0, min(b0 + half, tel.nbase)) for fi in range(tel.nfreq) for b0 in range(0, tel.nbase, half)]
     noisew = bt._noisew()[:, : tel.nbase]
-    npw = kl._npower(1.0)
-    jobs = [(blocks[m], noisew, kl.signal(), kl.foreground(), npw, bt.polsvcut, bt.svcut) for m in ms]
-    reps = [[_cpu_one_block(j) for j in jobs] for _ in range(3)]
-    svd_s = [float(np.median([r[i][0] for r in reps])) for i in range(len(ms))]
-    kl_s = [float(np.median([r[i][1] for r in reps])) for i in range(len(ms))]
-    ndofs = [reps[0][i][2] for i in range(len(ms))]
-    thr = dict(stage_s_per_block=dict(btgen=t_bt_block, svd=float(np.mean(svd_s)), kl=float(np.mean(kl_s))),
-               per_block_s=dict(svd=svd_s, kl=kl_s))
-    thr["m_blocks_per_s"] = 1.0 / sum(thr["stage_s_per_block"].values())
-    # fresh process (this one holds a GPU context: never fork or exec from it), one single-threaded worker per block
+    common = (noisew, kl.signal(), kl.foreground(), kl._npower(1.0), bt.polsvcut, bt.svcut)
+    # fresh process (this one holds a GPU context: never fork or exec from it)
     try:
         with tempfile.TemporaryDirectory() as tmp:
             path = os.path.join(tmp, "jobs.pkl")
             with open(path, "wb") as fh:
-                pickle.dump((jobs, desc), fh)
+                pickle.dump((blocks, common, desc0, bt_tasks), fh, protocol=4)
             env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(len(ms) + 1)],
-                                 env=env, stdout=subprocess.PIPE, timeout=900, check=True).stdout
-            w = json.loads(out.decode().strip().splitlines()[-1])
-        st = dict(btgen=w["bt_columns_s"] / 2.0 * ncol / M, svd=float(np.mean([p[0] for p in w["per_block"]])),
-                  kl=float(np.mean([p[1] for p in w["per_block"]])))
-        wk = dict(processes=len(ms) + 1, threads_each=1, wall_s=w["wall_s"], stage_s_per_block_one_core=st,
-                  per_block_s=dict(svd=[p[0] for p in w["per_block"]], kl=[p[1] for p in w["per_block"]]),
-                  m_blocks_per_s_per_core=1.0 / sum(st.values()),
-                  m_blocks_per_s=ncores / sum(st.values()), extrapolated_to_cores=ncores)
+            subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(nproc)],
+                           env=env, stdout=subprocess.PIPE, timeout=1200, check=True)
+            with open(path + ".out", "rb") as fh:
+                w, spectra, tols = pickle.load(fh)
     except Exception as e:  # the baseline is reporting only: never lose the bench line over it
-        wk = dict(error=repr(e), m_blocks_per_s=0.0)
-    best = "workers" if wk["m_blocks_per_s"] > thr["m_blocks_per_s"] else "threaded"
-    return dict(value=max(wk["m_blocks_per_s"], thr["m_blocks_per_s"]),
-                unit="m-blocks/s" + (" (EXTRAPOLATED: per-core rate of %d single-threaded worker processes x %d cores)"
-                                     % (wk.get("processes", 0), ncores) if best == "workers" else ""),
-                extrapolated=best == "workers", cores=ncores, kind="port",
-                mode=best, threaded=thr, workers=wk, sample_m=ms, sample_ndof=ndofs,
-                sample="oracle (numpy %s / scipy %s) on the real configs[1] blocks m = %s copied back from the device: SVD "
-                       "chain + covariance projections + KL per block, BT-gen (pixel kernels, one FFT per ring, Legendre matrix "
-                       "products) on 2 of %d (f,b) columns scaled to all; "
-                       "`threaded` = one process, BLAS on %d cores, median of 3; `workers` = single-threaded processes "
-                       "over m (the reference's MPI mode), per-core rate x %d cores"
-                       % (np.__version__, scipy.__version__, ms, ncol, ncores, ncores))
+        return dict(value=0.0, unit="m-blocks/s", cores=ncores, kind="port", error=repr(e), sample="failed"), None
+    # ---- parity of the GPU spectra against the oracle's, every block
+    sv_err, ev_err, ev_over, svnum_eq, kept_eq, kept_escape, worst = 0.0, 0.0, 0.0, True, 0, 0, None
+    for m in ms:
+        ndof, sv_o, ev_o = spectra[m]
+        sv_g, ev_g = np.asarray(gpu_sv[m]), np.asarray(gpu_ev[m])
+        if sv_o.max() > 0:
+            sv_err = max(sv_err, float(np.abs(sv_g - sv_o).max() / sv_o.max()))
+        n_g = (sv_g > sv_g.max() * bt.svcut).sum(axis=1) if sv_g.max() > 0 else np.zeros(sv_g.shape[0], int)
+        n_o = (sv_o > sv_o.max() * bt.svcut).sum(axis=1) if sv_o.max() > 0 else np.zeros(sv_o.shape[0], int)
+        svnum_eq = svnum_eq and bool(np.array_equal(n_g, n_o))
+        if ev_o.size and ev_g.shape == ev_o.shape:
+            lam = float(np.abs(ev_o).max())
+            e = float(np.abs(ev_g - ev_o).max() / max(lam, 1e-300))
+            tol = tols.get(m, 1e-10)
+            if e / tol > ev_over:
+                ev_over, worst = e / tol, dict(m=int(m), ndof=int(ndof), err=e, pencil_tol=tol)
+            ev_err = max(ev_err, e)
+            kg, ko = int((ev_g >= kl.threshold).sum()), int((ev_o >= kl.threshold).sum())
+            if kg == ko:
+                kept_eq += 1
+            elif np.abs(ev_o - kl.threshold).min() <= tol * lam:
+                kept_escape += 1
+        elif ev_g.shape != ev_o.shape:
+            svnum_eq = False
+        else:
+            kept_eq += 1
+    parity = dict(blocks=len(ms), sv_max_err_over_svmax=sv_err, sv_tol=1e-10, svnum_equal=svnum_eq,
+                  ev_max_err_over_lambda_max=ev_err, ev_max_err_over_pencil_tol=ev_over, ev_worst=worst,
+                  kept_counts_equal=kept_eq, kept_counts_differ_with_an_eigenvalue_within_tol_of_the_cut=kept_escape,
+                  kept_counts_differ_otherwise=len(ms) - kept_eq - kept_escape,
+                  green=bool(sv_err <= 1e-10 and svnum_eq and ev_over <= 1.0 and kept_eq + kept_escape == len(ms)),
+                  note="GPU spectra of the timed configuration against the oracle's on the SAME real blocks, all %d of them: "
+                       "singular values relative to the block's largest (bound 1e-10), eigenvalues relative to lambda_max "
+                       "against pencil_tol = max(1e-10, 50 eps cond(N)) (tests/parity_util.py), svnum and kept-mode counts" % len(ms))
+    core_s = w["bt_core_s"] + w["svd_core_s"] + w["kl_core_s"]
+    return dict(value=M / w["wall_s"], unit="m-blocks/s", extrapolated=False, cores=nproc, kind="port", mode="workers",
+                wall_s=w["wall_s"], host_cores=ncores, core_seconds=dict(btgen=w["bt_core_s"], svd=w["svd_core_s"], kl=w["kl_core_s"],
+                                                                         total=core_s),
+                parallel_efficiency=core_s / (w["wall_s"] * nproc),
+                stage_s_per_block_one_core=dict(btgen=w["bt_core_s"] / M, svd=w["svd_core_s"] / M, kl=w["kl_core_s"] / M),
+                sample="the WHOLE job, measured: oracle (numpy %s / scipy %s) SVD chain + covariance projections + KL of all %d "
+                       "real configs[1] blocks copied back from the device and BT-gen (pixel kernels, one FFT per ring, Legendre "
+                       "matrix products) of all %d (f, b) columns, on %d single-threaded worker processes over one task queue "
+                       "(the reference's MPI mode); wall = start to the last worker running dry"
+                       % (np.__version__, scipy.__version__, len(ms), tel.nfreq * tel.nbase, nproc)), parity
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -313,7 +423,7 @@ def _svd_kl_group(bt, kl, beam_all, ms, m0=0):
     return t1 - t0, time.perf_counter() - t1, out, sv
 
 
-def hot_path_step(tel, bt, kl, ctx, stage_times=None, streams=1, m_range=None, collect=False, keep=None):
+def hot_path_step(tel, bt, kl, ctx, stage_times=None, streams=1, m_range=None, collect=False, keep=None, spectra=None):
     """One pass over the m-blocks of this rank (all of them, or the contiguous `m_range`); everything stays on
     the device.  After the beam-transfer generation the m-blocks are dealt round-robin into `streams` groups,
     each driven by its own thread / libdriftmi context / HIP stream.  With `collect` the spectra of all ranks are
@@ -365,6 +475,11 @@ def hot_path_step(tel, bt, kl, ctx, stage_times=None, streams=1, m_range=None, c
         for mi in keep:
             if m0 <= mi < m0 + beam_all.shape[0]:
                 keep[mi] = beam_all[mi - m0].cpu().numpy()
+    if spectra is not None:   # the spectra of this pass on the host: singular values (F, K) and all eigenvalues per m
+        for g, p in zip(groups, parts):
+            for i, mi in enumerate(g):
+                spectra.setdefault("sv", {})[mi] = np.asarray(p[3][i])
+                spectra.setdefault("ev", {})[mi] = p[2][i][0].cpu().numpy()
     if stage_times is not None:
         tsvd = max(p[0] for p in parts)
         stage_times.append((t1 - t0, tsvd, (t3 - t1) - tsvd, tcoll))
@@ -429,6 +544,35 @@ def class_table(pr, steps=1.0):
     return out
 
 
+def job_conf(workload, toy=False, truncate=False):
+    """Configuration dictionary (the reference's YAML sections) of the north-star job: BASELINE configs[2]
+    (`KLTransform`) or configs[3] (+ `DoubleKL` + the exact Fisher matrix); `toy`: the same job on a toy telescope
+    (rehearsals of the control flow on CPU-sized boxes and in the tests)."""
+    tcfg = dict(CFG3, type="PolarisedCylinder")
+    if toy:
+        tcfg = dict(type="PolarisedCylinder", num_freq=4, freq_start=400.0, freq_end=440.0, freq_mode="edge", num_cylinders=2,
+                    cylinder_width=2.0, num_feeds=4, feed_spacing=0.4, tsys=1.0)
+    kls = [dict(type="KLTransform", name="kl", threshold=0.1)]
+    conf = dict(config=dict(beamtransfers=True, kltransform=True, psfisher=False, truncate=bool(truncate),
+                            device_chunk_gb=float(os.environ.get("DRIFT_BENCH_BT_GB", "48")), keep_products_gb=0.0),
+                telescope=tcfg, kltransform=kls)
+    if workload == "configs3":
+        kls.append(dict(type="DoubleKL", name="dk", threshold=0.1, foreground_threshold=100.0))
+        conf["config"]["psfisher"] = True
+        conf["psfisher"] = [dict(type="Full", name="ps", klname="kl", threshold=0.1, bandtype="polar", num_theta=3,
+                                 k_bands=[dict(spacing="linear", start=0.0, stop=0.25, num=4)])]
+    return conf
+
+
+def job_budgets(toy=False):
+    """Batch budgets (GB) of a rank of the north-star job on a 288 GB card: resident beam blocks of a BT-gen range / SVD
+    batch / KL batch / eigensolver arena; a toy rehearsal (several ranks on one card) takes 1 GB each."""
+    if toy:
+        return dict(beam=1.0, svd=1.0, kl=1.0, arena=1.0)
+    return dict(beam=float(os.environ.get("DRIFT_BENCH_BEAM_GB", "72")), svd=float(os.environ.get("DRIFT_BENCH_SVD_GB", "96")),
+                kl=float(os.environ.get("DRIFT_BENCH_KL_GB", "110")), arena=float(os.environ.get("DRIFTMI_WORKSPACE_GB", "100")))
+
+
 def measure_share(workload, share, files=False, share_mmax=None, truncate=False, outdir=None):
     """BASELINE configs[2] / configs[3] — the north-star job — through ProductManager.generate(): rank r of N is
     emulated in this process (`parallel.set_virtual`: its contiguous, cost-balanced range of m; no process group), so
@@ -455,19 +599,7 @@ def measure_share(workload, share, files=False, share_mmax=None, truncate=False,
 
     parallel.set_virtual(r, n)
     try:
-        tcfg = dict(CFG3, type="PolarisedCylinder")
-        if share_mmax:   # rehearsal of the mode on a toy telescope (tests, CPU-sized boxes)
-            tcfg = dict(type="PolarisedCylinder", num_freq=4, freq_start=400.0, freq_end=440.0, freq_mode="edge", num_cylinders=2,
-                        cylinder_width=2.0, num_feeds=4, feed_spacing=0.4, tsys=1.0)
-        kls = [dict(type="KLTransform", name="kl", threshold=0.1)]
-        conf = dict(config=dict(beamtransfers=True, kltransform=True, psfisher=False, truncate=bool(truncate),
-                                device_chunk_gb=float(os.environ.get("DRIFT_BENCH_BT_GB", "48")), keep_products_gb=0.0),
-                    telescope=tcfg, kltransform=kls)
-        if workload == "configs3":
-            kls.append(dict(type="DoubleKL", name="dk", threshold=0.1, foreground_threshold=100.0))
-            conf["config"]["psfisher"] = True
-            conf["psfisher"] = [dict(type="Full", name="ps", klname="kl", threshold=0.1, bandtype="polar", num_theta=3,
-                                     k_bands=[dict(spacing="linear", start=0.0, stop=0.25, num=4)])]
+        conf = job_conf(workload, share_mmax, truncate)
         with tempfile.TemporaryDirectory(dir=outdir) as tmp:
             conf["config"]["output_directory"] = os.path.join(tmp, "prod")
             cfile = os.path.join(tmp, "params.yaml")
@@ -476,11 +608,7 @@ def measure_share(workload, share, files=False, share_mmax=None, truncate=False,
             pm = manager.ProductManager.from_config(cfile)
             tel, bt = pm.telescope, pm.beamtransfer
             mine = bt._my_ms()
-            big = True
-            budgets = dict(beam=float(os.environ.get("DRIFT_BENCH_BEAM_GB", "72" if big else "125")),
-                           svd=float(os.environ.get("DRIFT_BENCH_SVD_GB", "96" if big else "48")),
-                           kl=float(os.environ.get("DRIFT_BENCH_KL_GB", "110" if big else "48")),
-                           arena=float(os.environ.get("DRIFTMI_WORKSPACE_GB", "100" if big else "80")))
+            budgets = job_budgets(bool(share_mmax))
             bt.beam_chunk_gb, bt.svd_chunk_gb = budgets["beam"], budgets["svd"]
             for kl in pm.kltransforms.values():
                 kl.kl_chunk_gb = budgets["kl"]
@@ -491,6 +619,7 @@ def measure_share(workload, share, files=False, share_mmax=None, truncate=False,
                 kl.signal(); kl.foreground()
             t_cl = time.perf_counter() - t0
             ctx.prof_reset(2)      # every kernel class of the path
+            bt.stage_log = []      # per BT-gen range / SVD batch / KL batch: wall seconds + kernel classes (device idle at the boundaries)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             pm.generate()
@@ -498,6 +627,7 @@ def measure_share(workload, share, files=False, share_mmax=None, truncate=False,
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             pr = ctx.prof_report()
+            stages = share_stages(tel, bt, pm, mine, dt)
             nbytes = 0
             if files:
                 for root, _, fl in os.walk(conf["config"]["output_directory"]):
@@ -527,17 +657,17 @@ def measure_share(workload, share, files=False, share_mmax=None, truncate=False,
                            "codec": os.environ.get("DRIFTMI_H5_CODEC", "lzf") if files else None},
                 "share_s": dt,
                 "share_note": "wall time of rank %d of %d for m = %d..%d; the job's wall time is the MAX over the N shares "
-                              "(m-blocks are independent, no data-path collective); rank 0 — lowest m, largest matrices, the m "
-                              "coupled by the polar rings of the SHT refinement — is the slowest share of the cost-balanced "
-                              "partition.  C_l tables %.1f s (host, once per job) not included" % (r, n, mine[0], mine[-1], t_cl),
-                "projected_job_s": dt if r == 0 else None,
-                "job_m_blocks_per_s": (nm / dt) if r == 0 else None,
+                              "(m-blocks are independent, no data-path collective) — ONE share says nothing about which is the "
+                              "slowest: all N are in profiles/*_configs2_shares.json.  C_l tables %.1f s (host, once per job) not "
+                              "included" % (r, n, mine[0], mine[-1], t_cl),
+                "m_range": [int(mine[0]), int(mine[-1])],
                 "file_bytes": nbytes,
                 "kernels_ms": {k: v["ms"] for k, v in pr.items()},
                 "arena_gb_at_end": float(ctx.lib.dm_ctx_workspace_bytes(ctx.h)) / float(1 << 30),
                 "classes": classes,
                 "kernel_s": kern_s,
                 "kernel_coverage_of_wall": kern_s / dt,
+                "stages": stages,
                 "zgemm_cov": None if cov is None else dict(
                     ms=cov["ms"], flop=cov["flops"], launches=cov["launches"],
                     tflops=cov["flops"] / (cov["ms"] * 1e-3) / 1e12 if cov["ms"] > 0 else None,
@@ -551,6 +681,171 @@ def measure_share(workload, share, files=False, share_mmax=None, truncate=False,
             return line
     finally:
         parallel.set_virtual(None)
+
+
+def share_stages(tel, bt, pm, mine, wall_s):
+    """SURVEY.md section 8(d) at the north-star workload: wall seconds of the three stages of the share (from the
+    product's own stage log: the device is idle at every stage boundary) and the algorithmic work W_A (Legendre), W_B
+    (SVD chain), W_C (projections + eig) over them as fractions of the fp64 MFMA peak — W from the REAL svnum / ndof of
+    the share's blocks and the modes actually kept — plus the kernel classes of each stage, so that the grouped ZGEMM
+    seconds of the SVD chain and of the eigensolver are told apart."""
+    import numpy as np
+
+    log = bt.stage_log or []
+    nkeep = {}
+    kls = list(pm.kltransforms.values())
+    if kls:
+        full = kls[0].__dict__.get("_evals_full_mem", {})
+        for mi, evf in full.items():
+            nkeep[mi] = int((np.asarray(evf) >= kls[0].threshold).sum()) if kls[0].subset else int(len(evf))
+    WA, WB, WC = stage_work(tel, bt, mine, nkeep=nkeep if len(nkeep) == len(mine) else None)
+    if len(kls) > 1 or getattr(pm, "gen_ps", False):
+        WC = None   # configs[3]: DoubleKL and the Fisher estimator run in the same downstream stage; W_C covers one KLTransform only
+    out = {}
+    for name, W in (("btgen", WA), ("svd", WB), ("kl", WC)):
+        recs = [r for r in log if r["stage"] == name]
+        secs = sum(r["seconds"] for r in recs)
+        cls = {}
+        for r in recs:
+            for k, v in r["classes"].items():
+                a = cls.setdefault(k, dict(ms=0.0, flops=0.0, launches=0))
+                a["ms"] += v["ms"]; a["flops"] += v["flops"]; a["launches"] += v["launches"]
+        tf = (W / secs / 1e12) if (W is not None and secs > 0) else None
+        out[name] = dict(seconds=secs, calls=len(recs), work_flop=W, tflops=tf,
+                         frac_of_fp64_mfma_peak=None if tf is None else tf / FP64_MFMA_PEAK_TFLOPS,
+                         kernel_s=sum(v["ms"] for v in cls.values()) * 1e-3,
+                         classes_ms={k: round(v["ms"], 1) for k, v in sorted(cls.items(), key=lambda kv: -kv[1]["ms"])},
+                         blocks_per_call=[len(r["ms"]) for r in recs])
+    out["other_s"] = wall_s - sum(out[k]["seconds"] for k in ("btgen", "svd", "kl"))
+    out["note"] = ("W_A = 8 Nr Lm F B P, W_B = sum_f [svd(T, P Lm) + svd(r1, (P-1) Lm) + svd(r2, Lm) + svd(n, P Lm)] + projections "
+                   "(svd(a, b) = 4 (2 max min^2 + 11 min^3), r1 = r2 = min(T, P Lm), n = the frequency's kept modes), "
+                   "W_C = 8 ndof^2 Lm (1 + n_F) + 8 T sum n_f^2 + eig(ndof, nkeep): SURVEY section 8(d); seconds are wall times "
+                   "between device-idle points of ProductManager.generate(); other_s = spectra collection, allocation, host")
+    return out
+
+
+def measure_job(workload, backend="nccl", one_gpu=False, toy=False):
+    """The north-star job on N REAL ranks (this process is one of them: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from
+    the launcher): every rank takes its `_my_ms()` range of BASELINE configs[2] (configs[3]: + DoubleKL + exact Fisher)
+    through `ProductManager.generate()` on its own GPU — the reference's functional test is exactly this with two MPI
+    ranks (tests/test_functional.py:58-88, drift/core/manager.py:278-305) — with the spectra gathered to rank 0
+    (kltransform.py:21-52) and, for configs[3], the Fisher matrix all-reduced over RCCL (psestimation.py:506-507).
+    Rank 0 returns the line: per-rank seconds, max / mean, seconds inside collectives, the ranks RCCL saw."""
+    import tempfile
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import yaml
+
+    from driftscan_amd import device, manager, parallel
+
+    world = int(os.environ["WORLD_SIZE"])
+    local = 0 if one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ["DRIFTMI_DEVICE"] = str(local)
+    os.environ["DRIFTMI_STORAGE"] = "discard"     # products stay in HBM, as in the share measurements
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local)
+    dist.init_process_group(backend=backend)
+    rank = dist.get_rank()
+    dev = "cuda" if backend == "nccl" else "cpu"
+    one = torch.ones(1, dtype=torch.float64, device=dev)
+    dist.all_reduce(one)                           # the tensor collective of the path, over the job's backend
+    seen = int(round(float(one.item())))
+    conf = job_conf(workload, toy)
+    # one product directory for all ranks (rank 0 makes it and broadcasts the name, as a shared file system would hold it)
+    tmp = tempfile.mkdtemp() if rank == 0 else None
+    tmp = parallel.bcast_object(tmp)
+    try:
+        conf["config"]["output_directory"] = os.path.join(tmp, "prod")
+        cfile = os.path.join(tmp, "params_%d.yaml" % rank)
+        with open(cfile, "w") as fh:
+            yaml.dump(conf, fh)
+        pm = manager.ProductManager.from_config(cfile)
+        tel, bt = pm.telescope, pm.beamtransfer
+        mine = bt._my_ms()
+        budgets = job_budgets(toy)
+        bt.beam_chunk_gb, bt.svd_chunk_gb = budgets["beam"], budgets["svd"]
+        for kl in pm.kltransforms.values():
+            kl.kl_chunk_gb = budgets["kl"]
+        ctx = device.get_context(workspace_bytes=int(budgets["arena"] * (1 << 30)))
+        for kl in pm.kltransforms.values():       # C_l tables: host, once per job, untimed (cora's models in the reference)
+            kl.signal(); kl.foreground()
+        ctx.prof_reset(1)
+        bt.stage_log = []
+        parallel.collective_stats(reset=True)
+        parallel.barrier()
+        torch.cuda.synchronize()
+        parallel.collective_stats(reset=True)
+        t0 = time.perf_counter()
+        pm.generate()
+        ctx.sync()
+        torch.cuda.synchronize()
+        t_mine = time.perf_counter() - t0          # this rank's generate(): compute + its waits inside the collectives
+        cs = parallel.collective_stats()
+        parallel.barrier()
+        t_job = time.perf_counter() - t0           # every rank has finished
+        st = {k: sum(r["seconds"] for r in bt.stage_log if r["stage"] == k) for k in ("btgen", "svd", "kl")}
+        vec = torch.tensor([t_mine, cs["seconds"], float(mine[0] if mine else -1), float(mine[-1] if mine else -1),
+                            float(len(mine)), st["btgen"], st["svd"], st["kl"], cs["allreduce_s"], float(cs["allreduce_calls"]),
+                            t_job, torch.cuda.max_memory_allocated() / 2 ** 30], dtype=torch.float64, device=dev)
+        allv = [torch.zeros_like(vec) for _ in range(world)]
+        dist.all_gather(allv, vec)
+        line = None
+        if rank == 0:
+            per = [dict(rank=i, seconds=float(v[0]), compute_s=float(v[0] - v[1]), collective_s=float(v[1]), m_lo=int(v[2]),
+                        m_hi=int(v[3]), m_blocks=int(v[4]), stage_s=dict(btgen=float(v[5]), svd=float(v[6]), kl=float(v[7])),
+                        allreduce_s=float(v[8]), allreduce_calls=int(v[9]), hbm_peak_gb=float(v[11])) for i, v in enumerate(allv)]
+            job_s = max(float(v[10]) for v in allv)
+            comp = [p_["compute_s"] for p_ in per]
+            nm = tel.mmax + 1
+            name = "configs[2]" if workload == "configs2" else "configs[3]"
+            line = {
+                "metric": "m-blocks/sec (BT-gen + SVD + KL)", "value": nm / job_s, "unit": "m-blocks/s", "n_gpus": world,
+                "steps": 1, "warmup": 0, "ms_per_step": 1e3 * job_s, "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "%s: the whole %s job (nfreq=%d, nbase=%d, lmax=mmax=%d, %d m-blocks) on %d REAL ranks through "
+                                       "ProductManager.generate(), one contiguous cost-balanced m-range per rank, %s, products left "
+                                       "in HBM (no files)" % (name, "toy-telescope REHEARSAL" if toy else "128-feed polarised cylinder",
+                                                              tel.nfreq, tel.nbase, tel.lmax, nm, world,
+                                                              "KLTransform" if workload == "configs2" else
+                                                              "KLTransform + DoubleKL + PSExact (9 polar bands), Fisher all-reduce"),
+                           "nfreq": tel.nfreq, "nbase": tel.nbase, "lmax": tel.lmax, "mmax": tel.mmax, "ranks": world,
+                           "backend": backend, "one_gpu": bool(one_gpu), "sht_iter": int(tel.sht_iter),
+                           "budgets_gb": budgets},
+                "job_s": job_s, "ranks_seen_by_rccl" if backend == "nccl" else "ranks_seen_by_gloo": seen,
+                "per_rank": per, "rank_seconds_max": max(comp), "rank_seconds_mean": float(np.mean(comp)),
+                "imbalance_max_over_mean": max(comp) / float(np.mean(comp)),
+                "collective_s_max": max(p_["collective_s"] for p_ in per),
+                "collectives": "pickled spectra gathered to rank 0 over %s (svdspectrum, evals), barriers%s" % (
+                    "a gloo side group" if backend == "nccl" else "gloo",
+                    ", Fisher + bias all-reduce over %s" % ("RCCL" if backend == "nccl" else "gloo") if workload == "configs3" else ""),
+                "note": "job_s = barrier to barrier around generate() on every rank (C_l tables made before, untimed); per rank: "
+                        "seconds = its generate(), collective_s = time inside barriers / gathers / all-reduce (mostly waiting for "
+                        "the slowest rank), compute_s = the difference",
+                "roofline": None, "cpu_baseline": None,
+            }
+        del pm
+    finally:
+        parallel.barrier()
+        if rank == 0:
+            import shutil
+
+            shutil.rmtree(tmp, ignore_errors=True)
+        dist.destroy_process_group()
+    return line
+
+
+def run_job(args):
+    """`bench.py --workload configs2|configs3 --job [--gpus N]`: under a launcher (WORLD_SIZE set) this process is one rank
+    of the job; without one it starts the N ranks itself (before touching the GPU)."""
+    if "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, sys.argv[1:])
+    line = measure_job(args.workload, backend=args.backend, one_gpu=args.one_gpu, toy=bool(args.share_mmax))
+    if line is not None:
+        print(json.dumps(line))
+        sys.stdout.flush()
+    return 0
 
 
 def run_share(args):
@@ -714,10 +1009,44 @@ def run_configs4(args):
     return 0
 
 
+def _share_child(args, share):
+    """One emulated share of the configs[2] job in a child process (started, never exec'ed into: this process keeps its HIP
+    context; a failure of the leg — a share holds ~150 GB of HBM — must not cost the configs[1] line)."""
+    retried = None
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "configs2", "--share", share]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    if res.returncode != 0 and "DRIFT_BENCH_SVD_GB" not in os.environ:
+        # once more at the batch budgets of rounds 1-3 (125 / 48 / 48 / 80 GB): a card with less free memory than the
+        # 230 GB the default budgets take should still give a figure — the line says which budgets it ran with
+        retried = res.stderr.decode()[-300:]
+        env = dict(os.environ, DRIFT_BENCH_BEAM_GB="125", DRIFT_BENCH_SVD_GB="48", DRIFT_BENCH_KL_GB="48", DRIFTMI_WORKSPACE_GB="80")
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+    if res.returncode != 0:
+        raise RuntimeError("share %s exited with %d: %s" % (share, res.returncode, res.stderr.decode()[-400:]))
+    return json.loads(res.stdout.decode().strip().splitlines()[-1]), retried
+
+
+def committed_shares():
+    """The latest profiles/*_configs2_shares.json: ALL N shares of the configs[2] job measured on one GPU each in one
+    gpurun call (scratch/shares_all.sh); None when absent."""
+    import glob
+
+    fl = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_configs2_shares.json")))
+    if not fl:
+        return None
+    try:
+        rec = json.load(open(fl[-1]))
+        rec["_file"] = os.path.relpath(fl[-1], ROOT)
+        return rec
+    except Exception:
+        return None
+
+
 def north_star_leg(args):
-    """The north-star workload inside the default line: one rank's share (default 0/8: the slowest) of the BASELINE
-    configs[2] job through ProductManager.generate(), with every kernel class timed.  Runs after the timed configs[1]
-    region, on rank 0 at --gpus 1 only."""
+    """The north-star workload inside the default line (rank 0 at --gpus 1): shares of the BASELINE configs[2] job through
+    ProductManager.generate(), every kernel class timed, stage-level W / t.  Measured LIVE: share 0/8 (lowest m: largest
+    matrices) and the share the committed all-shares record names as the slowest; `projected_job_s` = the MAX over the
+    eight shares — live figures where this run has them, the committed record (made at the build it names) for the rest."""
     import gc
 
     import torch
@@ -729,35 +1058,131 @@ def north_star_leg(args):
     gc.collect()
     torch.cuda.empty_cache()
     t0 = time.perf_counter()
-    # a child process (started, not exec'ed into: this process keeps its HIP context): a failure of the leg — the share
-    # holds ~150 GB of HBM — must not cost the configs[1] line
-    retried = None
+    rec = committed_shares()
+    n = int(args.north_star_share.split("/")[1])
+    shares = [args.north_star_share]
+    if rec and rec.get("n") == n and rec.get("shares") and os.environ.get("DRIFT_BENCH_NS_ONE") != "1":
+        slow = max(rec["shares"], key=lambda r_: r_["share_s"])["share"]
+        if slow not in shares:
+            shares.append(slow)
+    live, retried = {}, None
     try:
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", "configs2", "--share", args.north_star_share]
-        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-        if res.returncode != 0 and "DRIFT_BENCH_SVD_GB" not in os.environ:
-            # once more at the batch budgets of rounds 1-3 (125 / 48 / 48 / 80 GB): a card with less free memory than the
-            # 230 GB the default budgets take should still give a figure — the line says which budgets it ran with
-            retried = res.stderr.decode()[-300:]
-            env = dict(os.environ, DRIFT_BENCH_BEAM_GB="125", DRIFT_BENCH_SVD_GB="48", DRIFT_BENCH_KL_GB="48", DRIFTMI_WORKSPACE_GB="80")
-            res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
-        if res.returncode != 0:
-            return dict(error="north-star leg exited with %d: %s" % (res.returncode, res.stderr.decode()[-400:]))
-        sh = json.loads(res.stdout.decode().strip().splitlines()[-1])
+        for sh_ in shares:
+            live[sh_], rt = _share_child(args, sh_)
+            retried = retried or rt
     except Exception as e:   # reporting only
-        return dict(error=repr(e))
-    keep = ("share_s", "share_note", "projected_job_s", "job_m_blocks_per_s", "classes", "kernel_s",
-            "kernel_coverage_of_wall", "zgemm_cov", "hbm_peak_gb")
-    out = {k: sh[k] for k in keep}
+        if not live:
+            return dict(error=repr(e))
+    sh = live[shares[0]]
+    keep = ("share_s", "share_note", "classes", "kernel_s", "kernel_coverage_of_wall", "stages", "zgemm_cov", "hbm_peak_gb",
+            "m_range")
+    out = {k: sh.get(k) for k in keep}
     out["workload"] = sh["config"]["workload"]
     out["budgets_gb"] = sh["config"].get("budgets_gb")
     if retried is not None:
         out["first_attempt_failed"] = retried
-    out["share"] = args.north_star_share
+    out["share"] = shares[0]
     out["sht_iter"] = sh["config"]["sht_iter"]
     out["m_blocks"] = sh["value"] * sh["share_s"]
+    # every share of the job: live where measured now, else the committed record
+    bid = build_id()
+    allsh = {}
+    if rec and rec.get("n") == n:
+        for r_ in rec["shares"]:
+            allsh[r_["share"]] = dict(share_s=r_["share_s"], m_range=r_.get("m_range"), source=rec["_file"],
+                                      build_id=rec.get("_build_id"), stale=rec.get("_build_id") != bid)
+    for k, v in live.items():
+        allsh[k] = dict(share_s=v["share_s"], m_range=v.get("m_range"), source="live", build_id=bid, stale=False,
+                        stages={kk: vv["seconds"] for kk, vv in (v.get("stages") or {}).items() if isinstance(vv, dict)})
+    out["shares"] = allsh
+    complete = len(allsh) == n
+    worst = max(allsh, key=lambda k: allsh[k]["share_s"])
+    out["projected_job_s"] = allsh[worst]["share_s"] if complete else None
+    out["projected_job_slowest_share"] = worst if complete else None
+    out["job_m_blocks_per_s"] = (sh["config"]["mmax"] + 1) / allsh[worst]["share_s"] if complete else None
+    out["projected_job_note"] = ("MAX over the %d shares of the cost-balanced partition (m-blocks are independent, no data-path "
+                                 "collective); %d measured in this run, the others from %s%s" % (
+                                     n, len(live), rec["_file"] if rec else "nothing (no committed all-shares record)",
+                                     " — STALE build for those" if any(v["stale"] for v in allsh.values()) else ""))
+    if len(shares) > 1 and shares[1] in live:
+        s2 = live[shares[1]]
+        out["second_share"] = dict(share=shares[1], share_s=s2["share_s"], m_range=s2.get("m_range"), kernel_s=s2["kernel_s"],
+                                   stages=s2.get("stages"), zgemm_cov=s2.get("zgemm_cov"))
+    # counter evidence at THIS workload (rocprofv3 --pmc restricted to the kernels of interest, scratch/pmc_share.sh)
+    try:
+        import glob
+
+        pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_configs2_pmc_mfma.json")))
+        if pj and out.get("zgemm_cov"):
+            pr = json.load(open(pj[-1]))
+            if pr.get("_build_id") == bid:
+                out["zgemm_cov"]["mfma_busy"] = pr.get("zgemm_cov", {}).get("mfma_busy")
+                out["zgemm_cov"]["mfma_busy_source"] = os.path.relpath(pj[-1], ROOT)
+                out["pmc"] = {k: v for k, v in pr.items() if not k.startswith("_")}
+            else:
+                out["zgemm_cov"]["mfma_busy"] = None
+                out["zgemm_cov"]["mfma_busy_source"] = "%s is stale (build %s, running %s)" % (
+                    os.path.relpath(pj[-1], ROOT), pr.get("_build_id"), bid)
+    except Exception:
+        pass
+    cj = os.path.join(ROOT, "profiles", "r05_configs2_cpu_sample.json")
+    if os.path.exists(cj):
+        try:
+            out["cpu_sample"] = json.load(open(cj))
+        except Exception:
+            pass
     out["leg_wall_s"] = time.perf_counter() - t0
     out["target"] = "full configs[2] product set in under 600 s on 8 x MI355X; covariance GEMMs at >= 0.5 of the fp64 MFMA peak"
+    return out
+
+
+def north_star_job_leg(args, world, rank):
+    """The north-star workload at --gpus N > 1: the REAL N-rank configs[2] job (`measure_job`).  Every rank process of the
+    configs[1] line starts ONE child — its rank of the job, on its GPU, in a fresh process group on a port rank 0 picks —
+    and waits for it; rank 0's child prints the job's line."""
+    import gc
+    import socket
+
+    import torch
+
+    from driftscan_amd import beamtransfer, device, parallel
+
+    beamtransfer.BeamTransfer._clcache.clear()
+    device.reset_context()
+    gc.collect()
+    torch.cuda.empty_cache()
+    port = None
+    if rank == 0:
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+    port = parallel.bcast_object(port)
+    # a launcher's elastic agent variables would send the child's rendezvous to the PARENT job's store
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+               LOCAL_RANK=os.environ.get("LOCAL_RANK", str(rank)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "configs2", "--job", "--gpus", str(world),
+           "--backend", args.backend] + (["--one-gpu"] if args.one_gpu else []) + (
+               ["--share-mmax", str(args.share_mmax)] if args.share_mmax else [])
+    t0 = time.perf_counter()
+    out = None
+    try:
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+        if rank == 0:
+            if res.returncode != 0:
+                out = dict(error="rank 0 of the job exited with %d: %s" % (res.returncode, res.stderr.decode()[-600:]))
+            else:
+                out = dict(job=json.loads(res.stdout.decode().strip().splitlines()[-1]))
+    except Exception as e:
+        if rank == 0:
+            out = dict(error=repr(e))
+    parallel.barrier()
+    if rank == 0:
+        out["leg_wall_s"] = time.perf_counter() - t0
+        out["what"] = ("the REAL %d-rank BASELINE configs[2] job%s through ProductManager.generate(), one child process per rank "
+                       "started by the rank processes of this line" % (world, " (toy-telescope REHEARSAL)" if args.share_mmax else ""))
+        out["target"] = "full configs[2] product set in under 600 s on 8 x MI355X; covariance GEMMs at >= 0.5 of the fp64 MFMA peak"
     return out
 
 
@@ -769,7 +1194,7 @@ def main():
     if args.workload == "configs4":
         return run_configs4(args)
     if args.workload != "configs1":
-        return run_share(args)
+        return run_job(args) if args.job else run_share(args)
     if args.mode is None:
         args.mode = "sharded" if args.gpus > 1 else "weak"
     launched = "WORLD_SIZE" in os.environ
@@ -1055,11 +1480,12 @@ def main():
             for name, W, secs in (("btgen", WA, st[0]), ("svd", WB, st[1]), ("kl", WC, st[2])):
                 tf = W / secs / 1e12 if secs > 0 else 0.0
                 stages[name] = dict(work_flop=W, ms=1e3 * secs, tflops=tf, frac_of_fp64_mfma_peak=tf / FP64_MFMA_PEAK_TFLOPS)
-            cpu = None
+            cpu, parity = None, None
             if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N = 1 only
-                keep = {m: None for m in CPU_SAMPLE_M if m in my_ms}
-                hot_path_step(tel, bt, kl, ctx, streams=args.streams, m_range=m_range, keep=keep)   # untimed: real blocks
-                cpu = cpu_baseline(tel, bt, kl, {m: b for m, b in keep.items() if b is not None})
+                keep, spec = {m: None for m in my_ms}, {}
+                hot_path_step(tel, bt, kl, ctx, streams=args.streams, m_range=m_range, keep=keep, spectra=spec)   # untimed: real blocks
+                cpu, parity = cpu_baseline(tel, bt, kl, {m: b for m, b in keep.items() if b is not None}, spec["sv"], spec["ev"])
+                del keep
             line = {
                 "metric": "m-blocks/sec (BT-gen + SVD + KL)",
                 "value": value,
@@ -1107,10 +1533,20 @@ def main():
                 "kernels_ms": {k: v["ms"] / args.steps for k, v in prof.items()},
                 "roofline": roofline,
                 "cpu_baseline": cpu,
+                "parity": parity,
             }
-            if world == 1 and not force_dist and not args.no_north_star and args.streams == 1 and not args.all_modes:
-                del tel, bt, kl
-                line["north_star"] = north_star_leg(args)
+        else:
+            line = None
+        ns_ok = not args.no_north_star and args.streams == 1 and not args.all_modes and not args.shard
+        if world == 1 and not force_dist and ns_ok and rank == 0:
+            del tel, bt, kl
+            line["north_star"] = north_star_leg(args)
+        elif world > 1 and ns_ok:
+            del tel, bt, kl
+            ns = north_star_job_leg(args, world, rank)   # every rank takes part: each starts its rank of the job
+            if rank == 0:
+                line["north_star"] = ns
+        if rank == 0:
             print(json.dumps(line))
             sys.stdout.flush()
     if world > 1 or force_dist:

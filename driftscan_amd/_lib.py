@@ -650,6 +650,11 @@ PROF_NCLASS = len(PROF_CLASSES)
 def _prof_reset(self, enable=True):
     """enable: False / True (the MFMA and HBM-bound classes) / 2 (every kernel of the path: the extended classes too)."""
     self.check(self.lib.dm_prof_reset(self.h, int(enable)), "dm_prof_reset")
+    self._prof_level = int(enable)
+
+
+def _prof_enabled(self):
+    return bool(getattr(self, "_prof_level", 0))
 
 
 def _prof_report(self):
@@ -661,6 +666,7 @@ def _prof_report(self):
 
 
 Context.prof_reset = _prof_reset
+Context.prof_enabled = _prof_enabled
 Context.prof_report = _prof_report
 
 

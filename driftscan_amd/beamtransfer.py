@@ -79,6 +79,10 @@ class BeamTransfer(config.Reader):
     keep_products_gb = config.Property(proptype=float, default=32.0)  # SVD products of finished batches stay in HBM up to this
 
     noise_weight = True
+    # Opt-in stage log (bench.py's north-star share): `generate` appends (stage, [m...], wall seconds, kernel-class
+    # snapshot) per BT-gen range / SVD batch / downstream (KL) batch, waiting for the device at every stage boundary.
+    # None (the default): no waits beyond the ones the pipeline has anyway.
+    stage_log = None
 
     def __init__(self, directory, telescope=None):
         self.directory = directory
@@ -183,6 +187,30 @@ class BeamTransfer(config.Reader):
             return f["singularvalues"][:]
 
     # ---- generation -------------------------------------------------------------------
+    def _stage_begin(self):
+        if self.stage_log is None:
+            return None
+        ctx = get_context()
+        ctx.sync()
+        return (time.perf_counter(), ctx.prof_report() if ctx.prof_enabled() else {})
+
+    def _stage_end(self, tok, stage, ms):
+        """One record of the stage log: wall seconds between two device-idle points and the kernel-class times /
+        work counters that accrued in between (dm_prof_report differences)."""
+        if tok is None:
+            return
+        ctx = get_context()
+        ctx.sync()
+        dt = time.perf_counter() - tok[0]
+        now = ctx.prof_report() if ctx.prof_enabled() else {}
+        cls = {}
+        for k, v in now.items():
+            o = tok[1].get(k, dict(ms=0.0, flops=0.0, launches=0))
+            d = dict(ms=v["ms"] - o["ms"], flops=v["flops"] - o["flops"], launches=v["launches"] - o["launches"])
+            if d["launches"] > 0:
+                cls[k] = d
+        self.stage_log.append(dict(stage=stage, ms=[int(m) for m in ms], seconds=dt, classes=cls))
+
     def generate(self, regen=False, skip_svd=False, skip_svd_inv=False, after_batch=None):
         """Generate and save all products (beamtransfer.py:447-480).
 
@@ -214,19 +242,23 @@ class BeamTransfer(config.Reader):
             beam_all = None
             if need_bt:
                 whole = a == 0 and b == tel.mmax
+                tok = self._stage_begin()
                 beam_all = btgen.beam_m_all(tel, ctx=ctx, max_bytes=int(self.device_chunk_gb * (1 << 30)),
                                             m_range=None if whole else (a, b))
                 if self.truncate:
                     # beamtransfer.py:641-646: rows of the m-ordered array (runs over l) truncated to
                     # max(truncate_rel |z|, truncate_maxl max_l |z|); in place, so the SVD stage sees what the files hold
                     ctx.bit_truncate_max_complex(beam_all, self.truncate_rel, self.truncate_maxl)
+                self._stage_end(tok, "btgen", ms)
                 self._write_beam_files(beam_all, a, b, regen)
             self._beam_all, self._beam_all_m0 = beam_all, a
             if need_svd:
                 self._svd_batches(ms, regen, skip_svd_inv, after_batch)
             elif after_batch is not None and not skip_svd:
                 for batch in self._svd_batch_lists(ms):
+                    tok = self._stage_begin()
                     after_batch(batch)
+                    self._stage_end(tok, "kl", batch)
                     self._evict(batch)
             self._beam_all = None
             del beam_all
@@ -427,10 +459,12 @@ class BeamTransfer(config.Reader):
         T, P, L, K = self.ntel, tel.num_pol_sky, tel.lmax + 1, self.svd_len
         todo = [mi for mi in ms if regen or not storage.can_open(self._svdfile(mi))]
         for batch in self._svd_batch_lists(todo):
+            tok = self._stage_begin()
             blocks = self._device_beam_blocks(batch)
             res = self.svd_device(blocks, skip_svd_inv=skip_svd_inv)
             del blocks
             sv_host = ctx.to_host(res["singularvalues"])
+            self._stage_end(tok, "svd", batch)
             if not storage.discard():
                 ev = ctx.record_event()   # host copies by the copy thread (storage.Deferred); the products are read-only from here
 
@@ -457,7 +491,9 @@ class BeamTransfer(config.Reader):
                                    ctx.defer_host(but_v[i], ev), sv_host[i])
             del res
             if after_batch is not None:
+                tok = self._stage_begin()
                 after_batch(batch)
+                self._stage_end(tok, "kl", batch)
                 self._evict(batch)
 
     def _evict(self, ms):

@@ -8,8 +8,54 @@ collective at all: only small spectra are gathered to rank 0 and the Fisher
 matrix is all-reduced, exactly the reference's pattern.
 """
 import os
+import time
 
 import numpy as np
+
+# wall seconds this process spent inside collectives (barrier, gathers, broadcast, all-reduce) and how many it made:
+# what `bench.py`'s N-rank north-star job reports as `collective_s` (waiting for the slowest rank is part of it)
+_coll = dict(seconds=0.0, calls=0, allreduce_s=0.0, allreduce_calls=0)
+
+
+def collective_stats(reset=False):
+    out = dict(_coll)
+    if reset:
+        for k in _coll:
+            _coll[k] = 0 if k.endswith("calls") else 0.0
+    return out
+
+
+class _timed(object):
+    def __init__(self, kind=None):
+        self.kind = kind
+
+    def __enter__(self):
+        self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        dt = time.perf_counter() - self.t0
+        _coll["seconds"] += dt
+        _coll["calls"] += 1
+        if self.kind == "allreduce":
+            _coll["allreduce_s"] += dt
+            _coll["allreduce_calls"] += 1
+        return False
+
+
+_objgrp = None
+
+
+def _obj_group(d):
+    """Process group for the PICKLED-object collectives (spectra gathers, broadcasts): the default group on gloo; with
+    the default group on "nccl" a gloo side group made at first use — the reference gathers pickles over MPI on the
+    host (kltransform.py:29), RCCL is for the tensor collective of the path (the Fisher all-reduce).  Every rank
+    reaches its first object collective at the same point of the job, so the group creation is collective too."""
+    global _objgrp
+    if d.get_backend() != "nccl":
+        return None
+    if _objgrp is None or _objgrp[0] is not d.group.WORLD:
+        _objgrp = (d.group.WORLD, d.new_group(backend="gloo"))
+    return _objgrp[1]
 
 
 def _dist():
@@ -69,7 +115,13 @@ def io_root():
 def barrier():
     d = _dist()
     if d:
-        d.barrier()
+        with _timed():
+            if d.get_backend() == "nccl":
+                import torch
+
+                d.barrier(device_ids=[torch.cuda.current_device()])
+            else:
+                d.barrier()
 
 
 def init_from_env(backend=None):
@@ -170,7 +222,8 @@ def gather_objects(obj):
     if not d:
         return [obj]
     out = [None] * size() if rank0() else None
-    d.gather_object(obj, out, dst=0)
+    with _timed():
+        d.gather_object(obj, out, dst=0, group=_obj_group(d))
     return out
 
 
@@ -185,11 +238,13 @@ def exchange(parts):
     if not d:
         return [parts[rank()]] if len(parts) > 1 else [parts[0]]
     mine = None
-    for dst in range(n):
-        out = [None] * n if rank() == dst else None
-        d.gather_object(parts[dst], out, dst=dst)
-        if rank() == dst:
-            mine = out
+    with _timed():
+        grp = _obj_group(d)
+        for dst in range(n):
+            out = [None] * n if rank() == dst else None
+            d.gather_object(parts[dst], out, dst=dst, group=grp)
+            if rank() == dst:
+                mine = out
     return mine
 
 
@@ -198,7 +253,8 @@ def bcast_object(obj):
     if not d:
         return obj
     box = [obj]
-    d.broadcast_object_list(box, src=0)
+    with _timed():
+        d.broadcast_object_list(box, src=0, group=_obj_group(d))
     return box[0]
 
 
@@ -210,7 +266,9 @@ def allreduce_sum(arr):
     import torch
 
     t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64))
-    if d.get_backend() == "nccl":
-        t = t.cuda()
-    d.all_reduce(t)
-    return t.cpu().numpy()
+    with _timed("allreduce"):
+        if d.get_backend() == "nccl":
+            t = t.cuda()
+        d.all_reduce(t)
+        out = t.cpu().numpy()
+    return out

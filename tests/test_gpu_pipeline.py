@@ -506,3 +506,28 @@ def test_deferred_host_copies(tmp_path, monkeypatch):
     for i in range(6):
         with storage.File(str(tmp_path / ("d%d.hdf5" % i)), "r") as f:
             assert np.array_equal(f["a"][...], want[i][:2]) and np.array_equal(f["b"][...], want[i][2])
+
+
+def test_bench_job_mode_two_ranks_on_one_gpu():
+    """`bench.py --workload configs2 --job --gpus 2` — the north-star job on REAL ranks (two processes, gloo between them,
+    both on this GPU, toy telescope): every rank takes its `_my_ms()` range through ProductManager.generate(), the line
+    carries per-rank seconds, the seconds inside collectives and the number of ranks the backend saw; the ranges
+    partition 0..mmax.  (What `bench.py --gpus N` attaches as `north_star.job` for N > 1.)"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "configs2", "--job", "--gpus", "2",
+                          "--one-gpu", "--backend", "gloo", "--share-mmax", "1"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    line = json.loads(res.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen_by_gloo"] == 2 and line["config"]["ranks"] == 2
+    per = line["per_rank"]
+    assert [p["rank"] for p in per] == [0, 1]
+    assert per[0]["m_lo"] == 0 and per[1]["m_lo"] == per[0]["m_hi"] + 1 and per[1]["m_hi"] == line["config"]["mmax"]
+    assert sum(p["m_blocks"] for p in per) == line["config"]["mmax"] + 1
+    assert all(p["seconds"] > 0 and p["collective_s"] >= 0 and p["stage_s"]["svd"] > 0 for p in per)
+    assert line["job_s"] >= max(p["compute_s"] for p in per) and line["value"] > 0

@@ -96,7 +96,7 @@ tot = parallel.allreduce_sum(np.array([float(sum(mine)), 1.0]))
 word = parallel.bcast_object("hello" if parallel.rank0() else None)
 parallel.barrier()
 if parallel.rank0():
-    print(json.dumps(dict(parts=parts, tot=tot.tolist(), word=word)))
+    print(json.dumps(dict(parts=parts, tot=tot.tolist(), word=word, coll=parallel.collective_stats())))
 dist.destroy_process_group()
 '''
 
@@ -124,6 +124,8 @@ def test_two_rank_gloo(tmp_path):
     load = [sum(12 - m for m in by_rank[r][0]) for r in (0, 1)]
     assert abs(load[0] - load[1]) <= 12                                     # balanced
     assert res["tot"] == [float(sum(range(11))), 2.0] and res["word"] == "hello"
+    # the seconds a rank spends inside collectives are counted (bench.py's N-rank job reports them per rank)
+    assert res["coll"]["calls"] >= 4 and res["coll"]["allreduce_calls"] == 1 and res["coll"]["seconds"] > 0.0
 
 
 def test_storage_background_writers_and_lazy_reads(tmp_path, monkeypatch):
