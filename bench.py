@@ -403,7 +403,7 @@ def _svd_kl_group(bt, kl, beam_all, ms, m0=0):
         blocks = beam_all[ms[0] - m0 : ms[-1] - m0 + 1]                 # a contiguous range of m: a view (what generate() takes)
     else:   # groups dealt round-robin (--streams > 1): gathered — the index upload waits for the stream, the copy moves the blocks
         blocks = beam_all.index_select(0, torch.as_tensor([m - m0 for m in ms], device=beam_all.device))
-    res = bt.svd_device(blocks)                                        # SVD chain + pinv, the whole group at once
+    res = bt.svd_device(blocks, ms=list(ms))                           # SVD chain + pinv, the whole group at once
     sv = res["singularvalues"].cpu().numpy()
     ctx.sync()
     t1 = time.perf_counter()

@@ -56,6 +56,9 @@ SIGNATURES = {
     "dm_svd_chain": (
         c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp,
                 ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "dm_svd_chain_lmin": (
+        c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), c_vp, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp,
+                ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "dm_project_cov": (
         c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_vp,
                 c_int, ctypes.POINTER(c_int), c_vp, ctypes.POINTER(c_i64), c_int]),
@@ -296,9 +299,11 @@ def _larr(a):
     return a, a.ctypes.data_as(ctypes.POINTER(c_i64))
 
 
-def _svd_chain(self, beam_m, noisew, polsvcut, skip_svd_inv=False, max_bytes=None):
+def _svd_chain(self, beam_m, noisew, polsvcut, skip_svd_inv=False, max_bytes=None, lmin=None):
     """beam_m: device (nblk, F, T, P, L) c128; noisew: device (F, T) f64.
     Returns dict of device tensors + host nmodes (nblk, F) + sweeps[4].
+    ``lmin`` (nblk ints, optional): block i is exactly zero in its columns l < lmin[i] (the m-block of m = lmin[i]) —
+    the chains then work on the columns l >= lmin only (dm_svd_chain_lmin); the products come back padded.
     The (m, frequency) chains are independent: when the working set of all of them (augmented matrices,
     their row-mixing temporaries, Gram / eigenvector matrices and the eigensolver's workspace) exceeds
     ``max_bytes`` (default: DRIFTMI_SVD_CHUNK_GB, 96) the frequencies go through the library in slices."""
@@ -316,6 +321,11 @@ def _svd_chain(self, beam_m, noisew, polsvcut, skip_svd_inv=False, max_bytes=Non
     fc = max(1, min(F, int(max_bytes // max(per_chain * max(nblk, 1), 1.0))))
     nmodes_all = np.zeros((nblk, F), dtype=np.int64)
     sweeps_all = [0, 0, 0, 0]
+    lm = None
+    if lmin is not None:
+        lm_keep, lm = _iarr(np.clip(np.asarray(lmin, dtype=np.int64), 0, L - 1))
+        if len(lm_keep) != nblk:
+            raise ValueError("svd_chain: one lmin per block expected")
     for f0 in range(0, F, fc):
         f1 = min(F, f0 + fc)
         whole = f0 == 0 and f1 == F
@@ -328,10 +338,10 @@ def _svd_chain(self, beam_m, noisew, polsvcut, skip_svd_inv=False, max_bytes=Non
             singularvalues=self.empty((nblk, f1 - f0, K), np.float64))
         nmodes = (c_int * max(nblk * (f1 - f0), 1))()
         sweeps = (c_int * 4)()
-        rc = self.lib.dm_svd_chain(self.h, nblk, f1 - f0, T, P, L, self.ptr(bm), self.ptr(nw), float(polsvcut),
-                                   self.ptr(o["beam_svd"]), self.ptr(o["invbeam_svd"]), self.ptr(o["beam_ut"]),
-                                   self.ptr(o["singularvalues"]), nmodes, sweeps)
-        self.check(rc, "dm_svd_chain")
+        rc = self.lib.dm_svd_chain_lmin(self.h, nblk, f1 - f0, T, P, L, lm, self.ptr(bm), self.ptr(nw), float(polsvcut),
+                                        self.ptr(o["beam_svd"]), self.ptr(o["invbeam_svd"]), self.ptr(o["beam_ut"]),
+                                        self.ptr(o["singularvalues"]), nmodes, sweeps)
+        self.check(rc, "dm_svd_chain_lmin")
         nmodes_all[:, f0:f1] = np.array(nmodes[: nblk * (f1 - f0)], dtype=np.int64).reshape(nblk, f1 - f0)
         sweeps_all = [max(a, int(b)) for a, b in zip(sweeps_all, sweeps)]
         if not whole:

@@ -285,7 +285,12 @@ class BeamTransfer(config.Reader):
         """Relative cost of one m-block through the whole path: beam-transfer generation is about the same for every m,
         the SVD chain follows the number of l >= m, the KL stage its cube (ndof falls with m)."""
         x = float(self.telescope.lmax + 1 - m) / float(self.telescope.lmax + 1)
-        return 0.15 + 0.67 * x + self.kl_cost_weight * x ** 3
+        # Round 5: the SVD chain works on the columns l >= m only and forms cross Gram blocks, so its cost falls faster
+        # with m than the linear term of rounds 3-4 said — a cubic part of its own (rows^2 x columns).  Least-squares fit of
+        # flat + linear + cubic to the kernel seconds of the eight configs[2] shares of that build
+        # (profiles/r05e_configs2_shares.json: 0.090 + 0.360 x + 0.387 x^3 seconds per block, of which 0.19 units are the
+        # KLTransform's as before).
+        return 0.15 + 0.60 * x + (0.455 + self.kl_cost_weight) * x ** 3
 
     def _my_ms(self, mlist=None):
         """m-blocks owned by this rank: ONE contiguous range with (nearly) the same summed cost on every rank
@@ -301,8 +306,9 @@ class BeamTransfer(config.Reader):
             # The SHT refinement couples the m <= mcut through the polar rings: a rank whose range starts among them
             # transforms ALL of them.  That is a cost per RANK, not per m — a few fixed-point passes
             # spread it over the rank's own blocks and move the boundaries (every rank computes the same partition).  A block
-            # transformed on the side costs about 0.3 of the flat BT-gen term of `_m_cost` (calibrated on the configs[2]
-            # shares, profiles/r04b_configs2_share*of8_generate.json: 0.035 s per block against 0.15 units = 0.14 s).
+            # transformed on the side costs about 0.39 of the flat BT-gen term of `_m_cost` (calibrated on the configs[2]
+            # shares, profiles/r04b_configs2_share*of8_generate.json: 0.035 s per block; 0.15 units are 0.09 s since the
+            # round-5 refit of `_m_cost`).
             base = costs.copy()
             for _ in range(4):
                 extra = np.zeros_like(base)
@@ -312,7 +318,7 @@ class BeamTransfer(config.Reader):
                         continue
                     side = (min(mcut, mlist[-1]) + 1 - mlist[0]) - sum(1 for m in mine if m <= mcut)
                     i0 = mine[0] - mlist[0]
-                    extra[i0 : i0 + len(mine)] = 0.3 * 0.15 * max(side, 0) / len(mine)
+                    extra[i0 : i0 + len(mine)] = 0.39 * 0.15 * max(side, 0) / len(mine)
                 costs = base + extra
         return parallel.partition_contiguous(mlist, list(costs))
 
@@ -423,14 +429,16 @@ class BeamTransfer(config.Reader):
             cache[key] = ctx.to_device(self._noisew())
         return cache[key]
 
-    def svd_device(self, beam_blocks, skip_svd_inv=False):
+    def svd_device(self, beam_blocks, skip_svd_inv=False, ms=None):
         """Run the SVD chain on a device tensor (nblk, F, 2, B, P, L); returns the dict of
-        device products (see Context.svd_chain)."""
+        device products (see Context.svd_chain).  ``ms``: the m of each block — an m-block is zero for l < m
+        (`beam_m`, beamtransfer.py:257-308), and the chains then skip those columns."""
         ctx = get_context()
         nblk, F = int(beam_blocks.shape[0]), int(beam_blocks.shape[1])
         T, P, L = self.ntel, self.telescope.num_pol_sky, self.telescope.lmax + 1
         nw = self._noisew_device()
-        return ctx.svd_chain(beam_blocks.reshape(nblk, F, T, P, L), nw, self.polsvcut, skip_svd_inv=skip_svd_inv)
+        return ctx.svd_chain(beam_blocks.reshape(nblk, F, T, P, L), nw, self.polsvcut, skip_svd_inv=skip_svd_inv,
+                             lmin=None if ms is None else [int(m) for m in ms])
 
     def _svd_batch_lists(self, ms):
         tel = self.telescope
@@ -461,7 +469,7 @@ class BeamTransfer(config.Reader):
         for batch in self._svd_batch_lists(todo):
             tok = self._stage_begin()
             blocks = self._device_beam_blocks(batch)
-            res = self.svd_device(blocks, skip_svd_inv=skip_svd_inv)
+            res = self.svd_device(blocks, skip_svd_inv=skip_svd_inv, ms=batch)
             del blocks
             sv_host = ctx.to_host(res["singularvalues"])
             self._stage_end(tok, "svd", batch)
@@ -835,7 +843,7 @@ class BeamTransferFullSVD(BeamTransfer):
     def svd_len(self):
         return min((self.telescope.lmax + 1) * self.telescope.num_pol_sky, self.ntel)
 
-    def svd_device(self, beam_blocks, skip_svd_inv=False):
+    def svd_device(self, beam_blocks, skip_svd_inv=False, ms=None):
         ctx = get_context()
         nblk, F = int(beam_blocks.shape[0]), int(beam_blocks.shape[1])
         T, P, L = self.ntel, self.telescope.num_pol_sky, self.telescope.lmax + 1
@@ -856,7 +864,7 @@ class BeamTransferTempSVD(BeamTransfer):
     ride along as passengers — then the pseudo-inverse of the full `beam_svd` as in `invbeam_m` (a second pass on
     `[beam_svd | I]` and one grouped ZGEMM with the 1/sigma^2 weights; scipy's pinv cut rtol = max(M, N) eps)."""
 
-    def svd_device(self, beam_blocks, skip_svd_inv=False):
+    def svd_device(self, beam_blocks, skip_svd_inv=False, ms=None):
         ctx = get_context()
         nblk, F = int(beam_blocks.shape[0]), int(beam_blocks.shape[1])
         T, P, L, K = self.ntel, self.telescope.num_pol_sky, self.telescope.lmax + 1, self.svd_len

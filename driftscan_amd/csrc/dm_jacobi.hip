@@ -50,6 +50,7 @@ struct jac_item {
   int g0, g1;   // Gram columns [g0, g1)  (two-sided: g0 = column origin of the Hermitian block)
   int prob;     // problem index (convergence bookkeeping)
   int q;        // slot in the Q / G buffers
+  int fa, fb;   // one-sided mode: slots of the two blocks in the "rows mutually orthogonal" flags (jac_gram)
 };
 
 __device__ __forceinline__ int item_row(const jac_item& it, int k) {
@@ -62,24 +63,52 @@ __device__ __forceinline__ int item_row(const jac_item& it, int k) {
 // ---------------------------------------------------------------------------
 // 1. Gram of a row-block pair (one-sided mode)
 // ---------------------------------------------------------------------------
+// G = X X^H of the 64 rows of a pair is Hermitian, and most of it is known before it is computed:
+//   FULL   the 10 tiles (16 x 16) on and above the diagonal, dealt 3/3/2/2 to the four waves, the lower ones mirrored —
+//          taken the first time a block is met in a sweep (`blk_ok` clear);
+//   CROSS  once both blocks have been through a pair solve in this sweep their rows are mutually orthogonal to the inner
+//          solver's tolerance — the two diagonal 32 x 32 blocks of G are diagonal matrices, the squared row norms
+//          (recomputed from the rows: fp64 sums on the vector ALU while the tiles are staged) — and only the 32 x 32
+//          block A B^H is formed: one tile per wave, a quarter of the matrix-core work of a full Gram.
+// `blk_ok[fa]`, `blk_ok[fb]`: set by jac_inner when it has solved (or found solved) a pair holding the block; cleared by
+// the driver at the start of every sweep, so each block's own Gram is re-measured from the rows once per sweep.
+__device__ __constant__ unsigned char JG_TI[4][3] = {{0, 0, 0}, {0, 1, 1}, {1, 2, 0}, {2, 3, 0}};
+__device__ __constant__ unsigned char JG_TJ[4][3] = {{0, 1, 2}, {3, 1, 2}, {3, 2, 0}, {3, 3, 0}};
+__device__ __constant__ unsigned char JG_NT[4] = {3, 3, 2, 2};
+
 __global__ __launch_bounds__(256) void jac_gram_kernel(const jac_item* __restrict__ items,
                                                        const int* __restrict__ active, cplx* __restrict__ Gbuf,
+                                                       const int* __restrict__ blk_ok, int allow_cross,
                                                        unsigned long long* __restrict__ flopctr) {
   __shared__ double Xre[JP * XP], Xim[JP * XP];
+  __shared__ double nrm2[JP];
   const jac_item it = items[blockIdx.x];
   if (!active[it.prob]) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fi = lane & 15, fk = lane >> 4;
+  const bool cross = allow_cross && it.nb > 0 && blk_ok[it.fa] && blk_ok[it.fb];   // uniform over the workgroup
   if (flopctr && tid == 0) {
-    const unsigned long long nr = it.na + it.nb;
-    atomicAdd(flopctr, 8ull * nr * nr * (unsigned long long)(it.g1 - it.g0));
+    const unsigned long long kk = (unsigned long long)(it.g1 - it.g0), nr = it.na + it.nb;
+    // algorithmic flops: the Hermitian Gram on and above the diagonal, or the cross block plus the row norms
+    atomicAdd(flopctr, cross ? (8ull * it.na * it.nb + 4ull * nr) * kk : 4ull * nr * (nr + 1ull) * kk);
   }
 
-  dm_f64x4 gre[4], gim[4];
+  // tiles of this wave
+  int nt, ti[3], tj[3];
+  if (cross) {
+    nt = 1;
+    ti[0] = wave >> 1; tj[0] = 2 + (wave & 1);
+    ti[1] = ti[2] = tj[1] = tj[2] = 0;
+  } else {
+    nt = JG_NT[wave];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    gre[j] = dm_f64x4{0, 0, 0, 0};
-    gim[j] = dm_f64x4{0, 0, 0, 0};
+    for (int t = 0; t < 3; ++t) { ti[t] = JG_TI[wave][t]; tj[t] = JG_TJ[wave][t]; }
+  }
+  dm_f64x4 gre[3], gim[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    gre[t] = dm_f64x4{0, 0, 0, 0};
+    gim[t] = dm_f64x4{0, 0, 0, 0};
   }
 
   // staging map: 64 rows x 16 cols, k fastest (each row segment = 256 contiguous bytes)
@@ -92,6 +121,7 @@ __global__ __launch_bounds__(256) void jac_gram_kernel(const jac_item* __restric
     grow[i] = item_row(it, srow[i]);
   }
   cplx r[4];
+  double nacc[4] = {0.0, 0.0, 0.0, 0.0};
   auto load = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -107,34 +137,65 @@ __global__ __launch_bounds__(256) void jac_gram_kernel(const jac_item* __restric
     for (int i = 0; i < 4; ++i) {
       Xre[srow[i] * XP + scol[i]] = r[i].x;
       Xim[srow[i] * XP + scol[i]] = r[i].y;
+      nacc[i] = fma(r[i].x, r[i].x, fma(r[i].y, r[i].y, nacc[i]));
     }
     __syncthreads();
     if (kt + 1 < nk) load((kt + 1) * 16);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      int ra = (wave * 16 + fi) * XP + kk * 4 + fk;
-      double a_re = Xre[ra], a_im = Xim[ra], a_ren = -a_re;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int rb = (j * 16 + fi) * XP + kk * 4 + fk;
-        double x_re = Xre[rb], x_im = Xim[rb];
-        // G[i][j] += a_i * conj(x_j)
-        gre[j] = dm_mfma(a_re, x_re, gre[j]);
-        gre[j] = dm_mfma(a_im, x_im, gre[j]);
-        gim[j] = dm_mfma(a_im, x_re, gim[j]);
-        gim[j] = dm_mfma(a_ren, x_im, gim[j]);
+      for (int t = 0; t < 3; ++t) {
+        if (t < nt) {   // wave-uniform
+          const int ra = (ti[t] * 16 + fi) * XP + kk * 4 + fk;
+          const int rb = (tj[t] * 16 + fi) * XP + kk * 4 + fk;
+          const double a_re = Xre[ra], a_im = Xim[ra];
+          const double x_re = Xre[rb], x_im = Xim[rb];
+          // G[i][j] += a_i * conj(x_j)
+          gre[t] = dm_mfma(a_re, x_re, gre[t]);
+          gre[t] = dm_mfma(a_im, x_im, gre[t]);
+          gim[t] = dm_mfma(a_im, x_re, gim[t]);
+          gim[t] = dm_mfma(-a_re, x_im, gim[t]);
+        }
       }
     }
   }
   cplx* G = Gbuf + (size_t)it.q * JP * JP;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int t = 0; t < 3; ++t) {
+    if (t < nt) {
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      int row = wave * 16 + (lane >> 4) + 4 * rr;
-      int col = j * 16 + (lane & 15);
-      G[row * JP + col] = make_double2(gre[j][rr], gim[j][rr]);
+      for (int rr = 0; rr < 4; ++rr) {
+        const int row = ti[t] * 16 + (lane >> 4) + 4 * rr;
+        const int col = tj[t] * 16 + (lane & 15);
+        const cplx v = make_double2(gre[t][rr], gim[t][rr]);
+        if (ti[t] != tj[t]) {
+          G[row * JP + col] = v;
+          G[col * JP + row] = make_double2(v.x, -v.y);
+        } else if (row <= col) {   // diagonal tile: the upper part and its mirror (one writer per entry)
+          G[row * JP + col] = row == col ? make_double2(v.x, 0.0) : v;
+          if (row != col) G[col * JP + row] = make_double2(v.x, -v.y);
+        }
+      }
     }
+  }
+  if (cross) {
+    // the two diagonal 32 x 32 blocks: squared row norms on the diagonal, zero elsewhere
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      double v = nacc[i];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      if (scol[i] == 0) nrm2[srow[i]] = v;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < JP * JP / 2; idx += 256) {
+      const int blk = idx >> 10, rr = (idx >> 5) & 31, cc = idx & 31;   // 2 blocks x 32 x 32
+      const int row = blk * 32 + rr, col = blk * 32 + cc;
+      G[row * JP + col] = make_double2(rr == cc ? nrm2[row] : 0.0, 0.0);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -150,7 +211,8 @@ __global__ __launch_bounds__(JNT) void jac_inner_kernel(const jac_item* __restri
                                                         const cplx* __restrict__ Gbuf, cplx* __restrict__ Qbuf,
                                                         unsigned long long* __restrict__ offmax,
                                                         int* __restrict__ skip, double tol_outer,
-                                                        double tol_inner, int measure_only) {
+                                                        double tol_inner, int measure_only,
+                                                        int* __restrict__ blk_ok) {
   extern __shared__ __align__(16) unsigned char smem[];
   cplx* G = reinterpret_cast<cplx*>(smem);
   cplx* Q = G + JP * GP;
@@ -215,6 +277,12 @@ __global__ __launch_bounds__(JNT) void jac_inner_kernel(const jac_item* __restri
   if (tid == 0) {
     atomicMax(&offmax[it.prob], (unsigned long long)__double_as_longlong(mo));
     skip[it.q] = (mo <= tol_outer || measure_only) ? 1 : 0;
+    if (!HERM && blk_ok && !measure_only) {
+      // whether the pair is solved below or was found orthogonal already: after this item the rows of each of its
+      // blocks are mutually orthogonal to tolerance (what jac_gram's CROSS mode relies on)
+      blk_ok[it.fa] = 1;
+      if (it.nb > 0) blk_ok[it.fb] = 1;
+    }
   }
   if (mo <= tol_outer || measure_only) return;  // uniform across the block
 
@@ -706,6 +774,9 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
 
   round_plan plan;
   std::vector<int> nrows_eff(nrows);  // rows that take part in the sweeps (all of them unless drop_below cuts the tail)
+  // one "rows mutually orthogonal" flag per 32-row block of every problem (jac_gram's CROSS mode)
+  std::vector<int> flag0(np + 1, 0);
+  for (int p = 0; p < np; ++p) flag0[p + 1] = flag0[p] + (nrows[p] + JB - 1) / JB;
   auto build_plan = [&]() {
     plan_rounds(nrows_eff, [&](int p, int ba, int bb, int slot) {
       const dm_jac_problem& P = probs[p];
@@ -716,6 +787,7 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
       else { it.rb = 0; it.nb = 0; }
       it.c0 = 0; it.c1 = P.ncols; it.g0 = P.gc0; it.g1 = P.gc1;
       it.prob = p; it.q = slot;
+      it.fa = flag0[p] + ba; it.fb = bb >= 0 ? flag0[p] + bb : it.fa;
       return it;
     }, plan);
   };
@@ -746,9 +818,14 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
   double* d_key = dm_ws_alloc_t<double>(ctx, (size_t)np * sigma_stride);
   cplx* d_tmp = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(ttot, 1));
   double* d_floor = dm_ws_alloc_t<double>(ctx, np);
+  const size_t nflags = (size_t)std::max(flag0[np], 1);
+  int* d_ok = dm_ws_alloc_t<int>(ctx, nflags);
   if (!d_items || !d_pd || !d_nrows || !d_toff || !d_active || !d_off || !d_G || !d_Q || !d_skip || !d_rank ||
-      !d_key || !d_tmp || !d_floor)
+      !d_key || !d_tmp || !d_floor || !d_ok)
     return DM_ENOMEM;
+  // DM_JAC_CROSS=0: every pair Gram in full (upper tiles), as before round 5
+  static const int allow_cross = getenv("DM_JAC_CROSS") ? atoi(getenv("DM_JAC_CROSS")) : 1;
+  DM_HIP(ctx, hipMemsetAsync(d_ok, 0, sizeof(int) * nflags, ctx->stream));
 
   // noise floor for Gram entries: (4 eps)^2 * (largest row norm)^2.  Rows that are pure
   // rounding residue (rank-deficient inputs) can never be made mutually orthogonal to
@@ -782,9 +859,9 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
       const int nb = plan.round_begin[r], ni = plan.round_begin[r + 1] - nb;
       if (ni == 0) continue;
       hipLaunchKernelGGL(jac_gram_kernel, dim3(ni), dim3(256), 0, ctx->stream, d_items + nb, d_active, d_G,
-                         (unsigned long long*)nullptr);
+                         (const int*)d_ok, 0, (unsigned long long*)nullptr);
       hipLaunchKernelGGL(jac_inner_kernel<false>, dim3(ni), dim3(JNT), INNER_LDS, ctx->stream, d_items + nb, d_active,
-                         (const double*)d_floor, d_G, d_Q, d_off, d_skip, tol_outer, tol_inner, 1);
+                         (const double*)d_floor, d_G, d_Q, d_off, d_skip, tol_outer, tol_inner, 1, (int*)nullptr);
     }
     DM_HIP(ctx, hipGetLastError());
     DM_TRY(dm_download(ctx, h_off.data(), d_off, sizeof(unsigned long long) * np));
@@ -999,6 +1076,8 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
   for (int p = 0; p < np; ++p) any_pairs |= active[p] != 0;
   for (; any_pairs && sweep < max_sweeps; ++sweep) {
     DM_HIP(ctx, hipMemsetAsync(d_off, 0, sizeof(unsigned long long) * np, ctx->stream));
+    // every block's own Gram is measured from its rows the first time the block is met in a sweep
+    DM_HIP(ctx, hipMemsetAsync(d_ok, 0, sizeof(int) * nflags, ctx->stream));
     for (int r = 0; r < nrounds; ++r) {
       const int nb = plan.round_begin[r], ne = plan.round_begin[r + 1];
       const int ni = ne - nb;
@@ -1007,12 +1086,12 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
       {
         dm_prof_scope ps(ctx, DM_PROF_JAC_GRAM, 0.0);
         hipLaunchKernelGGL(jac_gram_kernel, dim3(ni), dim3(256), 0, ctx->stream, d_items + nb, d_active, d_G,
-                           fc ? fc + DM_PROF_JAC_GRAM : nullptr);
+                           (const int*)d_ok, allow_cross, fc ? fc + DM_PROF_JAC_GRAM : nullptr);
       }
       {
         dm_prof_scope ps(ctx, DM_PROF_JAC_INNER, 0.0);
         hipLaunchKernelGGL(jac_inner_kernel<false>, dim3(ni), dim3(JNT), INNER_LDS, ctx->stream, d_items + nb,
-                           d_active, (const double*)d_floor, d_G, d_Q, d_off, d_skip, tol_outer, tol_inner, 0);
+                           d_active, (const double*)d_floor, d_G, d_Q, d_off, d_skip, tol_outer, tol_inner, 0, d_ok);
       }
       {
         dm_prof_scope ps(ctx, DM_PROF_JAC_APPLY, 0.0);
@@ -1106,6 +1185,7 @@ int dm_jacobi_herm(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, d
       if (bb >= 0) { it.rb = bb * JB; it.nb = std::min(JB, P.n - bb * JB); } else { it.rb = 0; it.nb = 0; }
       it.c0 = 0; it.c1 = P.n; it.g0 = 0; it.g1 = P.n;
       it.prob = p; it.q = slot;
+      it.fa = it.fb = 0;
       return it;
     };
   };
@@ -1161,7 +1241,7 @@ int dm_jacobi_herm(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, d
       {
         dm_prof_scope ps(ctx, DM_PROF_JAC_INNER, 0.0);
         hipLaunchKernelGGL(jac_inner_kernel<true>, dim3(ni), dim3(JNT), INNER_LDS, ctx->stream, icur, d_active,
-                           d_floor, (const cplx*)nullptr, d_Q, d_off, d_skip, tol_outer, tol_inner, 0);
+                           d_floor, (const cplx*)nullptr, d_Q, d_off, d_skip, tol_outer, tol_inner, 0, (int*)nullptr);
       }
       {
         dm_prof_scope ps(ctx, DM_PROF_JAC_APPLY, 0.0);

@@ -33,41 +33,58 @@
 
 namespace {
 
-// Z[c] = [ nw[f] .* beam[c] | I ]
+// Per-chain geometry of the augmented matrices.  The blocks of an m carry exact zeros in the columns l < m (beam_m is
+// stored with l padded from 0, beamtransfer.py:257-308): those columns add nothing to any inner product and stay zero
+// under any row mixing, so a chain works on the COMPACT sky columns (p, l >= lmin) only — Lc = L - lmin per
+// polarisation — and the products are scattered back into the padded layout at the end.
+struct svd_geom {
+  size_t zoff;   // element offset of the chain's Z (T rows x ldz)
+  int lmin;      // first l kept
+  int Lc;        // L - lmin
+  int ldz;       // P * Lc + T
+};
+
+// Z[c] = [ nw[f] .* beam[c][:, (p, l >= lmin)] | I ]
 __global__ void svd_build_z_kernel(const cplx* __restrict__ beam, const double* __restrict__ noisew,
-                                   cplx* __restrict__ Z, int F, int T, int PL, int ldz) {
+                                   cplx* __restrict__ Z, const svd_geom* __restrict__ geo, int F, int T, int P, int L) {
   const int c = blockIdx.z;        // chain = blk * F + f
   const int f = c % F;
+  const svd_geom g = geo[c];
   const int row = blockIdx.y;
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= ldz) return;
+  if (col >= g.ldz) return;
+  const int PLc = P * g.Lc;
   cplx v;
-  if (col < PL) {
+  if (col < PLc) {
+    const int p = col / g.Lc, l = g.lmin + (col - p * g.Lc);
     const double w = noisew[(size_t)f * T + row];
-    cplx b = beam[((size_t)c * T + row) * PL + col];
+    cplx b = beam[((size_t)c * T + row) * ((size_t)P * L) + (size_t)p * L + l];
     v = make_double2(b.x * w, b.y * w);
   } else {
-    v = make_double2((col - PL) == row ? 1.0 : 0.0, 0.0);
+    v = make_double2((col - PLc) == row ? 1.0 : 0.0, 0.0);
   }
-  Z[((size_t)c * T + row) * ldz + col] = v;
+  Z[g.zoff + (size_t)row * g.ldz + col] = v;
 }
 
 // scatter the surviving rows into the (zero-initialised) output products
-__global__ void svd_extract_kernel(const cplx* __restrict__ Z, const int* __restrict__ row0,
-                                   const int* __restrict__ nmodes, const double* __restrict__ noisew,
-                                   const double* __restrict__ sig3, cplx* __restrict__ beam_svd,
-                                   cplx* __restrict__ beam_ut, double* __restrict__ sigma, int F, int T, int PL, int K,
-                                   int ldz) {
+__global__ void svd_extract_kernel(const cplx* __restrict__ Z, const svd_geom* __restrict__ geo,
+                                   const int* __restrict__ row0, const int* __restrict__ nmodes,
+                                   const double* __restrict__ noisew, const double* __restrict__ sig3,
+                                   cplx* __restrict__ beam_svd, cplx* __restrict__ beam_ut, double* __restrict__ sigma,
+                                   int F, int T, int P, int L, int K) {
   const int c = blockIdx.z;
   const int f = c % F;
   const int i = blockIdx.y;  // mode index
   if (i >= nmodes[c]) return;
+  const svd_geom g = geo[c];
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  const cplx* z = Z + ((size_t)c * T + row0[c] + i) * ldz;
-  if (col < PL) {
-    beam_svd[((size_t)c * K + i) * PL + col] = z[col];
-  } else if (col < PL + T) {
-    const int t = col - PL;
+  const int PLc = P * g.Lc;
+  const cplx* z = Z + g.zoff + (size_t)(row0[c] + i) * g.ldz;
+  if (col < PLc) {
+    const int p = col / g.Lc, l = g.lmin + (col - p * g.Lc);   // the columns l < lmin of the (zero-filled) output stay zero
+    beam_svd[((size_t)c * K + i) * ((size_t)P * L) + (size_t)p * L + l] = z[col];
+  } else if (col < PLc + T) {
+    const int t = col - PLc;
     const double w = noisew[(size_t)f * T + t];
     cplx u = z[col];
     beam_ut[((size_t)c * K + i) * T + t] = make_double2(u.x * w, u.y * w);
@@ -75,18 +92,24 @@ __global__ void svd_extract_kernel(const cplx* __restrict__ Z, const int* __rest
   if (col == 0) sigma[(size_t)c * K + i] = sig3[(size_t)c * T + i];
 }
 
-// Z2[c] = [ beam_svd[c][:nm] | I_nm ]   (K rows allocated per chain)
+// Z2[c] = [ beam_svd[c][:nm][:, (p, l >= lmin)] | I_nm ]   (geo2: K rows allocated per chain, ld2 = P * Lc + K)
 __global__ void svd_build_pinv_kernel(const cplx* __restrict__ beam_svd, const int* __restrict__ nmodes,
-                                      cplx* __restrict__ Z2, int K, int PL, int ld2) {
+                                      cplx* __restrict__ Z2, const svd_geom* __restrict__ geo2, int K, int P, int L) {
   const int c = blockIdx.z;
   const int i = blockIdx.y;
   if (i >= nmodes[c]) return;
+  const svd_geom g = geo2[c];
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= ld2) return;
+  if (col >= g.ldz) return;
+  const int PLc = P * g.Lc;
   cplx v;
-  if (col < PL) v = beam_svd[((size_t)c * K + i) * PL + col];
-  else v = make_double2((col - PL) == i ? 1.0 : 0.0, 0.0);
-  Z2[((size_t)c * K + i) * ld2 + col] = v;
+  if (col < PLc) {
+    const int p = col / g.Lc, l = g.lmin + (col - p * g.Lc);
+    v = beam_svd[((size_t)c * K + i) * ((size_t)P * L) + (size_t)p * L + l];
+  } else {
+    v = make_double2((col - PLc) == i ? 1.0 : 0.0, 0.0);
+  }
+  Z2[g.zoff + (size_t)i * g.ldz + col] = v;
 }
 
 // w[c][i] = 1/s^2 if s > rtol * s_max else 0   (scipy.linalg.pinv: rtol = max(M,N) eps)
@@ -106,6 +129,14 @@ __global__ void svd_pinv_weights_kernel(const double* __restrict__ s4, const int
 extern "C" int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, const void* beam_m_dev,
                             const double* noisew_dev, double polsvcut, void* beam_svd_dev, void* invbeam_svd_dev,
                             void* beam_ut_dev, double* sigma_dev, int* nmodes_host, int* sweeps_host) {
+  return dm_svd_chain_lmin(ctx, nblk, F, T, P, L, nullptr, beam_m_dev, noisew_dev, polsvcut, beam_svd_dev,
+                           invbeam_svd_dev, beam_ut_dev, sigma_dev, nmodes_host, sweeps_host);
+}
+
+extern "C" int dm_svd_chain_lmin(dm_ctx* ctx, int nblk, int F, int T, int P, int L, const int* lmin_host,
+                                 const void* beam_m_dev, const double* noisew_dev, double polsvcut,
+                                 void* beam_svd_dev, void* invbeam_svd_dev, void* beam_ut_dev, double* sigma_dev,
+                                 int* nmodes_host, int* sweeps_host) {
   if (!ctx) return DM_EARG;
   DM_ARG(ctx, nblk >= 0 && F > 0 && T > 0 && P > 0 && L > 0 && beam_m_dev && noisew_dev && beam_svd_dev &&
                   beam_ut_dev && sigma_dev && nmodes_host);
@@ -114,20 +145,36 @@ extern "C" int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, c
   if (nch == 0) return DM_OK;
   const int PL = P * L;
   const int K = std::min(L, T);
-  const int ldz = PL + T;
+  if (lmin_host)
+    for (int b = 0; b < nblk; ++b) DM_ARG(ctx, lmin_host[b] >= 0 && lmin_host[b] < L);
   dm_ws_scope ws_scope__(ctx);  // releases on every return path
   const size_t mark = ws_scope__.mark;
+  // geometry: chain c = blk * F + f works on the columns l >= lmin[blk] of every polarisation
+  static const bool no_compact = getenv("DM_SVD_NO_COMPACT") != nullptr;
+  std::vector<svd_geom> geo(nch);
+  size_t ztot = 0;
+  int ldz_max = 0;
+  for (int c = 0; c < nch; ++c) {
+    const int lm = (lmin_host && !no_compact) ? lmin_host[c / F] : 0;
+    geo[c].zoff = ztot;
+    geo[c].lmin = lm;
+    geo[c].Lc = L - lm;
+    geo[c].ldz = P * (L - lm) + T;
+    ztot += (size_t)T * geo[c].ldz;
+    ldz_max = std::max(ldz_max, geo[c].ldz);
+  }
 
   const cplx* beam = reinterpret_cast<const cplx*>(beam_m_dev);
   cplx* beam_svd = reinterpret_cast<cplx*>(beam_svd_dev);
   cplx* beam_ut = reinterpret_cast<cplx*>(beam_ut_dev);
   cplx* ibeam = reinterpret_cast<cplx*>(invbeam_svd_dev);
 
-  cplx* Z = dm_ws_alloc_t<cplx>(ctx, (size_t)nch * T * ldz);
+  cplx* Z = dm_ws_alloc_t<cplx>(ctx, ztot);
   double* sig = dm_ws_alloc_t<double>(ctx, (size_t)nch * T);
-  if (!Z || !sig) return DM_ENOMEM;
-  DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, svd_build_z_kernel, dim3((ldz + 255) / 256, T, nch), dim3(256), 0, ctx->stream, beam,
-                     noisew_dev, Z, F, T, PL, ldz);
+  svd_geom* d_geo = dm_ws_upload(ctx, geo);
+  if (!Z || !sig || !d_geo) return DM_ENOMEM;
+  DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, svd_build_z_kernel, dim3((ldz_max + 255) / 256, T, nch), dim3(256), 0, ctx->stream, beam,
+                     noisew_dev, Z, d_geo, F, T, P, L);
   DM_HIP(ctx, hipGetLastError());
 
   std::vector<double> hs((size_t)nch * T);
@@ -137,7 +184,8 @@ extern "C" int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, c
   if (P > 1) {
     // ---- phase 1: SVD1, image with rtol 1e-10 (beamtransfer.py:826, :98)
     std::vector<dm_jac_problem> pr(nch);
-    for (int c = 0; c < nch; ++c) pr[c] = dm_jac_problem{Z + (size_t)c * T * ldz, ldz, 0, T, ldz, 0, PL};
+    for (int c = 0; c < nch; ++c)
+      pr[c] = dm_jac_problem{Z + geo[c].zoff, geo[c].ldz, 0, T, geo[c].ldz, 0, P * geo[c].Lc};
     // SVD1 keeps s > 1e-10 s_0 (beamtransfer.py:826): rows two decades further down are left out of the sweeps
     dm_jac_rows_opts o1;
     o1.unconverged = true;
@@ -167,7 +215,8 @@ extern "C" int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, c
       fprintf(stderr, "\n");
     }
     // ---- phase 2: SVD2, left null space of the polarised columns, `>=` cut (:844-848, :137)
-    for (int c = 0; c < nch; ++c) pr[c] = dm_jac_problem{Z + (size_t)c * T * ldz, ldz, 0, r1[c], ldz, L, PL};
+    for (int c = 0; c < nch; ++c)
+      pr[c] = dm_jac_problem{Z + geo[c].zoff, geo[c].ldz, 0, r1[c], geo[c].ldz, geo[c].Lc, P * geo[c].Lc};
     dm_jac_rows_opts o2;
     o2.unconverged = true;
     DM_TRY(dm_jacobi_rows(ctx, pr, sig, T, &sw, &o2));
@@ -191,7 +240,7 @@ extern "C" int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, c
     for (int c = 0; c < nch; ++c) {
       row0[c] = cut2[c];
       nrow3[c] = alive[c] ? std::max(0, r1[c] - cut2[c]) : 0;
-      pr[c] = dm_jac_problem{Z + (size_t)c * T * ldz, ldz, row0[c], nrow3[c], ldz, 0, L};
+      pr[c] = dm_jac_problem{Z + geo[c].zoff, geo[c].ldz, row0[c], nrow3[c], geo[c].ldz, 0, geo[c].Lc};
     }
     // polarised: certainly not orthogonal yet.  Unpolarised: the measuring pass is kept, it retires the
     // all-zero and trivially orthogonal blocks of the high m (a fifth of config 2) before the eigensolver.
@@ -224,8 +273,8 @@ extern "C" int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, c
   DM_TRY(dm_fill_zero(ctx, beam_ut, sizeof(cplx) * (size_t)nch * K * T));
   DM_TRY(dm_fill_zero(ctx, sigma_dev, sizeof(double) * (size_t)nch * K));
   if (maxnm > 0) {
-    DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, svd_extract_kernel, dim3((ldz + 255) / 256, maxnm, nch), dim3(256), 0, ctx->stream, Z, d_row0,
-                       d_nm, noisew_dev, sig, beam_svd, beam_ut, sigma_dev, F, T, PL, K, ldz);
+    DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, svd_extract_kernel, dim3((ldz_max + 255) / 256, maxnm, nch), dim3(256), 0, ctx->stream, Z, d_geo,
+                       d_row0, d_nm, noisew_dev, sig, beam_svd, beam_ut, sigma_dev, F, T, P, L, K);
     DM_HIP(ctx, hipGetLastError());
   }
 
@@ -233,23 +282,35 @@ extern "C" int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, c
   if (ibeam) {
     DM_TRY(dm_fill_zero(ctx, ibeam, sizeof(cplx) * (size_t)nch * PL * K));
     if (maxnm > 0) {
-      const int ld2 = PL + K;
+      // [beam | I] per chain: K rows of P * Lc + K columns
+      std::vector<svd_geom> geo2(nch);
+      size_t z2tot = 0;
+      int ld2_max = 0;
+      for (int c = 0; c < nch; ++c) {
+        geo2[c] = geo[c];
+        geo2[c].zoff = z2tot;
+        geo2[c].ldz = P * geo[c].Lc + K;
+        z2tot += (size_t)K * geo2[c].ldz;
+        ld2_max = std::max(ld2_max, geo2[c].ldz);
+      }
       // Z is no longer needed: reuse its storage when it is large enough
-      cplx* Z2 = ((size_t)K * ld2 <= (size_t)T * ldz) ? Z : dm_ws_alloc_t<cplx>(ctx, (size_t)nch * K * ld2);
+      cplx* Z2 = (z2tot <= ztot) ? Z : dm_ws_alloc_t<cplx>(ctx, z2tot);
       double* s4 = dm_ws_alloc_t<double>(ctx, (size_t)nch * K);
       double* w4 = dm_ws_alloc_t<double>(ctx, (size_t)nch * K);
-      if (!Z2 || !s4 || !w4) return DM_ENOMEM;
-      DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, svd_build_pinv_kernel, dim3((ld2 + 255) / 256, maxnm, nch), dim3(256), 0, ctx->stream,
-                         beam_svd, d_nm, Z2, K, PL, ld2);
+      svd_geom* d_geo2 = dm_ws_upload(ctx, geo2);
+      if (!Z2 || !s4 || !w4 || !d_geo2) return DM_ENOMEM;
+      DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, svd_build_pinv_kernel, dim3((ld2_max + 255) / 256, maxnm, nch), dim3(256), 0, ctx->stream,
+                         beam_svd, d_nm, Z2, d_geo2, K, P, L);
       std::vector<dm_jac_problem> pr(nch);
       for (int c = 0; c < nch; ++c)
-        pr[c] = dm_jac_problem{Z2 + (size_t)c * K * ld2, ld2, 0, nmodes[c], PL + nmodes[c], 0, PL};
+        pr[c] = dm_jac_problem{Z2 + geo2[c].zoff, geo2[c].ldz, 0, nmodes[c], P * geo[c].Lc + nmodes[c], 0, P * geo[c].Lc};
       // unpolarised: these are exactly the rows SVD3 left orthogonal over the same columns (the measuring pass
       // sees that and skips everything); polarised: orthogonal over the T columns only
       dm_jac_rows_opts o4;
       o4.unconverged = P > 1;
       DM_TRY(dm_jacobi_rows(ctx, pr, s4, K, &sw, &o4));
       if (sweeps_host) sweeps_host[3] = sw;
+      // scipy.linalg.pinv: rtol = max(M, N) eps of the matrix it is GIVEN — the padded (nm x P L) beam (beamtransfer.py:891)
       const double rtol = (double)std::max(PL, maxnm) * 2.220446049250313e-16;
       DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, svd_pinv_weights_kernel, dim3(nch), dim3(256), 0, ctx->stream, s4, d_nm, w4, K, rtol);
       std::vector<dm_gemm_desc> g;
@@ -257,11 +318,15 @@ extern "C" int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, c
       for (int c = 0; c < nch; ++c) {
         const int nm = nmodes[c];
         if (nm == 0) continue;
-        const cplx* Y = Z2 + (size_t)c * K * ld2;           // (nm x PL): rows = s_k v_k^H
-        const cplx* W = Y + PL;                              // (nm x nm): rows of U_b^H
-        // ibeam (PL x nm) = Y^H diag(w) W ; destination is (P, L, K) with K the fastest axis
-        g.push_back(dm_gemm_make(Y, 1, ld2, true, W, ld2, 1, false, ibeam + (size_t)c * PL * K, K, PL, nm, nm, 1.0,
-                                 0.0, w4 + (size_t)c * K));
+        const int ld2 = geo2[c].ldz, Lc = geo[c].Lc;
+        const cplx* Y = Z2 + geo2[c].zoff;                   // (nm x P Lc): rows = s_k v_k^H
+        const cplx* W = Y + P * Lc;                          // (nm x nm): rows of U_b^H
+        // ibeam (PL x nm) = Y^H diag(w) W ; destination is (P, L, K) with K the fastest axis: one product per
+        // polarisation, into the rows l >= lmin of the (zero-filled) output
+        for (int pp = 0; pp < P; ++pp)
+          g.push_back(dm_gemm_make(Y + (size_t)pp * Lc, 1, ld2, true, W, ld2, 1, false,
+                                   ibeam + (size_t)c * PL * K + ((size_t)pp * L + geo[c].lmin) * K, K, Lc, nm, nm, 1.0,
+                                   0.0, w4 + (size_t)c * K));
       }
       DM_TRY(dm_gemm_grouped_launch(ctx, g));
     }

@@ -147,6 +147,16 @@ int dm_herm_eig_batched(dm_ctx* ctx, int n, void* C_dev, int ldc, int64_t stride
 int dm_svd_chain(dm_ctx* ctx, int nblk, int F, int T, int P, int L, const void* beam_m_dev,
                  const double* noisew_dev, double polsvcut, void* beam_svd_dev, void* invbeam_svd_dev,
                  void* beam_ut_dev, double* sigma_dev, int* nmodes_host, int* sweeps_host);
+/* The same chain for blocks whose columns l < lmin_host[blk] are exactly zero — block blk = the m-block of
+ * m = lmin_host[blk], as `BeamTransfer.beam_m` returns it (beamtransfer.py:257-308: l padded from 0).  Zero columns add
+ * nothing to an inner product and stay zero under row mixing, so every chain of block blk works on the
+ * P * (L - lmin) columns that can be non-zero; products come back in the padded layout, zero for l < lmin.
+ *   lmin_host    (nblk) int, 0 <= lmin < L; NULL = all zero (dm_svd_chain)
+ * The caller guarantees the zeros (a non-zero entry at l < lmin would be dropped).  Same products as dm_svd_chain up to
+ * the order of floating-point sums.  Replaces the same reference lines. */
+int dm_svd_chain_lmin(dm_ctx* ctx, int nblk, int F, int T, int P, int L, const int* lmin_host,
+                      const void* beam_m_dev, const double* noisew_dev, double polsvcut, void* beam_svd_dev,
+                      void* invbeam_svd_dev, void* beam_ut_dev, double* sigma_dev, int* nmodes_host, int* sweeps_host);
 
 /* ---- KL: covariance projection and generalised eigenproblem ---------------- */
 /* Project a sky covariance into the SVD basis for nblk m-blocks.

@@ -355,7 +355,9 @@ def test_m_ranges_account_for_the_sht_coupling(tmp_path):
             parts[it] = got
     finally:
         parallel.set_virtual(None)
-    assert len(parts[3][0]) < len(parts[0][0]) and len(parts[3][-1]) > len(parts[0][-1])
+    # the ranks that start among the coupled m give blocks away (none of them gains any), the last rank takes more
+    assert all(len(a) <= len(b) for a, b in zip(parts[3][:3], parts[0][:3]))
+    assert sum(len(p) for p in parts[3][:3]) < sum(len(p) for p in parts[0][:3]) and len(parts[3][-1]) > len(parts[0][-1])
 
 
 def test_rebalance_contiguous_levels_measured_times():
