@@ -40,7 +40,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 CFG2 = dict(num_freq=16, freq_start=400.0, freq_end=450.0, freq_mode="edge", num_cylinders=2, cylinder_width=5.0,
-            num_feeds=16, feed_spacing=0.4, tsys=1.0, force_lmax=128, force_mmax=128)
+            num_feeds=16, feed_spacing=0.4, tsys=1.0, force_lmax=128, force_mmax=128,
+            sht_iter=3)   # healpy's documented default, stated explicitly: the measured configuration does not move with the library's default
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (AMD datasheet)
 HBM_PEAK_GBS = 8000.0         # HBM3E spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 achievable)
 HBM_CLASSES = ("trd_symv", "trd_wx")
@@ -191,6 +192,9 @@ def _cpu_one_block(job):
     t0 = time.perf_counter()
     o = osvd.svd_m(blk, noisew, polsvcut=polsvcut)
     t1 = time.perf_counter()
+    if int(osvd.svd_num(o["singularvalues"], svcut)[0].sum()) == 0:
+        # no mode above svcut (an m beyond the telescope's band limit): the reference's `nside == 0` early-out, kltransform.py:324-326
+        return t1 - t0, 0.0, 0, np.asarray(o["singularvalues"]), np.zeros(0), np.zeros((0, 0), dtype=np.complex128)
     cs, cn = okl.sn_covariance(o["beam_svd"], o["beam_ut"], o["singularvalues"], cv_sg, cv_fg, npw, svcut=svcut)
     ev = okl.kl_transform_m(cs, cn)[0]
     t2 = time.perf_counter()
@@ -212,26 +216,32 @@ def _cpu_worker(wid, tasks, results, shared):
 
     jobs, common, desc0 = shared
     stash = {}
-    while True:
-        t = tasks.get()
-        if t is None:
-            break
-        if t[0] == "block":
-            m = t[1]
-            ts, tk, ndof, sv, ev, cn = _cpu_one_block((jobs[m],) + common)
-            stash[m] = cn
-            results.put(("block", m, ts, tk, ndof, sv, ev))
-        else:   # ("bt", fi, b0, b1): the (f, b) columns of one frequency and a range of baselines, all m
-            desc = dict(desc0, included_freq=np.array([t[1]]), included_baseline=np.arange(t[2], t[3]))
-            results.put(("bt", t[1], t[2], t[3], _cpu_bt_columns(desc)))
-    results.put(("dry", wid, time.perf_counter()))
-    for m, cn in stash.items():
-        tol = 1e-10
-        if cn.shape[0]:
-            w = np.linalg.eigvalsh(0.5 * (cn + cn.conj().T))
-            tol = max(1e-10, 50.0 * 2.220446049250313e-16 * abs(w[-1]) / max(abs(w[0]), 1e-300))   # tests/parity_util.pencil_tol
-        results.put(("tol", m, tol))
-    results.put(("end", wid))
+    try:
+        while True:
+            t = tasks.get()
+            if t is None:
+                break
+            if t[0] == "block":
+                m = t[1]
+                ts, tk, ndof, sv, ev, cn = _cpu_one_block((jobs[m],) + common)
+                stash[m] = cn
+                results.put(("block", m, ts, tk, ndof, sv, ev))
+            else:   # ("bt", fi, b0, b1): the (f, b) columns of one frequency and a range of baselines, all m
+                desc = dict(desc0, included_freq=np.array([t[1]]), included_baseline=np.arange(t[2], t[3]))
+                results.put(("bt", t[1], t[2], t[3], _cpu_bt_columns(desc)))
+        results.put(("dry", wid, time.perf_counter()))
+        for m, cn in stash.items():
+            tol = 1e-10
+            if cn.shape[0]:
+                w = np.linalg.eigvalsh(0.5 * (cn + cn.conj().T))
+                tol = max(1e-10, 50.0 * 2.220446049250313e-16 * abs(w[-1]) / max(abs(w[0]), 1e-300))   # tests/parity_util.pencil_tol
+            results.put(("tol", m, tol))
+    except BaseException as e:   # the parent must hear about it: it counts "end" messages
+        import traceback
+
+        results.put(("error", wid, "%r\n%s" % (e, traceback.format_exc()[-1500:])))
+    finally:
+        results.put(("end", wid))
 
 
 def cpu_worker_main(path, nproc):
@@ -265,10 +275,20 @@ def cpu_worker_main(path, nproc):
     procs = [ctxm.Process(target=_cpu_worker, args=(w, tasks, results, (jobs, common, desc0))) for w in range(nproc)]
     for p_ in procs:
         p_.start()
-    blocks, bts, tols, dry, ended = {}, [], {}, [], 0
+    blocks, bts, tols, dry, ended, errors = {}, [], {}, [], 0, []
+    import queue as _queue
+
     while ended < nproc:
-        r = results.get()
-        if r[0] == "block":
+        try:
+            r = results.get(timeout=30.0)
+        except _queue.Empty:
+            if not any(p_.is_alive() for p_ in procs):   # everybody gone without saying so (killed): do not wait for ever
+                errors.append("worker processes died")
+                break
+            continue
+        if r[0] == "error":
+            errors.append(r[2])
+        elif r[0] == "block":
             blocks[r[1]] = r[2:]
         elif r[0] == "bt":
             bts.append(r[4])
@@ -279,7 +299,12 @@ def cpu_worker_main(path, nproc):
         else:
             ended += 1
     for p_ in procs:
-        p_.join()
+        p_.join(10.0)
+        if p_.is_alive():
+            p_.kill()   # exactly the processes started above
+    if errors or len(blocks) != len(jobs):
+        print("cpu worker failed: %s" % (errors[:1] or ["%d of %d blocks done" % (len(blocks), len(jobs))]), file=sys.stderr)
+        sys.exit(3)
     out = dict(wall_s=max(dry), workers=nproc, dry_s=dry, bt_core_s=float(sum(bts)), bt_tasks=len(bts),
                svd_core_s=float(sum(v[0] for v in blocks.values())), kl_core_s=float(sum(v[1] for v in blocks.values())))
     with open(path + ".out", "wb") as fh:
@@ -528,7 +553,7 @@ def stage_work(tel, bt, ms, nkeep=None):
 
 
 CFG3 = dict(num_freq=64, freq_start=400.0, freq_end=500.0, freq_mode="edge", num_cylinders=4, cylinder_width=12.0,
-            num_feeds=16, feed_spacing=0.4, tsys=1.0, force_lmax=512, force_mmax=512)
+            num_feeds=16, feed_spacing=0.4, tsys=1.0, force_lmax=512, force_mmax=512, sht_iter=3)
 
 
 def class_table(pr, steps=1.0):
@@ -857,7 +882,7 @@ def run_share(args):
 
 
 CFG5 = dict(num_freq=256, freq_start=400.0, freq_end=800.0, freq_mode="edge", num_cylinders=4, cylinder_width=14.5,
-            num_feeds=64, feed_spacing=0.3, tsys=1.0, force_lmax=1024, force_mmax=1024)
+            num_feeds=64, feed_spacing=0.3, tsys=1.0, force_lmax=1024, force_mmax=1024, sht_iter=3)
 
 
 def measure_configs4_block(m=300, checks=True, workspace_gb=100, bt_gb=24, log=None):

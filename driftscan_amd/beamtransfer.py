@@ -242,6 +242,9 @@ class BeamTransfer(config.Reader):
             beam_all = None
             if need_bt:
                 whole = a == 0 and b == tel.mmax
+                # the writer queue may still hold views of the previous range's blocks (they are `resident`: outside its
+                # bound on device bytes) — let their host copies finish before a second chunk of up to beam_chunk_gb is allocated
+                storage.wait_copies()
                 tok = self._stage_begin()
                 beam_all = btgen.beam_m_all(tel, ctx=ctx, max_bytes=int(self.device_chunk_gb * (1 << 30)),
                                             m_range=None if whole else (a, b))
@@ -367,6 +370,10 @@ class BeamTransfer(config.Reader):
                     (1, 2, min(10, len(binc)), len(pinc), tel.lmax + 1 - mi)))
                 f.attrs["m"] = mi
                 f.attrs["frequencies"] = tel.frequencies
+                # not in the reference's files: which reading of its SHT (healpy.map2alm through cora, neither readable
+                # here) these blocks were made with — DESIGN.md section 3
+                f.attrs["sht_iter"] = int(getattr(tel, "sht_iter", 0) or 0)
+                f.attrs["sht_ring_weights"] = bool(getattr(tel, "sht_ring_weights", None) is not None)
 
         # the host copies are made by the writer pool's copy thread (storage.Deferred) while the SVD stage reads the same
         # blocks: nothing writes to `beam_all` after this point

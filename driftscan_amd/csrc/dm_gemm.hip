@@ -32,9 +32,15 @@
 namespace {
 
 constexpr int BM = 64, BN = 64, BK = 16, LDP = 17;
+#ifndef ZG_CH
+#define ZG_CH 2
+#endif
+#ifndef ZG_OCC
+#define ZG_OCC 2
+#endif
 
 template <bool B_REAL, bool B_GATHER>
-__global__ __launch_bounds__(256, 3) void zgemm_grouped_kernel(const dm_gemm_desc* __restrict__ descs,
+__global__ __launch_bounds__(256, ZG_OCC) void zgemm_grouped_kernel(const dm_gemm_desc* __restrict__ descs,
                                                             const dm_gemm_tile* __restrict__ tiles,
                                                             int ntiles) {
   __shared__ double As_re[BM * LDP], As_im[BM * LDP];
@@ -141,44 +147,51 @@ __global__ __launch_bounds__(256, 3) void zgemm_grouped_kernel(const dm_gemm_des
   };
 
   const int fi = lane & 15, fk = lane >> 4;
-  // MFMAs of one staged panel.  The two products that feed the same accumulator are issued eight
-  // MFMAs apart (all "first" products, then all "second" ones): a dependent MFMA right behind its
-  // producer stalls on the 16-pass f64 pipeline.
+  // MFMAs of one staged panel, ONE ACCUMULATOR AT A TIME: the eight products of a panel that feed an accumulator (four
+  // k-sub-steps x two real products) are issued back to back.  v_mfma_f64_16x16x4_f64 pays ~40 cycles whenever the
+  // accumulator changes (its 8 VGPRs of C go through the register file) and none when SrcC is the previous MFMA's
+  // result: scratch/mfma_peak3.hip measures 105 cycles per MFMA with the accumulators taken in rotation (47 TFLOP/s,
+  // what rounds 1-4 took for the instruction's ceiling), 83 in chains of 2, 75 in chains of 4, 69.5 in chains of 8, 66
+  // in chains of 16+ (75 TFLOP/s, the datasheet rate).  (Round 1 issued the two products of an accumulator eight MFMAs
+  // apart "to avoid the stall of a dependent MFMA" — the opposite of what the hardware wants.)
   auto compute_panel = [&]() {
+    // ZG_CH k-sub-steps per chain group: 2 x ZG_CH chained MFMAs per accumulator (ZG_CH = 4: the whole panel, 64 operand VGPRs)
 #pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-      double a_re[2], a_im[2], a_imn[2], b_re[2], b_im[2];
+    for (int k0 = 0; k0 < BK / 4; k0 += ZG_CH) {
+      double a_re[2][ZG_CH], a_im[2][ZG_CH], b_re[2][ZG_CH], b_im[2][ZG_CH];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        int r = (wm * 32 + i * 16 + fi) * LDP + kk * 4 + fk;
-        a_re[i] = As_re[r];
-        a_im[i] = As_im[r];
-        a_imn[i] = -a_im[i];
-      }
+      for (int kk = 0; kk < ZG_CH; ++kk) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        int r = (wn * 32 + j * 16 + fi) * LDP + kk * 4 + fk;
-        b_re[j] = Bs_re[r];
-        b_im[j] = B_REAL ? 0.0 : Bs_im[r];
+        for (int i = 0; i < 2; ++i) {
+          int r = (wm * 32 + i * 16 + fi) * LDP + (k0 + kk) * 4 + fk;
+          a_re[i][kk] = As_re[r];
+          a_im[i][kk] = As_im[r];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          int r = (wn * 32 + j * 16 + fi) * LDP + (k0 + kk) * 4 + fk;
+          b_re[j][kk] = Bs_re[r];
+          b_im[j][kk] = B_REAL ? 0.0 : Bs_im[r];
+        }
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           if (vi[i] && vj[j]) {
-            acc_re[i][j] = dm_mfma(a_re[i], b_re[j], acc_re[i][j]);
-            acc_im[i][j] = dm_mfma(a_im[i], b_re[j], acc_im[i][j]);
-          }
-      if (!B_REAL) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            if (vi[i] && vj[j]) {
-              acc_re[i][j] = dm_mfma(a_imn[i], b_im[j], acc_re[i][j]);
-              acc_im[i][j] = dm_mfma(a_re[i], b_im[j], acc_im[i][j]);
+            for (int kk = 0; kk < ZG_CH; ++kk) {
+              acc_re[i][j] = dm_mfma(a_re[i][kk], b_re[j][kk], acc_re[i][j]);
+              if (!B_REAL) acc_re[i][j] = dm_mfma(-a_im[i][kk], b_im[j][kk], acc_re[i][j]);
             }
-      }
+            __builtin_amdgcn_sched_barrier(0);   // the scheduler would interleave the chains again (it models a dependent MFMA as a stall)
+#pragma unroll
+            for (int kk = 0; kk < ZG_CH; ++kk) {
+              acc_im[i][j] = dm_mfma(a_im[i][kk], b_re[j][kk], acc_im[i][j]);
+              if (!B_REAL) acc_im[i][j] = dm_mfma(a_re[i][kk], b_im[j][kk], acc_im[i][j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
     }
   };
 
@@ -214,11 +227,11 @@ __global__ __launch_bounds__(256, 3) void zgemm_grouped_kernel(const dm_gemm_des
     __syncthreads();
     store_tiles();
     __syncthreads();
-    if (rmw) load_c();
     compute_panel();
-  } else if (rmw) {
-    load_c();
   }
+  // the old C values of a read-modify-write tile are requested together AFTER the last panel: held across it they cost 64
+  // VGPRs (spills at three workgroups per CU); the other workgroups of the CU cover the one memory latency this exposes
+  if (rmw) load_c();
 
   // epilogue: lane l, reg r -> row (l>>4) + 4r, col l&15 of each 16x16 tile
 #pragma unroll
@@ -557,18 +570,24 @@ __global__ __launch_bounds__(256) void dgemm_grouped_kernel(const dm_gemm_desc* 
     store_tiles();
     __syncthreads();
     if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+    // the four MFMAs of a panel that feed an accumulator back to back (chains on one accumulator: 75 cycles per
+    // v_mfma_f64_16x16x4_f64 against 105 with the four accumulators in rotation, scratch/mfma_peak3.hip)
+    double a[2][BK / 4], b[2][BK / 4];
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
-      double a[2], b[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = As[(wm * 32 + i * 16 + fi) * LDP + kk * 4 + fk];
+      for (int i = 0; i < 2; ++i) a[i][kk] = As[(wm * 32 + i * 16 + fi) * LDP + kk * 4 + fk];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = Bs[(wn * 32 + j * 16 + fi) * LDP + kk * 4 + fk];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = dm_mfma(a[i], b[j], acc[i][j]);
+      for (int j = 0; j < 2; ++j) b[j][kk] = Bs[(wn * 32 + j * 16 + fi) * LDP + kk * 4 + fk];
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) acc[i][j] = dm_mfma(a[i][kk], b[j][kk], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
   }
   double* __restrict__ C = reinterpret_cast<double*>(d.C);
   const int crow = lane >> 4, ccol = lane & 15;

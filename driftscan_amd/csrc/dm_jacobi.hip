@@ -122,11 +122,14 @@ __global__ __launch_bounds__(256) void jac_gram_kernel(const jac_item* __restric
   }
   cplx r[4];
   double nacc[4] = {0.0, 0.0, 0.0, 0.0};
+  // global_load (not flat: a flat load also counts on LGKM, so every LDS wait would drain the prefetch) from a clamped,
+  // always valid address; rows and columns outside the item read as zero
+  // (the loaded values are masked when they are staged, a stage later: a select right behind the load would wait for it)
   auto load = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int c = it.g0 + k0 + scol[i];
-      r[i] = (grow[i] >= 0 && c < it.g1) ? it.Z[(size_t)grow[i] * it.ld + c] : make_double2(0.0, 0.0);
+      const int c = it.g0 + k0 + scol[i];
+      r[i] = dm_ldg(it.Z, (size_t)(grow[i] >= 0 ? grow[i] : it.ra) * it.ld + min(c, it.g1 - 1));
     }
   };
   const int nk = (it.g1 - it.g0 + 15) / 16;
@@ -135,27 +138,41 @@ __global__ __launch_bounds__(256) void jac_gram_kernel(const jac_item* __restric
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      Xre[srow[i] * XP + scol[i]] = r[i].x;
-      Xim[srow[i] * XP + scol[i]] = r[i].y;
-      nacc[i] = fma(r[i].x, r[i].x, fma(r[i].y, r[i].y, nacc[i]));
+      const bool ok = grow[i] >= 0 && it.g0 + kt * 16 + scol[i] < it.g1;
+      const double xr = ok ? r[i].x : 0.0, xi = ok ? r[i].y : 0.0;
+      Xre[srow[i] * XP + scol[i]] = xr;
+      Xim[srow[i] * XP + scol[i]] = xi;
+      nacc[i] = fma(xr, xr, fma(xi, xi, nacc[i]));
     }
     __syncthreads();
     if (kt + 1 < nk) load((kt + 1) * 16);
+    // one accumulator at a time, its eight MFMAs of this stage back to back: v_mfma_f64_16x16x4_f64 runs at 69 cycles in
+    // chains of 8 on one accumulator against 83 in chains of 2 and 105 with the accumulators in rotation
+    // (scratch/mfma_peak3.hip: SrcC forwarded from the previous MFMA instead of read from the register file)
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int t = 0; t < 3; ++t) {
+      if (t < nt) {   // wave-uniform
+        double a_re[4], a_im[4], x_re[4], x_im[4];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        if (t < nt) {   // wave-uniform
+        for (int kk = 0; kk < 4; ++kk) {
           const int ra = (ti[t] * 16 + fi) * XP + kk * 4 + fk;
           const int rb = (tj[t] * 16 + fi) * XP + kk * 4 + fk;
-          const double a_re = Xre[ra], a_im = Xim[ra];
-          const double x_re = Xre[rb], x_im = Xim[rb];
-          // G[i][j] += a_i * conj(x_j)
-          gre[t] = dm_mfma(a_re, x_re, gre[t]);
-          gre[t] = dm_mfma(a_im, x_im, gre[t]);
-          gim[t] = dm_mfma(a_im, x_re, gim[t]);
-          gim[t] = dm_mfma(-a_re, x_im, gim[t]);
+          a_re[kk] = Xre[ra]; a_im[kk] = Xim[ra];
+          x_re[kk] = Xre[rb]; x_im[kk] = Xim[rb];
         }
+        // G[i][j] += a_i * conj(x_j)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          gre[t] = dm_mfma(a_re[kk], x_re[kk], gre[t]);
+          gre[t] = dm_mfma(a_im[kk], x_im[kk], gre[t]);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (the scheduler interleaves independent chains otherwise)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          gim[t] = dm_mfma(a_im[kk], x_re[kk], gim[t]);
+          gim[t] = dm_mfma(-a_re[kk], x_im[kk], gim[t]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -402,13 +419,14 @@ __global__ __launch_bounds__(JNT) void jac_inner_kernel(const jac_item* __restri
 // grid = (items, column chunks).  Each wave takes 16 columns at a time: the
 // 64x16 strip is pulled into registers (it is the MFMA B operand as it stands),
 // multiplied by Q^H from LDS, and written back — so the update is in place.
-constexpr int APPLY_CHUNK = 256;  // columns per workgroup
+constexpr int APPLY_CHUNK = 1024;  // columns per workgroup (Q^H, 64 KB, is re-read per chunk: 6 % on top of the rows)
+constexpr int APPLY_NT = 512;      // eight waves share one Q^H in LDS (82 KB: one workgroup per CU): two waves per SIMD
 
-__global__ __launch_bounds__(256) void jac_apply_kernel(const jac_item* __restrict__ items,
-                                                        const int* __restrict__ active,
-                                                        const int* __restrict__ skip,
-                                                        const cplx* __restrict__ Qbuf,
-                                                        unsigned long long* __restrict__ flopctr) {
+__global__ __launch_bounds__(APPLY_NT) void jac_apply_kernel(const jac_item* __restrict__ items,
+                                                             const int* __restrict__ active,
+                                                             const int* __restrict__ skip,
+                                                             const cplx* __restrict__ Qbuf,
+                                                             unsigned long long* __restrict__ flopctr) {
   extern __shared__ __align__(16) unsigned char smem[];
   double* Are = reinterpret_cast<double*>(smem);  // A = Q^H : Are[k][i] = Re conj(Q[k][i]) = Re Q[k][i]
   double* Aim = Are + JP * QP;                    //            Aim[k][i] = -Im Q[k][i]
@@ -424,48 +442,74 @@ __global__ __launch_bounds__(256) void jac_apply_kernel(const jac_item* __restri
   }
 
   const cplx* Qi = Qbuf + (size_t)it.q * JP * JP;
-  for (int idx = tid; idx < JP * JP; idx += 256) {
+  for (int idx = tid; idx < JP * JP; idx += APPLY_NT) {
     int k = idx >> 6, i = idx & 63;
-    cplx v = Qi[idx];  // Q[k][i]
+    cplx v = dm_ldg(Qi, idx);  // Q[k][i]
     Are[k * QP + i] = v.x;
     Aim[k * QP + i] = -v.y;
   }
   __syncthreads();
 
   const int fj = lane & 15, fk = lane >> 4;
-  // global rows of the 16 k-steps this lane feeds (k = 4*ks + fk)
-  int krow[16];
-#pragma unroll
-  for (int ks = 0; ks < 16; ++ks) krow[ks] = item_row(it, ks * 4 + fk);
-
-  for (int c = cbeg + wave * 16; c < cend; c += 64) {
-    const int col = c + fj;
-    const bool cok = col < cend;
-    double bre[16], bim[16];
+  // (lane feeds the k-steps k = 4*ks + fk: global row item_row(it, k))
+  // The strip a wave works on next is requested BEFORE the MFMAs of the current one (a wave used to load, compute and
+  // store in turn: with one or two waves per SIMD the matrix pipe idled through every load — 2.5 TB/s of row traffic).
+  constexpr int CSTEP = (APPLY_NT / 64) * 16;
+  cplx cur[16], nxt[16];
+  auto load_strip = [&](int c, cplx (&v)[16]) {
+    const int colc = min(c + fj, cend - 1);
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-      cplx v = (cok && krow[ks] >= 0) ? it.Z[(size_t)krow[ks] * it.ld + col] : make_double2(0.0, 0.0);
-      bre[ks] = v.x;
-      bim[ks] = v.y;
+      const int kr = item_row(it, ks * 4 + fk);
+      // global_load from a clamped (always valid) address, no branch per load; flat loads would also count on LGKM and
+      // every wait for an LDS read of Q^H would drain the prefetch
+      // No mask (a select behind the load would wait for it before the MFMAs): a row outside the item meets an exactly
+      // zero column of Q^H (jac_inner never rotates a row whose Gram entries are all zero: Q stays the identity there)
+      // and is not stored; a column outside the chunk only feeds its own, unstored, output column.
+      v[ks] = dm_ldg(it.Z, (size_t)(kr >= 0 ? kr : it.ra) * it.ld + colc);
     }
+  };
+  int c = cbeg + wave * 16;
+  if (c < cend) load_strip(c, cur);
+  for (; c < cend; c += CSTEP) {
+    const int col = c + fj;
+    const bool cok = col < cend;
+    if (c + CSTEP < cend) load_strip(c + CSTEP, nxt);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       dm_f64x4 ore = {0, 0, 0, 0}, oim = {0, 0, 0, 0};
+      // 8 MFMAs of an accumulator back to back (SrcC forwarding: 69.5 cycles per v_mfma_f64_16x16x4_f64 in chains of 8
+      // against 83 with re / im alternating in pairs, 107 at one wave per SIMD; scratch/mfma_peak3.hip)
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        int ra = (ks * 4 + fk) * QP + mt * 16 + fj;
-        double a_re = Are[ra], a_im = Aim[ra];
-        ore = dm_mfma(a_re, bre[ks], ore);
-        ore = dm_mfma(-a_im, bim[ks], ore);
-        oim = dm_mfma(a_re, bim[ks], oim);
-        oim = dm_mfma(a_im, bre[ks], oim);
+      for (int kq = 0; kq < 4; ++kq) {
+        double a_re[4], a_im[4];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          const int ra = ((kq * 4 + k4) * 4 + fk) * QP + mt * 16 + fj;
+          a_re[k4] = Are[ra];
+          a_im[k4] = Aim[ra];
+        }
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          ore = dm_mfma(a_re[k4], cur[kq * 4 + k4].x, ore);
+          ore = dm_mfma(-a_im[k4], cur[kq * 4 + k4].y, ore);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          oim = dm_mfma(a_re[k4], cur[kq * 4 + k4].y, oim);
+          oim = dm_mfma(a_im[k4], cur[kq * 4 + k4].x, oim);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         int grow = item_row(it, mt * 16 + (lane >> 4) + 4 * rr);
-        if (cok && grow >= 0) it.Z[(size_t)grow * it.ld + col] = make_double2(ore[rr], oim[rr]);
+        if (cok && grow >= 0) dm_stg(it.Z, (size_t)grow * it.ld + col, make_double2(ore[rr], oim[rr]));
       }
     }
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) cur[ks] = nxt[ks];
   }
 }
 
@@ -1095,7 +1139,7 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
       }
       {
         dm_prof_scope ps(ctx, DM_PROF_JAC_APPLY, 0.0);
-        hipLaunchKernelGGL(jac_apply_kernel, dim3(ni, chunks), dim3(256), APPLY_LDS, ctx->stream, d_items + nb,
+        hipLaunchKernelGGL(jac_apply_kernel, dim3(ni, chunks), dim3(APPLY_NT), APPLY_LDS, ctx->stream, d_items + nb,
                            d_active, d_skip, d_Q, fc ? fc + DM_PROF_JAC_APPLY : nullptr);
       }
     }
@@ -1245,19 +1289,19 @@ int dm_jacobi_herm(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, d
       }
       {
         dm_prof_scope ps(ctx, DM_PROF_JAC_APPLY, 0.0);
-        hipLaunchKernelGGL(jac_apply_kernel, dim3(ni, chunks), dim3(256), APPLY_LDS, ctx->stream, icur, d_active,
+        hipLaunchKernelGGL(jac_apply_kernel, dim3(ni, chunks), dim3(APPLY_NT), APPLY_LDS, ctx->stream, icur, d_active,
                            d_skip, d_Q, fc);
       }
       {
         dm_prof_scope ps(ctx, DM_PROF_JAC_APPLY, 0.0);
-        hipLaunchKernelGGL(jac_apply_kernel, dim3(ni, chunks), dim3(256), APPLY_LDS, ctx->stream, d_iW + nb,
+        hipLaunchKernelGGL(jac_apply_kernel, dim3(ni, chunks), dim3(APPLY_NT), APPLY_LDS, ctx->stream, d_iW + nb,
                            d_active, d_skip, d_Q, fc);
       }
       DM_PLAUNCH(ctx, DM_PROF_UTIL, jac_ctrans_kernel, dim3(tb, tb, np), dim3(256), 0, ctx->stream,
                          cur == 0 ? d_tdC : d_tdT, d_active);
       {
         dm_prof_scope ps(ctx, DM_PROF_JAC_APPLY, 0.0);
-        hipLaunchKernelGGL(jac_apply_kernel, dim3(ni, chunks), dim3(256), APPLY_LDS, ctx->stream, ioth, d_active,
+        hipLaunchKernelGGL(jac_apply_kernel, dim3(ni, chunks), dim3(APPLY_NT), APPLY_LDS, ctx->stream, ioth, d_active,
                            d_skip, d_Q, fc);
       }
       cur ^= 1;

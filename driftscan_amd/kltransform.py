@@ -391,7 +391,9 @@ class KLTransform(config.Reader):
     olddatafile = False
 
     @util.cache_last
-    def modes_m(self, mi, threshold=None):
+    def modes_m(self, mi, threshold=None, device=False):
+        """``device=True`` (the Fisher estimators during generation): the eigenvectors of a batch in flight may come back
+        as rows of the batch's DEVICE tensor; every other caller gets numpy arrays, as from the reference."""
         mc = self.__dict__.get("_mode_cache")
         if mc is not None and mi in mc:   # modes of the batch in flight (generate_ms), exactly what the file will hold
             evals, evecs = mc[mi]   # (evecs may be a DEVICE tensor here: rows of the batch's eigenvector matrix)
@@ -400,7 +402,10 @@ class KLTransform(config.Reader):
             startind = np.searchsorted(evals, threshold) if threshold is not None else 0
             if startind == evals.size:
                 return None, None
-            return evals[startind:], evecs[startind:]
+            evecs = evecs[startind:]
+            if not device and not isinstance(evecs, np.ndarray):
+                evecs = evecs.cpu().numpy()
+            return evals[startind:], evecs
         if not os.path.exists(self._evfile % mi):
             return self.transform_save(mi)
         with storage.File(self._evfile % mi, "r") as f:

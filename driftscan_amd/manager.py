@@ -135,7 +135,13 @@ class ProductManager(object):
         os.makedirs(self.directory, exist_ok=True)
         if parallel.io_root():
             with open(os.path.join(self.directory, "configdump.yaml"), "w") as fh:
-                yaml.dump(self.config, fh)
+                dump = dict(self.config)
+                # the settings of the SHT the products are made with, resolved (defaults included): healpy's `iter` and
+                # ring weights reach the reference through cora and cannot be read here
+                tel = self.telescope
+                dump["driftscan_amd"] = dict(sht_iter=int(getattr(tel, "sht_iter", 0) or 0),
+                                             sht_ring_weights=bool(getattr(tel, "sht_ring_weights", None) is not None))
+                yaml.dump(dump, fh)
         # manager.py:278-305 runs the stages one after the other through the files.  Here the KL transforms of a batch of
         # m run right behind its SVD chain, while the SVD products are resident in HBM (BeamTransfer.generate's
         # `after_batch`); `klobj.generate()` then only finishes what is left (nothing, unless the beams existed already),

@@ -101,7 +101,7 @@ class PSEstimation(config.Reader):
         return self.k_center.size
 
     def num_evals(self, mi):
-        evals = self.kltrans.modes_m(mi, threshold=self.threshold)[0]
+        evals = self.kltrans.modes_m(mi, threshold=self.threshold, device=True)[0]
         return evals.size if evals is not None else 0
 
     # ---- bands (psestimation.py:256-349) ------------------------------------------------------
@@ -264,7 +264,7 @@ class PSExact(PSEstimation):
         bt = kl.beamtransfer
         nb = self.clarray.shape[0]
         zero = (np.zeros((nb, nb), dtype=np.complex128), np.zeros(nb, dtype=np.complex128))
-        modes = [kl.modes_m(mi, threshold=self.threshold) for mi in ms]
+        modes = [kl.modes_m(mi, threshold=self.threshold, device=True) for mi in ms]
         nmodes = np.array([0 if ev is None else ev.size for ev, _ in modes], dtype=np.int64)
         if nmodes.sum() == 0:
             return [zero for _ in ms]

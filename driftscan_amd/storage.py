@@ -733,7 +733,24 @@ def _write_in_process(f, tmp):
         w = workers.get()
         try:
             w.run((tmp, specs, dict(f.attrs)))
-        finally:
+        except BaseException:
+            # the process may be gone (broken pipe, short read): never hand it out again — a fresh one takes its place
+            try:
+                w.stop()
+            except Exception:
+                pass
+            with _proc_lock:
+                if w in _worker_list:
+                    _worker_list.remove(w)
+                try:
+                    w = _Worker()
+                    _worker_list.append(w)
+                except Exception:
+                    w = None
+            if w is not None:
+                workers.put(w)
+            raise
+        else:
             workers.put(w)
     finally:
         for blk in blocks:
@@ -937,6 +954,17 @@ def submit(fn, *args):
         while _pending and _pending[0].done() and _pending[0].exception() is None:
             _pending.pop(0)
         _pending.append(fut)
+
+
+def wait_copies():
+    """Wait until every `Deferred` handed to `submit` so far has been copied to the host (NOT until its file is written):
+    the copy thread works in submission order, so a marker task behind them says when.  `BeamTransfer.generate` calls this
+    before it allocates the beam blocks of its next range of m: the views held by the queue keep the previous range's
+    allocation (up to `beam_chunk_gb`) alive, and those bytes are outside the `DRIFTMI_IO_DEVICE_GB` bound."""
+    with _plock:
+        copier = _copier
+    if copier is not None:
+        copier.submit(lambda: None).result()
 
 
 def flush():

@@ -165,6 +165,10 @@ def test_smallest_block_against_oracle_chain(c3):
     if i_o != i_g:   # only acceptable when an eigenvalue sits within the tolerance of the cut: say so
         _log("m 460: kept-mode count %d vs oracle %d — an eigenvalue lies within %.1e lambda_max of the threshold"
              % (ev_o.size - i_g, ev_o.size - i_o, tol))
+        import warnings
+
+        warnings.warn("configs[2] m = 460: kept-mode count %d vs the oracle's %d — an eigenvalue lies within tol of the cut"
+                      % (ev_o.size - i_g, ev_o.size - i_o))
     assert i_o == i_g or np.abs(ev_o - kl.threshold).min() < tol * np.abs(ev_o).max()
     assert ours[3]["ac"] == ac_o == 0.0
     c3["cs460"], c3["cn460"] = cs, cn
@@ -239,7 +243,11 @@ def test_doublekl_and_fisher_config4(c3):
     _log("m 460: DoubleKL keeps %d of %d modes past the foreground cut (oracle %d); f_evals error %.2e (bound %.1e)"
          % (ev_g.size, fev_o.size, ev_o.size, np.abs(extra["f_evals"] - fev_o).max() / np.abs(fev_o).max(), tol1))
     if ev_g.size != ev_o.size:   # only acceptable when an f_eval sits within the tolerance of the foreground cut
+        import warnings
+
         _log("m 460: DoubleKL kept %d modes, the oracle %d — an f_eval lies within %.1e of the cut" % (ev_g.size, ev_o.size, tol1))
+        warnings.warn("configs[3] m = 460: DoubleKL kept %d modes, the oracle %d — an f_eval lies within tol of the cut"
+                      % (ev_g.size, ev_o.size))
     assert ev_g.size == ev_o.size or near
     if ev_g.size == ev_o.size and ev_o.size:
         assert_spectrum(ev_g, ev_o, max(1e-8, 100 * tol1), "DoubleKL evals m=460")

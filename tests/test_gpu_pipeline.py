@@ -531,3 +531,49 @@ def test_bench_job_mode_two_ranks_on_one_gpu():
     assert sum(p["m_blocks"] for p in per) == line["config"]["mmax"] + 1
     assert all(p["seconds"] > 0 and p["collective_s"] >= 0 and p["stage_s"]["svd"] > 0 for p in per)
     assert line["job_s"] >= max(p["compute_s"] for p in per) and line["value"] > 0
+
+
+def test_several_btgen_ranges_with_files(tmp_path):
+    """`beam_chunk_gb` small enough for several BT-gen ranges per rank, product files on: the beam blocks of a range reach
+    the writer queue as views of ONE allocation; `generate` waits for their host copies before it allocates the next
+    range (`storage.wait_copies`) — at most two ranges' worth of blocks are ever alive, and every file equals the one of
+    the single-range run."""
+    import torch
+    import yaml
+
+    from driftscan_amd import device, manager, storage
+
+    def conf(outdir, chunk):
+        return dict(
+            config=dict(beamtransfers=True, kltransform=True, psfisher=False, output_directory=str(outdir), truncate=False,
+                        beam_chunk_gb=chunk),
+            telescope=dict(type="PolarisedCylinder", num_freq=3, freq_start=400.0, freq_end=430.0, freq_mode="edge",
+                           num_cylinders=2, cylinder_width=2.0, num_feeds=3, feed_spacing=0.4, tsys=1.0, sht_iter=3),
+            kltransform=[dict(type="KLTransform", name="kl", use_foregrounds=True, threshold=0.0)],
+        )
+
+    pms = {}
+    for name, chunk in (("one", 96.0), ("many", 1e-9)):     # 1e-9 GB: one m-block per range
+        device.reset_context()
+        c = tmp_path / (name + ".yaml")
+        c.write_text(yaml.dump(conf(tmp_path / name, chunk)))
+        pm = manager.ProductManager.from_config(str(c))
+        torch.cuda.reset_peak_memory_stats()
+        pm.generate()
+        storage.flush()
+        pms[name] = pm
+    t, bt = pms["one"].telescope, pms["one"].beamtransfer
+    one, many = str(tmp_path / "one"), str(tmp_path / "many")
+    for mi in range(t.mmax + 1):
+        f1 = bt._mfile(mi)
+        with storage.File(f1, "r") as fa, storage.File(f1.replace(one, many, 1), "r") as fb:
+            assert np.array_equal(fa["beam_m"][:], fb["beam_m"][:])
+            assert int(fb.attrs["sht_iter"]) == 3 and not bool(fb.attrs["sht_ring_weights"])
+        s1 = bt._svdfile(mi)
+        with storage.File(s1, "r") as fa, storage.File(s1.replace(one, many, 1), "r") as fb:
+            a, b = fa["singularvalues"][:], fb["singularvalues"][:]
+            assert np.abs(a - b).max() <= 1e-12 * max(a.max(), 1e-300)
+    import yaml as _y
+
+    dump = _y.safe_load(open(os.path.join(many, "configdump.yaml")))
+    assert dump["driftscan_amd"]["sht_iter"] == 3

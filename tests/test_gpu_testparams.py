@@ -124,6 +124,11 @@ def test_doublekl_against_oracle(products):
               "stage-1 shift %.3e (oracle %.3e)" % (mi, fev_o.size, e1, tol1, kept_g, kept_o, ac_g, ac_o))
         assert fev_g.shape == fev_o.shape and e1 <= tol1
         assert kept_g == kept_o or near
+        if kept_g != kept_o:   # the escape is taken: visible in the warnings summary of the run
+            import warnings
+
+            warnings.warn("configs[0] dk m = %d: %d modes past the foreground cut vs the oracle's %d — an eigenvalue lies within "
+                          "tol of the cut" % (mi, kept_g, kept_o))
         assert (ac_g > 0) == (ac_o > 0)
         if kept_g == kept_o and kept_o:
             got = evf_g[evf_g.size - kept_o:]
