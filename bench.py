@@ -377,11 +377,46 @@ def cpu_baseline(tel, bt, kl, blocks, gpu_sv, gpu_ev):
             svnum_eq = False
         else:
             kept_eq += 1
+    # Blocks whose eigenvalues differ from the oracle's by more than pencil_tol: the conditioning bound of the PENCIL does
+    # not cover the svcut truncation in front of it (a kept subspace with a singular value close to the cut is only
+    # determined to eps sigma_1 / gap).  Their yardstick is the sensitivity of the oracle's OWN answer: its whole chain run
+    # again on the block perturbed by one unit roundoff per entry (as tests/parity_util.pencil_sensitivity does for a pencil).
+    over = []
+    for m in ms:
+        ndof, sv_o, ev_o = spectra[m]
+        ev_g = np.asarray(gpu_ev[m])
+        if ev_o.size and ev_g.shape == ev_o.shape:
+            e = float(np.abs(ev_g - ev_o).max() / max(float(np.abs(ev_o).max()), 1e-300))
+            if e > tols.get(m, 1e-10):
+                over.append((e / tols.get(m, 1e-10), m, e))
+    over.sort(reverse=True)
+    sens_rec, over_ok = [], True
+    rng = np.random.default_rng(12345)
+    for _, m, e in over[:8]:
+        ev_o = spectra[m][2]
+        worst_s = 0.0
+        for _rep in range(2):
+            blk = blocks[m]
+            pert = blk * (1.0 + 2.220446049250313e-16 * rng.standard_normal(blk.shape)) \
+                + 1j * blk.imag * (2.220446049250313e-16 * rng.standard_normal(blk.shape))
+            ev_p = _cpu_one_block((pert,) + common)[4]
+            worst_s = float("inf") if ev_p.shape != ev_o.shape else max(
+                worst_s, float(np.abs(ev_p - ev_o).max() / max(float(np.abs(ev_o).max()), 1e-300)))
+        ok = e <= max(tols.get(m, 1e-10), 10.0 * worst_s)
+        over_ok = over_ok and ok
+        sens_rec.append(dict(m=int(m), ndof=int(spectra[m][0]), err=e, pencil_tol=tols.get(m, 1e-10),
+                             oracle_sensitivity_to_one_ulp_of_the_block=worst_s, within_10x_sensitivity=bool(ok)))
+    if len(over) > 8:
+        over_ok = False   # more offenders than were examined: not claimed
     parity = dict(blocks=len(ms), sv_max_err_over_svmax=sv_err, sv_tol=1e-10, svnum_equal=svnum_eq,
+                  ev_blocks_over_pencil_tol=len(over), ev_over_pencil_tol_examined=sens_rec,
                   ev_max_err_over_lambda_max=ev_err, ev_max_err_over_pencil_tol=ev_over, ev_worst=worst,
                   kept_counts_equal=kept_eq, kept_counts_differ_with_an_eigenvalue_within_tol_of_the_cut=kept_escape,
                   kept_counts_differ_otherwise=len(ms) - kept_eq - kept_escape,
-                  green=bool(sv_err <= 1e-10 and svnum_eq and ev_over <= 1.0 and kept_eq + kept_escape == len(ms)),
+                  green=bool(sv_err <= 1e-10 and svnum_eq and (ev_over <= 1.0 or over_ok) and kept_eq + kept_escape == len(ms)),
+                  green_rule="sigma within 1e-10 sigma_max, svnum equal, kept counts equal (or an eigenvalue within tol of the cut), "
+                             "eigenvalues within pencil_tol — or, for the blocks beyond it, within 10 x the measured sensitivity of "
+                             "the oracle's own spectrum to a one-ulp perturbation of the block",
                   note="GPU spectra of the timed configuration against the oracle's on the SAME real blocks, all %d of them: "
                        "singular values relative to the block's largest (bound 1e-10), eigenvalues relative to lambda_max "
                        "against pencil_tol = max(1e-10, 50 eps cond(N)) (tests/parity_util.py), svnum and kept-mode counts" % len(ms))

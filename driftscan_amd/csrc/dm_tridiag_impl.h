@@ -1425,6 +1425,39 @@ __global__ __launch_bounds__(256) void dc_ubuild_kernel(const dc_mat* __restrict
   M.U[(size_t)lo * M.n + (size_t)j * M.n + i] = M.zhat[lo + i] / ((M.dk[lo + i] - dor) - mu) * M.inv[lo + j];
 }
 
+// LAPACK's dstedc scales the tridiagonal to unit max-norm before the divide & conquer (DLASCL with ORGNRM) and scales
+// the eigenvalues back: dlaed2's deflation tolerance 8 eps max(|d|, |z|) compares poles — which carry the scale of the
+// matrix — with components of unit vectors.  Without the scaling a matrix of norm 1e-9 had its eigenvalues computed to
+// 1e-13 .. 1e-9 of its norm instead of 1e-15 (rounds 1-4; found by the full-size spectrum parity of bench.py on the
+// configs[1] blocks m = 101 .. 104, whose S/N pencils have lambda_max ~ 1e-10).
+struct dc_scale_mat { double* d; double* e; int n; double* scale; };
+__global__ __launch_bounds__(256) void dc_scale_kernel(const dc_scale_mat* __restrict__ ms) {
+  const dc_scale_mat M = ms[blockIdx.x];
+  __shared__ double red[4];
+  double mx = 0.0;
+  for (int i = threadIdx.x; i < M.n; i += 256) {
+    mx = fmax(mx, fabs(M.d[i]));
+    if (i + 1 < M.n) mx = fmax(mx, fabs(M.e[i]));
+  }
+  mx = dm_wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  const bool ok = mx > 0.0 && mx < 1e300;   // (an all-zero or non-finite tridiagonal is left as it is)
+  if (threadIdx.x == 0) *M.scale = ok ? mx : 1.0;
+  if (!ok) return;
+  const double inv = 1.0 / mx;
+  for (int i = threadIdx.x; i < M.n; i += 256) {
+    M.d[i] *= inv;
+    if (i + 1 < M.n) M.e[i] *= inv;
+  }
+}
+__global__ __launch_bounds__(256) void dc_unscale_kernel(const dc_scale_mat* __restrict__ ms) {
+  const dc_scale_mat M = ms[blockIdx.x];
+  const double sc = *M.scale;
+  for (int i = threadIdx.x; i < M.n; i += 256) M.d[i] *= sc;
+}
+
 struct dc_tear { double* d; const double* e; int b; };
 __global__ void dc_tear_kernel(const dc_tear* __restrict__ ts, int nt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1490,6 +1523,16 @@ static int dc_solve(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, 
   dc_mat* d_dm = dm_ws_upload(ctx, dm);
   if (!d_dm) return DM_ENOMEM;
   auto bound = [&](int p, int D, int i) { return (int)(((long long)i * probs[p].n) >> D); };
+
+  // ---- unit max-norm tridiagonals (dstedc's DLASCL); the eigenvalues are scaled back at the end
+  double* dscale = dm_ws_alloc_t<double>(ctx, std::max(np, 1));
+  if (!dscale) return DM_ENOMEM;
+  std::vector<dc_scale_mat> scm(np);
+  for (int p = 0; p < np; ++p) scm[p] = dc_scale_mat{dd + offn[p], ee + offn[p], probs[p].n, dscale + p};
+  dc_scale_mat* d_scm = dm_ws_upload(ctx, scm);
+  if (!d_scm) return DM_ENOMEM;
+  static const bool dc_noscale = getenv("DM_DC_NOSCALE") != nullptr;
+  if (!dc_noscale) DM_PLAUNCH(ctx, DM_PROF_DC, dc_scale_kernel, dim3(np), dim3(256), 0, ctx->stream, d_scm);
 
   // ---- tear at every leaf boundary, then solve the leaves with the QL kernels
   {
@@ -1653,6 +1696,7 @@ static int dc_solve(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs, 
     if (inB && probs[p].n > 0) cp.push_back(dm_cdesc{lamB + offn[p], dd + offn[p], sizeof(double) * probs[p].n});
   }
   DM_TRY(dm_copy_batched(ctx, cp));
+  if (!dc_noscale) DM_PLAUNCH(ctx, DM_PROF_DC, dc_unscale_kernel, dim3(np), dim3(256), 0, ctx->stream, d_scm);
   return DM_OK;
 }
 

@@ -205,6 +205,22 @@ def test_herm_eig_tridiag_beyond_lds(ctx, kind):
     assert np.abs(D - np.diag(ev)).max() <= 2e-12 * scale
 
 
+@pytest.mark.parametrize("n", [20, 66, 159, 300])
+@pytest.mark.parametrize("scale", [1.0, 1e-9, 1e-18, 1e12])
+def test_herm_eig_is_scale_invariant(ctx, n, scale):
+    """The eigenvalues of s A are s times those of A to a few ulp whatever the norm of the matrix: the divide & conquer
+    works on the tridiagonal scaled to unit max-norm, as LAPACK's dstedc does (DLASCL) — dlaed2's deflation tolerance
+    compares poles with components of unit vectors.  (Unscaled, a matrix of norm 1e-9 lost six digits: the S/N pencils of
+    the configs[1] blocks m = 101 .. 104 have lambda_max ~ 1e-10.)"""
+    rng = np.random.default_rng(n)
+    X = crand(rng, n, n)
+    A = (X @ X.conj().T) * scale
+    ref = np.linalg.eigvalsh(A)
+    ev, _ = ctx.herm_eig(ctx.to_device(A[None].copy()), n, n)
+    got = np.sort(ev.cpu().numpy()[0][:n])
+    assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+
+
 def test_herm_eig_mixed_sizes_via_eigh_gen(ctx):
     """Different n in one batch (the KL use: ndof varies with m)."""
     from driftscan_amd._lib import block_offsets
