@@ -964,7 +964,7 @@ def measure_configs4_block(m=300, checks=True, workspace_gb=100, bt_gb=24, log=N
         ctx.prof_reset(2)
         sync()
         t0 = time.perf_counter()
-        out = bt.svd_device(beam)
+        out = bt.svd_device(beam, ms=[m])     # (columns l >= m only, as generate() runs it)
         sync()
         rec["svd_s"] = time.perf_counter() - t0
         rec["svd_classes"] = class_table(ctx.prof_report())

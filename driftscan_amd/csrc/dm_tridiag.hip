@@ -62,7 +62,9 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
     for (const auto& p : probs) totn += p.n;
     const char* e = getenv("DM_TRD_TWOSTAGE");
     const int mode = e ? atoi(e) : -1;
-    if (mode == 1 || (mode != 0 && ((maxn >= 3500 && totn >= 24000) || maxn >= 14000))) width = 32;
+    static const bool ts_mid = !getenv("DM_TRD_TS_MID") || atoi(getenv("DM_TRD_TS_MID")) != 0;
+    if (mode == 1 || (mode != 0 && ((maxn >= 3500 && totn >= 24000) || (ts_mid && maxn >= 2400 && totn >= 48000) || maxn >= 14000)))
+      width = 32;
   }
   if (const char* e = getenv("DM_TRD_PANEL")) width = atoi(e) == 64 ? 64 : 32;
   return width == 32 ? dm_trd32::herm_eig_tridiag(ctx, probs, evals, evals_stride, sel)

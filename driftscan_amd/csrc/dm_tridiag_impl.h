@@ -1848,7 +1848,12 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
     if (const char* e = getenv("DM_TRD_TWOSTAGE")) mode = atoi(e);
     // (later sweep, after the launch chains were planned once per panel: 512 x 300 1.05 x, 512 x 432 1.12 x, 256 x 600
     // 1.14 x, 256 x 700 1.17 x, 512 x 864 1.19 x; 64 x 432 0.94 x, 64 x 700 0.96 x, 32 x 600 0.84 x, 16 x 1000 0.86 x)
-    const bool pays = (maxn >= 700 && np >= 64) || (maxn >= 300 && totn >= 120000) || (maxn >= 3500 && totn >= 24000) || maxn >= 14000;
+    // (round 5: the levels of the SVD preconditioner of a configs[4] slice are 23 matrices of n = 2500 .. 3552 — below the
+    // n_max >= 3500 rule, on the one-stage path at 0.45 of the HBM roofline for 13 of the 44 s of that stage: n_max >= 2400
+    // with sum n >= 48 000 joins; DM_TRD_TS_MID=0 takes it out)
+    static const bool ts_mid = !getenv("DM_TRD_TS_MID") || atoi(getenv("DM_TRD_TS_MID")) != 0;
+    const bool pays = (maxn >= 700 && np >= 64) || (maxn >= 300 && totn >= 120000) || (maxn >= 3500 && totn >= 24000) ||
+                      (ts_mid && maxn >= 2400 && totn >= 48000) || maxn >= 14000;
     two_stage = use_dc && maxn > TSM && maxn > SB + 2 && (mode == 1 || (mode != 0 && pays));
   }
 #else
