@@ -207,10 +207,12 @@ __device__ __forceinline__ dm_f64x4 dm_mfma(double a, double b, dm_f64x4 c) {
 // indicator inputs, scratch/mfma4_layout.hip; cbsz/abid have no effect for f64).  With
 // k = l >> 4, g = (l >> 2) & 3, t = l & 3:
 //   A: lane l holds A_g[i = t][k];  B: lane l holds B_g[k][j = t];  D_g[i][j] lands in lane 16 i + 4 g + j.
-// It issues at 71 TFLOP/s on MI355X against 49 for the 16x16x4 form (scratch/mfma_peak2.hip):
-// a 16x16 tile is built from it by putting row block g of A in slot g and column block
-// (g + s) & 3 of B in slot g for the four rotations s (the rotated B fragments are four LDS
-// reads with different addresses, no shuffles).
+// It issues at 16 cycles per instruction (73-77 TFLOP/s on MI355X) in ANY order of accumulators; the 16x16x4 form costs
+// 64 + ~41 / R cycles with R consecutive MFMAs on ONE accumulator (105 cycles = 47 TFLOP/s with the accumulators in
+// rotation — what rounds 1-4 took for that instruction's ceiling — 83 in chains of 2, 69.5 in chains of 8, 66 = 75
+// TFLOP/s in chains of 16+: scratch/mfma_peak3.hip).  A 16x16 tile is built from the 4x4x4 form
+// by putting row block g of A in slot g and column block (g + s) & 3 of B in slot g for the four rotations s (the
+// rotated B fragments are four LDS reads with different addresses, no shuffles).
 __device__ __forceinline__ double dm_mfma4(double a, double b, double c) {
   return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }

@@ -254,9 +254,12 @@ __global__ __launch_bounds__(256, ZG_OCC) void zgemm_grouped_kernel(const dm_gem
 
 
 // ---- register-only variant on v_mfma_f64_4x4x4_4b_f64 ------------------------------------------------------
-// The 16x16x4 form issues at 62 % of the datasheet rate on gfx950, the 4x4x4 form (four independent 4x4x4
-// products per instruction) at the full rate; it needs four times the operand values per flop, which an LDS-staged
-// loop pays in barriers and ds_read latency.  Here there is no LDS and no barrier at all: every lane loads the one
+// The 16x16x4 form reaches the datasheet rate only in long chains on one accumulator (64 + ~41 / R cycles for R chained
+// MFMAs, scratch/mfma_peak3.hip; rounds 1-4 read its 47 TFLOP/s with rotating accumulators as a ceiling), the 4x4x4 form
+// (four independent 4x4x4 products per instruction) issues at the full rate in any order; it needs four times the
+// operand values per flop, which an LDS-staged loop pays in barriers and ds_read latency.  (Round 5 re-measured the
+// LDS-staged 16x16x4 kernel above WITH per-accumulator chains: 47 TFLOP/s at 2048^3 against 39.6 before and 52.5 here
+// — that kernel is bound by its barriers, not by the instruction.)  Here there is no LDS and no barrier at all: every lane loads the one
 // A element and the one B element the instruction wants from it straight from L1 / L2 (the panels of a 64x64 tile
 // are shared by the four waves of the workgroup through the vector L1), prefetched one K-step of 4 ahead.
 //   lane l = 16 k + 4 g + t:  A operand = A[row 4 g + t][k],  B operand = B[k][col 4 g' + t]

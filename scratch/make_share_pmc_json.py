@@ -30,9 +30,8 @@ for name, pas in (("zgemm_cov", "cov"), ("jac_gram", "gram")):
     out[name] = dict(kernels=sorted(kern), dispatches=len(calls), mfma_busy_cycles=busy, grbm_gui_active=act,
                      sq_busy_cycles=val.get("SQ_BUSY_CYCLES", 0.0), mfma_busy=(busy / (act / 8.0 * 1024.0)) if act > 0 else None)
     try:   # the share's own line under the profiler (wall time with the serialised dispatches)
-        line = [l for l in open(os.path.join(os.path.dirname(os.path.dirname(fl[0])), "stdout.txt")).read().splitlines() if l.startswith("{")]
-        if not line:
-            line = [l for l in open(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_share_%s_%s" % (tag, pas), "stdout.txt"))[0]).read().splitlines() if l.startswith("{")]
+        so = os.path.join(ROOT, "gpurun_out", "pmc_share_%s_%s" % (tag, pas), "stdout.txt")
+        line = [l for l in open(so).read().splitlines() if l.startswith("{")]
         d = json.loads(line[-1])
         out[name]["share_s_under_profiler"] = d["share_s"]
         cls = d["classes"].get("zgemm_cov" if name == "zgemm_cov" else "jac_gram")
