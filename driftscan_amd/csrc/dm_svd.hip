@@ -92,6 +92,47 @@ __global__ void svd_extract_kernel(const cplx* __restrict__ Z, const svd_geom* _
   if (col == 0) sigma[(size_t)c * K + i] = sig3[(size_t)c * T + i];
 }
 
+// Polarised telescopes, round 5: SVD3 runs on a matrix of its own, Z3[c] = [ U^H (w B_T) | U^H ] — the rows cut2 .. r1 of
+// the accumulated row mixing (the identity part of Z after SVD2) and their total-intensity columns, recomputed from the
+// input block by one product — instead of dragging the 3 (L - lmin) polarised passenger columns through every level
+// product and rotation of the phase; the polarised part of `beam` is one product at the end, `ut3 . bfr` as the
+// reference writes it (beamtransfer.py:877).  geo3: r3 rows x (Lc + T) columns per chain.
+__global__ void svd_build_z3_kernel(const cplx* __restrict__ Z, const svd_geom* __restrict__ geo,
+                                    const svd_geom* __restrict__ geo3, const int* __restrict__ row0,
+                                    const int* __restrict__ nrow3, cplx* __restrict__ Z3, int T, int P) {
+  const int c = blockIdx.z;
+  const int i = blockIdx.y;
+  if (i >= nrow3[c]) return;
+  const svd_geom g = geo[c], g3 = geo3[c];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  Z3[g3.zoff + (size_t)i * g3.ldz + g.Lc + t] = Z[g.zoff + (size_t)(row0[c] + i) * g.ldz + (size_t)P * g.Lc + t];
+}
+
+// products of a polarised chain from Z3 (rows sorted by descending sigma): total-intensity part of beam_svd, beam_ut, sigma
+__global__ void svd_extract3_kernel(const cplx* __restrict__ Z3, const svd_geom* __restrict__ geo3,
+                                    const int* __restrict__ nmodes, const double* __restrict__ noisew,
+                                    const double* __restrict__ sig3, cplx* __restrict__ beam_svd,
+                                    cplx* __restrict__ beam_ut, double* __restrict__ sigma, int F, int T, int P, int L,
+                                    int K) {
+  const int c = blockIdx.z;
+  const int f = c % F;
+  const int i = blockIdx.y;
+  if (i >= nmodes[c]) return;
+  const svd_geom g = geo3[c];
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  const cplx* z = Z3 + g.zoff + (size_t)i * g.ldz;
+  if (col < g.Lc) {
+    beam_svd[((size_t)c * K + i) * ((size_t)P * L) + g.lmin + col] = z[col];
+  } else if (col < g.Lc + T) {
+    const int t = col - g.Lc;
+    const double w = noisew[(size_t)f * T + t];
+    const cplx u = z[col];
+    beam_ut[((size_t)c * K + i) * T + t] = make_double2(u.x * w, u.y * w);
+  }
+  if (col == 0) sigma[(size_t)c * K + i] = sig3[(size_t)c * T + i];
+}
+
 // Z2[c] = [ beam_svd[c][:nm][:, (p, l >= lmin)] | I_nm ]   (geo2: K rows allocated per chain, ld2 = P * Lc + K)
 __global__ void svd_build_pinv_kernel(const cplx* __restrict__ beam_svd, const int* __restrict__ nmodes,
                                       cplx* __restrict__ Z2, const svd_geom* __restrict__ geo2, int K, int P, int L) {
@@ -169,6 +210,9 @@ extern "C" int dm_svd_chain_lmin(dm_ctx* ctx, int nblk, int F, int T, int P, int
   cplx* beam_ut = reinterpret_cast<cplx*>(beam_ut_dev);
   cplx* ibeam = reinterpret_cast<cplx*>(invbeam_svd_dev);
 
+  // DM_SVD_NARROW=0: SVD2 / SVD3 on all columns of Z, as rounds 1-4 (the passengers of a phase ride through it)
+  static const bool narrow_env = !getenv("DM_SVD_NARROW") || atoi(getenv("DM_SVD_NARROW")) != 0;
+  const bool narrow = narrow_env && P > 1;
   cplx* Z = dm_ws_alloc_t<cplx>(ctx, ztot);
   double* sig = dm_ws_alloc_t<double>(ctx, (size_t)nch * T);
   svd_geom* d_geo = dm_ws_upload(ctx, geo);
@@ -215,8 +259,11 @@ extern "C" int dm_svd_chain_lmin(dm_ctx* ctx, int nblk, int F, int T, int P, int
       fprintf(stderr, "\n");
     }
     // ---- phase 2: SVD2, left null space of the polarised columns, `>=` cut (:844-848, :137)
+    // (narrow: the phase works on the columns [pol | I] — the view starts behind the total-intensity block, which is
+    // stale from here on and rebuilt for SVD3 from the identity part)
     for (int c = 0; c < nch; ++c)
-      pr[c] = dm_jac_problem{Z + geo[c].zoff, geo[c].ldz, 0, r1[c], geo[c].ldz, geo[c].Lc, P * geo[c].Lc};
+      pr[c] = narrow ? dm_jac_problem{Z + geo[c].zoff + geo[c].Lc, geo[c].ldz, 0, r1[c], geo[c].ldz - geo[c].Lc, 0, (P - 1) * geo[c].Lc}
+                     : dm_jac_problem{Z + geo[c].zoff, geo[c].ldz, 0, r1[c], geo[c].ldz, geo[c].Lc, P * geo[c].Lc};
     dm_jac_rows_opts o2;
     o2.unconverged = true;
     DM_TRY(dm_jacobi_rows(ctx, pr, sig, T, &sw, &o2));
@@ -235,12 +282,49 @@ extern "C" int dm_svd_chain_lmin(dm_ctx* ctx, int nblk, int F, int T, int P, int
 
   // ---- phase 3: SVD3 on the total-intensity columns, rtol 0 (:859-865)
   std::vector<int> row0(nch), nrow3(nch);
+  std::vector<svd_geom> geo3;
+  cplx* Z3 = nullptr;
+  svd_geom* d_geo3 = nullptr;
   {
     std::vector<dm_jac_problem> pr(nch);
     for (int c = 0; c < nch; ++c) {
       row0[c] = cut2[c];
       nrow3[c] = alive[c] ? std::max(0, r1[c] - cut2[c]) : 0;
       pr[c] = dm_jac_problem{Z + geo[c].zoff, geo[c].ldz, row0[c], nrow3[c], geo[c].ldz, 0, geo[c].Lc};
+    }
+    if (narrow) {
+      geo3.resize(nch);
+      size_t z3tot = 0;
+      int maxr3 = 0;
+      for (int c = 0; c < nch; ++c) {
+        geo3[c] = geo[c];
+        geo3[c].zoff = z3tot;
+        geo3[c].ldz = geo[c].Lc + T;
+        z3tot += (size_t)nrow3[c] * geo3[c].ldz;
+        maxr3 = std::max(maxr3, nrow3[c]);
+      }
+      Z3 = dm_ws_alloc_t<cplx>(ctx, std::max<size_t>(z3tot, 1));
+      d_geo3 = dm_ws_upload(ctx, geo3);
+      int* d_r0 = dm_ws_upload(ctx, row0);
+      int* d_n3 = dm_ws_upload(ctx, nrow3);
+      if (!Z3 || !d_geo3 || !d_r0 || !d_n3) return DM_ENOMEM;
+      if (maxr3 > 0) {
+        DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, svd_build_z3_kernel, dim3((T + 255) / 256, maxr3, nch), dim3(256), 0, ctx->stream, Z,
+                   d_geo, d_geo3, d_r0, d_n3, Z3, T, P);
+        DM_HIP(ctx, hipGetLastError());
+        // total-intensity part: U^H diag(noisew) B_T — one product per chain out of the input block
+        std::vector<dm_gemm_desc> g;
+        g.reserve(nch);
+        for (int c = 0; c < nch; ++c) {
+          if (nrow3[c] == 0) continue;
+          cplx* z3 = Z3 + geo3[c].zoff;
+          g.push_back(dm_gemm_make(z3 + geo[c].Lc, geo3[c].ldz, 1, false, beam + (size_t)c * T * PL + geo[c].lmin, PL, 1, false,
+                                   z3, geo3[c].ldz, nrow3[c], geo[c].Lc, T, 1.0, 0.0, noisew_dev + (size_t)(c % F) * T));
+        }
+        DM_TRY(dm_gemm_grouped_launch(ctx, g));
+      }
+      for (int c = 0; c < nch; ++c)
+        pr[c] = dm_jac_problem{Z3 + geo3[c].zoff, geo3[c].ldz, 0, nrow3[c], geo3[c].ldz, 0, geo[c].Lc};
     }
     // polarised: certainly not orthogonal yet.  Unpolarised: the measuring pass is kept, it retires the
     // all-zero and trivially orthogonal blocks of the high m (a fifth of config 2) before the eigensolver.
@@ -272,10 +356,29 @@ extern "C" int dm_svd_chain_lmin(dm_ctx* ctx, int nblk, int F, int T, int P, int
   DM_TRY(dm_fill_zero(ctx, beam_svd, sizeof(cplx) * (size_t)nch * K * PL));
   DM_TRY(dm_fill_zero(ctx, beam_ut, sizeof(cplx) * (size_t)nch * K * T));
   DM_TRY(dm_fill_zero(ctx, sigma_dev, sizeof(double) * (size_t)nch * K));
-  if (maxnm > 0) {
+  if (maxnm > 0 && !narrow) {
     DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, svd_extract_kernel, dim3((ldz_max + 255) / 256, maxnm, nch), dim3(256), 0, ctx->stream, Z, d_geo,
                        d_row0, d_nm, noisew_dev, sig, beam_svd, beam_ut, sigma_dev, F, T, P, L, K);
     DM_HIP(ctx, hipGetLastError());
+  }
+  if (maxnm > 0 && narrow) {
+    DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, svd_extract3_kernel, dim3((L + T + 255) / 256, maxnm, nch), dim3(256), 0, ctx->stream, Z3,
+                       d_geo3, d_nm, noisew_dev, sig, beam_svd, beam_ut, sigma_dev, F, T, P, L, K);
+    DM_HIP(ctx, hipGetLastError());
+    // the polarised part of `beam = ut3 . bfr` (beamtransfer.py:877): rows of U^H (the identity part of Z3) times the
+    // noise-weighted input block, one product per polarisation into the columns l >= lmin of the (zero-filled) output
+    std::vector<dm_gemm_desc> g;
+    g.reserve((size_t)nch * (P - 1));
+    for (int c = 0; c < nch; ++c) {
+      const int nm = nmodes[c];
+      if (nm == 0) continue;
+      const cplx* u = Z3 + geo3[c].zoff + geo[c].Lc;
+      for (int pp = 1; pp < P; ++pp)
+        g.push_back(dm_gemm_make(u, geo3[c].ldz, 1, false, beam + (size_t)c * T * PL + (size_t)pp * L + geo[c].lmin, PL, 1, false,
+                                 beam_svd + (size_t)c * K * PL + (size_t)pp * L + geo[c].lmin, PL, nm, geo[c].Lc, T, 1.0, 0.0,
+                                 noisew_dev + (size_t)(c % F) * T));
+    }
+    DM_TRY(dm_gemm_grouped_launch(ctx, g));
   }
 
   // ---- pseudo-inverse of `beam` (:887-921)
