@@ -22,12 +22,18 @@ def main():
     ap.add_argument("--workload", default="configs2")
     ap.add_argument("--out", required=True)
     ap.add_argument("--shares", default=None, help="comma-separated ranks (default: all)")
+    ap.add_argument("--pause", type=float, default=10.0,
+                    help="seconds between two shares: the driver wipes the ~240 GB the previous process freed in the background, and "
+                         "the next process's first large allocations wait for it (2-3 s in front of its BT-gen kernels when the shares "
+                         "run back to back; a rank of a real job starts on an idle card)")
     args = ap.parse_args()
     import bench
 
     ranks = [int(x) for x in args.shares.split(",")] if args.shares else list(range(args.n))
     shares = []
-    for r in ranks:
+    for k, r in enumerate(ranks):
+        if k and args.pause > 0:
+            time.sleep(args.pause)
         t0 = time.perf_counter()
         res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", args.workload, "--share",
                               "%d/%d" % (r, args.n)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
@@ -53,6 +59,7 @@ def main():
                max_s=max(s["share_s"] for s in ok) if ok else None,
                slowest=max(ok, key=lambda s: s["share_s"])["share"] if ok else None,
                mean_s=sum(s["share_s"] for s in ok) / len(ok) if ok else None,
+               pause_s=args.pause,
                note="every share of the cost-balanced contiguous partition through ProductManager.generate() on one MI355X, "
                     "products left in HBM; the job's wall time on N GPUs is max_s")
     with open(args.out, "w") as fh:
