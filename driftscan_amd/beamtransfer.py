@@ -293,6 +293,14 @@ class BeamTransfer(config.Reader):
         # flat + linear + cubic to the kernel seconds of the eight configs[2] shares of that build
         # (profiles/r05e_configs2_shares.json: 0.090 + 0.360 x + 0.387 x^3 seconds per block, of which 0.19 units are the
         # KLTransform's as before).
+        tel = self.telescope
+        P, T = int(tel.num_pol_sky), int(self.ntel)
+        if P > 1 and P * (tel.lmax + 1 - m) * 5 <= T * 4:
+            # a TALL block (more rows than sky columns l >= m: dm_svd_chain_lmin takes SVD1 through the transposed matrix, a
+            # P (L - m)-square Gram eigenproblem instead of a T-square one): 0.050 + 0.16 x + 0.30 x^2 seconds per block on the
+            # configs[2] shares (profiles/r05*_configs2_shares.json, share 7/8 and the m = 400 / 480 batches of
+            # scratch/svd_phase_probe.py), in the units of the line below
+            return 0.081 + 0.26 * x + 0.49 * x * x + self.kl_cost_weight * x ** 3
         return 0.15 + 0.60 * x + (0.455 + self.kl_cost_weight) * x ** 3
 
     def _my_ms(self, mlist=None):

@@ -41,6 +41,9 @@ struct dm_ctx {
   std::vector<prof_rec> prof;
   std::vector<hipEvent_t> ev_pool;
   unsigned long long* prof_dev = nullptr;  // device flop counters, one per class
+  // eigensolver policy override of the caller in flight (-1: the library's policy; 0: one-stage tridiagonalisation only):
+  // set and restored around dm_herm_eig_tridiag by a caller that knows its batch (dm_jacobi_rows, `one_stage_eig`)
+  int trd_mode_override = -1;
 };
 
 // Event records are not free on a chain of thousands of short launches (each is a marker packet that breaks the

@@ -1018,7 +1018,13 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
       DM_TRY(dm_gemm_grouped_launch(ctx, g));
       // evals land at consecutive strides of the *compacted* problem list
       dbg_mark("level: cleaning + Gram");
-      DM_TRY(dm_herm_eig_tridiag(ctx, hp, evp, sigma_stride));
+      {
+        const int keep_mode = ctx->trd_mode_override;
+        if (O.one_stage_eig) ctx->trd_mode_override = 0;
+        const int rc_eig = dm_herm_eig_tridiag(ctx, hp, evp, sigma_stride);
+        ctx->trd_mode_override = keep_mode;
+        DM_TRY(rc_eig);
+      }
       dbg_mark("level: eigensolver");
       std::vector<dm_jac_problem> sp;
       for (auto& h : hp) sp.push_back(dm_jac_problem{h.W, h.ldw, 0, h.n, h.n, 0, 0});

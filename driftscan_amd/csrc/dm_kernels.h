@@ -131,6 +131,7 @@ struct dm_jac_problem {
 struct dm_jac_rows_opts {
   bool unconverged = false;
   double drop_below = 0.0;
+  bool one_stage_eig = false;   // the Gram eigenproblems of the preconditioner levels on the one-stage tridiagonalisation
 };
 int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double* sigma, int sigma_stride,
                    int* sweeps_out = nullptr, const dm_jac_rows_opts* opts = nullptr);

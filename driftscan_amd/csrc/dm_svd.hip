@@ -92,6 +92,61 @@ __global__ void svd_extract_kernel(const cplx* __restrict__ Z, const svd_geom* _
   if (col == 0) sigma[(size_t)c * K + i] = sig3[(size_t)c * T + i];
 }
 
+// TALL chains (P (L - lmin) < T: more rows than sky columns — every m-block above m = L - T / P), SVD1: the T x T Gram
+// eigenproblem of the row-side preconditioner has rank <= P Lc, and rounds 1-4 paid for all of it (864^3 against 452^3 at
+// m = 400 of configs[2]).  The same singular triplets come out of the TRANSPOSED matrix: Yt = (w B)^H is P Lc x T, its
+// rows are mixed until orthogonal over all T columns — Yt' = Sigma U^H: row i is sigma_i u_i^H — and the rows of the
+// chain's Z follow as  [ u_i^H (w B) | u_i^H ]  (one product per polarisation); only r1 <= P Lc rows ever exist.
+// Yt[c][k = p Lc + j][t] = conj( nw[f][t] beam[c][t][p][lmin + j] ), through a 32 x 32 LDS tile (both sides coalesced)
+__global__ __launch_bounds__(256) void svd_build_yt_kernel(const cplx* __restrict__ beam, const double* __restrict__ noisew,
+                                                           cplx* __restrict__ Yt, const svd_geom* __restrict__ geo,
+                                                           const size_t* __restrict__ yoff, const int* __restrict__ tall,
+                                                           int F, int T, int P, int L) {
+  __shared__ cplx tile[32][33];
+  const int c = blockIdx.z;
+  if (!tall[c]) return;
+  const svd_geom g = geo[c];
+  const int f = c % F;
+  const int Kc = P * g.Lc;
+  const int k0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
+  if (k0 >= Kc || t0 >= T) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int t = t0 + j, k = k0 + tx;
+    cplx v = make_double2(0.0, 0.0);
+    if (t < T && k < Kc) {
+      const int p = k / g.Lc, l = g.lmin + (k - p * g.Lc);
+      const double w = noisew[(size_t)f * T + t];
+      const cplx b = beam[((size_t)c * T + t) * ((size_t)P * L) + (size_t)p * L + l];
+      v = make_double2(b.x * w, -b.y * w);
+    }
+    tile[j][tx] = v;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int k = k0 + j, t = t0 + tx;
+    if (k < Kc && t < T) Yt[yoff[c] + (size_t)k * T + t] = tile[tx][j];
+  }
+}
+
+// identity part of the rows of a tall chain: Z[c][i][P Lc + t] = Yt'[c][i][t] / sigma_i = u_i^H   (i < r1)
+__global__ void svd_tall_rows_kernel(const cplx* __restrict__ Yt, const size_t* __restrict__ yoff,
+                                     const int* __restrict__ tall, const int* __restrict__ r1,
+                                     const double* __restrict__ sigt, cplx* __restrict__ Z,
+                                     const svd_geom* __restrict__ geo, int T, int P) {
+  const int c = blockIdx.z;
+  if (!tall[c]) return;
+  const int i = blockIdx.y;
+  if (i >= r1[c]) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const svd_geom g = geo[c];
+  const double s = sigt[(size_t)c * T + i];
+  const double inv = s > 0.0 ? 1.0 / s : 0.0;
+  const cplx y = Yt[yoff[c] + (size_t)i * T + t];
+  Z[g.zoff + (size_t)i * g.ldz + (size_t)P * g.Lc + t] = make_double2(y.x * inv, y.y * inv);
+}
+
 // Polarised telescopes, round 5: SVD3 runs on a matrix of its own, Z3[c] = [ U^H (w B_T) | U^H ] — the rows cut2 .. r1 of
 // the accumulated row mixing (the identity part of Z after SVD2) and their total-intensity columns, recomputed from the
 // input block by one product — instead of dragging the 3 (L - lmin) polarised passenger columns through every level
@@ -227,16 +282,63 @@ extern "C" int dm_svd_chain_lmin(dm_ctx* ctx, int nblk, int F, int T, int P, int
 
   if (P > 1) {
     // ---- phase 1: SVD1, image with rtol 1e-10 (beamtransfer.py:826, :98)
+    // tall chains (P Lc <= 0.8 T) go through the transposed matrix (svd_build_yt_kernel); DM_SVD_TALL=0: all chains as they lie
+    static const bool tall_env = !getenv("DM_SVD_TALL") || atoi(getenv("DM_SVD_TALL")) != 0;
+    std::vector<int> tall(nch, 0);
+    std::vector<size_t> yoff(nch, 0);
+    size_t ytot = 0;
+    int ntall = 0, kc_max = 0;
+    for (int c = 0; c < nch; ++c) {
+      const int Kc = P * geo[c].Lc;
+      tall[c] = (tall_env && Kc * 5 <= T * 4) ? 1 : 0;
+      if (tall[c]) { yoff[c] = ytot; ytot += (size_t)Kc * T; ++ntall; kc_max = std::max(kc_max, Kc); }
+    }
     std::vector<dm_jac_problem> pr(nch);
     for (int c = 0; c < nch; ++c)
-      pr[c] = dm_jac_problem{Z + geo[c].zoff, geo[c].ldz, 0, T, geo[c].ldz, 0, P * geo[c].Lc};
+      pr[c] = dm_jac_problem{Z + geo[c].zoff, geo[c].ldz, 0, tall[c] ? 0 : T, geo[c].ldz, 0, P * geo[c].Lc};
     // SVD1 keeps s > 1e-10 s_0 (beamtransfer.py:826): rows two decades further down are left out of the sweeps
     dm_jac_rows_opts o1;
     o1.unconverged = true;
     o1.drop_below = 1e-12;
-    DM_TRY(dm_jacobi_rows(ctx, pr, sig, T, &sw, &o1));
+    if (ntall < nch) DM_TRY(dm_jacobi_rows(ctx, pr, sig, T, &sw, &o1));
     if (sweeps_host) sweeps_host[0] = sw;
     DM_TRY(dm_download(ctx, hs.data(), sig, sizeof(double) * hs.size()));
+    cplx* Yt = nullptr;
+    double* sigt = nullptr;
+    int* d_tall = nullptr;
+    size_t* d_yoff = nullptr;
+    if (ntall > 0) {
+      Yt = dm_ws_alloc_t<cplx>(ctx, ytot);
+      sigt = dm_ws_alloc_t<double>(ctx, (size_t)nch * T);
+      d_tall = dm_ws_upload(ctx, tall);
+      d_yoff = dm_ws_upload(ctx, yoff);
+      if (!Yt || !sigt || !d_tall || !d_yoff) return DM_ENOMEM;
+      DM_TRY(dm_fill_zero(ctx, sigt, sizeof(double) * (size_t)nch * T));
+      DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, svd_build_yt_kernel, dim3((kc_max + 31) / 32, (T + 31) / 32, nch), dim3(256), 0, ctx->stream,
+                 beam, noisew_dev, Yt, d_geo, d_yoff, d_tall, F, T, P, L);
+      DM_HIP(ctx, hipGetLastError());
+      std::vector<dm_jac_problem> pt(nch);
+      for (int c = 0; c < nch; ++c)
+        pt[c] = dm_jac_problem{Yt + yoff[c], T, 0, tall[c] ? P * geo[c].Lc : 0, T, 0, T};
+      int swt = 0;
+      // The Gram matrices of these problems have exactly zero rows and columns (sky columns beyond a frequency's band
+      // limit): a batch of ~350 of them came back WRONG from the two-stage tridiagonalisation (a slice of the low
+      // frequencies of 10+ blocks; smaller batches, and the dense Gram matrices of the wide chains, are fine) — cause not
+      // found this round, DESIGN.md section 7.  The one-stage reduction is as fast at n ~ 450 and is taken here.
+      dm_jac_rows_opts ot = o1;
+      static const bool tall_two_stage = getenv("DM_SVD_TALL_TWOSTAGE") != nullptr;
+      ot.one_stage_eig = !tall_two_stage;
+      DM_TRY(dm_jacobi_rows(ctx, pt, sigt, T, &swt, &ot));
+      sw = std::max(sw, swt);
+      if (sweeps_host) sweeps_host[0] = sw;
+      std::vector<double> hst((size_t)nch * T);
+      DM_TRY(dm_download(ctx, hst.data(), sigt, sizeof(double) * hst.size()));
+      for (int c = 0; c < nch; ++c)
+        if (tall[c]) {
+          const int Kc = P * geo[c].Lc;
+          for (int i = 0; i < T; ++i) hs[(size_t)c * T + i] = i < Kc ? hst[(size_t)c * T + i] : 0.0;
+        }
+    }
     for (int c = 0; c < nch; ++c) {
       const double* s = &hs[(size_t)c * T];
       int cnt = 0;
@@ -244,6 +346,30 @@ extern "C" int dm_svd_chain_lmin(dm_ctx* ctx, int nblk, int F, int T, int P, int
       r1[c] = cnt;
       // the reference's guard `(s1 > 0.0).any()` (beamtransfer.py:855-857)
       alive[c] = (s[0] > 0.0) ? 1 : 0;
+    }
+    if (ntall > 0) {
+      // rows of the tall chains: [ u_i^H (w B) | u_i^H ], i < r1
+      int maxr1 = 0;
+      for (int c = 0; c < nch; ++c) if (tall[c]) maxr1 = std::max(maxr1, r1[c]);
+      int* d_r1 = dm_ws_upload(ctx, r1);
+      if (!d_r1) return DM_ENOMEM;
+      if (maxr1 > 0) {
+        DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, svd_tall_rows_kernel, dim3((T + 255) / 256, maxr1, nch), dim3(256), 0, ctx->stream, Yt, d_yoff,
+                   d_tall, d_r1, sigt, Z, d_geo, T, P);
+        DM_HIP(ctx, hipGetLastError());
+        std::vector<dm_gemm_desc> g;
+        g.reserve((size_t)ntall * P);
+        for (int c = 0; c < nch; ++c) {
+          if (!tall[c] || r1[c] == 0) continue;
+          cplx* z = Z + geo[c].zoff;
+          const cplx* u = z + (size_t)P * geo[c].Lc;
+          for (int pp = 0; pp < P; ++pp)
+            g.push_back(dm_gemm_make(u, geo[c].ldz, 1, false, beam + (size_t)c * T * PL + (size_t)pp * L + geo[c].lmin, PL, 1, false,
+                                     z + (size_t)pp * geo[c].Lc, geo[c].ldz, r1[c], geo[c].Lc, T, 1.0, 0.0,
+                                     noisew_dev + (size_t)(c % F) * T));
+        }
+        DM_TRY(dm_gemm_grouped_launch(ctx, g));
+      }
     }
     if (getenv("DM_DEBUG")) {
       // decades of the SVD1 spectrum of the first chain, and the rank range over the batch

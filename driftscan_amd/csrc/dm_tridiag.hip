@@ -61,7 +61,7 @@ int dm_herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& pro
     size_t totn = 0;
     for (const auto& p : probs) totn += p.n;
     const char* e = getenv("DM_TRD_TWOSTAGE");
-    const int mode = e ? atoi(e) : -1;
+    const int mode = ctx->trd_mode_override >= 0 ? ctx->trd_mode_override : (e ? atoi(e) : -1);
     static const bool ts_mid = !getenv("DM_TRD_TS_MID") || atoi(getenv("DM_TRD_TS_MID")) != 0;
     if (mode == 1 || (mode != 0 && ((maxn >= 3500 && totn >= 24000) || (ts_mid && maxn >= 2400 && totn >= 48000) || maxn >= 14000)))
       width = 32;

@@ -1846,6 +1846,7 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
     // 1.03 x; 32 x 1200 0.89 x, 8 x 2000 0.81 x, 1 x 8192 0.75 x stay on the one-stage path.
     int mode = -1;
     if (const char* e = getenv("DM_TRD_TWOSTAGE")) mode = atoi(e);
+    if (ctx->trd_mode_override >= 0) mode = ctx->trd_mode_override;
     // (later sweep, after the launch chains were planned once per panel: 512 x 300 1.05 x, 512 x 432 1.12 x, 256 x 600
     // 1.14 x, 256 x 700 1.17 x, 512 x 864 1.19 x; 64 x 432 0.94 x, 64 x 700 0.96 x, 32 x 600 0.84 x, 16 x 1000 0.86 x)
     // (round 5: the levels of the SVD preconditioner of a configs[4] slice are 23 matrices of n = 2500 .. 3552 — below the

@@ -48,6 +48,9 @@ def main():
             dt = time.perf_counter() - t0
             pr = ctx.prof_report()
             sv = res["singularvalues"].cpu().numpy()
+            if os.environ.get("PROBE_SAVE"):
+                import numpy as _np
+                _np.savez(os.environ["PROBE_SAVE"], sv=sv, nmodes=_np.asarray(res["nmodes"]))
             print(json.dumps(dict(svd_s=dt, per_block_s=dt / args.n, sweeps=getattr(ctx, "last_sweeps", None),
                                   classes_ms={k: round(v["ms"], 1) for k, v in sorted(pr.items(), key=lambda kv: -kv[1]["ms"])},
                                   sv_sum=float(sv.sum()), nmodes_mean=float((sv > 0).sum(axis=-1).mean()))), flush=True)
