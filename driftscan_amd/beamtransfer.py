@@ -295,7 +295,7 @@ class BeamTransfer(config.Reader):
         # KLTransform's as before).
         tel = self.telescope
         P, T = int(tel.num_pol_sky), int(self.ntel)
-        if P > 1 and P * (tel.lmax + 1 - m) * 5 <= T * 4:
+        if P > 1 and P * (tel.lmax + 1 - m) * 100 <= T * 95:
             # a TALL block (more rows than sky columns l >= m: dm_svd_chain_lmin takes SVD1 through the transposed matrix, a
             # P (L - m)-square Gram eigenproblem instead of a T-square one): 0.050 + 0.16 x + 0.30 x^2 seconds per block on the
             # configs[2] shares (profiles/r05*_configs2_shares.json, share 7/8 and the m = 400 / 480 batches of

@@ -147,6 +147,28 @@ __global__ void svd_tall_rows_kernel(const cplx* __restrict__ Yt, const size_t* 
   Z[g.zoff + (size_t)i * g.ldz + (size_t)P * g.Lc + t] = make_double2(y.x * inv, y.y * inv);
 }
 
+// unpolarised tall chains (SVD3 through the transposed matrix): rows of Yt' = Sigma U^H -> u_i^H in place, beam_ut, sigma
+__global__ void svd_tall3_products_kernel(cplx* __restrict__ Yt, const size_t* __restrict__ yoff,
+                                          const int* __restrict__ tall, const int* __restrict__ nmodes,
+                                          const double* __restrict__ sigt, const double* __restrict__ noisew,
+                                          cplx* __restrict__ beam_ut, double* __restrict__ sigma, int F, int T, int K) {
+  const int c = blockIdx.z;
+  if (!tall[c]) return;
+  const int i = blockIdx.y;
+  if (i >= nmodes[c]) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const int f = c % F;
+  const double s = sigt[(size_t)c * T + i];
+  const double inv = s > 0.0 ? 1.0 / s : 0.0;
+  cplx y = Yt[yoff[c] + (size_t)i * T + t];
+  y = make_double2(y.x * inv, y.y * inv);
+  Yt[yoff[c] + (size_t)i * T + t] = y;
+  const double w = noisew[(size_t)f * T + t];
+  beam_ut[((size_t)c * K + i) * T + t] = make_double2(y.x * w, y.y * w);
+  if (t == 0) sigma[(size_t)c * K + i] = s;
+}
+
 // Polarised telescopes, round 5: SVD3 runs on a matrix of its own, Z3[c] = [ U^H (w B_T) | U^H ] — the rows cut2 .. r1 of
 // the accumulated row mixing (the identity part of Z after SVD2) and their total-intensity columns, recomputed from the
 // input block by one product — instead of dragging the 3 (L - lmin) polarised passenger columns through every level
@@ -282,15 +304,16 @@ extern "C" int dm_svd_chain_lmin(dm_ctx* ctx, int nblk, int F, int T, int P, int
 
   if (P > 1) {
     // ---- phase 1: SVD1, image with rtol 1e-10 (beamtransfer.py:826, :98)
-    // tall chains (P Lc <= 0.8 T) go through the transposed matrix (svd_build_yt_kernel); DM_SVD_TALL=0: all chains as they lie
+    // tall chains (P Lc <= 0.95 T) go through the transposed matrix (svd_build_yt_kernel); DM_SVD_TALL=0: all chains as they lie
     static const bool tall_env = !getenv("DM_SVD_TALL") || atoi(getenv("DM_SVD_TALL")) != 0;
+    static const int tall_pct = getenv("DM_SVD_TALL_PCT") ? std::min(100, atoi(getenv("DM_SVD_TALL_PCT"))) : 95;   // tall: P Lc <= tall_pct % of T (m = 320 of configs[2], P Lc = 0.89 T: 2.01 -> 1.64 s per 11 blocks; at P Lc = T even)
     std::vector<int> tall(nch, 0);
     std::vector<size_t> yoff(nch, 0);
     size_t ytot = 0;
     int ntall = 0, kc_max = 0;
     for (int c = 0; c < nch; ++c) {
       const int Kc = P * geo[c].Lc;
-      tall[c] = (tall_env && Kc * 5 <= T * 4) ? 1 : 0;
+      tall[c] = (tall_env && Kc * 100 <= T * tall_pct) ? 1 : 0;
       if (tall[c]) { yoff[c] = ytot; ytot += (size_t)Kc * T; ++ntall; kc_max = std::max(kc_max, Kc); }
     }
     std::vector<dm_jac_problem> pr(nch);
@@ -411,6 +434,13 @@ extern "C" int dm_svd_chain_lmin(dm_ctx* ctx, int nblk, int F, int T, int P, int
   std::vector<svd_geom> geo3;
   cplx* Z3 = nullptr;
   svd_geom* d_geo3 = nullptr;
+  std::vector<int> tall3(nch, 0);       // unpolarised chains whose SVD3 runs on the transposed matrix
+  std::vector<size_t> yoff3(nch, 0);
+  int ntall3 = 0, kc3_max = 0;
+  cplx* Yt3 = nullptr;
+  double* sigt3 = nullptr;
+  int* d_tall3 = nullptr;
+  size_t* d_yoff3 = nullptr;
   {
     std::vector<dm_jac_problem> pr(nch);
     for (int c = 0; c < nch; ++c) {
@@ -452,20 +482,58 @@ extern "C" int dm_svd_chain_lmin(dm_ctx* ctx, int nblk, int F, int T, int P, int
       for (int c = 0; c < nch; ++c)
         pr[c] = dm_jac_problem{Z3 + geo3[c].zoff, geo3[c].ldz, 0, nrow3[c], geo3[c].ldz, 0, geo[c].Lc};
     }
+    // Unpolarised telescopes: SVD3 is the whole chain, and a block with Lc <= 0.95 T sky columns goes through the
+    // transposed matrix Yt = (w B)^H (Lc x T) — Lc rows to orthogonalise instead of T (configs[1]: T = 92, Lc = 129 - m)
+    if (P == 1) {
+      static const bool tall_env3 = !getenv("DM_SVD_TALL") || atoi(getenv("DM_SVD_TALL")) != 0;
+      static const int tall_pct3 = getenv("DM_SVD_TALL_PCT") ? std::min(100, atoi(getenv("DM_SVD_TALL_PCT"))) : 95;
+      size_t ytot = 0;
+      for (int c = 0; c < nch; ++c) {
+        tall3[c] = (tall_env3 && geo[c].Lc * 100 <= T * tall_pct3) ? 1 : 0;
+        if (tall3[c]) {
+          yoff3[c] = ytot; ytot += (size_t)geo[c].Lc * T; ++ntall3; kc3_max = std::max(kc3_max, geo[c].Lc);
+          pr[c].nrows = 0;
+        }
+      }
+      if (ntall3 > 0) {
+        Yt3 = dm_ws_alloc_t<cplx>(ctx, ytot);
+        sigt3 = dm_ws_alloc_t<double>(ctx, (size_t)nch * T);
+        d_tall3 = dm_ws_upload(ctx, tall3);
+        d_yoff3 = dm_ws_upload(ctx, yoff3);
+        if (!Yt3 || !sigt3 || !d_tall3 || !d_yoff3) return DM_ENOMEM;
+        DM_TRY(dm_fill_zero(ctx, sigt3, sizeof(double) * (size_t)nch * T));
+        DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, svd_build_yt_kernel, dim3((kc3_max + 31) / 32, (T + 31) / 32, nch), dim3(256), 0,
+                   ctx->stream, beam, noisew_dev, Yt3, d_geo, d_yoff3, d_tall3, F, T, P, L);
+        DM_HIP(ctx, hipGetLastError());
+      }
+    }
     // polarised: certainly not orthogonal yet.  Unpolarised: the measuring pass is kept, it retires the
     // all-zero and trivially orthogonal blocks of the high m (a fifth of config 2) before the eigensolver.
     dm_jac_rows_opts o3;
     o3.unconverged = P > 1;
-    DM_TRY(dm_jacobi_rows(ctx, pr, sig, T, &sw, &o3));
+    if (ntall3 < nch) DM_TRY(dm_jacobi_rows(ctx, pr, sig, T, &sw, &o3));
     if (sweeps_host) sweeps_host[2] = sw;
     DM_TRY(dm_download(ctx, hs.data(), sig, sizeof(double) * hs.size()));
+    if (ntall3 > 0) {
+      std::vector<dm_jac_problem> pt(nch);
+      for (int c = 0; c < nch; ++c) pt[c] = dm_jac_problem{Yt3 + yoff3[c], T, 0, tall3[c] ? geo[c].Lc : 0, T, 0, T};
+      int swt = 0;
+      DM_TRY(dm_jacobi_rows(ctx, pt, sigt3, T, &swt, &o3));
+      sw = std::max(sw, swt);
+      if (sweeps_host) sweeps_host[2] = sw;
+      std::vector<double> hst((size_t)nch * T);
+      DM_TRY(dm_download(ctx, hst.data(), sigt3, sizeof(double) * hst.size()));
+      for (int c = 0; c < nch; ++c)
+        if (tall3[c])
+          for (int i = 0; i < T; ++i) hs[(size_t)c * T + i] = i < geo[c].Lc ? hst[(size_t)c * T + i] : 0.0;
+    }
   }
   std::vector<int> nmodes(nch, 0);
   int maxnm = 0;
   for (int c = 0; c < nch; ++c) {
     const double* s = &hs[(size_t)c * T];
     int cnt = 0;
-    const int lim = std::min(nrow3[c], K);
+    const int lim = std::min(tall3[c] ? geo[c].Lc : nrow3[c], K);
     for (int i = 0; i < lim; ++i) cnt += (s[i] > 0.0) ? 1 : 0;  // rtol = 0.0: strictly positive
     nmodes[c] = cnt;
     nmodes_host[c] = cnt;
@@ -483,9 +551,31 @@ extern "C" int dm_svd_chain_lmin(dm_ctx* ctx, int nblk, int F, int T, int P, int
   DM_TRY(dm_fill_zero(ctx, beam_ut, sizeof(cplx) * (size_t)nch * K * T));
   DM_TRY(dm_fill_zero(ctx, sigma_dev, sizeof(double) * (size_t)nch * K));
   if (maxnm > 0 && !narrow) {
+    const int* d_nm_z = d_nm;
+    if (ntall3 > 0) {   // the rows of those chains are not in Z
+      std::vector<int> nmz(nmodes);
+      for (int c = 0; c < nch; ++c) if (tall3[c]) nmz[c] = 0;
+      d_nm_z = dm_ws_upload(ctx, nmz);
+      if (!d_nm_z) return DM_ENOMEM;
+    }
     DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, svd_extract_kernel, dim3((ldz_max + 255) / 256, maxnm, nch), dim3(256), 0, ctx->stream, Z, d_geo,
-                       d_row0, d_nm, noisew_dev, sig, beam_svd, beam_ut, sigma_dev, F, T, P, L, K);
+                       d_row0, d_nm_z, noisew_dev, sig, beam_svd, beam_ut, sigma_dev, F, T, P, L, K);
     DM_HIP(ctx, hipGetLastError());
+    if (ntall3 > 0) {
+      // u_i^H = Yt'[i] / sigma_i (in place), beam_ut = u_i^H diag(noisew), sigma; beam = u_i^H (w B): one product per chain
+      DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, svd_tall3_products_kernel, dim3((T + 255) / 256, maxnm, nch), dim3(256), 0, ctx->stream, Yt3,
+                 d_yoff3, d_tall3, d_nm, sigt3, noisew_dev, beam_ut, sigma_dev, F, T, K);
+      DM_HIP(ctx, hipGetLastError());
+      std::vector<dm_gemm_desc> g;
+      g.reserve(ntall3);
+      for (int c = 0; c < nch; ++c) {
+        if (!tall3[c] || nmodes[c] == 0) continue;
+        g.push_back(dm_gemm_make(Yt3 + yoff3[c], T, 1, false, beam + (size_t)c * T * PL + geo[c].lmin, PL, 1, false,
+                                 beam_svd + (size_t)c * K * PL + geo[c].lmin, PL, nmodes[c], geo[c].Lc, T, 1.0, 0.0,
+                                 noisew_dev + (size_t)(c % F) * T));
+      }
+      DM_TRY(dm_gemm_grouped_launch(ctx, g));
+    }
   }
   if (maxnm > 0 && narrow) {
     DM_PLAUNCH(ctx, DM_PROF_SVD_OTHER, svd_extract3_kernel, dim3((L + T + 255) / 256, maxnm, nch), dim3(256), 0, ctx->stream, Z3,

@@ -89,7 +89,11 @@ def test_svd_properties_all_m(step):
             I = X @ ibs[mi, fi].reshape(L, K)[:, :n]
             worst["pinv"] = max(worst["pinv"], np.abs(I - np.eye(n)).max())
     assert worst["rows"] < 1e-12, worst
-    assert worst["orth"] < 1e-11, worst    # Jacobi stops at |cos| <= 1e-13 per 64-row block pair
+    # Blocks with more rows than sky columns go through the transposed matrix: there the Jacobi
+    # sweeps make the LEFT vectors orthogonal (|cos| <= 1e-13) and beam_svd = U^H (w B) is a product, as in the reference
+    # (beam = ut3 . bfr, beamtransfer.py:877) — a kept mode at svcut = 1e-6 of sigma_1 then carries eps sigma_1 / sigma_i
+    # ~ 1e-10 of the dominant rows, in LAPACK's U as here.  (The wide blocks rotate the rows of beam_svd themselves: 1e-13.)
+    assert worst["orth"] < 1e-9, worst
     assert worst["proj"] < 1e-12, worst
     assert worst["pinv"] < 1e-8, worst     # kappa(beam_svd) = 1/svcut = 1e6 amplifies eps
 

@@ -67,7 +67,7 @@ def test_fisher_file(setup):
         pass
 
     orig_modes = kl.modes_m
-    kl.modes_m = lambda mi, threshold=None: orig_modes(mi, threshold) if mi in mlist else (None, None)
+    kl.modes_m = lambda mi, threshold=None, device=False: orig_modes(mi, threshold, device=device) if mi in mlist else (None, None)
     orig_ndof = bt.ndof
     bt.ndof = lambda mi: orig_ndof(mi) if mi in mlist else 0
     orig_dev = bt._dev_products
