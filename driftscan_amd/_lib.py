@@ -180,9 +180,13 @@ class Context(object):
             pass
 
     def check(self, rc, what=""):
-        if rc < 0:
+        """Raise on every non-zero status of the C ABI: < 0 argument/runtime errors, > 0 the LAPACK-`info`-like numerical
+        failures (an eigen-iteration that did not converge, a B that stays indefinite) — none of the entry points hands
+        back usable products with one (a chain that went on after a failed Gram eigenproblem would be silently wrong)."""
+        if rc != 0:
             msg = self.lib.dm_last_error(self.h)
-            raise DriftMIError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+            kind = "failed" if rc < 0 else "numerical failure, info ="
+            raise DriftMIError("%s %s (%d): %s" % (what, kind, rc, msg.decode() if msg else ""))
         return rc
 
     def sync(self):

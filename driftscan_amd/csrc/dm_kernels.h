@@ -119,6 +119,13 @@ struct dm_jac_problem {
   int gc0, gc1;   // Gram column range (one-sided) / Hermitian block origin (two-sided)
 };
 
+// Householder columns whose squared norm is below this are left alone (tau = 0): sqrt(|alpha|^2 + |x|^2) of such a
+// column underflows towards 0 and tau = (beta - alpha) / beta turns into 0/0.  Matrices with exactly zero rows get there:
+// the rounding residue of one reflector is reflected again by the next sweep of the bulge chase (1e-16, 1e-32, ... of
+// the norm of the matrix), and after ten sweeps the residue of the residue is below 1e-160.  LAPACK's zlarfg rescales
+// instead; here the column is at most 1e-145 in magnitude and dropping it is a backward error far below rounding.
+constexpr double DM_REFL_TINY = 1e-290;
+
 // Orthogonalise rows (one-sided).  On return sigma[p][0..nrows) holds the row
 // norms over the Gram columns, rows sorted by descending norm (rows physically
 // permuted).  `sigma` is a device array with `sigma_stride` doubles per problem.

@@ -243,7 +243,7 @@ __device__ __forceinline__ cplx sb_from_lane(cplx v, int src) {
 // Householder scalars from alpha and the squared norm of the rest (zlarfg), every lane the same
 __device__ __forceinline__ trd_refl sb_reflector(double xnorm2, cplx alpha) {
   trd_refl R;
-  if (xnorm2 == 0.0 && alpha.y == 0.0) {
+  if ((xnorm2 == 0.0 && alpha.y == 0.0) || alpha.x * alpha.x + alpha.y * alpha.y + xnorm2 < DM_REFL_TINY) {
     R.tau = make_double2(0.0, 0.0);
     R.beta = alpha.x;
     R.scal = make_double2(0.0, 0.0);

@@ -345,9 +345,9 @@ extern "C" int dm_svd_chain_lmin(dm_ctx* ctx, int nblk, int F, int T, int P, int
         pt[c] = dm_jac_problem{Yt + yoff[c], T, 0, tall[c] ? P * geo[c].Lc : 0, T, 0, T};
       int swt = 0;
       // The Gram matrices of these problems have exactly zero rows and columns (sky columns beyond a frequency's band
-      // limit): a batch of ~350 of them came back WRONG from the two-stage tridiagonalisation (a slice of the low
-      // frequencies of 10+ blocks; smaller batches, and the dense Gram matrices of the wide chains, are fine) — cause not
-      // found this round, DESIGN.md section 7.  The one-stage reduction is as fast at n ~ 450 and is taken here.
+      // limit) — what exposed the underflow in the Householder scalars of the band chase (DM_REFL_TINY, dm_kernels.h).
+      // Both reductions are right now; the one-stage one is as fast at n ~ 450 (2.64 against 2.63 s on 14 blocks at
+      // m = 300) and stays the default of this call, DM_SVD_TALL_TWOSTAGE=1 leaves the choice to the size policy.
       dm_jac_rows_opts ot = o1;
       static const bool tall_two_stage = getenv("DM_SVD_TALL_TWOSTAGE") != nullptr;
       ot.one_stage_eig = !tall_two_stage;

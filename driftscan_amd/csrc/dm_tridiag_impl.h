@@ -65,7 +65,7 @@ struct trd_refl { cplx tau, scal; double beta; };
 __device__ __forceinline__ trd_refl trd_reflector_from(double npart_lane, cplx alpha) {
   const double xnorm2 = dm_wave_sum(npart_lane);
   trd_refl R;
-  if (xnorm2 == 0.0 && alpha.y == 0.0) {
+  if ((xnorm2 == 0.0 && alpha.y == 0.0) || alpha.x * alpha.x + alpha.y * alpha.y + xnorm2 < DM_REFL_TINY) {
     R.tau = make_double2(0.0, 0.0);
     R.beta = alpha.x;
     R.scal = make_double2(0.0, 0.0);
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(TST) void trd_small_kernel(const trs_mat* __restric
     const cplx alpha = make_double2(al.x, -al.y);
     double beta;
     cplx tau, scal;
-    if (xnorm2 == 0.0 && alpha.y == 0.0) {
+    if ((xnorm2 == 0.0 && alpha.y == 0.0) || alpha.x * alpha.x + alpha.y * alpha.y + xnorm2 < DM_REFL_TINY) {
       tau = make_double2(0.0, 0.0);
       beta = alpha.x;
       scal = make_double2(0.0, 0.0);

@@ -221,6 +221,31 @@ def test_herm_eig_is_scale_invariant(ctx, n, scale):
     assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("twostage", ["0", "1"])
+def test_herm_eig_with_exactly_zero_rows(ctx, monkeypatch, twostage):
+    """Gram matrices in which most rows and columns are exactly zero (the tall SVD chains of blocks with l < m columns
+    dropped get there; so does any rank-deficient covariance): the rounding residue of a reflector over a zero column is
+    reflected again by every later sweep of the band chase and falls through the underflow threshold — the Householder
+    scalars of such a column were 0/0 (NaN tridiagonals, "QL did not converge", status 1000 + p) until columns below
+    DM_REFL_TINY were left alone.  Both reductions, eigenvalues to rounding and unitary vectors."""
+    monkeypatch.setenv("DM_TRD_TWOSTAGE", twostage)
+    rng = np.random.default_rng(5)
+    n, K, nb = 452, 864, 4
+    G = np.zeros((nb, n, n), dtype=np.complex128)
+    for b in range(nb):
+        A = crand(rng, n, K)
+        A[rng.permutation(n)[: int(0.95 * n)]] = 0.0
+        G[b] = A @ A.conj().T
+    ref = np.linalg.eigvalsh(G)
+    ev, W = ctx.herm_eig(ctx.to_device(G.copy()), n, n, strideC=n * n, batch=nb)
+    got = np.sort(ev.cpu().numpy()[:, :n], axis=1)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+    Wh = W.cpu().numpy()
+    for b in range(nb):
+        assert np.abs(Wh[b] @ Wh[b].conj().T - np.eye(n)).max() < 1e-12
+
+
 def test_herm_eig_mixed_sizes_via_eigh_gen(ctx):
     """Different n in one batch (the KL use: ndof varies with m)."""
     from driftscan_amd._lib import block_offsets
