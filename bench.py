@@ -678,8 +678,9 @@ def measure_share(workload, share, files=False, share_mmax=None, truncate=False,
             for kl in pm.kltransforms.values():
                 kl.signal(); kl.foreground()
             t_cl = time.perf_counter() - t0
-            ctx.prof_reset(2)      # every kernel class of the path
-            bt.stage_log = []      # per BT-gen range / SVD batch / KL batch: wall seconds + kernel classes (device idle at the boundaries)
+            noprof = os.environ.get("DRIFT_BENCH_NOPROF") == "1"   # (what the event pairs and the idle points of the stage log cost)
+            ctx.prof_reset(0 if noprof else 2)      # every kernel class of the path
+            bt.stage_log = None if noprof else []   # per BT-gen range / SVD batch / KL batch: wall seconds + kernel classes (device idle at the boundaries)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             pm.generate()

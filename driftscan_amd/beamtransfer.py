@@ -289,19 +289,21 @@ class BeamTransfer(config.Reader):
         the SVD chain follows the number of l >= m, the KL stage its cube (ndof falls with m)."""
         x = float(self.telescope.lmax + 1 - m) / float(self.telescope.lmax + 1)
         # Round 5: the SVD chain works on the columns l >= m only and forms cross Gram blocks, so its cost falls faster
-        # with m than the linear term of rounds 3-4 said — a cubic part of its own (rows^2 x columns).  Least-squares fit of
-        # flat + linear + cubic to the kernel seconds of the eight configs[2] shares of that build
-        # (profiles/r05e_configs2_shares.json: 0.090 + 0.360 x + 0.387 x^3 seconds per block, of which 0.19 units are the
-        # KLTransform's as before).
+        # with m than the linear term of rounds 3-4 said.  The coefficients are what reproduces the boundaries that the
+        # MEASURED seconds per block of two full sets of configs[2] shares ask for (profiles/r05t_configs2_shares.json and
+        # the set before it, with different boundaries: both give (0, 28) (29, 58) (59, 92) (93, 130) (131, 176) (177, 235)
+        # (236, 315) (316, 512) when the per-share densities are re-partitioned; grid search over the coefficients with
+        # the SHT coupling of `_my_ms` in the loop).  One unit is about 0.49 s on an MI355X; 0.19 units x^3 are the
+        # KLTransform's (`kl_cost_weight`: DoubleKL and the Fisher stage raise it).
         tel = self.telescope
         P, T = int(tel.num_pol_sky), int(self.ntel)
         if P > 1 and P * (tel.lmax + 1 - m) * 100 <= T * 95:
             # a TALL block (more rows than sky columns l >= m: dm_svd_chain_lmin takes SVD1 through the transposed matrix, a
-            # P (L - m)-square Gram eigenproblem instead of a T-square one): 0.050 + 0.16 x + 0.30 x^2 seconds per block on the
-            # configs[2] shares (profiles/r05*_configs2_shares.json, share 7/8 and the m = 400 / 480 batches of
-            # scratch/svd_phase_probe.py), in the units of the line below
-            return 0.081 + 0.26 * x + 0.49 * x * x + self.kl_cost_weight * x ** 3
-        return 0.15 + 0.60 * x + (0.455 + self.kl_cost_weight) * x ** 3
+            # P (L - m)-square Gram eigenproblem instead of a T-square one): close to linear in x — SVD batches at
+            # m = 300 / 400 / 480 take 0.19 / 0.10 / 0.015 s per block (scratch/svd_phase_probe.py), BT-gen 0.024 s, less
+            # what the ring transform skips at high m (bt_ring_skip_lookup: 1.5 s of the last share)
+            return 0.03 + 0.92 * x + self.kl_cost_weight * x ** 3
+        return 0.15 + 0.90 * x + (0.36 + self.kl_cost_weight) * x ** 3
 
     def _my_ms(self, mlist=None):
         """m-blocks owned by this rank: ONE contiguous range with (nearly) the same summed cost on every rank

@@ -317,6 +317,10 @@ __device__ __forceinline__ void bt_synth_complex(const double* __restrict__ a, c
     m_re[3] = -sv.y; m_im[3] = sv.x;   // 1j * tc * (p01 - p10)
   }
 }
+// smallest |m| among the rows lo .. hi of a ring-transform pass (rows [0, cnt) are +m_lo + row, rows [cnt, 2 cnt) the -m)
+__device__ __forceinline__ int bt_pass_min_m(int lo, int hi, int m_lo, int cnt) {
+  return hi < cnt ? m_lo + lo : (lo >= cnt ? m_lo + lo - cnt : m_lo);
+}
 __global__ __launch_bounds__(256) void bt_fdft_pre_kernel(fdft_col* __restrict__ cols, int ncol, const double* __restrict__ omega) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= ncol) return;
@@ -326,7 +330,7 @@ template <int P, int NMG, int NCG, bool CB = false>
 __global__ __launch_bounds__(256) void bt_fused_dft_kernel(ring_geo g, frame3 fr, const double* __restrict__ beams, size_t bstride,
                                                            const fdft_col* __restrict__ cols, int ncol16, int m_lo, int cnt,
                                                            const double* __restrict__ ring_w, cplx* __restrict__ G, int ncp,
-                                                           const int* __restrict__ ring_list) {
+                                                           const int* __restrict__ ring_list, const int* __restrict__ mskip) {
   constexpr int NCOMP = P == 4 ? 2 : 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = ring_list ? ring_list[blockIdx.y] : (int)blockIdx.y;   // (the polar caps only, when the belt goes by FFT)
@@ -338,6 +342,9 @@ __global__ __launch_bounds__(256) void bt_fused_dft_kernel(ring_geo g, frame3 fr
   const int nphi = g.nphi[r];
   const double phi0 = g.phi0[r], st = g.sth[r], ct = g.cth[r];
   const int pix0 = g.start[r];
+  // rows whose |m| has reached mskip[r] are exact zeros (bt_ring_skip_lookup); a pass that holds only such rows does no work
+  const int msk = mskip ? mskip[r] : 0x7fffffff;
+  const int nloop = bt_pass_min_m(mg0 * 4, min(nm, (mg0 + NMG) * 4) - 1, m_lo, cnt) >= msk ? 0 : nphi;
   // m-values of this lane's twiddle rows: rows [0, cnt) are +m, rows [cnt, 2 cnt) are -m
   int mval[NMG];
   bool mok[NMG];
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(256) void bt_fused_dft_kernel(ring_geo g, frame3 fr
 #pragma unroll
   for (int a = 0; a < NMG; ++a) tw_re[a] = tw_im[a] = 0.0;
   int step = 0;
-  for (int q = 0; q < nphi; q += 4, ++step) {
+  for (int q = 0; q < nloop; q += 4, ++step) {
     const int j = q + k;
     const bool pv = j < nphi;
     const int jj = pv ? j : nphi - 1;
@@ -470,9 +477,10 @@ __global__ __launch_bounds__(256) void bt_fused_dft_kernel(ring_geo g, frame3 fr
     for (int a = 0; a < NMG; ++a) {
       const int mm = (mg0 + a) * 4 + i;
       if (mm >= nm) continue;
+      const double wz = (mm < cnt ? m_lo + mm : m_lo + mm - cnt) >= msk ? 0.0 : w;
       cplx* out = G + ((size_t)mm * g.nring + r) * ncp + (size_t)col;
 #pragma unroll
-      for (int p = 0; p < P; ++p) dm_stg(out, (size_t)p * (ncp / P), make_double2(w * acc_re[c][a][p], w * acc_im[c][a][p]));
+      for (int p = 0; p < P; ++p) dm_stg(out, (size_t)p * (ncp / P), make_double2(wz * acc_re[c][a][p], wz * acc_im[c][a][p]));
     }
   }
 }
@@ -491,7 +499,7 @@ template <int P, int NMG, int NCG, bool CB = false>
 __global__ __launch_bounds__(256) void bt_fused_dft2_kernel(ring_geo g, frame3 fr, const double* __restrict__ beams, size_t bstride,
                                                             const fdft_col* __restrict__ cols, int ncol16, int m_lo, int cnt,
                                                             const double* __restrict__ ring_w, cplx* __restrict__ G, int ncp,
-                                                            const int* __restrict__ ring_list) {
+                                                            const int* __restrict__ ring_list, const int* __restrict__ mskip) {
   constexpr int NCOMP = P == 4 ? 2 : 1;
   constexpr int QC = 4;  // quads per chunk = waves per workgroup
   const int lane = threadIdx.x & 63;
@@ -502,6 +510,13 @@ __global__ __launch_bounds__(256) void bt_fused_dft2_kernel(ring_geo g, frame3 f
   const int nm = 2 * cnt;
   const int mg0 = (blockIdx.z * 4 + wave) * NMG;  // first group of four m-values of this wave
   const bool has_m = mg0 * 4 < nm;                // (a wave without m-values still synthesises its quads)
+  // rows whose |m| has reached mskip[r] are exact zeros (bt_ring_skip_lookup): a workgroup whose pass holds only such rows
+  // does no work (uniform: the barriers below are skipped by all four waves), a wave whose own rows are all of that kind
+  // still synthesises its quads for the others but issues no MFMAs
+  const int msk = mskip ? mskip[r] : 0x7fffffff;
+  const int wg_row0 = blockIdx.z * 16 * NMG;
+  const bool wg_skip = bt_pass_min_m(wg_row0, min(nm, wg_row0 + 16 * NMG) - 1, m_lo, cnt) >= msk;
+  const bool use_m = has_m && bt_pass_min_m(mg0 * 4, min(nm, (mg0 + NMG) * 4) - 1, m_lo, cnt) < msk;
   const int k = lane >> 4, t = lane & 3;
   const int nphi = g.nphi[r];
   const double phi0 = g.phi0[r], st = g.sth[r], ct = g.cth[r];
@@ -539,7 +554,7 @@ __global__ __launch_bounds__(256) void bt_fused_dft2_kernel(ring_geo g, frame3 f
     sincos(2.0 * kPi * (double)m4 / (double)nphi, &rot_im[a], &rot_re[a]);
     tw_re[a] = tw_im[a] = 0.0;
   }
-  const int nchunk = (nphi + 4 * QC - 1) / (4 * QC);
+  const int nchunk = wg_skip ? 0 : (nphi + 4 * QC - 1) / (4 * QC);
   for (int ch = 0; ch < nchunk; ++ch) {
     const int buf = ch & 1;
     // ---- synthesis of quad `wave` of this chunk, all NCG groups
@@ -592,7 +607,7 @@ __global__ __launch_bounds__(256) void bt_fused_dft2_kernel(ring_geo g, frame3 f
       }
     }
     __syncthreads();
-    if (!has_m) continue;  // (wave-uniform; the barrier above is still reached every chunk)
+    if (!use_m) continue;  // (wave-uniform; the barrier above is still reached every chunk)
     // ---- this wave's m-values over the four quads of the chunk
 #pragma unroll
     for (int qi = 0; qi < QC; ++qi) {
@@ -653,9 +668,10 @@ __global__ __launch_bounds__(256) void bt_fused_dft2_kernel(ring_geo g, frame3 f
     for (int a = 0; a < NMG; ++a) {
       const int mm = (mg0 + a) * 4 + i;
       if (mm >= nm) continue;
+      const double wz = (mm < cnt ? m_lo + mm : m_lo + mm - cnt) >= msk ? 0.0 : w;
       cplx* out = G + ((size_t)mm * g.nring + r) * ncp + (size_t)col;
 #pragma unroll
-      for (int p = 0; p < P; ++p) dm_stg(out, (size_t)p * (ncp / P), make_double2(w * acc_re[c][a][p], w * acc_im[c][a][p]));
+      for (int p = 0; p < P; ++p) dm_stg(out, (size_t)p * (ncp / P), make_double2(wz * acc_re[c][a][p], wz * acc_im[c][a][p]));
     }
   }
 }
@@ -1046,6 +1062,49 @@ static const bt_alias_info& bt_alias_lookup(int nside, int lmax, bool pol, const
   }
   info.mlim.resize(info.ia, -1);
   return cache.emplace(key, std::move(info)).first->second;
+}
+
+// ---- rings that carry nothing at high m ------------------------------------------------------------------------------
+// lambda_lm(z_r) (and the spin-2 W, X) fall off super-exponentially once m exceeds l sin(theta_r): on the rings next to the
+// poles every l <= lmax is past its turning point from m = lmax sin(theta) on, and from some m on the whole table column
+// of the ring is below rounding.  mskip[r] = the first m from which max_l |table| < kRingSkipEps for good: the ring
+// transform G_m[r] of such (m, ring) pairs multiplies table entries that cannot move a coefficient by a tenth of an ulp
+// (the sum over at most 4 nside rings of 1e-18 x the scale of the kept terms), so it is neither computed nor stored as
+// anything but zero — libsharp's `mlim` rule of healpy.map2alm, here with the bound computed from the tables themselves.
+// The decision is per (m, ring), a function of (nside, lmax, polarised) alone: any partition of m over ranks and any
+// pass structure of the kernels gives the same bits.  A rank that owns m = 315 .. 512 of configs[2] (nside 256) skips
+// 3/4 of the cap work of its ring transform.
+constexpr double kRingSkipEps = 1e-18;
+
+static const std::vector<int>& bt_ring_skip_lookup(int nside, int lmax, bool pol, const double* cth, const double* sth) {
+  static std::mutex mu;
+  static std::map<std::tuple<int, int, bool>, std::vector<int>> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  const auto key = std::make_tuple(nside, lmax, pol);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  const int nring = 4 * nside - 1;
+  std::vector<int> ms(nring, lmax + 1);
+  for (int r = 0; r <= nring / 2; ++r) {
+    const double z = cth[r], st = sth[r];
+    int lo = std::min(lmax + 1, (int)std::ceil((double)lmax * st) + 1);   // candidates: lo .. lmax + 1 (= never skipped)
+    int hi = lmax + 1;
+    if (lo <= lmax && bt_table_peak(lmax, lmax, z, st, pol) < kRingSkipEps) {
+      // beyond the turning point the peak falls monotonically with m: bisect for the first m below the threshold
+      int a = lo, b = lmax;   // invariant: peak(b) < eps
+      while (a < b) {
+        const int mid = (a + b) / 2;
+        if (bt_table_peak(lmax, mid, z, st, pol) < kRingSkipEps) b = mid; else a = mid + 1;
+      }
+      hi = b;
+      // (guard against a non-monotonic stretch right at the boundary: step up while any of the next few m is above)
+      for (int m = hi; m <= std::min(lmax, hi + 3); ++m)
+        if (bt_table_peak(lmax, m, z, st, pol) >= kRingSkipEps) hi = m + 1;
+    }
+    ms[r] = hi;
+    ms[nring - 1 - r] = hi;
+  }
+  return cache.emplace(key, std::move(ms)).first->second;
 }
 
 // out[idx] = in[idx] * sc[idx % nring]   (tables scaled by the per-ring factor of A o S)
@@ -1486,11 +1545,18 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
         }
       }
     }
+    // (m, ring) pairs below rounding: exact zeros, no work (bt_ring_skip_lookup; DM_BT_RING_SKIP=0 computes them all)
+    const bool ring_skip_off = getenv("DM_BT_RING_SKIP") && atoi(getenv("DM_BT_RING_SKIP")) == 0;   // (read per call: the tests flip it)
+    const int* d_mskip = nullptr;
+    if (!ring_skip_off && nring_dft > 0) {
+      d_mskip = dm_ws_upload(ctx, bt_ring_skip_lookup(nside, lmax_grp, polarised != 0, ring_cth_host, ring_sth_host));
+      if (!d_mskip) return DM_ENOMEM;
+    }
     auto launch = [&](auto kern, int NMG, int NCG) {
       if (nring_dft == 0) return;
       const dim3 grid((unsigned)((ncol16 + 4 * NCG - 1) / (4 * NCG)), (unsigned)nring_dft, (unsigned)((nmg + NMG - 1) / NMG));
       DM_PLAUNCH(ctx, DM_PROF_BT_RING, kern, grid, dim3(256), 0, ctx->stream, gh.g, fr, syn->beams_dev, bstride, d_fc, ncol16, m_lo, cnt, d_rw, G,
-                         ncp, d_caps);
+                         ncp, d_caps, d_mskip);
     };
     // 32 complex accumulators per lane (64 AGPRs) keep two waves per SIMD: the sincos of one wave runs under
     // the MFMAs of the other
@@ -1501,7 +1567,7 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
       if (nring_dft == 0) return;
       const dim3 grid((unsigned)((ncol16 + NCG - 1) / NCG), (unsigned)nring_dft, (unsigned)((nmg + 4 * NMG - 1) / (4 * NMG)));
       DM_PLAUNCH(ctx, DM_PROF_BT_RING, kern, grid, dim3(256), 0, ctx->stream, gh.g, fr, syn->beams_dev, bstride, d_fc, ncol16, m_lo, cnt, d_rw, G,
-                         ncp, d_caps);
+                         ncp, d_caps, d_mskip);
     };
     static const int shared_env = getenv("DM_FDFT_SHARED") ? atoi(getenv("DM_FDFT_SHARED")) : 1;
     if (polarised) {

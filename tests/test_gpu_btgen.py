@@ -159,6 +159,28 @@ def test_beam_m_sht_iterations_and_ring_weights(ctx, pol, niter):
 
 
 @pytest.mark.parametrize("pol", [False, True])
+def test_ring_skip_is_below_rounding(ctx, pol, monkeypatch):
+    """(m, ring) pairs whose Legendre table column is below 1e-18 are neither transformed nor stored (libsharp's `mlim`
+    rule behind healpy.map2alm, here from the tables themselves: bt_ring_skip_lookup): the blocks with every pair
+    computed (DM_BT_RING_SKIP=0, read per call) differ by less than an ulp of the largest coefficient, at every m."""
+    from driftscan_amd import btgen
+
+    t = _tel(pol, cylinder_width=4.0, num_feeds=3, feed_spacing=0.5)
+    new = btgen.beam_m_all(t, ctx=ctx).cpu().numpy()
+    monkeypatch.setenv("DM_BT_RING_SKIP", "0")
+    old = btgen.beam_m_all(t, ctx=ctx).cpu().numpy()
+    monkeypatch.delenv("DM_BT_RING_SKIP")
+    assert old.shape == new.shape
+    scale = np.abs(old).max()
+    assert np.abs(new - old).max() <= 2e-16 * scale
+    # ... and relative to each block's own scale (the high-m blocks are the ones that lose rings)
+    for m in range(old.shape[0]):
+        sm = np.abs(old[m]).max()
+        if sm > 0:
+            assert np.abs(new[m] - old[m]).max() <= 1e-14 * sm, m
+
+
+@pytest.mark.parametrize("pol", [False, True])
 def test_fft_belt_and_fold_against_the_matrix_form(ctx, pol, tmp_path):
     """The round-3 ring transform (FFT in LDS on the equatorial belt, matrix-form sums on the caps) and the north/south
     fold of the Legendre stage against the round-2 path (matrix form on every ring, no fold; DM_BT_FFT=0 DM_BT_FOLD=0 —
