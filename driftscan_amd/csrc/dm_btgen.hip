@@ -1488,14 +1488,23 @@ static int bt_sht_impl(dm_ctx* ctx, int nside, const double* ring_cth_host, cons
     const int nmg = (nm + 3) / 4;  // groups of four m-values
     // The belt (rings nside - 1 .. 3 nside - 1, all with N = 4 nside pixels) goes by FFT when N is a power of two and the
     // P maps of a column fit the LDS; the matrix-form kernels below then see the rings of the two caps only.  The choice
-    // depends on nside and P alone — never on the m-range — so that any partition of m gives the same bits.
+    // depends on nside, P and on whether the call is narrow (below) — not on WHICH m it asks for.
     static const bool fft_off = getenv("DM_BT_FFT") && atoi(getenv("DM_BT_FFT")) == 0;
     const int N = 4 * nside;
     int fft_logn = 0;
     while ((1 << fft_logn) < N) ++fft_logn;
     const int fft_sh = std::max(5, fft_logn - 6);   // padding of the LDS arrays, as in the kernel
     const size_t fft_lds = sizeof(cplx) * ((size_t)P * (N + (N >> fft_sh) + 1) + (N / 2 + ((N / 2) >> fft_sh) + 1));
-    const bool use_fft = !fft_off && nside >= 2 && (N & (N - 1)) == 0 && N <= 4096 && fft_lds <= 160u * 1024u - 256u;
+    // A NARROW call (at most DM_BT_NARROW = 8 m-values: one pass of the shared-synthesis kernel) keeps the matrix form on
+    // the belt too: the FFT computes every m of a ring whether wanted or not — 14 CU-cycles per (pixel, column) at nside
+    // 512 with four maps (150 KB of LDS: one workgroup per CU) against ~1 per group of four m-rows on the matrix pipe.
+    // One m-block of configs[4] (59.6 GB: a rank holds one or two at a time) 24.8 -> 4.6 s of ring transform
+    // (scratch/btgen_narrow_probe.py: 784 -> 146 ms on 8 of the 256 frequencies; 4 m-values 833 -> 229, 8: 1039 -> 555).
+    // The two forms round differently (2e-13 of the largest coefficient): blocks are the same BITS for any partition
+    // of m whose calls are all wide, and equal to rounding when narrow calls are involved.
+    static const int narrow_max = getenv("DM_BT_NARROW") ? atoi(getenv("DM_BT_NARROW")) : 8;
+    const bool narrow = cnt <= narrow_max;
+    const bool use_fft = !fft_off && !narrow && nside >= 2 && (N & (N - 1)) == 0 && N <= 4096 && fft_lds <= 160u * 1024u - 256u;
     int nring_dft = nring;
     const int* d_caps = nullptr;
     if (use_fft) {
