@@ -52,9 +52,10 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
     # (the key carries everything the band limits and resolutions follow from: a telescope changed after a first call
     # gets new ones; `TransitTelescope.__getstate__` keeps the memo out of the telescope pickle)
     memo = tel.__dict__.setdefault("_btgen_memo", {})
-    mkey = (f_list.tobytes(), b_list.tobytes(), lside, float(tel.l_boost), float(tel.accuracy_boost), int(tel.num_pol_sky),
+    mkey = (f_list.tobytes(), b_list.tobytes(), row_f.tobytes(), row_b.tobytes(), lside, float(tel.l_boost), float(tel.accuracy_boost), int(tel.num_pol_sky),
             np.asarray(tel.wavelengths, dtype=np.float64).tobytes(), np.asarray(tel.baselines, dtype=np.float64).tobytes(),
-            float(getattr(tel, "u_width", 0.0)), float(getattr(tel, "v_width", 0.0)))
+            float(getattr(tel, "u_width", 0.0)), float(getattr(tel, "v_width", 0.0)),
+            np.asarray(tel.beamclass).tobytes(), np.asarray(tel.uniquepairs).tobytes())
     if mkey not in memo:
         if len(memo) > 8:
             memo.clear()
@@ -63,6 +64,7 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
             raise ValueError("a baseline's natural lmax exceeds the telescope lmax (force_lmax too small)")
         memo[mkey] = (lmax_bf, _nside_of(tel, lmax_bf))
     lmax_bf, nsides = memo[mkey]
+    cmemo = tel.__dict__.setdefault("_btgen_chunk_memo", {})
     pairs = tel.uniquepairs
     cls = np.asarray(tel.beamclass)
     wl = tel.wavelengths
@@ -111,19 +113,29 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
         order = sel[np.lexsort((row_b[sel], row_f[sel]))]
         for c0 in range(0, order.size, ncol_max):
             cols = order[c0 : c0 + ncol_max]
-            # distinct (frequency, beam class) beams of this chunk
-            keys = {}
-            feed_of = {}
-            bi = np.empty(cols.size, dtype=np.int32)
-            bj = np.empty(cols.size, dtype=np.int32)
-            for k, c in enumerate(cols):
-                fi_, fj_ = pairs[b_list[c]]
-                for which, feed in ((bi, fi_), (bj, fj_)):
-                    key = (int(f_list[c]), int(cls[feed]))
-                    if key not in keys:
-                        keys[key] = len(keys)
-                        feed_of[key] = int(feed)
-                    which[k] = keys[key]
+            # distinct (frequency, beam class) beams of this chunk and the per-column constants: they follow from the column
+            # list alone and are remembered with it (27 648 columns per chunk at configs[2]: the Python loop below is
+            # tens of milliseconds of idle GPU per call otherwise)
+            ckey = (mkey, int(nside), int(c0), int(ncol_max))
+            if ckey not in cmemo:
+                if len(cmemo) > 64:
+                    cmemo.clear()
+                keys = {}
+                feed_of = {}
+                bi = np.empty(cols.size, dtype=np.int32)
+                bj = np.empty(cols.size, dtype=np.int32)
+                for k, c in enumerate(cols):
+                    fi_, fj_ = pairs[b_list[c]]
+                    for which, feed in ((bi, fi_), (bj, fj_)):
+                        key = (int(f_list[c]), int(cls[feed]))
+                        if key not in keys:
+                            keys[key] = len(keys)
+                            feed_of[key] = int(feed)
+                        which[k] = keys[key]
+                cmemo[ckey] = (keys, feed_of, bi, bj, np.ascontiguousarray(tel.baselines[b_list[cols]] / wl[f_list[cols]][:, None]),
+                               np.ascontiguousarray(row_f[cols]), np.ascontiguousarray(row_b[cols]),
+                               np.ascontiguousarray(lmax_bf[cols]), int(lmax_bf[cols].max()))
+            keys, feed_of, bi, bj, uv, rf_c, rb_c, lm_c, lm_top = cmemo[ckey]
             ncomp = 2 if pol else 1
             # the reference's plug-in interface: beam(feed, freq) evaluated by the telescope class on the host
             # (telescope.py:954-973 keys the maps by beam class as here), uploaded once
@@ -147,21 +159,20 @@ def fill_beam_m(tel, beam_m, f_list, b_list, row_f=None, row_b=None, F=None, B=N
             # all device-evaluated patterns of the chunk in one call (geometry and tables staged once)
             ctx.bt_beams_cyl(int(nside), cth, sth, frame, dev_specs, beams, dev_rows)
             del hostb
-            uv = tel.baselines[b_list[cols]] / wl[f_list[cols]][:, None]
             if fused:
                 # (with the refinement every chunk of the group is transformed against the GROUP's band limit: the set of
                 # aliased (ring, m) pairs follows from it, and the bits of a block must not depend on how the columns were
                 # chunked — the chunking depends on the m-range of the caller)
                 ctx.bt_columns(int(nside), cth, sth, frame, pol, beams, uv, bi, bj, lside, mmax,
-                               lgrp if niter else int(lmax_bf[cols].max()), F, B,
-                               row_f[cols], row_b[cols], lmax_bf[cols], beam_m, m_range=m_range,
+                               lgrp if niter else lm_top, F, B,
+                               rf_c, rb_c, lm_c, beam_m, m_range=m_range,
                                ring_w=None if ringw is None else ringw.get(int(nside)), niter=niter)
                 del beams
                 continue
             maps = ctx.empty((cols.size, P, npix), np.complex128)
             ctx.bt_maps(int(nside), cth, sth, frame, pol, beams, uv, bi, bj, maps)
-            ctx.bt_sht(int(nside), cth, sth, pol, lside, mmax, lgrp if niter else int(lmax_bf[cols].max()), F, B, row_f[cols],
-                       row_b[cols], lmax_bf[cols], maps, beam_m, m_range=m_range, niter=niter,
+            ctx.bt_sht(int(nside), cth, sth, pol, lside, mmax, lgrp if niter else lm_top, F, B, rf_c,
+                       rb_c, lm_c, maps, beam_m, m_range=m_range, niter=niter,
                        ring_w=None if ringw is None else ringw.get(int(nside)))
             del maps, beams
     return beam_m

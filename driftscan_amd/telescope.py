@@ -106,6 +106,7 @@ class TransitTelescope(config.Reader):
         per-process memo of BT-gen band limits."""
         state = dict(self.__dict__)
         state.pop("_btgen_memo", None)
+        state.pop("_btgen_chunk_memo", None)
         return state
     _npol_sky_ = 1
 
