@@ -305,7 +305,7 @@ __global__ __launch_bounds__(JNT) void jac_inner_kernel(const jac_item* __restri
 
   // ---- cyclic Jacobi, 63 parallel steps of 32 disjoint rotations per sweep
   for (int sweep = 0; sweep < 24; ++sweep) {
-    if (tid == 0) ctl[0] = 0;
+    if (tid == 0) { ctl[0] = 0; ctl[33] = 0; }
     __syncthreads();
     for (int step = 0; step < 63; ++step) {
       // phase A: rotation parameters
@@ -403,7 +403,26 @@ __global__ __launch_bounds__(JNT) void jac_inner_kernel(const jac_item* __restri
       __syncthreads();
     }
     if (ctl[0] == 0) break;
+    // Would the next sweep rotate anything?  It applies the test of phase A to every pair, and a sweep that finds no
+    // pair active changes nothing — so one parallel pass over G with the same test decides, instead of 63 steps of two
+    // barriers each that only confirm convergence (the same Q bit for bit; a pair solve is 2 - 3 rotating sweeps, the
+    // confirming one was a quarter to a third of the kernel).
+    {
+      bool need = false;
+      for (int idx = tid; idx < JP * JP; idx += JNT) {
+        const int r = idx >> 6, c = idx & 63;
+        if (r < c) {
+          const cplx g = G[r * GP + c];
+          const double ag = sqrt(g.x * g.x + g.y * g.y);
+          if (ag > 0.0 && ag > absfloor && ag > tol_inner * sqrt(fabs(G[r * GP + r].x * G[c * GP + c].x))) need = true;
+        }
+      }
+      if (need) ctl[33] = 1;  // benign race: all writers store 1
+    }
     __syncthreads();
+    const int go = ctl[33];
+    __syncthreads();
+    if (!go) break;
   }
 
   cplx* Qo = Qbuf + (size_t)it.q * JP * JP;
