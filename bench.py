@@ -1128,7 +1128,11 @@ def north_star_leg(args):
             shares.append(slow)
     live, retried = {}, None
     try:
-        for sh_ in shares:
+        for k_, sh_ in enumerate(shares):
+            # the driver wipes what the previous process freed in the background, and the first large allocations of the
+            # next one wait for it (scratch/shares_all.py: 2-3 s in front of the BT-gen kernels, once an out-of-memory);
+            # a rank of a real job starts on an idle card
+            time.sleep(float(os.environ.get("DRIFT_BENCH_NS_PAUSE", "10")))
             live[sh_], rt = _share_child(args, sh_)
             retried = retried or rt
     except Exception as e:   # reporting only
