@@ -947,6 +947,7 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
   // hundred of them, spread over 8 more decades: 30 sweeps).  So the preconditioner is applied again to
   // just those rows — their own Gram matrix resolves another 8 decades relative to THEIR largest norm —
   // and once more below that; each level costs a fraction of one sweep.
+  std::vector<char> placed(np, 0);   // subspace mode: a level of the preconditioner placed the cut of this problem
   {
     std::vector<size_t> goff(np);
     size_t gtot = 0;
@@ -1090,12 +1091,18 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
         lvl_on[p] = 0;
         if (!(ev[0] > 0.0)) continue;
         int i = 0;
-        while (i < ns && ev[i] >= 1e-9 * ev[0]) ++i;
+        // (subspace mode: the level below begins at margin x cut of the largest row norm if that is higher than the
+        // regular boundary — the rows next to the cut then get a level of their own)
+        const double sm2 = O.subspace_cut > 0.0 ? O.subspace_margin * O.subspace_margin * O.subspace_cut * O.subspace_cut : 0.0;
+        const double bound = std::max(1e-9 * ev[0], level == 0 ? sm2 * ev[0] : 0.0);
+        while (i < ns && ev[i] >= bound) ++i;
         const double e4 = 4.0 * 2.220446049250313e-16;
         // worth a level only when the rows below span several row blocks: a sweep costs ~(row blocks)^2, and up
         // to one pair of blocks the inner Jacobi solver sorts them out in LDS anyway (config 2: T = 92 rows)
-        if (ns - i <= level_min_rows || i == 0) continue;
-        if (1e-9 * ev[0] <= e4 * e4 * ev0[p]) continue;  // what is left is rounding residue of the largest rows
+        // subspace mode: this level begins within margin x cut of the largest row norm — the cut is placed
+        if (O.subspace_cut > 0.0 && ev[0] <= sm2 * ev0[p] * (1.0 + 1e-9)) { placed[p] = 1; continue; }
+        if (ns - i <= level_min_rows || i == 0) continue;   // (subspace mode: not placed — the sweeps below do it)
+        if (bound <= e4 * e4 * ev0[p]) continue;  // what is left is rounding residue of the largest rows
         if (O.drop_below > 0.0 && ev[i] <= O.drop_below * O.drop_below * ev0[p] * 1e-2) continue;  // nobody wants them
         sub0[p] += i;
         lvl_on[p] = 1;
@@ -1113,6 +1120,14 @@ int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double
   }
 
   dbg_mark("level: W Z + rest");
+  if (O.subspace_cut > 0.0) {
+    // the problems whose cut is placed are done: their rows are unitary mixtures of the input rows, split at the cut to
+    // the accuracy a converged SVD would give; the others (too few rows for a level of their own, level cap) are swept
+    bool ch = false;
+    for (int p = 0; p < np; ++p)
+      if (placed[p] && active[p]) { active[p] = 0; ch = true; }
+    if (ch) DM_TRY(dm_upload(ctx, d_active, active.data(), sizeof(int) * np));
+  }
   if (O.drop_below > 0.0) {
     // rows below the caller's level of interest leave the tournament (they sit at the end: the levels are
     // ordered by scale and sorted inside)

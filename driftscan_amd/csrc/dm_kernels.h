@@ -139,6 +139,20 @@ struct dm_jac_rows_opts {
   bool unconverged = false;
   double drop_below = 0.0;
   bool one_stage_eig = false;   // the Gram eigenproblems of the preconditioner levels on the one-stage tridiagonalisation
+  // > 0: the caller only splits the rows at subspace_cut * (largest row norm) and keeps one side as a SUBSPACE (the image
+  // of SVD1, the null space of SVD2: whatever orthonormal basis the next phase is handed, its products are the same).
+  // The preconditioner then stops at the first level whose Gram eigenvalues resolve the cut (a level with largest
+  // eigenvalue e_top places a row norm s to eps e_top / s^2 relative), and no Jacobi sweep follows: the rows are
+  // unitary mixtures of the input rows either way, sorted by norm; what a converged SVD would add is the order
+  // INSIDE the two sides.
+  double subspace_cut = 0.0;
+  // ... how far above the cut the LAST level may begin (in units of the cut): a pair of rows (i, j) on the two sides of the
+  // cut comes out of a level whose largest row norm is s_top with a residual angle eps s_top^2 / |s_i^2 - s_j^2|, and
+  // what leaks across the cut is that angle times the row.  SVD2 (cut 1e-4, rows of all sizes next to it: 5e-9 of
+  // sigma_max in the final spectrum when the split is left to the first level) asks for 100: the level that places the
+  // cut holds the rows below 1e-2 of the largest, angles <= 1e-12 / (relative gap) as from a converged SVD; SVD1 (cut
+  // 1e-10: whatever leaks is of that size itself) takes the regular level boundaries.
+  double subspace_margin = 3.2e5;
 };
 int dm_jacobi_rows(dm_ctx* ctx, const std::vector<dm_jac_problem>& probs, double* sigma, int sigma_stride,
                    int* sweeps_out = nullptr, const dm_jac_rows_opts* opts = nullptr);

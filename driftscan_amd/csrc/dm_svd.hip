@@ -323,6 +323,9 @@ extern "C" int dm_svd_chain_lmin(dm_ctx* ctx, int nblk, int F, int T, int P, int
     dm_jac_rows_opts o1;
     o1.unconverged = true;
     o1.drop_below = 1e-12;
+    // SVD1 hands its IMAGE to SVD2 (the rows above the cut, as a subspace): DM_SVD_SUBSPACE=0 converges it as an SVD
+    const bool subspace = !getenv("DM_SVD_SUBSPACE") || atoi(getenv("DM_SVD_SUBSPACE")) != 0;   // (read per call: the tests flip it)
+    if (subspace) o1.subspace_cut = 1e-10;
     if (ntall < nch) DM_TRY(dm_jacobi_rows(ctx, pr, sig, T, &sw, &o1));
     if (sweeps_host) sweeps_host[0] = sw;
     DM_TRY(dm_download(ctx, hs.data(), sig, sizeof(double) * hs.size()));
@@ -349,6 +352,7 @@ extern "C" int dm_svd_chain_lmin(dm_ctx* ctx, int nblk, int F, int T, int P, int
       // Both reductions are right now; the one-stage one is as fast at n ~ 450 (2.64 against 2.63 s on 14 blocks at
       // m = 300) and stays the default of this call, DM_SVD_TALL_TWOSTAGE=1 leaves the choice to the size policy.
       dm_jac_rows_opts ot = o1;
+      ot.subspace_cut = 0.0;   // the rows of Yt become sigma_i u_i^H only when they are ORTHOGONAL: a converged SVD, not a split
       static const bool tall_two_stage = getenv("DM_SVD_TALL_TWOSTAGE") != nullptr;
       ot.one_stage_eig = !tall_two_stage;
       DM_TRY(dm_jacobi_rows(ctx, pt, sigt, T, &swt, &ot));
@@ -415,6 +419,10 @@ extern "C" int dm_svd_chain_lmin(dm_ctx* ctx, int nblk, int F, int T, int P, int
                      : dm_jac_problem{Z + geo[c].zoff, geo[c].ldz, 0, r1[c], geo[c].ldz, geo[c].Lc, P * geo[c].Lc};
     dm_jac_rows_opts o2;
     o2.unconverged = true;
+    if (subspace && polsvcut > 0.0 && polsvcut <= 1e-3) {   // SVD2 hands its null space (the rows below the cut) to SVD3
+      o2.subspace_cut = polsvcut;
+      o2.subspace_margin = 100.0;
+    }
     DM_TRY(dm_jacobi_rows(ctx, pr, sig, T, &sw, &o2));
     if (sweeps_host) sweeps_host[1] = sw;
     DM_TRY(dm_download(ctx, hs.data(), sig, sizeof(double) * hs.size()));

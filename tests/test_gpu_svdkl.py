@@ -202,6 +202,47 @@ def test_svd_chain_wide_dynamic_range(ctx):
         assert np.abs(b1 @ i1 - np.eye(n)).max() < 1e-8  # kappa = 1 / svcut
 
 
+def test_svd_chain_subspace_phases_match_converged_ones(ctx, monkeypatch):
+    """SVD1 hands its image and SVD2 its null space to the next phase as SUBSPACES: the products do not depend on the
+    basis inside them, so those two phases stop when the preconditioner level that holds the rows next to the cut has
+    placed it, without Jacobi sweeps (`dm_jac_rows_opts::subspace_cut`; a configs[2] batch 4.47 -> 3.39 s).  Against the
+    converged phases (DM_SVD_SUBSPACE=0) on a block with several hundred rows below 1e-8 sigma_1 and polarised singular
+    values on both sides of `polsvcut`: the same spectrum to 1e-12 sigma_max — the north-star tolerance is 1e-10; the
+    first version, which left SVD2's split to the first level, was at 5e-9 — and the same row spaces."""
+    rng = np.random.default_rng(78)
+    F, B, P, L = 2, 200, 4, 120
+    T = 2 * B
+    beam = np.zeros((F, T, P, L), dtype=np.complex128)
+    for f in range(F):
+        u = np.linalg.qr(rng.standard_normal((T, T)) + 1j * rng.standard_normal((T, T)))[0]
+        v = np.linalg.qr(rng.standard_normal((L, L)) + 1j * rng.standard_normal((L, L)))[0]
+        beam[f, :, 0, :] = (u[:, :L] * 10.0 ** np.linspace(0, -15, L)) @ v.conj().T
+        r = T // 2
+        a = np.linalg.qr(rng.standard_normal((T, r)) + 1j * rng.standard_normal((T, r)))[0]
+        c = rng.standard_normal((r, 3 * L)) + 1j * rng.standard_normal((r, 3 * L))
+        beam[f, :, 1:, :] = ((a * 10.0 ** np.linspace(0, -9, r)) @ c).reshape(T, 3, L) * 0.05   # polarised part: sigma over 9 decades
+    nw = rng.uniform(0.5, 2.0, (F, T))
+    polsvcut = 1e-4
+    dev = ctx.to_device(beam[None])
+    fast = ctx.svd_chain(dev, ctx.to_device(nw), polsvcut)
+    monkeypatch.setenv("DM_SVD_SUBSPACE", "0")
+    full = ctx.svd_chain(dev, ctx.to_device(nw), polsvcut)
+    monkeypatch.delenv("DM_SVD_SUBSPACE")
+    assert (fast["nmodes"] == full["nmodes"]).all() and fast["nmodes"].min() > 10
+    s0, s1 = full["singularvalues"].cpu().numpy()[0], fast["singularvalues"].cpu().numpy()[0]
+    assert np.abs(s0 - s1).max() <= 1e-12 * s0.max()
+    keep = s0 > 1e-6 * s0.max(axis=1, keepdims=True)
+    assert (np.abs(s0 - s1)[keep] <= 1e-10 * s0[keep]).all()
+    assert fast["sweeps"][0] == 0 or fast["sweeps"][0] < full["sweeps"][0]   # SVD1 placed its cut without sweeps
+    for f in range(F):
+        n = int((s0[f] > 1e-6 * s0[f].max()).sum())
+        b0 = full["beam_svd"].cpu().numpy()[0, f, :n].reshape(n, -1)
+        b1 = fast["beam_svd"].cpu().numpy()[0, f, :n].reshape(n, -1)
+        assert relerr(b1.T.conj() @ b1, b0.T.conj() @ b0) < 1e-9
+        u1 = fast["beam_ut"].cpu().numpy()[0, f, :n] / nw[f][None, :]
+        assert np.abs(u1 @ u1.conj().T - np.eye(n)).max() < 1e-12
+
+
 def test_svd_chain_frequency_slices(ctx, gold):
     """The (m, frequency) chains are independent: pushing the frequencies through the library in slices
     (what a CHIME-sized block needs, 111 GB of augmented matrices otherwise) changes nothing."""
