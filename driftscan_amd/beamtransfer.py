@@ -290,11 +290,12 @@ class BeamTransfer(config.Reader):
         x = float(self.telescope.lmax + 1 - m) / float(self.telescope.lmax + 1)
         # Round 5: the SVD chain works on the columns l >= m only and forms cross Gram blocks, so its cost falls faster
         # with m than the linear term of rounds 3-4 said.  The coefficients are what reproduces the boundaries that the
-        # MEASURED seconds per block of two full sets of configs[2] shares ask for (profiles/r05t_configs2_shares.json and
-        # the set before it, with different boundaries: both give (0, 28) (29, 58) (59, 92) (93, 130) (131, 176) (177, 235)
-        # (236, 315) (316, 512) when the per-share densities are re-partitioned; grid search over the coefficients with
-        # the SHT coupling of `_my_ms` in the loop).  One unit is about 0.49 s on an MI355X; 0.19 units x^3 are the
-        # KLTransform's (`kl_cost_weight`: DoubleKL and the Fisher stage raise it).
+        # MEASURED seconds per block of full sets of configs[2] shares ask for (the per-share densities re-partitioned;
+        # grid search over the coefficients with the SHT coupling of `_my_ms` in the loop): first on
+        # profiles/r05t_configs2_shares.json and the set before it, then — SVD1 / SVD2 as subspace phases took a quarter off
+        # the wide chains and little off the tall ones — on the set of that build, which asks for (0, 25) (26, 54) (55, 86)
+        # (87, 123) (124, 170) (171, 231) (232, 316) (317, 512).  0.19 units x^3 are the KLTransform's (`kl_cost_weight`:
+        # DoubleKL and the Fisher stage raise it).
         tel = self.telescope
         P, T = int(tel.num_pol_sky), int(self.ntel)
         if P > 1 and P * (tel.lmax + 1 - m) * 100 <= T * 95:
@@ -302,8 +303,8 @@ class BeamTransfer(config.Reader):
             # P (L - m)-square Gram eigenproblem instead of a T-square one): close to linear in x — SVD batches at
             # m = 300 / 400 / 480 take 0.19 / 0.10 / 0.015 s per block (scratch/svd_phase_probe.py), BT-gen 0.024 s, less
             # what the ring transform skips at high m (bt_ring_skip_lookup: 1.5 s of the last share)
-            return 0.03 + 0.92 * x + self.kl_cost_weight * x ** 3
-        return 0.15 + 0.90 * x + (0.36 + self.kl_cost_weight) * x ** 3
+            return 0.92 * x + self.kl_cost_weight * x ** 3
+        return 0.10 + 0.60 * x + (0.36 + self.kl_cost_weight) * x ** 3
 
     def _my_ms(self, mlist=None):
         """m-blocks owned by this rank: ONE contiguous range with (nearly) the same summed cost on every rank
