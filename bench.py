@@ -633,6 +633,13 @@ def job_budgets(toy=False):
                 kl=float(os.environ.get("DRIFT_BENCH_KL_GB", "110")), arena=float(os.environ.get("DRIFTMI_WORKSPACE_GB", "100")))
 
 
+def storage_io_stats():
+    """Seconds the writer pipeline of this process spent where (summed over its threads), `storage.io_stats`."""
+    from driftscan_amd import storage
+
+    return {k: (round(v, 3) if isinstance(v, float) else v) for k, v in storage.io_stats().items()}
+
+
 def measure_share(workload, share, files=False, share_mmax=None, truncate=False, outdir=None):
     """BASELINE configs[2] / configs[3] — the north-star job — through ProductManager.generate(): rank r of N is
     emulated in this process (`parallel.set_virtual`: its contiguous, cost-balanced range of m; no process group), so
@@ -736,6 +743,7 @@ def measure_share(workload, share, files=False, share_mmax=None, truncate=False,
                     note="the covariance projections (B_f o C_l) B_f'^H of the KL stage (gathered-B grouped ZGEMM), "
                          "8 M N K flops per product over the HIP-event time of its launches"),
                 "hbm_peak_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+                "io": storage_io_stats() if files else None,
                 "roofline": None, "cpu_baseline": None,
             }
             del pm

@@ -20,6 +20,7 @@ configured back-end.
 import ctypes
 import os
 import threading
+import time
 
 import numpy as np
 
@@ -814,19 +815,44 @@ class Deferred:
 
     def host(self):
         torch = self.ctx.torch
+        t0 = time.perf_counter()
         with torch.cuda.device(self.ctx.device):
             h = torch.empty(self.t.shape, dtype=self.t.dtype, pin_memory=True)
+            t1 = time.perf_counter()
             s = _copy_stream(self.ctx)
             s.wait_event(self.event)
             with torch.cuda.stream(s):
                 h.copy_(self.t, non_blocking=True)
             s.synchronize()
+        t2 = time.perf_counter()
+        _io_stat("pinned_alloc_s", t1 - t0)
+        _io_stat("copy_wait_and_transfer_s", t2 - t1)
+        _io_stat("copied_bytes", self.nbytes)
         self.t = self.event = None
         return h.numpy()
 
 
 _copy_streams = {}
 _copier = None
+# where the writer pipeline spends its time (seconds summed over its threads; `io_stats()`): the copy thread's page-locked
+# allocations and transfers, its waits for room on the host, the writer threads' closures (gather + compress + HDF5)
+_io_stats = {}
+_io_stats_lock = threading.Lock()
+
+
+def _io_stat(key, val):
+    with _io_stats_lock:
+        _io_stats[key] = _io_stats.get(key, 0.0) + val
+
+
+def io_stats(reset=False):
+    with _io_stats_lock:
+        out = dict(_io_stats)
+        if reset:
+            _io_stats.clear()
+    return out
+
+
 # what the queue holds: host bytes (products copied or being copied, until their file is written), tasks, and device
 # bytes (deferred products not yet copied, other than `resident` ones)
 _cv = threading.Condition()
@@ -916,11 +942,14 @@ def submit(fn, *args):
         pool, copier = _pool, _copier
 
     def write():
+        t0 = time.perf_counter()
         try:
             return fn(*write.args)
         finally:
             write.args = None
             _release(host=nbytes, count=1)
+            _io_stat("writer_closure_s", time.perf_counter() - t0)
+            _io_stat("files", 1)
 
     if deferred:
         dev = sum(a.nbytes for a in deferred if not a.resident)
@@ -934,7 +963,9 @@ def submit(fn, *args):
         def copy():
             got = False
             try:
+                t0 = time.perf_counter()
                 _host_acquire(nbytes, nthreads)
+                _io_stat("copy_thread_wait_for_host_room_s", time.perf_counter() - t0)
                 got = True
                 write.args = _resolve(args)
             except BaseException:
