@@ -744,6 +744,10 @@ def measure_share(workload, share, files=False, share_mmax=None, truncate=False,
                          "8 M N K flops per product over the HIP-event time of its launches"),
                 "hbm_peak_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
                 "io": storage_io_stats() if files else None,
+                "stage_log": None if not bt.stage_log else [dict(stage=r_["stage"], m0=r_["ms"][0] if r_["ms"] else None, n=len(r_["ms"]),
+                                                                 seconds=round(r_["seconds"], 3),
+                                                                 kernel_s=round(sum(v["ms"] for v in r_["classes"].values()) * 1e-3, 3))
+                                                            for r_ in bt.stage_log],
                 "roofline": None, "cpu_baseline": None,
             }
             del pm

@@ -313,6 +313,11 @@ def _svd_chain(self, beam_m, noisew, polsvcut, skip_svd_inv=False, max_bytes=Non
     ``max_bytes`` (default: DRIFTMI_SVD_CHUNK_GB, 96) the frequencies go through the library in slices."""
     nblk, F, T, P, L = [int(x) for x in beam_m.shape]
     K = min(L, T)
+    _tm = os.environ.get("DRIFTMI_TIMING") == "1"   # (host-side stopwatch of this call on stderr: allocation / library / copies)
+    if _tm:
+        import sys
+        import time
+        self.sync(); _t0 = time.perf_counter(); _tc = 0.0
     out = dict(
         beam_svd=self.empty((nblk, F, K, P, L), np.complex128),
         invbeam_svd=None if skip_svd_inv else self.empty((nblk, F, P, L, K), np.complex128),
@@ -342,9 +347,13 @@ def _svd_chain(self, beam_m, noisew, polsvcut, skip_svd_inv=False, max_bytes=Non
             singularvalues=self.empty((nblk, f1 - f0, K), np.float64))
         nmodes = (c_int * max(nblk * (f1 - f0), 1))()
         sweeps = (c_int * 4)()
+        if _tm:
+            self.sync(); _t1 = time.perf_counter()
         rc = self.lib.dm_svd_chain_lmin(self.h, nblk, f1 - f0, T, P, L, lm, self.ptr(bm), self.ptr(nw), float(polsvcut),
                                         self.ptr(o["beam_svd"]), self.ptr(o["invbeam_svd"]), self.ptr(o["beam_ut"]),
                                         self.ptr(o["singularvalues"]), nmodes, sweeps)
+        if _tm:
+            self.sync(); _tc += time.perf_counter() - _t1
         self.check(rc, "dm_svd_chain_lmin")
         nmodes_all[:, f0:f1] = np.array(nmodes[: nblk * (f1 - f0)], dtype=np.int64).reshape(nblk, f1 - f0)
         sweeps_all = [max(a, int(b)) for a, b in zip(sweeps_all, sweeps)]
@@ -355,6 +364,11 @@ def _svd_chain(self, beam_m, noisew, polsvcut, skip_svd_inv=False, max_bytes=Non
             del o, bm
     out["nmodes"] = nmodes_all
     out["sweeps"] = sweeps_all
+    if _tm:
+        self.sync()
+        _tt = time.perf_counter() - _t0
+        sys.stderr.write("[timing] svd_chain %d blocks, %d slice(s): %.3f s, of it %.3f s in the library, %.3f s allocation + copies\n"
+                         % (nblk, -(-F // fc), _tt, _tc, _tt - _tc))
     return out
 
 
