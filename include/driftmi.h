@@ -141,6 +141,11 @@ int dm_herm_eig_batched(dm_ctx* ctx, int n, void* C_dev, int ldc, int64_t stride
  *   sigma_dev    (nblk, F, K) f64         out
  *   nmodes_host  (nblk*F) int             out
  *   sweeps_host  optional int[4]: Jacobi sweeps used by SVD1, SVD2, SVD3, pinv
+ * SVD1 hands its image and SVD2 its null space to the next SVD as orthonormal bases (:826, :844-848): a unitary change of
+ * basis inside either subspace is undone by the next SVD, so on polarised blocks these two phases stop when the cut
+ * (1e-10, polsvcut) is placed to the accuracy of a converged SVD and do not order the rows inside each side
+ * (sweeps_host[0..1] = 0 then; DM_SVD_SUBSPACE=0 converges them).  sigma, nmodes and every product are those of the
+ * reference chain (same spectra to 1e-13 sigma_max).
  * Synchronises.
  * Replaces: BeamTransfer._generate_svdfile_m, drift/core/beamtransfer.py:802-924
  * (matrix_image :68-104, matrix_nullspace :107-143, scipy.linalg.pinv :891). */
