@@ -124,11 +124,13 @@ class ProductManager(object):
         if self.gen_kl and self.kltransforms and "kl_cost_weight" not in yconf["config"]:
             # the cost of an m-block downstream of the SVD chain, for the m-ranges of the ranks: a DoubleKL is two
             # eigenproblems plus, at low m, the non-positive-definite rescue; a Fisher estimator projects every band
-            # (round 4: 0.19 / 0.35 / 0.085 — refitted to the kernel seconds of configs[2] and configs[3] shares after the
-            # large-matrix stages got faster, profiles/r04q_configs{2,3}_share*; round 3 had 0.25 / 0.625 / 0.125)
-            w = sum(0.35 if isinstance(k, doublekl.DoubleKL) else 0.19 for k in self.kltransforms.values())
+            # (round 5: 0.19 / 0.57 / 0.14 in the units of `BeamTransfer._m_cost` — the SVD chain got a third cheaper
+            # this round and the stages behind it did not: the eight configs[3] shares measured with the round-4 weights
+            # (0.19 / 0.35 / 0.085) ran 28.5 .. 25.2 s from rank 0 to rank 7, and their densities re-partitioned ask for a
+            # total of 0.90, profiles/r05z_configs3_shares.json; round 3 had 0.25 / 0.625 / 0.125)
+            w = sum(0.57 if isinstance(k, doublekl.DoubleKL) else 0.19 for k in self.kltransforms.values())
             if self.gen_ps:
-                w += 0.085 * sum(1 for p in self.psestimators.values() if p is not None)
+                w += 0.14 * sum(1 for p in self.psestimators.values() if p is not None)
             self.beamtransfer.kl_cost_weight = float(w)
 
     def generate(self):
