@@ -1484,7 +1484,7 @@ def main():
                     if key in rec:
                         traffic = rec[key]["fetch_bytes_per_launch"] + rec[key]["write_bytes_per_launch"]
                         traffic_src = os.path.relpath(tj[-1], ROOT)
-                mj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_mfma.json")))
+                mj = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_mfma.json")) if "configs2" not in os.path.basename(f))
                 if mj:
                     mrec = json.load(open(mj[-1]))
                     if mrec.get("_build_id") == bid:
