@@ -360,6 +360,42 @@ def test_m_ranges_account_for_the_sht_coupling(tmp_path):
     assert sum(len(p) for p in parts[3][:3]) < sum(len(p) for p in parts[0][:3]) and len(parts[3][-1]) > len(parts[0][-1])
 
 
+def test_north_star_partitions_match_the_committed_share_records(tmp_path):
+    """The m-ranges of the eight ranks of the configs[2] and configs[3] jobs, as `ProductManager` partitions them (cost
+    model of `BeamTransfer._m_cost` + the downstream weights of `ProductManager`: 0.19 KLTransform, 0.57 DoubleKL, 0.14
+    per Fisher estimator), are the ranges the committed all-shares records were measured on — a change of the model
+    without a new record would leave `north_star.projected_job_s` describing another partition."""
+    import glob
+    import json
+    import os
+
+    import yaml
+
+    import bench
+    from driftscan_amd import manager, parallel
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        for wl, pat, w in (("configs2", "*_configs2_shares.json", 0.19), ("configs3", "*_configs3_shares.json", 0.90)):
+            recs = sorted(glob.glob(os.path.join(root, "profiles", pat)))
+            assert recs, pat
+            rec = json.load(open(recs[-1]))
+            conf = bench.job_conf(wl)
+            conf["config"]["output_directory"] = str(tmp_path / wl)
+            cfile = str(tmp_path / (wl + ".yaml"))
+            with open(cfile, "w") as fh:
+                yaml.dump(conf, fh)
+            pm = manager.ProductManager.from_config(cfile)
+            assert abs(pm.beamtransfer.kl_cost_weight - w) < 1e-12
+            for sh in rec["shares"]:
+                r, n = (int(x) for x in sh["share"].split("/"))
+                parallel.set_virtual(r, n)
+                mine = pm.beamtransfer._my_ms()
+                assert [mine[0], mine[-1]] == list(sh["m_range"]), (wl, sh["share"], mine[0], mine[-1], sh["m_range"])
+    finally:
+        parallel.set_virtual(None)
+
+
 def test_rebalance_contiguous_levels_measured_times():
     """`parallel.rebalance_contiguous` (the measured load balancing of `bench.py --mode sharded`): with a cost model the static
     partition does not know — a floor per rank plus a steeply falling cost per item, like the lock-step chains of the small
