@@ -288,9 +288,12 @@ class PSExact(PSEstimation):
         # (nbands, L, F, F) -> (nbands, F, F, L): the contraction index innermost, as dm_project_cov reads it
         cache = self.__dict__.get("_cl_dev")
         if cache is None or cache[0] is not self.clarray or cache[1].device.index != ctx.device:
-            c64 = np.asarray(self.clarray, dtype=np.float64)
-            cache = (self.clarray, ctx.to_device(np.ascontiguousarray(c64.transpose(0, 2, 3, 1))),
-                     bool(np.array_equal(c64, c64.swapaxes(2, 3))))  # f <-> f' symmetry, checked not assumed
+            # uploaded as it lies; the (.., F, F, L) layout and the symmetry test are made on the device (on the host the
+            # strided transposition and comparison of the configs[3] table — 151 MB — are a second of idle GPU per rank)
+            dev0 = ctx.to_device(np.ascontiguousarray(np.asarray(self.clarray, dtype=np.float64)))
+            cache = (self.clarray, dev0.permute(0, 2, 3, 1).contiguous(),
+                     bool(torch.equal(dev0, dev0.transpose(2, 3))))  # f <-> f' symmetry, checked not assumed
+            del dev0
             self.__dict__["_cl_dev"] = cache  # the band tables do not change between batches (151 MB at config 3)
         cl = cache[1]
         F = ctx.fisher(bsvd, svnum, np.array(ms), cl, Ed, eoff, nmodes, ctx.to_device(Vh), voff,

@@ -6,7 +6,7 @@ import bench
 share = sys.argv[1] if len(sys.argv) > 1 else "0/8"
 pr = cProfile.Profile()
 pr.enable()
-line = bench.measure_share("configs2", share)
+line = bench.measure_share(sys.argv[2] if len(sys.argv) > 2 else "configs2", share)
 pr.disable()
 print("share_s", line["share_s"])
 s = io.StringIO()
