@@ -743,6 +743,8 @@ def measure_share(workload, share, files=False, share_mmax=None, truncate=False,
                     note="the covariance projections (B_f o C_l) B_f'^H of the KL stage (gathered-B grouped ZGEMM), "
                          "8 M N K flops per product over the HIP-event time of its launches"),
                 "hbm_peak_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+                "hbm_reserved_peak_gb": torch.cuda.max_memory_reserved() / 2 ** 30,
+                "alloc_retries": int(torch.cuda.memory_stats().get("num_alloc_retries", 0)),   # the caching allocator ran out, emptied its cache and asked the driver again
                 "io": storage_io_stats() if files else None,
                 "stage_log": None if not bt.stage_log else [dict(stage=r_["stage"], m0=r_["ms"][0] if r_["ms"] else None, n=len(r_["ms"]),
                                                                  seconds=round(r_["seconds"], 3),
