@@ -123,13 +123,16 @@ def launch_ranks(args, argv):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    import tempfile
+
     procs = []
+    out0f = tempfile.TemporaryFile()   # rank 0's stdout (detail line + driver line): a file, not a pipe nobody drains
     for r in range(args.gpus):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", DRIFT_BENCH_CHILD="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+                                      stdout=out0f if r == 0 else subprocess.DEVNULL))
     rc = 0
     try:
         while True:
@@ -145,9 +148,11 @@ def launch_ranks(args, argv):
         for p in procs:
             if p.poll() is None:
                 p.kill()   # exactly the PIDs started above
-        out0 = procs[0].stdout.read() or b""   # one JSON line: far below the pipe buffer
         for p in procs:
             p.wait()
+        out0f.seek(0)
+        out0 = out0f.read() or b""
+        out0f.close()
     sys.stdout.write(out0.decode())
     sys.stdout.flush()
     return rc
@@ -353,6 +358,7 @@ def cpu_baseline(tel, bt, kl, blocks, gpu_sv, gpu_ev):
         return dict(value=0.0, unit="m-blocks/s", cores=ncores, kind="port", error=repr(e), sample="failed"), None
     # ---- parity of the GPU spectra against the oracle's, every block
     sv_err, ev_err, ev_over, svnum_eq, kept_eq, kept_escape, worst = 0.0, 0.0, 0.0, True, 0, 0, None
+    kept_rel, kept_n, kept_worst = 0.0, 0, None   # element-wise relative error of the KEPT eigenvalues (lambda_o >= threshold)
     for m in ms:
         ndof, sv_o, ev_o = spectra[m]
         sv_g, ev_g = np.asarray(gpu_sv[m]), np.asarray(gpu_ev[m])
@@ -368,6 +374,12 @@ def cpu_baseline(tel, bt, kl, blocks, gpu_sv, gpu_ev):
             if e / tol > ev_over:
                 ev_over, worst = e / tol, dict(m=int(m), ndof=int(ndof), err=e, pencil_tol=tol)
             ev_err = max(ev_err, e)
+            kp = ev_o >= kl.threshold          # the modes transform_save keeps (kltransform.py:385-398): what goes downstream
+            if kp.any():
+                r_ = np.abs(ev_g[kp] - ev_o[kp]) / ev_o[kp]
+                kept_n += int(kp.sum())
+                if float(r_.max()) > kept_rel:
+                    kept_rel, kept_worst = float(r_.max()), dict(m=int(m), ndof=int(ndof), lambda_o=float(ev_o[kp][int(r_.argmax())]))
             kg, ko = int((ev_g >= kl.threshold).sum()), int((ev_o >= kl.threshold).sum())
             if kg == ko:
                 kept_eq += 1
@@ -411,10 +423,15 @@ def cpu_baseline(tel, bt, kl, blocks, gpu_sv, gpu_ev):
     parity = dict(blocks=len(ms), sv_max_err_over_svmax=sv_err, sv_tol=1e-10, svnum_equal=svnum_eq,
                   ev_blocks_over_pencil_tol=len(over), ev_over_pencil_tol_examined=sens_rec,
                   ev_max_err_over_lambda_max=ev_err, ev_max_err_over_pencil_tol=ev_over, ev_worst=worst,
+                  ev_kept_max_rel_err=kept_rel, ev_kept_modes=kept_n, ev_kept_worst=kept_worst, ev_kept_rel_tol=1e-4,
+                  ev_kept_note="max over the modes with lambda_o >= threshold of |lambda - lambda_o| / lambda_o, element-wise: the "
+                               "reference's own bar is rel 1e-4 (tests/test_functional.py:29-31,209); north_star asks 1e-10",
                   kept_counts_equal=kept_eq, kept_counts_differ_with_an_eigenvalue_within_tol_of_the_cut=kept_escape,
                   kept_counts_differ_otherwise=len(ms) - kept_eq - kept_escape,
-                  green=bool(sv_err <= 1e-10 and svnum_eq and (ev_over <= 1.0 or over_ok) and kept_eq + kept_escape == len(ms)),
-                  green_rule="sigma within 1e-10 sigma_max, svnum equal, kept counts equal (or an eigenvalue within tol of the cut), "
+                  green=bool(sv_err <= 1e-10 and svnum_eq and (ev_over <= 1.0 or over_ok) and kept_eq + kept_escape == len(ms)
+                             and kept_rel <= 1e-4),
+                  green_rule="sigma within 1e-10 sigma_max, svnum equal, kept counts equal (or an eigenvalue within tol of the cut), kept "
+                             "eigenvalues element-wise within rel 1e-4, "
                              "eigenvalues within pencil_tol — or, for the blocks beyond it, within 10 x the measured sensitivity of "
                              "the oracle's own spectrum to a one-ulp perturbation of the block",
                   note="GPU spectra of the timed configuration against the oracle's on the SAME real blocks, all %d of them: "
@@ -1550,6 +1567,12 @@ def main():
                                                 frac=oa / FP64_MFMA_PEAK_TFLOPS, ms_per_step=q["ms"] / args.steps)
                 if mfma_busy is not None:
                     roofline["mfma_busy"] = mfma_busy
+                    # the counter figure of the dominant class itself (the heaviest kernel of the class by MFMA cycles)
+                    pref = {"zgemm_grouped": "zgemm4_grouped_kernel<false, false", "gemm_grouped_realB": "zgemm4_grouped_kernel<true, false",
+                            "dgemm_grouped": "dgemm_grouped_kernel", "jac_gram": "jac_gram_kernel", "jac_apply": "jac_apply_kernel"}.get(dom)
+                    cand = [v for k, v in mfma_busy.items() if pref and k.startswith(pref) and isinstance(v, dict) and "util" in v]
+                    if cand:
+                        roofline["mfma_busy_dominant"] = max(cand, key=lambda v: v.get("mfma_busy_cycles", 0.0))["util"]
                 if valu_busy is not None:
                     roofline["valu_busy"] = valu_busy
             # per-stage fractions of SURVEY.md §8(d): algorithmic work of the stage / its wall time / fp64 MFMA peak
@@ -1626,8 +1649,11 @@ def main():
             if rank == 0:
                 line["north_star"] = ns
         if rank == 0:
-            print(json.dumps(line))
-            sys.stdout.flush()
+            # the full record goes to bench_detail.json and an EARLIER stdout line; the LAST line is the compact driver
+            # line (< 8 KB: contract keys, roofline, cpu_baseline, parity, north_star in scalars)
+            from benchlib import line as benchline
+
+            benchline.emit(line)
     if world > 1 or force_dist:
         import torch.distributed as dist
 
