@@ -14,6 +14,12 @@ _default_ws = None
 _gen = 0  # bumped by reset_context so that every thread drops its closed context
 
 
+def device_index():
+    """The GPU of this process: one process per GPU, LOCAL_RANK picks it; DRIFTMI_DEVICE overrides (several ranks on one
+    card in tests).  The ONE place the choice is made: contexts and the nccl collectives of `parallel` both ask here."""
+    return int(os.environ.get("DRIFTMI_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
 def get_context(workspace_bytes=None):
     """The Context of the calling thread (created on first use).  Raises if no GPU."""
     global _default_ws
@@ -23,8 +29,7 @@ def get_context(workspace_bytes=None):
     if ctx is None:
         from ._lib import Context
 
-        # one process per GPU: LOCAL_RANK picks it; DRIFTMI_DEVICE overrides (several ranks on one card in tests)
-        dev = int(os.environ.get("DRIFTMI_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        dev = device_index()
         if workspace_bytes is None:
             workspace_bytes = _default_ws
         if workspace_bytes is None:

@@ -112,14 +112,27 @@ def io_root():
     return rank0() or _dist() is None
 
 
+def _bind_device():
+    """nccl collectives run on torch's CURRENT device, which is only set once a driftmi Context exists; barriers are reached
+    earlier (ProductManager.from_config, BeamTransfer.__init__, _generate_dirs).  Without this every rank would report
+    device 0 there and the first RCCL barrier of a multi-GPU job would fail with 'Duplicate GPU detected'.  The device is
+    `device.device_index()` — the same choice the contexts make."""
+    import torch
+
+    from . import device
+
+    dev = device.device_index()
+    if torch.cuda.current_device() != dev:
+        torch.cuda.set_device(dev)
+    return dev
+
+
 def barrier():
     d = _dist()
     if d:
         with _timed():
             if d.get_backend() == "nccl":
-                import torch
-
-                d.barrier(device_ids=[torch.cuda.current_device()])
+                d.barrier(device_ids=[_bind_device()])
             else:
                 d.barrier()
 
@@ -135,6 +148,8 @@ def init_from_env(backend=None):
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
+    if backend == "nccl":
+        _bind_device()
     dist.init_process_group(backend=backend)
 
 
@@ -268,7 +283,7 @@ def allreduce_sum(arr):
     t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64))
     with _timed("allreduce"):
         if d.get_backend() == "nccl":
-            t = t.cuda()
+            t = t.cuda(_bind_device())
         d.all_reduce(t)
         out = t.cpu().numpy()
     return out

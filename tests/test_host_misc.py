@@ -485,3 +485,46 @@ def test_batches_are_cut_to_equal_sizes(tmp_path):
     bt.ndof = lambda mi: 3000 if mi < 3 else 1000              # uneven blocks: the even cut must still respect the budget
     for b in kl._batches(list(range(23))):
         assert sum(16.0 * bt.ndof(mi) ** 2 * 16.0 for mi in b) <= kl.kl_chunk_gb * (1 << 30) or len(b) == 1
+
+
+def test_nccl_collectives_bind_the_rank_device_before_any_context(monkeypatch):
+    """ProductManager.from_config / BeamTransfer.__init__ reach barriers before a driftmi Context has set torch's current
+    device: under nccl every rank would then report device 0 ('Duplicate GPU detected').  `parallel` binds the device
+    `device.device_index()` names (LOCAL_RANK, DRIFTMI_DEVICE overriding) before each nccl collective."""
+    import torch
+
+    from driftscan_amd import device
+
+    calls = []
+    state = dict(cur=0)
+
+    class FakeDist(object):
+        group = type("g", (), dict(WORLD=object()))
+
+        @staticmethod
+        def get_backend():
+            return "nccl"
+
+        @staticmethod
+        def barrier(device_ids=None):
+            calls.append(("barrier", tuple(device_ids), state["cur"]))
+
+        @staticmethod
+        def all_reduce(t):
+            calls.append(("all_reduce", state["cur"]))
+
+    monkeypatch.setattr(parallel, "_dist", lambda: FakeDist)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: state["cur"])
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: state.__setitem__("cur", int(d)))
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, dev=None: self)
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    monkeypatch.delenv("DRIFTMI_DEVICE", raising=False)
+    assert device.device_index() == 3
+    parallel.barrier()
+    assert calls[-1] == ("barrier", (3,), 3)
+    state["cur"] = 0
+    parallel.allreduce_sum(np.ones(4))
+    assert calls[-1] == ("all_reduce", 3)
+    monkeypatch.setenv("DRIFTMI_DEVICE", "1")   # several ranks on one card (tests): the override wins
+    parallel.barrier()
+    assert calls[-1] == ("barrier", (1,), 1)

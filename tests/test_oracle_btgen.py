@@ -32,6 +32,35 @@ def test_pixel_kernels_vs_reference(pk):
     assert np.abs(outr - pk["pol_real_xy"]).max() <= 1e-13 * np.abs(pk["pol_real_xy"]).max()
 
 
+def test_pixel_kernels_live_against_the_compiled_reference_extension():
+    """oracle/_ref holds the reference's OWN native extension (drift/util/_fast_tools.pyx compiled by oracle/Makefile; a
+    binary, git-ignored, it travels to the GPU box): the restated pixel kernels against it on seeds the fixture does not
+    hold, at HEALPix pixel counts that exercise the OpenMP reduction."""
+    from oracle import refimport
+
+    ft = refimport.load_fast_tools()
+    if ft is None:
+        pytest.skip("oracle/_ref not built (make -C oracle ref needs the reference tree)")
+    for seed, n in ((11, 1), (12, 257), (13, 12 * 32 * 32)):
+        rng = np.random.default_rng(seed)
+        ap = np.stack([np.arccos(rng.uniform(-1, 1, n)), rng.uniform(0, 2 * np.pi, n)], axis=-1)
+        zen = np.array([np.pi / 2.0 - np.radians(rng.uniform(20.0, 60.0)), 0.0])
+        uv = rng.uniform(-40.0, 40.0, 2)
+        fr = ft.fringe(ap, zen, uv)
+        assert np.abs(ob.fringe(ap, zen, uv) - fr).max() < 1e-11
+        st = rng.uniform(-1, 1, n)
+        assert np.abs(ob.beam_exptan(st, 0.9) - ft.beam_exptan(st, 0.9)).max() < 1e-15
+        hz = ob.horizon(ap, zen).astype(np.float64)
+        bx, by = rng.standard_normal((n, 2)), rng.standard_normal((n, 2))
+        if hz.sum() == 0:
+            continue
+        ref = ft._construct_pol_real(bx, by, fr, hz)
+        assert np.abs(ob.construct_pol_real(bx, by, fr, hz) - ref).max() <= 1e-12 * np.abs(ref).max()
+        bxc, byc = bx * np.exp(0.3j), by * np.exp(-0.7j)
+        refc = ft._construct_pol_complex(bxc, byc, fr, hz)
+        assert np.abs(ob.construct_pol_complex(bxc, byc, fr, hz) - refc).max() <= 1e-12 * np.abs(refc).max()
+
+
 def test_cylinder_beams_vs_reference(pk):
     ap, zen = pk["angpos"], pk["zenith"]
     w, fe, fh = float(pk["cyl_width"]), float(pk["cyl_fwhm_e"]), float(pk["cyl_fwhm_h"])
