@@ -171,7 +171,75 @@ def test_smallest_block_against_oracle_chain(c3):
                       % (ev_o.size - i_g, ev_o.size - i_o))
     assert i_o == i_g or np.abs(ev_o - kl.threshold).min() < tol * np.abs(ev_o).max()
     assert ours[3]["ac"] == ac_o == 0.0
+    kp = ev_o >= kl.threshold
+    if kp.any():
+        rel = np.abs(ours[0][kp] - ev_o[kp]) / ev_o[kp]
+        _log("m 460: %d kept modes, element-wise relative error max %.2e" % (int(kp.sum()), rel.max()))
+        assert rel.max() <= 1e-4
     c3["cs460"], c3["cn460"] = cs, cn
+
+
+@pytest.mark.parametrize("mi", [0, 200])
+def test_low_m_singular_values_against_oracle_chain(c3, mi):
+    """m = 0 and m = 200 (864 x 2052 per frequency: the multi-level Jacobi preconditioner, the subspace phases of SVD1 /
+    SVD2 and — at m = 200, where 4 (L - m) > T — nothing of the transposed tall route; at m = 0 the widest blocks): singular
+    values, nmodes and svnum of frequencies {0, 21, 42, 63} against the oracle's restatement of `_generate_svdfile_m`
+    (beamtransfer.py:802-924) on the SAME beam block (~1.2 s per frequency on the host)."""
+    from oracle import svdchain as osvd
+
+    tel, bt, res, sv, beam = c3["tel"], c3["bt"], c3["res"], c3["sv"], c3["beam"]
+    i = MS.index(mi)
+    fsel = [0, 21, 42, 63]
+    blk = beam[i].cpu().numpy()[fsel]                         # (4, 2, B, P, L)
+    t0 = time.perf_counter()
+    o = osvd.svd_m(blk, bt._noisew()[fsel][:, : tel.nbase], polsvcut=bt.polsvcut, skip_svd_inv=True)
+    smax = sv[i].max()
+    svnum = bt._svd_num(mi)[0]
+    for k, fi in enumerate(fsel):
+        err = np.abs(o["singularvalues"][k] - sv[i, fi]).max() / smax
+        n_o = int((o["singularvalues"][k] > smax * bt.svcut).sum())
+        _log("m %d f %d: singular values vs oracle %.2e of sigma_max, svnum %d (oracle %d), nmodes %d (oracle %d)"
+             % (mi, fi, err, int(svnum[fi]), n_o, int(res["nmodes"][i, fi]), int(o["nmodes"][k]) if "nmodes" in o else -1))
+        assert err < 1e-10
+        assert n_o == int(svnum[fi])
+        if "nmodes" in o:
+            assert int(o["nmodes"][k]) == int(res["nmodes"][i, fi])
+    _log("m %d: oracle chain of 4 frequencies %.1f s" % (mi, time.perf_counter() - t0))
+
+
+def test_m200_kl_spectrum_against_oracle(c3):
+    """m = 200 (ndof ~3750: the two-stage tridiagonalisation, D&C merge nodes beyond LDS, a foreground-dominated pencil):
+    the whole KL spectrum against the oracle's `sn_covariance` + `eigh_gen` (kltransform.py:258-355) fed with OUR SVD
+    products of every frequency, within pencil_tol relative to lambda_max; and ELEMENT-WISE on the kept modes
+    (lambda_o >= threshold, what transform_save writes, kltransform.py:385-398) within the reference's own bar of rel 1e-4
+    (tests/test_functional.py:29-31,209), with the figure logged against north_star's 1e-10."""
+    from oracle import kl as okl
+    from parity_util import assert_spectrum, pencil_sensitivity
+
+    tel, bt, kl, res, sv = c3["tel"], c3["bt"], c3["kl"], c3["res"], c3["sv"]
+    i, mi = MS.index(200), 200
+    bs, bu = res["beam_svd"][i].cpu().numpy(), res["beam_ut"][i].cpu().numpy()
+    t0 = time.perf_counter()
+    cs, cn = okl.sn_covariance(bs, bu, sv[i], kl.signal(), kl.foreground(), kl._npower(1.0), svcut=bt.svcut)
+    t1 = time.perf_counter()
+    ev_o, _, ac_o = okl.kl_transform_m(cs, cn)
+    t2 = time.perf_counter()
+    ours = kl._transform_batch([mi], to_host=True)[0]
+    tol = max(1e-10, 10 * pencil_sensitivity(cs, cn, nrep=1))
+    err = np.abs(ours[0] - ev_o).max() / np.abs(ev_o).max()
+    _log("m 200: ndof %d, oracle covariances %.1f s + eigh %.1f s; KL spectrum vs oracle %.2e of lambda_max (bound %.1e)"
+         % (ev_o.size, t1 - t0, t2 - t1, err, tol))
+    assert ev_o.size == int(bt.ndof(mi))
+    assert_spectrum(ours[0], ev_o, tol, "KL evals m=200")
+    kp = ev_o >= kl.threshold
+    assert kp.any()
+    rel = np.abs(ours[0][kp] - ev_o[kp]) / ev_o[kp]
+    _log("m 200: %d kept modes, element-wise relative error of the kept eigenvalues max %.2e (reference bar 1e-4, north star 1e-10)"
+         % (int(kp.sum()), rel.max()))
+    assert rel.max() <= 1e-4
+    i_o, i_g = int(np.searchsorted(ev_o, kl.threshold)), int(np.searchsorted(ours[0], kl.threshold))
+    assert i_o == i_g or np.abs(ev_o - kl.threshold).min() < tol * np.abs(ev_o).max()
+    assert ours[3]["ac"] == ac_o == 0.0
 
 
 @pytest.mark.parametrize("mi,bound", [(460, 1e-9), (200, 1e-9), (1, 1e-4), (0, 1e-4)])
