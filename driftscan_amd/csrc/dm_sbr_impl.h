@@ -1437,6 +1437,578 @@ __global__ __launch_bounds__(128 * NP) void sb_chase2_kernel(const sb_chase_mat*
   }
 }
 
+// ---- S2 by band position -----------------------------------------------------------------------------------------------
+//
+// sb_chase2_kernel lets a wave pair own a SWEEP and follow its bulge down the band: every task takes its two 32 x 32 blocks
+// from the pair that wrote them one task earlier (store -> L2 -> progress word -> poll -> load: 32 KB per hand-off, 43 GB per
+// launch at configs[1] against 1 GB of bands, more than half of the ~5 us per task).  Here a wave pair owns a POSITION j of
+// the band for ALL sweeps: E_j = A[R_j, R_{j-1}] lives in the registers of the E wave, D_j = A[R_j, R_j] in those of the D
+// wave (R_j(s) = s + 1 + j SB + [0, SB)), and the windows slide by one row and one column per sweep.  The blocks are kept in
+// SLOT coordinates — element (r, c) sits in lane (r & 7, c & 7), register [(r >> 3) & 3][(c >> 3) & 3] — so sliding moves
+// nothing: the slot of the dropped first row / column (r0_old & 31) is where the new last row / column belongs.  What
+// crosses between positions per task (scratch/proto_chase_pos.py is the index-level model of this):
+//   left -> right   the reflector v_{j-1}(s) and its tau                           (E_{j-1} -> E_j; E_j -> D_j inside the pair)
+//   right -> left   E_{j+1}(s - 1)[0, 0] (beta of its reflector: the corner of E_j(s); the rest of E's new last row lies outside
+//                   the band), the first row of E_{j+1}(s - 1) after its task and D_{j+1}(s - 1)[0, 0]: the new last row of D_j(s)
+//   D_j -> E_j      the first column of D_j(s - 1): the new last column of E_j(s)
+// — about 1 KB per task instead of 32 KB, and nothing is written back to the band array at all (AB is read once, at sweep 0;
+// the outputs are d, e and the reflectors).  Everything a neighbour waits for is posted AS SOON AS IT EXISTS: the reflector
+// and beta right after the pivot column is known (before the block itself is updated), the first column and corner of D
+// right after its w vector — the dependent cycle  E_j(s) -> v -> E_{j+1}(s) -> beta -> E_j(s + 1)  only holds a matrix-vector
+// product and the Householder scalars per hop, the rank-1 / rank-2 updates run beside it.
+// NP positions share a workgroup and hand over through LDS mailboxes; at a workgroup boundary the same packets travel as
+// DATA-TAGGED granules {4 bytes of payload, 4 bytes of tag = sweep + 1} written by sc1 stores and polled by sc1 loads
+// (MI355X_MICROARCH.md "handoff-1to1": ~1 us per hop, valid for ANY placement of the two workgroups — no XCD affinity is
+// needed, and none is assumed).  Mailbox depths follow from the dependencies (task (s + 1, j) needs (s, j + 1) and
+// (s + 1, j - 1)): v, beta and the D column are consumed before their writer can come round again (depth 1); the row packet
+// and the D corner can be overtaken by one sweep (depth 2, slot s & 1).
+//
+// Scheduling: one workgroup per entry (matrix, group of NP positions), entries taken by TICKET (atomic counter) in table
+// order — largest matrix first, its groups left to right — so that whatever the dispatch order, the matrix of the lowest
+// unfinished ticket has all its groups resident and makes progress (the host keeps matrices that would not fit the chip
+// in one piece on sb_chase2_kernel).  Every wait gives up after SB_POS_WAIT_TICKS of wall time and raises the error flag,
+// which every other wait polls: the grid always drains.
+struct sb_pos_ctl { int* ticket; const int2* ent; int nent; int* err; char* mail; };
+constexpr int SB_POS_NP = 4;                   // positions (wave pairs) per workgroup
+// bytes of global mailbox per entry: V 1 KB | ROW[2] 2 x 1 KB | DCORN[2] 2 x 64 B | ECORN[2] 2 x 64 B
+constexpr size_t SB_POS_MAIL = 4096;
+constexpr unsigned SB_GM_V = 0u, SB_GM_ROW = 1024u, SB_GM_DCORN = 3072u, SB_GM_ECORN = 3200u;
+constexpr unsigned long long SB_POS_WAIT_TICKS = 10ull * 100000000ull;   // 10 s of the 100 MHz counter
+
+struct sb_pos_box {           // what ONE position publishes inside its workgroup
+  cplx v[SB];                 // reflector of the current sweep by row slot (E wave)
+  cplx tau;
+  cplx ecorn[2];              // E[0, 0] after the task (beta when a reflector was made) (E wave); [s & 1]
+  cplx row[2][SB];            // first row of E after the task, by column slot (E wave); [s & 1]
+  cplx dcol[SB];              // first column of D after the task, by row slot (D wave)
+  double dcorn[2];            // D[0, 0] after the task (D wave); [s & 1]
+  int seqV, seqEc[2], seqRow[2], seqDcol, seqDc[2];   // sweep + 1 of the last post
+};
+
+// one double per lane as two tagged granules in one 16-byte sc1 store; the reader polls until all 64 lanes carry the tag
+__device__ __forceinline__ void sb_g_post(__amdgpu_buffer_rsrc_t rs, unsigned byteoff, double val, unsigned tag) {
+  const long long b = __double_as_longlong(val);
+  sb_u4 w;
+  w.x = (unsigned)(b & 0xffffffffll); w.y = tag; w.z = (unsigned)(b >> 32); w.w = tag;
+  __builtin_amdgcn_raw_buffer_store_b128(w, rs, byteoff, 0, 16);
+}
+__device__ __forceinline__ bool sb_g_wait(__amdgpu_buffer_rsrc_t rs, unsigned byteoff, unsigned tag, double& val, int* err, int code, int lane) {
+  int spins = 0;
+  const unsigned long long t_wait0 = wall_clock64();
+  for (;;) {
+    const sb_u4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, byteoff, 0, 16);
+    const bool ok = (w.y == tag) && (w.w == tag);
+    if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) {
+      val = __longlong_as_double(((long long)w.z << 32) | (long long)w.x);
+      return true;
+    }
+    ++spins;
+    if ((spins & 255) == 0) {
+      if (wall_clock64() - t_wait0 > SB_POS_WAIT_TICKS) {
+        if (lane == 0) atomicCAS(err, 0, code);
+        return false;
+      }
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    }
+  }
+}
+// wait for an LDS sequence word of the workgroup to reach `need`
+__device__ __forceinline__ bool sb_pos_wait(int* word, int need, int* err, int code, int lane) {
+  int spins = 0;
+  const unsigned long long t_wait0 = wall_clock64();
+  for (;;) {
+    if (sb_lds_ld(word) >= need) break;
+    __builtin_amdgcn_s_sleep(1);
+    ++spins;
+    if ((spins & 4095) == 0) {
+      if (wall_clock64() - t_wait0 > SB_POS_WAIT_TICKS) {
+        if (lane == 0) atomicCAS(err, 0, code);
+        return false;
+      }
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return true;
+}
+__device__ __forceinline__ void sb_pos_publish(int* word, int v, int lane) {   // after the payload writes of this wave
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) sb_lds_st(word, v);
+}
+// Register choice by a WAVE-UNIFORM index: one scalar branch into code with static register numbers (a select chain would
+// cost a dozen v_cndmask per value — or, left visible to the optimiser, become ONE load with a dynamic index that sends
+// the whole 32 x 32 block of the wave to scratch memory).
+__device__ __forceinline__ cplx sb_sel4v(cplx x0, cplx x1, cplx x2, cplx x3, int k) {   // (for the few single values)
+  asm("" : "+v"(x0.x), "+v"(x0.y), "+v"(x1.x), "+v"(x1.y), "+v"(x2.x), "+v"(x2.y), "+v"(x3.x), "+v"(x3.y));
+  cplx r = x0;
+  r.x = (k == 1) ? x1.x : r.x; r.y = (k == 1) ? x1.y : r.y;
+  r.x = (k == 2) ? x2.x : r.x; r.y = (k == 2) ? x2.y : r.y;
+  r.x = (k == 3) ? x3.x : r.x; r.y = (k == 3) ? x3.y : r.y;
+  return r;
+}
+#define SB_DISPATCH4(k, CALL)            \
+  do {                                   \
+    switch (k) {                         \
+      case 0: { constexpr int K = 0; CALL; } break; \
+      case 1: { constexpr int K = 1; CALL; } break; \
+      case 2: { constexpr int K = 2; CALL; } break; \
+      default: { constexpr int K = 3; CALL; } break; \
+    }                                    \
+  } while (0)
+
+// Householder scalars and the vector from x (by rows br + 8 a, replicated over the lanes that share the rows), pivot slot o
+__device__ __forceinline__ trd_refl sb_pos_reflector(const cplx (&x)[4], int o, int br, int bc, cplx (&vrow)[4]) {
+  const int oa = o >> 3, ob = o & 7;
+  double sq = 0.0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const bool piv = (a == oa) && (br == ob);
+    sq += piv ? 0.0 : cabs2(x[a]);
+  }
+  const cplx xo = sb_sel4v(x[0], x[1], x[2], x[3], oa);
+  if (bc != 0) sq = 0.0;
+  const cplx t = sb_sum_br(make_double2(sq, 0.0));
+  const double xn2 = __shfl(t.x, 0, 64);
+  const cplx alpha = sb_from_lane(xo, ob * 8);
+  const trd_refl R = sb_reflector(xn2, alpha);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    cplx v = cmul(x[a], R.scal);
+    if ((a == oa) && (br == ob)) v = make_double2(1.0, 0.0);
+    vrow[a] = v;
+  }
+  return R;
+}
+
+// post the reflector of sweep s (LDS: the D wave of this position and the E wave of the next one; the wire when that one
+// lives in another workgroup — tau travels in the place of the leading 1) and keep it for the back-transformation
+__device__ __forceinline__ void sb_pos_post_v(const sb_chase_mat& M, sb_pos_box* me, const cplx (&vrow)[4], cplx tau, int s, int j, int r0,
+                                              bool wire, __amdgpu_buffer_rsrc_t rsM, int lane) {
+  const int br = lane >> 3, bc = lane & 7, o = r0 & 31;
+  if (bc == 0) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) me->v[br + 8 * a] = vrow[a];
+  }
+  if (lane == 0) me->tau = tau;
+  sb_pos_publish(&me->seqV, s + 1, lane);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (wire) {
+    double val = reinterpret_cast<const double*>(me->v)[lane];
+    if ((lane >> 1) == o) val = (lane & 1) ? tau.y : tau.x;
+    sb_g_post(rsM, SB_GM_V + 16u * lane, val, (unsigned)(s + 1));
+  }
+}
+__device__ __forceinline__ void sb_pos_store_v(const sb_chase_mat& M, const sb_pos_box* me, cplx tau, int s, int j, int r0, int lane) {
+  // row gi of the diamond block (G, j), zeros outside the vector
+  const int G = s / SBG, gi = s % SBG;
+  const size_t blk = (size_t)G * M.jb + j;
+  const int k = lane - gi;
+  const cplx vv = (k >= 0 && k < SB) ? me->v[(r0 + k) & 31] : make_double2(0.0, 0.0);
+  dm_stg(M.Vd, (blk * SBG + gi) * SBW + lane, vv);
+  if (lane == 0) M.tau2[blk * SBG + gi] = tau;
+}
+
+// corner of the window of position j at sweep s (> 0): E_{j+1}(s - 1)[0, 0], zero when that position did not run
+__device__ __forceinline__ bool sb_pos_get_corner(sb_pos_box* right, bool remoteR, __amdgpu_buffer_rsrc_t rsR, int n, int s, int j, cplx& corner,
+                                                  int* err, int lane) {
+  corner = make_double2(0.0, 0.0);
+  if (s + (j + 1) * SB >= n) return true;   // position j + 1 did not run sweep s - 1
+  const int sl = (s - 1) & 1;
+  if (remoteR) {
+    double val;
+    if (!sb_g_wait(rsR, SB_GM_ECORN + 64u * sl + 16u * (lane & 1), (unsigned)s, val, err, 100 + s, lane)) return false;
+    corner = make_double2(__shfl(val, 0, 64), __shfl(val, 1, 64));
+  } else {
+    if (!sb_pos_wait(&right->seqEc[sl], s, err, 100 + s, lane)) return false;
+    corner = right->ecorn[sl];
+  }
+  return true;
+}
+__device__ __forceinline__ void sb_pos_post_corner(sb_pos_box* me, cplx corner, int s, bool remoteL, __amdgpu_buffer_rsrc_t rsM, int lane) {
+  const int sl = s & 1;
+  if (lane == 0) me->ecorn[sl] = corner;
+  sb_pos_publish(&me->seqEc[sl], s + 1, lane);
+  if (remoteL && lane < 2) sb_g_post(rsM, SB_GM_ECORN + 64u * sl + 16u * lane, lane ? corner.y : corner.x, (unsigned)(s + 1));
+}
+
+// The E wave of position 0: no block to its left — its "E" is column s of the matrix, a vector
+__device__ __forceinline__ void sb_pos_E0(const sb_chase_mat& M, sb_pos_box* boxes, bool remoteR, __amdgpu_buffer_rsrc_t rsM, __amdgpu_buffer_rsrc_t rsR,
+                                          int* err, int lane) {
+  const int n = M.n;
+  const int br = lane >> 3, bc = lane & 7;
+  sb_pos_box* me = boxes + 1;
+  sb_pos_box* right = boxes + 2;
+  for (int s = 0; s <= n - 2; ++s) {
+    const int r0 = s + 1, o = r0 & 31, oo = s & 31;
+    cplx x[4];
+    if (s == 0) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int r = 1 + ((br + 8 * a - 1) & 31);
+        x[a] = (r < n) ? dm_ldg(M.AB, (size_t)r) : make_double2(0.0, 0.0);
+      }
+    } else {
+      cplx corner;
+      if (!sb_pos_get_corner(right, remoteR, rsR, n, s, 0, corner, err, lane)) return;
+      if (!sb_pos_wait(&me->seqDcol, s, err, 200 + s, lane)) return;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        x[a] = me->dcol[br + 8 * a];
+        if (br + 8 * a == oo) x[a] = corner;
+      }
+    }
+    cplx vrow[4];
+    const trd_refl R = sb_pos_reflector(x, o, br, bc, vrow);
+    sb_pos_post_v(M, me, vrow, R.tau, s, 0, r0, remoteR && s + 1 + SB < n, rsM, lane);
+    if (lane == 0) M.e[s] = R.beta;
+    sb_pos_store_v(M, me, R.tau, s, 0, r0, lane);
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void sb_pos_e_insert(cplx (&e)[4][4], const cplx (&dc)[4], cplx corner, bool rowl, bool coll) {
+  // slot oo = 8 K + oob: the new last row is zero but for the corner, the new last column is the first column of D
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+    if (rowl) e[K][b] = make_double2(0.0, 0.0);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+    if (coll) e[a][K] = dc[a];
+  if (rowl && coll) e[K][K] = corner;
+}
+template <int K>
+__device__ __forceinline__ void sb_pos_col(const cplx (&e)[4][4], cplx (&xs)[4]) {
+#pragma unroll
+  for (int a = 0; a < 4; ++a) xs[a] = e[a][K];
+}
+template <int K>
+__device__ __forceinline__ void sb_pos_row(const cplx (&e)[4][4], cplx (&xs)[4]) {
+#pragma unroll
+  for (int b = 0; b < 4; ++b) xs[b] = e[K][b];
+}
+
+// The E wave of position j >= 1 (local index i in its workgroup).  rsL / rsR: the global mailboxes of the entries to the
+// left / right (read side), rsM: of this entry (write side); remoteL / remoteR: that neighbour lives in another workgroup.
+__device__ __forceinline__ void sb_pos_E(const sb_chase_mat& M, sb_pos_box* boxes, int i, int j, bool remoteL, bool remoteR,
+                                         __amdgpu_buffer_rsrc_t rsL, __amdgpu_buffer_rsrc_t rsM, __amdgpu_buffer_rsrc_t rsR,
+                                         int* err, int lane) {
+  const int n = M.n;
+  const int br = lane >> 3, bc = lane & 7;
+  sb_pos_box* me = boxes + (i + 1);
+  sb_pos_box* left = boxes + i;          // virtual box 0 = the remote left neighbour
+  sb_pos_box* right = boxes + (i + 2);   // virtual box NP + 1 = the remote right neighbour
+  const int s_last = n - 2 - j * SB;
+  cplx e[4][4];
+  // ---- sweep 0: the block from the band (rows >= n are zero)
+  {
+    const int r0 = 1 + j * SB, o = r0 & 31;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int r = r0 + ((br + 8 * a - o) & 31);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int c = r0 - SB + ((bc + 8 * b - o) & 31);
+        e[a][b] = (r < n) ? dm_ldg(M.AB, (size_t)c * SLD + (r - c)) : make_double2(0.0, 0.0);
+      }
+    }
+  }
+  for (int s = 0; s <= s_last; ++s) {
+    const int r0 = s + 1 + j * SB;
+    const int nr = min(SB, n - r0);
+    const int o = r0 & 31, oa = o >> 3, ob = o & 7;
+    const int oo = (r0 - 1) & 31, ooa = oo >> 3, oob = oo & 7;
+    if (s > 0) {
+      // ---- slide: the slot oo takes the new last row (zeros + corner) and the new last column (first column of D_j(s - 1))
+      cplx corner;
+      if (!sb_pos_get_corner(right, remoteR, rsR, n, s, j, corner, err, lane)) return;
+      if (!sb_pos_wait(&me->seqDcol, s, err, 200 + s, lane)) return;
+      cplx dc[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) dc[a] = me->dcol[br + 8 * a];
+      SB_DISPATCH4(ooa, sb_pos_e_insert<K>(e, dc, corner, br == oob, bc == oob));
+    }
+    // ---- v_{j-1}(s)
+    if (remoteL) {
+      double val;
+      if (!sb_g_wait(rsL, SB_GM_V + 16u * lane, (unsigned)(s + 1), val, err, 300 + s, lane)) return;
+      // tau travels in the place of the reflector's leading 1 (slot of the first row of R_{j-1}: o again, SB = 32)
+      const double tx = __shfl(val, 2 * o, 64), ty = __shfl(val, 2 * o + 1, 64);
+      if ((lane >> 1) == o) val = (lane & 1) ? 0.0 : 1.0;
+      reinterpret_cast<double*>(left->v)[lane] = val;
+      if (lane == 0) left->tau = make_double2(tx, ty);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+      if (!sb_pos_wait(&left->seqV, s + 1, err, 300 + s, lane)) return;
+    }
+    cplx vcol[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) vcol[b] = left->v[bc + 8 * b];
+    const cplx taup = left->tau;
+    // ---- w = tau E v_{j-1}: with it the first column of E H_{j-1} is known (v_{j-1} has its 1 in that column's slot)
+    cplx w[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) sb_cfma(acc, e[a][b], vcol[b]);
+      w[a] = cmul(taup, sb_sum_bc(acc));
+    }
+    cplx x[4];
+    {
+      cplx xs[4];
+      SB_DISPATCH4(oa, sb_pos_col<K>(e, xs));
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const cplx t = sb_from_lane(xs[a], (lane & ~7) | ob);
+        x[a] = make_double2(t.x - w[a].x, t.y - w[a].y);
+      }
+    }
+    const bool reflect = nr >= 2;
+    cplx vrow[4];
+    cplx tau = make_double2(0.0, 0.0);
+    double beta = 0.0;
+    if (reflect) {
+      const trd_refl R = sb_pos_reflector(x, o, br, bc, vrow);
+      tau = R.tau;
+      beta = R.beta;
+      // ---- what the neighbours wait for leaves now: v_j to the right (and to the D wave), beta to the left
+      sb_pos_post_v(M, me, vrow, tau, s, j, r0, remoteR && s + 1 + (j + 1) * SB < n, rsM, lane);
+      sb_pos_post_corner(me, make_double2(beta, 0.0), s, remoteL, rsM, lane);
+    } else {
+      // one row left: no reflector; the corner is the row's first entry after the right-multiplication
+      sb_pos_post_corner(me, sb_from_lane(sb_sel4v(x[0], x[1], x[2], x[3], oa), ob * 8), s, remoteL, rsM, lane);
+    }
+    // ---- E <- E H_{j-1}
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) sb_cfms_cb(e[a][b], w[a], vcol[b]);
+    if (reflect) {
+      // ---- E <- H_j^H E; the annihilated column keeps beta on top (its other entries leave the window at the next slide)
+      cplx y[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) sb_cfma_ca(acc, vrow[a], e[a][b]);
+        y[b] = cmul(cconj(tau), sb_sum_br(acc));
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) sb_cfms(e[a][b], vrow[a], y[b]);
+    }
+    // ---- the first row of the block goes left: the new last row of D_{j-1}(s + 1)
+    {
+      const int sl = s & 1;
+      cplx rw[4];
+      SB_DISPATCH4(oa, sb_pos_row<K>(e, rw));
+      if (br == ob) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) me->row[sl][bc + 8 * b] = rw[b];
+      }
+      sb_pos_publish(&me->seqRow[sl], s + 1, lane);
+      if (remoteL) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        sb_g_post(rsM, SB_GM_ROW + 1024u * sl + 16u * lane, reinterpret_cast<const double*>(me->row[sl])[lane], (unsigned)(s + 1));
+      }
+    }
+    if (reflect) sb_pos_store_v(M, me, tau, s, j, r0, lane);
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void sb_pos_d_insert(cplx (&d)[4][4], const cplx (&rw)[4], const cplx (&cl)[4], double dcn, bool rowl, bool coll) {
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+    if (rowl) d[K][b] = rw[b];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+    if (coll) d[a][K] = cl[a];
+  if (rowl && coll) d[K][K] = make_double2(dcn, 0.0);
+}
+// the first column of D after the rank-2 update, from the lanes that own it (bc == ob): d - v conj(w_o) - w conj(v_o), v_o = 1
+template <int K>
+__device__ __forceinline__ void sb_pos_d_firstcol(const cplx (&d)[4][4], const cplx (&vrow)[4], const cplx (&wv)[4], const cplx (&wc)[4], cplx (&col)[4]) {
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    cplx t = d[a][K];
+    sb_cfms_cb(t, vrow[a], wc[K]);
+    t.x -= wv[a].x; t.y -= wv[a].y;
+    col[a] = t;
+  }
+}
+
+// D[0, 0] after the task: d[s + 1] of the tridiagonal for position 0, the new corner of D_{j-1}(s + 1) otherwise
+__device__ __forceinline__ void sb_pos_post_dcorn(const sb_chase_mat& M, sb_pos_box* me, double dc, int s, int j, bool remoteL,
+                                                  __amdgpu_buffer_rsrc_t rsM, int lane) {
+  if (j == 0) {
+    if (lane == 0) M.d[s + 1] = dc;
+  } else {
+    const int sl = s & 1;
+    if (lane == 0) me->dcorn[sl] = dc;
+    sb_pos_publish(&me->seqDc[sl], s + 1, lane);
+    if (remoteL) sb_g_post(rsM, SB_GM_DCORN + 64u * sl, dc, (unsigned)(s + 1));   // (all lanes write the same 16 bytes)
+  }
+}
+
+// The D wave of position j
+__device__ __forceinline__ void sb_pos_D(const sb_chase_mat& M, sb_pos_box* boxes, int i, int j, bool remoteL, bool remoteR,
+                                         __amdgpu_buffer_rsrc_t rsM, __amdgpu_buffer_rsrc_t rsR, int* err, int lane) {
+  const int n = M.n;
+  const int br = lane >> 3, bc = lane & 7;
+  sb_pos_box* me = boxes + (i + 1);
+  sb_pos_box* right = boxes + (i + 2);
+  const int s_last = n - 2 - j * SB;
+  cplx d[4][4];
+  {
+    const int r0 = 1 + j * SB, o = r0 & 31;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int r = r0 + ((br + 8 * a - o) & 31);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int c = r0 + ((bc + 8 * b - o) & 31);
+        cplx v = make_double2(0.0, 0.0);
+        if (r < n && c < n) {
+          v = (r >= c) ? dm_ldg(M.AB, (size_t)c * SLD + (r - c)) : cconj(dm_ldg(M.AB, (size_t)r * SLD + (c - r)));
+          if (r == c) v.y = 0.0;
+        }
+        d[a][b] = v;
+      }
+    }
+    if (j == 0 && lane == 0) M.d[0] = dm_ldg(M.AB, 0).x;
+  }
+  for (int s = 0; s <= s_last; ++s) {
+    const int r0 = s + 1 + j * SB;
+    const int nr = min(SB, n - r0);
+    const int o = r0 & 31, oa = o >> 3, ob = o & 7;
+    const int oo = (r0 - 1) & 31, ooa = oo >> 3, oob = oo & 7;
+    if (s > 0) {
+      // ---- slide: row / column oo <- first row of E_{j+1}(s - 1) (its corner entry belongs to E_j) and D_{j+1}(s - 1)[0, 0]
+      const bool rightOn = s + (j + 1) * SB < n;
+      const int sl = (s - 1) & 1;
+      double dcn = 0.0;
+      cplx rw[4], cl[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) rw[a] = cl[a] = make_double2(0.0, 0.0);
+      if (rightOn) {
+        if (remoteR) {
+          // the row packet off the wire, into the place a local neighbour would have written
+          double val;
+          if (!sb_g_wait(rsR, SB_GM_ROW + 1024u * sl + 16u * lane, (unsigned)s, val, err, 400 + s, lane)) return;
+          reinterpret_cast<double*>(right->row[sl])[lane] = val;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          if (!sb_g_wait(rsR, SB_GM_DCORN + 64u * sl, (unsigned)s, val, err, 500 + s, lane)) return;
+          dcn = val;
+        } else {
+          if (!sb_pos_wait(&right->seqRow[sl], s, err, 400 + s, lane)) return;
+          if (!sb_pos_wait(&right->seqDc[sl], s, err, 500 + s, lane)) return;
+          dcn = right->dcorn[sl];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          rw[a] = right->row[sl][bc + 8 * a];          // row oo by columns
+          cl[a] = cconj(right->row[sl][br + 8 * a]);   // column oo by rows
+        }
+      }
+      SB_DISPATCH4(ooa, sb_pos_d_insert<K>(d, rw, cl, dcn, br == oob, bc == oob));
+    }
+    const bool reflect = (j == 0) || nr >= 2;
+    if (reflect) {
+      if (!sb_pos_wait(&me->seqV, s + 1, err, 600 + s, lane)) return;
+      cplx vrow[4], vcol[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        vrow[a] = me->v[br + 8 * a];
+        vcol[a] = me->v[bc + 8 * a];
+      }
+      const cplx tau = me->tau;
+      // ---- D <- H^H D H (zhetd2's x, w recurrences on the full Hermitian block)
+      cplx wv[4], wc[4];
+      {
+        cplx x[4];
+        cplx xv = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) sb_cfma(acc, d[a][b], vcol[b]);
+          x[a] = cmul(tau, sb_sum_bc(acc));
+          sb_cfma_ca(xv, x[a], vrow[a]);
+        }
+        xv = sb_sum_br(xv);
+        const cplx al = cmul(make_double2(-0.5 * tau.x, -0.5 * tau.y), xv);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) wv[a] = cadd(x[a], cmul(al, vrow[a]));
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) wc[a] = sb_from_lane(wv[a], bc * 8);
+      // ---- the first column (slot o) and the corner leave now: the new last column of E_j(s + 1), the corner of D_{j-1}(s + 1)
+      {
+        cplx col[4];
+        SB_DISPATCH4(oa, sb_pos_d_firstcol<K>(d, vrow, wv, wc, col));
+        if (bc == ob) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) me->dcol[br + 8 * a] = col[a];
+        }
+        sb_pos_publish(&me->seqDcol, s + 1, lane);
+        const double dc = __shfl(sb_sel4v(col[0], col[1], col[2], col[3], oa).x, ob * 9, 64);   // lane (br, bc) = (ob, ob)
+        sb_pos_post_dcorn(M, me, dc, s, j, remoteL, rsM, lane);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          sb_cfms_cb(d[a][b], vrow[a], wc[b]);
+          sb_cfms_cb(d[a][b], wv[a], vcol[b]);
+          if (a == b && br == bc) d[a][b].y = 0.0;
+        }
+    } else {
+      cplx rw[4];
+      SB_DISPATCH4(oa, sb_pos_row<K>(d, rw));
+      const double dc = __shfl(sb_sel4v(rw[0], rw[1], rw[2], rw[3], oa).x, ob * 9, 64);
+      sb_pos_post_dcorn(M, me, dc, s, j, remoteL, rsM, lane);
+    }
+  }
+}
+
+__global__ __launch_bounds__(128 * SB_POS_NP) void sb_chase_pos_kernel(const sb_chase_mat* __restrict__ ms, const sb_pos_ctl ctl) {
+  constexpr int NP = SB_POS_NP;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  __shared__ int s_ticket;
+  __shared__ sb_pos_box boxes[NP + 2];
+  if (threadIdx.x == 0) s_ticket = atomicAdd(ctl.ticket, 1);
+  for (int k = threadIdx.x; k < (int)(sizeof(boxes) / (sizeof(int))); k += blockDim.x) reinterpret_cast<int*>(boxes)[k] = 0;
+  __syncthreads();
+  const int t = s_ticket;
+  if (t >= ctl.nent) return;
+  const int2 ent = ctl.ent[t];
+  const sb_chase_mat M = ms[ent.x];
+  if (M.n == 1) {
+    if (threadIdx.x == 0) M.d[0] = dm_ldg(M.AB, 0).x;
+    return;
+  }
+  const int i = wave >> 1, j = ent.y * NP + i;
+  if (j >= M.jb) return;
+  const bool remoteL = (i == 0) && (j > 0);
+  const bool remoteR = (i == NP - 1) && (j + 1 < M.jb);
+  const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)(ctl.mail + (size_t)t * SB_POS_MAIL), 0, (int)SB_POS_MAIL, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsL =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(ctl.mail + (size_t)(remoteL ? t - 1 : t) * SB_POS_MAIL), 0, (int)SB_POS_MAIL, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(ctl.mail + (size_t)(remoteR ? t + 1 : t) * SB_POS_MAIL), 0, (int)SB_POS_MAIL, 0x00020000);
+  if ((wave & 1) == 0) {
+    if (j == 0) sb_pos_E0(M, boxes, remoteR, rsM, rsR, ctl.err, lane);
+    else sb_pos_E(M, boxes, i, j, remoteL, remoteR, rsL, rsM, rsR, ctl.err, lane);
+  } else {
+    sb_pos_D(M, boxes, i, j, remoteL, remoteR, rsM, rsR, ctl.err, lane);
+  }
+}
+
 __global__ __launch_bounds__(256) void sb_vd_tail_zero_kernel(const sb_chase_mat* __restrict__ ms) {
   const sb_chase_mat M = ms[blockIdx.y];
   const int n = M.n, G = blockIdx.x;

@@ -2290,6 +2290,58 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
       if (!d_bm) return DM_ENOMEM;
       DM_PLAUNCH(ctx, DM_PROF_EIG_OTHER, sb_band_extract_kernel, dim3((unsigned)((maxel + 255) / 256), nc), dim3(256), 0, ctx->stream, d_bm);
       if (dump) DM_TRY(dump_arr(".band", sbAB, sizeof(cplx) * totn * SLD));
+      // ---- the chase BY BAND POSITION (sb_chase_pos_kernel; DM_SB_CHASE=pairs keeps the sweep-owning pairs below): one
+      // workgroup per (matrix, group of SB_POS_NP positions), largest matrix first, groups left to right; a matrix whose
+      // groups could not all be resident at once stays on the sweep-owning kernel (its hand-offs need no co-residency)
+      static const bool by_pos = !(getenv("DM_SB_CHASE") && strcmp(getenv("DM_SB_CHASE"), "pairs") == 0) && !getenv("DM_SB_NOPAIRS");
+      int pos_cap = 224;   // workgroups of one matrix that may have to be resident together (one per CU, some CUs left to others)
+      if (const char* e = getenv("DM_SB_POS_CAP")) pos_cap = std::max(1, atoi(e));
+      bool pos_fits = by_pos;
+      for (int i = 0; i < nc && pos_fits; ++i)
+        if (cm[i].n >= 2 && (cm[i].jb + SB_POS_NP - 1) / SB_POS_NP > pos_cap) pos_fits = false;
+      if (pos_fits) {
+        std::vector<int> order(nc);
+        for (int i = 0; i < nc; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cm[a].n > cm[b].n; });
+        std::vector<int2> ent;
+        double fl = 0.0;
+        for (int i : order) {
+          const int n = cm[i].n;
+          if (n < 1) continue;
+          const int ng = n >= 2 ? (cm[i].jb + SB_POS_NP - 1) / SB_POS_NP : 1;
+          for (int g = 0; g < ng; ++g) ent.push_back(make_int2(i, g));
+          fl += 8.0 * 6.0 * SB * SB * ((double)n * n / (2.0 * SB));
+        }
+        if (!ent.empty()) {
+          sb_pos_ctl pc;
+          int2* d_ent = dm_ws_upload(ctx, ent);
+          char* mail = dm_ws_alloc_t<char>(ctx, ent.size() * SB_POS_MAIL);
+          if (!d_ent || !mail) return DM_ENOMEM;
+          DM_TRY(dm_fill_zero(ctx, mail, ent.size() * SB_POS_MAIL));            // tags 0: no sweep has posted
+          DM_TRY(dm_fill_zero(ctx, sbNext + 2 * (size_t)np, sizeof(int) * 9));  // ticket counter, error flag
+          pc.ticket = sbNext + 2 * (size_t)np;
+          pc.err = sbNext + 2 * (size_t)np + 8;
+          pc.ent = d_ent;
+          pc.nent = (int)ent.size();
+          pc.mail = mail;
+          {
+            dm_prof_scope ps(ctx, DM_PROF_SB_CHASE, fl);
+            hipLaunchKernelGGL(sb_chase_pos_kernel, dim3((unsigned)ent.size()), dim3(128 * SB_POS_NP), 0, ctx->stream, d_cmat, pc);
+          }
+          int herr = 0;
+          DM_TRY(dm_download(ctx, &herr, pc.err, sizeof(int)));
+          if (herr) {
+            ctx->err = "bulge chase (by position): a wave waited for its neighbour for too long";
+            return 2000 + herr;
+          }
+        }
+        if (dump) {
+          DM_TRY(dump_arr(".d", dd, sizeof(double) * totn));
+          DM_TRY(dump_arr(".e", ee, sizeof(double) * totn));
+        }
+        DM_HIP(ctx, hipGetLastError());
+        return DM_OK;
+      }
       // One persistent launch: per-XCD queues of matrix ids; a matrix gets as many entries (= workgroups) as its
       // pipeline of sweeps can keep busy (sweep s + 1 trails sweep s by two blocks: n / (2 SB) sweeps in flight).
       constexpr int NW = 8, NP = 4;
