@@ -467,7 +467,7 @@ _BUSY = [0.0]   # seconds this rank spent in its own BT-gen + SVD + KL (without 
 _NKEEP = {}   # m -> eigenvectors actually back-transformed in the last pass (the modes transform_save keeps)
 
 
-def _svd_kl_group(bt, kl, beam_all, ms, m0=0):
+def _svd_kl_group(bt, kl, beam_all, ms, m0=0, ready=None):
     """SVD chain + KL for one group of m-blocks on the calling thread's context; returns
     (seconds in SVD, seconds in KL, KL products, singular values (host), ndofs)."""
     import torch
@@ -475,6 +475,8 @@ def _svd_kl_group(bt, kl, beam_all, ms, m0=0):
     from driftscan_amd import device
 
     ctx = device.get_context()
+    if ready is not None:
+        device.wait_for(ready)       # the blocks come from the main thread's stream
     t0 = time.perf_counter()
     if len(ms) and list(ms) == list(range(ms[0], ms[-1] + 1)):
         blocks = beam_all[ms[0] - m0 : ms[-1] - m0 + 1]                 # a contiguous range of m: a view (what generate() takes)
@@ -520,7 +522,10 @@ def hot_path_step(tel, bt, kl, ctx, stage_times=None, streams=1, m_range=None, c
     t1 = time.perf_counter()
     m0 = 0 if m_range is None else m_range[0]
     ms = list(range(tel.mmax + 1)) if m_range is None else list(range(m_range[0], m_range[1] + 1))
-    groups = [ms[g::streams] for g in range(streams)]
+    if streams > 1 and os.environ.get("DRIFT_BENCH_SPLIT") == "contig":
+        groups = [parallel.partition_contiguous(ms, [bt._m_cost(m) for m in ms], n=streams, r=g) for g in range(streams)]
+    else:
+        groups = [ms[g::streams] for g in range(streams)]
     if streams == 1:
         parts = [_svd_kl_group(bt, kl, beam_all, groups[0], m0)]
     else:
@@ -528,7 +533,8 @@ def hot_path_step(tel, bt, kl, ctx, stage_times=None, streams=1, m_range=None, c
             from concurrent.futures import ThreadPoolExecutor
 
             _pool = ThreadPoolExecutor(max_workers=streams)
-        futs = [_pool.submit(_svd_kl_group, bt, kl, beam_all, g, m0) for g in groups]
+        ready = ctx.record_event()
+        futs = [_pool.submit(_svd_kl_group, bt, kl, beam_all, g, m0, ready) for g in groups]
         parts = [f.result() for f in futs]
     torch.cuda.synchronize()
     t3 = time.perf_counter()

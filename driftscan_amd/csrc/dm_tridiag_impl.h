@@ -1853,7 +1853,11 @@ int herm_eig_tridiag(dm_ctx* ctx, const std::vector<dm_jac_herm_problem>& probs,
     // n_max >= 3500 rule, on the one-stage path at 0.45 of the HBM roofline for 13 of the 44 s of that stage: n_max >= 2400
     // with sum n >= 48 000 joins; DM_TRD_TS_MID=0 takes it out)
     static const bool ts_mid = !getenv("DM_TRD_TS_MID") || atoi(getenv("DM_TRD_TS_MID")) != 0;
-    const bool pays = (maxn >= 700 && np >= 64) || (maxn >= 300 && totn >= 120000) || (maxn >= 3500 && totn >= 24000) ||
+    // (round 6, after the chase by band position: 200 x 128 1.15 x, 300 x 64 1.04, 432 x 64 1.08, 700 x 64 1.05, 700 x 16 1.02,
+    // 1000 x 16 1.02, 1200 x 32 1.06, 2000 x 8 1.04, 16384 x 1 1.26; 300 x 16 0.93, 432 x 16 0.95, 600 x 8 0.90, 1200 x 8 0.96,
+    // 2000 x 2 0.83, 3000 x 4 0.97, 4000 x 2 0.88, 8192 x 1 0.96 — profiles/r06e_twostage_sweep.txt)
+    const bool pays = (maxn >= 700 && np >= 16) || (maxn >= 200 && np >= 64) || (maxn >= 2000 && np >= 8) ||
+                      (maxn >= 300 && totn >= 120000) || (maxn >= 3500 && totn >= 24000) ||
                       (ts_mid && maxn >= 2400 && totn >= 48000) || maxn >= 14000;
     two_stage = use_dc && maxn > TSM && maxn > SB + 2 && (mode == 1 || (mode != 0 && pays));
   }

@@ -30,6 +30,17 @@ def get_context(workspace_bytes=None):
         from ._lib import Context
 
         dev = device_index()
+        if threading.current_thread() is not threading.main_thread() and os.environ.get("DRIFTMI_THREAD_STREAMS", "1") != "0":
+            # a worker thread driving its own group of m-blocks: a HIP stream of its own (torch's pool streams are
+            # non-blocking: no implicit join with the default stream), made this thread's current stream so that the
+            # library's kernels and torch's copies / allocations of the thread stay in one order.  What the thread takes
+            # from another stream it must wait for itself (`wait_for_main`).
+            import torch
+
+            torch.cuda.set_device(dev)
+            st = torch.cuda.Stream(device=dev)
+            torch.cuda.set_stream(st)
+            _local.stream = st
         if workspace_bytes is None:
             workspace_bytes = _default_ws
         if workspace_bytes is None:
@@ -42,6 +53,13 @@ def get_context(workspace_bytes=None):
         with _lock:
             _all.append(ctx)
     return ctx
+
+
+def wait_for(event):
+    """Make the calling thread's stream wait for a torch.cuda.Event recorded on another stream (no host wait)."""
+    import torch
+
+    torch.cuda.current_stream(device_index()).wait_event(event)
 
 
 def reset_context():
