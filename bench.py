@@ -1227,10 +1227,12 @@ def north_star_leg(args):
                     os.path.relpath(pj[-1], ROOT), pr.get("_build_id"), bid)
     except Exception:
         pass
-    cj = os.path.join(ROOT, "profiles", "r05_configs2_cpu_sample.json")
-    if os.path.exists(cj):
+    import glob as _glob
+
+    cjs = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_configs2_cpu_sample.json")))
+    if cjs:   # the oracle on real configs[2] blocks (scratch/cpu_sample_configs2.py): seconds per sample AND its sigma against the device's
         try:
-            out["cpu_sample"] = json.load(open(cj))
+            out["cpu_sample"] = dict(json.load(open(cjs[-1])), source=os.path.relpath(cjs[-1], ROOT), live=False)
         except Exception:
             pass
     out["leg_wall_s"] = time.perf_counter() - t0

@@ -453,9 +453,6 @@ def _eigh_gen(self, A, B, ndofs, off, cut=None):
     rc = self.lib.dm_eigh_gen(self.h, len(n), np_, self.ptr(A), self.ptr(B), op, self.ptr(evals), eop,
                               self.ptr(evecs), ac, ctypes.byref(sw), mode, thr, nk)
     self.check(rc, "dm_eigh_gen")
-    if rc > 0:
-        msg = self.lib.dm_last_error(self.h)
-        raise DriftMIError("dm_eigh_gen: numerical failure (info=%d): %s" % (rc, msg.decode() if msg else ""))
     self.last_nkeep = np.array(nk[: len(n)], dtype=np.int64)
     return evals, evoff, evecs, np.array(ac[: len(n)], dtype=np.float64), sw.value
 
@@ -484,8 +481,6 @@ def _kl_m(self, beam_svd, beam_ut, svnum, l0, cl_sg, sg_mask, sg_sym, cl_fg, fg_
                           int(bool(sg_sym)), self.ptr(cl_fg), fmp, int(bool(fg_sym)), self.ptr(npower), float(noise_scale),
                           float(regulariser), mode, thr, self.ptr(evals), eop, self.ptr(evecs), op, ac, nk)
     self.check(rc, "dm_kl_m")
-    if rc > 0:
-        raise DriftMIError("dm_kl_m: numerical failure (info=%d)" % rc)
     return evals, evoff, evecs, off, np.array(ac[:nblk]), np.array(nk[:nblk], dtype=np.int64)
 
 
@@ -515,8 +510,6 @@ def _doublekl_m(self, beam_svd, beam_ut, svnum, l0, cl_sg, sg_mask, sg_sym, cl_f
                                 float(regulariser), float(foreground_threshold), mode, thr, self.ptr(f_evals), self.ptr(evals),
                                 eop, self.ptr(modes), op, nm, nk, ac)
     self.check(rc, "dm_doublekl_m")
-    if rc > 0:
-        raise DriftMIError("dm_doublekl_m: numerical failure (info=%d)" % rc)
     return (f_evals, evals, evoff, modes, off, np.array(nm[:nblk], dtype=np.int64), np.array(nk[:nblk], dtype=np.int64),
             np.array(ac[:nblk]))
 
@@ -703,8 +696,6 @@ def _herm_eig(self, C, n, ldc, strideC=0, batch=1):
     ev = self.empty((batch, max(n, 1)), np.float64)
     rc = self.lib.dm_herm_eig_batched(self.h, n, self.ptr(C), ldc, strideC, self.ptr(W), n, n * n, batch, self.ptr(ev))
     self.check(rc, "dm_herm_eig_batched")
-    if rc > 0:
-        raise DriftMIError("dm_herm_eig_batched: QL failure (%d)" % rc)
     return ev, W
 
 

@@ -268,7 +268,7 @@ extern "C" int dm_svd_chain_lmin(dm_ctx* ctx, int nblk, int F, int T, int P, int
   dm_ws_scope ws_scope__(ctx);  // releases on every return path
   const size_t mark = ws_scope__.mark;
   // geometry: chain c = blk * F + f works on the columns l >= lmin[blk] of every polarisation
-  static const bool no_compact = getenv("DM_SVD_NO_COMPACT") != nullptr;
+  const bool no_compact = getenv("DM_SVD_NO_COMPACT") != nullptr;   // (the switches of this call are read per call: the tests flip them)
   std::vector<svd_geom> geo(nch);
   size_t ztot = 0;
   int ldz_max = 0;
@@ -288,7 +288,7 @@ extern "C" int dm_svd_chain_lmin(dm_ctx* ctx, int nblk, int F, int T, int P, int
   cplx* ibeam = reinterpret_cast<cplx*>(invbeam_svd_dev);
 
   // DM_SVD_NARROW=0: SVD2 / SVD3 on all columns of Z, as rounds 1-4 (the passengers of a phase ride through it)
-  static const bool narrow_env = !getenv("DM_SVD_NARROW") || atoi(getenv("DM_SVD_NARROW")) != 0;
+  const bool narrow_env = !getenv("DM_SVD_NARROW") || atoi(getenv("DM_SVD_NARROW")) != 0;
   const bool narrow = narrow_env && P > 1;
   cplx* Z = dm_ws_alloc_t<cplx>(ctx, ztot);
   double* sig = dm_ws_alloc_t<double>(ctx, (size_t)nch * T);
@@ -305,7 +305,7 @@ extern "C" int dm_svd_chain_lmin(dm_ctx* ctx, int nblk, int F, int T, int P, int
   if (P > 1) {
     // ---- phase 1: SVD1, image with rtol 1e-10 (beamtransfer.py:826, :98)
     // tall chains (P Lc <= 0.95 T) go through the transposed matrix (svd_build_yt_kernel); DM_SVD_TALL=0: all chains as they lie
-    static const bool tall_env = !getenv("DM_SVD_TALL") || atoi(getenv("DM_SVD_TALL")) != 0;
+    const bool tall_env = !getenv("DM_SVD_TALL") || atoi(getenv("DM_SVD_TALL")) != 0;
     static const int tall_pct = getenv("DM_SVD_TALL_PCT") ? std::min(100, atoi(getenv("DM_SVD_TALL_PCT"))) : 95;   // tall: P Lc <= tall_pct % of T (m = 320 of configs[2], P Lc = 0.89 T: 2.01 -> 1.64 s per 11 blocks; at P Lc = T even)
     std::vector<int> tall(nch, 0);
     std::vector<size_t> yoff(nch, 0);

@@ -623,6 +623,10 @@ _worker_list = []
 _proc_lock = threading.Lock()
 
 
+class WriteFailed(IOError):
+    """A writer process REPORTED a failed write (disk full, a bad dataset): the process itself is fine."""
+
+
 class _Worker(object):
     """One writer process: `python -c "... io_worker.main()"` talking length-prefixed pickles over its pipes (not
     multiprocessing's spawn, which would re-import the caller's __main__ module in every child)."""
@@ -649,7 +653,7 @@ class _Worker(object):
             raise IOError("writer process died (exit code %s)" % self.p.poll())
         status, val = pickle.loads(self.p.stdout.read(struct.unpack("<Q", hdr)[0]))
         if status != "ok":
-            raise IOError("writer process: %s" % val)
+            raise WriteFailed("writer process: %s" % val)   # the process answered: it is alive and in step
         return val
 
     def stop(self):
@@ -732,24 +736,34 @@ def _write_in_process(f, tmp):
             np.copyto(np.ndarray(arr.shape, dtype=arr.dtype, buffer=blk.buf), arr)
             specs.append((name, blk.name, arr.shape, arr.dtype.str, chunks, comp))
         w = workers.get()
+        if w is None:
+            # a slot whose process could not be restarted: the slot goes back as it is (the pool never shrinks, nobody
+            # blocks in get() for ever) and this file is written here, in the writer thread
+            workers.put(None)
+            f._write_local(tmp)
+            return
         try:
             w.run((tmp, specs, dict(f.attrs)))
+        except WriteFailed:
+            workers.put(w)      # a reported failure: the worker stays (respawning it would wait up to 30 s in stop())
+            raise
         except BaseException:
-            # the process may be gone (broken pipe, short read): never hand it out again — a fresh one takes its place
+            # transport failure (broken pipe, short read): the process may be gone or out of step — never hand it out
+            # again; a fresh one takes its slot, or the slot stays as a None marker when none can be started
             try:
-                w.stop()
+                w.p.kill()
             except Exception:
                 pass
+            fresh = None
             with _proc_lock:
                 if w in _worker_list:
                     _worker_list.remove(w)
                 try:
-                    w = _Worker()
-                    _worker_list.append(w)
+                    fresh = _Worker()
+                    _worker_list.append(fresh)
                 except Exception:
-                    w = None
-            if w is not None:
-                workers.put(w)
+                    fresh = None
+            workers.put(fresh)
             raise
         else:
             workers.put(w)

@@ -10,7 +10,10 @@
  *   - every pointer named *_dev is DEVICE memory owned by the caller (e.g. a
  *     torch tensor's data_ptr()); pointers named *_host are host memory.
  *   - every function returns int: 0 ok, <0 argument/runtime error (see
- *     dm_last_error), >0 numerical status mirroring LAPACK `info`.
+ *     dm_last_error), >0 numerical status mirroring LAPACK `info`.  0 is the ONLY
+ *     success value: no entry point reports a count or a warning through its
+ *     return value (the Python binding raises on every non-zero status, positive
+ *     ones included — products behind a failed eigen-iteration are not usable).
  *   - a dm_ctx owns a device id, a HIP stream and a growable device workspace;
  *     one context per GPU, one host thread per context.  All work is enqueued on
  *     the context's stream; functions documented as "synchronises" block the

@@ -57,6 +57,16 @@ def main():
             ctx.sync()
             bs, bu, sv = (res[k][0].cpu().numpy() for k in ("beam_svd", "beam_ut", "singularvalues"))
             rec["ndof"] = int(osvd.svd_num(sv, bt.svcut)[0].sum())
+            # the sigma the oracle has just computed are the GPU's yardstick (not thrown away): the two sampled frequencies
+            # against the device chain on the SAME block, relative to the block's largest singular value; svnum per frequency
+            smax = float(sv.max())
+            sv_o = np.asarray(o2["singularvalues"])
+            rec["sv_max_err_over_svmax"] = float(np.abs(sv_o - sv[fsel]).max() / smax)
+            n_o = (sv_o > smax * bt.svcut).sum(axis=1)
+            n_g = (sv[fsel] > smax * bt.svcut).sum(axis=1)
+            rec["svnum"] = [int(x) for x in n_g]
+            rec["svnum_equal"] = bool(np.array_equal(n_o, n_g))
+            rec["nmodes_equal"] = bool(np.array_equal(np.asarray(o2["nmodes"]), res["nmodes"][0].cpu().numpy()[fsel]))
             if m == 460:
                 t0 = time.perf_counter()
                 cs, cn = okl.sn_covariance(bs, bu, sv, kl.signal(), kl.foreground(), kl._npower(1.0), svcut=bt.svcut)
@@ -64,6 +74,14 @@ def main():
                 ev = okl.kl_transform_m(cs, cn)[0]
                 t2 = time.perf_counter()
                 rec.update(kl_projections_s=t1 - t0, kl_eigh_s=t2 - t1, kl_s=t2 - t0)
+                # ... and the KL spectrum of the block against the device's (oracle fed with the device's SVD products)
+                bt._dev[m] = dict(beam_svd=res["beam_svd"][0], beam_ut=res["beam_ut"][0], singularvalues=sv)
+                ev_g = kl._transform_batch([m], to_host=True)[0][0]
+                rec["ev_max_err_over_lambda_max"] = float(np.abs(ev_g - ev).max() / np.abs(ev).max())
+                kp = ev >= kl.threshold
+                rec["ev_kept_modes"] = int(kp.sum())
+                rec["ev_kept_max_rel_err"] = float((np.abs(ev_g[kp] - ev[kp]) / ev[kp]).max()) if kp.any() else 0.0
+                bt._dev.clear()
             del res, bs, bu
             out["samples"]["m=%d" % m] = rec
             del blk_d
@@ -87,6 +105,9 @@ def main():
             kl_tot += t_
             if m_ == 0:
                 kl_m0 = t_
+        out["sv_max_err_over_svmax"] = max(r["sv_max_err_over_svmax"] for r in out["samples"].values())
+        out["svnum_equal"] = all(r["svnum_equal"] for r in out["samples"].values())
+        out["seconds"] = sum(r["svd_chain_s_for_2_frequencies"] + r.get("kl_s", 0.0) for r in out["samples"].values())
         out["estimate"] = dict(
             svd_core_s_whole_job=svd_tot, kl_core_s_whole_job=kl_tot, kl_core_s_block_m0_est=kl_m0,
             zhegvd_rate_gflops_one_core=rate / 1e9,

@@ -243,6 +243,93 @@ def test_svd_chain_subspace_phases_match_converged_ones(ctx, monkeypatch):
         assert np.abs(u1 @ u1.conj().T - np.eye(n)).max() < 1e-12
 
 
+
+@pytest.mark.parametrize("P", [1, 4])
+def test_svd_chain_lmin_tall_and_narrow_routes_match_the_plain_chain(ctx, monkeypatch, P):
+    """`dm_svd_chain_lmin` has four routes of its own: the chains compacted to the columns l >= lmin, the transposed "tall"
+    SVD1 / SVD3 (P (L - m) <= 0.95 T), the narrow SVD2 with a separate Z3 for SVD3, the per-polarisation pinv scatter.  Each
+    against the plain chain — lmin = None, DM_SVD_TALL = 0, DM_SVD_NARROW = 0, DM_SVD_NO_COMPACT — on blocks that are zero
+    below l = m, wide (m = 0, 3) and tall (m = 14, 17: P (L - m) = 24 and 12 of T = 40) and rank-deficient in the polarised
+    part, and against the oracle's restatement of beamtransfer.py:802-924: singular values, nmodes, the row space of
+    beam_ut (whitened rows orthonormal to 1e-12), beam_svd and invbeam_svd beam_svd = 1 on the kept modes."""
+    from oracle import svdchain as osvd
+
+    rng = np.random.default_rng(100 + P)
+    F, B, L = 3, 20, 20
+    T = 2 * B
+    ms = [0, 3, 14, 17]
+    beam = np.zeros((len(ms), F, T, P, L), dtype=np.complex128)
+    for i, m in enumerate(ms):
+        for f in range(F):
+            lc = L - m
+            r = min(T, lc)
+            u = np.linalg.qr(rng.standard_normal((T, T)) + 1j * rng.standard_normal((T, T)))[0]
+            v = np.linalg.qr(rng.standard_normal((lc, lc)) + 1j * rng.standard_normal((lc, lc)))[0]
+            beam[i, f, :, 0, m:] = (u[:, :r] * 10.0 ** np.linspace(0, -7, r)) @ v[:, :r].conj().T
+            if P > 1:
+                k = max(2, r // 2)   # polarised part of rank k sharing half of its row space with the temperature part
+                a = np.concatenate([u[:, : k // 2], np.linalg.qr(rng.standard_normal((T, k - k // 2)) + 0j)[0]], axis=1)
+                c = rng.standard_normal((k, 3 * lc)) + 1j * rng.standard_normal((k, 3 * lc))
+                beam[i, f, :, 1:, m:] = ((a * 10.0 ** np.linspace(0, -6, k)) @ c).reshape(T, 3, lc) * 0.05
+    nw = rng.uniform(0.5, 2.0, (F, T))
+    polsvcut, svcut = 1e-4, 1e-6
+    dev, dnw = ctx.to_device(beam), ctx.to_device(nw)
+
+    def run(lmin=None, **env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        try:
+            r = ctx.svd_chain(dev, dnw, polsvcut, lmin=lmin)
+            ctx.sync()
+        finally:
+            for k in env:
+                monkeypatch.delenv(k)
+        return dict(sv=r["singularvalues"].cpu().numpy(), bs=r["beam_svd"].cpu().numpy(), ut=r["beam_ut"].cpu().numpy(),
+                    ib=r["invbeam_svd"].cpu().numpy(), nmodes=np.array(r["nmodes"]))
+
+    base = run(lmin=ms)
+    variants = dict(no_lmin=run(lmin=None), no_compact=run(lmin=ms, DM_SVD_NO_COMPACT="1"), not_tall=run(lmin=ms, DM_SVD_TALL="0"),
+                    not_narrow=run(lmin=ms, DM_SVD_NARROW="0"), plainest=run(lmin=None, DM_SVD_TALL="0", DM_SVD_NARROW="0"))
+    for i, m in enumerate(ms):
+        smax = base["sv"][i].max()
+        for name, var in variants.items():
+            assert (var["nmodes"][i] == base["nmodes"][i]).all(), (name, m)
+            assert np.abs(var["sv"][i] - base["sv"][i]).max() <= 1e-11 * smax, (name, m)
+        for f in range(F):
+            n = int((base["sv"][i, f] > svcut * smax).sum())
+            if n == 0:
+                continue
+            U = base["ut"][i, f, :n] / nw[f][None, :]
+            assert np.abs(U @ U.conj().T - np.eye(n)).max() < 1e-12, (m, f)
+            b = base["bs"][i, f, :n].reshape(n, P * L)
+            assert not b.reshape(n, P, L)[:, :, :m].any()                       # l < m stays zero in the padded products
+            Bw = beam[i, f].reshape(T, P * L) * nw[f][:, None]
+            assert np.abs(U @ Bw - b).max() <= 1e-11 * smax
+            ib = base["ib"][i, f].reshape(P * L, -1)[:, :n]
+            assert np.abs(b @ ib - np.eye(n)).max() < 1e-7
+            for name, var in variants.items():
+                U2 = var["ut"][i, f, :n] / nw[f][None, :]
+                assert np.abs(U2.conj().T @ U2 - U.conj().T @ U).max() < 1e-8, (name, m, f)       # the same row space
+                b2 = var["bs"][i, f, :n].reshape(n, P * L)
+                assert relerr(b2.conj().T @ b2, b.conj().T @ b) < 1e-8, (name, m, f)
+                ib2 = var["ib"][i, f].reshape(P * L, -1)[:, :n]
+                assert relerr(ib2 @ b2, ib @ b) < 1e-6, (name, m, f)
+    # ... and the oracle on the same blocks (noise weights per baseline, duplicated for the two m signs inside)
+    nwb = rng.uniform(0.5, 2.0, (F, B))
+    nw2 = np.concatenate([nwb, nwb], axis=1)
+    res = ctx.svd_chain(dev, ctx.to_device(nw2), polsvcut, lmin=ms)
+    sv = res["singularvalues"].cpu().numpy()
+    for i, m in enumerate(ms):
+        o = osvd.svd_m(beam[i].reshape(F, 2, B, P, L), nwb, polsvcut=polsvcut)
+        assert np.abs(o["singularvalues"] - sv[i]).max() <= 1e-10 * sv[i].max(), m
+        # svnum is what defines the shapes downstream (beamtransfer.py:1116-1133).  nmodes itself is not comparable here: the
+        # reference counts sigma > 0 (rtol = 0), and of the P m exactly-zero columns LAPACK returns some sigma ~ 1e-17 sigma_max
+        # as positive where the compacted chain has none at all (19 against 17 at m = 3, P = 1)
+        n_o = (o["singularvalues"] > svcut * o["singularvalues"].max()).sum(axis=1)
+        n_g = (sv[i] > svcut * sv[i].max()).sum(axis=1)
+        assert (n_o == n_g).all() and (np.asarray(res["nmodes"][i]) >= n_g).all(), m
+
+
 def test_svd_chain_frequency_slices(ctx, gold):
     """The (m, frequency) chains are independent: pushing the frequencies through the library in slices
     (what a CHIME-sized block needs, 111 GB of augmented matrices otherwise) changes nothing."""

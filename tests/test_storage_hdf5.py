@@ -467,3 +467,74 @@ def test_chunk_threads_do_not_change_the_file(tmp_path, monkeypatch):
     assert sizes["1"] == sizes["4"] == sizes["7"]
     raw = {nt: np.frombuffer(open(str(tmp_path / ("t%s.hdf5" % nt)), "rb").read(), np.uint8) for nt in sizes}
     assert (raw["1"] != raw["4"]).sum() <= 16 and (raw["1"] != raw["7"]).sum() <= 16   # object-header time stamps only
+
+
+def test_writer_pool_survives_a_dead_process_and_an_unstartable_one(tmp_path, monkeypatch):
+    """The pool never shrinks: a writer process that dies is replaced in its slot; when no process can be started any more
+    the slot stays as a marker and its files are written in the writer thread — flush() raises the transport error once and
+    never blocks; a REPORTED write failure (`WriteFailed`) leaves the process where it is."""
+    monkeypatch.setenv("DRIFTMI_STORAGE", "hdf5")
+    if storage.backend() != "driftio":
+        pytest.skip("libdriftio is not the writer in use")
+    monkeypatch.setenv("DRIFTMI_IO_THREADS", "2")
+    monkeypatch.setenv("DRIFTMI_IO_PROCS", "2")
+    rng = np.random.default_rng(7)
+    big = rng.standard_normal((200, 1000))
+
+    def write(tag):
+        with storage.File(str(tmp_path / ("%s.hdf5" % tag)), "w") as f:
+            f.create_dataset("x", data=big)
+
+    try:
+        storage.submit(write, "a")
+        storage.flush()
+        assert len(storage._worker_list) == 2
+        pids = sorted(w.p.pid for w in storage._worker_list)
+        # a reported failure keeps both processes
+        def bad():
+            with storage.File(str(tmp_path / "missing" / "x.hdf5"), "w") as f:
+                f.create_dataset("x", data=big)
+
+        storage.submit(bad)
+        with pytest.raises(IOError):
+            storage.flush()
+        assert sorted(w.p.pid for w in storage._worker_list) == pids
+        # kill both processes: the next writes hit a broken pipe, fresh processes take the slots
+        for w in list(storage._worker_list):
+            w.p.kill(); w.p.wait()
+        def drain():   # flush() re-raises the FIRST failure and leaves the rest queued: wait for all of them
+            n = 0
+            while True:
+                try:
+                    storage.flush()
+                    return n
+                except IOError:
+                    n += 1
+
+        storage.submit(write, "b"); storage.submit(write, "c")
+        assert drain() >= 1
+        assert len(storage._worker_list) == 2 and sorted(w.p.pid for w in storage._worker_list) != pids
+        storage.submit(write, "d")
+        storage.flush()
+        assert os.path.exists(str(tmp_path / "d.hdf5"))
+        # no process can be started any more: kill them again with a _Worker that refuses to start
+        for w in list(storage._worker_list):
+            w.p.kill(); w.p.wait()
+
+        class Refuses(object):
+            def __init__(self):
+                raise OSError("no more processes")
+
+        monkeypatch.setattr(storage, "_Worker", Refuses)
+        storage.submit(write, "e"); storage.submit(write, "f")
+        assert drain() >= 1
+        assert storage._worker_list == []
+        for tag in ("g", "h", "i"):                       # slots are markers now: written in the writer threads, no deadlock
+            storage.submit(write, tag)
+        storage.flush()
+        for tag in ("g", "h", "i"):
+            with storage.File(str(tmp_path / ("%s.hdf5" % tag)), "r") as f:
+                assert np.array_equal(f["x"][...], big)
+    finally:
+        monkeypatch.undo()
+        storage.shutdown_writers()
