@@ -1565,11 +1565,13 @@ __device__ __forceinline__ trd_refl sb_pos_reflector(const cplx (&x)[4], int o, 
     const bool piv = (a == oa) && (br == ob);
     sq += piv ? 0.0 : cabs2(x[a]);
   }
-  const cplx xo = sb_sel4v(x[0], x[1], x[2], x[3], oa);
-  if (bc != 0) sq = 0.0;
-  const cplx t = sb_sum_br(make_double2(sq, 0.0));
-  const double xn2 = __shfl(t.x, 0, 64);
-  const cplx alpha = sb_from_lane(xo, ob * 8);
+  // x is replicated over the lanes that share the rows: the sum over the eight row groups of a column of lanes IS the sum
+  // over all 32 rows, in every lane — the norm and the pivot element (held by the row group br == ob alone) come out of one
+  // butterfly, no broadcast through the LDS crossbar
+  cplx xo = sb_sel4v(x[0], x[1], x[2], x[3], oa);
+  if (br != ob) xo = make_double2(0.0, 0.0);
+  const double xn2 = sb_sum_br(make_double2(sq, 0.0)).x;
+  const cplx alpha = sb_sum_br(xo);
   const trd_refl R = sb_reflector(xn2, alpha);
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
@@ -1830,11 +1832,11 @@ __device__ __forceinline__ void sb_pos_d_insert(cplx (&d)[4][4], const cplx (&rw
 }
 // the first column of D after the rank-2 update, from the lanes that own it (bc == ob): d - v conj(w_o) - w conj(v_o), v_o = 1
 template <int K>
-__device__ __forceinline__ void sb_pos_d_firstcol(const cplx (&d)[4][4], const cplx (&vrow)[4], const cplx (&wv)[4], const cplx (&wc)[4], cplx (&col)[4]) {
+__device__ __forceinline__ void sb_pos_d_firstcol(const cplx (&d)[4][4], const cplx (&vrow)[4], const cplx (&wv)[4], cplx wo, cplx (&col)[4]) {
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     cplx t = d[a][K];
-    sb_cfms_cb(t, vrow[a], wc[K]);
+    sb_cfms_cb(t, vrow[a], wo);
     t.x -= wv[a].x; t.y -= wv[a].y;
     col[a] = t;
   }
@@ -1944,12 +1946,14 @@ __device__ __forceinline__ void sb_pos_D(const sb_chase_mat& M, sb_pos_box* boxe
 #pragma unroll
         for (int a = 0; a < 4; ++a) wv[a] = cadd(x[a], cmul(al, vrow[a]));
       }
-#pragma unroll
-      for (int a = 0; a < 4; ++a) wc[a] = sb_from_lane(wv[a], bc * 8);
       // ---- the first column (slot o) and the corner leave now: the new last column of E_j(s + 1), the corner of D_{j-1}(s + 1)
       {
+        // w at slot o alone (one exchange instead of four before the posts): the row group br == ob holds it
+        cplx wo = sb_sel4v(wv[0], wv[1], wv[2], wv[3], oa);
+        if (br != ob) wo = make_double2(0.0, 0.0);
+        wo = sb_sum_br(wo);
         cplx col[4];
-        SB_DISPATCH4(oa, sb_pos_d_firstcol<K>(d, vrow, wv, wc, col));
+        SB_DISPATCH4(oa, sb_pos_d_firstcol<K>(d, vrow, wv, wo, col));
         if (bc == ob) {
 #pragma unroll
           for (int a = 0; a < 4; ++a) me->dcol[br + 8 * a] = col[a];
@@ -1958,6 +1962,8 @@ __device__ __forceinline__ void sb_pos_D(const sb_chase_mat& M, sb_pos_box* boxe
         const double dc = __shfl(sb_sel4v(col[0], col[1], col[2], col[3], oa).x, ob * 9, 64);   // lane (br, bc) = (ob, ob)
         sb_pos_post_dcorn(M, me, dc, s, j, remoteL, rsM, lane);
       }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) wc[a] = sb_from_lane(wv[a], bc * 8);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
