@@ -16,7 +16,8 @@ ft, fc = load("gpurun_out/pmc_fetch_" + tag, "FETCH_SIZE")
 wt, wc = load("gpurun_out/pmc_write_" + tag, "WRITE_SIZE")
 out = {"_note": "bench.py --steps 1 --warmup 1 under rocprofv3 --pmc (2 passes of the step per run); bytes per launch; "
                 "FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-load correction), WRITE_SIZE KiB x 1024"}
-for k in sorted(ft, key=lambda k: -(ft[k] + wt.get(k, 0)))[:12]:
+top = sorted(ft, key=lambda k: -(ft[k] + wt.get(k, 0)))
+for k in top[:12] + [k for k in top[12:] if "chase" in k or "q2_apply" in k or "panel_fused" in k]:   # (the chase always: its traffic is a tracked figure)
     n = max(fc.get(k, 1), 1)
     out[k] = {"launches": n, "fetch_bytes_per_launch": ft[k] * 1024 * 2 / n, "write_bytes_per_launch": wt.get(k, 0.0) * 1024 / max(wc.get(k, 1), 1)}
 import os, sys as _sys

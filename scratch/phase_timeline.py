@@ -26,20 +26,23 @@ for r in last:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     p = phase_of(r["Kernel_Name"], cur[0] if cur else "start")
     if cur is None or p != cur[0]:
-        cur = [p, s, e, 0.0, 0]
+        cur = [p, s, e, 0.0, 0, 0, 0.0]
         runs.append(cur)
     cur[2] = max(cur[2], e)
     cur[3] += e - s
     cur[4] += 1
+    if "copyBuffer" in r["Kernel_Name"] or "fillBuffer" in r["Kernel_Name"]:
+        cur[5] += 1
+        cur[6] += e - s
 t0 = runs[0][1]
 agg = OrderedDict()
 print("span of the step: %.2f ms" % ((runs[-1][2] - t0) / 1e6))
-for i, (p, s, e, k, n) in enumerate(runs):
+for i, (p, s, e, k, n, nc, tc) in enumerate(runs):
     nxt = runs[i + 1][1] if i + 1 < len(runs) else e
-    a = agg.setdefault(p, [0.0, 0.0, 0])
-    a[0] += (nxt - s) / 1e6; a[1] += k / 1e6; a[2] += n
-for p, (w, k, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
-    print("%-14s wall %7.2f ms  kernels %7.2f ms  launches %5d" % (p, w, k, n))
+    a = agg.setdefault(p, [0.0, 0.0, 0, 0, 0.0])
+    a[0] += (nxt - s) / 1e6; a[1] += k / 1e6; a[2] += n; a[3] += nc; a[4] += tc / 1e6
+for p, (w, k, n, nc, tc) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+    print("%-14s wall %7.2f ms  kernels %7.2f ms  launches %5d  of them copies / fills %4d (%.2f ms)" % (p, w, k, n, nc, tc))
 if len(sys.argv) > 2:
-    for p, s, e, k, n in runs:
+    for p, s, e, k, n, nc, tc in runs:
         print("%9.3f ms  %-14s wall %7.3f kernels %7.3f launches %4d" % ((s - t0) / 1e6, p, (e - s) / 1e6, k / 1e6, n))
