@@ -22,6 +22,10 @@ def main():
     ap.add_argument("--workload", default="configs2")
     ap.add_argument("--out", required=True)
     ap.add_argument("--shares", default=None, help="comma-separated ranks (default: all)")
+    ap.add_argument("--files", action="store_true",
+                    help="every share WRITES its product files (bitshuffle + LZ4, blocks truncated on the device: the reference's "
+                         "production setting) into a temporary directory under --outdir, removed after the share")
+    ap.add_argument("--outdir", default=None)
     ap.add_argument("--pause", type=float, default=10.0,
                     help="seconds between two shares: the driver wipes the ~240 GB the previous process freed in the background, and "
                          "the next process's first large allocations wait for it (2-3 s in front of its BT-gen kernels when the shares "
@@ -35,8 +39,12 @@ def main():
         if k and args.pause > 0:
             time.sleep(args.pause)
         t0 = time.perf_counter()
-        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", args.workload, "--share",
-                              "%d/%d" % (r, args.n)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", args.workload, "--share", "%d/%d" % (r, args.n)]
+        env = dict(os.environ)
+        if args.files:
+            cmd += ["--files", "--truncate"] + (["--outdir", args.outdir] if args.outdir else [])
+            env["DRIFTMI_H5_CODEC"] = "bitshuffle"
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
         if res.returncode != 0:
             print("share %d failed: %s" % (r, res.stderr.decode()[-800:]), file=sys.stderr, flush=True)
             shares.append(dict(share="%d/%d" % (r, args.n), error=res.stderr.decode()[-400:]))
@@ -50,6 +58,9 @@ def main():
                    zgemm_cov=None if not d.get("zgemm_cov") else dict(frac=d["zgemm_cov"]["frac"], ms=d["zgemm_cov"]["ms"]),
                    zgemm_grouped_frac=(d["classes"].get("zgemm_grouped") or {}).get("frac"),
                    child_wall_s=time.perf_counter() - t0, budgets_gb=d["config"].get("budgets_gb"))
+        if args.files:
+            rec.update(file_bytes=d.get("file_bytes"), other_s=st.get("other_s"), io=d.get("io"),
+                       kernel_coverage_of_wall=d.get("kernel_coverage_of_wall"))
         shares.append(rec)
         print("share %d/%d: m = %s  %.2f s (btgen %.1f svd %.1f kl %.1f)" % (
             r, args.n, rec["m_range"], rec["share_s"], rec["stages"].get("btgen", {}).get("seconds", 0.0),
@@ -59,7 +70,7 @@ def main():
                max_s=max(s["share_s"] for s in ok) if ok else None,
                slowest=max(ok, key=lambda s: s["share_s"])["share"] if ok else None,
                mean_s=sum(s["share_s"] for s in ok) / len(ok) if ok else None,
-               pause_s=args.pause,
+               pause_s=args.pause, files=bool(args.files), outdir=args.outdir,
                note="every share of the cost-balanced contiguous partition through ProductManager.generate() on one MI355X, "
                     "products left in HBM; the job's wall time on N GPUs is max_s")
     with open(args.out, "w") as fh:
