@@ -385,6 +385,10 @@ class BeamTransfer(config.Reader):
                 # here) these blocks were made with — DESIGN.md section 3
                 f.attrs["sht_iter"] = int(getattr(tel, "sht_iter", 0) or 0)
                 f.attrs["sht_ring_weights"] = bool(getattr(tel, "sht_ring_weights", None) is not None)
+                # calls covering at most this many m take the belt rings through the matrix form instead of the FFT
+                # (DM_BT_NARROW): blocks made by such calls equal those of wide calls to rounding (2e-13), not bit for bit
+                # — with truncation on, the quantised files can therefore depend on beam_chunk_gb / the rank count
+                f.attrs["sht_narrow_max_m"] = int(os.environ.get("DM_BT_NARROW", "8"))
 
         # the host copies are made by the writer pool's copy thread (storage.Deferred) while the SVD stage reads the same
         # blocks: nothing writes to `beam_all` after this point
