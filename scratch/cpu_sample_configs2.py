@@ -66,7 +66,7 @@ def main():
             n_g = (sv[fsel] > smax * bt.svcut).sum(axis=1)
             rec["svnum"] = [int(x) for x in n_g]
             rec["svnum_equal"] = bool(np.array_equal(n_o, n_g))
-            rec["nmodes_equal"] = bool(np.array_equal(np.asarray(o2["nmodes"]), res["nmodes"][0].cpu().numpy()[fsel]))
+            rec["nmodes_equal"] = bool(np.array_equal(np.asarray(o2["nmodes"]), np.asarray(res["nmodes"][0])[fsel]))
             if m == 460:
                 t0 = time.perf_counter()
                 cs, cn = okl.sn_covariance(bs, bu, sv, kl.signal(), kl.foreground(), kl._npower(1.0), svcut=bt.svcut)
