@@ -1,7 +1,12 @@
 """ctypes binding of libdriftcomm.so (include/driftcomm.h): gather and all-reduce of doubles over RCCL for hosts
-that do not use torch.distributed.  The pipeline classes of this package talk through ``parallel.py``
-(torch.distributed, backend "nccl" = RCCL) and never load this module; it exists so that the C ABI alone is enough to
-run the m-sharded job on several GPUs (one communicator per process = one rank per GPU)."""
+that do not use torch.distributed.
+
+BINDING ONLY — deliberately not a second collective stack of this package.  The pipeline classes talk through
+``parallel.py`` (torch.distributed, backend "nccl" = RCCL) and never load this module; ``parallel.allreduce_sum`` and the
+gathers do NOT fall back to it.  It exists for a driftscan maintainer whose launcher is MPI without torch: the C ABI alone
+(libdriftmi + libdriftcomm) is then enough to run the m-sharded job on several GPUs, one communicator per process = one
+rank per GPU, the unique id travelling over the host's own channel.  Exercised by
+tests/test_gpu_primitives.py (one rank: the pool gives one GPU per call) and tests/test_cabi_symbols.py (exports)."""
 import ctypes
 import os
 
