@@ -73,7 +73,9 @@ def _north_star(ns):
         out["job_s"] = job.get("job_s")
         out["job_m_blocks_per_s"] = job.get("value")
         out["ranks"] = job.get("n_gpus")
-        out["ranks_seen_by_rccl"] = job.get("ranks_seen_by_rccl", job.get("ranks_seen_by_gloo"))
+        for k in ("ranks_seen_by_rccl", "ranks_seen_by_gloo"):   # which backend the job's tensor collective ran over
+            if k in job:
+                out[k] = job[k]
         per = job.get("per_rank") or []
         out["rank_seconds"] = [p.get("seconds") for p in per]
         out["rank_collective_s"] = [p.get("collective_s") for p in per]
