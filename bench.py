@@ -219,6 +219,7 @@ def hot_path_step(tel, bt, kl, ctx, stage_times=None, streams=1, m_range=None, c
     if streams == 1:
         parts = [_svd_kl_group(bt, kl, beam_all, groups[0], m0)]
     else:
+        os.environ["DRIFTMI_THREAD_STREAMS"] = "1"   # each group's thread on a HIP stream of its own (device.get_context)
         if _pool is None or _pool._max_workers != streams:
             from concurrent.futures import ThreadPoolExecutor
 

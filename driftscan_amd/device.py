@@ -30,11 +30,13 @@ def get_context(workspace_bytes=None):
         from ._lib import Context
 
         dev = device_index()
-        if threading.current_thread() is not threading.main_thread() and os.environ.get("DRIFTMI_THREAD_STREAMS", "1") != "0":
-            # a worker thread driving its own group of m-blocks: a HIP stream of its own (torch's pool streams are
-            # non-blocking: no implicit join with the default stream), made this thread's current stream so that the
-            # library's kernels and torch's copies / allocations of the thread stay in one order.  What the thread takes
-            # from another stream it must wait for itself (`wait_for_main`).
+        if threading.current_thread() is not threading.main_thread() and os.environ.get("DRIFTMI_THREAD_STREAMS", "0") == "1":
+            # OPT-IN (DRIFTMI_THREAD_STREAMS=1; `bench.py --streams N` sets it): a worker thread driving its own group of
+            # m-blocks gets a HIP stream of its own (torch's pool streams are non-blocking: no implicit join with the default
+            # stream), made this thread's current stream so that the library's kernels and torch's copies / allocations of
+            # the thread stay in one order.  What the thread takes from another stream it must wait for itself (`wait_for`).
+            # Off by default: every context then binds the default stream, and tensors handed between threads keep the
+            # implicit ordering callers of the operator API may rely on.
             import torch
 
             torch.cuda.set_device(dev)
