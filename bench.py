@@ -26,7 +26,7 @@ Modes (m-blocks are independent: no data-path collective in either):
            matrix (the Fisher assembly pattern, psestimation.py:506-507) are inside the timed
            region.  value = 129 * steps / time ("scaling": "strong").
 
-Output (rank 0): the full record as `{"bench_detail": {...}}` on an EARLIER stdout line and in `bench_detail.json`
+Output (rank 0): the full record as `bench_detail {...}` on an EARLIER stdout line and in `bench_detail.json`
 ($DRIFT_BENCH_DETAIL), then — LAST — the compact driver line (< 8 KB; `benchlib/line.py`): the contract keys, `config`, `roofline`
 (dominant kernel class: algorithmic flops per launch / its average launch duration by HIP events over the timed region, peak,
 frac, PMC traffic per launch), `cpu_baseline` (the oracle on the host cores, N = 1 only), `parity`, `stage_ms`, per-rank step

@@ -6,8 +6,8 @@ how each figure was taken).  The driver reads the LAST stdout line and gave up o
 
   * `compact(full)`  -> the driver line: the contract keys, `roofline`, `cpu_baseline`, `parity`, `north_star`, scalars
     only, never more than MAX_LINE_BYTES (tests/test_bench_line.py holds it to that on a canned full record);
-  * `emit(full, path)` writes the full record to `bench_detail.json`, prints it as an EARLIER stdout line (prefixed key
-    `bench_detail`) and prints the compact line LAST.
+  * `emit(full, path)` writes the full record to `bench_detail.json`, prints it as an EARLIER stdout line (`bench_detail {...}`:
+    prefixed, not itself a JSON object line) and prints the compact line LAST.
 """
 import json
 import math
@@ -180,7 +180,9 @@ def emit(full, detail_path=None, out=None):
         shown = detail_path
     except OSError as e:   # a read-only working directory must not cost the line
         shown = "not written (%s); see the `bench_detail` line on stdout" % e.__class__.__name__
-    out.write(json.dumps({"bench_detail": full}, default=str) + "\n")
+    # (prefixed, so that the compact line is the ONLY stdout line that is a JSON object: whichever way a consumer picks
+    # "the JSON line" — the last line, the first line that starts with a brace, the last line that parses — it gets that one)
+    out.write("bench_detail " + json.dumps(full, default=str) + "\n")
     line = compact(full, detail_file=shown)
     s = json.dumps(line)
     assert len(s) < MAX_LINE_BYTES

@@ -26,7 +26,7 @@ cp profiles/${tag}_pmc_traffic.json profiles/${tag}_pmc_mfma.json gpurun_out/ 2>
 f=$(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/${tag}_bench_kernel_stats.csv
 find gpurun_out/pmc_fetch_$tag gpurun_out/pmc_write_$tag gpurun_out/pmc_mfma_$tag gpurun_out/pmc_valu_$tag gpurun_out/prof_$tag -name "*.csv" -size +5M -delete
 echo "$(date +%T) bench default"
-timeout -k 10 1000 python bench.py 2> gpurun_out/${tag}_bench_default.err | grep "^{" > gpurun_out/${tag}_bench_default.json || exit 7
+DRIFT_BENCH_DETAIL=gpurun_out/${tag}_bench_detail.json timeout -k 10 1000 python bench.py 2> gpurun_out/${tag}_bench_default.err | grep "^{" > gpurun_out/${tag}_bench_default.json || exit 7   # the compact line; the full record is the detail file
 fi
 if [ "$part" = "b" ]; then
 echo "$(date +%T) share kernel stats"

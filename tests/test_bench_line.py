@@ -98,7 +98,8 @@ def test_emit_prints_the_compact_line_last(full, tmp_path):
     benchline.emit(full, detail_path=path, out=buf)
     lines = buf.getvalue().strip().splitlines()
     assert len(lines) == 2
-    assert "bench_detail" in json.loads(lines[0])
+    assert lines[0].startswith("bench_detail {") and json.loads(lines[0][len("bench_detail "):])["metric"] == full["metric"]
+    assert [ln for ln in lines if ln.startswith("{")] == [lines[-1]]      # the only JSON-object line of stdout
     last = json.loads(lines[-1])
     assert len(lines[-1]) < benchline.MAX_LINE_BYTES
     _check_contract(last)
