@@ -16,7 +16,7 @@ rank processes itself — before it makes any GPU call — one per GPU over RCCL
 rank 0's JSON line and exits non-zero if a rank fails.  Under `torch.distributed.run` the
 RANK/LOCAL_RANK/WORLD_SIZE of the launcher are used.
 
-Modes (m-blocks are independent: no data-path collective in either):
+Modes (m-blocks are independent: no data-path collective in either; weak is the default at every N):
   weak     every rank runs the full 129-block workload (per-GPU work fixed); the singular-value and
            eigenvalue spectra of every rank are gathered to rank 0 inside the timed region, as
            `_collect_svd_spectrum` / `KLTransform._collect` do.  value = N * 129 * steps / time.
@@ -61,7 +61,7 @@ def parse_args(argv=None):
     ap.add_argument("--prime-passes", type=int, default=10,
                     help="untimed passes of the hot path before the warm-up steps (settles a fresh box; 0 to skip)")
     ap.add_argument("--mode", choices=["weak", "sharded"], default=None,
-                    help="default: weak at --gpus 1 (one full workload), sharded at --gpus N > 1 (ONE workload in m-ranges)")
+                    help="default: weak (a full 129-block workload per GPU); sharded: ONE workload in cost-balanced m-ranges over the ranks")
     ap.add_argument("--workload", choices=["configs1", "configs2", "configs3", "configs4"], default="configs1",
                     help="configs1 = BASELINE configs[1] (the default line); configs2 / configs3 = the north-star job "
                          "(128-feed polarised cylinder, nfreq 64, lmax 512; configs3 adds DoubleKL + the exact Fisher matrix) "
@@ -312,7 +312,13 @@ def main():
     if args.workload != "configs1":
         return run_job(args) if args.job else run_share(args)
     if args.mode is None:
-        args.mode = "sharded" if args.gpus > 1 else "weak"
+        # m-blocks are independent units with no data-path collective: the units are sharded over the ranks at a FIXED number
+        # per GPU — every rank takes a full 129-block workload (as every rank of a large job takes its share of the blocks), the
+        # spectra of all ranks are gathered inside the timed region: "scaling": "weak", value = all ranks' blocks / time.
+        # `--mode sharded` splits ONE 129-block workload instead (strong scaling: a lock-step chain whose length follows the
+        # largest matrix of a range, 1.2 x / 1.8 x / 2.3 x expected at 2 / 4 / 8 ranks); the north-star
+        # leg of the N > 1 line runs the REAL m-sharded configs[2] job on the N ranks either way.
+        args.mode = "weak"
     launched = "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not launched:
         # no launcher: start the ranks ourselves, before anything here touches the GPU
